@@ -1,0 +1,378 @@
+/*
+ * oracle/c/bp_oracle.c -- TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+ *
+ * Plain-C CPU restatement of the arithmetic the reference performs on its hot
+ * path, for sizes the pure-Python restatement (oracle/bp_ref.py) cannot reach,
+ * and as the "port" CPU baseline that bench.py times beside the GPU.
+ *
+ *   orc_msm              = Pippenger.multiexp over EC(secp256k1)
+ *                          (/root/reference/src/pippenger/pippenger.py:22-61 with
+ *                          group.py:27-32).  The RESULT is restated, not the
+ *                          subset-table schedule: sum e_i*g_i is a canonical affine
+ *                          point, so any correct schedule is bit-identical.  The
+ *                          schedule here is the textbook signed-window bucket method.
+ *   orc_ec_mul_batch     = `ModP * Point` / `int * Point` (src/utils/utils.py:43-44),
+ *                          e.g. hsp[i] = y^-i * hs[i] (src/rangeproofs/rangeproof_prover.py:77)
+ *   orc_ec_lincomb2_batch= the g/h fold  x^-1*g_lo + x*g_hi
+ *                          (src/innerproduct/inner_product_prover.py:107-108)
+ *   orc_ec_add           = Point + Point (fastecdsa; src/pippenger/group.py:31-32)
+ *   orc_sc_dot           = inner_product (src/utils/utils.py:134-137)
+ *   orc_sc_fold          = a' = x*a_lo + x^-1*a_hi (inner_product_prover.py:109-110)
+ *
+ * Byte layout (same as include/bpmi.h): field elements and scalars are 32 bytes
+ * little-endian; an affine point is x||y (64 B); the identity is 64 zero bytes.
+ * It is pinned against oracle/ec.py + the reference-generated goldens in
+ * tests/test_oracle_c.py.
+ */
+#include <pthread.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef unsigned __int128 u128;
+typedef uint64_t u64;
+
+typedef struct { u64 v[4]; } fe;            /* mod p, fully reduced between calls */
+typedef struct { fe X, Y, Z; } jac;         /* Z == 0 <=> identity */
+typedef struct { fe x, y; } aff;            /* (0,0) <=> identity */
+
+static const fe FE_P = {{0xFFFFFFFEFFFFFC2FULL, 0xFFFFFFFFFFFFFFFFULL, 0xFFFFFFFFFFFFFFFFULL, 0xFFFFFFFFFFFFFFFFULL}};
+#define P_C 0x1000003D1ULL /* 2^256 - p */
+
+static const u64 Q_N[4] = {0xBFD25E8CD0364141ULL, 0xBAAEDCE6AF48A03BULL, 0xFFFFFFFFFFFFFFFEULL, 0xFFFFFFFFFFFFFFFFULL};
+/* 2^256 - q (129 bits) */
+static const u64 Q_C[3] = {0x402DA1732FC9BEBFULL, 0x4551231950B75FC4ULL, 0x1ULL};
+
+/* ------------------------------------------------------------------ field */
+static int fe_is_zero(const fe *a) { return (a->v[0] | a->v[1] | a->v[2] | a->v[3]) == 0; }
+static int ge4(const u64 a[4], const u64 b[4]) {
+    for (int i = 3; i >= 0; i--) { if (a[i] != b[i]) return a[i] > b[i]; }
+    return 1;
+}
+static u64 sub4(u64 r[4], const u64 a[4], const u64 b[4]) {
+    u64 br = 0;
+    for (int i = 0; i < 4; i++) { u128 t = (u128)a[i] - b[i] - br; r[i] = (u64)t; br = (u64)(t >> 64) & 1; }
+    return br;
+}
+static u64 add4(u64 r[4], const u64 a[4], const u64 b[4]) {
+    u64 c = 0;
+    for (int i = 0; i < 4; i++) { u128 t = (u128)a[i] + b[i] + c; r[i] = (u64)t; c = (u64)(t >> 64); }
+    return c;
+}
+static void fe_add(fe *r, const fe *a, const fe *b) {
+    u64 c = add4(r->v, a->v, b->v);
+    if (c || ge4(r->v, FE_P.v)) sub4(r->v, r->v, FE_P.v);
+}
+static void fe_sub(fe *r, const fe *a, const fe *b) {
+    if (sub4(r->v, a->v, b->v)) add4(r->v, r->v, FE_P.v);
+}
+static void fe_neg(fe *r, const fe *a) { fe z = {{0, 0, 0, 0}}; fe_sub(r, &z, a); }
+static void fe_reduce512(fe *r, const u64 t[8]) {
+    /* t = lo + 2^256*hi == lo + hi*P_C (mod p) */
+    u64 m[5]; u128 c = 0;
+    for (int i = 0; i < 4; i++) { c += (u128)t[4 + i] * P_C; m[i] = (u64)c; c >>= 64; }
+    m[4] = (u64)c;                                    /* < 2^34 */
+    u64 s[5]; c = 0;
+    for (int i = 0; i < 4; i++) { c += (u128)t[i] + m[i]; s[i] = (u64)c; c >>= 64; }
+    s[4] = (u64)c + m[4];                             /* < 2^35 */
+    c = (u128)s[4] * P_C;                             /* second fold */
+    u64 carry;
+    { u128 a = (u128)s[0] + (u64)c; r->v[0] = (u64)a; carry = (u64)(a >> 64); }
+    { u128 a = (u128)s[1] + (u64)(c >> 64) + carry; r->v[1] = (u64)a; carry = (u64)(a >> 64); }
+    { u128 a = (u128)s[2] + carry; r->v[2] = (u64)a; carry = (u64)(a >> 64); }
+    { u128 a = (u128)s[3] + carry; r->v[3] = (u64)a; carry = (u64)(a >> 64); }
+    if (carry) {                                      /* wrapped 2^256: add P_C once more */
+        u128 a = (u128)r->v[0] + P_C; r->v[0] = (u64)a; u64 k = (u64)(a >> 64);
+        for (int i = 1; i < 4 && k; i++) { a = (u128)r->v[i] + k; r->v[i] = (u64)a; k = (u64)(a >> 64); }
+    }
+    if (ge4(r->v, FE_P.v)) sub4(r->v, r->v, FE_P.v);
+}
+static void fe_mul(fe *r, const fe *a, const fe *b) {
+    u64 t[8] = {0};
+    for (int i = 0; i < 4; i++) {
+        u128 c = 0;
+        for (int j = 0; j < 4; j++) { c += (u128)a->v[i] * b->v[j] + t[i + j]; t[i + j] = (u64)c; c >>= 64; }
+        t[i + 4] = (u64)c;
+    }
+    fe_reduce512(r, t);
+}
+static void fe_sqr(fe *r, const fe *a) { fe_mul(r, a, a); }
+static void fe_pow(fe *r, const fe *a, const u64 e[4]) {
+    fe acc = {{1, 0, 0, 0}};
+    for (int i = 255; i >= 0; i--) {
+        fe_sqr(&acc, &acc);
+        if ((e[i >> 6] >> (i & 63)) & 1) fe_mul(&acc, &acc, a);
+    }
+    *r = acc;
+}
+static void fe_inv(fe *r, const fe *a) {
+    u64 e[4] = {FE_P.v[0] - 2, FE_P.v[1], FE_P.v[2], FE_P.v[3]};
+    fe_pow(r, a, e);
+}
+
+/* ------------------------------------------------------------- scalars mod q */
+static void sc_reduce512(u64 r[4], const u64 t[8]) {
+    /* fold hi*Q_C three times (Q_C is 129 bits), then conditional subtracts */
+    u64 cur[8]; memcpy(cur, t, sizeof(cur));
+    for (int round = 0; round < 3; round++) {
+        u64 prod[8] = {0};
+        for (int i = 0; i < 4; i++) {
+            u128 c = 0;
+            for (int j = 0; j < 3; j++) {
+                c += (u128)cur[4 + i] * Q_C[j] + prod[i + j]; prod[i + j] = (u64)c; c >>= 64;
+            }
+            int k = i + 3;
+            while (c && k < 8) { c += prod[k]; prod[k] = (u64)c; c >>= 64; k++; }
+        }
+        u128 c = 0;
+        for (int i = 0; i < 8; i++) { c += (u128)prod[i] + (i < 4 ? cur[i] : 0); cur[i] = (u64)c; c >>= 64; }
+    }
+    /* now cur < 2^256 + small; cur[4] in {0,1} */
+    while (cur[4] || ge4(cur, Q_N)) {
+        u64 br = sub4(cur, cur, Q_N);
+        cur[4] -= br;
+    }
+    memcpy(r, cur, 32);
+}
+static void sc_mul(u64 r[4], const u64 a[4], const u64 b[4]) {
+    u64 t[8] = {0};
+    for (int i = 0; i < 4; i++) {
+        u128 c = 0;
+        for (int j = 0; j < 4; j++) { c += (u128)a[i] * b[j] + t[i + j]; t[i + j] = (u64)c; c >>= 64; }
+        t[i + 4] = (u64)c;
+    }
+    sc_reduce512(r, t);
+}
+static void sc_add(u64 r[4], const u64 a[4], const u64 b[4]) {
+    u64 c = add4(r, a, b);
+    if (c || ge4(r, Q_N)) sub4(r, r, Q_N);
+}
+
+/* ------------------------------------------------------------------ points */
+static void jac_set_inf(jac *r) { memset(r, 0, sizeof(*r)); r->Y.v[0] = 1; }
+static int jac_is_inf(const jac *a) { return fe_is_zero(&a->Z); }
+
+static void jac_dbl(jac *r, const jac *a) {
+    if (jac_is_inf(a) || fe_is_zero(&a->Y)) { jac_set_inf(r); return; }
+    fe A, B, C, D, E, F, t, X3, Y3, Z3;
+    fe_sqr(&A, &a->X); fe_sqr(&B, &a->Y); fe_sqr(&C, &B);
+    fe_add(&t, &a->X, &B); fe_sqr(&t, &t); fe_sub(&t, &t, &A); fe_sub(&t, &t, &C); fe_add(&D, &t, &t);
+    fe_add(&E, &A, &A); fe_add(&E, &E, &A);
+    fe_sqr(&F, &E);
+    fe_sub(&X3, &F, &D); fe_sub(&X3, &X3, &D);
+    fe_sub(&t, &D, &X3); fe_mul(&Y3, &E, &t);
+    fe_add(&C, &C, &C); fe_add(&C, &C, &C); fe_add(&C, &C, &C); fe_sub(&Y3, &Y3, &C);
+    fe_mul(&Z3, &a->Y, &a->Z); fe_add(&Z3, &Z3, &Z3);
+    r->X = X3; r->Y = Y3; r->Z = Z3;
+}
+/* r = a + (x2, y2), complete: handles a = inf, a = b (doubling), a = -b */
+static void jac_madd(jac *r, const jac *a, const fe *x2, const fe *y2) {
+    if (jac_is_inf(a)) { r->X = *x2; r->Y = *y2; memset(&r->Z, 0, sizeof(fe)); r->Z.v[0] = 1; return; }
+    fe Z1Z1, U2, S2, H, R, HH, HHH, V, t, X3, Y3, Z3;
+    fe_sqr(&Z1Z1, &a->Z); fe_mul(&U2, x2, &Z1Z1);
+    fe_mul(&S2, y2, &a->Z); fe_mul(&S2, &S2, &Z1Z1);
+    fe_sub(&H, &U2, &a->X); fe_sub(&R, &S2, &a->Y);
+    if (fe_is_zero(&H)) {
+        if (fe_is_zero(&R)) { jac_dbl(r, a); return; }
+        jac_set_inf(r); return;
+    }
+    fe_sqr(&HH, &H); fe_mul(&HHH, &H, &HH); fe_mul(&V, &a->X, &HH);
+    fe_sqr(&X3, &R); fe_sub(&X3, &X3, &HHH); fe_sub(&X3, &X3, &V); fe_sub(&X3, &X3, &V);
+    fe_sub(&t, &V, &X3); fe_mul(&Y3, &R, &t); fe_mul(&t, &a->Y, &HHH); fe_sub(&Y3, &Y3, &t);
+    fe_mul(&Z3, &a->Z, &H);
+    r->X = X3; r->Y = Y3; r->Z = Z3;
+}
+static void jac_add(jac *r, const jac *a, const jac *b) {
+    if (jac_is_inf(a)) { *r = *b; return; }
+    if (jac_is_inf(b)) { *r = *a; return; }
+    fe Z1Z1, Z2Z2, U1, U2, S1, S2, H, R, HH, HHH, V, t, X3, Y3, Z3;
+    fe_sqr(&Z1Z1, &a->Z); fe_sqr(&Z2Z2, &b->Z);
+    fe_mul(&U1, &a->X, &Z2Z2); fe_mul(&U2, &b->X, &Z1Z1);
+    fe_mul(&S1, &a->Y, &b->Z); fe_mul(&S1, &S1, &Z2Z2);
+    fe_mul(&S2, &b->Y, &a->Z); fe_mul(&S2, &S2, &Z1Z1);
+    fe_sub(&H, &U2, &U1); fe_sub(&R, &S2, &S1);
+    if (fe_is_zero(&H)) {
+        if (fe_is_zero(&R)) { jac_dbl(r, a); return; }
+        jac_set_inf(r); return;
+    }
+    fe_sqr(&HH, &H); fe_mul(&HHH, &H, &HH); fe_mul(&V, &U1, &HH);
+    fe_sqr(&X3, &R); fe_sub(&X3, &X3, &HHH); fe_sub(&X3, &X3, &V); fe_sub(&X3, &X3, &V);
+    fe_sub(&t, &V, &X3); fe_mul(&Y3, &R, &t); fe_mul(&t, &S1, &HHH); fe_sub(&Y3, &Y3, &t);
+    fe_mul(&Z3, &a->Z, &b->Z); fe_mul(&Z3, &Z3, &H);
+    r->X = X3; r->Y = Y3; r->Z = Z3;
+}
+static void jac_to_aff(aff *r, const jac *a) {
+    if (jac_is_inf(a)) { memset(r, 0, sizeof(*r)); return; }
+    fe zi, zi2, zi3;
+    fe_inv(&zi, &a->Z); fe_sqr(&zi2, &zi); fe_mul(&zi3, &zi2, &zi);
+    fe_mul(&r->x, &a->X, &zi2); fe_mul(&r->y, &a->Y, &zi3);
+}
+static int aff_is_inf(const aff *a) { return fe_is_zero(&a->x) && fe_is_zero(&a->y); }
+static void aff_load(aff *r, const uint8_t *b) { memcpy(r, b, 64); }
+static void aff_store(uint8_t *b, const aff *a) { memcpy(b, a, 64); }
+
+/* k * P by left-to-right double-and-add */
+static void jac_mul(jac *r, const aff *P, const u64 k[4]) {
+    jac acc; jac_set_inf(&acc);
+    if (aff_is_inf(P)) { *r = acc; return; }
+    int started = 0;
+    for (int i = 255; i >= 0; i--) {
+        if (started) jac_dbl(&acc, &acc);
+        if ((k[i >> 6] >> (i & 63)) & 1) { jac_madd(&acc, &acc, &P->x, &P->y); started = 1; }
+    }
+    *r = acc;
+}
+
+/* ------------------------------------------------------------------- MSM */
+static int pick_window(u64 n) {
+    int c = 1; while ((1ULL << (c + 1)) <= n) c++;        /* floor(log2 n) */
+    c = c - 2; if (c < 2) c = 2; if (c > 16) c = 16; return c;
+}
+typedef struct {
+    const uint8_t *pts, *sc; u64 n; int c, nwin, w0, w1; jac *win_sums;
+} msm_job;
+
+/* signed digit of window w for scalar k (c bits, digits in [-2^(c-1), 2^(c-1)]) */
+static int64_t signed_digit(const u64 k[4], int w, int c) {
+    /* recompute the carry chain from window 0 (cheap for the oracle) */
+    int carry = 0; int64_t d = 0;
+    for (int j = 0; j <= w; j++) {
+        int bit = j * c; u64 raw = 0;
+        if (bit < 256) {
+            int limb = bit >> 6, off = bit & 63;
+            raw = k[limb] >> off;
+            if (off + c > 64 && limb < 3) raw |= k[limb + 1] << (64 - off);
+            raw &= ((1ULL << c) - 1);
+        }
+        d = (int64_t)raw + carry;
+        if (d > (1LL << (c - 1))) { d -= (1LL << c); carry = 1; } else carry = 0;
+    }
+    return d;
+}
+static void *msm_worker(void *arg) {
+    msm_job *J = (msm_job *)arg;
+    u64 nb = (1ULL << (J->c - 1)) + 1;
+    jac *buckets = (jac *)malloc(nb * sizeof(jac));
+    for (int w = J->w0; w < J->w1; w++) {
+        for (u64 b = 0; b < nb; b++) jac_set_inf(&buckets[b]);
+        for (u64 i = 0; i < J->n; i++) {
+            u64 k[4]; memcpy(k, J->sc + 32 * i, 32);
+            int64_t d = signed_digit(k, w, J->c);
+            if (d == 0) continue;
+            aff P; aff_load(&P, J->pts + 64 * i);
+            if (aff_is_inf(&P)) continue;
+            if (d < 0) { fe_neg(&P.y, &P.y); d = -d; }
+            jac_madd(&buckets[d], &buckets[d], &P.x, &P.y);
+        }
+        jac run, sum; jac_set_inf(&run); jac_set_inf(&sum);
+        for (u64 b = nb - 1; b >= 1; b--) { jac_add(&run, &run, &buckets[b]); jac_add(&sum, &sum, &run); }
+        J->win_sums[w] = sum;
+    }
+    free(buckets);
+    return NULL;
+}
+
+void orc_msm(const uint8_t *pts, const uint8_t *scalars, u64 n, int threads, uint8_t out[64]) {
+    aff res; memset(&res, 0, sizeof(res));
+    if (n == 0) { aff_store(out, &res); return; }
+    int c = pick_window(n);
+    int nwin = (256 + c - 1) / c + 1;                   /* +1 for the signed carry */
+    jac *sums = (jac *)malloc(nwin * sizeof(jac));
+    if (threads < 1) threads = 1;
+    if (threads > nwin) threads = nwin;
+    pthread_t th[64]; msm_job jobs[64];
+    if (threads > 64) threads = 64;
+    for (int t = 0; t < threads; t++) {
+        jobs[t] = (msm_job){pts, scalars, n, c, nwin, nwin * t / threads, nwin * (t + 1) / threads, sums};
+        pthread_create(&th[t], NULL, msm_worker, &jobs[t]);
+    }
+    for (int t = 0; t < threads; t++) pthread_join(th[t], NULL);
+    jac acc = sums[nwin - 1];
+    for (int w = nwin - 2; w >= 0; w--) {
+        for (int k = 0; k < c; k++) jac_dbl(&acc, &acc);
+        jac_add(&acc, &acc, &sums[w]);
+    }
+    free(sums);
+    jac_to_aff(&res, &acc);
+    aff_store(out, &res);
+}
+
+/* ------------------------------------------------------- batch point ops */
+typedef struct {
+    const uint8_t *p1, *p2, *k1, *k2; uint8_t *out; u64 i0, i1; int per_elem_scalars; int two;
+} batch_job;
+static void *batch_worker(void *arg) {
+    batch_job *J = (batch_job *)arg;
+    for (u64 i = J->i0; i < J->i1; i++) {
+        aff P; u64 k[4]; jac r;
+        aff_load(&P, J->p1 + 64 * i);
+        memcpy(k, J->k1 + (J->per_elem_scalars ? 32 * i : 0), 32);
+        jac_mul(&r, &P, k);
+        if (J->two) {
+            jac r2; aff_load(&P, J->p2 + 64 * i);
+            memcpy(k, J->k2 + (J->per_elem_scalars ? 32 * i : 0), 32);
+            jac_mul(&r2, &P, k); jac_add(&r, &r, &r2);
+        }
+        aff a; jac_to_aff(&a, &r); aff_store(J->out + 64 * i, &a);
+    }
+    return NULL;
+}
+static void run_batch(batch_job proto, u64 n, int threads) {
+    if (threads < 1) threads = 1;
+    if (threads > 64) threads = 64;
+    if ((u64)threads > n) threads = n ? (int)n : 1;
+    pthread_t th[64]; batch_job jobs[64];
+    for (int t = 0; t < threads; t++) {
+        jobs[t] = proto; jobs[t].i0 = n * t / threads; jobs[t].i1 = n * (t + 1) / threads;
+        pthread_create(&th[t], NULL, batch_worker, &jobs[t]);
+    }
+    for (int t = 0; t < threads; t++) pthread_join(th[t], NULL);
+}
+/* out_i = k_i * P_i */
+void orc_ec_mul_batch(const uint8_t *pts, const uint8_t *scalars, u64 n, int threads, uint8_t *out) {
+    batch_job J = {pts, NULL, scalars, NULL, out, 0, 0, 1, 0};
+    run_batch(J, n, threads);
+}
+/* out_i = k1 * P1_i + k2 * P2_i  (k1, k2 shared by all i) */
+void orc_ec_lincomb2_batch(const uint8_t *p1, const uint8_t *p2, const uint8_t k1[32], const uint8_t k2[32],
+                           u64 n, int threads, uint8_t *out) {
+    batch_job J = {p1, p2, k1, k2, out, 0, 0, 0, 1};
+    run_batch(J, n, threads);
+}
+void orc_ec_add(const uint8_t a[64], const uint8_t b[64], uint8_t out[64]) {
+    aff A, B, R; jac J;
+    aff_load(&A, a); aff_load(&B, b);
+    if (aff_is_inf(&A)) { aff_store(out, &B); return; }
+    jac_set_inf(&J); jac_madd(&J, &J, &A.x, &A.y);
+    if (!aff_is_inf(&B)) jac_madd(&J, &J, &B.x, &B.y);
+    jac_to_aff(&R, &J); aff_store(out, &R);
+}
+
+/* ----------------------------------------------------------- scalar bulk */
+void orc_sc_dot(const uint8_t *a, const uint8_t *b, u64 n, uint8_t out[32]) {
+    u64 acc[4] = {0, 0, 0, 0};
+    for (u64 i = 0; i < n; i++) {
+        u64 x[4], y[4], t[4];
+        memcpy(x, a + 32 * i, 32); memcpy(y, b + 32 * i, 32);
+        sc_mul(t, x, y); sc_add(acc, acc, t);
+    }
+    memcpy(out, acc, 32);
+}
+/* out_i = x * lo_i + xinv * hi_i */
+void orc_sc_fold(const uint8_t *lo, const uint8_t *hi, const uint8_t x[32], const uint8_t xinv[32], u64 n, uint8_t *out) {
+    u64 X[4], XI[4];
+    memcpy(X, x, 32); memcpy(XI, xinv, 32);
+    for (u64 i = 0; i < n; i++) {
+        u64 a[4], b[4], t[4], s[4];
+        memcpy(a, lo + 32 * i, 32); memcpy(b, hi + 32 * i, 32);
+        sc_mul(t, X, a); sc_mul(s, XI, b); sc_add(t, t, s);
+        memcpy(out + 32 * i, t, 32);
+    }
+}
+void orc_sc_mul(const uint8_t a[32], const uint8_t b[32], uint8_t out[32]) {
+    u64 x[4], y[4], t[4];
+    memcpy(x, a, 32); memcpy(y, b, 32); sc_mul(t, x, y); memcpy(out, t, 32);
+}
+void orc_fe_mul(const uint8_t a[32], const uint8_t b[32], uint8_t out[32]) {
+    fe x, y, t; memcpy(&x, a, 32); memcpy(&y, b, 32); fe_mul(&t, &x, &y); memcpy(out, &t, 32);
+}
