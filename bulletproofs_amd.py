@@ -1,0 +1,12 @@
+"""Import shim: the package directory is named `python-bulletproofs_amd/` (not a valid
+Python identifier), so `import bulletproofs_amd` loads it from there."""
+import importlib.util
+import os
+import sys
+
+_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "python-bulletproofs_amd")
+_spec = importlib.util.spec_from_file_location(
+    "bulletproofs_amd", os.path.join(_dir, "__init__.py"), submodule_search_locations=[_dir])
+_mod = importlib.util.module_from_spec(_spec)
+sys.modules["bulletproofs_amd"] = _mod
+_spec.loader.exec_module(_mod)

@@ -1,0 +1,141 @@
+/*
+ * bpmi.h -- C-ABI of libbpmi.so: the MI355X (gfx950) multi-scalar-multiplication +
+ * inner-product-argument engine that drops in behind src/pippenger and
+ * src/innerproduct of wborgeaud/python-bulletproofs.
+ *
+ * The reference has no FFI layer of its own: its hot path is a Python call
+ * surface that bottoms out in the third-party `fastecdsa` C extension.  Each
+ * entry point below names the reference interface it replaces (paths relative to
+ * /root/reference); INTEGRATION.md shows the ctypes stub a maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++ or torch types cross this boundary;
+ *   - field elements / scalars: 32 bytes little-endian (= 4 x u64 LE limbs);
+ *     affine point: x || y (64 bytes); the identity is 64 zero bytes
+ *     ((0,0) is not on y^2 = x^3 + 7);
+ *   - scalars handed in must already be reduced to [0, q) -- the Python wrapper
+ *     does the `% order` of pippenger.py:26 and the length check of :23-24;
+ *   - every function returns 0 on success or a negative BPMI_E_* code, never
+ *     throws, never aborts; bpmi_last_error(ctx) gives the message
+ *     (ctx == NULL: the message of the last failed bpmi_ctx_create);
+ *   - a ctx is for use by one thread at a time; distinct ctxs are independent;
+ *   - `*_dev` variants take DEVICE pointers (hipMalloc'd, or torch tensors'
+ *     data_ptr()) on the ctx's device and enqueue on the ctx's stream; results
+ *     written to host pointers are complete when the call returns;
+ *   - there is NO CPU fallback: without a usable gfx950 device bpmi_ctx_create
+ *     fails with BPMI_E_NODEVICE.
+ */
+#ifndef BPMI_H
+#define BPMI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BPMI_OK 0
+#define BPMI_E_NODEVICE -1   /* no HIP device / wrong architecture */
+#define BPMI_E_HIP -2        /* a HIP runtime call failed (message has the call) */
+#define BPMI_E_ARG -3        /* bad argument (NULL pointer, n too large, ...) */
+#define BPMI_E_NOMEM -4      /* device or host allocation failed */
+#define BPMI_E_STATE -5      /* call not valid in the object's current state */
+
+#define BPMI_MAX_N (1ull << 26) /* largest supported vector length */
+
+typedef struct bpmi_ctx bpmi_ctx;
+typedef struct bpmi_ipa bpmi_ipa;
+
+/* ---- library / context ---------------------------------------------------- */
+int bpmi_version(void);
+/* number of visible HIP devices (0 if none); does not initialise a device */
+int bpmi_device_count(void);
+/* `stream`: a hipStream_t to enqueue on (e.g. torch.cuda.current_stream().cuda_stream),
+ * or NULL for a stream owned by the ctx.  Returns NULL on failure. */
+bpmi_ctx *bpmi_ctx_create(int device, void *stream);
+void bpmi_ctx_destroy(bpmi_ctx *ctx);
+const char *bpmi_last_error(const bpmi_ctx *ctx);
+int bpmi_sync(bpmi_ctx *ctx);
+
+/* tuning knobs (0 = automatic): MSM window bits c in [2,16]; where the O(256)
+ * sequential window-combine tail runs: 0 auto, 1 device kernel, 2 host thread */
+int bpmi_set_option(bpmi_ctx *ctx, const char *name, int64_t value);
+
+/* ---- device buffers (so callers need no other GPU runtime) ------------------- */
+int bpmi_malloc(bpmi_ctx *ctx, size_t bytes, void **dptr);
+int bpmi_free(bpmi_ctx *ctx, void *dptr);
+int bpmi_upload(bpmi_ctx *ctx, void *dptr, const void *host, size_t bytes);
+int bpmi_download(bpmi_ctx *ctx, void *host, const void *dptr, size_t bytes);
+
+/* ---- multi-scalar multiplication ------------------------------------------------
+ * out = sum_i scalars[i] * pts[i].
+ * Replaces Pippenger.multiexp on EC(secp256k1) = the PipSECP256k1 singleton
+ * (src/pippenger/pippenger.py:22-61, src/pippenger/__init__.py:5; group law
+ * src/pippenger/group.py:27-32), i.e. every call site listed in SURVEY.md
+ * section 8b: src/utils/commitments.py:13, src/innerproduct/inner_product_verifier.py:134,140,
+ * src/rangeproofs/rangeproof_prover.py:81, rangeproof_verifier.py:92, ...
+ * n == 0 gives the identity (pippenger.py:28-29). */
+int bpmi_msm(bpmi_ctx *ctx, const uint8_t *pts, const uint8_t *scalars, uint64_t n, uint8_t out[64]);
+int bpmi_msm_dev(bpmi_ctx *ctx, const void *d_pts, const void *d_scalars, uint64_t n, uint8_t out[64]);
+
+/* ---- batched point operations ----------------------------------------------------
+ * out[i] = scalars[i] * pts[i]       replaces `ModP * Point` / `int * Point`
+ * (src/utils/utils.py:43-44), e.g. hsp[i] = y^-i * hs[i]
+ * (src/rangeproofs/rangeproof_prover.py:77, rangeproof_verifier.py:72). */
+int bpmi_ec_mul_batch(bpmi_ctx *ctx, const uint8_t *pts, const uint8_t *scalars, uint64_t n, uint8_t *out);
+int bpmi_ec_mul_batch_dev(bpmi_ctx *ctx, const void *d_pts, const void *d_scalars, uint64_t n, void *d_out);
+/* out[i] = k1 * p1[i] + k2 * p2[i]   replaces the generator fold
+ * g' = x^-1 * g_lo + x * g_hi (src/innerproduct/inner_product_prover.py:107-108). */
+int bpmi_ec_lincomb2_batch(bpmi_ctx *ctx, const uint8_t *p1, const uint8_t *p2, const uint8_t k1[32],
+                           const uint8_t k2[32], uint64_t n, uint8_t *out);
+int bpmi_ec_lincomb2_batch_dev(bpmi_ctx *ctx, const void *d_p1, const void *d_p2, const uint8_t k1[32],
+                               const uint8_t k2[32], uint64_t n, void *d_out);
+/* out = sum_i pts[i]                 replaces chains of `Point + Point`
+ * (fastecdsa Point.__add__; e.g. `A + x*S + multiexp(...)`, rangeproof_prover.py:78-87),
+ * and folds the per-GPU partial results of a sharded MSM. */
+int bpmi_ec_sum(bpmi_ctx *ctx, const uint8_t *pts, uint64_t n, uint8_t out[64]);
+
+/* ---- bulk scalar (mod q) operations ------------------------------------------------
+ * out = sum_i a[i] * b[i] mod q       replaces inner_product (src/utils/utils.py:134-137) */
+int bpmi_sc_dot(bpmi_ctx *ctx, const uint8_t *a, const uint8_t *b, uint64_t n, uint8_t out[32]);
+int bpmi_sc_dot_dev(bpmi_ctx *ctx, const void *d_a, const void *d_b, uint64_t n, uint8_t out[32]);
+/* out[i] = x * lo[i] + y * hi[i] mod q  replaces the a / b fold
+ * (src/innerproduct/inner_product_prover.py:109-110) */
+int bpmi_sc_fold(bpmi_ctx *ctx, const uint8_t *lo, const uint8_t *hi, const uint8_t x[32], const uint8_t y[32],
+                 uint64_t n, uint8_t *out);
+int bpmi_sc_fold_dev(bpmi_ctx *ctx, const void *d_lo, const void *d_hi, const uint8_t x[32], const uint8_t y[32],
+                     uint64_t n, void *d_out);
+
+/* ---- inner-product argument prover, split at the Fiat-Shamir edge ----------------------
+ * One object = one run of FastNIProver2.prove (src/innerproduct/inner_product_prover.py:70-110).
+ * g, h: n points; a, b: n scalars; u: one point; all copied to the device once and
+ * halved in place every round (device-resident ping-pong buffers).
+ *   bpmi_ipa_round_LR : cl, cr, L, R of the current round          (:96-99)
+ *   --- host: transcript.add_list_points([L, R]); x = H(transcript) (:102-106) ---
+ *   bpmi_ipa_fold     : g, h, a, b <- folded with x, x^-1           (:107-110)
+ *   bpmi_ipa_finish   : the final a[0], b[0]                         (:85-94)     */
+int bpmi_ipa_create(bpmi_ctx *ctx, const uint8_t *g, const uint8_t *h, const uint8_t *a, const uint8_t *b,
+                    uint64_t n, const uint8_t u[64], bpmi_ipa **out);
+int bpmi_ipa_create_dev(bpmi_ctx *ctx, const void *d_g, const void *d_h, const void *d_a, const void *d_b,
+                        uint64_t n, const uint8_t u[64], bpmi_ipa **out);
+uint64_t bpmi_ipa_len(const bpmi_ipa *st);
+int bpmi_ipa_round_LR(bpmi_ipa *st, uint8_t L[64], uint8_t R[64]);
+int bpmi_ipa_fold(bpmi_ipa *st, const uint8_t x[32], const uint8_t xinv[32]);
+int bpmi_ipa_finish(bpmi_ipa *st, uint8_t a[32], uint8_t b[32]);
+void bpmi_ipa_destroy(bpmi_ipa *st);
+
+/* ---- per-stage device timing (HIP events on the ctx's stream) --------------------------
+ * After bpmi_profile(ctx, 1) every MSM records HIP events around each kernel
+ * stage; bpmi_profile_read returns accumulated milliseconds and launch counts
+ * per stage since the last reset.  Stage names: bpmi_profile_stage_name(i). */
+#define BPMI_NSTAGES 12
+int bpmi_profile(bpmi_ctx *ctx, int enable);
+int bpmi_profile_reset(bpmi_ctx *ctx);
+int bpmi_profile_read(bpmi_ctx *ctx, double ms[BPMI_NSTAGES], uint64_t calls[BPMI_NSTAGES]);
+const char *bpmi_profile_stage_name(int stage);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BPMI_H */

@@ -1,0 +1,70 @@
+"""ctypes loader for libbpmi.so (include/bpmi.h).  There is no CPU fallback: if the
+library or a gfx950 device is missing, everything that needs it raises."""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libbpmi.so")
+NSTAGES = 12
+
+# name -> (restype, argtypes); this table is checked against include/bpmi.h by tests
+_vp, _cp, _u64, _i, _sz = ctypes.c_void_p, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_size_t
+SIGNATURES = {
+    "bpmi_version": (_i, []),
+    "bpmi_device_count": (_i, []),
+    "bpmi_ctx_create": (_vp, [_i, _vp]),
+    "bpmi_ctx_destroy": (None, [_vp]),
+    "bpmi_last_error": (_cp, [_vp]),
+    "bpmi_sync": (_i, [_vp]),
+    "bpmi_set_option": (_i, [_vp, _cp, ctypes.c_int64]),
+    "bpmi_malloc": (_i, [_vp, _sz, ctypes.POINTER(_vp)]),
+    "bpmi_free": (_i, [_vp, _vp]),
+    "bpmi_upload": (_i, [_vp, _vp, _cp, _sz]),
+    "bpmi_download": (_i, [_vp, _vp, _vp, _sz]),
+    "bpmi_msm": (_i, [_vp, _cp, _cp, _u64, _cp]),
+    "bpmi_msm_dev": (_i, [_vp, _vp, _vp, _u64, _cp]),
+    "bpmi_ec_mul_batch": (_i, [_vp, _cp, _cp, _u64, _cp]),
+    "bpmi_ec_mul_batch_dev": (_i, [_vp, _vp, _vp, _u64, _vp]),
+    "bpmi_ec_lincomb2_batch": (_i, [_vp, _cp, _cp, _cp, _cp, _u64, _cp]),
+    "bpmi_ec_lincomb2_batch_dev": (_i, [_vp, _vp, _vp, _cp, _cp, _u64, _vp]),
+    "bpmi_ec_sum": (_i, [_vp, _cp, _u64, _cp]),
+    "bpmi_sc_dot": (_i, [_vp, _cp, _cp, _u64, _cp]),
+    "bpmi_sc_dot_dev": (_i, [_vp, _vp, _vp, _u64, _cp]),
+    "bpmi_sc_fold": (_i, [_vp, _cp, _cp, _cp, _cp, _u64, _cp]),
+    "bpmi_sc_fold_dev": (_i, [_vp, _vp, _vp, _cp, _cp, _u64, _vp]),
+    "bpmi_ipa_create": (_i, [_vp, _cp, _cp, _cp, _cp, _u64, _cp, ctypes.POINTER(_vp)]),
+    "bpmi_ipa_create_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _u64, _cp, ctypes.POINTER(_vp)]),
+    "bpmi_ipa_len": (_u64, [_vp]),
+    "bpmi_ipa_round_LR": (_i, [_vp, _cp, _cp]),
+    "bpmi_ipa_fold": (_i, [_vp, _cp, _cp]),
+    "bpmi_ipa_finish": (_i, [_vp, _cp, _cp]),
+    "bpmi_ipa_destroy": (None, [_vp]),
+    "bpmi_profile": (_i, [_vp, _i]),
+    "bpmi_profile_reset": (_i, [_vp]),
+    "bpmi_profile_read": (_i, [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_u64)]),
+    "bpmi_profile_stage_name": (_cp, [_i]),
+}
+
+_lib = None
+
+
+class NativeLibraryMissing(RuntimeError):
+    pass
+
+
+def load():
+    """Load libbpmi.so and declare every entry point; raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryMissing(
+            "libbpmi.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'`; "
+            "there is no CPU fallback for the MSM / IPA path." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = header / library drift
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

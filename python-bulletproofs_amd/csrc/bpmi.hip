@@ -1,0 +1,1292 @@
+// bpmi.hip -- libbpmi.so: MSM + inner-product-argument engine for MI355X (gfx950).
+// C-ABI in include/bpmi.h; design notes in DESIGN.md.
+//
+// MSM pipeline (replaces Pippenger.multiexp, /root/reference/src/pippenger/pippenger.py:22-94,
+// by the signed-digit bucket method; the result -- a canonical affine point -- is
+// schedule independent, so it is bit-identical to the reference's subset-table schedule):
+//   k_digits_hist   scalar -> W signed c-bit digits, per-(window,bucket) histogram
+//   k_scan_*        exclusive scan of the histogram -> run offsets
+//   k_scatter       counting-sort scatter of (point index, sign) by (window, bucket)
+//   k_accum_l0      every thread adds exactly L sorted entries (perfectly balanced for
+//                   ANY digit distribution); runs that end inside a chunk go to their
+//                   bucket, the first/last run of a chunk become partial records
+//   k_segscan       block-wide segmented scan over partial records, 256 -> 2 per block,
+//                   repeated until one block is left
+//   k_bucket_digit_sums / k_weighted31   sum_b b*B[w][b] as base-32 digit sums + a
+//                   31-term suffix scan per (window, digit position)
+//   tail            O(256) sequential doublings: window combine + to-affine
+//                   (device kernel or host thread, same formulas)
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/bpmi.h"
+#include "curve.hpp"
+#include "field.hpp"
+#include "scalar.hpp"
+
+using namespace bpmi;
+
+#define BPMI_VERSION 100
+
+// ------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------
+enum Stage {
+  ST_DIGITS = 0, ST_SCAN, ST_SCATTER, ST_ACCUM, ST_SEGSCAN, ST_BREDUCE, ST_TAIL,
+  ST_MULBATCH, ST_LINCOMB2, ST_SCDOT, ST_SCFOLD, ST_MISC
+};
+static const char *STAGE_NAMES[BPMI_NSTAGES] = {
+  "msm_digits_hist", "msm_scan", "msm_scatter", "msm_accumulate", "msm_segscan", "msm_bucket_reduce",
+  "msm_tail", "ec_mul_batch", "ec_lincomb2", "sc_dot", "sc_fold", "misc"
+};
+
+struct EvPair { int stage; hipEvent_t a, b; };
+
+struct bpmi_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::string err;
+  // workspace (grown on demand, never shrunk)
+  void *ws = nullptr; size_t ws_bytes = 0;
+  void *pin = nullptr; size_t pin_bytes = 0;       // pinned host staging
+  void *stage_in = nullptr; size_t stage_in_bytes = 0;  // device staging for host-pointer entry points
+  // options
+  int opt_c = 0;        // window bits, 0 = auto
+  int opt_tail = 0;     // 0 auto, 1 device, 2 host
+  int opt_chunk = 0;    // entries per thread in k_accum_l0, 0 = auto
+  // profiling
+  bool prof = false;
+  std::vector<EvPair> evs;
+  double prof_ms[BPMI_NSTAGES] = {0};
+  uint64_t prof_calls[BPMI_NSTAGES] = {0};
+};
+
+static std::string g_create_err;
+static std::mutex g_mu;
+
+static int fail(bpmi_ctx *ctx, int code, const std::string &msg) {
+  if (ctx) ctx->err = msg;
+  else { std::lock_guard<std::mutex> lk(g_mu); g_create_err = msg; }
+  return code;
+}
+#define HIPCHK(ctx, call)                                                                   \
+  do {                                                                                      \
+    hipError_t e_ = (call);                                                                 \
+    if (e_ != hipSuccess)                                                                   \
+      return fail(ctx, e_ == hipErrorOutOfMemory ? BPMI_E_NOMEM : BPMI_E_HIP,               \
+                  std::string(#call) + ": " + hipGetErrorString(e_));                       \
+  } while (0)
+
+static bool g_debug_sync = getenv("BPMI_DEBUG_SYNC") != nullptr;
+static void debug_sync(bpmi_ctx *ctx, const char *what) {
+  if (!g_debug_sync) return;
+  fprintf(stderr, "[bpmi] sync after %s ... ", what); fflush(stderr);
+  hipError_t e = hipStreamSynchronize(ctx->stream);
+  fprintf(stderr, "%s\n", hipGetErrorString(e)); fflush(stderr);
+}
+struct StageTimer {
+  bpmi_ctx *ctx; int stage; hipEvent_t a = nullptr, b = nullptr;
+  StageTimer(bpmi_ctx *c, int s) : ctx(c), stage(s) {
+    if (ctx->prof) {
+      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
+      (void)hipEventRecord(a, ctx->stream);
+    }
+  }
+  ~StageTimer() {
+    if (ctx->prof && a) { (void)hipEventRecord(b, ctx->stream); ctx->evs.push_back({stage, a, b}); }
+  }
+};
+
+static int ensure_ws(bpmi_ctx *ctx, size_t bytes) {
+  if (bytes <= ctx->ws_bytes) return BPMI_OK;
+  if (ctx->ws) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(ctx->ws)); ctx->ws = nullptr; ctx->ws_bytes = 0; }
+  size_t want = bytes + bytes / 8;
+  HIPCHK(ctx, hipMalloc(&ctx->ws, want));
+  ctx->ws_bytes = want;
+  return BPMI_OK;
+}
+static int ensure_stage_in(bpmi_ctx *ctx, size_t bytes) {
+  if (bytes <= ctx->stage_in_bytes) return BPMI_OK;
+  if (ctx->stage_in) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(ctx->stage_in)); ctx->stage_in = nullptr; ctx->stage_in_bytes = 0; }
+  HIPCHK(ctx, hipMalloc(&ctx->stage_in, bytes));
+  ctx->stage_in_bytes = bytes;
+  return BPMI_OK;
+}
+static int ensure_pin(bpmi_ctx *ctx, size_t bytes) {
+  if (bytes <= ctx->pin_bytes) return BPMI_OK;
+  if (ctx->pin) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipHostFree(ctx->pin)); ctx->pin = nullptr; ctx->pin_bytes = 0; }
+  HIPCHK(ctx, hipHostMalloc(&ctx->pin, bytes, hipHostMallocDefault));
+  ctx->pin_bytes = bytes;
+  return BPMI_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------
+#define XYZZ_WORDS 36
+#define LDS_STRIDE 37   // odd stride: conflict-free ds_read/ds_write of 36-word records
+
+// up to three (points, scalars) segments presented as one logical array, so that
+// e.g. L = <a_lo, g_hi> + <b_hi, h_lo> + cl*u is ONE MSM without any gather/concat
+// (the reference concatenates Python lists: src/utils/commitments.py:13)
+struct Segs {
+  const u32 *pts[3];
+  const u32 *sc[3];
+  u32 n[3];
+  u32 total;
+};
+
+__device__ __forceinline__ void load_words16(u32 w[16], const u32 *p) {
+  const uint4 *q = reinterpret_cast<const uint4 *>(p);
+#pragma unroll
+  for (int i = 0; i < 4; i++) { uint4 t = q[i]; w[4 * i] = t.x; w[4 * i + 1] = t.y; w[4 * i + 2] = t.z; w[4 * i + 3] = t.w; }
+}
+__device__ __forceinline__ void load_words8(u32 w[8], const u32 *p) {
+  const uint4 *q = reinterpret_cast<const uint4 *>(p);
+#pragma unroll
+  for (int i = 0; i < 2; i++) { uint4 t = q[i]; w[4 * i] = t.x; w[4 * i + 1] = t.y; w[4 * i + 2] = t.z; w[4 * i + 3] = t.w; }
+}
+__device__ __forceinline__ void store_words16(u32 *p, const u32 w[16]) {
+  uint4 *q = reinterpret_cast<uint4 *>(p);
+#pragma unroll
+  for (int i = 0; i < 4; i++) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+}
+__device__ __forceinline__ void store_words8(u32 *p, const u32 w[8]) {
+  uint4 *q = reinterpret_cast<uint4 *>(p);
+#pragma unroll
+  for (int i = 0; i < 2; i++) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+}
+__device__ __forceinline__ const u32 *seg_point(const Segs &s, u32 i) {
+  if (i < s.n[0]) return s.pts[0] + 16ull * i;
+  i -= s.n[0];
+  if (i < s.n[1]) return s.pts[1] + 16ull * i;
+  i -= s.n[1];
+  return s.pts[2] + 16ull * i;
+}
+__device__ __forceinline__ const u32 *seg_scalar(const Segs &s, u32 i) {
+  if (i < s.n[0]) return s.sc[0] + 8ull * i;
+  i -= s.n[0];
+  if (i < s.n[1]) return s.sc[1] + 8ull * i;
+  i -= s.n[1];
+  return s.sc[2] + 8ull * i;
+}
+__device__ __forceinline__ void load_affine(affine &P, const u32 *p) {
+  u32 w[16];
+  load_words16(w, p);
+  affine_from_words(P, w);
+}
+__device__ __forceinline__ void xyzz_load_g(xyzz &a, const u32 *p) {   // 144 B, 16-B aligned
+  u32 w[XYZZ_WORDS];
+  const uint4 *q = reinterpret_cast<const uint4 *>(p);
+#pragma unroll
+  for (int i = 0; i < 9; i++) { uint4 t = q[i]; w[4 * i] = t.x; w[4 * i + 1] = t.y; w[4 * i + 2] = t.z; w[4 * i + 3] = t.w; }
+  xyzz_load(a, w);
+}
+__device__ __forceinline__ void xyzz_store_g(u32 *p, const xyzz &a) {
+  u32 w[XYZZ_WORDS];
+  xyzz_store(w, a);
+  uint4 *q = reinterpret_cast<uint4 *>(p);
+#pragma unroll
+  for (int i = 0; i < 9; i++) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+}
+
+// ------------------------------------------------------------------------------------
+// MSM kernels
+// ------------------------------------------------------------------------------------
+struct MsmGeom {
+  u32 n;       // pairs
+  u32 c;       // window bits
+  u32 W;       // windows
+  u32 B;       // buckets per window = 2^(c-1)
+  u32 G;       // W * B
+  u32 L;       // entries per thread in k_accum_l0
+  u32 nv;      // base-32 digit positions of a bucket index (ceil(c / 5))
+};
+
+// scalar -> signed digits + histogram.  dig[w * n + i] = |d| | (sign << 31)
+__global__ void __launch_bounds__(256) k_digits_hist(Segs segs, MsmGeom g, u32 *__restrict__ dig, u32 *__restrict__ hist) {
+  const u32 stride = gridDim.x * blockDim.x;
+  for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < g.n; i += stride) {
+    sc s;
+    load_words8(s.v, seg_scalar(segs, i));
+    // s > (q-1)/2  ->  use q - s on the negated point: halves the digit range, keeps
+    // s < 2^255 so W*c >= 256 never overflows, and turns the range-proof scalar q-1
+    // (aR, rangeproof_prover.py:43-45) into the single digit -1.
+    const bool neg = sc_is_high(s);
+    if (neg) sc_neg(s, s);
+    u32 carry = 0;
+    const u32 mask = (1u << g.c) - 1u;
+    for (u32 w = 0; w < g.W; w++) {
+      u32 t = (s.v[0] & mask) + carry;
+      // shift the 256-bit register right by c (static register indexing)
+#pragma unroll
+      for (int k = 0; k < 7; k++) s.v[k] = (u32)((((u64)s.v[k + 1] << 32) | s.v[k]) >> g.c);
+      s.v[7] >>= g.c;
+      u32 b, sign;
+      if (t > g.B) { b = (1u << g.c) - t; sign = 1; carry = 1; }
+      else { b = t; sign = 0; carry = 0; }
+      sign ^= (u32)neg;
+      dig[(u64)w * g.n + i] = b | (b ? (sign << 31) : 0u);
+      // histogram: one atomic per lane, or one per wave when the whole wave agrees
+      // (degenerate inputs: all-equal scalars, the {0,1,q-1} A-commitment shape)
+      const u32 key = b ? (w * g.B + b - 1u) : 0xFFFFFFFFu;
+      const unsigned long long act = __ballot(1);
+      const u32 first = __builtin_amdgcn_readfirstlane(key);
+      const unsigned long long same = __ballot(key == first);
+      if (same == act) {
+        if (first != 0xFFFFFFFFu) {
+          const u32 lane_rank = __builtin_amdgcn_mbcnt_hi((u32)(act >> 32), __builtin_amdgcn_mbcnt_lo((u32)act, 0));
+          if (lane_rank == 0) atomicAdd(&hist[first], (u32)__popcll(act));
+        }
+      } else if (b) {
+        atomicAdd(&hist[key], 1u);
+      }
+    }
+  }
+}
+
+// ---- exclusive scan of hist[0..G) -> off[0..G], cursor[0..G) = off ------------------
+#define SCAN_PER_THREAD 16
+#define SCAN_TILE (256 * SCAN_PER_THREAD)
+__global__ void __launch_bounds__(256) k_scan_partials(const u32 *__restrict__ hist, u32 G, u32 *__restrict__ bsum) {
+  __shared__ u32 red[256];
+  const u32 base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_PER_THREAD;
+  u32 s = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_PER_THREAD; k++) { const u32 j = base + k; if (j < G) s += hist[j]; }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int d = 128; d > 0; d >>= 1) { if (threadIdx.x < d) red[threadIdx.x] += red[threadIdx.x + d]; __syncthreads(); }
+  if (threadIdx.x == 0) bsum[blockIdx.x] = red[0];
+}
+// single block: exclusive scan of bsum[0..nb) in place, total -> off[G]
+__global__ void __launch_bounds__(1024) k_scan_top(u32 *__restrict__ bsum, u32 nb, u32 *__restrict__ off, u32 G) {
+  __shared__ u32 sh[1024];
+  u32 running = 0;
+  for (u32 base = 0; base < nb; base += 1024) {
+    const u32 j = base + threadIdx.x;
+    const u32 v = j < nb ? bsum[j] : 0;
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+      u32 t = threadIdx.x >= d ? sh[threadIdx.x - d] : 0;
+      __syncthreads();
+      sh[threadIdx.x] += t;
+      __syncthreads();
+    }
+    if (j < nb) bsum[j] = running + sh[threadIdx.x] - v;
+    const u32 tot = sh[1023];
+    __syncthreads();
+    running += tot;
+  }
+  if (threadIdx.x == 0) off[G] = running;
+}
+__global__ void __launch_bounds__(256) k_scan_final(const u32 *__restrict__ hist, u32 G, const u32 *__restrict__ bsum,
+                                                    u32 *__restrict__ off, u32 *__restrict__ cursor) {
+  __shared__ u32 sh[256];
+  const u32 base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_PER_THREAD;
+  u32 v[SCAN_PER_THREAD];
+  u32 s = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_PER_THREAD; k++) { const u32 j = base + k; v[k] = j < G ? hist[j] : 0; s += v[k]; }
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int d = 1; d < 256; d <<= 1) {
+    u32 t = threadIdx.x >= d ? sh[threadIdx.x - d] : 0;
+    __syncthreads();
+    sh[threadIdx.x] += t;
+    __syncthreads();
+  }
+  u32 run = bsum[blockIdx.x] + sh[threadIdx.x] - s;
+#pragma unroll
+  for (int k = 0; k < SCAN_PER_THREAD; k++) {
+    const u32 j = base + k;
+    if (j < G) { off[j] = run; cursor[j] = run; }
+    run += v[k];
+  }
+}
+
+// ---- counting-sort scatter --------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_scatter(MsmGeom g, const u32 *__restrict__ dig, u32 *__restrict__ cursor,
+                                                 u32 *__restrict__ skey, u32 *__restrict__ sidx) {
+  const u32 stride = gridDim.x * blockDim.x;
+  for (u32 w = 0; w < g.W; w++) {
+    for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < g.n; i += stride) {
+      const u32 d = dig[(u64)w * g.n + i];
+      const u32 b = d & 0x7FFFFFFFu;
+      const u32 key = b ? (w * g.B + b - 1u) : 0xFFFFFFFFu;
+      const unsigned long long act = __ballot(1);
+      const u32 first = __builtin_amdgcn_readfirstlane(key);
+      const unsigned long long same = __ballot(key == first);
+      u32 pos = 0;
+      if (same == act) {
+        if (first != 0xFFFFFFFFu) {
+          const u32 lane_rank = __builtin_amdgcn_mbcnt_hi((u32)(act >> 32), __builtin_amdgcn_mbcnt_lo((u32)act, 0));
+          u32 basepos = 0;
+          if (lane_rank == 0) basepos = atomicAdd(&cursor[first], (u32)__popcll(act));
+          basepos = __builtin_amdgcn_readfirstlane(basepos);
+          pos = basepos + lane_rank;
+        }
+      } else if (b) {
+        pos = atomicAdd(&cursor[key], 1u);
+      }
+      if (b) { skey[pos] = key; sidx[pos] = i | (d & 0x80000000u); }
+    }
+  }
+}
+
+// ---- level 0: every thread adds exactly L sorted entries --------------------------------
+__global__ void __launch_bounds__(256) k_accum_l0(Segs segs, MsmGeom g, const u32 *__restrict__ off,
+                                                  const u32 *__restrict__ skey, const u32 *__restrict__ sidx,
+                                                  u32 *__restrict__ buckets, u32 *__restrict__ rec_key, u32 *__restrict__ rec_pt) {
+  const u32 E = off[g.G];
+  const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  const u64 start = t * g.L;
+  if (start >= E) return;
+  const u32 end = (u32)((start + g.L < E) ? start + g.L : E);
+  xyzz acc;
+  xyzz_set_inf(acc);
+  u32 cur = skey[start];
+  bool first = true;
+  for (u32 j = (u32)start; j < end; j++) {
+    const u32 k = skey[j];
+    if (k != cur) {
+      if (first) { rec_key[2 * t] = cur; xyzz_store_g(rec_pt + (2 * t) * XYZZ_WORDS, acc); first = false; }
+      else xyzz_store_g(buckets + (u64)cur * XYZZ_WORDS, acc);
+      xyzz_set_inf(acc);
+      cur = k;
+    }
+    const u32 e = sidx[j];
+    affine P;
+    load_affine(P, seg_point(segs, e & 0x7FFFFFFFu));
+    xyzz_madd_signed(acc, P, (e >> 31) != 0);
+  }
+  if (first) {
+    rec_key[2 * t] = cur; xyzz_store_g(rec_pt + (2 * t) * XYZZ_WORDS, acc);
+    xyzz_set_inf(acc);
+  }
+  rec_key[2 * t + 1] = cur;
+  xyzz_store_g(rec_pt + (2 * t + 1) * XYZZ_WORDS, acc);
+}
+
+// number of records entering segscan level `level` (1-based); 0 when that level has nothing to do
+__device__ __forceinline__ u32 records_at_level(u32 E, u32 L, int level, bool &is_final) {
+  is_final = false;
+  if (E == 0) return 0;
+  u32 R = 2u * ((E + L - 1) / L);
+  for (int l = 1; l < level; l++) {
+    const u32 nb = (R + 255u) / 256u;
+    if (nb <= 1) return 0;          // the previous level was already final
+    R = 2u * nb;
+  }
+  is_final = ((R + 255u) / 256u) <= 1;
+  return R;
+}
+
+// ---- levels >= 1: block-wide segmented scan over partial records -------------------------
+__global__ void __launch_bounds__(256) k_segscan(MsmGeom g, const u32 *__restrict__ off, int level,
+                                                 const u32 *__restrict__ in_key, const u32 *__restrict__ in_pt,
+                                                 u32 *__restrict__ out_key, u32 *__restrict__ out_pt, u32 *__restrict__ buckets) {
+  __shared__ u32 s_key[256];
+  __shared__ u32 s_val[256 * LDS_STRIDE];
+  bool is_final;
+  const u32 R = records_at_level(off[g.G], g.L, level, is_final);
+  const u32 nb = (R + 255u) / 256u;
+  if (blockIdx.x >= nb) return;
+  const u32 tid = threadIdx.x;
+  const u32 j = blockIdx.x * 256u + tid;
+  const bool valid = j < R;
+  const u32 key = valid ? in_key[j] : 0xFFFFFFFFu;
+  xyzz val;
+  if (valid) xyzz_load_g(val, in_pt + (u64)j * XYZZ_WORDS); else xyzz_set_inf(val);
+  s_key[tid] = key;
+  __syncthreads();
+  for (u32 d = 1; d < 256; d <<= 1) {
+    xyzz_store(s_val + tid * LDS_STRIDE, val);
+    __syncthreads();
+    if (valid && tid >= d && s_key[tid - d] == key) {
+      xyzz other;
+      xyzz_load(other, s_val + (tid - d) * LDS_STRIDE);
+      xyzz_add(val, other, val);
+    }
+    __syncthreads();
+  }
+  if (!valid) return;
+  const u32 last_idx = (R - blockIdx.x * 256u >= 256u) ? 255u : (R - blockIdx.x * 256u - 1u);
+  const bool run_end = (tid == last_idx) || (s_key[tid + 1] != key);
+  if (!run_end) return;
+  const u32 first_key = s_key[0], last_key = s_key[last_idx];
+  // One store site with a per-thread destination.  (A three-way if/else over
+  // buckets / head record / tail record made hipcc 7.2 merge the stores behind
+  // scalar base-pointer selects in divergent flow, and the multi-block case faulted
+  // on gfx950; tests/test_gpu_msm.py::test_msm_multiblock_segscan pins this.)
+  const bool to_bucket = is_final || (key != first_key && key != last_key);
+  const bool is_head = !to_bucket && (key == first_key);
+  const u32 slot = 2u * blockIdx.x + (is_head ? 0u : 1u);
+  u32 *dst = to_bucket ? buckets + (u64)key * XYZZ_WORDS : out_pt + (u64)slot * XYZZ_WORDS;
+  if (!to_bucket) out_key[slot] = key;
+  xyzz_store_g(dst, val);
+  if (is_head && first_key == last_key) {       // the block is one single run: empty tail record
+    xyzz inf;
+    xyzz_set_inf(inf);
+    out_key[slot + 1u] = key;
+    xyzz_store_g(out_pt + (u64)(slot + 1u) * XYZZ_WORDS, inf);
+  }
+}
+
+// block-wide tree sum of one XYZZ value per thread (256 threads); result valid in thread 0
+__device__ __forceinline__ void block_tree_sum(xyzz &val, u32 *s_val) {
+  const u32 tid = threadIdx.x;
+  for (u32 d = blockDim.x >> 1; d > 0; d >>= 1) {
+    xyzz_store(s_val + tid * LDS_STRIDE, val);
+    __syncthreads();
+    if (tid < d) {
+      xyzz other;
+      xyzz_load(other, s_val + (tid + d) * LDS_STRIDE);
+      xyzz_add(val, val, other);
+    }
+    __syncthreads();
+  }
+}
+
+// ---- bucket reduction, step 1: D[w][v][d] = sum of buckets b in [1,B] whose base-32 digit v is d
+// grid = W * nv * 31 blocks of 256
+__global__ void __launch_bounds__(256) k_bucket_digit_sums(MsmGeom g, const u32 *__restrict__ buckets, u32 *__restrict__ D) {
+  __shared__ u32 s_val[256 * LDS_STRIDE];
+  const u32 blk = blockIdx.x;
+  const u32 d = blk % 31u + 1u;
+  const u32 v = (blk / 31u) % g.nv;
+  const u32 w = blk / (31u * g.nv);
+  const u32 sh = 5u * v;
+  xyzz acc;
+  xyzz_set_inf(acc);
+  // element e -> b = (hi << (sh+5)) | (d << sh) | lo,  lo = low `sh` bits of e, hi = e >> sh
+  // valid (hi, lo): all lo for hi < hi_max, and lo <= B - base for hi == hi_max
+  const u32 hi_max = g.B >> (sh + 5u);
+  const u64 base_last = ((u64)hi_max << (sh + 5u)) | ((u64)d << sh);
+  u32 last_cnt = 0;
+  if (base_last <= g.B) { const u64 r = (u64)g.B - base_last + 1u; last_cnt = r < (1ull << sh) ? (u32)r : (1u << sh); }
+  const u32 ecount = (hi_max << sh) + last_cnt;
+  for (u32 e = threadIdx.x; e < ecount; e += 256u) {
+    const u32 lo = e & ((1u << sh) - 1u), hi = e >> sh;
+    const u64 b = ((u64)hi << (sh + 5u)) | ((u64)d << sh) | lo;
+    {
+      xyzz x;
+      xyzz_load_g(x, buckets + ((u64)w * g.B + (b - 1u)) * XYZZ_WORDS);
+      xyzz_add(acc, acc, x);
+    }
+  }
+  block_tree_sum(acc, s_val);
+  if (threadIdx.x == 0) xyzz_store_g(D + (u64)blk * XYZZ_WORDS, acc);
+}
+// ---- step 2: E[w][v] = sum_{d=1..31} d * D[w][v][d]  (suffix scan + sum over 32 lanes)
+// grid = W * nv blocks of 64
+__global__ void __launch_bounds__(64) k_weighted31(const u32 *__restrict__ D, u32 *__restrict__ Eout) {
+  __shared__ u32 s_val[64 * LDS_STRIDE];
+  const u32 tid = threadIdx.x;
+  xyzz val;
+  if (tid < 31u) xyzz_load_g(val, D + ((u64)blockIdx.x * 31u + tid) * XYZZ_WORDS); else xyzz_set_inf(val);
+  // inclusive suffix scan: val[l] = sum_{j >= l} D[j]
+  for (u32 d = 1; d < 32; d <<= 1) {
+    xyzz_store(s_val + tid * LDS_STRIDE, val);
+    __syncthreads();
+    if (tid + d < 31u) {
+      xyzz other;
+      xyzz_load(other, s_val + (tid + d) * LDS_STRIDE);
+      xyzz_add(val, val, other);
+    }
+    __syncthreads();
+  }
+  block_tree_sum(val, s_val);
+  if (tid == 0) xyzz_store_g(Eout + (u64)blockIdx.x * XYZZ_WORDS, val);
+}
+
+// ---- tail: result = sum_w 2^(c w) sum_v 32^v E[w][v], to canonical affine -----------------
+BPMI_HD void msm_tail_combine(u32 out_words[16], const u32 *E, u32 W, u32 nv, u32 c) {
+  xyzz acc;
+  xyzz_set_inf(acc);
+  for (int w = (int)W - 1; w >= 0; w--) {
+    for (u32 k = 0; k < c; k++) xyzz_dbl(acc, acc);
+    xyzz tw;
+    xyzz_set_inf(tw);
+    for (int v = (int)nv - 1; v >= 0; v--) {
+      for (int k = 0; k < 5; k++) xyzz_dbl(tw, tw);
+      xyzz e;
+      xyzz_load(e, E + ((u64)w * nv + v) * XYZZ_WORDS);
+      xyzz_add(tw, tw, e);
+    }
+    xyzz_add(acc, acc, tw);
+  }
+  affine r;
+  xyzz_to_affine(r, acc);
+  affine_to_words(out_words, r);
+}
+__global__ void k_tail(const u32 *__restrict__ E, u32 W, u32 nv, u32 c, u32 *__restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    u32 w16[16];
+    msm_tail_combine(w16, E, W, nv, c);
+#pragma unroll
+    for (int i = 0; i < 16; i++) out[i] = w16[i];
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// batched point kernels
+// ------------------------------------------------------------------------------------
+// out[i] = k_i * P_i   (left-to-right double-and-add; lanes diverge only on the add)
+__global__ void __launch_bounds__(256) k_ec_mul_batch(const u32 *__restrict__ pts, const u32 *__restrict__ scs, u32 n, u32 *__restrict__ out) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  affine P;
+  load_affine(P, pts + 16ull * i);
+  sc s;
+  load_words8(s.v, scs + 8ull * i);
+  bool neg = sc_is_high(s);
+  if (neg) sc_neg(s, s);
+  affine Q = P;
+  if (neg) affine_neg(Q, P);
+  xyzz acc;
+  xyzz_set_inf(acc);
+  const bool pinf = affine_is_inf(Q);
+  for (int word = 7; word >= 0; word--) {
+    // static word selection keeps s.v[] in registers
+    u32 wv = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) if (k == word) wv = s.v[k];
+    for (int bit = 31; bit >= 0; bit--) {
+      xyzz_dbl(acc, acc);
+      if (((wv >> bit) & 1u) && !pinf) xyzz_madd(acc, Q.x, Q.y);
+    }
+  }
+  affine r;
+  xyzz_to_affine(r, acc);
+  u32 w16[16];
+  affine_to_words(w16, r);
+  store_words16(out + 16ull * i, w16);
+}
+
+struct Sc2 { u32 k1[8]; u32 k2[8]; };
+// out[i] = k1 * P1_i + k2 * P2_i with k1, k2 shared by all i (Shamir's trick; the branch
+// on the scalar bits is wave-uniform)
+__global__ void __launch_bounds__(256) k_ec_lincomb2(const u32 *p1, const u32 *p2, Sc2 ks, u32 n, u32 *out) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  affine A, Bp;
+  load_affine(A, p1 + 16ull * i);
+  load_affine(Bp, p2 + 16ull * i);
+  xyzz T, XA, XB;                              // T = A + B
+  xyzz_from_affine(XA, A);
+  xyzz_from_affine(XB, Bp);
+  xyzz_add(T, XA, XB);
+  xyzz acc;
+  xyzz_set_inf(acc);
+  for (int word = 7; word >= 0; word--) {
+    const u32 w1 = ks.k1[word], w2 = ks.k2[word];
+    for (int bit = 31; bit >= 0; bit--) {
+      xyzz_dbl(acc, acc);
+      const u32 sel = ((w1 >> bit) & 1u) | (((w2 >> bit) & 1u) << 1);
+      if (sel == 1u) xyzz_madd_signed(acc, A, false);
+      else if (sel == 2u) xyzz_madd_signed(acc, Bp, false);
+      else if (sel == 3u) xyzz_add(acc, acc, T);
+    }
+  }
+  affine r;
+  xyzz_to_affine(r, acc);
+  u32 w16[16];
+  affine_to_words(w16, r);
+  store_words16(out + 16ull * i, w16);
+}
+
+// out = sum of n affine points (one block)
+__global__ void __launch_bounds__(256) k_ec_sum(const u32 *__restrict__ pts, u32 n, u32 *__restrict__ out) {
+  __shared__ u32 s_val[256 * LDS_STRIDE];
+  xyzz acc;
+  xyzz_set_inf(acc);
+  for (u32 i = threadIdx.x; i < n; i += 256u) {
+    affine P;
+    load_affine(P, pts + 16ull * i);
+    xyzz_madd_signed(acc, P, false);
+  }
+  block_tree_sum(acc, s_val);
+  if (threadIdx.x == 0) {
+    affine r;
+    xyzz_to_affine(r, acc);
+    u32 w16[16];
+    affine_to_words(w16, r);
+#pragma unroll
+    for (int k = 0; k < 16; k++) out[k] = w16[k];
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// scalar kernels
+// ------------------------------------------------------------------------------------
+// partial[b] = sum over the block's stride of a_i * b_i ; then k_sc_dot_final sums partials
+__global__ void __launch_bounds__(256) k_sc_dot(const u32 *__restrict__ a, const u32 *__restrict__ b, u32 n, u32 *__restrict__ partial) {
+  __shared__ u32 sh[256 * 8];
+  sc acc;
+#pragma unroll
+  for (int k = 0; k < 8; k++) acc.v[k] = 0;
+  const u32 stride = gridDim.x * blockDim.x;
+  for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    sc x, y, t;
+    load_words8(x.v, a + 8ull * i);
+    load_words8(y.v, b + 8ull * i);
+    sc_mul(t, x, y);
+    sc_add(acc, acc, t);
+  }
+  for (u32 d = 128; d > 0; d >>= 1) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) sh[threadIdx.x * 8 + k] = acc.v[k];
+    __syncthreads();
+    if (threadIdx.x < d) {
+      sc o;
+#pragma unroll
+      for (int k = 0; k < 8; k++) o.v[k] = sh[(threadIdx.x + d) * 8 + k];
+      sc_add(acc, acc, o);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) store_words8(partial + 8ull * blockIdx.x, acc.v);
+}
+__global__ void __launch_bounds__(256) k_sc_sum(const u32 *__restrict__ partial, u32 n, u32 *__restrict__ out) {
+  __shared__ u32 sh[256 * 8];
+  sc acc;
+#pragma unroll
+  for (int k = 0; k < 8; k++) acc.v[k] = 0;
+  for (u32 i = threadIdx.x; i < n; i += 256u) { sc x; load_words8(x.v, partial + 8ull * i); sc_add(acc, acc, x); }
+  for (u32 d = 128; d > 0; d >>= 1) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) sh[threadIdx.x * 8 + k] = acc.v[k];
+    __syncthreads();
+    if (threadIdx.x < d) {
+      sc o;
+#pragma unroll
+      for (int k = 0; k < 8; k++) o.v[k] = sh[(threadIdx.x + d) * 8 + k];
+      sc_add(acc, acc, o);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) store_words8(out, acc.v);
+}
+// out[i] = x * lo[i] + y * hi[i]
+__global__ void __launch_bounds__(256) k_sc_fold(const u32 *lo, const u32 *hi, Sc2 xy, u32 n, u32 *out) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  sc X, Y, a, b, t, s;
+#pragma unroll
+  for (int k = 0; k < 8; k++) { X.v[k] = xy.k1[k]; Y.v[k] = xy.k2[k]; }
+  load_words8(a.v, lo + 8ull * i);
+  load_words8(b.v, hi + 8ull * i);
+  sc_mul(t, X, a);
+  sc_mul(s, Y, b);
+  sc_add(t, t, s);
+  store_words8(out + 8ull * i, t.v);
+}
+
+// ------------------------------------------------------------------------------------
+// host orchestration
+// ------------------------------------------------------------------------------------
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+static u32 pick_window_bits(const bpmi_ctx *ctx, uint64_t n) {
+  if (ctx->opt_c >= 2 && ctx->opt_c <= 16) return (u32)ctx->opt_c;
+  u32 lg = 0;
+  while ((1ull << (lg + 1)) <= n) lg++;
+  int c = (int)lg - 3;
+  if (n >= (1u << 19)) c = (int)lg - 4;
+  if (c < 4) c = 4;
+  if (c > 16) c = 16;
+  return (u32)c;
+}
+
+struct MsmWs {
+  u32 *dig, *hist, *off, *cursor, *bsum, *skey, *sidx, *buckets;
+  u32 *rec_key[2], *rec_pt[2];
+  u32 *D, *E, *out;
+  size_t total;
+  u32 nscan_blocks, rec0_max;
+};
+static void msm_layout(const MsmGeom &g, MsmWs &w, char *base) {
+  size_t o = 0;
+  auto take = [&](size_t bytes) { char *p = base ? base + o : nullptr; o += align_up(bytes, 256); return (u32 *)p; };
+  const size_t nW = (size_t)g.n * g.W;
+  w.nscan_blocks = (u32)((g.G + SCAN_TILE - 1) / SCAN_TILE);
+  w.rec0_max = (u32)(2 * ((nW + g.L - 1) / g.L));
+  const u32 rec1_max = 2 * ((w.rec0_max + 255) / 256);
+  w.hist = take(4ull * g.G);                 // hist | off | cursor | bsum are zeroed/filled per call
+  w.off = take(4ull * (g.G + 1));
+  w.cursor = take(4ull * g.G);
+  w.bsum = take(4ull * (w.nscan_blocks + 1));
+  w.dig = take(4ull * nW);
+  w.skey = take(4ull * nW);
+  w.sidx = take(4ull * nW);
+  w.buckets = take(4ull * XYZZ_WORDS * g.G);
+  w.rec_key[0] = take(4ull * w.rec0_max);
+  w.rec_pt[0] = take(4ull * XYZZ_WORDS * w.rec0_max);
+  w.rec_key[1] = take(4ull * rec1_max);
+  w.rec_pt[1] = take(4ull * XYZZ_WORDS * rec1_max);
+  w.D = take(4ull * XYZZ_WORDS * g.W * g.nv * 31);
+  w.E = take(4ull * XYZZ_WORDS * g.W * g.nv);
+  w.out = take(64);
+  w.total = o;
+}
+
+static int msm_run(bpmi_ctx *ctx, const Segs &segs, uint8_t out[64]) {
+  const uint64_t n = segs.total;
+  if (n == 0) { memset(out, 0, 64); return BPMI_OK; }
+  if (n > BPMI_MAX_N) return fail(ctx, BPMI_E_ARG, "n exceeds BPMI_MAX_N");
+  MsmGeom g;
+  g.n = (u32)n;
+  g.c = pick_window_bits(ctx, n);
+  g.W = 255u / g.c + 1u;
+  g.B = 1u << (g.c - 1);
+  g.G = g.W * g.B;
+  g.L = ctx->opt_chunk > 0 ? (u32)ctx->opt_chunk : 32u;
+  g.nv = (g.c + 4u) / 5u;
+  MsmWs w;
+  msm_layout(g, w, nullptr);
+  int rc = ensure_ws(ctx, w.total);
+  if (rc) return rc;
+  msm_layout(g, w, (char *)ctx->ws);
+  hipStream_t st = ctx->stream;
+  const u32 nblk_n = (u32)std::min<uint64_t>((n + 255) / 256, 8192);
+  {
+    StageTimer t(ctx, ST_MISC);
+    HIPCHK(ctx, hipMemsetAsync(w.hist, 0, 4ull * g.G, st));
+    HIPCHK(ctx, hipMemsetAsync(w.buckets, 0, 4ull * XYZZ_WORDS * g.G, st));
+  }
+  debug_sync(ctx, "ST_MISC");
+  {
+    StageTimer t(ctx, ST_DIGITS);
+    hipLaunchKernelGGL(k_digits_hist, dim3(nblk_n), dim3(256), 0, st, segs, g, w.dig, w.hist);
+  }
+  debug_sync(ctx, "ST_DIGITS");
+  {
+    StageTimer t(ctx, ST_SCAN);
+    hipLaunchKernelGGL(k_scan_partials, dim3(w.nscan_blocks), dim3(256), 0, st, w.hist, g.G, w.bsum);
+    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, w.bsum, w.nscan_blocks, w.off, g.G);
+    hipLaunchKernelGGL(k_scan_final, dim3(w.nscan_blocks), dim3(256), 0, st, w.hist, g.G, w.bsum, w.off, w.cursor);
+  }
+  debug_sync(ctx, "ST_SCAN");
+  {
+    StageTimer t(ctx, ST_SCATTER);
+    hipLaunchKernelGGL(k_scatter, dim3(nblk_n), dim3(256), 0, st, g, w.dig, w.cursor, w.skey, w.sidx);
+  }
+  debug_sync(ctx, "ST_SCATTER");
+  {
+    StageTimer t(ctx, ST_ACCUM);
+    const u32 nthreads = w.rec0_max / 2;
+    hipLaunchKernelGGL(k_accum_l0, dim3((nthreads + 255) / 256), dim3(256), 0, st, segs, g, w.off, w.skey, w.sidx,
+                       w.buckets, w.rec_key[0], w.rec_pt[0]);
+  }
+  debug_sync(ctx, "ST_ACCUM");
+  {
+    StageTimer t(ctx, ST_SEGSCAN);
+    u32 R = w.rec0_max;
+    int level = 1, src = 0;
+    for (;;) {
+      const u32 nb = (R + 255) / 256;
+      hipLaunchKernelGGL(k_segscan, dim3(nb), dim3(256), 0, st, g, w.off, level, w.rec_key[src], w.rec_pt[src],
+                         w.rec_key[src ^ 1], w.rec_pt[src ^ 1], w.buckets);
+      if (g_debug_sync) { fprintf(stderr, "[bpmi] segscan level %d nb %u R %u\n", level, nb, R); debug_sync(ctx, "segscan level"); }
+      if (nb <= 1) break;
+      R = 2 * nb;
+      // ping-pong: level 1 reads buffer 0 (large) and writes buffer 1; later levels are
+      // small enough for either buffer (rec1_max >= every later level)
+      src ^= 1;
+      level++;
+    }
+  }
+  debug_sync(ctx, "ST_SEGSCAN");
+  {
+    StageTimer t(ctx, ST_BREDUCE);
+    hipLaunchKernelGGL(k_bucket_digit_sums, dim3(g.W * g.nv * 31), dim3(256), 0, st, g, w.buckets, w.D);
+    hipLaunchKernelGGL(k_weighted31, dim3(g.W * g.nv), dim3(64), 0, st, w.D, w.E);
+  }
+  debug_sync(ctx, "ST_BREDUCE");
+  {
+    StageTimer t(ctx, ST_TAIL);
+    const int tail = ctx->opt_tail ? ctx->opt_tail : 2;
+    if (tail == 1) {
+      hipLaunchKernelGGL(k_tail, dim3(1), dim3(64), 0, st, w.E, g.W, g.nv, g.c, w.out);
+      rc = ensure_pin(ctx, 4096);
+      if (rc) return rc;
+      HIPCHK(ctx, hipMemcpyAsync(ctx->pin, w.out, 64, hipMemcpyDeviceToHost, st));
+      HIPCHK(ctx, hipStreamSynchronize(st));
+      memcpy(out, ctx->pin, 64);
+    } else {
+      const size_t eb = 4ull * XYZZ_WORDS * g.W * g.nv;
+      rc = ensure_pin(ctx, eb);
+      if (rc) return rc;
+      HIPCHK(ctx, hipMemcpyAsync(ctx->pin, w.E, eb, hipMemcpyDeviceToHost, st));
+      HIPCHK(ctx, hipStreamSynchronize(st));
+      u32 w16[16];
+      msm_tail_combine(w16, (const u32 *)ctx->pin, g.W, g.nv, g.c);
+      memcpy(out, w16, 64);
+    }
+  }
+  debug_sync(ctx, "ST_TAIL");
+  HIPCHK(ctx, hipGetLastError());
+  return BPMI_OK;
+}
+
+// second-level segscan buffer sizing relies on this: every level after the first has
+// at most rec1_max records (R shrinks monotonically)
+
+// ------------------------------------------------------------------------------------
+// C-ABI
+// ------------------------------------------------------------------------------------
+extern "C" {
+
+int bpmi_version(void) { return BPMI_VERSION; }
+
+int bpmi_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+bpmi_ctx *bpmi_ctx_create(int device, void *stream) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) { fail(nullptr, BPMI_E_NODEVICE, "no HIP device visible (libbpmi has no CPU fallback)"); return nullptr; }
+  if (device < 0 || device >= n) { fail(nullptr, BPMI_E_ARG, "device index out of range"); return nullptr; }
+  if (hipSetDevice(device) != hipSuccess) { fail(nullptr, BPMI_E_HIP, "hipSetDevice failed"); return nullptr; }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) { fail(nullptr, BPMI_E_HIP, "hipGetDeviceProperties failed"); return nullptr; }
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    fail(nullptr, BPMI_E_NODEVICE, std::string("device is ") + prop.gcnArchName + ", libbpmi is built for gfx950 only");
+    return nullptr;
+  }
+  bpmi_ctx *ctx = new bpmi_ctx();
+  ctx->device = device;
+  if (stream) { ctx->stream = (hipStream_t)stream; ctx->own_stream = false; }
+  else {
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+      delete ctx; fail(nullptr, BPMI_E_HIP, "hipStreamCreate failed"); return nullptr;
+    }
+    ctx->own_stream = true;
+  }
+  return ctx;
+}
+
+void bpmi_ctx_destroy(bpmi_ctx *ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  for (auto &e : ctx->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+  if (ctx->ws) (void)hipFree(ctx->ws);
+  if (ctx->stage_in) (void)hipFree(ctx->stage_in);
+  if (ctx->pin) (void)hipHostFree(ctx->pin);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char *bpmi_last_error(const bpmi_ctx *ctx) {
+  if (ctx) return ctx->err.c_str();
+  return g_create_err.c_str();
+}
+
+int bpmi_sync(bpmi_ctx *ctx) {
+  if (!ctx) return BPMI_E_ARG;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return BPMI_OK;
+}
+
+int bpmi_set_option(bpmi_ctx *ctx, const char *name, int64_t value) {
+  if (!ctx || !name) return BPMI_E_ARG;
+  if (!strcmp(name, "window_bits")) { if (value != 0 && (value < 2 || value > 16)) return fail(ctx, BPMI_E_ARG, "window_bits must be 0 or 2..16"); ctx->opt_c = (int)value; return BPMI_OK; }
+  if (!strcmp(name, "tail")) { if (value < 0 || value > 2) return fail(ctx, BPMI_E_ARG, "tail must be 0, 1 or 2"); ctx->opt_tail = (int)value; return BPMI_OK; }
+  if (!strcmp(name, "chunk")) { if (value < 0 || value > 4096) return fail(ctx, BPMI_E_ARG, "chunk must be 0..4096"); ctx->opt_chunk = (int)value; return BPMI_OK; }
+  return fail(ctx, BPMI_E_ARG, std::string("unknown option ") + name);
+}
+
+int bpmi_malloc(bpmi_ctx *ctx, size_t bytes, void **dptr) {
+  if (!ctx || !dptr) return BPMI_E_ARG;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipMalloc(dptr, bytes ? bytes : 16));
+  return BPMI_OK;
+}
+int bpmi_free(bpmi_ctx *ctx, void *dptr) {
+  if (!ctx) return BPMI_E_ARG;
+  if (!dptr) return BPMI_OK;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx, hipFree(dptr));
+  return BPMI_OK;
+}
+int bpmi_upload(bpmi_ctx *ctx, void *dptr, const void *host, size_t bytes) {
+  if (!ctx || (bytes && (!dptr || !host))) return BPMI_E_ARG;
+  if (!bytes) return BPMI_OK;
+  HIPCHK(ctx, hipMemcpyAsync(dptr, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return BPMI_OK;
+}
+int bpmi_download(bpmi_ctx *ctx, void *host, const void *dptr, size_t bytes) {
+  if (!ctx || (bytes && (!dptr || !host))) return BPMI_E_ARG;
+  if (!bytes) return BPMI_OK;
+  HIPCHK(ctx, hipMemcpyAsync(host, dptr, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return BPMI_OK;
+}
+
+// ---- MSM ------------------------------------------------------------------------------
+int bpmi_msm_dev(bpmi_ctx *ctx, const void *d_pts, const void *d_scalars, uint64_t n, uint8_t out[64]) {
+  if (!ctx || !out || (n && (!d_pts || !d_scalars))) return ctx ? fail(ctx, BPMI_E_ARG, "null argument") : BPMI_E_ARG;
+  if (n > BPMI_MAX_N) return fail(ctx, BPMI_E_ARG, "n exceeds BPMI_MAX_N");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  Segs s = {};
+  s.pts[0] = (const u32 *)d_pts; s.sc[0] = (const u32 *)d_scalars; s.n[0] = (u32)n; s.total = (u32)n;
+  return msm_run(ctx, s, out);
+}
+int bpmi_msm(bpmi_ctx *ctx, const uint8_t *pts, const uint8_t *scalars, uint64_t n, uint8_t out[64]) {
+  if (!ctx || !out || (n && (!pts || !scalars))) return ctx ? fail(ctx, BPMI_E_ARG, "null argument") : BPMI_E_ARG;
+  if (n > BPMI_MAX_N) return fail(ctx, BPMI_E_ARG, "n exceeds BPMI_MAX_N");
+  if (n == 0) { memset(out, 0, 64); return BPMI_OK; }
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  int rc = ensure_stage_in(ctx, 96 * n + 512);
+  if (rc) return rc;
+  char *dp = (char *)ctx->stage_in;
+  char *ds = dp + align_up(64 * n, 256);
+  HIPCHK(ctx, hipMemcpyAsync(dp, pts, 64 * n, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(ds, scalars, 32 * n, hipMemcpyHostToDevice, ctx->stream));
+  return bpmi_msm_dev(ctx, dp, ds, n, out);
+}
+
+// ---- batched point ops --------------------------------------------------------------------
+int bpmi_ec_mul_batch_dev(bpmi_ctx *ctx, const void *d_pts, const void *d_scalars, uint64_t n, void *d_out) {
+  if (!ctx || (n && (!d_pts || !d_scalars || !d_out))) return ctx ? fail(ctx, BPMI_E_ARG, "null argument") : BPMI_E_ARG;
+  if (n > BPMI_MAX_N) return fail(ctx, BPMI_E_ARG, "n exceeds BPMI_MAX_N");
+  if (n == 0) return BPMI_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  {
+    StageTimer t(ctx, ST_MULBATCH);
+    hipLaunchKernelGGL(k_ec_mul_batch, dim3((u32)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const u32 *)d_pts,
+                       (const u32 *)d_scalars, (u32)n, (u32 *)d_out);
+  }
+  HIPCHK(ctx, hipGetLastError());
+  return BPMI_OK;
+}
+int bpmi_ec_mul_batch(bpmi_ctx *ctx, const uint8_t *pts, const uint8_t *scalars, uint64_t n, uint8_t *out) {
+  if (!ctx || (n && (!pts || !scalars || !out))) return ctx ? fail(ctx, BPMI_E_ARG, "null argument") : BPMI_E_ARG;
+  if (n > BPMI_MAX_N) return fail(ctx, BPMI_E_ARG, "n exceeds BPMI_MAX_N");
+  if (n == 0) return BPMI_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  int rc = ensure_stage_in(ctx, 160 * n + 1024);
+  if (rc) return rc;
+  char *dp = (char *)ctx->stage_in, *ds = dp + align_up(64 * n, 256), *dout = ds + align_up(32 * n, 256);
+  HIPCHK(ctx, hipMemcpyAsync(dp, pts, 64 * n, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(ds, scalars, 32 * n, hipMemcpyHostToDevice, ctx->stream));
+  rc = bpmi_ec_mul_batch_dev(ctx, dp, ds, n, dout);
+  if (rc) return rc;
+  HIPCHK(ctx, hipMemcpyAsync(out, dout, 64 * n, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return BPMI_OK;
+}
+int bpmi_ec_lincomb2_batch_dev(bpmi_ctx *ctx, const void *d_p1, const void *d_p2, const uint8_t k1[32], const uint8_t k2[32],
+                               uint64_t n, void *d_out) {
+  if (!ctx || !k1 || !k2 || (n && (!d_p1 || !d_p2 || !d_out))) return ctx ? fail(ctx, BPMI_E_ARG, "null argument") : BPMI_E_ARG;
+  if (n > BPMI_MAX_N) return fail(ctx, BPMI_E_ARG, "n exceeds BPMI_MAX_N");
+  if (n == 0) return BPMI_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  Sc2 ks;
+  memcpy(ks.k1, k1, 32); memcpy(ks.k2, k2, 32);
+  {
+    StageTimer t(ctx, ST_LINCOMB2);
+    hipLaunchKernelGGL(k_ec_lincomb2, dim3((u32)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const u32 *)d_p1,
+                       (const u32 *)d_p2, ks, (u32)n, (u32 *)d_out);
+  }
+  HIPCHK(ctx, hipGetLastError());
+  return BPMI_OK;
+}
+int bpmi_ec_lincomb2_batch(bpmi_ctx *ctx, const uint8_t *p1, const uint8_t *p2, const uint8_t k1[32], const uint8_t k2[32],
+                           uint64_t n, uint8_t *out) {
+  if (!ctx || !k1 || !k2 || (n && (!p1 || !p2 || !out))) return ctx ? fail(ctx, BPMI_E_ARG, "null argument") : BPMI_E_ARG;
+  if (n > BPMI_MAX_N) return fail(ctx, BPMI_E_ARG, "n exceeds BPMI_MAX_N");
+  if (n == 0) return BPMI_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  int rc = ensure_stage_in(ctx, 192 * n + 1024);
+  if (rc) return rc;
+  char *d1 = (char *)ctx->stage_in, *d2 = d1 + align_up(64 * n, 256), *dout = d2 + align_up(64 * n, 256);
+  HIPCHK(ctx, hipMemcpyAsync(d1, p1, 64 * n, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(d2, p2, 64 * n, hipMemcpyHostToDevice, ctx->stream));
+  rc = bpmi_ec_lincomb2_batch_dev(ctx, d1, d2, k1, k2, n, dout);
+  if (rc) return rc;
+  HIPCHK(ctx, hipMemcpyAsync(out, dout, 64 * n, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return BPMI_OK;
+}
+int bpmi_ec_sum(bpmi_ctx *ctx, const uint8_t *pts, uint64_t n, uint8_t out[64]) {
+  if (!ctx || !out || (n && !pts)) return ctx ? fail(ctx, BPMI_E_ARG, "null argument") : BPMI_E_ARG;
+  if (n > BPMI_MAX_N) return fail(ctx, BPMI_E_ARG, "n exceeds BPMI_MAX_N");
+  if (n == 0) { memset(out, 0, 64); return BPMI_OK; }
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  int rc = ensure_stage_in(ctx, 64 * n + 512);
+  if (rc) return rc;
+  char *dp = (char *)ctx->stage_in, *dout = dp + align_up(64 * n, 256);
+  HIPCHK(ctx, hipMemcpyAsync(dp, pts, 64 * n, hipMemcpyHostToDevice, ctx->stream));
+  {
+    StageTimer t(ctx, ST_MISC);
+    hipLaunchKernelGGL(k_ec_sum, dim3(1), dim3(256), 0, ctx->stream, (const u32 *)dp, (u32)n, (u32 *)dout);
+  }
+  HIPCHK(ctx, hipMemcpyAsync(out, dout, 64, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return BPMI_OK;
+}
+
+// ---- scalar ops -------------------------------------------------------------------------------
+static int sc_dot_dev_to(bpmi_ctx *ctx, const void *d_a, const void *d_b, uint64_t n, u32 *d_out, u32 *d_partial) {
+  const u32 nb = (u32)std::min<uint64_t>((n + 255) / 256, 1024);
+  StageTimer t(ctx, ST_SCDOT);
+  hipLaunchKernelGGL(k_sc_dot, dim3(nb), dim3(256), 0, ctx->stream, (const u32 *)d_a, (const u32 *)d_b, (u32)n, d_partial);
+  hipLaunchKernelGGL(k_sc_sum, dim3(1), dim3(256), 0, ctx->stream, d_partial, nb, d_out);
+  return BPMI_OK;
+}
+int bpmi_sc_dot_dev(bpmi_ctx *ctx, const void *d_a, const void *d_b, uint64_t n, uint8_t out[32]) {
+  if (!ctx || !out || (n && (!d_a || !d_b))) return ctx ? fail(ctx, BPMI_E_ARG, "null argument") : BPMI_E_ARG;
+  if (n > BPMI_MAX_N) return fail(ctx, BPMI_E_ARG, "n exceeds BPMI_MAX_N");
+  if (n == 0) { memset(out, 0, 32); return BPMI_OK; }
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  int rc = ensure_ws(ctx, 32 * 1024 + 256);
+  if (rc) return rc;
+  u32 *partial = (u32 *)ctx->ws, *dout = partial + 8 * 1024;
+  sc_dot_dev_to(ctx, d_a, d_b, n, dout, partial);
+  rc = ensure_pin(ctx, 4096);
+  if (rc) return rc;
+  HIPCHK(ctx, hipMemcpyAsync(ctx->pin, dout, 32, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  memcpy(out, ctx->pin, 32);
+  return BPMI_OK;
+}
+int bpmi_sc_dot(bpmi_ctx *ctx, const uint8_t *a, const uint8_t *b, uint64_t n, uint8_t out[32]) {
+  if (!ctx || !out || (n && (!a || !b))) return ctx ? fail(ctx, BPMI_E_ARG, "null argument") : BPMI_E_ARG;
+  if (n > BPMI_MAX_N) return fail(ctx, BPMI_E_ARG, "n exceeds BPMI_MAX_N");
+  if (n == 0) { memset(out, 0, 32); return BPMI_OK; }
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  int rc = ensure_stage_in(ctx, 64 * n + 512);
+  if (rc) return rc;
+  char *da = (char *)ctx->stage_in, *db = da + align_up(32 * n, 256);
+  HIPCHK(ctx, hipMemcpyAsync(da, a, 32 * n, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(db, b, 32 * n, hipMemcpyHostToDevice, ctx->stream));
+  return bpmi_sc_dot_dev(ctx, da, db, n, out);
+}
+int bpmi_sc_fold_dev(bpmi_ctx *ctx, const void *d_lo, const void *d_hi, const uint8_t x[32], const uint8_t y[32], uint64_t n, void *d_out) {
+  if (!ctx || !x || !y || (n && (!d_lo || !d_hi || !d_out))) return ctx ? fail(ctx, BPMI_E_ARG, "null argument") : BPMI_E_ARG;
+  if (n > BPMI_MAX_N) return fail(ctx, BPMI_E_ARG, "n exceeds BPMI_MAX_N");
+  if (n == 0) return BPMI_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  Sc2 xy;
+  memcpy(xy.k1, x, 32); memcpy(xy.k2, y, 32);
+  {
+    StageTimer t(ctx, ST_SCFOLD);
+    hipLaunchKernelGGL(k_sc_fold, dim3((u32)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const u32 *)d_lo, (const u32 *)d_hi, xy, (u32)n, (u32 *)d_out);
+  }
+  HIPCHK(ctx, hipGetLastError());
+  return BPMI_OK;
+}
+int bpmi_sc_fold(bpmi_ctx *ctx, const uint8_t *lo, const uint8_t *hi, const uint8_t x[32], const uint8_t y[32], uint64_t n, uint8_t *out) {
+  if (!ctx || !x || !y || (n && (!lo || !hi || !out))) return ctx ? fail(ctx, BPMI_E_ARG, "null argument") : BPMI_E_ARG;
+  if (n > BPMI_MAX_N) return fail(ctx, BPMI_E_ARG, "n exceeds BPMI_MAX_N");
+  if (n == 0) return BPMI_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  int rc = ensure_stage_in(ctx, 96 * n + 1024);
+  if (rc) return rc;
+  char *dl = (char *)ctx->stage_in, *dh = dl + align_up(32 * n, 256), *dout = dh + align_up(32 * n, 256);
+  HIPCHK(ctx, hipMemcpyAsync(dl, lo, 32 * n, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(dh, hi, 32 * n, hipMemcpyHostToDevice, ctx->stream));
+  rc = bpmi_sc_fold_dev(ctx, dl, dh, x, y, n, dout);
+  if (rc) return rc;
+  HIPCHK(ctx, hipMemcpyAsync(out, dout, 32 * n, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return BPMI_OK;
+}
+
+// ---- IPA prover state ---------------------------------------------------------------------------
+}  // extern "C"
+
+struct bpmi_ipa {
+  bpmi_ctx *ctx;
+  uint64_t n0, n;       // initial and current length
+  u32 *g, *h, *a, *b;   // device, halved in place
+  u32 *u;               // device, 64 B point
+  u32 *cl, *cr;         // device, 32 B scalars (stay on device between dot and MSM)
+  u32 *partial;         // device scratch for dots
+  void *block;          // one allocation
+  bool lr_done;
+};
+
+extern "C" {
+
+static int ipa_alloc(bpmi_ctx *ctx, uint64_t n, bpmi_ipa **out) {
+  bpmi_ipa *st = new bpmi_ipa();
+  st->ctx = ctx; st->n0 = st->n = n; st->lr_done = false;
+  const size_t bytes = align_up(64 * n, 256) * 2 + align_up(32 * n, 256) * 2 + 256 * 3 + 32 * 1024;
+  hipError_t e = hipMalloc(&st->block, bytes);
+  if (e != hipSuccess) { delete st; return fail(ctx, BPMI_E_NOMEM, std::string("hipMalloc(ipa state): ") + hipGetErrorString(e)); }
+  char *p = (char *)st->block;
+  st->g = (u32 *)p; p += align_up(64 * n, 256);
+  st->h = (u32 *)p; p += align_up(64 * n, 256);
+  st->a = (u32 *)p; p += align_up(32 * n, 256);
+  st->b = (u32 *)p; p += align_up(32 * n, 256);
+  st->u = (u32 *)p; p += 256;
+  st->cl = (u32 *)p; p += 256;
+  st->cr = (u32 *)p; p += 256;
+  st->partial = (u32 *)p;
+  *out = st;
+  return BPMI_OK;
+}
+static bool is_pow2(uint64_t n) { return n && !(n & (n - 1)); }
+
+int bpmi_ipa_create_dev(bpmi_ctx *ctx, const void *d_g, const void *d_h, const void *d_a, const void *d_b, uint64_t n,
+                        const uint8_t u[64], bpmi_ipa **out) {
+  if (!ctx || !d_g || !d_h || !d_a || !d_b || !u || !out) return ctx ? fail(ctx, BPMI_E_ARG, "null argument") : BPMI_E_ARG;
+  if (!is_pow2(n) || n > BPMI_MAX_N) return fail(ctx, BPMI_E_ARG, "n must be a power of two <= BPMI_MAX_N");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  bpmi_ipa *st = nullptr;
+  int rc = ipa_alloc(ctx, n, &st);
+  if (rc) return rc;
+  hipStream_t s = ctx->stream;
+  hipError_t e = hipMemcpyAsync(st->g, d_g, 64 * n, hipMemcpyDeviceToDevice, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(st->h, d_h, 64 * n, hipMemcpyDeviceToDevice, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(st->a, d_a, 32 * n, hipMemcpyDeviceToDevice, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(st->b, d_b, 32 * n, hipMemcpyDeviceToDevice, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(st->u, u, 64, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  if (e != hipSuccess) { (void)hipFree(st->block); delete st; return fail(ctx, BPMI_E_HIP, std::string("ipa_create copy: ") + hipGetErrorString(e)); }
+  *out = st;
+  return BPMI_OK;
+}
+int bpmi_ipa_create(bpmi_ctx *ctx, const uint8_t *g, const uint8_t *h, const uint8_t *a, const uint8_t *b, uint64_t n,
+                    const uint8_t u[64], bpmi_ipa **out) {
+  if (!ctx || !g || !h || !a || !b || !u || !out) return ctx ? fail(ctx, BPMI_E_ARG, "null argument") : BPMI_E_ARG;
+  if (!is_pow2(n) || n > BPMI_MAX_N) return fail(ctx, BPMI_E_ARG, "n must be a power of two <= BPMI_MAX_N");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  bpmi_ipa *st = nullptr;
+  int rc = ipa_alloc(ctx, n, &st);
+  if (rc) return rc;
+  hipStream_t s = ctx->stream;
+  hipError_t e = hipMemcpyAsync(st->g, g, 64 * n, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(st->h, h, 64 * n, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(st->a, a, 32 * n, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(st->b, b, 32 * n, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(st->u, u, 64, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  if (e != hipSuccess) { (void)hipFree(st->block); delete st; return fail(ctx, BPMI_E_HIP, std::string("ipa_create copy: ") + hipGetErrorString(e)); }
+  *out = st;
+  return BPMI_OK;
+}
+uint64_t bpmi_ipa_len(const bpmi_ipa *st) { return st ? st->n : 0; }
+
+int bpmi_ipa_round_LR(bpmi_ipa *st, uint8_t L[64], uint8_t R[64]) {
+  if (!st || !L || !R) return BPMI_E_ARG;
+  bpmi_ctx *ctx = st->ctx;
+  if (st->n < 2) return fail(ctx, BPMI_E_STATE, "ipa already reduced to length 1");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const uint64_t np = st->n / 2;
+  u32 *g_lo = st->g, *g_hi = st->g + 16 * np, *h_lo = st->h, *h_hi = st->h + 16 * np;
+  u32 *a_lo = st->a, *a_hi = st->a + 8 * np, *b_lo = st->b, *b_hi = st->b + 8 * np;
+  // cl = <a_lo, b_hi>, cr = <a_hi, b_lo>  (inner_product_prover.py:96-97), kept on the device
+  sc_dot_dev_to(ctx, a_lo, b_hi, np, st->cl, st->partial);
+  sc_dot_dev_to(ctx, a_hi, b_lo, np, st->cr, st->partial);
+  // L = <a_lo, g_hi> + <b_hi, h_lo> + cl*u  (:98) as ONE three-segment MSM
+  Segs sL = {};
+  sL.pts[0] = g_hi; sL.sc[0] = a_lo; sL.n[0] = (u32)np;
+  sL.pts[1] = h_lo; sL.sc[1] = b_hi; sL.n[1] = (u32)np;
+  sL.pts[2] = st->u; sL.sc[2] = st->cl; sL.n[2] = 1;
+  sL.total = (u32)(2 * np + 1);
+  int rc = msm_run(ctx, sL, L);
+  if (rc) return rc;
+  // R = <a_hi, g_lo> + <b_lo, h_hi> + cr*u  (:99)
+  Segs sR = {};
+  sR.pts[0] = g_lo; sR.sc[0] = a_hi; sR.n[0] = (u32)np;
+  sR.pts[1] = h_hi; sR.sc[1] = b_lo; sR.n[1] = (u32)np;
+  sR.pts[2] = st->u; sR.sc[2] = st->cr; sR.n[2] = 1;
+  sR.total = (u32)(2 * np + 1);
+  rc = msm_run(ctx, sR, R);
+  if (rc) return rc;
+  st->lr_done = true;
+  return BPMI_OK;
+}
+
+int bpmi_ipa_fold(bpmi_ipa *st, const uint8_t x[32], const uint8_t xinv[32]) {
+  if (!st || !x || !xinv) return BPMI_E_ARG;
+  bpmi_ctx *ctx = st->ctx;
+  if (st->n < 2) return fail(ctx, BPMI_E_STATE, "ipa already reduced to length 1");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const uint64_t np = st->n / 2;
+  int rc;
+  // g' = x^-1 g_lo + x g_hi ; h' = x h_lo + x^-1 h_hi  (:107-108); in place: thread i
+  // reads elements i and np+i and writes element i only
+  rc = bpmi_ec_lincomb2_batch_dev(ctx, st->g, st->g + 16 * np, xinv, x, np, st->g);
+  if (rc) return rc;
+  rc = bpmi_ec_lincomb2_batch_dev(ctx, st->h, st->h + 16 * np, x, xinv, np, st->h);
+  if (rc) return rc;
+  // a' = x a_lo + x^-1 a_hi ; b' = x^-1 b_lo + x b_hi  (:109-110)
+  rc = bpmi_sc_fold_dev(ctx, st->a, st->a + 8 * np, x, xinv, np, st->a);
+  if (rc) return rc;
+  rc = bpmi_sc_fold_dev(ctx, st->b, st->b + 8 * np, xinv, x, np, st->b);
+  if (rc) return rc;
+  st->n = np;
+  st->lr_done = false;
+  return BPMI_OK;
+}
+
+int bpmi_ipa_finish(bpmi_ipa *st, uint8_t a[32], uint8_t b[32]) {
+  if (!st || !a || !b) return BPMI_E_ARG;
+  bpmi_ctx *ctx = st->ctx;
+  if (st->n != 1) return fail(ctx, BPMI_E_STATE, "ipa not yet reduced to length 1");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipMemcpyAsync(a, st->a, 32, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(b, st->b, 32, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return BPMI_OK;
+}
+
+void bpmi_ipa_destroy(bpmi_ipa *st) {
+  if (!st) return;
+  (void)hipSetDevice(st->ctx->device);
+  (void)hipStreamSynchronize(st->ctx->stream);
+  (void)hipFree(st->block);
+  delete st;
+}
+
+// ---- profiling -----------------------------------------------------------------------------------
+static void prof_drain(bpmi_ctx *ctx) {
+  (void)hipStreamSynchronize(ctx->stream);
+  for (auto &e : ctx->evs) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) { ctx->prof_ms[e.stage] += ms; ctx->prof_calls[e.stage]++; }
+    (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b);
+  }
+  ctx->evs.clear();
+}
+int bpmi_profile(bpmi_ctx *ctx, int enable) {
+  if (!ctx) return BPMI_E_ARG;
+  prof_drain(ctx);
+  ctx->prof = enable != 0;
+  return BPMI_OK;
+}
+int bpmi_profile_reset(bpmi_ctx *ctx) {
+  if (!ctx) return BPMI_E_ARG;
+  prof_drain(ctx);
+  for (int i = 0; i < BPMI_NSTAGES; i++) { ctx->prof_ms[i] = 0; ctx->prof_calls[i] = 0; }
+  return BPMI_OK;
+}
+int bpmi_profile_read(bpmi_ctx *ctx, double ms[BPMI_NSTAGES], uint64_t calls[BPMI_NSTAGES]) {
+  if (!ctx || !ms || !calls) return BPMI_E_ARG;
+  prof_drain(ctx);
+  for (int i = 0; i < BPMI_NSTAGES; i++) { ms[i] = ctx->prof_ms[i]; calls[i] = ctx->prof_calls[i]; }
+  return BPMI_OK;
+}
+const char *bpmi_profile_stage_name(int stage) {
+  if (stage < 0 || stage >= BPMI_NSTAGES) return "";
+  return STAGE_NAMES[stage];
+}
+
+}  // extern "C"

@@ -1,0 +1,185 @@
+// curve.hpp -- secp256k1 group law (y^2 = x^3 + 7) for the MSM / IPA kernels.
+// Replaces fastecdsa's `Point.__add__` / `Point.__rmul__` as used by the reference
+// (/root/reference/src/pippenger/group.py:31-32, src/utils/utils.py:43-44).
+//
+// Working form is XYZZ ("extended Jacobian": x = X/ZZ, y = Y/ZZZ, ZZ^3 = ZZZ^2),
+// which makes the bucket update acc += affine cost 8M + 2S with no inversion.
+// The identity is ZZ == 0.  All formulas are COMPLETE: acc = identity, P + P and
+// P + (-P) are detected and handled, because real Bulletproofs inputs hit them
+// (duplicate generators, scalars in {0, 1, q-1}; SURVEY.md section 7 "hard parts").
+// Results are only ever compared / exported after to_affine + fe_canon, so the
+// (non-unique) projective representative never leaks.
+#pragma once
+#include "field.hpp"
+
+namespace bpmi {
+
+struct affine { fe x, y; };              // tight limbs; identity = (0, 0)
+struct xyzz { fe X, Y, ZZ, ZZZ; };       // tight limbs; identity = ZZ == 0
+
+BPMI_HD void xyzz_set_inf(xyzz &r) {
+  fe_set_zero(r.X); fe_set_zero(r.Y); fe_set_zero(r.ZZ); fe_set_zero(r.ZZZ);
+}
+BPMI_HD bool xyzz_is_inf(const xyzz &a) { return fe_is_zero_tight(a.ZZ); }
+BPMI_HD bool affine_is_inf(const affine &a) {
+  u32 z = 0;
+#pragma unroll
+  for (int k = 0; k < 9; k++) z |= a.x.v[k] | a.y.v[k];
+  return z == 0;
+}
+BPMI_HD void xyzz_from_affine(xyzz &r, const affine &a) {
+  if (affine_is_inf(a)) { xyzz_set_inf(r); return; }
+  r.X = a.x; r.Y = a.y; fe_set_one(r.ZZ); fe_set_one(r.ZZZ);
+}
+
+// 64-byte wire form (x || y, 32-byte little-endian each = 16 u32 words) <-> affine
+BPMI_HD void affine_from_words(affine &r, const u32 w[16]) {
+  fe_from_words(r.x, w);
+  fe_from_words(r.y, w + 8);
+}
+BPMI_HD void affine_to_words(u32 w[16], const affine &a) {
+  fe cx, cy;
+  fe_canon(cx, a.x); fe_canon(cy, a.y);
+  fe_to_words(w, cx); fe_to_words(w + 8, cy);
+}
+BPMI_HD void affine_neg(affine &r, const affine &a) {
+  r.x = a.x;
+  if (affine_is_inf(a)) { r.y = a.y; return; }
+  fe t; fe_neg(t, a.y); fe_carry(r.y, t);
+}
+
+// r = 2 * (x, y) for an affine point (mdbl-2008-s-1): 2M + 3S... here 3M + 3S with Y3's products
+BPMI_HD void xyzz_dbl_affine(xyzz &r, const fe &x, const fe &y) {
+  fe U, V, W, S, M, t, t2;
+  fe_add(U, y, y);                       // mag 2
+  fe_sqr(V, U);                          // V = 4y^2
+  fe_mul(W, U, V);                       // W = 8y^3
+  fe_mul(S, x, V);
+  fe_sqr(t, x); fe_mul_small(M, t, 3);   // M = 3x^2, mag 3
+  fe_carry(M, M);
+  fe_sqr(t, M);                          // M^2
+  fe_sub(t, t, S); fe_sub(t, t, S);      // mag 5
+  fe_carry(r.X, t);
+  fe_sub(t, S, r.X);                     // mag 3
+  fe_mul(t, M, t);
+  fe_mul(t2, W, y);
+  fe_sub(t, t, t2); fe_carry(r.Y, t);
+  r.ZZ = V; r.ZZZ = W;
+}
+
+// r = 2 * a (dbl-2008-s-1, a = 0): 6M + 3S.  2-torsion does not exist on
+// secp256k1 (prime order), so Y == 0 only for the identity.
+BPMI_HD void xyzz_dbl(xyzz &r, const xyzz &a) {
+  if (xyzz_is_inf(a)) { xyzz_set_inf(r); return; }
+  fe U, V, W, S, M, t, t2, X3;
+  fe_add(U, a.Y, a.Y);
+  fe_sqr(V, U);
+  fe_mul(W, U, V);
+  fe_mul(S, a.X, V);
+  fe_sqr(t, a.X); fe_mul_small(M, t, 3); fe_carry(M, M);
+  fe_sqr(t, M);
+  fe_sub(t, t, S); fe_sub(t, t, S);
+  fe_carry(X3, t);
+  fe_sub(t, S, X3);
+  fe_mul(t, M, t);
+  fe_mul(t2, W, a.Y);
+  fe_sub(t, t, t2);
+  fe_mul(r.ZZ, V, a.ZZ);
+  fe_mul(r.ZZZ, W, a.ZZZ);
+  fe_carry(r.Y, t);
+  r.X = X3;
+}
+
+// acc += (x2, y2), affine addend that is NOT the identity (madd-2008-s): 8M + 2S
+BPMI_HD void xyzz_madd(xyzz &acc, const fe &x2, const fe &y2) {
+  if (xyzz_is_inf(acc)) { acc.X = x2; acc.Y = y2; fe_set_one(acc.ZZ); fe_set_one(acc.ZZZ); return; }
+  fe U2, S2, P, R, PP, PPP, Q, t, t2;
+  fe_mul(U2, x2, acc.ZZ);
+  fe_mul(S2, y2, acc.ZZZ);
+  fe_sub(P, U2, acc.X); fe_carry(P, P);
+  fe_sub(R, S2, acc.Y); fe_carry(R, R);
+  if (fe_is_zero_tight(P)) {
+    if (fe_is_zero_tight(R)) { xyzz_dbl_affine(acc, x2, y2); return; }   // acc == addend
+    xyzz_set_inf(acc); return;                                             // acc == -addend
+  }
+  fe_sqr(PP, P);
+  fe_mul(PPP, P, PP);
+  fe_mul(Q, acc.X, PP);
+  fe_sqr(t, R);
+  fe_sub(t, t, PPP); fe_sub(t, t, Q); fe_sub(t, t, Q);   // mag 7
+  fe_carry(acc.X, t);
+  fe_sub(t, Q, acc.X);                                    // mag 3
+  fe_mul(t, R, t);
+  fe_mul(t2, acc.Y, PPP);
+  fe_sub(t, t, t2); fe_carry(acc.Y, t);
+  fe_mul(acc.ZZ, acc.ZZ, PP);
+  fe_mul(acc.ZZZ, acc.ZZZ, PPP);
+}
+// acc += P for an affine point that may be the identity, optionally negated
+BPMI_HD void xyzz_madd_signed(xyzz &acc, const affine &P, bool negate) {
+  if (affine_is_inf(P)) return;
+  if (negate) { fe ny, t; fe_neg(t, P.y); fe_carry(ny, t); xyzz_madd(acc, P.x, ny); }
+  else xyzz_madd(acc, P.x, P.y);
+}
+
+// r = a + b, both XYZZ (add-2008-s): 12M + 2S
+BPMI_HD void xyzz_add(xyzz &r, const xyzz &a, const xyzz &b) {
+  if (xyzz_is_inf(a)) { r = b; return; }
+  if (xyzz_is_inf(b)) { r = a; return; }
+  fe U1, U2, S1, S2, P, R, PP, PPP, Q, t, t2, X3;
+  fe_mul(U1, a.X, b.ZZ);
+  fe_mul(U2, b.X, a.ZZ);
+  fe_mul(S1, a.Y, b.ZZZ);
+  fe_mul(S2, b.Y, a.ZZZ);
+  fe_sub(P, U2, U1); fe_carry(P, P);
+  fe_sub(R, S2, S1); fe_carry(R, R);
+  if (fe_is_zero_tight(P)) {
+    if (fe_is_zero_tight(R)) { xyzz_dbl(r, a); return; }
+    xyzz_set_inf(r); return;
+  }
+  fe_sqr(PP, P);
+  fe_mul(PPP, P, PP);
+  fe_mul(Q, U1, PP);
+  fe_sqr(t, R);
+  fe_sub(t, t, PPP); fe_sub(t, t, Q); fe_sub(t, t, Q);
+  fe_carry(X3, t);
+  fe_sub(t, Q, X3);
+  fe_mul(t, R, t);
+  fe_mul(t2, S1, PPP);
+  fe_sub(t, t, t2);
+  fe_mul(t2, a.ZZ, b.ZZ); fe_mul(r.ZZ, t2, PP);
+  fe_mul(t2, a.ZZZ, b.ZZZ); fe_mul(r.ZZZ, t2, PPP);
+  fe_carry(r.Y, t);
+  r.X = X3;
+}
+
+BPMI_HD void xyzz_neg(xyzz &r, const xyzz &a) {
+  r = a;
+  if (xyzz_is_inf(a)) return;
+  fe t; fe_neg(t, a.Y); fe_carry(r.Y, t);
+}
+
+// canonical affine form (one field inversion); identity -> (0, 0)
+BPMI_HD void xyzz_to_affine(affine &r, const xyzz &a) {
+  if (xyzz_is_inf(a)) { fe_set_zero(r.x); fe_set_zero(r.y); return; }
+  fe zz_zzz, inv, izz, izzz;
+  fe_mul(zz_zzz, a.ZZ, a.ZZZ);
+  fe_inv(inv, zz_zzz);
+  fe_mul(izz, inv, a.ZZZ);               // 1/ZZ
+  fe_mul(izzz, inv, a.ZZ);               // 1/ZZZ
+  fe_mul(r.x, a.X, izz);
+  fe_mul(r.y, a.Y, izzz);
+  fe_canon(r.x, r.x); fe_canon(r.y, r.y);
+}
+
+// XYZZ record in memory: 4 x 9 u32 (144 B), limb form as is
+BPMI_HD void xyzz_store(u32 *dst, const xyzz &a) {
+#pragma unroll
+  for (int k = 0; k < 9; k++) { dst[k] = a.X.v[k]; dst[9 + k] = a.Y.v[k]; dst[18 + k] = a.ZZ.v[k]; dst[27 + k] = a.ZZZ.v[k]; }
+}
+BPMI_HD void xyzz_load(xyzz &a, const u32 *src) {
+#pragma unroll
+  for (int k = 0; k < 9; k++) { a.X.v[k] = src[k]; a.Y.v[k] = src[9 + k]; a.ZZ.v[k] = src[18 + k]; a.ZZZ.v[k] = src[27 + k]; }
+}
+
+}  // namespace bpmi

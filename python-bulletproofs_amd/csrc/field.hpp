@@ -1,0 +1,236 @@
+// field.hpp -- arithmetic in F_p, p = 2^256 - 2^32 - 977 (secp256k1 base field),
+// for gfx950.  Replaces what the reference reaches through fastecdsa/GMP on every
+// `Point + Point` (/root/reference/src/pippenger/group.py:31-32).
+//
+// Representation: 9 limbs of 29 bits in u32 (value = sum v[k] * 2^(29k)).
+// Why not 8x32: on gfx950 v_mad_u64_u32 adds a full 64-bit value for free but has
+// no carry-in, and a carry through VCC costs wait states (profiles/r01_fe_microbench.txt:
+// 9x29 carry-free 171 G mul/s vs 8x32 137-165 G).  With 29-bit limbs nine products
+// (< 2^58 each) accumulate in one u64 column with no carry handling at all.
+//
+// Magnitudes.  A value has magnitude m when every limb is < m * 2^29.
+//   tight  = magnitude 1, limb 8 <= 2^24 + 2^20        (output of mul/sqr/carry)
+//   fe_add / fe_sub are LAZY (no carry): magnitudes add; fe_sub adds 2 (a bias of 2p)
+//   fe_mul / fe_sqr need  mag(a) * mag(b) <= 7   (9 * 7 * 2^58 < 2^64)
+// Values are kept only weakly reduced (any representative < 2^257); fe_canon gives
+// the unique representative in [0, p) for comparison and output.
+//
+// Everything here is plain C++ so the same header is unit-tested on the host
+// (tests/csrc_host) before it ever runs on a GPU.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define BPMI_HD __host__ __device__ __forceinline__
+#else
+#define BPMI_HD inline
+#endif
+
+namespace bpmi {
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+struct fe { u32 v[9]; };
+
+constexpr u32 M29 = 0x1FFFFFFFu;
+constexpr u32 M24 = 0x00FFFFFFu;
+
+#define BPMI_FE_P     {0x1FFFFC2Fu, 0x1FFFFFF7u, 0x1FFFFFFFu, 0x1FFFFFFFu, 0x1FFFFFFFu, 0x1FFFFFFFu, 0x1FFFFFFFu, 0x1FFFFFFFu, 0x00FFFFFFu}
+#define BPMI_FE_2P    {0x1FFFF85Eu, 0x1FFFFFEFu, 0x1FFFFFFFu, 0x1FFFFFFFu, 0x1FFFFFFFu, 0x1FFFFFFFu, 0x1FFFFFFFu, 0x1FFFFFFFu, 0x01FFFFFFu}
+// 2p written with every limb >= the largest tight limb, so (a + BIAS2 - b) never borrows
+#define BPMI_FE_BIAS2 {0x3FFFF85Eu, 0x3FFFFFEEu, 0x3FFFFFFEu, 0x3FFFFFFEu, 0x3FFFFFFEu, 0x3FFFFFFEu, 0x3FFFFFFEu, 0x3FFFFFFEu, 0x01FFFFFEu}
+// 4p written so that a magnitude-2 value can be subtracted
+#define BPMI_FE_BIAS4 {0x5FFFF0BCu, 0x5FFFFFDDu, 0x5FFFFFFDu, 0x5FFFFFFDu, 0x5FFFFFFDu, 0x5FFFFFFDu, 0x5FFFFFFDu, 0x5FFFFFFDu, 0x03FFFFFDu}
+
+BPMI_HD void fe_set_zero(fe &r) {
+#pragma unroll
+  for (int k = 0; k < 9; k++) r.v[k] = 0;
+}
+BPMI_HD void fe_set_one(fe &r) { fe_set_zero(r); r.v[0] = 1; }
+
+// ---- 32-byte little-endian <-> limbs (the C-ABI layout: 8 x u32 LE words) ----
+BPMI_HD void fe_from_words(fe &r, const u32 w[8]) {
+#pragma unroll
+  for (int k = 0; k < 9; k++) {
+    const int bit = 29 * k, i = bit >> 5, s = bit & 31;
+    u64 x = w[i];
+    if (i + 1 < 8) x |= (u64)w[i + 1] << 32;
+    r.v[k] = (u32)(x >> s) & M29;
+  }
+}
+// a must be canonical (fe_canon) -- limbs < 2^29, value < 2^256
+BPMI_HD void fe_to_words(u32 w[8], const fe &a) {
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const int bit = 32 * i, k = bit / 29, s = bit - 29 * k;
+    u64 x = (u64)a.v[k] >> s;
+    x |= (u64)a.v[k + 1] << (29 - s);
+    if (k + 2 < 9) x |= (u64)a.v[k + 2] << (58 - s);
+    w[i] = (u32)x;
+  }
+}
+
+// ---- lazy add / sub ----------------------------------------------------------
+BPMI_HD void fe_add(fe &r, const fe &a, const fe &b) {
+#pragma unroll
+  for (int k = 0; k < 9; k++) r.v[k] = a.v[k] + b.v[k];
+}
+// r = a - b + 2p ; b must be tight; mag(r) = mag(a) + 2
+BPMI_HD void fe_sub(fe &r, const fe &a, const fe &b) {
+  const u32 bias[9] = BPMI_FE_BIAS2;
+#pragma unroll
+  for (int k = 0; k < 9; k++) r.v[k] = a.v[k] + bias[k] - b.v[k];
+}
+// r = a - b + 4p ; b of magnitude <= 2; mag(r) = mag(a) + 3
+BPMI_HD void fe_sub_m2(fe &r, const fe &a, const fe &b) {
+  const u32 bias[9] = BPMI_FE_BIAS4;
+#pragma unroll
+  for (int k = 0; k < 9; k++) r.v[k] = a.v[k] + bias[k] - b.v[k];
+}
+// r = 2p - a ; a tight; mag 2
+BPMI_HD void fe_neg(fe &r, const fe &a) {
+  const u32 bias[9] = BPMI_FE_BIAS2;
+#pragma unroll
+  for (int k = 0; k < 9; k++) r.v[k] = bias[k] - a.v[k];
+}
+
+// ---- carry: any limbs (< 2^32) -> tight -----------------------------------------
+BPMI_HD void fe_carry(fe &r, const fe &a) {
+  const u32 h = a.v[8] >> 24;                      // units of 2^256 == 2^32 + 977
+  u64 c = (u64)a.v[0] + (u64)h * 977u;
+  r.v[0] = (u32)c & M29; c >>= 29;
+  c += (u64)a.v[1] + ((u64)h << 3);                // 2^32 = 2^29 * 8
+  r.v[1] = (u32)c & M29; c >>= 29;
+#pragma unroll
+  for (int k = 2; k < 8; k++) { c += a.v[k]; r.v[k] = (u32)c & M29; c >>= 29; }
+  r.v[8] = (a.v[8] & M24) + (u32)c;
+}
+
+// ---- product columns -> tight result ------------------------------------------------
+BPMI_HD void fe_fold_columns(fe &r, const u64 acc[17]) {
+  u32 t[18];
+  u64 c = 0;
+#pragma unroll
+  for (int k = 0; k < 17; k++) { c += acc[k]; t[k] = (u32)c & M29; c >>= 29; }
+  t[17] = (u32)c;
+  // 2^261 == 2^37 + 31264 (mod p): limb 9+k folds into limb k (x31264) and k+1 (x256)
+  u64 u[10];
+#pragma unroll
+  for (int k = 0; k < 9; k++) u[k] = (u64)t[9 + k] * 31264u + t[k];
+#pragma unroll
+  for (int k = 1; k < 9; k++) u[k] += (u64)t[8 + k] << 8;
+  u[9] = (u64)t[17] << 8;
+  // everything at or above 2^256 (limb 8 bit 24) folds once more: 2^256 == 2^32 + 977
+  const u64 H = (u[8] >> 24) + (u[9] << 5);
+  u[8] &= M24;
+  u[0] += H * 977u;
+  u[1] += H << 3;
+  c = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) { c += u[k]; r.v[k] = (u32)c & M29; c >>= 29; }
+  r.v[8] = (u32)(c + u[8]);
+}
+
+BPMI_HD void fe_mul(fe &r, const fe &a, const fe &b) {
+  u64 acc[17];
+#pragma unroll
+  for (int k = 0; k < 17; k++) {
+    u64 s = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      const int j = k - i;
+      if (j < 0 || j > 8) continue;
+      s += (u64)a.v[i] * b.v[j];
+    }
+    acc[k] = s;
+  }
+  fe_fold_columns(r, acc);
+}
+
+// a of magnitude <= 2 (doubled limbs must fit 32 bits and 9 * 2 * m^2 * 2^58 < 2^64)
+BPMI_HD void fe_sqr(fe &r, const fe &a) {
+  u32 d[9];
+#pragma unroll
+  for (int i = 0; i < 9; i++) d[i] = a.v[i] << 1;
+  u64 acc[17];
+#pragma unroll
+  for (int k = 0; k < 17; k++) {
+    u64 s = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      const int j = k - i;
+      if (j < 0 || j > 8 || i > j) continue;
+      s += (i == j) ? (u64)a.v[i] * a.v[j] : (u64)d[i] * a.v[j];
+    }
+    acc[k] = s;
+  }
+  fe_fold_columns(r, acc);
+}
+
+// r = a * k for a small constant (k * mag(a) must stay < 8), lazy
+BPMI_HD void fe_mul_small(fe &r, const fe &a, u32 k) {
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.v[i] = a.v[i] * k;
+}
+
+// ---- canonical form in [0, p) ----------------------------------------------------
+BPMI_HD void fe_canon(fe &r, const fe &a) {
+  fe t;
+  fe_carry(t, a);
+  fe_carry(t, t);                                   // now value < 2^256 + tiny, tight
+  // t >= p  <=>  t + (2^32 + 977) >= 2^256
+  u32 s[9];
+  u64 c = (u64)t.v[0] + 977u; s[0] = (u32)c & M29; c >>= 29;
+  c += (u64)t.v[1] + 8u;      s[1] = (u32)c & M29; c >>= 29;
+#pragma unroll
+  for (int k = 2; k < 8; k++) { c += t.v[k]; s[k] = (u32)c & M29; c >>= 29; }
+  c += t.v[8]; s[8] = (u32)c;
+  const bool ge = (s[8] >> 24) != 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) r.v[k] = ge ? s[k] : t.v[k];
+  r.v[8] = ge ? (s[8] & M24) : t.v[8];
+}
+
+// a tight: is it == 0 (mod p)?  The tight representatives of 0 below 2^257 are 0, p, 2p.
+BPMI_HD bool fe_is_zero_tight(const fe &a) {
+  const u32 P1[9] = BPMI_FE_P, P2[9] = BPMI_FE_2P;
+  u32 z = 0, d1 = 0, d2 = 0;
+#pragma unroll
+  for (int k = 0; k < 9; k++) { z |= a.v[k]; d1 |= a.v[k] ^ P1[k]; d2 |= a.v[k] ^ P2[k]; }
+  return (z == 0) | (d1 == 0) | (d2 == 0);
+}
+BPMI_HD bool fe_is_zero(const fe &a) {
+  fe t;
+  fe_carry(t, a);
+  return fe_is_zero_tight(t);
+}
+BPMI_HD bool fe_equal(const fe &a, const fe &b) {   // both tight
+  fe d;
+  fe_sub(d, a, b);
+  return fe_is_zero(d);
+}
+
+// r = a^(p-2): 255 squarings + 15 multiplications (addition chain on the run
+// structure of p - 2 = 2^256 - 2^32 - 979: blocks of 223, 22, 1, 1 ones ...)
+BPMI_HD void fe_inv(fe &r, const fe &a) {
+  fe x2, x3, x6, x9, x11, x22, x44, x88, x176, x220, x223, t1;
+  fe_sqr(x2, a); fe_mul(x2, x2, a);
+  fe_sqr(x3, x2); fe_mul(x3, x3, a);
+  x6 = x3; for (int j = 0; j < 3; j++) fe_sqr(x6, x6); fe_mul(x6, x6, x3);
+  x9 = x6; for (int j = 0; j < 3; j++) fe_sqr(x9, x9); fe_mul(x9, x9, x3);
+  x11 = x9; for (int j = 0; j < 2; j++) fe_sqr(x11, x11); fe_mul(x11, x11, x2);
+  x22 = x11; for (int j = 0; j < 11; j++) fe_sqr(x22, x22); fe_mul(x22, x22, x11);
+  x44 = x22; for (int j = 0; j < 22; j++) fe_sqr(x44, x44); fe_mul(x44, x44, x22);
+  x88 = x44; for (int j = 0; j < 44; j++) fe_sqr(x88, x88); fe_mul(x88, x88, x44);
+  x176 = x88; for (int j = 0; j < 88; j++) fe_sqr(x176, x176); fe_mul(x176, x176, x88);
+  x220 = x176; for (int j = 0; j < 44; j++) fe_sqr(x220, x220); fe_mul(x220, x220, x44);
+  x223 = x220; for (int j = 0; j < 3; j++) fe_sqr(x223, x223); fe_mul(x223, x223, x3);
+  // p - 2 = 1^223 0 1^22 0000 101101
+  t1 = x223; for (int j = 0; j < 23; j++) fe_sqr(t1, t1); fe_mul(t1, t1, x22);
+  for (int j = 0; j < 5; j++) fe_sqr(t1, t1); fe_mul(t1, t1, a);
+  for (int j = 0; j < 3; j++) fe_sqr(t1, t1); fe_mul(t1, t1, x2);
+  for (int j = 0; j < 2; j++) fe_sqr(t1, t1); fe_mul(r, t1, a);
+}
+
+}  // namespace bpmi

@@ -1,0 +1,117 @@
+// scalar.hpp -- arithmetic mod q (the secp256k1 group order) on 8 x u32 words,
+// canonical values in [0, q).  Replaces the reference's `ModP` arithmetic where
+// it runs in bulk inside the IPA loop (/root/reference/src/utils/utils.py:24-81,
+// inner_product :134-137, the a/b fold src/innerproduct/inner_product_prover.py:109-110).
+// Plain C++ (host + device); this is O(n) work next to the O(n) EC work, so it is
+// written for clarity, not for the last cycle.
+#pragma once
+#include "field.hpp"
+
+namespace bpmi {
+
+struct sc { u32 v[8]; };
+
+#define BPMI_SC_Q  {0xD0364141u, 0xBFD25E8Cu, 0xAF48A03Bu, 0xBAAEDCE6u, 0xFFFFFFFEu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}
+// 2^256 - q (129 bits)
+#define BPMI_SC_C  {0x2FC9BEBFu, 0x402DA173u, 0x50B75FC4u, 0x45512319u, 0x00000001u}
+// (q - 1) / 2
+#define BPMI_SC_HALF {0x681B20A0u, 0xDFE92F46u, 0x57A4501Du, 0x5D576E73u, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0x7FFFFFFFu}
+
+BPMI_HD bool sc_is_zero(const sc &a) {
+  u32 z = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) z |= a.v[i];
+  return z == 0;
+}
+// a > b ?
+BPMI_HD bool words_gt(const u32 a[8], const u32 b[8]) {
+  bool gt = false, decided = false;
+#pragma unroll
+  for (int i = 7; i >= 0; i--) {
+    if (!decided && a[i] != b[i]) { gt = a[i] > b[i]; decided = true; }
+  }
+  return gt;
+}
+BPMI_HD bool sc_is_high(const sc &a) {   // a > (q-1)/2
+  const u32 half[8] = BPMI_SC_HALF;
+  return words_gt(a.v, half);
+}
+// r = a - b over 2^256, returns borrow
+BPMI_HD u32 words_sub(u32 r[8], const u32 a[8], const u32 b[8]) {
+  u64 br = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    u64 t = (u64)a[i] - b[i] - br;
+    r[i] = (u32)t;
+    br = (t >> 32) & 1;
+  }
+  return (u32)br;
+}
+BPMI_HD void sc_neg(sc &r, const sc &a) {   // q - a (a != 0)
+  const u32 q[8] = BPMI_SC_Q;
+  if (sc_is_zero(a)) { r = a; return; }
+  words_sub(r.v, q, a.v);
+}
+BPMI_HD void sc_cond_sub_q(u32 t[9]) {
+  const u32 q[8] = BPMI_SC_Q;
+  u32 s[8];
+  const u32 br = words_sub(s, t, q);
+  // t >= q  <=>  t[8] != 0 or no borrow
+  const bool ge = (t[8] != 0) | (br == 0);
+  if (ge) {
+    t[8] -= br;
+#pragma unroll
+    for (int i = 0; i < 8; i++) t[i] = s[i];
+  }
+}
+BPMI_HD void sc_add(sc &r, const sc &a, const sc &b) {
+  u32 t[9];
+  u64 c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) { c += (u64)a.v[i] + b.v[i]; t[i] = (u32)c; c >>= 32; }
+  t[8] = (u32)c;
+  sc_cond_sub_q(t);
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = t[i];
+}
+// out[0..NO) = lo[0..8) + hi[0..NH) * C   (NO >= max(8, NH + 5) + 1)
+template <int NH, int NO>
+BPMI_HD void sc_fold_once(u32 out[NO], const u32 lo[8], const u32 hi[NH]) {
+  const u32 C[5] = BPMI_SC_C;
+#pragma unroll
+  for (int i = 0; i < NO; i++) out[i] = i < 8 ? lo[i] : 0;
+#pragma unroll
+  for (int i = 0; i < NH; i++) {
+    u64 c = 0;
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+      c += (u64)hi[i] * C[j] + out[i + j];
+      out[i + j] = (u32)c;
+      c >>= 32;
+    }
+#pragma unroll
+    for (int k = i + 5; k < NO; k++) { c += out[k]; out[k] = (u32)c; c >>= 32; }
+  }
+}
+BPMI_HD void sc_mul(sc &r, const sc &a, const sc &b) {
+  u32 t[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) t[i] = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    u64 c = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) { c += (u64)a.v[i] * b.v[j] + t[i + j]; t[i + j] = (u32)c; c >>= 32; }
+    t[i + 8] = (u32)c;
+  }
+  u32 f1[14], f2[11], f3[9];
+  sc_fold_once<8, 14>(f1, t, t + 8);        // < 2^386
+  sc_fold_once<6, 11>(f2, f1, f1 + 8);      // hi <= 130 bits -> < 2^260
+  sc_fold_once<1, 9>(f3, f2, f2 + 8);       // hi <= 4 bits   -> < 2^256 + 2^134
+  sc_cond_sub_q(f3);
+  sc_cond_sub_q(f3);
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = f3[i];
+}
+
+}  // namespace bpmi

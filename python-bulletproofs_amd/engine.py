@@ -1,0 +1,219 @@
+"""Engine: one bpmi_ctx (one GPU, one stream) plus byte-level helpers.
+
+This is the only module that talks to libbpmi.so.  Everything above it (the
+reference-shaped Python call surface in pippenger/, utils/, innerproduct/,
+rangeproofs/) goes through an Engine; nothing here or above computes EC or bulk
+scalar arithmetic on the CPU.
+"""
+import ctypes
+import os
+import threading
+
+from . import _native
+
+Q = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141
+P_FIELD = 2**256 - 2**32 - 977
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+class DeviceBuffer:
+    """hipMalloc'd bytes owned by an Engine."""
+
+    def __init__(self, engine, nbytes):
+        self.engine = engine
+        self.nbytes = nbytes
+        p = ctypes.c_void_p()
+        engine._ck(engine.lib.bpmi_malloc(engine.ctx, nbytes, ctypes.byref(p)))
+        self.ptr = p.value
+
+    def upload(self, data, offset=0):
+        assert offset + len(data) <= self.nbytes
+        self.engine._ck(self.engine.lib.bpmi_upload(self.engine.ctx, self.ptr + offset, bytes(data), len(data)))
+        return self
+
+    def download(self, nbytes=None, offset=0):
+        nbytes = self.nbytes - offset if nbytes is None else nbytes
+        out = ctypes.create_string_buffer(nbytes)
+        self.engine._ck(self.engine.lib.bpmi_download(self.engine.ctx, out, self.ptr + offset, nbytes))
+        return out.raw
+
+    def free(self):
+        if self.ptr:
+            self.engine.lib.bpmi_free(self.engine.ctx, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Engine:
+    def __init__(self, device=None, stream=None):
+        self.lib = _native.load()
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0")) if self.lib.bpmi_device_count() > 1 else 0
+        self.device = device
+        self.ctx = self.lib.bpmi_ctx_create(device, stream)
+        if not self.ctx:
+            raise EngineError("bpmi_ctx_create failed: %s" % self.lib.bpmi_last_error(None).decode())
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.bpmi_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise EngineError("libbpmi error %d: %s" % (rc, self.lib.bpmi_last_error(self.ctx).decode()))
+
+    def set_option(self, name, value):
+        self._ck(self.lib.bpmi_set_option(self.ctx, name.encode(), int(value)))
+
+    def sync(self):
+        self._ck(self.lib.bpmi_sync(self.ctx))
+
+    def alloc(self, nbytes):
+        return DeviceBuffer(self, nbytes)
+
+    def upload(self, data):
+        return DeviceBuffer(self, max(len(data), 16)).upload(data)
+
+    # ---- byte-level operations (wire format of include/bpmi.h) ----
+    def msm_bytes(self, pts, scalars, n):
+        out = ctypes.create_string_buffer(64)
+        self._ck(self.lib.bpmi_msm(self.ctx, pts, scalars, n, out))
+        return out.raw
+
+    def msm_dev(self, d_pts, d_scalars, n):
+        out = ctypes.create_string_buffer(64)
+        self._ck(self.lib.bpmi_msm_dev(self.ctx, _ptr(d_pts), _ptr(d_scalars), n, out))
+        return out.raw
+
+    def ec_mul_batch_bytes(self, pts, scalars, n):
+        out = ctypes.create_string_buffer(64 * n)
+        self._ck(self.lib.bpmi_ec_mul_batch(self.ctx, pts, scalars, n, out))
+        return out.raw
+
+    def ec_lincomb2_batch_bytes(self, p1, p2, k1, k2, n):
+        out = ctypes.create_string_buffer(64 * n)
+        self._ck(self.lib.bpmi_ec_lincomb2_batch(self.ctx, p1, p2, k1, k2, n, out))
+        return out.raw
+
+    def ec_sum_bytes(self, pts, n):
+        out = ctypes.create_string_buffer(64)
+        self._ck(self.lib.bpmi_ec_sum(self.ctx, pts, n, out))
+        return out.raw
+
+    def sc_dot_bytes(self, a, b, n):
+        out = ctypes.create_string_buffer(32)
+        self._ck(self.lib.bpmi_sc_dot(self.ctx, a, b, n, out))
+        return out.raw
+
+    def sc_fold_bytes(self, lo, hi, x, y, n):
+        out = ctypes.create_string_buffer(32 * n)
+        self._ck(self.lib.bpmi_sc_fold(self.ctx, lo, hi, x, y, n, out))
+        return out.raw
+
+    # ---- IPA prover state ----
+    def ipa_create(self, g, h, a, b, n, u):
+        st = ctypes.c_void_p()
+        self._ck(self.lib.bpmi_ipa_create(self.ctx, g, h, a, b, n, u, ctypes.byref(st)))
+        return IpaState(self, st.value)
+
+    def ipa_create_dev(self, d_g, d_h, d_a, d_b, n, u):
+        st = ctypes.c_void_p()
+        self._ck(self.lib.bpmi_ipa_create_dev(self.ctx, _ptr(d_g), _ptr(d_h), _ptr(d_a), _ptr(d_b), n, u, ctypes.byref(st)))
+        return IpaState(self, st.value)
+
+    # ---- profiling ----
+    def profile(self, enable=True):
+        self._ck(self.lib.bpmi_profile(self.ctx, 1 if enable else 0))
+
+    def profile_reset(self):
+        self._ck(self.lib.bpmi_profile_reset(self.ctx))
+
+    def profile_read(self):
+        ms = (ctypes.c_double * _native.NSTAGES)()
+        calls = (ctypes.c_uint64 * _native.NSTAGES)()
+        self._ck(self.lib.bpmi_profile_read(self.ctx, ms, calls))
+        return {self.lib.bpmi_profile_stage_name(i).decode(): (ms[i], calls[i]) for i in range(_native.NSTAGES)}
+
+
+class IpaState:
+    """One FastNIProver2 run on the device, split at the Fiat-Shamir edge."""
+
+    def __init__(self, engine, handle):
+        self.engine = engine
+        self.handle = handle
+
+    def __len__(self):
+        return self.engine.lib.bpmi_ipa_len(self.handle)
+
+    def round_LR(self):
+        L = ctypes.create_string_buffer(64)
+        R = ctypes.create_string_buffer(64)
+        self.engine._ck(self.engine.lib.bpmi_ipa_round_LR(self.handle, L, R))
+        return L.raw, R.raw
+
+    def fold(self, x, xinv):
+        self.engine._ck(self.engine.lib.bpmi_ipa_fold(self.handle, sc_bytes(x), sc_bytes(xinv)))
+
+    def finish(self):
+        a = ctypes.create_string_buffer(32)
+        b = ctypes.create_string_buffer(32)
+        self.engine._ck(self.engine.lib.bpmi_ipa_finish(self.handle, a, b))
+        return int.from_bytes(a.raw, "little"), int.from_bytes(b.raw, "little")
+
+    def close(self):
+        if self.handle:
+            self.engine.lib.bpmi_ipa_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _ptr(x):
+    if isinstance(x, DeviceBuffer):
+        return x.ptr
+    if hasattr(x, "data_ptr"):  # torch tensor on the engine's device
+        return x.data_ptr()
+    return int(x)
+
+
+def sc_bytes(k):
+    return (int(k) % Q).to_bytes(32, "little")
+
+
+_default = None
+_default_lock = threading.Lock()
+
+
+def default_engine():
+    """Process-wide engine (like the reference's PipSECP256k1 singleton it is stateless
+    between calls).  Raises if libbpmi.so or the GPU is missing."""
+    global _default
+    with _default_lock:
+        if _default is None:
+            _default = Engine()
+        return _default
+
+
+def set_default_engine(engine):
+    global _default
+    with _default_lock:
+        _default = engine

@@ -1,0 +1,64 @@
+// Host-side build of the DEVICE arithmetic headers (csrc/field.hpp, csrc/curve.hpp),
+// for unit tests only: the headers are plain C++, so their limb arithmetic,
+// magnitude discipline and exceptional-case handling can be checked against
+// Python integers here, without a GPU.  Not part of the product library.
+#include <string.h>
+#include "field.hpp"
+#include "curve.hpp"
+using namespace bpmi;
+
+static void load_fe(fe &r, const uint8_t *b) { u32 w[8]; memcpy(w, b, 32); fe_from_words(r, w); }
+static void store_fe(uint8_t *b, const fe &a) { fe c; fe_canon(c, a); u32 w[8]; fe_to_words(w, c); memcpy(b, w, 32); }
+static void load_aff(affine &r, const uint8_t *b) { u32 w[16]; memcpy(w, b, 64); affine_from_words(r, w); }
+static void store_aff(uint8_t *b, const affine &a) { u32 w[16]; affine_to_words(w, a); memcpy(b, w, 64); }
+
+extern "C" {
+// op: 0 mul, 1 sqr(a), 2 add, 3 sub, 4 neg(a), 5 inv(a), 6 (a+b)*(a+b) lazy, 7 (a-b)*(b) lazy, 8 canon roundtrip
+void t_fe_op(int op, const uint8_t *a, const uint8_t *b, uint8_t *out) {
+  fe x, y, r, t;
+  load_fe(x, a); load_fe(y, b);
+  switch (op) {
+    case 0: fe_mul(r, x, y); break;
+    case 1: fe_sqr(r, x); break;
+    case 2: fe_add(r, x, y); break;
+    case 3: fe_sub(r, x, y); break;
+    case 4: fe_neg(r, x); break;
+    case 5: fe_inv(r, x); break;
+    case 6: fe_add(t, x, y); fe_sqr(r, t); break;
+    case 7: fe_sub(t, x, y); fe_mul(r, t, y); break;
+    case 8: r = x; break;
+    case 9: fe_sub(t, x, y); fe_sub(t, t, y); fe_sub(t, t, y); fe_carry(r, t); break;  // mag 7 carry
+    case 10: fe_add(t, x, y); fe_sub_m2(r, x, t); fe_carry(r, r); break;              // x - (x+y) = -y
+    default: fe_set_zero(r);
+  }
+  store_fe(out, r);
+}
+int t_fe_is_zero(const uint8_t *a, const uint8_t *b) {  // is a - b == 0 ?
+  fe x, y; load_fe(x, a); load_fe(y, b);
+  return fe_equal(x, y) ? 1 : 0;
+}
+// acc (affine, may be inf) += sum of n affine points (each optionally negated), via XYZZ madd
+void t_madd_chain(const uint8_t *start, const uint8_t *pts, const uint8_t *neg, int n, uint8_t *out) {
+  affine s; load_aff(s, start);
+  xyzz acc; xyzz_from_affine(acc, s);
+  for (int i = 0; i < n; i++) { affine p; load_aff(p, pts + 64 * i); xyzz_madd_signed(acc, p, neg[i] != 0); }
+  affine r; xyzz_to_affine(r, acc); store_aff(out, r);
+}
+// tree: sum n affine points by first converting to XYZZ (through a madd so ZZ != 1 when pre > 0) then xyzz_add
+void t_xyzz_sum(const uint8_t *pts, int n, int pre, uint8_t *out) {
+  xyzz acc; xyzz_set_inf(acc);
+  for (int i = 0; i < n; i++) {
+    affine p; load_aff(p, pts + 64 * i);
+    xyzz q; xyzz_from_affine(q, p);
+    for (int k = 0; k < pre; k++) { xyzz d; xyzz_dbl(d, q); xyzz nq; xyzz_neg(nq, q); xyzz_add(q, d, nq); }  // q = 2q - q, non-trivial Z
+    xyzz_add(acc, acc, q);
+  }
+  affine r; xyzz_to_affine(r, acc); store_aff(out, r);
+}
+void t_xyzz_dbl_n(const uint8_t *pt, int n, uint8_t *out) {
+  affine p; load_aff(p, pt);
+  xyzz q; xyzz_from_affine(q, p);
+  for (int k = 0; k < n; k++) xyzz_dbl(q, q);
+  affine r; xyzz_to_affine(r, q); store_aff(out, r);
+}
+}
