@@ -1,0 +1,117 @@
+"""Point / Curve: the surface of the third-party `fastecdsa` package that the reference
+uses (Point(x, y, curve), +, int *, ==, .x .y .curve, IDENTITY_ELEMENT; Curve.p .a .b .q
+.G .is_point_on_curve; mod_sqrt) -- call sites: /root/reference/src/pippenger/group.py:29-32,
+src/utils/utils.py:43-44,100-131, src/innerproduct/inner_product_verifier.py:145.
+
+Group operations are NOT computed here: `+` and `*` go to the HIP engine
+(bpmi_ec_sum / bpmi_ec_mul_batch).  Only representation-level work (equality, negation
+of y, the on-curve check of the constructor, byte packing) is done with Python ints.
+"""
+from . import engine as _engine
+
+
+class Curve:
+    def __init__(self, name, p, a, b, q, gx, gy):
+        self.name, self.p, self.a, self.b, self.q, self.gx, self.gy = name, p, a, b, q, gx, gy
+
+    @property
+    def G(self):
+        return Point(self.gx, self.gy, self)
+
+    def is_point_on_curve(self, xy):
+        x, y = xy
+        return (y * y - x * x * x - self.a * x - self.b) % self.p == 0
+
+    def __repr__(self):
+        return self.name
+
+
+secp256k1 = Curve(
+    "secp256k1",
+    p=2**256 - 2**32 - 977,
+    a=0,
+    b=7,
+    q=0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141,
+    gx=0x79BE667EF9DCBBAC55A06295CE870B07029BFCDB2DCE28D959F2815B16F81798,
+    gy=0x483ADA7726A3C4655DA4FBFC0E1108A8FD17B448A68554199C47D08FFB10D4B8,
+)
+
+
+class Point:
+    __slots__ = ("x", "y", "curve")
+    IDENTITY_ELEMENT = None
+
+    def __init__(self, x, y, curve=secp256k1):
+        if curve is None:
+            if x or y:
+                raise ValueError("identity must be (0, 0)")
+        elif not curve.is_point_on_curve((x, y)):
+            raise ValueError("coordinates are not on curve %s" % curve)
+        self.x, self.y, self.curve = x, y, curve
+
+    @classmethod
+    def _raw(cls, x, y):
+        pt = cls.__new__(cls)
+        pt.x, pt.y = x, y
+        pt.curve = secp256k1 if (x or y) else None
+        return pt
+
+    # -- representation-level ------------------------------------------------
+    def __eq__(self, other):
+        return isinstance(other, Point) and self.x == other.x and self.y == other.y
+
+    def __hash__(self):
+        return hash((self.x, self.y))
+
+    def __neg__(self):
+        if self.curve is None:
+            return self
+        return Point._raw(self.x, (-self.y) % self.curve.p)
+
+    def to_le64(self):
+        return self.x.to_bytes(32, "little") + self.y.to_bytes(32, "little")
+
+    @classmethod
+    def from_le64(cls, b):
+        return cls._raw(int.from_bytes(b[:32], "little"), int.from_bytes(b[32:64], "little"))
+
+    # -- group operations: on the GPU ----------------------------------------------
+    def __add__(self, other):
+        if not isinstance(other, Point):
+            return NotImplemented
+        eng = _engine.default_engine()
+        return Point.from_le64(eng.ec_sum_bytes(self.to_le64() + other.to_le64(), 2))
+
+    def __sub__(self, other):
+        return self + (-other)
+
+    def __mul__(self, k):
+        k = int(k) % secp256k1.q
+        eng = _engine.default_engine()
+        return Point.from_le64(eng.ec_mul_batch_bytes(self.to_le64(), k.to_bytes(32, "little"), 1))
+
+    __rmul__ = __mul__
+
+    def __repr__(self):
+        return "Point(inf)" if self.curve is None else "Point(0x%x, 0x%x)" % (self.x, self.y)
+
+
+Point.IDENTITY_ELEMENT = Point._raw(0, 0)
+
+
+def mod_sqrt(a, p):
+    """(r, p - r) for p = 3 (mod 4); used only by codecs / generator derivation."""
+    r = pow(a, (p + 1) // 4, p)
+    return (r, p - r)
+
+
+def pack_points(pts):
+    return b"".join(p.to_le64() for p in pts)
+
+
+def pack_scalars(es, q=secp256k1.q):
+    return b"".join((int(e % q)).to_bytes(32, "little") for e in es)
+
+
+def unpack_points(buf, n):
+    return [Point.from_le64(buf[64 * i: 64 * i + 64]) for i in range(n)]

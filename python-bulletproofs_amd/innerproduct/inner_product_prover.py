@@ -1,0 +1,69 @@
+"""Inner-product argument provers (reference: src/innerproduct/inner_product_prover.py).
+
+FastNIProver2 keeps g, h, a, b resident on the GPU for the whole log-n halving
+(bpmi_ipa_*); per round only L and R (64 bytes each) come back for the host-side
+Fiat-Shamir hash, and x, x^-1 (32 bytes each) go down for the fold."""
+from typing import Optional
+
+from .. import engine as _engine
+from ..ec import Point, pack_points, pack_scalars
+from ..utils.transcript import Transcript
+from ..utils.utils import ModP
+from .inner_product_verifier import Proof1, Proof2
+
+
+class NIProver:
+    """Protocol 1 -> Protocol 2 reduction (reference :11-45)."""
+
+    def __init__(self, g, h, u, P, c, a, b, group, seed=b""):
+        assert len(g) == len(h) == len(a) == len(b)
+        self.g, self.h, self.u, self.P, self.c, self.a, self.b = g, h, u, P, c, a, b
+        self.group = group
+        self.transcript = Transcript(seed)
+
+    def prove(self) -> Proof1:
+        x = self.transcript.get_modp(self.group.q)
+        self.transcript.add_number(x)
+        P_new = self.P + (x * self.c) * self.u
+        u_new = x * self.u
+        inner = FastNIProver2(self.g, self.h, u_new, P_new, self.a, self.b, self.group, self.transcript.digest)
+        return Proof1(u_new, P_new, inner.prove(), self.transcript.digest)
+
+
+class FastNIProver2:
+    """Protocol 2 prover (reference :48-110)."""
+
+    def __init__(self, g, h, u, P, a, b, group, transcript: Optional[bytes] = None):
+        assert len(g) == len(h) == len(a) == len(b)
+        assert len(a) & (len(a) - 1) == 0
+        self.n = len(a)
+        self.log_n = self.n.bit_length() - 1
+        self.g, self.h, self.u, self.P, self.a, self.b, self.group = g, h, u, P, a, b, group
+        self.transcript = Transcript()
+        if transcript:
+            self.transcript.digest += transcript
+            self.init_transcript_length = len(transcript.split(b"&"))
+        else:
+            self.init_transcript_length = 1
+
+    def prove(self) -> Proof2:
+        q = self.group.q
+        eng = _engine.default_engine()
+        state = eng.ipa_create(pack_points(self.g), pack_points(self.h), pack_scalars(self.a, q),
+                               pack_scalars(self.b, q), self.n, self.u.to_le64())
+        xs, Ls, Rs = [], [], []
+        try:
+            while len(state) > 1:
+                Lb, Rb = state.round_LR()                      # reference :96-99
+                L, R = Point.from_le64(Lb), Point.from_le64(Rb)
+                Ls.append(L)
+                Rs.append(R)
+                self.transcript.add_list_points([L, R])        # :102
+                x = self.transcript.get_modp(q)                # :104
+                xs.append(x)
+                self.transcript.add_number(x)
+                state.fold(x.x, x.inv().x)                     # :107-110
+            a, b = state.finish()
+        finally:
+            state.close()
+        return Proof2(ModP(a, q), ModP(b, q), xs, Ls, Rs, self.transcript.digest, self.init_transcript_length)

@@ -1,0 +1,7 @@
+from .rangeproof_prover import NIRangeProver
+from .rangeproof_verifier import RangeVerifier
+from .rangeproof_aggreg_prover import AggregNIRangeProver
+from .rangeproof_aggreg_verifier import AggregRangeVerifier
+from .common import Proof
+
+__all__ = ["NIRangeProver", "RangeVerifier", "AggregNIRangeProver", "AggregRangeVerifier", "Proof"]

@@ -1,0 +1,30 @@
+"""Single range proof verifier (reference: src/rangeproofs/rangeproof_verifier.py)."""
+from ..ec import secp256k1
+from ..innerproduct.inner_product_verifier import Verifier1
+from ..pippenger import PipSECP256k1
+from ..utils.utils import ModP
+from .common import Proof, VerifierBase, scaled_generators
+
+CURVE = secp256k1
+
+
+class RangeVerifier(VerifierBase):
+    def __init__(self, V, g, h, gs, hs, u, proof: Proof):
+        self.V, self.g, self.h, self.gs, self.hs, self.u, self.proof = V, g, h, gs, hs, u, proof
+
+    def verify(self):
+        self.verify_transcript()
+        g, h, gs, hs, x, y, z, proof = self.g, self.h, self.gs, self.hs, self.x, self.y, self.z, self.proof
+        n = len(gs)
+        ysum, cur = ModP(0, CURVE.q), ModP(1, CURVE.q)
+        for _ in range(n):
+            ysum = ysum + cur
+            cur = cur * y
+        delta_yz = (z - z ** 2) * ysum - (z ** 3) * ModP(2 ** n - 1, CURVE.q)
+        hsp = scaled_generators(hs, y)
+        # t_hat*g + taux*h == z^2*V + delta*g + x*T1 + x^2*T2  (reference :73-76)
+        lhs = PipSECP256k1.multiexp([g, h], [proof.t_hat, proof.taux])
+        rhs = PipSECP256k1.multiexp([self.V, g, proof.T1, proof.T2], [z ** 2, delta_yz, x, x ** 2])
+        self.assertThat(lhs == rhs)
+        P_inner = self._getP(x, y, z, proof.A, proof.S, gs, hsp, n, extra_pts=[h], extra_sc=[-proof.mu])
+        return Verifier1(gs, hsp, self.u, P_inner, proof.t_hat, proof.innerProof).verify()

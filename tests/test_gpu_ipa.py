@@ -1,0 +1,132 @@
+"""GPU parity of the inner-product argument (FastNIProver2 / NIProver / Verifier1 /
+Verifier2 of the product package) vs the reference goldens and the oracle; mirrors
+/root/reference/src/tests/test_innerprod.py (sizes 2^0..2^8 and every cheating case)."""
+import random
+
+import pytest
+
+from conftest import load_golden
+from helpers import P, Q, gens, hx, scal
+from oracle import bp_ref as R
+from oracle import cbind
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gp():
+    import gpu_common
+    return gpu_common
+
+
+def build_case(gp, c):
+    from bulletproofs_amd.ec import secp256k1
+    n = c["n"]
+    s = [bytes.fromhex(x) for x in c["seeds"]]
+    og, oh = gens(n, s[0]), gens(n, s[1])
+    ou = R.elliptic_hash(s[2])
+    oa, ob = scal(n, s[3]), scal(n, s[4])
+    return dict(n=n, s=s, g=gp.to_gpu_list(og), h=gp.to_gpu_list(oh), u=gp.to_gpu(ou),
+                a=[gp.gsc(v) for v in oa], b=[gp.gsc(v) for v in ob], curve=secp256k1)
+
+
+def check_proof2(gp, p2, want):
+    assert hx(p2.a.x) == want["a"] and hx(p2.b.x) == want["b"]
+    assert [hx(x.x) for x in p2.xs] == want["xs"]
+    assert all(gp.same_point(a, P(b)) for a, b in zip(p2.Ls, want["Ls"])) and len(p2.Ls) == len(want["Ls"])
+    assert all(gp.same_point(a, P(b)) for a, b in zip(p2.Rs, want["Rs"])) and len(p2.Rs) == len(want["Rs"])
+    assert p2.transcript.decode() == want["transcript"]
+    assert p2.start_transcript == want["start_transcript"]
+
+
+@pytest.mark.parametrize("k", range(9))
+def test_ipa_reference_goldens(gp, k):
+    from bulletproofs_amd.innerproduct import NIProver, FastNIProver2, Verifier1, Verifier2
+    from bulletproofs_amd.utils import vector_commitment, inner_product
+    c = load_golden("ipa.json")["cases"][k]
+    d = build_case(gp, c)
+    ip = inner_product(d["a"], d["b"])
+    assert hx(ip.x) == c["c"]
+    Pt = vector_commitment(d["g"], d["h"], d["a"], d["b"]) + ip * d["u"]
+    assert gp.same_point(Pt, P(c["P"]))
+    p2 = FastNIProver2(d["g"], d["h"], d["u"], Pt, d["a"], d["b"], d["curve"]).prove()
+    check_proof2(gp, p2, c["proof2"])
+    v2 = Verifier2(d["g"], d["h"], d["u"], Pt, p2)
+    assert [hx(x.x) for x in v2.get_ss(p2.xs)] == c["ss"]
+    assert v2.verify() is True
+    P1 = gp.to_gpu(P(c["P1"]))
+    p1 = NIProver(d["g"], d["h"], d["u"], P1, ip, d["a"], d["b"], d["curve"], d["s"][5]).prove()
+    assert gp.same_point(p1.u_new, P(c["proof1"]["u_new"])) and gp.same_point(p1.P_new, P(c["proof1"]["P_new"]))
+    assert p1.transcript.decode() == c["proof1"]["transcript"]
+    check_proof2(gp, p1.proof2, c["proof1"]["proof2"])
+    assert Verifier1(d["g"], d["h"], d["u"], P1, ip, p1).verify() is True
+
+
+def test_ipa_cheating_cases(gp):
+    """src/tests/test_innerprod.py:33-98, 138-268."""
+    from bulletproofs_amd.innerproduct import NIProver, FastNIProver2, Verifier1, Verifier2
+    from bulletproofs_amd.utils import vector_commitment, inner_product, ModP
+    c = load_golden("ipa.json")["cases"][4]          # n = 16
+    d = build_case(gp, c)
+    g, h, u, a, b, curve = d["g"], d["h"], d["u"], d["a"], d["b"], d["curve"]
+    ip = inner_product(a, b)
+    Pt = vector_commitment(g, h, a, b) + ip * u
+    p2 = FastNIProver2(g, h, u, Pt, a, b, curve).prove()
+    with pytest.raises(Exception, match="Proof invalid"):
+        Verifier2(g, h, u, 2 * Pt, p2).verify()
+    with pytest.raises(Exception, match="Proof invalid"):
+        Verifier2(g, h, 2 * u, Pt, p2).verify()
+    a_bad = list(a)
+    a_bad[3] = a_bad[3] * 2
+    with pytest.raises(Exception, match="Proof invalid"):
+        Verifier2(g, h, u, Pt, FastNIProver2(g, h, u, Pt, a_bad, b, curve).prove()).verify()
+    b_bad = list(b)
+    b_bad[5] = b_bad[5] * 2
+    with pytest.raises(Exception, match="Proof invalid"):
+        Verifier2(g, h, u, Pt, FastNIProver2(g, h, u, Pt, a, b_bad, curve).prove()).verify()
+    P1 = vector_commitment(g, h, a, b)
+    p1 = NIProver(g, h, u, P1, ip, a, b, curve, d["s"][5]).prove()
+    with pytest.raises(Exception, match="Proof invalid"):
+        Verifier1(g, h, u, P1, ip + ModP(1, Q), p1).verify()
+    with pytest.raises(Exception, match="Proof invalid"):
+        Verifier1(g, h, u, 2 * P1, ip, p1).verify()
+    # corrupted outer transcript / swapped inner transcript
+    good = p1.transcript
+    p1.transcript = good.replace(good.split(b"&")[1], b"1234", 1)
+    with pytest.raises(Exception, match="Proof invalid"):
+        Verifier1(g, h, u, P1, ip, p1).verify()
+    p1.transcript = good
+    other = NIProver(g, h, u, P1, ip, a, b, curve, b"another seed").prove()
+    p1.proof2.transcript = other.proof2.transcript
+    with pytest.raises(Exception, match="Proof invalid"):
+        Verifier1(g, h, u, P1, ip, p1).verify()
+
+
+@pytest.mark.parametrize("n", [2, 64, 1024, 8192])
+def test_ipa_rounds_vs_oracle(gp, n):
+    """Every round's L, R and the folded vectors against the C oracle, through the raw
+    C-ABI state object (bpmi_ipa_*), with arbitrary challenges."""
+    eng = gp.engine()
+    pts, _ = gp.rand_points(2 * n + 1, 40 + n)
+    g, h, u = pts[:n], pts[n:2 * n], pts[2 * n]
+    rnd = random.Random(n)
+    a = [rnd.randrange(Q) for _ in range(n)]
+    b = [rnd.randrange(Q) for _ in range(n)]
+    st = eng.ipa_create(cbind.pack_points(g), cbind.pack_points(h), cbind.pack_scalars(a), cbind.pack_scalars(b),
+                        n, cbind.pack_points([u]))
+    while len(st) > 1:
+        half = len(st) // 2
+        L, Rr = st.round_LR()
+        cl = cbind.sc_dot(a[:half], b[half:])
+        cr = cbind.sc_dot(a[half:], b[:half])
+        assert L == cbind.pack_points([cbind.msm(g[half:] + h[:half] + [u], a[:half] + b[half:] + [cl])])
+        assert Rr == cbind.pack_points([cbind.msm(g[:half] + h[half:] + [u], a[half:] + b[:half] + [cr])])
+        x = rnd.randrange(1, Q)
+        xi = pow(x, -1, Q)
+        st.fold(x, xi)
+        g = cbind.ec_lincomb2_batch(g[:half], g[half:], xi, x)
+        h = cbind.ec_lincomb2_batch(h[:half], h[half:], x, xi)
+        a = cbind.sc_fold(a[:half], a[half:], x, xi)
+        b = cbind.sc_fold(b[:half], b[half:], xi, x)
+    assert st.finish() == (a[0], b[0])
+    st.close()

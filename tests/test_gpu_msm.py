@@ -1,0 +1,149 @@
+"""GPU parity: Pippenger.multiexp on EC(secp256k1) through the C-ABI vs the reference
+goldens, the C oracle on seeded inputs, and size-independent properties at the
+BASELINE.json sizes (n = 2^16, 2^20)."""
+import ctypes
+import random
+
+import pytest
+
+from conftest import load_golden
+from helpers import P, Q, seed
+from oracle import cbind
+from oracle.ec import INF
+from test_oracle_golden import multiexp_case_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gp():
+    import gpu_common
+    return gpu_common
+
+
+def test_multiexp_reference_goldens(gp):
+    from bulletproofs_amd.pippenger import PipSECP256k1
+    g = load_golden("multiexp.json")
+    sg, ss = bytes.fromhex(g["seed_points"]), bytes.fromhex(g["seed_scalars"])
+    for case in g["cases"]:
+        gs, es = multiexp_case_inputs(case, sg, ss)
+        es = [gp.gsc(e) if hasattr(e, "x") else e for e in es]
+        got = PipSECP256k1.multiexp(gp.to_gpu_list(gs), es)
+        assert gp.same_point(got, P(case["result"])), (case["label"], case["n"])
+
+
+def test_multiexp_call_surface(gp):
+    from bulletproofs_amd.pippenger import PipSECP256k1, Pippenger, EC
+    from bulletproofs_amd.ec import Point, secp256k1
+    assert PipSECP256k1.multiexp([], []) == Point.IDENTITY_ELEMENT
+    with pytest.raises(Exception, match="Different number of group elements and exponents"):
+        PipSECP256k1.multiexp([secp256k1.G], [1, 2])
+    Gp = secp256k1.G
+    assert PipSECP256k1.multiexp([Gp], [0]) == Point.IDENTITY_ELEMENT
+    assert PipSECP256k1.multiexp([Gp, Gp], [Q - 1, 1]) == Point.IDENTITY_ELEMENT
+    assert PipSECP256k1.multiexp([Gp], [-1]) == -Gp
+    assert PipSECP256k1.multiexp([Gp], [Q + 2]) == Gp + Gp
+    assert PipSECP256k1.multiexp([Point.IDENTITY_ELEMENT, Gp], [5, 3]) == 3 * Gp
+    assert Pippenger(EC(secp256k1)).multiexp([Gp, 2 * Gp], [3, 4]) == 11 * Gp
+    inputs = [Gp, 2 * Gp]
+    before = [(p.x, p.y) for p in inputs]
+    PipSECP256k1.multiexp(inputs, [7, 9])
+    assert [(p.x, p.y) for p in inputs] == before           # inputs are never mutated
+
+
+@pytest.mark.parametrize("n", [1, 2, 7, 63, 64, 65, 255, 1000, 4097, 20000, 65536])
+def test_msm_vs_oracle_random(gp, n):
+    pts, _ = gp.rand_points(n, 100 + n)
+    rnd = random.Random(n)
+    es = [rnd.randrange(Q) for _ in range(n)]
+    pb, sb = cbind.pack_points(pts), cbind.pack_scalars(es)
+    assert gp.engine().msm_bytes(pb, sb, n) == cbind.msm_bytes(pb, sb, n)
+
+
+@pytest.mark.parametrize("shape", ["acommit", "all_same", "same_point", "zeros", "cancel", "small", "with_inf", "top"])
+def test_msm_degenerate_shapes(gp, shape):
+    n = 5000
+    pts, _ = gp.rand_points(n, 7)
+    rnd = random.Random(11)
+    es = [rnd.randrange(Q) for _ in range(n)]
+    if shape == "acommit":            # rangeproof_prover.py:42-47: {0,1} then {0,q-1}
+        es = [rnd.randrange(2) for _ in range(n // 2)] + [(rnd.randrange(2) - 1) % Q for _ in range(n - n // 2)]
+    elif shape == "all_same":
+        es = [es[0]] * n
+    elif shape == "same_point":
+        pts = [pts[0]] * n
+    elif shape == "zeros":
+        es = [0] * n
+    elif shape == "cancel":
+        pts = pts[: n // 2] + [-p for p in pts[: n // 2]]
+        es = es[: n // 2] * 2
+    elif shape == "small":
+        es = [rnd.randrange(1 << 20) for _ in range(n)]
+    elif shape == "with_inf":
+        pts = [INF if i % 3 == 0 else p for i, p in enumerate(pts)]
+    elif shape == "top":              # scalars around q/2 and q-1: sign recoding edges
+        half = (Q - 1) // 2
+        es = [[half, half + 1, half - 1, Q - 1, Q - 2, 1, 2][i % 7] for i in range(n)]
+    pb, sb = cbind.pack_points(pts), cbind.pack_scalars(es)
+    assert gp.engine().msm_bytes(pb, sb, n) == cbind.msm_bytes(pb, sb, n)
+
+
+@pytest.mark.parametrize("n,chunk,c", [(9, 1, 4), (20, 1, 4), (64, 1, 0), (300, 2, 0), (200, 1, 8), (1000, 0, 4),
+                                       (1000, 8, 6), (3000, 0, 16), (3000, 3, 9), (1 << 12, 0, 2)])
+def test_msm_multiblock_segscan(gp, n, chunk, c):
+    """Forces the multi-level partial-record path (many 256-record blocks) and every
+    window size: regression for the segscan store epilogue."""
+    eng = gp.engine()
+    pts, _ = gp.rand_points(n, 5)
+    rnd = random.Random(n * 31 + chunk)
+    es = [rnd.randrange(Q) for _ in range(n)]
+    pb, sb = cbind.pack_points(pts), cbind.pack_scalars(es)
+    try:
+        eng.set_option("chunk", chunk)
+        eng.set_option("window_bits", c)
+        for tail in (1, 2):
+            eng.set_option("tail", tail)
+            assert eng.msm_bytes(pb, sb, n) == cbind.msm_bytes(pb, sb, n)
+    finally:
+        eng.set_option("chunk", 0)
+        eng.set_option("window_bits", 0)
+        eng.set_option("tail", 0)
+
+
+@pytest.mark.parametrize("logn", [16, 20])
+def test_msm_full_size_properties(gp, logn):
+    """At BASELINE.json's sizes the oracle is too slow to be the only check, so use
+    properties that do not depend on n:
+      known answer  P_i = k_i*G  =>  MSM(P, e) = (sum e_i k_i mod q) * G
+      linearity     MSM(P, e) + MSM(P, f) = MSM(P, e + f)
+      determinism   same input twice -> identical bytes
+    and, at 2^16, the C oracle on all host cores."""
+    eng = gp.engine()
+    n = 1 << logn
+    rnd = random.Random(logn)
+    ks = [rnd.randrange(1, Q) for _ in range(n)]
+    Gb = cbind.pack_points([gp.G])
+    d_G = eng.upload(Gb * n)
+    d_k = eng.upload(cbind.pack_scalars(ks))
+    d_pts = eng.alloc(64 * n)
+    eng._ck(eng.lib.bpmi_ec_mul_batch_dev(eng.ctx, d_G.ptr, d_k.ptr, n, d_pts.ptr))
+    d_G.free()
+    es = [rnd.randrange(Q) for _ in range(n)]
+    fs = [rnd.randrange(Q) for _ in range(n)]
+    d_e = eng.upload(cbind.pack_scalars(es))
+    d_f = eng.upload(cbind.pack_scalars(fs))
+    d_ef = eng.upload(cbind.pack_scalars([(a + b) % Q for a, b in zip(es, fs)]))
+    r_e = eng.msm_dev(d_pts, d_e, n)
+    r_f = eng.msm_dev(d_pts, d_f, n)
+    r_ef = eng.msm_dev(d_pts, d_ef, n)
+    assert r_e == eng.msm_dev(d_pts, d_e, n)
+    want = (sum(e * k for e, k in zip(es, ks)) % Q) * gp.G
+    assert r_e == cbind.pack_points([want])
+    assert eng.ec_sum_bytes(r_e + r_f, 2) == r_ef
+    if logn == 16:
+        pts_host = d_pts.download()
+        assert r_e == cbind.msm_bytes(pts_host, cbind.pack_scalars(es), n)
+        # spot-check the generated points themselves
+        assert pts_host[:64] == cbind.pack_points([ks[0] * gp.G])
+    for d in (d_k, d_pts, d_e, d_f, d_ef):
+        d.free()
