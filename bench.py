@@ -94,17 +94,15 @@ def main():
     eng.sync()
     del d_G, d_k
     d_sc = torch.frombuffer(bytearray(synth_scalars(n, rank)), dtype=torch.uint8).to(dev)
-    gather = [torch.empty(64, dtype=torch.uint8, device=dev) for _ in range(world)] if world > 1 else None
     t_in = time.time() - t_in
 
+    from bulletproofs_amd.distributed import ShardedMSM
+    sharded = ShardedMSM(engine=eng)
+
     def step():
-        part = eng.msm_dev(d_pts, d_sc, n)                     # 64-byte affine partial result
-        if world == 1:
-            return part
-        mine = torch.frombuffer(bytearray(part), dtype=torch.uint8).to(dev)
-        dist.all_gather(gather, mine)                          # the single exchange step
-        allp = b"".join(bytes(t.cpu().numpy().tobytes()) for t in gather)
-        return eng.ec_sum_bytes(allp, world)
+        # per-rank MSM on the local shard, then (N > 1) ONE all_gather of the 64-byte
+        # partials + bpmi_ec_sum fold: every rank ends the step with the global result
+        return sharded.multiexp_local_dev(d_pts, d_sc, n)
 
     def barrier():
         if world > 1:
