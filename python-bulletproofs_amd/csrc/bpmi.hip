@@ -354,17 +354,25 @@ __global__ void __launch_bounds__(256) k_accum_l0(Segs segs, MsmGeom g, const u3
   xyzz_set_inf(acc);
   u32 cur = skey[start];
   bool first = true;
+  // software pipeline: the (key, index, point) of entry j+1 is in flight while entry j is added
+  u32 k_next = cur, e_next = sidx[start];
+  u32 w_next[16];
+  load_words16(w_next, seg_point(segs, e_next & 0x7FFFFFFFu));
   for (u32 j = (u32)start; j < end; j++) {
-    const u32 k = skey[j];
+    const u32 k = k_next, e = e_next;
+    affine P;
+    affine_from_words(P, w_next);
+    if (j + 1 < end) {
+      k_next = skey[j + 1];
+      e_next = sidx[j + 1];
+      load_words16(w_next, seg_point(segs, e_next & 0x7FFFFFFFu));
+    }
     if (k != cur) {
       if (first) { rec_key[2 * t] = cur; xyzz_store_g(rec_pt + (2 * t) * XYZZ_WORDS, acc); first = false; }
       else xyzz_store_g(buckets + (u64)cur * XYZZ_WORDS, acc);
       xyzz_set_inf(acc);
       cur = k;
     }
-    const u32 e = sidx[j];
-    affine P;
-    load_affine(P, seg_point(segs, e & 0x7FFFFFFFu));
     xyzz_madd_signed(acc, P, (e >> 31) != 0);
   }
   if (first) {

@@ -116,10 +116,16 @@ BPMI_HD void xyzz_madd(xyzz &acc, const fe &x2, const fe &y2) {
   fe_mul(acc.ZZZ, acc.ZZZ, PPP);
 }
 // acc += P for an affine point that may be the identity, optionally negated
+// The sign is data (random per entry), so it must be a SELECT, not a branch: a branch
+// makes every wave execute two copies of the 8M+2S add with half the lanes masked.
 BPMI_HD void xyzz_madd_signed(xyzz &acc, const affine &P, bool negate) {
   if (affine_is_inf(P)) return;
-  if (negate) { fe ny, t; fe_neg(t, P.y); fe_carry(ny, t); xyzz_madd(acc, P.x, ny); }
-  else xyzz_madd(acc, P.x, P.y);
+  fe ny, t;
+  fe_neg(t, P.y);
+  fe_carry(ny, t);
+#pragma unroll
+  for (int k = 0; k < 9; k++) ny.v[k] = negate ? ny.v[k] : P.y.v[k];
+  xyzz_madd(acc, P.x, ny);
 }
 
 // r = a + b, both XYZZ (add-2008-s): 12M + 2S
