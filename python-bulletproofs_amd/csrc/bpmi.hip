@@ -209,32 +209,40 @@ struct MsmGeom {
   u32 nv;      // base-32 digit positions of a bucket index (ceil(c / 5))
 };
 
-// scalar -> signed digits + histogram.  dig[w * n + i] = |d| | (sign << 31)
+// Signed-digit recoding of scalar i: calls f(w, b, sign) for every window, b = |digit|
+// in [0, B] (0 = nothing to add), sign = 1 when the NEGATED point is added.
+//   s > (q-1)/2  ->  use q - s on the negated point: halves the digit range, keeps
+//   s < 2^255 so W*c >= 256 never overflows, and turns the range-proof scalar q-1
+//   (aR, rangeproof_prover.py:43-45) into the single digit -1.
+template <typename F>
+__device__ __forceinline__ void for_each_digit(const Segs &segs, const MsmGeom &g, u32 i, F f) {
+  sc s;
+  load_words8(s.v, seg_scalar(segs, i));
+  const bool neg = sc_is_high(s);
+  if (neg) sc_neg(s, s);
+  u32 carry = 0;
+  const u32 mask = (1u << g.c) - 1u;
+  for (u32 w = 0; w < g.W; w++) {
+    const u32 t = (s.v[0] & mask) + carry;
+    // shift the 256-bit register right by c (static register indexing)
+#pragma unroll
+    for (int k = 0; k < 7; k++) s.v[k] = (u32)((((u64)s.v[k + 1] << 32) | s.v[k]) >> g.c);
+    s.v[7] >>= g.c;
+    u32 b, sign;
+    if (t > g.B) { b = (1u << g.c) - t; sign = 1; carry = 1; }
+    else { b = t; sign = 0; carry = 0; }
+    f(w, b, b ? (sign ^ (u32)neg) : 0u);
+  }
+}
+
+// ================= sort path 1 (small n, c < 10): global-atomic counting sort ===========
+// dig[w * n + i] = |d| | (sign << 31); histogram with one atomic per lane, or one per wave
+// when the whole wave agrees (degenerate inputs)
 __global__ void __launch_bounds__(256) k_digits_hist(Segs segs, MsmGeom g, u32 *__restrict__ dig, u32 *__restrict__ hist) {
   const u32 stride = gridDim.x * blockDim.x;
   for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < g.n; i += stride) {
-    sc s;
-    load_words8(s.v, seg_scalar(segs, i));
-    // s > (q-1)/2  ->  use q - s on the negated point: halves the digit range, keeps
-    // s < 2^255 so W*c >= 256 never overflows, and turns the range-proof scalar q-1
-    // (aR, rangeproof_prover.py:43-45) into the single digit -1.
-    const bool neg = sc_is_high(s);
-    if (neg) sc_neg(s, s);
-    u32 carry = 0;
-    const u32 mask = (1u << g.c) - 1u;
-    for (u32 w = 0; w < g.W; w++) {
-      u32 t = (s.v[0] & mask) + carry;
-      // shift the 256-bit register right by c (static register indexing)
-#pragma unroll
-      for (int k = 0; k < 7; k++) s.v[k] = (u32)((((u64)s.v[k + 1] << 32) | s.v[k]) >> g.c);
-      s.v[7] >>= g.c;
-      u32 b, sign;
-      if (t > g.B) { b = (1u << g.c) - t; sign = 1; carry = 1; }
-      else { b = t; sign = 0; carry = 0; }
-      sign ^= (u32)neg;
-      dig[(u64)w * g.n + i] = b | (b ? (sign << 31) : 0u);
-      // histogram: one atomic per lane, or one per wave when the whole wave agrees
-      // (degenerate inputs: all-equal scalars, the {0,1,q-1} A-commitment shape)
+    for_each_digit(segs, g, i, [&](u32 w, u32 b, u32 sign) {
+      dig[(u64)w * g.n + i] = b | (sign << 31);
       const u32 key = b ? (w * g.B + b - 1u) : 0xFFFFFFFFu;
       const unsigned long long act = __ballot(1);
       const u32 first = __builtin_amdgcn_readfirstlane(key);
@@ -247,8 +255,103 @@ __global__ void __launch_bounds__(256) k_digits_hist(Segs segs, MsmGeom g, u32 *
       } else if (b) {
         atomicAdd(&hist[key], 1u);
       }
-    }
+    });
   }
+}
+
+// ================= sort path 2 (c >= 10): two-level LDS partition sort ==================
+// Bucket key k = b - 1 (c-1 bits) = hi * 256 + lo.  Level A partitions all W*n digits by
+// (window, hi) with LDS histograms -- global atomics only to reserve one range per
+// (tile, partition); level B gives every partition to one block, which counting-sorts it
+// by lo entirely in LDS.  No per-element global atomic anywhere.
+#define PART_MAX 2048          // W * (B / 256) <= 2048 for every c in [10, 16]
+#define TILE_SCALARS 4096      // scalars per block-iteration in level A
+__global__ void __launch_bounds__(256) k_coarse_hist(Segs segs, MsmGeom g, u32 P, u32 *__restrict__ coarse_hist) {
+  __shared__ u32 lh[PART_MAX];
+  for (u32 p = threadIdx.x; p < P; p += 256u) lh[p] = 0;
+  __syncthreads();
+  const u32 Bc = g.B >> 8;
+  const u32 stride = gridDim.x * blockDim.x;
+  for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < g.n; i += stride) {
+    for_each_digit(segs, g, i, [&](u32 w, u32 b, u32) {
+      if (b) atomicAdd(&lh[w * Bc + ((b - 1u) >> 8)], 1u);
+    });
+  }
+  __syncthreads();
+  for (u32 p = threadIdx.x; p < P; p += 256u) { const u32 v = lh[p]; if (v) atomicAdd(&coarse_hist[p], v); }
+}
+// part[pos] = lo << 24 | sign << 23 | i   (n <= 2^23), grouped by partition
+__global__ void __launch_bounds__(256) k_partition(Segs segs, MsmGeom g, u32 P, u32 *__restrict__ coarse_cursor, u32 *__restrict__ part) {
+  __shared__ u32 lh[PART_MAX];
+  const u32 Bc = g.B >> 8;
+  const u32 ntiles = (g.n + TILE_SCALARS - 1) / TILE_SCALARS;
+  for (u32 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    for (u32 p = threadIdx.x; p < P; p += 256u) lh[p] = 0;
+    __syncthreads();
+    const u32 i0 = tile * TILE_SCALARS;
+    const u32 i1 = (i0 + TILE_SCALARS < g.n) ? i0 + TILE_SCALARS : g.n;
+    for (u32 i = i0 + threadIdx.x; i < i1; i += 256u) {
+      for_each_digit(segs, g, i, [&](u32 w, u32 b, u32) {
+        if (b) atomicAdd(&lh[w * Bc + ((b - 1u) >> 8)], 1u);
+      });
+    }
+    __syncthreads();
+    // reserve this tile's range in every partition: count -> base position
+    for (u32 p = threadIdx.x; p < P; p += 256u) { const u32 v = lh[p]; if (v) lh[p] = atomicAdd(&coarse_cursor[p], v); }
+    __syncthreads();
+    for (u32 i = i0 + threadIdx.x; i < i1; i += 256u) {
+      for_each_digit(segs, g, i, [&](u32 w, u32 b, u32 sign) {
+        if (b) {
+          const u32 k = b - 1u;
+          const u32 pos = atomicAdd(&lh[w * Bc + (k >> 8)], 1u);
+          part[pos] = ((k & 255u) << 24) | (sign << 23) | i;
+        }
+      });
+    }
+    __syncthreads();
+  }
+}
+// chunk_key[t] = bucket that contains sorted position t * L (for every chunk start inside [lo, hi))
+__device__ __forceinline__ void fill_chunk_keys(u32 *__restrict__ chunk_key, u32 L, u32 key, u32 lo, u32 hi) {
+  for (u32 t = (lo + L - 1u) / L; (u64)t * L < hi; t++) chunk_key[t] = key;
+}
+// one block per partition p = (window, hi): LDS counting sort by lo; writes sidx, the
+// bucket offsets off[p*256 .. p*256+255] and the chunk keys
+__global__ void __launch_bounds__(256) k_fine_sort(MsmGeom g, const u32 *__restrict__ coarse_off, const u32 *__restrict__ part,
+                                                   u32 *__restrict__ sidx, u32 *__restrict__ off, u32 *__restrict__ chunk_key) {
+  __shared__ u32 h[256];
+  __shared__ u32 sc_[256];
+  const u32 p = blockIdx.x, tid = threadIdx.x;
+  const u32 a = coarse_off[p], b = coarse_off[p + 1];
+  h[tid] = 0;
+  __syncthreads();
+  for (u32 j = a + tid; j < b; j += 256u) atomicAdd(&h[part[j] >> 24], 1u);
+  __syncthreads();
+  const u32 cnt = h[tid];
+  sc_[tid] = cnt;
+  __syncthreads();
+  for (u32 d = 1; d < 256; d <<= 1) {
+    const u32 t = tid >= d ? sc_[tid - d] : 0;
+    __syncthreads();
+    sc_[tid] += t;
+    __syncthreads();
+  }
+  const u32 lo = a + sc_[tid] - cnt;            // first sorted position of fine bucket (p, tid)
+  off[p * 256u + tid] = lo;
+  fill_chunk_keys(chunk_key, g.L, p * 256u + tid, lo, lo + cnt);
+  h[tid] = lo;                                  // becomes the running cursor
+  __syncthreads();
+  for (u32 j = a + tid; j < b; j += 256u) {
+    const u32 e = part[j];
+    const u32 pos = atomicAdd(&h[e >> 24], 1u);
+    sidx[pos] = (e & 0x7FFFFFu) | ((e & 0x800000u) << 8);
+  }
+}
+// path 1 equivalent of the chunk-key fill: one thread per bucket
+__global__ void __launch_bounds__(256) k_chunk_keys(MsmGeom g, const u32 *__restrict__ off, u32 *__restrict__ chunk_key) {
+  const u32 key = blockIdx.x * blockDim.x + threadIdx.x;
+  if (key >= g.G) return;
+  fill_chunk_keys(chunk_key, g.L, key, off[key], off[key + 1]);
 }
 
 // ---- exclusive scan of hist[0..G) -> off[0..G], cursor[0..G) = off ------------------
@@ -312,9 +415,9 @@ __global__ void __launch_bounds__(256) k_scan_final(const u32 *__restrict__ hist
   }
 }
 
-// ---- counting-sort scatter --------------------------------------------------------------
+// ---- counting-sort scatter (path 1) ---------------------------------------------------
 __global__ void __launch_bounds__(256) k_scatter(MsmGeom g, const u32 *__restrict__ dig, u32 *__restrict__ cursor,
-                                                 u32 *__restrict__ skey, u32 *__restrict__ sidx) {
+                                                 u32 *__restrict__ sidx) {
   const u32 stride = gridDim.x * blockDim.x;
   for (u32 w = 0; w < g.W; w++) {
     for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < g.n; i += stride) {
@@ -336,14 +439,14 @@ __global__ void __launch_bounds__(256) k_scatter(MsmGeom g, const u32 *__restric
       } else if (b) {
         pos = atomicAdd(&cursor[key], 1u);
       }
-      if (b) { skey[pos] = key; sidx[pos] = i | (d & 0x80000000u); }
+      if (b) sidx[pos] = i | (d & 0x80000000u);
     }
   }
 }
 
 // ---- level 0: every thread adds exactly L sorted entries --------------------------------
 __global__ void __launch_bounds__(256) k_accum_l0(Segs segs, MsmGeom g, const u32 *__restrict__ off,
-                                                  const u32 *__restrict__ skey, const u32 *__restrict__ sidx,
+                                                  const u32 *__restrict__ chunk_key, const u32 *__restrict__ sidx,
                                                   u32 *__restrict__ buckets, u32 *__restrict__ rec_key, u32 *__restrict__ rec_pt) {
   const u32 E = off[g.G];
   const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -352,26 +455,26 @@ __global__ void __launch_bounds__(256) k_accum_l0(Segs segs, MsmGeom g, const u3
   const u32 end = (u32)((start + g.L < E) ? start + g.L : E);
   xyzz acc;
   xyzz_set_inf(acc);
-  u32 cur = skey[start];
+  u32 cur = chunk_key[t];              // bucket containing position `start`
+  u32 boundary = off[cur + 1];         // first position after that bucket's run
   bool first = true;
-  // software pipeline: the (key, index, point) of entry j+1 is in flight while entry j is added
-  u32 k_next = cur, e_next = sidx[start];
+  // software pipeline: the (index, point) of entry j+1 is in flight while entry j is added
+  u32 e_next = sidx[start];
   u32 w_next[16];
   load_words16(w_next, seg_point(segs, e_next & 0x7FFFFFFFu));
   for (u32 j = (u32)start; j < end; j++) {
-    const u32 k = k_next, e = e_next;
+    const u32 e = e_next;
     affine P;
     affine_from_words(P, w_next);
     if (j + 1 < end) {
-      k_next = skey[j + 1];
       e_next = sidx[j + 1];
       load_words16(w_next, seg_point(segs, e_next & 0x7FFFFFFFu));
     }
-    if (k != cur) {
+    if (j == boundary) {               // the run of `cur` ended: flush, move to the next non-empty bucket
       if (first) { rec_key[2 * t] = cur; xyzz_store_g(rec_pt + (2 * t) * XYZZ_WORDS, acc); first = false; }
       else xyzz_store_g(buckets + (u64)cur * XYZZ_WORDS, acc);
       xyzz_set_inf(acc);
-      cur = k;
+      do { cur++; boundary = off[cur + 1]; } while (boundary == j);
     }
     xyzz_madd_signed(acc, P, (e >> 31) != 0);
   }
@@ -715,7 +818,8 @@ static u32 pick_window_bits(const bpmi_ctx *ctx, uint64_t n) {
 }
 
 struct MsmWs {
-  u32 *dig, *hist, *off, *cursor, *bsum, *skey, *sidx, *buckets;
+  u32 *dig, *hist, *off, *cursor, *bsum, *sidx, *buckets, *chunk_key, *coarse_hist, *coarse_off, *coarse_cursor;
+  u32 P;          // partitions of sort path 2 (0 = path 1)
   u32 *rec_key[2], *rec_pt[2];
   u32 *D, *E, *out;
   size_t total;
@@ -728,13 +832,19 @@ static void msm_layout(const MsmGeom &g, MsmWs &w, char *base) {
   w.nscan_blocks = (u32)((g.G + SCAN_TILE - 1) / SCAN_TILE);
   w.rec0_max = (u32)(2 * ((nW + g.L - 1) / g.L));
   const u32 rec1_max = 2 * ((w.rec0_max + 255) / 256);
-  w.hist = take(4ull * g.G);                 // hist | off | cursor | bsum are zeroed/filled per call
+  // sort path 2 (LDS partition sort) when the bucket key has more than 8 bits and the
+  // packed entry (8-bit lo | sign | 23-bit index) fits; path 1 (global atomics) otherwise
+  w.P = (g.c >= 10 && g.n <= (1u << 23)) ? g.W * (g.B >> 8) : 0;
+  w.hist = take(4ull * g.G);                 // path 1 only
   w.off = take(4ull * (g.G + 1));
-  w.cursor = take(4ull * g.G);
+  w.cursor = take(4ull * g.G);               // path 1 only
   w.bsum = take(4ull * (w.nscan_blocks + 1));
-  w.dig = take(4ull * nW);
-  w.skey = take(4ull * nW);
+  w.coarse_hist = take(4ull * (PART_MAX + 1));
+  w.coarse_off = take(4ull * (PART_MAX + 1));
+  w.coarse_cursor = take(4ull * (PART_MAX + 1));
+  w.dig = take(4ull * nW);                   // path 1: digits; path 2: partitioned entries
   w.sidx = take(4ull * nW);
+  w.chunk_key = take(4ull * (w.rec0_max / 2 + 1));
   w.buckets = take(4ull * XYZZ_WORDS * g.G);
   w.rec_key[0] = take(4ull * w.rec0_max);
   w.rec_pt[0] = take(4ull * XYZZ_WORDS * w.rec0_max);
@@ -767,31 +877,57 @@ static int msm_run(bpmi_ctx *ctx, const Segs &segs, uint8_t out[64]) {
   const u32 nblk_n = (u32)std::min<uint64_t>((n + 255) / 256, 8192);
   {
     StageTimer t(ctx, ST_MISC);
-    HIPCHK(ctx, hipMemsetAsync(w.hist, 0, 4ull * g.G, st));
+    if (w.P) HIPCHK(ctx, hipMemsetAsync(w.coarse_hist, 0, 4ull * (PART_MAX + 1), st));
+    else HIPCHK(ctx, hipMemsetAsync(w.hist, 0, 4ull * g.G, st));
     HIPCHK(ctx, hipMemsetAsync(w.buckets, 0, 4ull * XYZZ_WORDS * g.G, st));
   }
   debug_sync(ctx, "ST_MISC");
-  {
-    StageTimer t(ctx, ST_DIGITS);
-    hipLaunchKernelGGL(k_digits_hist, dim3(nblk_n), dim3(256), 0, st, segs, g, w.dig, w.hist);
+  if (w.P) {
+    {
+      StageTimer t(ctx, ST_DIGITS);
+      hipLaunchKernelGGL(k_coarse_hist, dim3(std::min<u32>(nblk_n, 512)), dim3(256), 0, st, segs, g, w.P, w.coarse_hist);
+    }
+    debug_sync(ctx, "ST_DIGITS");
+    {
+      StageTimer t(ctx, ST_SCAN);
+      // exclusive scan of <= 2048 partition counts; total -> coarse_off[P] and off[G]
+      hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(256), 0, st, w.coarse_hist, w.P, w.bsum);
+      hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, w.bsum, 1u, w.off, g.G);
+      hipLaunchKernelGGL(k_scan_final, dim3(1), dim3(256), 0, st, w.coarse_hist, w.P, w.bsum, w.coarse_off, w.coarse_cursor);
+      HIPCHK(ctx, hipMemcpyAsync(w.coarse_off + w.P, w.off + g.G, 4, hipMemcpyDeviceToDevice, st));
+    }
+    debug_sync(ctx, "ST_SCAN");
+    {
+      StageTimer t(ctx, ST_SCATTER);
+      const u32 ntiles = (g.n + TILE_SCALARS - 1) / TILE_SCALARS;
+      hipLaunchKernelGGL(k_partition, dim3(std::min<u32>(ntiles, 2048)), dim3(256), 0, st, segs, g, w.P, w.coarse_cursor, w.dig);
+      hipLaunchKernelGGL(k_fine_sort, dim3(w.P), dim3(256), 0, st, g, w.coarse_off, w.dig, w.sidx, w.off, w.chunk_key);
+    }
+    debug_sync(ctx, "ST_SCATTER");
+  } else {
+    {
+      StageTimer t(ctx, ST_DIGITS);
+      hipLaunchKernelGGL(k_digits_hist, dim3(nblk_n), dim3(256), 0, st, segs, g, w.dig, w.hist);
+    }
+    debug_sync(ctx, "ST_DIGITS");
+    {
+      StageTimer t(ctx, ST_SCAN);
+      hipLaunchKernelGGL(k_scan_partials, dim3(w.nscan_blocks), dim3(256), 0, st, w.hist, g.G, w.bsum);
+      hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, w.bsum, w.nscan_blocks, w.off, g.G);
+      hipLaunchKernelGGL(k_scan_final, dim3(w.nscan_blocks), dim3(256), 0, st, w.hist, g.G, w.bsum, w.off, w.cursor);
+    }
+    debug_sync(ctx, "ST_SCAN");
+    {
+      StageTimer t(ctx, ST_SCATTER);
+      hipLaunchKernelGGL(k_scatter, dim3(nblk_n), dim3(256), 0, st, g, w.dig, w.cursor, w.sidx);
+      hipLaunchKernelGGL(k_chunk_keys, dim3((g.G + 255) / 256), dim3(256), 0, st, g, w.off, w.chunk_key);
+    }
+    debug_sync(ctx, "ST_SCATTER");
   }
-  debug_sync(ctx, "ST_DIGITS");
-  {
-    StageTimer t(ctx, ST_SCAN);
-    hipLaunchKernelGGL(k_scan_partials, dim3(w.nscan_blocks), dim3(256), 0, st, w.hist, g.G, w.bsum);
-    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, w.bsum, w.nscan_blocks, w.off, g.G);
-    hipLaunchKernelGGL(k_scan_final, dim3(w.nscan_blocks), dim3(256), 0, st, w.hist, g.G, w.bsum, w.off, w.cursor);
-  }
-  debug_sync(ctx, "ST_SCAN");
-  {
-    StageTimer t(ctx, ST_SCATTER);
-    hipLaunchKernelGGL(k_scatter, dim3(nblk_n), dim3(256), 0, st, g, w.dig, w.cursor, w.skey, w.sidx);
-  }
-  debug_sync(ctx, "ST_SCATTER");
   {
     StageTimer t(ctx, ST_ACCUM);
     const u32 nthreads = w.rec0_max / 2;
-    hipLaunchKernelGGL(k_accum_l0, dim3((nthreads + 255) / 256), dim3(256), 0, st, segs, g, w.off, w.skey, w.sidx,
+    hipLaunchKernelGGL(k_accum_l0, dim3((nthreads + 255) / 256), dim3(256), 0, st, segs, g, w.off, w.chunk_key, w.sidx,
                        w.buckets, w.rec_key[0], w.rec_pt[0]);
   }
   debug_sync(ctx, "ST_ACCUM");
