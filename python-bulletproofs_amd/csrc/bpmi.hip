@@ -4,9 +4,12 @@
 // MSM pipeline (replaces Pippenger.multiexp, /root/reference/src/pippenger/pippenger.py:22-94,
 // by the signed-digit bucket method; the result -- a canonical affine point -- is
 // schedule independent, so it is bit-identical to the reference's subset-table schedule):
-//   k_digits_hist   scalar -> W signed c-bit digits, per-(window,bucket) histogram
-//   k_scan_*        exclusive scan of the histogram -> run offsets
-//   k_scatter       counting-sort scatter of (point index, sign) by (window, bucket)
+//   sort            (window, bucket) counting sort of (point index, sign):
+//                   n >= 2^13: k_coarse_hist / k_partition / k_fine_hist / k_fine_scatter --
+//                   a two-level radix partition whose histograms and ranks live in LDS
+//                   (global atomics only reserve one range per tile and bin);
+//                   smaller n: k_digits_hist / k_scatter with global atomics
+//   k_scan_*        exclusive scans of the histograms -> run offsets
 //   k_accum_l0      every thread adds exactly L sorted entries (perfectly balanced for
 //                   ANY digit distribution); runs that end inside a chunk go to their
 //                   bucket, the first/last run of a chunk become partial records
@@ -315,35 +318,83 @@ __global__ void __launch_bounds__(256) k_partition(Segs segs, MsmGeom g, u32 P, 
 __device__ __forceinline__ void fill_chunk_keys(u32 *__restrict__ chunk_key, u32 L, u32 key, u32 lo, u32 hi) {
   for (u32 t = (lo + L - 1u) / L; (u64)t * L < hi; t++) chunk_key[t] = key;
 }
-// one block per partition p = (window, hi): LDS counting sort by lo; writes sidx, the
-// bucket offsets off[p*256 .. p*256+255] and the chunk keys
-__global__ void __launch_bounds__(256) k_fine_sort(MsmGeom g, const u32 *__restrict__ coarse_off, const u32 *__restrict__ part,
-                                                   u32 *__restrict__ sidx, u32 *__restrict__ off, u32 *__restrict__ chunk_key) {
-  __shared__ u32 h[256];
-  __shared__ u32 sc_[256];
-  const u32 p = blockIdx.x, tid = threadIdx.x;
-  const u32 a = coarse_off[p], b = coarse_off[p + 1];
-  h[tid] = 0;
+// Level B works on fixed-size TILES of the partitioned array (not one block per
+// partition), so a partition -- or a single bucket -- of any size is spread over many
+// blocks: balanced for every digit distribution (e.g. a top window that holds only the
+// recoding carry puts n/2 entries into one bucket).
+//   k_fine_hist     per tile: LDS histogram over fine buckets -> global fine histogram
+//   (k_scan_*)      -> off[], cursor[]
+//   k_fine_scatter  per tile: LDS histogram again, reserve one range per touched bucket,
+//                   scatter with LDS cursors
+// The LDS table covers FINE_BINS consecutive buckets starting at the tile's first one
+// (16 partitions); entries beyond it (only when many tiny partitions share a tile) use a
+// global atomic directly.
+#define FINE_TILE 4096
+#define FINE_BINS 4096
+struct FineTile {
+  u32 j0, j1;        // positions covered
+  u32 p_first;       // partition of position j0
+};
+__device__ __forceinline__ FineTile fine_tile_setup(const u32 *__restrict__ coarse_off, u32 P, u32 E, u32 *s_off) {
+  // s_off[0..P] = coarse_off (LDS copy for the partition walk)
+  for (u32 i = threadIdx.x; i <= P; i += 256u) s_off[i] = coarse_off[i];
   __syncthreads();
-  for (u32 j = a + tid; j < b; j += 256u) atomicAdd(&h[part[j] >> 24], 1u);
+  FineTile t;
+  t.j0 = blockIdx.x * FINE_TILE;
+  t.j1 = (t.j0 + FINE_TILE < E) ? t.j0 + FINE_TILE : E;
+  // largest p with s_off[p] <= j0 and s_off[p+1] > j0 (binary search, same in every thread)
+  u32 lo = 0, hi = P;
+  while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (s_off[mid] <= t.j0) lo = mid; else hi = mid; }
+  t.p_first = lo;
+  return t;
+}
+__global__ void __launch_bounds__(256) k_fine_hist(MsmGeom g, u32 P, const u32 *__restrict__ coarse_off, const u32 *__restrict__ part,
+                                                   const u32 *__restrict__ offE, u32 *__restrict__ fine_hist) {
+  __shared__ u32 s_off[PART_MAX + 1];
+  __shared__ u32 bins[FINE_BINS];
+  const u32 E = offE[0];
+  if (blockIdx.x * FINE_TILE >= E) return;
+  const FineTile t = fine_tile_setup(coarse_off, P, E, s_off);
+  for (u32 i = threadIdx.x; i < FINE_BINS; i += 256u) bins[i] = 0;
   __syncthreads();
-  const u32 cnt = h[tid];
-  sc_[tid] = cnt;
-  __syncthreads();
-  for (u32 d = 1; d < 256; d <<= 1) {
-    const u32 t = tid >= d ? sc_[tid - d] : 0;
-    __syncthreads();
-    sc_[tid] += t;
-    __syncthreads();
+  const u32 g_first = t.p_first * 256u;
+  u32 pcur = t.p_first;
+  for (u32 j = t.j0 + threadIdx.x; j < t.j1; j += 256u) {
+    while (j >= s_off[pcur + 1]) pcur++;
+    const u32 key = pcur * 256u + (part[j] >> 24);
+    const u32 rel = key - g_first;
+    if (rel < FINE_BINS) atomicAdd(&bins[rel], 1u); else atomicAdd(&fine_hist[key], 1u);
   }
-  const u32 lo = a + sc_[tid] - cnt;            // first sorted position of fine bucket (p, tid)
-  off[p * 256u + tid] = lo;
-  fill_chunk_keys(chunk_key, g.L, p * 256u + tid, lo, lo + cnt);
-  h[tid] = lo;                                  // becomes the running cursor
   __syncthreads();
-  for (u32 j = a + tid; j < b; j += 256u) {
+  for (u32 i = threadIdx.x; i < FINE_BINS; i += 256u) { const u32 v = bins[i]; if (v) atomicAdd(&fine_hist[g_first + i], v); }
+}
+__global__ void __launch_bounds__(256) k_fine_scatter(MsmGeom g, u32 P, const u32 *__restrict__ coarse_off, const u32 *__restrict__ part,
+                                                      const u32 *__restrict__ offE, u32 *__restrict__ cursor, u32 *__restrict__ sidx) {
+  __shared__ u32 s_off[PART_MAX + 1];
+  __shared__ u32 bins[FINE_BINS];
+  const u32 E = offE[0];
+  if (blockIdx.x * FINE_TILE >= E) return;
+  const FineTile t = fine_tile_setup(coarse_off, P, E, s_off);
+  for (u32 i = threadIdx.x; i < FINE_BINS; i += 256u) bins[i] = 0;
+  __syncthreads();
+  const u32 g_first = t.p_first * 256u;
+  u32 pcur = t.p_first;
+  for (u32 j = t.j0 + threadIdx.x; j < t.j1; j += 256u) {
+    while (j >= s_off[pcur + 1]) pcur++;
+    const u32 rel = pcur * 256u + (part[j] >> 24) - g_first;
+    if (rel < FINE_BINS) atomicAdd(&bins[rel], 1u);
+  }
+  __syncthreads();
+  // reserve this tile's range in every touched bucket: count -> base position
+  for (u32 i = threadIdx.x; i < FINE_BINS; i += 256u) { const u32 v = bins[i]; if (v) bins[i] = atomicAdd(&cursor[g_first + i], v); }
+  __syncthreads();
+  pcur = t.p_first;
+  for (u32 j = t.j0 + threadIdx.x; j < t.j1; j += 256u) {
+    while (j >= s_off[pcur + 1]) pcur++;
     const u32 e = part[j];
-    const u32 pos = atomicAdd(&h[e >> 24], 1u);
+    const u32 key = pcur * 256u + (e >> 24);
+    const u32 rel = key - g_first;
+    const u32 pos = (rel < FINE_BINS) ? atomicAdd(&bins[rel], 1u) : atomicAdd(&cursor[key], 1u);
     sidx[pos] = (e & 0x7FFFFFu) | ((e & 0x800000u) << 8);
   }
 }
@@ -806,15 +857,19 @@ __global__ void __launch_bounds__(256) k_sc_fold(const u32 *lo, const u32 *hi, S
 // ------------------------------------------------------------------------------------
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// Window bits from the tools/tune_msm.py sweeps on MI355X (profiles/r01_tune_msm.txt).
+// Besides the usual bucket-count trade-off, windows whose TOP window holds only a few
+// bits (255 mod c small: c = 15, 14, 12, 11) concentrate a whole window's digits in a
+// handful of buckets, so c in {8, 13, 16} (top window 7, 8, 15 bits) are preferred.
 static u32 pick_window_bits(const bpmi_ctx *ctx, uint64_t n) {
   if (ctx->opt_c >= 2 && ctx->opt_c <= 16) return (u32)ctx->opt_c;
+  if (n >= (1u << 19)) return 16;
+  if (n >= (1u << 15)) return 13;
+  if (n >= (1u << 10)) return 8;
   u32 lg = 0;
   while ((1ull << (lg + 1)) <= n) lg++;
-  int c = (int)lg - 3;
-  if (n >= (1u << 19)) c = (int)lg - 4;
-  if (c < 4) c = 4;
-  if (c > 16) c = 16;
-  return (u32)c;
+  const int c = (int)lg - 2;
+  return (u32)(c < 4 ? 4 : c);
 }
 
 struct MsmWs {
@@ -866,7 +921,7 @@ static int msm_run(bpmi_ctx *ctx, const Segs &segs, uint8_t out[64]) {
   g.W = 255u / g.c + 1u;
   g.B = 1u << (g.c - 1);
   g.G = g.W * g.B;
-  g.L = ctx->opt_chunk > 0 ? (u32)ctx->opt_chunk : 32u;
+  g.L = ctx->opt_chunk > 0 ? (u32)ctx->opt_chunk : (n >= (1u << 19) ? 64u : 32u);   // tools/tune_msm.py sweep
   g.nv = (g.c + 4u) / 5u;
   MsmWs w;
   msm_layout(g, w, nullptr);
@@ -901,7 +956,15 @@ static int msm_run(bpmi_ctx *ctx, const Segs &segs, uint8_t out[64]) {
       StageTimer t(ctx, ST_SCATTER);
       const u32 ntiles = (g.n + TILE_SCALARS - 1) / TILE_SCALARS;
       hipLaunchKernelGGL(k_partition, dim3(std::min<u32>(ntiles, 2048)), dim3(256), 0, st, segs, g, w.P, w.coarse_cursor, w.dig);
-      hipLaunchKernelGGL(k_fine_sort, dim3(w.P), dim3(256), 0, st, g, w.coarse_off, w.dig, w.sidx, w.off, w.chunk_key);
+      // level B over fixed-size tiles of the partitioned array (grid sized for the maximum E)
+      const u32 nft = (u32)(((size_t)g.n * g.W + FINE_TILE - 1) / FINE_TILE);
+      HIPCHK(ctx, hipMemsetAsync(w.hist, 0, 4ull * g.G, st));
+      hipLaunchKernelGGL(k_fine_hist, dim3(nft), dim3(256), 0, st, g, w.P, w.coarse_off, w.dig, w.coarse_off + w.P, w.hist);
+      hipLaunchKernelGGL(k_scan_partials, dim3(w.nscan_blocks), dim3(256), 0, st, w.hist, g.G, w.bsum);
+      hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, w.bsum, w.nscan_blocks, w.off, g.G);
+      hipLaunchKernelGGL(k_scan_final, dim3(w.nscan_blocks), dim3(256), 0, st, w.hist, g.G, w.bsum, w.off, w.cursor);
+      hipLaunchKernelGGL(k_fine_scatter, dim3(nft), dim3(256), 0, st, g, w.P, w.coarse_off, w.dig, w.coarse_off + w.P, w.cursor, w.sidx);
+      hipLaunchKernelGGL(k_chunk_keys, dim3((g.G + 255) / 256), dim3(256), 0, st, g, w.off, w.chunk_key);
     }
     debug_sync(ctx, "ST_SCATTER");
   } else {
