@@ -701,65 +701,120 @@ __global__ void k_tail(const u32 *__restrict__ E, u32 W, u32 nv, u32 c, u32 *__r
 // ------------------------------------------------------------------------------------
 // batched point kernels
 // ------------------------------------------------------------------------------------
-// out[i] = k_i * P_i   (left-to-right double-and-add; lanes diverge only on the add)
-__global__ void __launch_bounds__(256) k_ec_mul_batch(const u32 *__restrict__ pts, const u32 *__restrict__ scs, u32 n, u32 *__restrict__ out) {
+// out[i] = k_i * P_i   (left-to-right double-and-add in Jacobian coordinates; the scalars
+// differ per lane, so lanes diverge on the addition only)
+__global__ void __launch_bounds__(256, 3) k_ec_mul_batch(const u32 *__restrict__ pts, const u32 *__restrict__ scs, u32 n, u32 *__restrict__ out) {
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   affine P;
   load_affine(P, pts + 16ull * i);
   sc s;
   load_words8(s.v, scs + 8ull * i);
-  bool neg = sc_is_high(s);
+  const bool neg = sc_is_high(s);
   if (neg) sc_neg(s, s);
-  affine Q = P;
-  if (neg) affine_neg(Q, P);
-  xyzz acc;
-  xyzz_set_inf(acc);
-  const bool pinf = affine_is_inf(Q);
+  jac acc;
+  jac_set_inf(acc);
+  const bool pinf = affine_is_inf(P);
   for (int word = 7; word >= 0; word--) {
     // static word selection keeps s.v[] in registers
     u32 wv = 0;
 #pragma unroll
     for (int k = 0; k < 8; k++) if (k == word) wv = s.v[k];
     for (int bit = 31; bit >= 0; bit--) {
-      xyzz_dbl(acc, acc);
-      if (((wv >> bit) & 1u) && !pinf) xyzz_madd(acc, Q.x, Q.y);
+      jac_dbl(acc, acc);
+      if (((wv >> bit) & 1u) && !pinf) jac_madd_signed(acc, P.x, P.y, neg);
     }
   }
   affine r;
-  xyzz_to_affine(r, acc);
+  jac_to_affine(r, acc);
   u32 w16[16];
   affine_to_words(w16, r);
   store_words16(out + 16ull * i, w16);
 }
 
 struct Sc2 { u32 k1[8]; u32 k2[8]; };
-// out[i] = k1 * P1_i + k2 * P2_i with k1, k2 shared by all i (Shamir's trick; the branch
-// on the scalar bits is wave-uniform)
-__global__ void __launch_bounds__(256) k_ec_lincomb2(const u32 *p1, const u32 *p2, Sc2 ks, u32 n, u32 *out) {
-  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+
+// Non-adjacent forms of the two shared scalars, computed once on the host: bit i of nz*
+// says digit i is non-zero, bit i of sg* says it is -1.  257 positions each.
+struct NafPair { u32 nz1[9], sg1[9], nz2[9], sg2[9]; int top; };
+static void host_naf(const uint8_t k32[32], u32 nz[9], u32 sg[9], int &top) {
+  u32 w[9];
+  memcpy(w, k32, 32);
+  w[8] = 0;
+  for (int i = 0; i < 9; i++) nz[i] = sg[i] = 0;
+  for (int pos = 0; pos < 257; pos++) {
+    if (w[0] & 1u) {
+      const bool minus = (w[0] & 3u) == 3u;          // k mod 4 == 3 -> digit -1, k += 1
+      nz[pos >> 5] |= 1u << (pos & 31);
+      if (minus) {
+        sg[pos >> 5] |= 1u << (pos & 31);
+        for (int i = 0; i < 9; i++) { if (++w[i] != 0) break; }
+      } else {
+        w[0] &= ~1u;
+      }
+      if (pos > top) top = pos;
+    }
+    for (int i = 0; i < 8; i++) w[i] = (w[i] >> 1) | (w[i + 1] << 31);
+    w[8] >>= 1;
+  }
+}
+
+// out[i] = k1 * P1_i + k2 * P2_i with k1, k2 shared by all i (the generator fold,
+// inner_product_prover.py:107-108).  Jacobian ladder driven by the NAF digits: every
+// branch is on a kernel argument, hence wave-uniform; only mixed additions; the two input
+// points of each thread are parked in LDS ([word][thread], conflict-free) to keep the
+// register count at the ladder's working set.
+struct LincombJob { const u32 *p1, *p2; u32 *out; u32 n; };
+// Two independent jobs share one launch (threads [0, A.n) do job A, the next B.n do job
+// B): a ladder thread is ~2 ms of serial issue, so per-launch latency, not throughput,
+// bounds the small rounds of the IPA -- g and h are therefore folded together.
+__global__ void __launch_bounds__(256, 3) k_ec_lincomb2(LincombJob ja, NafPair nfa, LincombJob jb, NafPair nfb) {
+  __shared__ u32 s_pts[36 * 256];
+  const u32 tid = threadIdx.x;
+  u32 i = blockIdx.x * blockDim.x + tid;
+  const bool second = i >= ja.n;          // may differ inside one wave only at the seam
+  if (second) i -= ja.n;
+  const u32 n = second ? jb.n : ja.n;
   if (i >= n) return;
-  affine A, Bp;
-  load_affine(A, p1 + 16ull * i);
-  load_affine(Bp, p2 + 16ull * i);
-  xyzz T, XA, XB;                              // T = A + B
-  xyzz_from_affine(XA, A);
-  xyzz_from_affine(XB, Bp);
-  xyzz_add(T, XA, XB);
-  xyzz acc;
-  xyzz_set_inf(acc);
-  for (int word = 7; word >= 0; word--) {
-    const u32 w1 = ks.k1[word], w2 = ks.k2[word];
-    for (int bit = 31; bit >= 0; bit--) {
-      xyzz_dbl(acc, acc);
-      const u32 sel = ((w1 >> bit) & 1u) | (((w2 >> bit) & 1u) << 1);
-      if (sel == 1u) xyzz_madd_signed(acc, A, false);
-      else if (sel == 2u) xyzz_madd_signed(acc, Bp, false);
-      else if (sel == 3u) xyzz_add(acc, acc, T);
+  const u32 *p1 = second ? jb.p1 : ja.p1;
+  const u32 *p2 = second ? jb.p2 : ja.p2;
+  u32 *out = second ? jb.out : ja.out;
+  bool inf1, inf2;
+  {
+    affine A;
+    load_affine(A, p1 + 16ull * i);
+    inf1 = affine_is_inf(A);
+#pragma unroll
+    for (int k = 0; k < 9; k++) { s_pts[k * 256 + tid] = A.x.v[k]; s_pts[(9 + k) * 256 + tid] = A.y.v[k]; }
+    load_affine(A, p2 + 16ull * i);
+    inf2 = affine_is_inf(A);
+#pragma unroll
+    for (int k = 0; k < 9; k++) { s_pts[(18 + k) * 256 + tid] = A.x.v[k]; s_pts[(27 + k) * 256 + tid] = A.y.v[k]; }
+  }
+  jac acc;
+  jac_set_inf(acc);
+  const int top = nfa.top > nfb.top ? nfa.top : nfb.top;
+  for (int pos = top; pos >= 0; pos--) {
+    jac_dbl(acc, acc);
+    const u32 m = 1u << (pos & 31);
+    const int wd = pos >> 5;
+    // one inlined copy of the addition serves both points (the loop is kept rolled)
+#pragma unroll 1
+    for (int which = 0; which < 2; which++) {
+      const u32 nzw = second ? (which ? nfb.nz2[wd] : nfb.nz1[wd]) : (which ? nfa.nz2[wd] : nfa.nz1[wd]);
+      const u32 sgw = second ? (which ? nfb.sg2[wd] : nfb.sg1[wd]) : (which ? nfa.sg2[wd] : nfa.sg1[wd]);
+      const bool isinf = which ? inf2 : inf1;
+      if ((nzw & m) && !isinf) {
+        fe x, y;
+        const u32 base = which ? 18u * 256u : 0u;
+#pragma unroll
+        for (int k = 0; k < 9; k++) { x.v[k] = s_pts[base + k * 256 + tid]; y.v[k] = s_pts[base + (9 + k) * 256 + tid]; }
+        jac_madd_signed(acc, x, y, (sgw & m) != 0);
+      }
     }
   }
   affine r;
-  xyzz_to_affine(r, acc);
+  jac_to_affine(r, acc);
   u32 w16[16];
   affine_to_words(w16, r);
   store_words16(out + 16ull * i, w16);
@@ -1196,21 +1251,34 @@ int bpmi_ec_mul_batch(bpmi_ctx *ctx, const uint8_t *pts, const uint8_t *scalars,
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return BPMI_OK;
 }
+static void make_naf_pair(NafPair &nf, const uint8_t k1[32], const uint8_t k2[32]) {
+  nf.top = -1;
+  host_naf(k1, nf.nz1, nf.sg1, nf.top);
+  host_naf(k2, nf.nz2, nf.sg2, nf.top);
+}
+// out_a[i] = ka1 * a1[i] + ka2 * a2[i] (i < na)  and  out_b[i] = kb1 * b1[i] + kb2 * b2[i] (i < nb), one launch
+static int lincomb2_pair_dev(bpmi_ctx *ctx, const void *a1, const void *a2, const uint8_t ka1[32], const uint8_t ka2[32], uint64_t na, void *out_a,
+                             const void *b1, const void *b2, const uint8_t kb1[32], const uint8_t kb2[32], uint64_t nb, void *out_b) {
+  LincombJob ja = {(const u32 *)a1, (const u32 *)a2, (u32 *)out_a, (u32)na};
+  LincombJob jb = {(const u32 *)b1, (const u32 *)b2, (u32 *)out_b, (u32)nb};
+  NafPair nfa, nfb;
+  make_naf_pair(nfa, ka1, ka2);
+  if (nb) make_naf_pair(nfb, kb1, kb2); else { memset(&nfb, 0, sizeof(nfb)); nfb.top = -1; }
+  const uint64_t total = na + nb;
+  {
+    StageTimer t(ctx, ST_LINCOMB2);
+    hipLaunchKernelGGL(k_ec_lincomb2, dim3((u32)((total + 255) / 256)), dim3(256), 0, ctx->stream, ja, nfa, jb, nfb);
+  }
+  HIPCHK(ctx, hipGetLastError());
+  return BPMI_OK;
+}
 int bpmi_ec_lincomb2_batch_dev(bpmi_ctx *ctx, const void *d_p1, const void *d_p2, const uint8_t k1[32], const uint8_t k2[32],
                                uint64_t n, void *d_out) {
   if (!ctx || !k1 || !k2 || (n && (!d_p1 || !d_p2 || !d_out))) return ctx ? fail(ctx, BPMI_E_ARG, "null argument") : BPMI_E_ARG;
   if (n > BPMI_MAX_N) return fail(ctx, BPMI_E_ARG, "n exceeds BPMI_MAX_N");
   if (n == 0) return BPMI_OK;
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  Sc2 ks;
-  memcpy(ks.k1, k1, 32); memcpy(ks.k2, k2, 32);
-  {
-    StageTimer t(ctx, ST_LINCOMB2);
-    hipLaunchKernelGGL(k_ec_lincomb2, dim3((u32)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const u32 *)d_p1,
-                       (const u32 *)d_p2, ks, (u32)n, (u32 *)d_out);
-  }
-  HIPCHK(ctx, hipGetLastError());
-  return BPMI_OK;
+  return lincomb2_pair_dev(ctx, d_p1, d_p2, k1, k2, n, d_out, nullptr, nullptr, nullptr, nullptr, 0, nullptr);
 }
 int bpmi_ec_lincomb2_batch(bpmi_ctx *ctx, const uint8_t *p1, const uint8_t *p2, const uint8_t k1[32], const uint8_t k2[32],
                            uint64_t n, uint8_t *out) {
@@ -1430,9 +1498,8 @@ int bpmi_ipa_fold(bpmi_ipa *st, const uint8_t x[32], const uint8_t xinv[32]) {
   int rc;
   // g' = x^-1 g_lo + x g_hi ; h' = x h_lo + x^-1 h_hi  (:107-108); in place: thread i
   // reads elements i and np+i and writes element i only
-  rc = bpmi_ec_lincomb2_batch_dev(ctx, st->g, st->g + 16 * np, xinv, x, np, st->g);
-  if (rc) return rc;
-  rc = bpmi_ec_lincomb2_batch_dev(ctx, st->h, st->h + 16 * np, x, xinv, np, st->h);
+  rc = lincomb2_pair_dev(ctx, st->g, st->g + 16 * np, xinv, x, np, st->g,
+                         st->h, st->h + 16 * np, x, xinv, np, st->h);
   if (rc) return rc;
   // a' = x a_lo + x^-1 a_hi ; b' = x^-1 b_lo + x b_hi  (:109-110)
   rc = bpmi_sc_fold_dev(ctx, st->a, st->a + 8 * np, x, xinv, np, st->a);

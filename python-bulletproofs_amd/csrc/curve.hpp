@@ -178,6 +178,89 @@ BPMI_HD void xyzz_to_affine(affine &r, const xyzz &a) {
   fe_canon(r.x, r.x); fe_canon(r.y, r.y);
 }
 
+// ---- Jacobian coordinates (x = X/Z^2, y = Y/Z^3; identity = Z == 0) ------------------
+// Used by the doubling-heavy ladders (generator fold, batch scalar multiplication):
+// doubling is 2M + 5S here against 6M + 3S in XYZZ.
+struct jac { fe X, Y, Z; };              // tight limbs
+
+BPMI_HD void jac_set_inf(jac &r) { fe_set_zero(r.X); fe_set_one(r.Y); fe_set_zero(r.Z); }
+BPMI_HD bool jac_is_inf(const jac &a) { return fe_is_zero_tight(a.Z); }
+
+// r = 2a (dbl-2009-l, curve a = 0).  Z = 0 maps to Z = 0, so the identity needs no branch;
+// Y = 0 cannot occur (no 2-torsion on a prime-order curve).
+BPMI_HD void jac_dbl(jac &r, const jac &a) {
+  // statement order keeps at most ~6 field elements live (register pressure decides the
+  // occupancy of the ladder kernels)
+  fe A, B, C, D, E, t;
+  fe_mul(t, a.Y, a.Z);
+  fe_sqr(B, a.Y);
+  fe_sqr(A, a.X);
+  fe_add(D, a.X, B);                     // mag 2
+  fe_add(r.Z, t, t); fe_carry(r.Z, r.Z); // Z3 = 2YZ   (a.Y, a.Z dead from here)
+  fe_sqr(D, D);                          // (X + B)^2
+  fe_sqr(C, B);
+  fe_sub(D, D, A); fe_sub(D, D, C);      // mag 5
+  fe_carry(D, D);
+  fe_add(D, D, D); fe_carry(D, D);       // D = 2((X+B)^2 - A - C), tight
+  fe_mul_small(E, A, 3); fe_carry(E, E); // E = 3A, tight
+  fe_sqr(t, E);
+  fe_sub(t, t, D); fe_sub(t, t, D);      // mag 5
+  fe_carry(r.X, t);
+  fe_sub(t, D, r.X);                     // mag 3
+  fe_mul(t, E, t);
+  fe_mul_small(C, C, 8); fe_carry(C, C); // 8C
+  fe_sub(t, t, C); fe_carry(r.Y, t);
+}
+// acc += (x2, y2), affine addend that is NOT the identity: 8M + 3S, complete
+BPMI_HD void jac_madd(jac &acc, const fe &x2, const fe &y2) {
+  if (jac_is_inf(acc)) { acc.X = x2; acc.Y = y2; fe_set_one(acc.Z); return; }
+  fe H, R, HH, V, t;
+  fe_sqr(HH, acc.Z);                     // Z1Z1
+  fe_mul(H, x2, HH);                     // U2
+  fe_mul(t, y2, acc.Z);
+  fe_mul(R, t, HH);                      // S2
+  fe_sub(H, H, acc.X); fe_carry(H, H);   // H = U2 - X1
+  fe_sub(R, R, acc.Y); fe_carry(R, R);   // R = S2 - Y1
+  if (fe_is_zero_tight(H)) {
+    if (fe_is_zero_tight(R)) {           // acc == addend: double the affine point
+      jac d; d.X = x2; d.Y = y2; fe_set_one(d.Z);
+      jac_dbl(acc, d);
+      return;
+    }
+    jac_set_inf(acc); return;            // acc == -addend
+  }
+  fe_sqr(HH, H);
+  fe_mul(acc.Z, acc.Z, H);               // Z3
+  fe_mul(H, H, HH);                      // HHH
+  fe_mul(V, acc.X, HH);
+  fe_mul(HH, acc.Y, H);                  // Y1 * HHH
+  fe_sqr(t, R);
+  fe_sub(t, t, H); fe_sub(t, t, V); fe_sub(t, t, V);   // mag 7
+  fe_carry(acc.X, t);
+  fe_sub(t, V, acc.X);                   // mag 3
+  fe_mul(t, R, t);
+  fe_sub(t, t, HH); fe_carry(acc.Y, t);
+}
+// y-sign as a select (see xyzz_madd_signed)
+BPMI_HD void jac_madd_signed(jac &acc, const fe &x2, const fe &y2, bool negate) {
+  fe ny, t;
+  fe_neg(t, y2);
+  fe_carry(ny, t);
+#pragma unroll
+  for (int k = 0; k < 9; k++) ny.v[k] = negate ? ny.v[k] : y2.v[k];
+  jac_madd(acc, x2, ny);
+}
+BPMI_HD void jac_to_affine(affine &r, const jac &a) {
+  if (jac_is_inf(a)) { fe_set_zero(r.x); fe_set_zero(r.y); return; }
+  fe zi, zi2, zi3;
+  fe_inv(zi, a.Z);
+  fe_sqr(zi2, zi);
+  fe_mul(zi3, zi2, zi);
+  fe_mul(r.x, a.X, zi2);
+  fe_mul(r.y, a.Y, zi3);
+  fe_canon(r.x, r.x); fe_canon(r.y, r.y);
+}
+
 // XYZZ record in memory: 4 x 9 u32 (144 B), limb form as is
 BPMI_HD void xyzz_store(u32 *dst, const xyzz &a) {
 #pragma unroll

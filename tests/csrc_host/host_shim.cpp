@@ -55,6 +55,27 @@ void t_xyzz_sum(const uint8_t *pts, int n, int pre, uint8_t *out) {
   }
   affine r; xyzz_to_affine(r, acc); store_aff(out, r);
 }
+// Jacobian ladder: out = k * P by double-and-add with signed additions of +-P (bits of k,
+// `neg` flips every addition and the result is negated back), exercising jac_dbl / jac_madd
+void t_jac_mul(const uint8_t *pt, const uint8_t *k32, int neg, uint8_t *out) {
+  affine p; load_aff(p, pt);
+  jac acc; jac_set_inf(acc);
+  if (!affine_is_inf(p)) {
+    for (int i = 255; i >= 0; i--) {
+      jac_dbl(acc, acc);
+      if ((k32[i >> 3] >> (i & 7)) & 1) jac_madd_signed(acc, p.x, p.y, neg != 0);
+    }
+  }
+  affine r; jac_to_affine(r, acc);
+  if (neg) { affine nr; affine_neg(nr, r); r = nr; }
+  store_aff(out, r);
+}
+// chain of jac_madd with arbitrary points / signs (exceptional cases)
+void t_jac_madd_chain(const uint8_t *pts, const uint8_t *neg, int n, uint8_t *out) {
+  jac acc; jac_set_inf(acc);
+  for (int i = 0; i < n; i++) { affine p; load_aff(p, pts + 64 * i); if (!affine_is_inf(p)) jac_madd_signed(acc, p.x, p.y, neg[i] != 0); }
+  affine r; jac_to_affine(r, acc); store_aff(out, r);
+}
 void t_xyzz_dbl_n(const uint8_t *pt, int n, uint8_t *out) {
   affine p; load_aff(p, pt);
   xyzz q; xyzz_from_affine(q, p);

@@ -29,6 +29,8 @@ def shim():
     L.t_madd_chain.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p]
     L.t_xyzz_sum.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_char_p]
     L.t_xyzz_dbl_n.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p]
+    L.t_jac_mul.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p]
+    L.t_jac_madd_chain.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p]
     return L
 
 
@@ -118,3 +120,25 @@ def test_xyzz_add_and_double(shim):
     out = ctypes.create_string_buffer(64)
     shim.t_xyzz_dbl_n(point_to_le64(INF), 3, out)
     assert point_from_le64(out.raw) == INF
+
+
+def test_jacobian_ladder_and_exceptions(shim):
+    from helpers import Q
+    pts = gens(10, seed(33))
+    rnd = random.Random(8)
+    ks = [0, 1, 2, 3, Q - 1, Q - 2, (Q - 1) // 2, 2**255, 2**256 - 1] + [rnd.randrange(2**256) for _ in range(20)]
+    for k in ks:
+        for neg in (0, 1):
+            out = ctypes.create_string_buffer(64)
+            shim.t_jac_mul(point_to_le64(pts[0]), k.to_bytes(32, "little"), neg, out)
+            assert point_from_le64(out.raw) == (k % Q) * pts[0], (k, neg)
+    out = ctypes.create_string_buffer(64)
+    shim.t_jac_mul(point_to_le64(INF), (5).to_bytes(32, "little"), 0, out)
+    assert point_from_le64(out.raw) == INF
+    A, B = pts[1], pts[2]
+    for lst, negs, want in (([A, A], [0, 0], 2 * A), ([A, A], [0, 1], INF), ([A, A, B], [0, 1, 0], B),
+                            ([A, B, A + B], [0, 0, 1], INF), ([A, B, A + B], [0, 0, 0], 2 * (A + B)),
+                            ([A, A, A, A, A], [0] * 5, 5 * A), ([A, INF, B], [0, 0, 1], A - B)):
+        out = ctypes.create_string_buffer(64)
+        shim.t_jac_madd_chain(b"".join(point_to_le64(p) for p in lst), bytes(negs), len(lst), out)
+        assert point_from_le64(out.raw) == want
