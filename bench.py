@@ -133,6 +133,14 @@ def main():
 
     pairs_per_s = world * n * args.steps / elapsed
     # dominant kernel: msm_accumulate (one launch per MSM processes all n pairs)
+    traffic = None
+    try:   # per-launch HBM bytes of the dominant kernel from the committed rocprofv3 --pmc passes
+        with open(os.path.join(REPO, "profiles", "r01_pmc_traffic_msm_n2e20.json")) as f:
+            for row in json.load(f)["kernels"]:
+                if row["kernel"] == "k_accum_l0" and args.logn == 20:
+                    traffic = row["hbm_bytes_per_launch_guide_corrected"]
+    except (OSError, KeyError, ValueError):
+        pass
     acc_ms, acc_calls = prof["msm_accumulate"]
     acc_avg_s = acc_ms / max(acc_calls, 1) / 1e3
     achieved_gbs = ALGO_BYTES_PER_PAIR * n / acc_avg_s / 1e9 if acc_avg_s > 0 else 0.0
@@ -155,7 +163,8 @@ def main():
                                "inputs resident in HBM, 64-byte result to host every step" % args.logn,
                    "pairs_per_gpu": n, "sharding": "pairs across ranks, one all_gather of 64 B partials per step"},
         "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                     "traffic_source": "profiles/r01_pmc_traffic_msm_n2e20.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)",
                      "kernel": "k_accum_l0 (msm_accumulate)", "kernel_avg_ms": acc_avg_s * 1e3,
                      "note": "integer-ALU bound path: 96 algorithmic B/pair vs ~1.8e5 integer ops/pair"},
         "stage_ms_per_msm": stages,
