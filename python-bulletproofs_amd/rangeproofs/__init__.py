@@ -3,5 +3,7 @@ from .rangeproof_verifier import RangeVerifier
 from .rangeproof_aggreg_prover import AggregNIRangeProver
 from .rangeproof_aggreg_verifier import AggregRangeVerifier
 from .common import Proof
+from .batch import BatchRangeVerifier, batch_verify
 
-__all__ = ["NIRangeProver", "RangeVerifier", "AggregNIRangeProver", "AggregRangeVerifier", "Proof"]
+__all__ = ["NIRangeProver", "RangeVerifier", "AggregNIRangeProver", "AggregRangeVerifier", "Proof",
+           "BatchRangeVerifier", "batch_verify"]

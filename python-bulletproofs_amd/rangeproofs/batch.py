@@ -1,0 +1,141 @@
+"""Batch verification of 64-bit-style single range proofs that share (g, h, u, gs, hs):
+every proof's four EC verification equations are combined with fresh random weights into
+ONE multi-scalar multiplication that must evaluate to the identity (SURVEY.md section
+8f item 3; not present in the reference, which verifies one proof at a time).
+
+For proof k (notation of the reference: rangeproof_verifier.py:55-99,
+inner_product_verifier.py:44-58,127-147), with hsp_i = y^-i * hs_i folded into scalars:
+
+  E1  (t_hat - delta) g + taux h - z^2 V - x T1 - x^2 T2                         = 0
+  E2  P_new - A - x S + sum_i z gs_i - sum_i (z y^i + z^2 2^i) y^-i hs_i
+        + mu h - (x_ip t_hat) u                                                  = 0
+  E3  u_new - x_ip u                                                             = 0
+  E4  sum_i (a s_i) gs_i + sum_i (b s_i^-1 y^-i) hs_i + (a b) u_new
+        - P_new - sum_j (x_j^2 L_j + x_j^-2 R_j)                                 = 0
+
+E1 is the range-proof polynomial check, E2 / E3 are Verifier1's two point equalities, E4
+is Verifier2's final check.  All byte-level transcript checks of the three verifiers are
+performed exactly as the individual verifiers do (host side) when a proof is added.
+With independent uniform weights w1..w4 per proof, a batch containing any failing equation
+passes with probability about 1/q.  Cost: 19 points per proof + 2n + 3 shared points in
+one MSM, instead of ~8 latency-bound GPU calls per proof.
+
+The shards of a multi-GPU batch are disjoint sets of proofs: every rank builds the MSM of
+its own proofs (with its own share of the shared-generator coefficients) and the 64-byte
+partial results are combined with one all_gather + fold (distributed.ShardedMSM.combine).
+"""
+import secrets
+
+from .. import engine as _engine
+from ..ec import Point, secp256k1
+from ..innerproduct.inner_product_verifier import Verifier1, Verifier2
+from .rangeproof_verifier import RangeVerifier
+
+Q = secp256k1.q
+_ZERO64 = bytes(64)
+
+
+def _le32(v):
+    return (v % Q).to_bytes(32, "little")
+
+
+class BatchRangeVerifier:
+    def __init__(self, g, h, gs, hs, u, msm=None, rng=None):
+        """msm(points_bytes, scalar_bytes, n) -> 64 bytes; default: the HIP engine.
+        rng() -> int: source of the random weights; default: secrets (CSPRNG)."""
+        assert len(gs) == len(hs)
+        self.g, self.h, self.gs, self.hs, self.u = g, h, gs, hs, u
+        self.n = len(gs)
+        self._msm = msm
+        self._rng = rng or (lambda: secrets.randbits(320))
+        self._shared_pts = g.to_le64() + h.to_le64() + u.to_le64() + b"".join(p.to_le64() for p in gs) + \
+            b"".join(p.to_le64() for p in hs)
+        self.reset()
+
+    def reset(self):
+        self.c_g = self.c_h = self.c_u = 0
+        self.c_gs = [0] * self.n
+        self.c_hs = [0] * self.n
+        self._pts = []          # per-proof points, 64-byte strings
+        self._scs = []          # matching scalars (ints mod q)
+        self.count = 0
+
+    def _weight(self):
+        w = self._rng() % Q
+        return w or 1
+
+    def add(self, V, proof):
+        """Host-side transcript checks of RangeVerifier / Verifier1 / Verifier2 (raise
+        Exception("Proof invalid") exactly as they do), then accumulate the proof's
+        weighted equations."""
+        n, q = self.n, Q
+        rv = RangeVerifier(V, self.g, self.h, self.gs, self.hs, self.u, proof)
+        rv.verify_transcript()                               # A, S, T1, T2 bytes; reads y, z, x
+        x, y, z = rv.x.x % q, rv.y.x % q, rv.z.x % q
+        ip = proof.innerProof
+        v1 = Verifier1(self.gs, None, self.u, None, proof.t_hat, ip)
+        v1.verify_transcript()                               # x_ip = H(transcript)
+        x_ip = int(ip.transcript.split(b"&")[1]) % q
+        p2 = ip.proof2
+        Verifier2(self.gs, None, None, None, p2).verify_transcript()   # L, R bytes; every x_j re-hashed
+        log_n = n.bit_length() - 1
+        rv.assertThat(len(p2.xs) == log_n and len(p2.Ls) == log_n and len(p2.Rs) == log_n)
+        xs = [xj.x % q for xj in p2.xs]
+        a, b = p2.a.x % q, p2.b.x % q
+        t_hat, taux, mu = proof.t_hat.x % q, proof.taux.x % q, proof.mu.x % q
+
+        w1, w2, w3, w4 = self._weight(), self._weight(), self._weight(), self._weight()
+        # powers and the s-vector (get_ss, inner_product_verifier.py:91-102) with plain ints
+        yinv = pow(y, -1, q)
+        xinvs = [pow(v, -1, q) for v in xs]
+        ss, si = [1], [1]
+        for xv, xi in zip(reversed(xs), reversed(xinvs)):
+            ss = [s * xi % q for s in ss] + [s * xv % q for s in ss]
+            si = [s * xv % q for s in si] + [s * xi % q for s in si]
+        z2 = z * z % q
+        ysum, yp, ypi, two = 0, 1, 1, 1
+        w2z, w4a, w4b, w2z2 = w2 * z % q, w4 * a % q, w4 * b % q, w2 * z2 % q
+        for i in range(n):
+            ysum += yp
+            self.c_gs[i] = (self.c_gs[i] + w2z + w4a * ss[i]) % q
+            # y^-i * ( -w2 (z y^i + z^2 2^i) + w4 b s_i^-1 )
+            self.c_hs[i] = (self.c_hs[i] - w2z + ypi * ((w4b * si[i] - w2z2 * two) % q)) % q
+            yp = yp * y % q
+            ypi = ypi * yinv % q
+            two = two * 2 % q
+        delta = ((z - z2) * ysum - z2 * z * ((1 << n) - 1)) % q
+        self.c_g = (self.c_g + w1 * (t_hat - delta)) % q
+        self.c_h = (self.c_h + w1 * taux + w2 * mu) % q
+        self.c_u = (self.c_u - w2 * x_ip % q * t_hat - w3 * x_ip) % q
+        pts = [V, proof.T1, proof.T2, proof.A, proof.S, ip.P_new, ip.u_new] + list(p2.Ls) + list(p2.Rs)
+        scs = [-w1 * z2, -w1 * x, -w1 * x % q * x, -w2, -w2 * x, w2 - w4, w3 + w4 * a % q * b]
+        scs += [-w4 * xv % q * xv for xv in xs] + [-w4 * xi % q * xi for xi in xinvs]
+        self._pts.append(b"".join(p.to_le64() for p in pts))
+        self._scs.extend(scs)
+        self.count += 1
+
+    def partial(self):
+        """The 64-byte value of this verifier's accumulated combination (one MSM)."""
+        shared = [self.c_g, self.c_h, self.c_u] + self.c_gs + self.c_hs
+        pts = self._shared_pts + b"".join(self._pts)
+        scs = b"".join(_le32(v) for v in shared) + b"".join(_le32(v) for v in self._scs)
+        npts = 3 + 2 * self.n + len(self._scs)
+        msm = self._msm or _engine.default_engine().msm_bytes
+        return msm(pts, scs, npts)
+
+    def verify(self, sharded=None):
+        """True if every added proof is valid; raises Exception("Proof invalid") otherwise.
+        `sharded`: a distributed.ShardedMSM whose combine() folds the ranks' partials."""
+        part = self.partial()
+        if sharded is not None:
+            part = sharded.combine(part)
+        if part != _ZERO64:
+            raise Exception("Proof invalid")
+        return True
+
+
+def batch_verify(Vs, proofs, g, h, gs, hs, u, **kw):
+    bv = BatchRangeVerifier(g, h, gs, hs, u, **kw)
+    for V, pr in zip(Vs, proofs):
+        bv.add(V, pr)
+    return bv.verify()

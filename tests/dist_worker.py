@@ -24,7 +24,38 @@ def oracle_fold(buf, k):
     return point_to_le64(acc)
 
 
+def batch_mode():
+    """Each rank batch-verifies its own half of the proofs; the partial values fold to the
+    identity iff the whole batch is valid."""
+    from test_batch_verify_cpu import make_batch, oracle_msm
+    from bulletproofs_amd.rangeproofs.batch import BatchRangeVerifier
+    from bulletproofs_amd.utils.utils import ModP
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    b = make_batch(5)
+    sm = ShardedMSM(msm=oracle_msm, fold=oracle_fold)
+    lo, hi = shard_bounds(5, world, rank)
+    for corrupt in (False, True):
+        bv = BatchRangeVerifier(b["g"], b["h"], b["gs"], b["hs"], b["u"], msm=oracle_msm)
+        for k in range(lo, hi):
+            pr = b["proofs"][k]
+            if corrupt and k == 4:
+                pr.mu = pr.mu + ModP(1, secp256k1.q)
+            bv.add(b["Vs"][k], pr)
+        try:
+            ok = bv.verify(sharded=sm)
+        except Exception as e:
+            ok = str(e)
+        assert ok == ("Proof invalid" if corrupt else True), (rank, corrupt, ok)
+    dist.barrier()
+    if rank == 0:
+        print("DIST_BATCH_OK world=%d" % world)
+    dist.destroy_process_group()
+
+
 def main():
+    if os.environ.get("BPMI_DIST_MODE") == "batch":
+        return batch_mode()
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     Q = secp256k1.q

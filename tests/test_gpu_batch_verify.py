@@ -1,0 +1,125 @@
+"""Random-linear-combination batch verifier (bulletproofs_amd.rangeproofs.batch): it must
+accept exactly when every proof is individually accepted.  The oracle for it is the
+individual verifier (product and oracle restatement), since the reference has no batch
+verifier; every cheating mutation of the reference's tests, applied to one proof of the
+batch, must make the batch fail."""
+import copy
+import random
+
+import pytest
+
+from helpers import Q, gens
+from oracle import bp_ref as R
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gp():
+    import gpu_common
+    return gpu_common
+
+
+@pytest.fixture(scope="module")
+def batch(gp):
+    from bulletproofs_amd.ec import secp256k1
+    from bulletproofs_amd.rangeproofs import NIRangeProver
+    from bulletproofs_amd.utils import ModP, mod_hash, commitment
+    n = 16
+    gs, hs = gp.to_gpu_list(gens(n, b"bgs")), gp.to_gpu_list(gens(n, b"bhs"))
+    g, h, u = (gp.to_gpu(R.elliptic_hash(s)) for s in (b"bg", b"bh", b"bu"))
+    rnd = random.Random(1)
+    Vs, proofs = [], []
+    for k in range(6):
+        v = ModP(rnd.randrange(2 ** n), Q)
+        gamma = mod_hash(b"gamma%d" % k, Q)
+        Vs.append(commitment(g, h, v, gamma))
+        proofs.append(NIRangeProver(v, n, g, h, gs, hs, gamma, u, secp256k1, b"seed%d" % k).prove())
+    return dict(n=n, gs=gs, hs=hs, g=g, h=h, u=u, Vs=Vs, proofs=proofs)
+
+
+def run(b, Vs, proofs, seed=7):
+    from bulletproofs_amd.rangeproofs import batch_verify
+    rnd = random.Random(seed)
+    return batch_verify(Vs, proofs, b["g"], b["h"], b["gs"], b["hs"], b["u"], rng=lambda: rnd.getrandbits(320))
+
+
+def test_batch_accepts_valid_proofs(gp, batch):
+    from bulletproofs_amd.rangeproofs import RangeVerifier, BatchRangeVerifier
+    b = batch
+    assert run(b, b["Vs"], b["proofs"]) is True
+    assert run(b, b["Vs"][:1], b["proofs"][:1]) is True
+    for V, pr in zip(b["Vs"], b["proofs"]):
+        assert RangeVerifier(V, b["g"], b["h"], b["gs"], b["hs"], b["u"], pr).verify() is True
+    # default CSPRNG weights, incremental use and reset
+    bv = BatchRangeVerifier(b["g"], b["h"], b["gs"], b["hs"], b["u"])
+    for V, pr in zip(b["Vs"], b["proofs"]):
+        bv.add(V, pr)
+    assert bv.count == 6 and bv.verify() is True
+    bv.reset()
+    assert bv.verify() is True          # empty batch: all coefficients zero -> identity
+
+
+MUTATIONS = ["taux", "mu", "t_hat", "T1", "T2", "A_point_only", "V", "inner_a", "inner_b", "L0", "R_last",
+             "u_new", "P_new", "swap_V"]
+
+
+@pytest.mark.parametrize("what", MUTATIONS)
+def test_batch_rejects_one_bad_proof(gp, batch, what):
+    from bulletproofs_amd.rangeproofs import RangeVerifier
+    from bulletproofs_amd.utils import ModP
+    b = batch
+    Vs, proofs = list(b["Vs"]), [copy.deepcopy(p) for p in b["proofs"]]
+    k = 3
+    pr = proofs[k]
+    one = ModP(1, Q)
+    if what == "taux":
+        pr.taux = pr.taux + one
+    elif what == "mu":
+        pr.mu = pr.mu + one
+    elif what == "t_hat":
+        pr.t_hat = pr.t_hat + one
+    elif what == "T1":
+        pr.T1 = pr.T1 + b["g"]
+    elif what == "T2":
+        pr.T2 = pr.T2 + b["g"]
+    elif what == "A_point_only":
+        pr.A = pr.A + b["g"]            # transcript no longer matches -> host check fails
+    elif what == "V":
+        Vs[k] = Vs[k] + b["g"]
+    elif what == "inner_a":
+        pr.innerProof.proof2.a = pr.innerProof.proof2.a + one
+    elif what == "inner_b":
+        pr.innerProof.proof2.b = pr.innerProof.proof2.b + one
+    elif what == "L0":
+        pr.innerProof.proof2.Ls[0] = pr.innerProof.proof2.Ls[0] + b["g"]
+    elif what == "R_last":
+        pr.innerProof.proof2.Rs[-1] = pr.innerProof.proof2.Rs[-1] + b["g"]
+    elif what == "u_new":
+        pr.innerProof.u_new = pr.innerProof.u_new + b["g"]
+    elif what == "P_new":
+        pr.innerProof.P_new = pr.innerProof.P_new + b["g"]
+    elif what == "swap_V":
+        Vs[k], Vs[k + 1] = Vs[k + 1], Vs[k]
+    # the individual verifier rejects the mutated proof ...
+    with pytest.raises(Exception, match="Proof invalid"):
+        RangeVerifier(Vs[k], b["g"], b["h"], b["gs"], b["hs"], b["u"], proofs[k]).verify()
+    # ... and so does the batch, under several independent weight draws
+    for seed in (1, 2, 3):
+        with pytest.raises(Exception, match="Proof invalid"):
+            run(b, Vs, proofs, seed)
+
+
+def test_batch_partials_add_up(gp, batch):
+    """Sharding by proof: the partial values of two disjoint sub-batches fold to the
+    identity exactly when the whole batch is valid."""
+    from bulletproofs_amd.rangeproofs import BatchRangeVerifier
+    b = batch
+    eng = gp.engine()
+    parts = []
+    for lo, hi in ((0, 2), (2, 6)):
+        bv = BatchRangeVerifier(b["g"], b["h"], b["gs"], b["hs"], b["u"])
+        for V, pr in zip(b["Vs"][lo:hi], b["proofs"][lo:hi]):
+            bv.add(V, pr)
+        parts.append(bv.partial())
+    assert eng.ec_sum_bytes(b"".join(parts), 2) == bytes(64)
