@@ -1,0 +1,78 @@
+"""Error behaviour of the C-ABI on a live GPU: negative codes + messages, never a crash;
+state-machine errors of the IPA object; option validation."""
+import ctypes
+
+import pytest
+
+from helpers import Q
+from oracle import cbind
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gp():
+    import gpu_common
+    return gpu_common
+
+
+def test_argument_errors(gp):
+    from bulletproofs_amd.engine import EngineError
+    eng = gp.engine()
+    lib, ctx = eng.lib, eng.ctx
+    out = ctypes.create_string_buffer(64)
+    assert lib.bpmi_msm(ctx, None, None, 5, out) == -3
+    assert b"null" in lib.bpmi_last_error(ctx)
+    assert lib.bpmi_msm(ctx, b"", b"", 0, out) == 0 and out.raw == bytes(64)
+    assert lib.bpmi_msm_dev(ctx, 1, 1, (1 << 26) + 1, out) == -3
+    assert b"BPMI_MAX_N" in lib.bpmi_last_error(ctx)
+    assert lib.bpmi_msm(None, b"", b"", 0, out) == -3
+    assert lib.bpmi_set_option(ctx, b"window_bits", 17) == -3
+    assert lib.bpmi_set_option(ctx, b"no_such_option", 1) == -3
+    assert lib.bpmi_set_option(ctx, b"window_bits", 0) == 0
+    with pytest.raises(EngineError, match="window_bits"):
+        eng.set_option("window_bits", 1)
+    assert lib.bpmi_ec_sum(ctx, None, 0, out) == 0 and out.raw == bytes(64)
+    out32 = ctypes.create_string_buffer(32)
+    assert lib.bpmi_sc_dot(ctx, None, None, 0, out32) == 0 and out32.raw == bytes(32)
+
+
+def test_ipa_state_errors(gp):
+    eng = gp.engine()
+    pts, _ = gp.rand_points(9, 77)
+    g, h, u = pts[:4], pts[4:8], pts[8]
+    a, b = [3, 5, 7, 11], [13, 17, 19, 23]
+    st = ctypes.c_void_p()
+    # length must be a power of two
+    rc = eng.lib.bpmi_ipa_create(eng.ctx, cbind.pack_points(g[:3]), cbind.pack_points(h[:3]), cbind.pack_scalars(a[:3]),
+                                 cbind.pack_scalars(b[:3]), 3, cbind.pack_points([u]), ctypes.byref(st))
+    assert rc == -3
+    s = eng.ipa_create(cbind.pack_points(g), cbind.pack_points(h), cbind.pack_scalars(a), cbind.pack_scalars(b), 4,
+                       cbind.pack_points([u]))
+    A32, B32 = ctypes.create_string_buffer(32), ctypes.create_string_buffer(32)
+    assert eng.lib.bpmi_ipa_finish(s.handle, A32, B32) == -5          # not reduced yet
+    for _ in range(2):
+        s.round_LR()
+        s.fold(5, pow(5, -1, Q))
+    L, R = ctypes.create_string_buffer(64), ctypes.create_string_buffer(64)
+    assert eng.lib.bpmi_ipa_round_LR(s.handle, L, R) == -5           # already length 1
+    assert eng.lib.bpmi_ipa_fold(s.handle, (5).to_bytes(32, "little"), (5).to_bytes(32, "little")) == -5
+    fa, fb = s.finish()
+    x, xi = 5, pow(5, -1, Q)
+    a1 = [(x * a[0] + xi * a[2]) % Q, (x * a[1] + xi * a[3]) % Q]
+    assert fa == (x * a1[0] + xi * a1[1]) % Q
+    s.close()
+
+
+def test_profile_interface(gp):
+    eng = gp.engine()
+    pts, _ = gp.rand_points(300, 3)
+    pb, sb = cbind.pack_points(pts), cbind.pack_scalars(list(range(1, 301)))
+    eng.profile(True)
+    eng.profile_reset()
+    eng.msm_bytes(pb, sb, 300)
+    eng.msm_bytes(pb, sb, 300)
+    prof = eng.profile_read()
+    eng.profile(False)
+    assert prof["msm_accumulate"][1] == 2 and prof["msm_accumulate"][0] > 0
+    assert set(prof) >= {"msm_digits_hist", "msm_scatter", "msm_tail", "ec_lincomb2", "sc_dot"}
