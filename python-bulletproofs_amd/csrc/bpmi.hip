@@ -671,19 +671,19 @@ __global__ void __launch_bounds__(64) k_weighted31(const u32 *__restrict__ D, u3
 
 // ---- tail: result = sum_w 2^(c w) sum_v 32^v E[w][v], to canonical affine -----------------
 BPMI_HD void msm_tail_combine(u32 out_words[16], const u32 *E, u32 W, u32 nv, u32 c) {
+  // ONE Horner chain over bit positions: E[w][v] carries weight 2^(c*w + 5*v), so walking
+  // t from the top bit down costs c*W doublings in total (not c*W + 5*nv*W)
   xyzz acc;
   xyzz_set_inf(acc);
   for (int w = (int)W - 1; w >= 0; w--) {
-    for (u32 k = 0; k < c; k++) xyzz_dbl(acc, acc);
-    xyzz tw;
-    xyzz_set_inf(tw);
+    int prev = (int)c;                              // bit offset (within the window) already reached
     for (int v = (int)nv - 1; v >= 0; v--) {
-      for (int k = 0; k < 5; k++) xyzz_dbl(tw, tw);
+      for (int k = prev; k > 5 * v; k--) xyzz_dbl(acc, acc);
+      prev = 5 * v;
       xyzz e;
       xyzz_load(e, E + ((u64)w * nv + v) * XYZZ_WORDS);
-      xyzz_add(tw, tw, e);
+      xyzz_add(acc, acc, e);
     }
-    xyzz_add(acc, acc, tw);
   }
   affine r;
   xyzz_to_affine(r, acc);
