@@ -63,6 +63,7 @@ struct bpmi_ctx {
   int opt_c = 0;        // window bits, 0 = auto
   int opt_tail = 0;     // 0 auto, 1 device, 2 host
   int opt_chunk = 0;    // entries per thread in k_accum_l0, 0 = auto
+  int64_t opt_ipa_big = 0;   // base length from which the IPA folds generators 16-way (0 = default 2^18)
   // profiling
   bool prof = false;
   std::vector<EvPair> evs;
@@ -820,6 +821,91 @@ __global__ void __launch_bounds__(256, 3) k_ec_lincomb2(LincombJob ja, NafPair n
   store_words16(out + 16ull * i, w16);
 }
 
+// ---- deferred generator folding (IPA) ----------------------------------------------------
+// After d deferred folds the logical generator i (i < m) is sum_t coef[t] * G[i + t*m],
+// t < 2^d, over the UNFOLDED base array G of length M = m << d; the newest fold is the
+// least significant bit of t:  coef'[2t + s] = coef[t] * (s ? hi_factor : lo_factor).
+__global__ void __launch_bounds__(256) k_ipa_coef_update(const u32 *cg, const u32 *ch, Sc2 x_xinv, u32 K, u32 *cg2, u32 *ch2) {
+  const u32 j = blockIdx.x * blockDim.x + threadIdx.x;     // new index in [0, 2K)
+  if (j >= 2u * K) return;
+  sc X, XI, c, r;
+#pragma unroll
+  for (int k = 0; k < 8; k++) { X.v[k] = x_xinv.k1[k]; XI.v[k] = x_xinv.k2[k]; }
+  // g' = x^-1 g_lo + x g_hi ;  h' = x h_lo + x^-1 h_hi   (inner_product_prover.py:107-108)
+  load_words8(c.v, cg + 8ull * (j >> 1));
+  sc_mul(r, c, (j & 1u) ? X : XI);
+  store_words8(cg2 + 8ull * j, r.v);
+  load_words8(c.v, ch + 8ull * (j >> 1));
+  sc_mul(r, c, (j & 1u) ? XI : X);
+  store_words8(ch2 + 8ull * j, r.v);
+}
+// scalars of the L (right = 0) or R (right = 1) MSM over the unfolded bases:
+//   L = <a_lo, g_hi> + <b_hi, h_lo>,  R = <a_hi, g_lo> + <b_lo, h_hi>   (:98-99)
+__global__ void __launch_bounds__(256) k_ipa_expand(const u32 *__restrict__ a, const u32 *__restrict__ b, const u32 *__restrict__ cg,
+                                                    const u32 *__restrict__ ch, u32 M, u32 logm, int right,
+                                                    u32 *__restrict__ eg, u32 *__restrict__ eh) {
+  const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= M) return;
+  const u32 m = 1u << logm, half = m >> 1;
+  const u32 i = k & (m - 1u), t = k >> logm;
+  const bool hi = i >= half;
+  sc z;
+#pragma unroll
+  for (int q = 0; q < 8; q++) z.v[q] = 0;
+  sc rg = z, rh = z;
+  // g side uses the g-half OPPOSITE to the a-half: L pairs a_lo with g_hi
+  if (hi != (right != 0)) {
+    sc av, c;
+    load_words8(av.v, a + 8ull * (right ? half + i : i - half));
+    load_words8(c.v, cg + 8ull * t);
+    sc_mul(rg, av, c);
+  }
+  if (hi == (right != 0)) {
+    sc bv, c;
+    load_words8(bv.v, b + 8ull * (right ? i - half : half + i));
+    load_words8(c.v, ch + 8ull * t);
+    sc_mul(rh, bv, c);
+  }
+  store_words8(eg + 8ull * k, rg.v);
+  store_words8(eh + 8ull * k, rh.v);
+}
+// materialise 2^d-way folded generators: out[i] = sum_t coef[t] * G[i + t*m], i < m, as an
+// interleaved NAF ladder (shared scalars -> wave-uniform branches); two jobs (g and h) per launch
+#define MULTIFOLD_MAXK 16
+struct NafK { u32 nz[MULTIFOLD_MAXK][9]; u32 sg[MULTIFOLD_MAXK][9]; int top; };
+struct MultifoldJob { const u32 *base; u32 *out; };
+__global__ void __launch_bounds__(256, 3) k_ec_multifold(MultifoldJob ja, MultifoldJob jb, const NafK *__restrict__ nfa, const NafK *__restrict__ nfb,
+                                                         u32 m, u32 K) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool second = i >= m;
+  if (second) i -= m;
+  if (i >= m) return;
+  const u32 *base = second ? jb.base : ja.base;
+  u32 *out = second ? jb.out : ja.out;
+  const NafK *nf = second ? nfb : nfa;
+  jac acc;
+  jac_set_inf(acc);
+  const int top = nf->top;
+  for (int pos = top; pos >= 0; pos--) {
+    jac_dbl(acc, acc);
+    const u32 msk = 1u << (pos & 31);
+    const int wd = pos >> 5;
+#pragma unroll 1
+    for (u32 t = 0; t < K; t++) {
+      if (nf->nz[t][wd] & msk) {
+        affine P;
+        load_affine(P, base + 16ull * ((u64)i + (u64)t * m));
+        if (!affine_is_inf(P)) jac_madd_signed(acc, P.x, P.y, (nf->sg[t][wd] & msk) != 0);
+      }
+    }
+  }
+  affine r;
+  jac_to_affine(r, acc);
+  u32 w16[16];
+  affine_to_words(w16, r);
+  store_words16(out + 16ull * i, w16);
+}
+
 // out = sum of n affine points (one block)
 __global__ void __launch_bounds__(256) k_ec_sum(const u32 *__restrict__ pts, u32 n, u32 *__restrict__ out) {
   __shared__ u32 s_val[256 * LDS_STRIDE];
@@ -1167,6 +1253,7 @@ int bpmi_set_option(bpmi_ctx *ctx, const char *name, int64_t value) {
   if (!strcmp(name, "window_bits")) { if (value != 0 && (value < 2 || value > 16)) return fail(ctx, BPMI_E_ARG, "window_bits must be 0 or 2..16"); ctx->opt_c = (int)value; return BPMI_OK; }
   if (!strcmp(name, "tail")) { if (value < 0 || value > 2) return fail(ctx, BPMI_E_ARG, "tail must be 0, 1 or 2"); ctx->opt_tail = (int)value; return BPMI_OK; }
   if (!strcmp(name, "chunk")) { if (value < 0 || value > 4096) return fail(ctx, BPMI_E_ARG, "chunk must be 0..4096"); ctx->opt_chunk = (int)value; return BPMI_OK; }
+  if (!strcmp(name, "ipa_big_m")) { if (value < 0 || (value & (value - 1))) return fail(ctx, BPMI_E_ARG, "ipa_big_m must be 0 or a power of two"); ctx->opt_ipa_big = value; return BPMI_OK; }
   return fail(ctx, BPMI_E_ARG, std::string("unknown option ") + name);
 }
 
@@ -1387,32 +1474,68 @@ int bpmi_sc_fold(bpmi_ctx *ctx, const uint8_t *lo, const uint8_t *hi, const uint
 
 struct bpmi_ipa {
   bpmi_ctx *ctx;
-  uint64_t n0, n;       // initial and current length
-  u32 *g, *h, *a, *b;   // device, halved in place
+  uint64_t n0, n;       // initial and current LOGICAL length m
+  uint64_t M;           // length of the (unfolded) base arrays g, h;  M = n << d
+  u32 d;                // deferred folds
+  uint64_t big_m;       // materialisation threshold (ctx option ipa_big_m)
+  u32 *g, *h;           // device bases (M points each)
+  u32 *g2, *h2;         // device, materialisation targets (M/16 points each)
+  u32 *a, *b;           // device, folded in place every round
+  u32 *eg, *eh;         // device, expanded scalars for the deferred MSMs (M each)
+  u32 *cg[2], *ch[2];   // device coefficient tables (ping-pong), 2^d entries in cg[cur]
+  int cur;
   u32 *u;               // device, 64 B point
   u32 *cl, *cr;         // device, 32 B scalars (stay on device between dot and MSM)
   u32 *partial;         // device scratch for dots
+  NafK *nafk[2];        // device, NAF tables for the multifold kernel
   void *block;          // one allocation
+  std::vector<sc> hcg, hch;   // host copies of the coefficient tables while 2^d <= 16
   bool lr_done;
 };
+
+// deferral policy: bases of 2^18 points or more are folded 16-way at once (an MSM over the
+// unfolded bases costs ~2.6 ms per L/R at 2^20 against ~50 ms for the pairwise ladder fold,
+// while a K-term ladder stays throughput-bound only for many outputs); smaller bases are
+// never folded -- the prover needs L and R, not the folded generators, and a ladder launch
+// is ~2 ms of pure latency.
+#define IPA_BIG_M_DEFAULT (1u << 18)
+#define IPA_BIG_D 4
 
 extern "C" {
 
 static int ipa_alloc(bpmi_ctx *ctx, uint64_t n, bpmi_ipa **out) {
   bpmi_ipa *st = new bpmi_ipa();
-  st->ctx = ctx; st->n0 = st->n = n; st->lr_done = false;
-  const size_t bytes = align_up(64 * n, 256) * 2 + align_up(32 * n, 256) * 2 + 256 * 3 + 32 * 1024;
+  st->ctx = ctx; st->n0 = st->n = st->M = n; st->d = 0; st->cur = 0; st->lr_done = false;
+  st->big_m = ctx->opt_ipa_big > 0 ? (uint64_t)ctx->opt_ipa_big : IPA_BIG_M_DEFAULT;
+  if (st->big_m < 32) st->big_m = 32;
+  const size_t pts = align_up(64 * n, 256), scs = align_up(32 * n, 256);
+  const size_t pts2 = align_up(64 * (n / 16 + 1), 256), coef = align_up(32 * n, 256);
+  const size_t bytes = pts * 2 + pts2 * 2 + scs * 4 + coef * 4 + 256 * 3 + 32 * 1024 + 2 * align_up(sizeof(NafK), 256);
   hipError_t e = hipMalloc(&st->block, bytes);
   if (e != hipSuccess) { delete st; return fail(ctx, BPMI_E_NOMEM, std::string("hipMalloc(ipa state): ") + hipGetErrorString(e)); }
   char *p = (char *)st->block;
-  st->g = (u32 *)p; p += align_up(64 * n, 256);
-  st->h = (u32 *)p; p += align_up(64 * n, 256);
-  st->a = (u32 *)p; p += align_up(32 * n, 256);
-  st->b = (u32 *)p; p += align_up(32 * n, 256);
+  st->g = (u32 *)p; p += pts;
+  st->h = (u32 *)p; p += pts;
+  st->g2 = (u32 *)p; p += pts2;
+  st->h2 = (u32 *)p; p += pts2;
+  st->a = (u32 *)p; p += scs;
+  st->b = (u32 *)p; p += scs;
+  st->eg = (u32 *)p; p += scs;
+  st->eh = (u32 *)p; p += scs;
+  for (int k = 0; k < 2; k++) { st->cg[k] = (u32 *)p; p += coef; st->ch[k] = (u32 *)p; p += coef; }
   st->u = (u32 *)p; p += 256;
   st->cl = (u32 *)p; p += 256;
   st->cr = (u32 *)p; p += 256;
-  st->partial = (u32 *)p;
+  st->partial = (u32 *)p; p += 32 * 1024;
+  for (int k = 0; k < 2; k++) { st->nafk[k] = (NafK *)p; p += align_up(sizeof(NafK), 256); }
+  // coefficient tables start as [1]
+  uint8_t one[32] = {1};
+  e = hipMemcpyAsync(st->cg[0], one, 32, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(st->ch[0], one, 32, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) { (void)hipFree(st->block); delete st; return fail(ctx, BPMI_E_HIP, std::string("ipa_alloc: ") + hipGetErrorString(e)); }
+  sc o; memset(&o, 0, sizeof(o)); o.v[0] = 1;
+  st->hcg.assign(1, o); st->hch.assign(1, o);
   *out = st;
   return BPMI_OK;
 }
@@ -1464,30 +1587,54 @@ int bpmi_ipa_round_LR(bpmi_ipa *st, uint8_t L[64], uint8_t R[64]) {
   if (st->n < 2) return fail(ctx, BPMI_E_STATE, "ipa already reduced to length 1");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   const uint64_t np = st->n / 2;
-  u32 *g_lo = st->g, *g_hi = st->g + 16 * np, *h_lo = st->h, *h_hi = st->h + 16 * np;
   u32 *a_lo = st->a, *a_hi = st->a + 8 * np, *b_lo = st->b, *b_hi = st->b + 8 * np;
   // cl = <a_lo, b_hi>, cr = <a_hi, b_lo>  (inner_product_prover.py:96-97), kept on the device
   sc_dot_dev_to(ctx, a_lo, b_hi, np, st->cl, st->partial);
   sc_dot_dev_to(ctx, a_hi, b_lo, np, st->cr, st->partial);
-  // L = <a_lo, g_hi> + <b_hi, h_lo> + cl*u  (:98) as ONE three-segment MSM
-  Segs sL = {};
-  sL.pts[0] = g_hi; sL.sc[0] = a_lo; sL.n[0] = (u32)np;
-  sL.pts[1] = h_lo; sL.sc[1] = b_hi; sL.n[1] = (u32)np;
-  sL.pts[2] = st->u; sL.sc[2] = st->cl; sL.n[2] = 1;
-  sL.total = (u32)(2 * np + 1);
-  int rc = msm_run(ctx, sL, L);
-  if (rc) return rc;
-  // R = <a_hi, g_lo> + <b_lo, h_hi> + cr*u  (:99)
-  Segs sR = {};
-  sR.pts[0] = g_lo; sR.sc[0] = a_hi; sR.n[0] = (u32)np;
-  sR.pts[1] = h_hi; sR.sc[1] = b_lo; sR.n[1] = (u32)np;
-  sR.pts[2] = st->u; sR.sc[2] = st->cr; sR.n[2] = 1;
-  sR.total = (u32)(2 * np + 1);
-  rc = msm_run(ctx, sR, R);
-  if (rc) return rc;
+  int rc;
+  if (st->d == 0) {
+    // bases are the current generators: L = <a_lo, g_hi> + <b_hi, h_lo> + cl*u  (:98) as ONE
+    // three-segment MSM, R = <a_hi, g_lo> + <b_lo, h_hi> + cr*u  (:99)
+    u32 *g_lo = st->g, *g_hi = st->g + 16 * np, *h_lo = st->h, *h_hi = st->h + 16 * np;
+    Segs sL = {};
+    sL.pts[0] = g_hi; sL.sc[0] = a_lo; sL.n[0] = (u32)np;
+    sL.pts[1] = h_lo; sL.sc[1] = b_hi; sL.n[1] = (u32)np;
+    sL.pts[2] = st->u; sL.sc[2] = st->cl; sL.n[2] = 1;
+    sL.total = (u32)(2 * np + 1);
+    rc = msm_run(ctx, sL, L);
+    if (rc) return rc;
+    Segs sR = {};
+    sR.pts[0] = g_lo; sR.sc[0] = a_hi; sR.n[0] = (u32)np;
+    sR.pts[1] = h_hi; sR.sc[1] = b_lo; sR.n[1] = (u32)np;
+    sR.pts[2] = st->u; sR.sc[2] = st->cr; sR.n[2] = 1;
+    sR.total = (u32)(2 * np + 1);
+    rc = msm_run(ctx, sR, R);
+    if (rc) return rc;
+  } else {
+    // deferred: MSM over the UNFOLDED bases with the fold coefficients multiplied into the
+    // scalars (half of them are zero and drop out in the digit pass)
+    u32 logm = 0;
+    while ((1ull << logm) < st->n) logm++;
+    for (int right = 0; right < 2; right++) {
+      {
+        StageTimer t(ctx, ST_SCFOLD);
+        hipLaunchKernelGGL(k_ipa_expand, dim3((u32)((st->M + 255) / 256)), dim3(256), 0, ctx->stream, st->a, st->b,
+                           st->cg[st->cur], st->ch[st->cur], (u32)st->M, logm, right, st->eg, st->eh);
+      }
+      Segs sg = {};
+      sg.pts[0] = st->g; sg.sc[0] = st->eg; sg.n[0] = (u32)st->M;
+      sg.pts[1] = st->h; sg.sc[1] = st->eh; sg.n[1] = (u32)st->M;
+      sg.pts[2] = st->u; sg.sc[2] = right ? st->cr : st->cl; sg.n[2] = 1;
+      sg.total = (u32)(2 * st->M + 1);
+      rc = msm_run(ctx, sg, right ? R : L);
+      if (rc) return rc;
+    }
+  }
   st->lr_done = true;
   return BPMI_OK;
 }
+
+static void host_sc_from(sc &r, const uint8_t b[32]) { memcpy(r.v, b, 32); }
 
 int bpmi_ipa_fold(bpmi_ipa *st, const uint8_t x[32], const uint8_t xinv[32]) {
   if (!st || !x || !xinv) return BPMI_E_ARG;
@@ -1496,18 +1643,68 @@ int bpmi_ipa_fold(bpmi_ipa *st, const uint8_t x[32], const uint8_t xinv[32]) {
   HIPCHK(ctx, hipSetDevice(ctx->device));
   const uint64_t np = st->n / 2;
   int rc;
-  // g' = x^-1 g_lo + x g_hi ; h' = x h_lo + x^-1 h_hi  (:107-108); in place: thread i
-  // reads elements i and np+i and writes element i only
-  rc = lincomb2_pair_dev(ctx, st->g, st->g + 16 * np, xinv, x, np, st->g,
-                         st->h, st->h + 16 * np, x, xinv, np, st->h);
-  if (rc) return rc;
   // a' = x a_lo + x^-1 a_hi ; b' = x^-1 b_lo + x b_hi  (:109-110)
   rc = bpmi_sc_fold_dev(ctx, st->a, st->a + 8 * np, x, xinv, np, st->a);
   if (rc) return rc;
   rc = bpmi_sc_fold_dev(ctx, st->b, st->b + 8 * np, xinv, x, np, st->b);
   if (rc) return rc;
+  // g' = x^-1 g_lo + x g_hi ; h' = x h_lo + x^-1 h_hi  (:107-108): deferred -- only the
+  // coefficient tables double
+  const u32 K = 1u << st->d;
+  Sc2 xs;
+  memcpy(xs.k1, x, 32); memcpy(xs.k2, xinv, 32);
+  {
+    StageTimer t(ctx, ST_SCFOLD);
+    hipLaunchKernelGGL(k_ipa_coef_update, dim3((2 * K + 255) / 256), dim3(256), 0, ctx->stream, st->cg[st->cur], st->ch[st->cur],
+                       xs, K, st->cg[st->cur ^ 1], st->ch[st->cur ^ 1]);
+  }
+  st->cur ^= 1;
+  const bool track_host = (2 * K <= MULTIFOLD_MAXK) && st->M >= st->big_m;
+  if (track_host) {
+    sc X, XI;
+    host_sc_from(X, x); host_sc_from(XI, xinv);
+    std::vector<sc> ng(2 * K), nh(2 * K);
+    for (u32 j = 0; j < 2 * K; j++) {
+      sc_mul(ng[j], st->hcg[j >> 1], (j & 1u) ? X : XI);
+      sc_mul(nh[j], st->hch[j >> 1], (j & 1u) ? XI : X);
+    }
+    st->hcg.swap(ng); st->hch.swap(nh);
+  }
+  st->d += 1;
   st->n = np;
   st->lr_done = false;
+  if (st->M >= st->big_m && st->d == IPA_BIG_D && st->n > 1) {
+    // materialise the 16-way folded generators: out[i] = sum_t coef[t] * base[i + t*m]
+    const u32 K2 = 1u << st->d;
+    NafK ha, hb;
+    memset(&ha, 0, sizeof(ha)); memset(&hb, 0, sizeof(hb));
+    ha.top = hb.top = -1;
+    for (u32 t = 0; t < K2; t++) {
+      host_naf((const uint8_t *)st->hcg[t].v, ha.nz[t], ha.sg[t], ha.top);
+      host_naf((const uint8_t *)st->hch[t].v, hb.nz[t], hb.sg[t], hb.top);
+    }
+    HIPCHK(ctx, hipMemcpyAsync(st->nafk[0], &ha, sizeof(NafK), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(st->nafk[1], &hb, sizeof(NafK), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));     // ha / hb are stack objects
+    MultifoldJob ja = {st->g, st->g2}, jb = {st->h, st->h2};
+    {
+      StageTimer t(ctx, ST_LINCOMB2);
+      hipLaunchKernelGGL(k_ec_multifold, dim3((u32)((2 * st->n + 255) / 256)), dim3(256), 0, ctx->stream, ja, jb, st->nafk[0], st->nafk[1],
+                         (u32)st->n, K2);
+    }
+    HIPCHK(ctx, hipGetLastError());
+    // the folded generators become the new bases
+    std::swap(st->g, st->g2);
+    std::swap(st->h, st->h2);
+    st->M = st->n;
+    st->d = 0;
+    uint8_t one[32] = {1};
+    HIPCHK(ctx, hipMemcpyAsync(st->cg[st->cur], one, 32, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(st->ch[st->cur], one, 32, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    sc o; memset(&o, 0, sizeof(o)); o.v[0] = 1;
+    st->hcg.assign(1, o); st->hch.assign(1, o);
+  }
   return BPMI_OK;
 }
 

@@ -102,11 +102,14 @@ def test_ipa_cheating_cases(gp):
         Verifier1(g, h, u, P1, ip, p1).verify()
 
 
-@pytest.mark.parametrize("n", [2, 64, 1024, 8192])
-def test_ipa_rounds_vs_oracle(gp, n):
+@pytest.mark.parametrize("n,big_m", [(2, 0), (64, 0), (1024, 0), (8192, 0), (4096, 256), (1 << 14, 1 << 10), (1 << 12, 1 << 12)])
+def test_ipa_rounds_vs_oracle(gp, n, big_m):
     """Every round's L, R and the folded vectors against the C oracle, through the raw
-    C-ABI state object (bpmi_ipa_*), with arbitrary challenges."""
+    C-ABI state object (bpmi_ipa_*), with arbitrary challenges.  `big_m` lowers the base
+    length from which generators are folded 16-way at once, so the deferred-MSM path, the
+    materialisation kernel and the rounds after it are all exercised at test sizes."""
     eng = gp.engine()
+    eng.set_option("ipa_big_m", big_m)
     pts, _ = gp.rand_points(2 * n + 1, 40 + n)
     g, h, u = pts[:n], pts[n:2 * n], pts[2 * n]
     rnd = random.Random(n)
@@ -130,3 +133,4 @@ def test_ipa_rounds_vs_oracle(gp, n):
         b = cbind.sc_fold(b[:half], b[half:], xi, x)
     assert st.finish() == (a[0], b[0])
     st.close()
+    eng.set_option("ipa_big_m", 0)
