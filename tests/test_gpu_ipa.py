@@ -134,3 +134,34 @@ def test_ipa_rounds_vs_oracle(gp, n, big_m):
     assert st.finish() == (a[0], b[0])
     st.close()
     eng.set_option("ipa_big_m", 0)
+
+
+def test_ipa_full_size_round_trip(gp):
+    """Size-independent property at a size the oracle cannot reach in seconds: a proof
+    produced by FastNIProver2 at n = 2^16 (deferred folding, 32 MSMs) must be accepted by
+    Verifier2 (one MSM of 2n+1 points against one of 2 log n), and rejected after any
+    single-field mutation."""
+    import copy
+    from bulletproofs_amd.ec import Point, secp256k1, unpack_points
+    from bulletproofs_amd.innerproduct import FastNIProver2, Verifier2
+    from bulletproofs_amd.utils import ModP, inner_product, vector_commitment
+    eng = gp.engine()
+    n = 1 << 16
+    rnd = random.Random(2016)
+    G64 = secp256k1.G.to_le64()
+    ks = b"".join(rnd.randrange(1, Q).to_bytes(32, "little") for _ in range(2 * n + 1))
+    pts = unpack_points(eng.ec_mul_batch_bytes(G64 * (2 * n + 1), ks, 2 * n + 1), 2 * n + 1)
+    g, h, u = pts[:n], pts[n:2 * n], pts[2 * n]
+    a = [ModP(rnd.randrange(Q), Q) for _ in range(n)]
+    b = [ModP(rnd.randrange(Q), Q) for _ in range(n)]
+    P = vector_commitment(g, h, a, b) + inner_product(a, b) * u
+    proof = FastNIProver2(g, h, u, P, a, b, secp256k1).prove()
+    assert len(proof.Ls) == 16 and len(proof.xs) == 16
+    assert Verifier2(g, h, u, P, proof).verify() is True
+    for field in ("a", "b"):
+        bad = copy.copy(proof)
+        setattr(bad, field, getattr(bad, field) + ModP(1, Q))
+        with pytest.raises(Exception, match="Proof invalid"):
+            Verifier2(g, h, u, P, bad).verify()
+    with pytest.raises(Exception, match="Proof invalid"):
+        Verifier2(g, h, u, P + u, proof).verify()
