@@ -58,6 +58,14 @@ struct bpmi_ctx {
   // workspace (grown on demand, never shrunk)
   void *ws = nullptr; size_t ws_bytes = 0;
   void *pin = nullptr; size_t pin_bytes = 0;       // pinned host staging
+  // second MSM lane: an independent stream + workspace, so two independent MSMs (the L and
+  // R of an IPA round) overlap -- the latency-bound stages of one hide under the
+  // throughput-bound stages of the other
+  hipStream_t stream1 = nullptr;
+  void *ws1 = nullptr; size_t ws1_bytes = 0;
+  void *pin1 = nullptr; size_t pin1_bytes = 0;
+  hipEvent_t ev_fork = nullptr;
+  struct PendingMsm { bool active = false; u32 W = 0, nv = 0, c = 0; int tail = 2; u32 *E = nullptr, *out = nullptr; } pend[2];
   void *stage_in = nullptr; size_t stage_in_bytes = 0;  // device staging for host-pointer entry points
   // options
   int opt_c = 0;        // window bits, 0 = auto
@@ -88,22 +96,22 @@ static int fail(bpmi_ctx *ctx, int code, const std::string &msg) {
   } while (0)
 
 static bool g_debug_sync = getenv("BPMI_DEBUG_SYNC") != nullptr;
-static void debug_sync(bpmi_ctx *ctx, const char *what) {
+static void debug_sync(bpmi_ctx *ctx, const char *what, hipStream_t stream = nullptr) {
   if (!g_debug_sync) return;
   fprintf(stderr, "[bpmi] sync after %s ... ", what); fflush(stderr);
-  hipError_t e = hipStreamSynchronize(ctx->stream);
+  hipError_t e = hipStreamSynchronize(stream ? stream : ctx->stream);
   fprintf(stderr, "%s\n", hipGetErrorString(e)); fflush(stderr);
 }
 struct StageTimer {
-  bpmi_ctx *ctx; int stage; hipEvent_t a = nullptr, b = nullptr;
-  StageTimer(bpmi_ctx *c, int s) : ctx(c), stage(s) {
+  bpmi_ctx *ctx; int stage; hipStream_t stream; hipEvent_t a = nullptr, b = nullptr;
+  StageTimer(bpmi_ctx *c, int s, hipStream_t st = nullptr) : ctx(c), stage(s), stream(st ? st : c->stream) {
     if (ctx->prof) {
       if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
-      (void)hipEventRecord(a, ctx->stream);
+      (void)hipEventRecord(a, stream);
     }
   }
   ~StageTimer() {
-    if (ctx->prof && a) { (void)hipEventRecord(b, ctx->stream); ctx->evs.push_back({stage, a, b}); }
+    if (ctx->prof && a) { (void)hipEventRecord(b, stream); ctx->evs.push_back({stage, a, b}); }
   }
 };
 
@@ -115,6 +123,23 @@ static int ensure_ws(bpmi_ctx *ctx, size_t bytes) {
   ctx->ws_bytes = want;
   return BPMI_OK;
 }
+static int ensure_lane(bpmi_ctx *ctx, int lane) {
+  if (lane == 0 || ctx->stream1) return BPMI_OK;
+  HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream1, hipStreamNonBlocking));
+  HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+  return BPMI_OK;
+}
+static hipStream_t lane_stream(bpmi_ctx *ctx, int lane) { return lane ? ctx->stream1 : ctx->stream; }
+static int ensure_ws_lane(bpmi_ctx *ctx, int lane, size_t bytes) {
+  if (lane == 0) return ensure_ws(ctx, bytes);
+  if (bytes <= ctx->ws1_bytes) return BPMI_OK;
+  if (ctx->ws1) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream1)); HIPCHK(ctx, hipFree(ctx->ws1)); ctx->ws1 = nullptr; ctx->ws1_bytes = 0; }
+  const size_t want = bytes + bytes / 8;
+  HIPCHK(ctx, hipMalloc(&ctx->ws1, want));
+  ctx->ws1_bytes = want;
+  return BPMI_OK;
+}
+static int ensure_pin_lane(bpmi_ctx *ctx, int lane, size_t bytes);
 static int ensure_stage_in(bpmi_ctx *ctx, size_t bytes) {
   if (bytes <= ctx->stage_in_bytes) return BPMI_OK;
   if (ctx->stage_in) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(ctx->stage_in)); ctx->stage_in = nullptr; ctx->stage_in_bytes = 0; }
@@ -127,6 +152,15 @@ static int ensure_pin(bpmi_ctx *ctx, size_t bytes) {
   if (ctx->pin) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipHostFree(ctx->pin)); ctx->pin = nullptr; ctx->pin_bytes = 0; }
   HIPCHK(ctx, hipHostMalloc(&ctx->pin, bytes, hipHostMallocDefault));
   ctx->pin_bytes = bytes;
+  return BPMI_OK;
+}
+
+static int ensure_pin_lane(bpmi_ctx *ctx, int lane, size_t bytes) {
+  if (lane == 0) return ensure_pin(ctx, bytes);
+  if (bytes <= ctx->pin1_bytes) return BPMI_OK;
+  if (ctx->pin1) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream1)); HIPCHK(ctx, hipHostFree(ctx->pin1)); ctx->pin1 = nullptr; ctx->pin1_bytes = 0; }
+  HIPCHK(ctx, hipHostMalloc(&ctx->pin1, bytes, hipHostMallocDefault));
+  ctx->pin1_bytes = bytes;
   return BPMI_OK;
 }
 
@@ -1052,9 +1086,13 @@ static void msm_layout(const MsmGeom &g, MsmWs &w, char *base) {
   w.total = o;
 }
 
-static int msm_run(bpmi_ctx *ctx, const Segs &segs, uint8_t out[64]) {
+// Enqueue every GPU stage of one MSM on `lane` (0 = the ctx stream, 1 = the second lane),
+// including the device->pinned-host copy the tail needs; returns without synchronising.
+static int msm_enqueue(bpmi_ctx *ctx, int lane, const Segs &segs) {
   const uint64_t n = segs.total;
-  if (n == 0) { memset(out, 0, 64); return BPMI_OK; }
+  bpmi_ctx::PendingMsm &pd = ctx->pend[lane];
+  pd.active = false;
+  if (n == 0) return BPMI_OK;
   if (n > BPMI_MAX_N) return fail(ctx, BPMI_E_ARG, "n exceeds BPMI_MAX_N");
   MsmGeom g;
   g.n = (u32)n;
@@ -1066,35 +1104,37 @@ static int msm_run(bpmi_ctx *ctx, const Segs &segs, uint8_t out[64]) {
   g.nv = (g.c + 4u) / 5u;
   MsmWs w;
   msm_layout(g, w, nullptr);
-  int rc = ensure_ws(ctx, w.total);
+  int rc = ensure_lane(ctx, lane);
   if (rc) return rc;
-  msm_layout(g, w, (char *)ctx->ws);
-  hipStream_t st = ctx->stream;
+  rc = ensure_ws_lane(ctx, lane, w.total);
+  if (rc) return rc;
+  msm_layout(g, w, (char *)(lane ? ctx->ws1 : ctx->ws));
+  hipStream_t st = lane_stream(ctx, lane);
   const u32 nblk_n = (u32)std::min<uint64_t>((n + 255) / 256, 8192);
   {
-    StageTimer t(ctx, ST_MISC);
+    StageTimer t(ctx, ST_MISC, st);
     if (w.P) HIPCHK(ctx, hipMemsetAsync(w.coarse_hist, 0, 4ull * (PART_MAX + 1), st));
     else HIPCHK(ctx, hipMemsetAsync(w.hist, 0, 4ull * g.G, st));
     HIPCHK(ctx, hipMemsetAsync(w.buckets, 0, 4ull * XYZZ_WORDS * g.G, st));
   }
-  debug_sync(ctx, "ST_MISC");
+  debug_sync(ctx, "ST_MISC", st);
   if (w.P) {
     {
-      StageTimer t(ctx, ST_DIGITS);
+      StageTimer t(ctx, ST_DIGITS, st);
       hipLaunchKernelGGL(k_coarse_hist, dim3(std::min<u32>(nblk_n, 512)), dim3(256), 0, st, segs, g, w.P, w.coarse_hist);
     }
-    debug_sync(ctx, "ST_DIGITS");
+    debug_sync(ctx, "ST_DIGITS", st);
     {
-      StageTimer t(ctx, ST_SCAN);
+      StageTimer t(ctx, ST_SCAN, st);
       // exclusive scan of <= 2048 partition counts; total -> coarse_off[P] and off[G]
       hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(256), 0, st, w.coarse_hist, w.P, w.bsum);
       hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, w.bsum, 1u, w.off, g.G);
       hipLaunchKernelGGL(k_scan_final, dim3(1), dim3(256), 0, st, w.coarse_hist, w.P, w.bsum, w.coarse_off, w.coarse_cursor);
       HIPCHK(ctx, hipMemcpyAsync(w.coarse_off + w.P, w.off + g.G, 4, hipMemcpyDeviceToDevice, st));
     }
-    debug_sync(ctx, "ST_SCAN");
+    debug_sync(ctx, "ST_SCAN", st);
     {
-      StageTimer t(ctx, ST_SCATTER);
+      StageTimer t(ctx, ST_SCATTER, st);
       const u32 ntiles = (g.n + TILE_SCALARS - 1) / TILE_SCALARS;
       hipLaunchKernelGGL(k_partition, dim3(std::min<u32>(ntiles, 2048)), dim3(256), 0, st, segs, g, w.P, w.coarse_cursor, w.dig);
       // level B over fixed-size tiles of the partitioned array (grid sized for the maximum E)
@@ -1107,43 +1147,43 @@ static int msm_run(bpmi_ctx *ctx, const Segs &segs, uint8_t out[64]) {
       hipLaunchKernelGGL(k_fine_scatter, dim3(nft), dim3(256), 0, st, g, w.P, w.coarse_off, w.dig, w.coarse_off + w.P, w.cursor, w.sidx);
       hipLaunchKernelGGL(k_chunk_keys, dim3((g.G + 255) / 256), dim3(256), 0, st, g, w.off, w.chunk_key);
     }
-    debug_sync(ctx, "ST_SCATTER");
+    debug_sync(ctx, "ST_SCATTER", st);
   } else {
     {
-      StageTimer t(ctx, ST_DIGITS);
+      StageTimer t(ctx, ST_DIGITS, st);
       hipLaunchKernelGGL(k_digits_hist, dim3(nblk_n), dim3(256), 0, st, segs, g, w.dig, w.hist);
     }
-    debug_sync(ctx, "ST_DIGITS");
+    debug_sync(ctx, "ST_DIGITS", st);
     {
-      StageTimer t(ctx, ST_SCAN);
+      StageTimer t(ctx, ST_SCAN, st);
       hipLaunchKernelGGL(k_scan_partials, dim3(w.nscan_blocks), dim3(256), 0, st, w.hist, g.G, w.bsum);
       hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, w.bsum, w.nscan_blocks, w.off, g.G);
       hipLaunchKernelGGL(k_scan_final, dim3(w.nscan_blocks), dim3(256), 0, st, w.hist, g.G, w.bsum, w.off, w.cursor);
     }
-    debug_sync(ctx, "ST_SCAN");
+    debug_sync(ctx, "ST_SCAN", st);
     {
-      StageTimer t(ctx, ST_SCATTER);
+      StageTimer t(ctx, ST_SCATTER, st);
       hipLaunchKernelGGL(k_scatter, dim3(nblk_n), dim3(256), 0, st, g, w.dig, w.cursor, w.sidx);
       hipLaunchKernelGGL(k_chunk_keys, dim3((g.G + 255) / 256), dim3(256), 0, st, g, w.off, w.chunk_key);
     }
-    debug_sync(ctx, "ST_SCATTER");
+    debug_sync(ctx, "ST_SCATTER", st);
   }
   {
-    StageTimer t(ctx, ST_ACCUM);
+    StageTimer t(ctx, ST_ACCUM, st);
     const u32 nthreads = w.rec0_max / 2;
     hipLaunchKernelGGL(k_accum_l0, dim3((nthreads + 255) / 256), dim3(256), 0, st, segs, g, w.off, w.chunk_key, w.sidx,
                        w.buckets, w.rec_key[0], w.rec_pt[0]);
   }
-  debug_sync(ctx, "ST_ACCUM");
+  debug_sync(ctx, "ST_ACCUM", st);
   {
-    StageTimer t(ctx, ST_SEGSCAN);
+    StageTimer t(ctx, ST_SEGSCAN, st);
     u32 R = w.rec0_max;
     int level = 1, src = 0;
     for (;;) {
       const u32 nb = (R + 255) / 256;
       hipLaunchKernelGGL(k_segscan, dim3(nb), dim3(256), 0, st, g, w.off, level, w.rec_key[src], w.rec_pt[src],
                          w.rec_key[src ^ 1], w.rec_pt[src ^ 1], w.buckets);
-      if (g_debug_sync) { fprintf(stderr, "[bpmi] segscan level %d nb %u R %u\n", level, nb, R); debug_sync(ctx, "segscan level"); }
+      if (g_debug_sync) { fprintf(stderr, "[bpmi] segscan level %d nb %u R %u\n", level, nb, R); debug_sync(ctx, "segscan level", st); }
       if (nb <= 1) break;
       R = 2 * nb;
       // ping-pong: level 1 reads buffer 0 (large) and writes buffer 1; later levels are
@@ -1152,37 +1192,71 @@ static int msm_run(bpmi_ctx *ctx, const Segs &segs, uint8_t out[64]) {
       level++;
     }
   }
-  debug_sync(ctx, "ST_SEGSCAN");
+  debug_sync(ctx, "ST_SEGSCAN", st);
   {
-    StageTimer t(ctx, ST_BREDUCE);
+    StageTimer t(ctx, ST_BREDUCE, st);
     hipLaunchKernelGGL(k_bucket_digit_sums, dim3(g.W * g.nv * 31), dim3(256), 0, st, g, w.buckets, w.D);
     hipLaunchKernelGGL(k_weighted31, dim3(g.W * g.nv), dim3(64), 0, st, w.D, w.E);
   }
-  debug_sync(ctx, "ST_BREDUCE");
+  debug_sync(ctx, "ST_BREDUCE", st);
   {
-    StageTimer t(ctx, ST_TAIL);
+    StageTimer t(ctx, ST_TAIL, st);
     const int tail = ctx->opt_tail ? ctx->opt_tail : 2;
     if (tail == 1) {
       hipLaunchKernelGGL(k_tail, dim3(1), dim3(64), 0, st, w.E, g.W, g.nv, g.c, w.out);
-      rc = ensure_pin(ctx, 4096);
+      rc = ensure_pin_lane(ctx, lane, 4096);
       if (rc) return rc;
-      HIPCHK(ctx, hipMemcpyAsync(ctx->pin, w.out, 64, hipMemcpyDeviceToHost, st));
-      HIPCHK(ctx, hipStreamSynchronize(st));
-      memcpy(out, ctx->pin, 64);
+      HIPCHK(ctx, hipMemcpyAsync(lane ? ctx->pin1 : ctx->pin, w.out, 64, hipMemcpyDeviceToHost, st));
     } else {
       const size_t eb = 4ull * XYZZ_WORDS * g.W * g.nv;
-      rc = ensure_pin(ctx, eb);
+      rc = ensure_pin_lane(ctx, lane, eb);
       if (rc) return rc;
-      HIPCHK(ctx, hipMemcpyAsync(ctx->pin, w.E, eb, hipMemcpyDeviceToHost, st));
-      HIPCHK(ctx, hipStreamSynchronize(st));
-      u32 w16[16];
-      msm_tail_combine(w16, (const u32 *)ctx->pin, g.W, g.nv, g.c);
-      memcpy(out, w16, 64);
+      HIPCHK(ctx, hipMemcpyAsync(lane ? ctx->pin1 : ctx->pin, w.E, eb, hipMemcpyDeviceToHost, st));
     }
+    pd.active = true; pd.W = g.W; pd.nv = g.nv; pd.c = g.c; pd.tail = tail;
   }
-  debug_sync(ctx, "ST_TAIL");
   HIPCHK(ctx, hipGetLastError());
   return BPMI_OK;
+}
+// Wait for the lane and run the host part of the tail; out = the MSM result.
+static int msm_finish(bpmi_ctx *ctx, int lane, uint8_t out[64]) {
+  bpmi_ctx::PendingMsm &pd = ctx->pend[lane];
+  if (!pd.active) { memset(out, 0, 64); return BPMI_OK; }      // n == 0
+  hipStream_t st = lane_stream(ctx, lane);
+  HIPCHK(ctx, hipStreamSynchronize(st));
+  const void *pin = lane ? ctx->pin1 : ctx->pin;
+  if (pd.tail == 1) {
+    memcpy(out, pin, 64);
+  } else {
+    u32 w16[16];
+    msm_tail_combine(w16, (const u32 *)pin, pd.W, pd.nv, pd.c);
+    memcpy(out, w16, 64);
+  }
+  pd.active = false;
+  debug_sync(ctx, "ST_TAIL", st);
+  return BPMI_OK;
+}
+static int msm_run(bpmi_ctx *ctx, const Segs &segs, uint8_t out[64]) {
+  if (segs.total > BPMI_MAX_N) return fail(ctx, BPMI_E_ARG, "n exceeds BPMI_MAX_N");
+  int rc = msm_enqueue(ctx, 0, segs);
+  if (rc) return rc;
+  return msm_finish(ctx, 0, out);
+}
+// two independent MSMs, overlapped on the two lanes; everything already enqueued on the
+// ctx stream (the producers of the scalars) is ordered before both
+static int msm_run_pair(bpmi_ctx *ctx, const Segs &s0, uint8_t out0[64], const Segs &s1, uint8_t out1[64]) {
+  if (s0.total > BPMI_MAX_N || s1.total > BPMI_MAX_N) return fail(ctx, BPMI_E_ARG, "n exceeds BPMI_MAX_N");
+  int rc = ensure_lane(ctx, 1);
+  if (rc) return rc;
+  HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+  HIPCHK(ctx, hipStreamWaitEvent(ctx->stream1, ctx->ev_fork, 0));
+  rc = msm_enqueue(ctx, 0, s0);
+  if (rc) return rc;
+  rc = msm_enqueue(ctx, 1, s1);
+  if (rc) return rc;
+  rc = msm_finish(ctx, 0, out0);
+  const int rc1 = msm_finish(ctx, 1, out1);
+  return rc ? rc : rc1;
 }
 
 // second-level segscan buffer sizing relies on this: every level after the first has
@@ -1233,6 +1307,10 @@ void bpmi_ctx_destroy(bpmi_ctx *ctx) {
   if (ctx->ws) (void)hipFree(ctx->ws);
   if (ctx->stage_in) (void)hipFree(ctx->stage_in);
   if (ctx->pin) (void)hipHostFree(ctx->pin);
+  if (ctx->stream1) { (void)hipStreamSynchronize(ctx->stream1); (void)hipStreamDestroy(ctx->stream1); }
+  if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+  if (ctx->ws1) (void)hipFree(ctx->ws1);
+  if (ctx->pin1) (void)hipHostFree(ctx->pin1);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -1481,7 +1559,7 @@ struct bpmi_ipa {
   u32 *g, *h;           // device bases (M points each)
   u32 *g2, *h2;         // device, materialisation targets (M/16 points each)
   u32 *a, *b;           // device, folded in place every round
-  u32 *eg, *eh;         // device, expanded scalars for the deferred MSMs (M each)
+  u32 *eg, *eh, *eg2, *eh2;   // device, expanded scalars for the deferred L and R MSMs (M each)
   u32 *cg[2], *ch[2];   // device coefficient tables (ping-pong), 2^d entries in cg[cur]
   int cur;
   u32 *u;               // device, 64 B point
@@ -1510,7 +1588,7 @@ static int ipa_alloc(bpmi_ctx *ctx, uint64_t n, bpmi_ipa **out) {
   if (st->big_m < 32) st->big_m = 32;
   const size_t pts = align_up(64 * n, 256), scs = align_up(32 * n, 256);
   const size_t pts2 = align_up(64 * (n / 16 + 1), 256), coef = align_up(32 * n, 256);
-  const size_t bytes = pts * 2 + pts2 * 2 + scs * 4 + coef * 4 + 256 * 3 + 32 * 1024 + 2 * align_up(sizeof(NafK), 256);
+  const size_t bytes = pts * 2 + pts2 * 2 + scs * 6 + coef * 4 + 256 * 3 + 32 * 1024 + 2 * align_up(sizeof(NafK), 256);
   hipError_t e = hipMalloc(&st->block, bytes);
   if (e != hipSuccess) { delete st; return fail(ctx, BPMI_E_NOMEM, std::string("hipMalloc(ipa state): ") + hipGetErrorString(e)); }
   char *p = (char *)st->block;
@@ -1522,6 +1600,8 @@ static int ipa_alloc(bpmi_ctx *ctx, uint64_t n, bpmi_ipa **out) {
   st->b = (u32 *)p; p += scs;
   st->eg = (u32 *)p; p += scs;
   st->eh = (u32 *)p; p += scs;
+  st->eg2 = (u32 *)p; p += scs;
+  st->eh2 = (u32 *)p; p += scs;
   for (int k = 0; k < 2; k++) { st->cg[k] = (u32 *)p; p += coef; st->ch[k] = (u32 *)p; p += coef; }
   st->u = (u32 *)p; p += 256;
   st->cl = (u32 *)p; p += 256;
@@ -1601,34 +1681,34 @@ int bpmi_ipa_round_LR(bpmi_ipa *st, uint8_t L[64], uint8_t R[64]) {
     sL.pts[1] = h_lo; sL.sc[1] = b_hi; sL.n[1] = (u32)np;
     sL.pts[2] = st->u; sL.sc[2] = st->cl; sL.n[2] = 1;
     sL.total = (u32)(2 * np + 1);
-    rc = msm_run(ctx, sL, L);
-    if (rc) return rc;
     Segs sR = {};
     sR.pts[0] = g_lo; sR.sc[0] = a_hi; sR.n[0] = (u32)np;
     sR.pts[1] = h_hi; sR.sc[1] = b_lo; sR.n[1] = (u32)np;
     sR.pts[2] = st->u; sR.sc[2] = st->cr; sR.n[2] = 1;
     sR.total = (u32)(2 * np + 1);
-    rc = msm_run(ctx, sR, R);
+    rc = msm_run_pair(ctx, sL, L, sR, R);
     if (rc) return rc;
   } else {
     // deferred: MSM over the UNFOLDED bases with the fold coefficients multiplied into the
     // scalars (half of them are zero and drop out in the digit pass)
     u32 logm = 0;
     while ((1ull << logm) < st->n) logm++;
+    Segs sg[2];
     for (int right = 0; right < 2; right++) {
+      u32 *eg = right ? st->eg2 : st->eg, *eh = right ? st->eh2 : st->eh;
       {
         StageTimer t(ctx, ST_SCFOLD);
         hipLaunchKernelGGL(k_ipa_expand, dim3((u32)((st->M + 255) / 256)), dim3(256), 0, ctx->stream, st->a, st->b,
-                           st->cg[st->cur], st->ch[st->cur], (u32)st->M, logm, right, st->eg, st->eh);
+                           st->cg[st->cur], st->ch[st->cur], (u32)st->M, logm, right, eg, eh);
       }
-      Segs sg = {};
-      sg.pts[0] = st->g; sg.sc[0] = st->eg; sg.n[0] = (u32)st->M;
-      sg.pts[1] = st->h; sg.sc[1] = st->eh; sg.n[1] = (u32)st->M;
-      sg.pts[2] = st->u; sg.sc[2] = right ? st->cr : st->cl; sg.n[2] = 1;
-      sg.total = (u32)(2 * st->M + 1);
-      rc = msm_run(ctx, sg, right ? R : L);
-      if (rc) return rc;
+      sg[right] = Segs{};
+      sg[right].pts[0] = st->g; sg[right].sc[0] = eg; sg[right].n[0] = (u32)st->M;
+      sg[right].pts[1] = st->h; sg[right].sc[1] = eh; sg[right].n[1] = (u32)st->M;
+      sg[right].pts[2] = st->u; sg[right].sc[2] = right ? st->cr : st->cl; sg[right].n[2] = 1;
+      sg[right].total = (u32)(2 * st->M + 1);
     }
+    rc = msm_run_pair(ctx, sg[0], L, sg[1], R);
+    if (rc) return rc;
   }
   st->lr_done = true;
   return BPMI_OK;
