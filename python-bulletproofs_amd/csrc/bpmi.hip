@@ -654,7 +654,7 @@ __device__ __forceinline__ void block_tree_sum(xyzz &val, u32 *s_val) {
 
 // ---- bucket reduction, step 1: D[w][v][d] = sum of buckets b in [1,B] whose base-32 digit v is d
 // grid = W * nv * 31 blocks of 256
-__global__ void __launch_bounds__(256) k_bucket_digit_sums(MsmGeom g, const u32 *__restrict__ buckets, u32 *__restrict__ D) {
+__global__ void __launch_bounds__(256, 4) k_bucket_digit_sums(MsmGeom g, const u32 *__restrict__ buckets, u32 *__restrict__ D) {
   __shared__ u32 s_val[256 * LDS_STRIDE];
   const u32 blk = blockIdx.x;
   const u32 d = blk % 31u + 1u;

@@ -1,4 +1,4 @@
-"""Batch verification of 64-bit-style single range proofs that share (g, h, u, gs, hs):
+"""Batch verification of range proofs (single or aggregated) that share (g, h, u, gs, hs):
 every proof's four EC verification equations are combined with fresh random weights into
 ONE multi-scalar multiplication that must evaluate to the identity (SURVEY.md section
 8f item 3; not present in the reference, which verifies one proof at a time).
@@ -7,6 +7,8 @@ For proof k (notation of the reference: rangeproof_verifier.py:55-99,
 inner_product_verifier.py:44-58,127-147), with hsp_i = y^-i * hs_i folded into scalars:
 
   E1  (t_hat - delta) g + taux h - z^2 V - x T1 - x^2 T2                         = 0
+      (aggregated, m values: - sum_j z^(j+2) V_j, and z^(2 + i//n) 2^(i%n) in E2;
+       rangeproof_aggreg_verifier.py:55-108)
   E2  P_new - A - x S + sum_i z gs_i - sum_i (z y^i + z^2 2^i) y^-i hs_i
         + mu h - (x_ip t_hat) u                                                  = 0
   E3  u_new - x_ip u                                                             = 0
@@ -67,9 +69,15 @@ class BatchRangeVerifier:
     def add(self, V, proof):
         """Host-side transcript checks of RangeVerifier / Verifier1 / Verifier2 (raise
         Exception("Proof invalid") exactly as they do), then accumulate the proof's
-        weighted equations."""
-        n, q = self.n, Q
-        rv = RangeVerifier(V, self.g, self.h, self.gs, self.hs, self.u, proof)
+        weighted equations.  `V` is one commitment (single proof over all len(gs) bits) or
+        a list of m commitments (aggregated proof, len(gs) = n * m)."""
+        nm, q = self.n, Q
+        Vs = list(V) if isinstance(V, (list, tuple)) else [V]
+        aggregated = isinstance(V, (list, tuple))
+        m = len(Vs)
+        rv = RangeVerifier(Vs[0], self.g, self.h, self.gs, self.hs, self.u, proof)
+        rv.assertThat(m >= 1 and nm % m == 0)
+        n = nm // m
         rv.verify_transcript()                               # A, S, T1, T2 bytes; reads y, z, x
         x, y, z = rv.x.x % q, rv.y.x % q, rv.z.x % q
         ip = proof.innerProof
@@ -78,7 +86,7 @@ class BatchRangeVerifier:
         x_ip = int(ip.transcript.split(b"&")[1]) % q
         p2 = ip.proof2
         Verifier2(self.gs, None, None, None, p2).verify_transcript()   # L, R bytes; every x_j re-hashed
-        log_n = n.bit_length() - 1
+        log_n = nm.bit_length() - 1
         rv.assertThat(len(p2.xs) == log_n and len(p2.Ls) == log_n and len(p2.Rs) == log_n)
         xs = [xj.x % q for xj in p2.xs]
         a, b = p2.a.x % q, p2.b.x % q
@@ -92,23 +100,26 @@ class BatchRangeVerifier:
         for xv, xi in zip(reversed(xs), reversed(xinvs)):
             ss = [s * xi % q for s in ss] + [s * xv % q for s in ss]
             si = [s * xv % q for s in si] + [s * xi % q for s in si]
-        z2 = z * z % q
-        ysum, yp, ypi, two = 0, 1, 1, 1
-        w2z, w4a, w4b, w2z2 = w2 * z % q, w4 * a % q, w4 * b % q, w2 * z2 % q
-        for i in range(n):
+        zpow = [pow(z, 2 + j, q) for j in range(m)]          # z^2 for a single proof
+        ysum, yp, ypi = 0, 1, 1
+        w2z, w4a, w4b = w2 * z % q, w4 * a % q, w4 * b % q
+        for i in range(nm):
             ysum += yp
             self.c_gs[i] = (self.c_gs[i] + w2z + w4a * ss[i]) % q
-            # y^-i * ( -w2 (z y^i + z^2 2^i) + w4 b s_i^-1 )
-            self.c_hs[i] = (self.c_hs[i] - w2z + ypi * ((w4b * si[i] - w2z2 * two) % q)) % q
+            zt = zpow[i // n] * (1 << (i % n)) % q           # z^(2 + i//n) 2^(i%n)
+            # y^-i * ( -w2 (z y^i + zt) + w4 b s_i^-1 )
+            self.c_hs[i] = (self.c_hs[i] - w2z + ypi * ((w4b * si[i] - w2 * zt) % q)) % q
             yp = yp * y % q
             ypi = ypi * yinv % q
-            two = two * 2 % q
-        delta = ((z - z2) * ysum - z2 * z * ((1 << n) - 1)) % q
+        if aggregated:
+            delta = ((z - z * z) * ysum - sum(pow(z, j + 2, q) for j in range(1, m + 1)) * ((1 << n) - 1)) % q
+        else:
+            delta = ((z - z * z) * ysum - pow(z, 3, q) * ((1 << n) - 1)) % q
         self.c_g = (self.c_g + w1 * (t_hat - delta)) % q
         self.c_h = (self.c_h + w1 * taux + w2 * mu) % q
         self.c_u = (self.c_u - w2 * x_ip % q * t_hat - w3 * x_ip) % q
-        pts = [V, proof.T1, proof.T2, proof.A, proof.S, ip.P_new, ip.u_new] + list(p2.Ls) + list(p2.Rs)
-        scs = [-w1 * z2, -w1 * x, -w1 * x % q * x, -w2, -w2 * x, w2 - w4, w3 + w4 * a % q * b]
+        pts = Vs + [proof.T1, proof.T2, proof.A, proof.S, ip.P_new, ip.u_new] + list(p2.Ls) + list(p2.Rs)
+        scs = [-w1 * zp for zp in zpow] + [-w1 * x, -w1 * x % q * x, -w2, -w2 * x, w2 - w4, w3 + w4 * a % q * b]
         scs += [-w4 * xv % q * xv for xv in xs] + [-w4 * xi % q * xi for xi in xinvs]
         self._pts.append(b"".join(p.to_le64() for p in pts))
         self._scs.extend(scs)

@@ -123,3 +123,35 @@ def test_batch_partials_add_up(gp, batch):
             bv.add(V, pr)
         parts.append(bv.partial())
     assert eng.ec_sum_bytes(b"".join(parts), 2) == bytes(64)
+
+
+def test_batch_aggregated_proofs(gp):
+    """Aggregated proofs (m values each) in the same batch machinery, mixed with nothing
+    else; one bad commitment must fail the batch."""
+    from bulletproofs_amd.ec import secp256k1
+    from bulletproofs_amd.rangeproofs import AggregNIRangeProver, AggregRangeVerifier, BatchRangeVerifier
+    from bulletproofs_amd.utils import ModP, mod_hash, commitment
+    n, m = 8, 4
+    gs, hs = gp.to_gpu_list(gens(n * m, b"ags")), gp.to_gpu_list(gens(n * m, b"ahs"))
+    g, h, u = (gp.to_gpu(R.elliptic_hash(s)) for s in (b"ag", b"ah", b"au"))
+    rnd = random.Random(3)
+    items = []
+    for k in range(3):
+        vs = [ModP(rnd.randrange(2 ** n), Q) for _ in range(m)]
+        gammas = [mod_hash(b"ag%d_%d" % (k, j), Q) for j in range(m)]
+        Vs = [commitment(g, h, vs[j], gammas[j]) for j in range(m)]
+        pr = AggregNIRangeProver(vs, n, g, h, gs, hs, gammas, u, secp256k1, b"aseed%d" % k).prove()
+        assert AggregRangeVerifier(Vs, g, h, gs, hs, u, pr).verify() is True
+        items.append((Vs, pr))
+    bv = BatchRangeVerifier(g, h, gs, hs, u)
+    for Vs, pr in items:
+        bv.add(Vs, pr)
+    assert bv.verify() is True
+    bv.reset()
+    for k, (Vs, pr) in enumerate(items):
+        if k == 1:
+            Vs = list(Vs)
+            Vs[2] = Vs[2] + g
+        bv.add(Vs, pr)
+    with pytest.raises(Exception, match="Proof invalid"):
+        bv.verify()

@@ -147,3 +147,23 @@ def test_msm_full_size_properties(gp, logn):
         assert pts_host[:64] == cbind.pack_points([ks[0] * gp.G])
     for d in (d_k, d_pts, d_e, d_f, d_ef):
         d.free()
+
+
+def test_msm_2e24_periodic_inputs(gp):
+    """n = 2^24 (the global-atomic sort path used above 2^23, 2^28 sorted entries, 32-bit
+    position arithmetic near its range) with inputs of period 2^16: MSM(P x 256, e x 256)
+    must equal 256 * MSM(P, e).  Every bucket receives 256 copies of the same point, so the
+    P + P branch of the complete addition formula runs millions of times."""
+    eng = gp.engine()
+    m, reps = 1 << 16, 256
+    rnd = random.Random(24)
+    G64 = cbind.pack_points([gp.G])
+    ks = b"".join(rnd.randrange(1, Q).to_bytes(32, "little") for _ in range(m))
+    pts = eng.ec_mul_batch_bytes(G64 * m, ks, m)
+    es = b"".join(rnd.randrange(Q).to_bytes(32, "little") for _ in range(m))
+    small = eng.msm_bytes(pts, es, m)
+    d_p, d_e = eng.upload(pts * reps), eng.upload(es * reps)
+    big = eng.msm_dev(d_p, d_e, m * reps)
+    d_p.free()
+    d_e.free()
+    assert big == eng.ec_mul_batch_bytes(small, (reps).to_bytes(32, "little"), 1)
