@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""Config C5: batch-verify 2^14 x 64-bit range proofs, sharded by proof across the GPUs of
+one node (one process per GPU):
+
+  python tools/bench_batch_verify.py [--log-batch 14] [--distinct 64]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         tools/bench_batch_verify.py --log-batch 14
+
+Every rank proves `distinct` proofs (seeded, identical on all ranks), cycles them to fill
+its shard of the batch, runs the host-side transcript checks and scalar preparation for its
+shard, evaluates ONE MSM (rangeproofs/batch.py), and the 64-byte partial values are
+combined with one all_gather + fold.  Prints one JSON line on rank 0."""
+import argparse
+import hashlib
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--log-batch", type=int, default=14)
+    ap.add_argument("--distinct", type=int, default=64)
+    args = ap.parse_args()
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    import bulletproofs_amd  # noqa: F401
+    from bulletproofs_amd.distributed import ShardedMSM, shard_bounds
+    from bulletproofs_amd.ec import secp256k1
+    from bulletproofs_amd.engine import Engine, set_default_engine
+    from bulletproofs_amd.rangeproofs import BatchRangeVerifier, NIRangeProver
+    from bulletproofs_amd.utils import ModP, commitment, elliptic_hash, mod_hash
+    eng = Engine(device=local)
+    set_default_engine(eng)
+    Q = secp256k1.q
+    n = 64
+    gs = [elliptic_hash(str(i).encode() + b"gs") for i in range(n)]
+    hs = [elliptic_hash(str(i).encode() + b"hs") for i in range(n)]
+    g, h, u = elliptic_hash(b"g"), elliptic_hash(b"h"), elliptic_hash(b"u")
+    proofs = []
+    t0 = time.perf_counter()
+    for j in range(args.distinct):
+        v = ModP(int.from_bytes(hashlib.sha256(b"v%d" % j).digest()[:8], "big"), Q)
+        gamma = mod_hash(b"gamma%d" % j, Q)
+        proofs.append((commitment(g, h, v, gamma), NIRangeProver(v, n, g, h, gs, hs, gamma, u, secp256k1, b"seed%d" % j).prove()))
+    t_prove = time.perf_counter() - t0
+    total = 1 << args.log_batch
+    lo, hi = shard_bounds(total, world, rank)
+    sharded = ShardedMSM(engine=eng)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    bv = BatchRangeVerifier(g, h, gs, hs, u)
+    for k in range(lo, hi):
+        V, pr = proofs[k % args.distinct]
+        bv.add(V, pr)
+    t_host = time.perf_counter() - t0
+    ok = bv.verify(sharded=sharded if world > 1 else None)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    if rank == 0:
+        print(json.dumps({"metric": "range-proof verifies/sec (batched, 64-bit proofs)", "value": total / elapsed,
+                          "unit": "verifies/s", "n_gpus": world, "batch": total, "seconds": elapsed,
+                          "host_prep_s_rank0": t_host, "msm_points_rank0": 3 + 2 * n + 19 * (hi - lo), "ok": ok,
+                          "proves_per_s_one_gpu": args.distinct / t_prove}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
