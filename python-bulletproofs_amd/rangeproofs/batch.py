@@ -56,6 +56,7 @@ class BatchRangeVerifier:
 
     def reset(self):
         self.c_g = self.c_h = self.c_u = 0
+        self._gs_const = self._hs_const = 0   # terms that are equal for every generator index
         self.c_gs = [0] * self.n
         self.c_hs = [0] * self.n
         self._pts = []          # per-proof points, 64-byte strings
@@ -93,24 +94,51 @@ class BatchRangeVerifier:
         t_hat, taux, mu = proof.t_hat.x % q, proof.taux.x % q, proof.mu.x % q
 
         w1, w2, w3, w4 = self._weight(), self._weight(), self._weight(), self._weight()
-        # powers and the s-vector (get_ss, inner_product_verifier.py:91-102) with plain ints
-        yinv = pow(y, -1, q)
-        xinvs = [pow(v, -1, q) for v in xs]
-        ss, si = [1], [1]
+        # one modular inversion for (x_1 .. x_k, y) (Montgomery's trick)
+        vals = xs + [y]
+        pre, acc = [], 1
+        for v in vals:
+            pre.append(acc)
+            acc = acc * v % q
+        inv = pow(acc, -1, q)
+        invs = [0] * len(vals)
+        for k in range(len(vals) - 1, -1, -1):
+            invs[k] = inv * pre[k] % q
+            inv = inv * vals[k] % q
+        xinvs, yinv = invs[:-1], invs[-1]
+        # s-vector by doubling (get_ss, inner_product_verifier.py:91-102) with the weights
+        # folded in:  sg_i = w4 a s_i   and   sh_i = w4 b s_i^-1 y^-i  (the step that creates
+        # index bit k multiplies the bit-1 half by y^-(2^k) as well)
+        sg, sh = [w4 * a % q], [w4 * b % q]
+        ypow2 = yinv
         for xv, xi in zip(reversed(xs), reversed(xinvs)):
-            ss = [s * xi % q for s in ss] + [s * xv % q for s in ss]
-            si = [s * xv % q for s in si] + [s * xi % q for s in si]
+            hi_g, hi_h = xv, xi * ypow2 % q
+            sg = [s_ * xi % q for s_ in sg] + [s_ * hi_g % q for s_ in sg]
+            sh = [s_ * xv % q for s_ in sh] + [s_ * hi_h % q for s_ in sh]
+            ypow2 = ypow2 * ypow2 % q
         zpow = [pow(z, 2 + j, q) for j in range(m)]          # z^2 for a single proof
-        ysum, yp, ypi = 0, 1, 1
-        w2z, w4a, w4b = w2 * z % q, w4 * a % q, w4 * b % q
-        for i in range(nm):
-            ysum += yp
-            self.c_gs[i] = (self.c_gs[i] + w2z + w4a * ss[i]) % q
-            zt = zpow[i // n] * (1 << (i % n)) % q           # z^(2 + i//n) 2^(i%n)
-            # y^-i * ( -w2 (z y^i + zt) + w4 b s_i^-1 )
-            self.c_hs[i] = (self.c_hs[i] - w2z + ypi * ((w4b * si[i] - w2 * zt) % q)) % q
-            yp = yp * y % q
-            ypi = ypi * yinv % q
+        w2z = w2 * z % q
+        c_gs, c_hs = self.c_gs, self.c_hs
+        self._gs_const = (self._gs_const + w2z) % q          # the same w2 z on every gs_i ...
+        self._hs_const = (self._hs_const - w2z) % q          # ... and -w2 z on every hs_i
+        r = 2 * yinv % q                                     # (2/y)^i runs geometrically inside a value block
+        yn_inv = pow(yinv, n, q)
+        blk = 1                                              # y^-(n j)
+        i = 0
+        for j in range(m):
+            geo = w2 * zpow[j] % q * blk % q                 # w2 z^(2+j) 2^(i%n) y^-i  at i = n j
+            for _ in range(n):
+                c_gs[i] += sg[i]
+                c_hs[i] += sh[i] - geo
+                geo = geo * r % q
+                i += 1
+            blk = blk * yn_inv % q
+        # sum_{i<nm} y^i by doubling
+        ysum, ypw, length = 1, y, 1
+        while length < nm:
+            ysum = ysum * (1 + ypw) % q
+            ypw = ypw * ypw % q
+            length *= 2
         if aggregated:
             delta = ((z - z * z) * ysum - sum(pow(z, j + 2, q) for j in range(1, m + 1)) * ((1 << n) - 1)) % q
         else:
@@ -127,7 +155,8 @@ class BatchRangeVerifier:
 
     def partial(self):
         """The 64-byte value of this verifier's accumulated combination (one MSM)."""
-        shared = [self.c_g, self.c_h, self.c_u] + self.c_gs + self.c_hs
+        shared = [self.c_g, self.c_h, self.c_u] + [v + self._gs_const for v in self.c_gs] + \
+            [v + self._hs_const for v in self.c_hs]
         pts = self._shared_pts + b"".join(self._pts)
         scs = b"".join(_le32(v) for v in shared) + b"".join(_le32(v) for v in self._scs)
         npts = 3 + 2 * self.n + len(self._scs)
