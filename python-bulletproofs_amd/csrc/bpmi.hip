@@ -1038,8 +1038,8 @@ static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; 
 // handful of buckets, so c in {8, 13, 16} (top window 7, 8, 15 bits) are preferred.
 static u32 pick_window_bits(const bpmi_ctx *ctx, uint64_t n) {
   if (ctx->opt_c >= 2 && ctx->opt_c <= 16) return (u32)ctx->opt_c;
-  if (n >= (1u << 19)) return 16;
-  if (n >= (1u << 15)) return 13;
+  if (n >= (1u << 18)) return 16;
+  if (n >= (1u << 16)) return 13;
   if (n >= (1u << 10)) return 8;
   u32 lg = 0;
   while ((1ull << (lg + 1)) <= n) lg++;
@@ -1100,7 +1100,7 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, const Segs &segs) {
   g.W = 255u / g.c + 1u;
   g.B = 1u << (g.c - 1);
   g.G = g.W * g.B;
-  g.L = ctx->opt_chunk > 0 ? (u32)ctx->opt_chunk : (n >= (1u << 19) ? 64u : 32u);   // tools/tune_msm.py sweep
+  g.L = ctx->opt_chunk > 0 ? (u32)ctx->opt_chunk : (n >= (1u << 19) ? 64u : (n >= (1u << 16) ? 32u : 16u));   // tools/tune_msm.py sweeps
   g.nv = (g.c + 4u) / 5u;
   MsmWs w;
   msm_layout(g, w, nullptr);

@@ -21,9 +21,9 @@ for logn in [int(a) for a in sys.argv[1:]] or [20]:
     n = 1 << logn
     d_p, d_s = device_points(n, 1), eng.upload(sha_scalars(n, 2))
     ref = None
-    for c in (0, logn - 5, logn - 4, logn - 3, logn - 2):
+    for c in (0, 8, 10, 13, 16):
         if c and not (4 <= c <= 16): continue
-        for chunk in (32, 48, 64, 96, 128):
+        for chunk in (16, 32, 64):
             eng.set_option("window_bits", c); eng.set_option("chunk", chunk)
             r = eng.msm_dev(d_p, d_s, n)
             ref = ref or r
