@@ -8,7 +8,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbpmi.so")
 SOURCES = ["bpmi.hip"]
-HEADERS = ["field.hpp", "curve.hpp", "scalar.hpp", os.path.join("..", "..", "include", "bpmi.h")]
+HEADERS = ["field.hpp", "curve.hpp", "scalar.hpp", "context.hpp", "device_util.hpp", "msm_kernels.hpp",
+           "point_kernels.hpp", "scalar_kernels.hpp", "msm_host.hpp", os.path.join("..", "..", "include", "bpmi.h")]
 
 
 def hipcc():

@@ -1,0 +1,131 @@
+// context.hpp -- part of libbpmi (included by bpmi.hip; one translation unit).
+// Engine context: streams, workspaces, error reporting, per-stage HIP-event timers.
+#pragma once
+
+// ------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------
+enum Stage {
+  ST_DIGITS = 0, ST_SCAN, ST_SCATTER, ST_ACCUM, ST_SEGSCAN, ST_BREDUCE, ST_TAIL,
+  ST_MULBATCH, ST_LINCOMB2, ST_SCDOT, ST_SCFOLD, ST_MISC
+};
+static const char *STAGE_NAMES[BPMI_NSTAGES] = {
+  "msm_digits_hist", "msm_scan", "msm_scatter", "msm_accumulate", "msm_segscan", "msm_bucket_reduce",
+  "msm_tail", "ec_mul_batch", "ec_lincomb2", "sc_dot", "sc_fold", "misc"
+};
+
+struct EvPair { int stage; hipEvent_t a, b; };
+
+struct bpmi_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::string err;
+  // workspace (grown on demand, never shrunk)
+  void *ws = nullptr; size_t ws_bytes = 0;
+  void *pin = nullptr; size_t pin_bytes = 0;       // pinned host staging
+  // second MSM lane: an independent stream + workspace, so two independent MSMs (the L and
+  // R of an IPA round) overlap -- the latency-bound stages of one hide under the
+  // throughput-bound stages of the other
+  hipStream_t stream1 = nullptr;
+  void *ws1 = nullptr; size_t ws1_bytes = 0;
+  void *pin1 = nullptr; size_t pin1_bytes = 0;
+  hipEvent_t ev_fork = nullptr;
+  struct PendingMsm { bool active = false; u32 W = 0, nv = 0, c = 0; int tail = 2; u32 *E = nullptr, *out = nullptr; } pend[2];
+  void *stage_in = nullptr; size_t stage_in_bytes = 0;  // device staging for host-pointer entry points
+  // options
+  int opt_c = 0;        // window bits, 0 = auto
+  int opt_tail = 0;     // 0 auto, 1 device, 2 host
+  int opt_chunk = 0;    // entries per thread in k_accum_l0, 0 = auto
+  int64_t opt_ipa_big = 0;   // base length from which the IPA folds generators 16-way (0 = default 2^18)
+  // profiling
+  bool prof = false;
+  std::vector<EvPair> evs;
+  double prof_ms[BPMI_NSTAGES] = {0};
+  uint64_t prof_calls[BPMI_NSTAGES] = {0};
+};
+
+static std::string g_create_err;
+static std::mutex g_mu;
+
+static int fail(bpmi_ctx *ctx, int code, const std::string &msg) {
+  if (ctx) ctx->err = msg;
+  else { std::lock_guard<std::mutex> lk(g_mu); g_create_err = msg; }
+  return code;
+}
+#define HIPCHK(ctx, call)                                                                   \
+  do {                                                                                      \
+    hipError_t e_ = (call);                                                                 \
+    if (e_ != hipSuccess)                                                                   \
+      return fail(ctx, e_ == hipErrorOutOfMemory ? BPMI_E_NOMEM : BPMI_E_HIP,               \
+                  std::string(#call) + ": " + hipGetErrorString(e_));                       \
+  } while (0)
+
+static bool g_debug_sync = getenv("BPMI_DEBUG_SYNC") != nullptr;
+static void debug_sync(bpmi_ctx *ctx, const char *what, hipStream_t stream = nullptr) {
+  if (!g_debug_sync) return;
+  fprintf(stderr, "[bpmi] sync after %s ... ", what); fflush(stderr);
+  hipError_t e = hipStreamSynchronize(stream ? stream : ctx->stream);
+  fprintf(stderr, "%s\n", hipGetErrorString(e)); fflush(stderr);
+}
+struct StageTimer {
+  bpmi_ctx *ctx; int stage; hipStream_t stream; hipEvent_t a = nullptr, b = nullptr;
+  StageTimer(bpmi_ctx *c, int s, hipStream_t st = nullptr) : ctx(c), stage(s), stream(st ? st : c->stream) {
+    if (ctx->prof) {
+      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
+      (void)hipEventRecord(a, stream);
+    }
+  }
+  ~StageTimer() {
+    if (ctx->prof && a) { (void)hipEventRecord(b, stream); ctx->evs.push_back({stage, a, b}); }
+  }
+};
+
+static int ensure_ws(bpmi_ctx *ctx, size_t bytes) {
+  if (bytes <= ctx->ws_bytes) return BPMI_OK;
+  if (ctx->ws) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(ctx->ws)); ctx->ws = nullptr; ctx->ws_bytes = 0; }
+  size_t want = bytes + bytes / 8;
+  HIPCHK(ctx, hipMalloc(&ctx->ws, want));
+  ctx->ws_bytes = want;
+  return BPMI_OK;
+}
+static int ensure_lane(bpmi_ctx *ctx, int lane) {
+  if (lane == 0 || ctx->stream1) return BPMI_OK;
+  HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream1, hipStreamNonBlocking));
+  HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+  return BPMI_OK;
+}
+static hipStream_t lane_stream(bpmi_ctx *ctx, int lane) { return lane ? ctx->stream1 : ctx->stream; }
+static int ensure_ws_lane(bpmi_ctx *ctx, int lane, size_t bytes) {
+  if (lane == 0) return ensure_ws(ctx, bytes);
+  if (bytes <= ctx->ws1_bytes) return BPMI_OK;
+  if (ctx->ws1) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream1)); HIPCHK(ctx, hipFree(ctx->ws1)); ctx->ws1 = nullptr; ctx->ws1_bytes = 0; }
+  const size_t want = bytes + bytes / 8;
+  HIPCHK(ctx, hipMalloc(&ctx->ws1, want));
+  ctx->ws1_bytes = want;
+  return BPMI_OK;
+}
+static int ensure_pin_lane(bpmi_ctx *ctx, int lane, size_t bytes);
+static int ensure_stage_in(bpmi_ctx *ctx, size_t bytes) {
+  if (bytes <= ctx->stage_in_bytes) return BPMI_OK;
+  if (ctx->stage_in) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(ctx->stage_in)); ctx->stage_in = nullptr; ctx->stage_in_bytes = 0; }
+  HIPCHK(ctx, hipMalloc(&ctx->stage_in, bytes));
+  ctx->stage_in_bytes = bytes;
+  return BPMI_OK;
+}
+static int ensure_pin(bpmi_ctx *ctx, size_t bytes) {
+  if (bytes <= ctx->pin_bytes) return BPMI_OK;
+  if (ctx->pin) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipHostFree(ctx->pin)); ctx->pin = nullptr; ctx->pin_bytes = 0; }
+  HIPCHK(ctx, hipHostMalloc(&ctx->pin, bytes, hipHostMallocDefault));
+  ctx->pin_bytes = bytes;
+  return BPMI_OK;
+}
+
+static int ensure_pin_lane(bpmi_ctx *ctx, int lane, size_t bytes) {
+  if (lane == 0) return ensure_pin(ctx, bytes);
+  if (bytes <= ctx->pin1_bytes) return BPMI_OK;
+  if (ctx->pin1) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream1)); HIPCHK(ctx, hipHostFree(ctx->pin1)); ctx->pin1 = nullptr; ctx->pin1_bytes = 0; }
+  HIPCHK(ctx, hipHostMalloc(&ctx->pin1, bytes, hipHostMallocDefault));
+  ctx->pin1_bytes = bytes;
+  return BPMI_OK;
+}

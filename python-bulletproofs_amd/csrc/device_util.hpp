@@ -1,0 +1,73 @@
+// device_util.hpp -- part of libbpmi (included by bpmi.hip; one translation unit).
+// Device-side load/store helpers, the multi-segment input descriptor.
+#pragma once
+
+// ------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------
+#define XYZZ_WORDS 36
+#define LDS_STRIDE 37   // odd stride: conflict-free ds_read/ds_write of 36-word records
+
+// up to three (points, scalars) segments presented as one logical array, so that
+// e.g. L = <a_lo, g_hi> + <b_hi, h_lo> + cl*u is ONE MSM without any gather/concat
+// (the reference concatenates Python lists: src/utils/commitments.py:13)
+struct Segs {
+  const u32 *pts[3];
+  const u32 *sc[3];
+  u32 n[3];
+  u32 total;
+};
+
+__device__ __forceinline__ void load_words16(u32 w[16], const u32 *p) {
+  const uint4 *q = reinterpret_cast<const uint4 *>(p);
+#pragma unroll
+  for (int i = 0; i < 4; i++) { uint4 t = q[i]; w[4 * i] = t.x; w[4 * i + 1] = t.y; w[4 * i + 2] = t.z; w[4 * i + 3] = t.w; }
+}
+__device__ __forceinline__ void load_words8(u32 w[8], const u32 *p) {
+  const uint4 *q = reinterpret_cast<const uint4 *>(p);
+#pragma unroll
+  for (int i = 0; i < 2; i++) { uint4 t = q[i]; w[4 * i] = t.x; w[4 * i + 1] = t.y; w[4 * i + 2] = t.z; w[4 * i + 3] = t.w; }
+}
+__device__ __forceinline__ void store_words16(u32 *p, const u32 w[16]) {
+  uint4 *q = reinterpret_cast<uint4 *>(p);
+#pragma unroll
+  for (int i = 0; i < 4; i++) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+}
+__device__ __forceinline__ void store_words8(u32 *p, const u32 w[8]) {
+  uint4 *q = reinterpret_cast<uint4 *>(p);
+#pragma unroll
+  for (int i = 0; i < 2; i++) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+}
+__device__ __forceinline__ const u32 *seg_point(const Segs &s, u32 i) {
+  if (i < s.n[0]) return s.pts[0] + 16ull * i;
+  i -= s.n[0];
+  if (i < s.n[1]) return s.pts[1] + 16ull * i;
+  i -= s.n[1];
+  return s.pts[2] + 16ull * i;
+}
+__device__ __forceinline__ const u32 *seg_scalar(const Segs &s, u32 i) {
+  if (i < s.n[0]) return s.sc[0] + 8ull * i;
+  i -= s.n[0];
+  if (i < s.n[1]) return s.sc[1] + 8ull * i;
+  i -= s.n[1];
+  return s.sc[2] + 8ull * i;
+}
+__device__ __forceinline__ void load_affine(affine &P, const u32 *p) {
+  u32 w[16];
+  load_words16(w, p);
+  affine_from_words(P, w);
+}
+__device__ __forceinline__ void xyzz_load_g(xyzz &a, const u32 *p) {   // 144 B, 16-B aligned
+  u32 w[XYZZ_WORDS];
+  const uint4 *q = reinterpret_cast<const uint4 *>(p);
+#pragma unroll
+  for (int i = 0; i < 9; i++) { uint4 t = q[i]; w[4 * i] = t.x; w[4 * i + 1] = t.y; w[4 * i + 2] = t.z; w[4 * i + 3] = t.w; }
+  xyzz_load(a, w);
+}
+__device__ __forceinline__ void xyzz_store_g(u32 *p, const xyzz &a) {
+  u32 w[XYZZ_WORDS];
+  xyzz_store(w, a);
+  uint4 *q = reinterpret_cast<uint4 *>(p);
+#pragma unroll
+  for (int i = 0; i < 9; i++) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+}

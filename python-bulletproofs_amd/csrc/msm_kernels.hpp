@@ -1,0 +1,502 @@
+// msm_kernels.hpp -- part of libbpmi (included by bpmi.hip; one translation unit).
+// Kernels of the bucket-method MSM (replaces Pippenger.multiexp, /root/reference/src/pippenger/pippenger.py:22-94).
+#pragma once
+
+// ------------------------------------------------------------------------------------
+// MSM kernels
+// ------------------------------------------------------------------------------------
+struct MsmGeom {
+  u32 n;       // pairs
+  u32 c;       // window bits
+  u32 W;       // windows
+  u32 B;       // buckets per window = 2^(c-1)
+  u32 G;       // W * B
+  u32 L;       // entries per thread in k_accum_l0
+  u32 nv;      // base-32 digit positions of a bucket index (ceil(c / 5))
+};
+
+// Signed-digit recoding of scalar i: calls f(w, b, sign) for every window, b = |digit|
+// in [0, B] (0 = nothing to add), sign = 1 when the NEGATED point is added.
+//   s > (q-1)/2  ->  use q - s on the negated point: halves the digit range, keeps
+//   s < 2^255 so W*c >= 256 never overflows, and turns the range-proof scalar q-1
+//   (aR, rangeproof_prover.py:43-45) into the single digit -1.
+template <typename F>
+__device__ __forceinline__ void for_each_digit(const Segs &segs, const MsmGeom &g, u32 i, F f) {
+  sc s;
+  load_words8(s.v, seg_scalar(segs, i));
+  const bool neg = sc_is_high(s);
+  if (neg) sc_neg(s, s);
+  u32 carry = 0;
+  const u32 mask = (1u << g.c) - 1u;
+  for (u32 w = 0; w < g.W; w++) {
+    const u32 t = (s.v[0] & mask) + carry;
+    // shift the 256-bit register right by c (static register indexing)
+#pragma unroll
+    for (int k = 0; k < 7; k++) s.v[k] = (u32)((((u64)s.v[k + 1] << 32) | s.v[k]) >> g.c);
+    s.v[7] >>= g.c;
+    u32 b, sign;
+    if (t > g.B) { b = (1u << g.c) - t; sign = 1; carry = 1; }
+    else { b = t; sign = 0; carry = 0; }
+    f(w, b, b ? (sign ^ (u32)neg) : 0u);
+  }
+}
+
+// ================= sort path 1 (small n, c < 10): global-atomic counting sort ===========
+// dig[w * n + i] = |d| | (sign << 31); histogram with one atomic per lane, or one per wave
+// when the whole wave agrees (degenerate inputs)
+__global__ void __launch_bounds__(256) k_digits_hist(Segs segs, MsmGeom g, u32 *__restrict__ dig, u32 *__restrict__ hist) {
+  const u32 stride = gridDim.x * blockDim.x;
+  for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < g.n; i += stride) {
+    for_each_digit(segs, g, i, [&](u32 w, u32 b, u32 sign) {
+      dig[(u64)w * g.n + i] = b | (sign << 31);
+      const u32 key = b ? (w * g.B + b - 1u) : 0xFFFFFFFFu;
+      const unsigned long long act = __ballot(1);
+      const u32 first = __builtin_amdgcn_readfirstlane(key);
+      const unsigned long long same = __ballot(key == first);
+      if (same == act) {
+        if (first != 0xFFFFFFFFu) {
+          const u32 lane_rank = __builtin_amdgcn_mbcnt_hi((u32)(act >> 32), __builtin_amdgcn_mbcnt_lo((u32)act, 0));
+          if (lane_rank == 0) atomicAdd(&hist[first], (u32)__popcll(act));
+        }
+      } else if (b) {
+        atomicAdd(&hist[key], 1u);
+      }
+    });
+  }
+}
+
+// ================= sort path 2 (c >= 10): two-level LDS partition sort ==================
+// Bucket key k = b - 1 (c-1 bits) = hi * 256 + lo.  Level A partitions all W*n digits by
+// (window, hi) with LDS histograms -- global atomics only to reserve one range per
+// (tile, partition); level B gives every partition to one block, which counting-sorts it
+// by lo entirely in LDS.  No per-element global atomic anywhere.
+#define PART_MAX 2048          // W * (B / 256) <= 2048 for every c in [10, 16]
+#define TILE_SCALARS 4096      // scalars per block-iteration in level A
+__global__ void __launch_bounds__(256) k_coarse_hist(Segs segs, MsmGeom g, u32 P, u32 *__restrict__ coarse_hist) {
+  __shared__ u32 lh[PART_MAX];
+  for (u32 p = threadIdx.x; p < P; p += 256u) lh[p] = 0;
+  __syncthreads();
+  const u32 Bc = g.B >> 8;
+  const u32 stride = gridDim.x * blockDim.x;
+  for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < g.n; i += stride) {
+    for_each_digit(segs, g, i, [&](u32 w, u32 b, u32) {
+      if (b) atomicAdd(&lh[w * Bc + ((b - 1u) >> 8)], 1u);
+    });
+  }
+  __syncthreads();
+  for (u32 p = threadIdx.x; p < P; p += 256u) { const u32 v = lh[p]; if (v) atomicAdd(&coarse_hist[p], v); }
+}
+// part[pos] = lo << 24 | sign << 23 | i   (n <= 2^23), grouped by partition
+__global__ void __launch_bounds__(256) k_partition(Segs segs, MsmGeom g, u32 P, u32 *__restrict__ coarse_cursor, u32 *__restrict__ part) {
+  __shared__ u32 lh[PART_MAX];
+  const u32 Bc = g.B >> 8;
+  const u32 ntiles = (g.n + TILE_SCALARS - 1) / TILE_SCALARS;
+  for (u32 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    for (u32 p = threadIdx.x; p < P; p += 256u) lh[p] = 0;
+    __syncthreads();
+    const u32 i0 = tile * TILE_SCALARS;
+    const u32 i1 = (i0 + TILE_SCALARS < g.n) ? i0 + TILE_SCALARS : g.n;
+    for (u32 i = i0 + threadIdx.x; i < i1; i += 256u) {
+      for_each_digit(segs, g, i, [&](u32 w, u32 b, u32) {
+        if (b) atomicAdd(&lh[w * Bc + ((b - 1u) >> 8)], 1u);
+      });
+    }
+    __syncthreads();
+    // reserve this tile's range in every partition: count -> base position
+    for (u32 p = threadIdx.x; p < P; p += 256u) { const u32 v = lh[p]; if (v) lh[p] = atomicAdd(&coarse_cursor[p], v); }
+    __syncthreads();
+    for (u32 i = i0 + threadIdx.x; i < i1; i += 256u) {
+      for_each_digit(segs, g, i, [&](u32 w, u32 b, u32 sign) {
+        if (b) {
+          const u32 k = b - 1u;
+          const u32 pos = atomicAdd(&lh[w * Bc + (k >> 8)], 1u);
+          part[pos] = ((k & 255u) << 24) | (sign << 23) | i;
+        }
+      });
+    }
+    __syncthreads();
+  }
+}
+// chunk_key[t] = bucket that contains sorted position t * L (for every chunk start inside [lo, hi))
+__device__ __forceinline__ void fill_chunk_keys(u32 *__restrict__ chunk_key, u32 L, u32 key, u32 lo, u32 hi) {
+  for (u32 t = (lo + L - 1u) / L; (u64)t * L < hi; t++) chunk_key[t] = key;
+}
+// Level B works on fixed-size TILES of the partitioned array (not one block per
+// partition), so a partition -- or a single bucket -- of any size is spread over many
+// blocks: balanced for every digit distribution (e.g. a top window that holds only the
+// recoding carry puts n/2 entries into one bucket).
+//   k_fine_hist     per tile: LDS histogram over fine buckets -> global fine histogram
+//   (k_scan_*)      -> off[], cursor[]
+//   k_fine_scatter  per tile: LDS histogram again, reserve one range per touched bucket,
+//                   scatter with LDS cursors
+// The LDS table covers FINE_BINS consecutive buckets starting at the tile's first one
+// (16 partitions); entries beyond it (only when many tiny partitions share a tile) use a
+// global atomic directly.
+#define FINE_TILE 4096
+#define FINE_BINS 4096
+struct FineTile {
+  u32 j0, j1;        // positions covered
+  u32 p_first;       // partition of position j0
+};
+__device__ __forceinline__ FineTile fine_tile_setup(const u32 *__restrict__ coarse_off, u32 P, u32 E, u32 *s_off) {
+  // s_off[0..P] = coarse_off (LDS copy for the partition walk)
+  for (u32 i = threadIdx.x; i <= P; i += 256u) s_off[i] = coarse_off[i];
+  __syncthreads();
+  FineTile t;
+  t.j0 = blockIdx.x * FINE_TILE;
+  t.j1 = (t.j0 + FINE_TILE < E) ? t.j0 + FINE_TILE : E;
+  // largest p with s_off[p] <= j0 and s_off[p+1] > j0 (binary search, same in every thread)
+  u32 lo = 0, hi = P;
+  while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (s_off[mid] <= t.j0) lo = mid; else hi = mid; }
+  t.p_first = lo;
+  return t;
+}
+__global__ void __launch_bounds__(256) k_fine_hist(MsmGeom g, u32 P, const u32 *__restrict__ coarse_off, const u32 *__restrict__ part,
+                                                   const u32 *__restrict__ offE, u32 *__restrict__ fine_hist) {
+  __shared__ u32 s_off[PART_MAX + 1];
+  __shared__ u32 bins[FINE_BINS];
+  const u32 E = offE[0];
+  if (blockIdx.x * FINE_TILE >= E) return;
+  const FineTile t = fine_tile_setup(coarse_off, P, E, s_off);
+  for (u32 i = threadIdx.x; i < FINE_BINS; i += 256u) bins[i] = 0;
+  __syncthreads();
+  const u32 g_first = t.p_first * 256u;
+  u32 pcur = t.p_first;
+  for (u32 j = t.j0 + threadIdx.x; j < t.j1; j += 256u) {
+    while (j >= s_off[pcur + 1]) pcur++;
+    const u32 key = pcur * 256u + (part[j] >> 24);
+    const u32 rel = key - g_first;
+    if (rel < FINE_BINS) atomicAdd(&bins[rel], 1u); else atomicAdd(&fine_hist[key], 1u);
+  }
+  __syncthreads();
+  for (u32 i = threadIdx.x; i < FINE_BINS; i += 256u) { const u32 v = bins[i]; if (v) atomicAdd(&fine_hist[g_first + i], v); }
+}
+__global__ void __launch_bounds__(256) k_fine_scatter(MsmGeom g, u32 P, const u32 *__restrict__ coarse_off, const u32 *__restrict__ part,
+                                                      const u32 *__restrict__ offE, u32 *__restrict__ cursor, u32 *__restrict__ sidx) {
+  __shared__ u32 s_off[PART_MAX + 1];
+  __shared__ u32 bins[FINE_BINS];
+  const u32 E = offE[0];
+  if (blockIdx.x * FINE_TILE >= E) return;
+  const FineTile t = fine_tile_setup(coarse_off, P, E, s_off);
+  for (u32 i = threadIdx.x; i < FINE_BINS; i += 256u) bins[i] = 0;
+  __syncthreads();
+  const u32 g_first = t.p_first * 256u;
+  u32 pcur = t.p_first;
+  for (u32 j = t.j0 + threadIdx.x; j < t.j1; j += 256u) {
+    while (j >= s_off[pcur + 1]) pcur++;
+    const u32 rel = pcur * 256u + (part[j] >> 24) - g_first;
+    if (rel < FINE_BINS) atomicAdd(&bins[rel], 1u);
+  }
+  __syncthreads();
+  // reserve this tile's range in every touched bucket: count -> base position
+  for (u32 i = threadIdx.x; i < FINE_BINS; i += 256u) { const u32 v = bins[i]; if (v) bins[i] = atomicAdd(&cursor[g_first + i], v); }
+  __syncthreads();
+  pcur = t.p_first;
+  for (u32 j = t.j0 + threadIdx.x; j < t.j1; j += 256u) {
+    while (j >= s_off[pcur + 1]) pcur++;
+    const u32 e = part[j];
+    const u32 key = pcur * 256u + (e >> 24);
+    const u32 rel = key - g_first;
+    const u32 pos = (rel < FINE_BINS) ? atomicAdd(&bins[rel], 1u) : atomicAdd(&cursor[key], 1u);
+    sidx[pos] = (e & 0x7FFFFFu) | ((e & 0x800000u) << 8);
+  }
+}
+// path 1 equivalent of the chunk-key fill: one thread per bucket
+__global__ void __launch_bounds__(256) k_chunk_keys(MsmGeom g, const u32 *__restrict__ off, u32 *__restrict__ chunk_key) {
+  const u32 key = blockIdx.x * blockDim.x + threadIdx.x;
+  if (key >= g.G) return;
+  fill_chunk_keys(chunk_key, g.L, key, off[key], off[key + 1]);
+}
+
+// ---- exclusive scan of hist[0..G) -> off[0..G], cursor[0..G) = off ------------------
+#define SCAN_PER_THREAD 16
+#define SCAN_TILE (256 * SCAN_PER_THREAD)
+__global__ void __launch_bounds__(256) k_scan_partials(const u32 *__restrict__ hist, u32 G, u32 *__restrict__ bsum) {
+  __shared__ u32 red[256];
+  const u32 base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_PER_THREAD;
+  u32 s = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_PER_THREAD; k++) { const u32 j = base + k; if (j < G) s += hist[j]; }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int d = 128; d > 0; d >>= 1) { if (threadIdx.x < d) red[threadIdx.x] += red[threadIdx.x + d]; __syncthreads(); }
+  if (threadIdx.x == 0) bsum[blockIdx.x] = red[0];
+}
+// single block: exclusive scan of bsum[0..nb) in place, total -> off[G]
+__global__ void __launch_bounds__(1024) k_scan_top(u32 *__restrict__ bsum, u32 nb, u32 *__restrict__ off, u32 G) {
+  __shared__ u32 sh[1024];
+  u32 running = 0;
+  for (u32 base = 0; base < nb; base += 1024) {
+    const u32 j = base + threadIdx.x;
+    const u32 v = j < nb ? bsum[j] : 0;
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+      u32 t = threadIdx.x >= d ? sh[threadIdx.x - d] : 0;
+      __syncthreads();
+      sh[threadIdx.x] += t;
+      __syncthreads();
+    }
+    if (j < nb) bsum[j] = running + sh[threadIdx.x] - v;
+    const u32 tot = sh[1023];
+    __syncthreads();
+    running += tot;
+  }
+  if (threadIdx.x == 0) off[G] = running;
+}
+__global__ void __launch_bounds__(256) k_scan_final(const u32 *__restrict__ hist, u32 G, const u32 *__restrict__ bsum,
+                                                    u32 *__restrict__ off, u32 *__restrict__ cursor) {
+  __shared__ u32 sh[256];
+  const u32 base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_PER_THREAD;
+  u32 v[SCAN_PER_THREAD];
+  u32 s = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_PER_THREAD; k++) { const u32 j = base + k; v[k] = j < G ? hist[j] : 0; s += v[k]; }
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int d = 1; d < 256; d <<= 1) {
+    u32 t = threadIdx.x >= d ? sh[threadIdx.x - d] : 0;
+    __syncthreads();
+    sh[threadIdx.x] += t;
+    __syncthreads();
+  }
+  u32 run = bsum[blockIdx.x] + sh[threadIdx.x] - s;
+#pragma unroll
+  for (int k = 0; k < SCAN_PER_THREAD; k++) {
+    const u32 j = base + k;
+    if (j < G) { off[j] = run; cursor[j] = run; }
+    run += v[k];
+  }
+}
+
+// ---- counting-sort scatter (path 1) ---------------------------------------------------
+__global__ void __launch_bounds__(256) k_scatter(MsmGeom g, const u32 *__restrict__ dig, u32 *__restrict__ cursor,
+                                                 u32 *__restrict__ sidx) {
+  const u32 stride = gridDim.x * blockDim.x;
+  for (u32 w = 0; w < g.W; w++) {
+    for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < g.n; i += stride) {
+      const u32 d = dig[(u64)w * g.n + i];
+      const u32 b = d & 0x7FFFFFFFu;
+      const u32 key = b ? (w * g.B + b - 1u) : 0xFFFFFFFFu;
+      const unsigned long long act = __ballot(1);
+      const u32 first = __builtin_amdgcn_readfirstlane(key);
+      const unsigned long long same = __ballot(key == first);
+      u32 pos = 0;
+      if (same == act) {
+        if (first != 0xFFFFFFFFu) {
+          const u32 lane_rank = __builtin_amdgcn_mbcnt_hi((u32)(act >> 32), __builtin_amdgcn_mbcnt_lo((u32)act, 0));
+          u32 basepos = 0;
+          if (lane_rank == 0) basepos = atomicAdd(&cursor[first], (u32)__popcll(act));
+          basepos = __builtin_amdgcn_readfirstlane(basepos);
+          pos = basepos + lane_rank;
+        }
+      } else if (b) {
+        pos = atomicAdd(&cursor[key], 1u);
+      }
+      if (b) sidx[pos] = i | (d & 0x80000000u);
+    }
+  }
+}
+
+// ---- level 0: every thread adds exactly L sorted entries --------------------------------
+__global__ void __launch_bounds__(256) k_accum_l0(Segs segs, MsmGeom g, const u32 *__restrict__ off,
+                                                  const u32 *__restrict__ chunk_key, const u32 *__restrict__ sidx,
+                                                  u32 *__restrict__ buckets, u32 *__restrict__ rec_key, u32 *__restrict__ rec_pt) {
+  const u32 E = off[g.G];
+  const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  const u64 start = t * g.L;
+  if (start >= E) return;
+  const u32 end = (u32)((start + g.L < E) ? start + g.L : E);
+  xyzz acc;
+  xyzz_set_inf(acc);
+  u32 cur = chunk_key[t];              // bucket containing position `start`
+  u32 boundary = off[cur + 1];         // first position after that bucket's run
+  bool first = true;
+  // software pipeline: the (index, point) of entry j+1 is in flight while entry j is added
+  u32 e_next = sidx[start];
+  u32 w_next[16];
+  load_words16(w_next, seg_point(segs, e_next & 0x7FFFFFFFu));
+  for (u32 j = (u32)start; j < end; j++) {
+    const u32 e = e_next;
+    affine P;
+    affine_from_words(P, w_next);
+    if (j + 1 < end) {
+      e_next = sidx[j + 1];
+      load_words16(w_next, seg_point(segs, e_next & 0x7FFFFFFFu));
+    }
+    if (j == boundary) {               // the run of `cur` ended: flush, move to the next non-empty bucket
+      if (first) { rec_key[2 * t] = cur; xyzz_store_g(rec_pt + (2 * t) * XYZZ_WORDS, acc); first = false; }
+      else xyzz_store_g(buckets + (u64)cur * XYZZ_WORDS, acc);
+      xyzz_set_inf(acc);
+      do { cur++; boundary = off[cur + 1]; } while (boundary == j);
+    }
+    xyzz_madd_signed(acc, P, (e >> 31) != 0);
+  }
+  if (first) {
+    rec_key[2 * t] = cur; xyzz_store_g(rec_pt + (2 * t) * XYZZ_WORDS, acc);
+    xyzz_set_inf(acc);
+  }
+  rec_key[2 * t + 1] = cur;
+  xyzz_store_g(rec_pt + (2 * t + 1) * XYZZ_WORDS, acc);
+}
+
+// number of records entering segscan level `level` (1-based); 0 when that level has nothing to do
+__device__ __forceinline__ u32 records_at_level(u32 E, u32 L, int level, bool &is_final) {
+  is_final = false;
+  if (E == 0) return 0;
+  u32 R = 2u * ((E + L - 1) / L);
+  for (int l = 1; l < level; l++) {
+    const u32 nb = (R + 255u) / 256u;
+    if (nb <= 1) return 0;          // the previous level was already final
+    R = 2u * nb;
+  }
+  is_final = ((R + 255u) / 256u) <= 1;
+  return R;
+}
+
+// ---- levels >= 1: block-wide segmented scan over partial records -------------------------
+__global__ void __launch_bounds__(256) k_segscan(MsmGeom g, const u32 *__restrict__ off, int level,
+                                                 const u32 *__restrict__ in_key, const u32 *__restrict__ in_pt,
+                                                 u32 *__restrict__ out_key, u32 *__restrict__ out_pt, u32 *__restrict__ buckets) {
+  __shared__ u32 s_key[256];
+  __shared__ u32 s_val[256 * LDS_STRIDE];
+  bool is_final;
+  const u32 R = records_at_level(off[g.G], g.L, level, is_final);
+  const u32 nb = (R + 255u) / 256u;
+  if (blockIdx.x >= nb) return;
+  const u32 tid = threadIdx.x;
+  const u32 j = blockIdx.x * 256u + tid;
+  const bool valid = j < R;
+  const u32 key = valid ? in_key[j] : 0xFFFFFFFFu;
+  xyzz val;
+  if (valid) xyzz_load_g(val, in_pt + (u64)j * XYZZ_WORDS); else xyzz_set_inf(val);
+  s_key[tid] = key;
+  __syncthreads();
+  for (u32 d = 1; d < 256; d <<= 1) {
+    xyzz_store(s_val + tid * LDS_STRIDE, val);
+    __syncthreads();
+    if (valid && tid >= d && s_key[tid - d] == key) {
+      xyzz other;
+      xyzz_load(other, s_val + (tid - d) * LDS_STRIDE);
+      xyzz_add(val, other, val);
+    }
+    __syncthreads();
+  }
+  if (!valid) return;
+  const u32 last_idx = (R - blockIdx.x * 256u >= 256u) ? 255u : (R - blockIdx.x * 256u - 1u);
+  const bool run_end = (tid == last_idx) || (s_key[tid + 1] != key);
+  if (!run_end) return;
+  const u32 first_key = s_key[0], last_key = s_key[last_idx];
+  // One store site with a per-thread destination.  (A three-way if/else over
+  // buckets / head record / tail record made hipcc 7.2 merge the stores behind
+  // scalar base-pointer selects in divergent flow, and the multi-block case faulted
+  // on gfx950; tests/test_gpu_msm.py::test_msm_multiblock_segscan pins this.)
+  const bool to_bucket = is_final || (key != first_key && key != last_key);
+  const bool is_head = !to_bucket && (key == first_key);
+  const u32 slot = 2u * blockIdx.x + (is_head ? 0u : 1u);
+  u32 *dst = to_bucket ? buckets + (u64)key * XYZZ_WORDS : out_pt + (u64)slot * XYZZ_WORDS;
+  if (!to_bucket) out_key[slot] = key;
+  xyzz_store_g(dst, val);
+  if (is_head && first_key == last_key) {       // the block is one single run: empty tail record
+    xyzz inf;
+    xyzz_set_inf(inf);
+    out_key[slot + 1u] = key;
+    xyzz_store_g(out_pt + (u64)(slot + 1u) * XYZZ_WORDS, inf);
+  }
+}
+
+// block-wide tree sum of one XYZZ value per thread (256 threads); result valid in thread 0
+__device__ __forceinline__ void block_tree_sum(xyzz &val, u32 *s_val) {
+  const u32 tid = threadIdx.x;
+  for (u32 d = blockDim.x >> 1; d > 0; d >>= 1) {
+    xyzz_store(s_val + tid * LDS_STRIDE, val);
+    __syncthreads();
+    if (tid < d) {
+      xyzz other;
+      xyzz_load(other, s_val + (tid + d) * LDS_STRIDE);
+      xyzz_add(val, val, other);
+    }
+    __syncthreads();
+  }
+}
+
+// ---- bucket reduction, step 1: D[w][v][d] = sum of buckets b in [1,B] whose base-32 digit v is d
+// grid = W * nv * 31 blocks of 256
+__global__ void __launch_bounds__(256, 4) k_bucket_digit_sums(MsmGeom g, const u32 *__restrict__ buckets, u32 *__restrict__ D) {
+  __shared__ u32 s_val[256 * LDS_STRIDE];
+  const u32 blk = blockIdx.x;
+  const u32 d = blk % 31u + 1u;
+  const u32 v = (blk / 31u) % g.nv;
+  const u32 w = blk / (31u * g.nv);
+  const u32 sh = 5u * v;
+  xyzz acc;
+  xyzz_set_inf(acc);
+  // element e -> b = (hi << (sh+5)) | (d << sh) | lo,  lo = low `sh` bits of e, hi = e >> sh
+  // valid (hi, lo): all lo for hi < hi_max, and lo <= B - base for hi == hi_max
+  const u32 hi_max = g.B >> (sh + 5u);
+  const u64 base_last = ((u64)hi_max << (sh + 5u)) | ((u64)d << sh);
+  u32 last_cnt = 0;
+  if (base_last <= g.B) { const u64 r = (u64)g.B - base_last + 1u; last_cnt = r < (1ull << sh) ? (u32)r : (1u << sh); }
+  const u32 ecount = (hi_max << sh) + last_cnt;
+  for (u32 e = threadIdx.x; e < ecount; e += 256u) {
+    const u32 lo = e & ((1u << sh) - 1u), hi = e >> sh;
+    const u64 b = ((u64)hi << (sh + 5u)) | ((u64)d << sh) | lo;
+    {
+      xyzz x;
+      xyzz_load_g(x, buckets + ((u64)w * g.B + (b - 1u)) * XYZZ_WORDS);
+      xyzz_add(acc, acc, x);
+    }
+  }
+  block_tree_sum(acc, s_val);
+  if (threadIdx.x == 0) xyzz_store_g(D + (u64)blk * XYZZ_WORDS, acc);
+}
+// ---- step 2: E[w][v] = sum_{d=1..31} d * D[w][v][d]  (suffix scan + sum over 32 lanes)
+// grid = W * nv blocks of 64
+__global__ void __launch_bounds__(64) k_weighted31(const u32 *__restrict__ D, u32 *__restrict__ Eout) {
+  __shared__ u32 s_val[64 * LDS_STRIDE];
+  const u32 tid = threadIdx.x;
+  xyzz val;
+  if (tid < 31u) xyzz_load_g(val, D + ((u64)blockIdx.x * 31u + tid) * XYZZ_WORDS); else xyzz_set_inf(val);
+  // inclusive suffix scan: val[l] = sum_{j >= l} D[j]
+  for (u32 d = 1; d < 32; d <<= 1) {
+    xyzz_store(s_val + tid * LDS_STRIDE, val);
+    __syncthreads();
+    if (tid + d < 31u) {
+      xyzz other;
+      xyzz_load(other, s_val + (tid + d) * LDS_STRIDE);
+      xyzz_add(val, val, other);
+    }
+    __syncthreads();
+  }
+  block_tree_sum(val, s_val);
+  if (tid == 0) xyzz_store_g(Eout + (u64)blockIdx.x * XYZZ_WORDS, val);
+}
+
+// ---- tail: result = sum_w 2^(c w) sum_v 32^v E[w][v], to canonical affine -----------------
+BPMI_HD void msm_tail_combine(u32 out_words[16], const u32 *E, u32 W, u32 nv, u32 c) {
+  // ONE Horner chain over bit positions: E[w][v] carries weight 2^(c*w + 5*v), so walking
+  // t from the top bit down costs c*W doublings in total (not c*W + 5*nv*W)
+  xyzz acc;
+  xyzz_set_inf(acc);
+  for (int w = (int)W - 1; w >= 0; w--) {
+    int prev = (int)c;                              // bit offset (within the window) already reached
+    for (int v = (int)nv - 1; v >= 0; v--) {
+      for (int k = prev; k > 5 * v; k--) xyzz_dbl(acc, acc);
+      prev = 5 * v;
+      xyzz e;
+      xyzz_load(e, E + ((u64)w * nv + v) * XYZZ_WORDS);
+      xyzz_add(acc, acc, e);
+    }
+  }
+  affine r;
+  xyzz_to_affine(r, acc);
+  affine_to_words(out_words, r);
+}
+__global__ void k_tail(const u32 *__restrict__ E, u32 W, u32 nv, u32 c, u32 *__restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    u32 w16[16];
+    msm_tail_combine(w16, E, W, nv, c);
+#pragma unroll
+    for (int i = 0; i < 16; i++) out[i] = w16[i];
+  }
+}

@@ -1,0 +1,231 @@
+// point_kernels.hpp -- part of libbpmi (included by bpmi.hip; one translation unit).
+// Batched point kernels: scalar multiplication, shared-scalar folds, deferred-fold helpers of the IPA (/root/reference/src/innerproduct/inner_product_prover.py:107-108, src/utils/utils.py:43-44).
+#pragma once
+
+// ------------------------------------------------------------------------------------
+// batched point kernels
+// ------------------------------------------------------------------------------------
+// out[i] = k_i * P_i   (left-to-right double-and-add in Jacobian coordinates; the scalars
+// differ per lane, so lanes diverge on the addition only)
+__global__ void __launch_bounds__(256, 3) k_ec_mul_batch(const u32 *__restrict__ pts, const u32 *__restrict__ scs, u32 n, u32 *__restrict__ out) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  affine P;
+  load_affine(P, pts + 16ull * i);
+  sc s;
+  load_words8(s.v, scs + 8ull * i);
+  const bool neg = sc_is_high(s);
+  if (neg) sc_neg(s, s);
+  jac acc;
+  jac_set_inf(acc);
+  const bool pinf = affine_is_inf(P);
+  for (int word = 7; word >= 0; word--) {
+    // static word selection keeps s.v[] in registers
+    u32 wv = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) if (k == word) wv = s.v[k];
+    for (int bit = 31; bit >= 0; bit--) {
+      jac_dbl(acc, acc);
+      if (((wv >> bit) & 1u) && !pinf) jac_madd_signed(acc, P.x, P.y, neg);
+    }
+  }
+  affine r;
+  jac_to_affine(r, acc);
+  u32 w16[16];
+  affine_to_words(w16, r);
+  store_words16(out + 16ull * i, w16);
+}
+
+struct Sc2 { u32 k1[8]; u32 k2[8]; };
+
+// Non-adjacent forms of the two shared scalars, computed once on the host: bit i of nz*
+// says digit i is non-zero, bit i of sg* says it is -1.  257 positions each.
+struct NafPair { u32 nz1[9], sg1[9], nz2[9], sg2[9]; int top; };
+static void host_naf(const uint8_t k32[32], u32 nz[9], u32 sg[9], int &top) {
+  u32 w[9];
+  memcpy(w, k32, 32);
+  w[8] = 0;
+  for (int i = 0; i < 9; i++) nz[i] = sg[i] = 0;
+  for (int pos = 0; pos < 257; pos++) {
+    if (w[0] & 1u) {
+      const bool minus = (w[0] & 3u) == 3u;          // k mod 4 == 3 -> digit -1, k += 1
+      nz[pos >> 5] |= 1u << (pos & 31);
+      if (minus) {
+        sg[pos >> 5] |= 1u << (pos & 31);
+        for (int i = 0; i < 9; i++) { if (++w[i] != 0) break; }
+      } else {
+        w[0] &= ~1u;
+      }
+      if (pos > top) top = pos;
+    }
+    for (int i = 0; i < 8; i++) w[i] = (w[i] >> 1) | (w[i + 1] << 31);
+    w[8] >>= 1;
+  }
+}
+
+// out[i] = k1 * P1_i + k2 * P2_i with k1, k2 shared by all i (the generator fold,
+// inner_product_prover.py:107-108).  Jacobian ladder driven by the NAF digits: every
+// branch is on a kernel argument, hence wave-uniform; only mixed additions; the two input
+// points of each thread are parked in LDS ([word][thread], conflict-free) to keep the
+// register count at the ladder's working set.
+struct LincombJob { const u32 *p1, *p2; u32 *out; u32 n; };
+// Two independent jobs share one launch (threads [0, A.n) do job A, the next B.n do job
+// B): a ladder thread is ~2 ms of serial issue, so per-launch latency, not throughput,
+// bounds the small rounds of the IPA -- g and h are therefore folded together.
+__global__ void __launch_bounds__(256, 3) k_ec_lincomb2(LincombJob ja, NafPair nfa, LincombJob jb, NafPair nfb) {
+  __shared__ u32 s_pts[36 * 256];
+  const u32 tid = threadIdx.x;
+  u32 i = blockIdx.x * blockDim.x + tid;
+  const bool second = i >= ja.n;          // may differ inside one wave only at the seam
+  if (second) i -= ja.n;
+  const u32 n = second ? jb.n : ja.n;
+  if (i >= n) return;
+  const u32 *p1 = second ? jb.p1 : ja.p1;
+  const u32 *p2 = second ? jb.p2 : ja.p2;
+  u32 *out = second ? jb.out : ja.out;
+  bool inf1, inf2;
+  {
+    affine A;
+    load_affine(A, p1 + 16ull * i);
+    inf1 = affine_is_inf(A);
+#pragma unroll
+    for (int k = 0; k < 9; k++) { s_pts[k * 256 + tid] = A.x.v[k]; s_pts[(9 + k) * 256 + tid] = A.y.v[k]; }
+    load_affine(A, p2 + 16ull * i);
+    inf2 = affine_is_inf(A);
+#pragma unroll
+    for (int k = 0; k < 9; k++) { s_pts[(18 + k) * 256 + tid] = A.x.v[k]; s_pts[(27 + k) * 256 + tid] = A.y.v[k]; }
+  }
+  jac acc;
+  jac_set_inf(acc);
+  const int top = nfa.top > nfb.top ? nfa.top : nfb.top;
+  for (int pos = top; pos >= 0; pos--) {
+    jac_dbl(acc, acc);
+    const u32 m = 1u << (pos & 31);
+    const int wd = pos >> 5;
+    // one inlined copy of the addition serves both points (the loop is kept rolled)
+#pragma unroll 1
+    for (int which = 0; which < 2; which++) {
+      const u32 nzw = second ? (which ? nfb.nz2[wd] : nfb.nz1[wd]) : (which ? nfa.nz2[wd] : nfa.nz1[wd]);
+      const u32 sgw = second ? (which ? nfb.sg2[wd] : nfb.sg1[wd]) : (which ? nfa.sg2[wd] : nfa.sg1[wd]);
+      const bool isinf = which ? inf2 : inf1;
+      if ((nzw & m) && !isinf) {
+        fe x, y;
+        const u32 base = which ? 18u * 256u : 0u;
+#pragma unroll
+        for (int k = 0; k < 9; k++) { x.v[k] = s_pts[base + k * 256 + tid]; y.v[k] = s_pts[base + (9 + k) * 256 + tid]; }
+        jac_madd_signed(acc, x, y, (sgw & m) != 0);
+      }
+    }
+  }
+  affine r;
+  jac_to_affine(r, acc);
+  u32 w16[16];
+  affine_to_words(w16, r);
+  store_words16(out + 16ull * i, w16);
+}
+
+// ---- deferred generator folding (IPA) ----------------------------------------------------
+// After d deferred folds the logical generator i (i < m) is sum_t coef[t] * G[i + t*m],
+// t < 2^d, over the UNFOLDED base array G of length M = m << d; the newest fold is the
+// least significant bit of t:  coef'[2t + s] = coef[t] * (s ? hi_factor : lo_factor).
+__global__ void __launch_bounds__(256) k_ipa_coef_update(const u32 *cg, const u32 *ch, Sc2 x_xinv, u32 K, u32 *cg2, u32 *ch2) {
+  const u32 j = blockIdx.x * blockDim.x + threadIdx.x;     // new index in [0, 2K)
+  if (j >= 2u * K) return;
+  sc X, XI, c, r;
+#pragma unroll
+  for (int k = 0; k < 8; k++) { X.v[k] = x_xinv.k1[k]; XI.v[k] = x_xinv.k2[k]; }
+  // g' = x^-1 g_lo + x g_hi ;  h' = x h_lo + x^-1 h_hi   (inner_product_prover.py:107-108)
+  load_words8(c.v, cg + 8ull * (j >> 1));
+  sc_mul(r, c, (j & 1u) ? X : XI);
+  store_words8(cg2 + 8ull * j, r.v);
+  load_words8(c.v, ch + 8ull * (j >> 1));
+  sc_mul(r, c, (j & 1u) ? XI : X);
+  store_words8(ch2 + 8ull * j, r.v);
+}
+// scalars of the L (right = 0) or R (right = 1) MSM over the unfolded bases:
+//   L = <a_lo, g_hi> + <b_hi, h_lo>,  R = <a_hi, g_lo> + <b_lo, h_hi>   (:98-99)
+__global__ void __launch_bounds__(256) k_ipa_expand(const u32 *__restrict__ a, const u32 *__restrict__ b, const u32 *__restrict__ cg,
+                                                    const u32 *__restrict__ ch, u32 M, u32 logm, int right,
+                                                    u32 *__restrict__ eg, u32 *__restrict__ eh) {
+  const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= M) return;
+  const u32 m = 1u << logm, half = m >> 1;
+  const u32 i = k & (m - 1u), t = k >> logm;
+  const bool hi = i >= half;
+  sc z;
+#pragma unroll
+  for (int q = 0; q < 8; q++) z.v[q] = 0;
+  sc rg = z, rh = z;
+  // g side uses the g-half OPPOSITE to the a-half: L pairs a_lo with g_hi
+  if (hi != (right != 0)) {
+    sc av, c;
+    load_words8(av.v, a + 8ull * (right ? half + i : i - half));
+    load_words8(c.v, cg + 8ull * t);
+    sc_mul(rg, av, c);
+  }
+  if (hi == (right != 0)) {
+    sc bv, c;
+    load_words8(bv.v, b + 8ull * (right ? i - half : half + i));
+    load_words8(c.v, ch + 8ull * t);
+    sc_mul(rh, bv, c);
+  }
+  store_words8(eg + 8ull * k, rg.v);
+  store_words8(eh + 8ull * k, rh.v);
+}
+// materialise 2^d-way folded generators: out[i] = sum_t coef[t] * G[i + t*m], i < m, as an
+// interleaved NAF ladder (shared scalars -> wave-uniform branches); two jobs (g and h) per launch
+#define MULTIFOLD_MAXK 16
+struct NafK { u32 nz[MULTIFOLD_MAXK][9]; u32 sg[MULTIFOLD_MAXK][9]; int top; };
+struct MultifoldJob { const u32 *base; u32 *out; };
+__global__ void __launch_bounds__(256, 3) k_ec_multifold(MultifoldJob ja, MultifoldJob jb, const NafK *__restrict__ nfa, const NafK *__restrict__ nfb,
+                                                         u32 m, u32 K) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool second = i >= m;
+  if (second) i -= m;
+  if (i >= m) return;
+  const u32 *base = second ? jb.base : ja.base;
+  u32 *out = second ? jb.out : ja.out;
+  const NafK *nf = second ? nfb : nfa;
+  jac acc;
+  jac_set_inf(acc);
+  const int top = nf->top;
+  for (int pos = top; pos >= 0; pos--) {
+    jac_dbl(acc, acc);
+    const u32 msk = 1u << (pos & 31);
+    const int wd = pos >> 5;
+#pragma unroll 1
+    for (u32 t = 0; t < K; t++) {
+      if (nf->nz[t][wd] & msk) {
+        affine P;
+        load_affine(P, base + 16ull * ((u64)i + (u64)t * m));
+        if (!affine_is_inf(P)) jac_madd_signed(acc, P.x, P.y, (nf->sg[t][wd] & msk) != 0);
+      }
+    }
+  }
+  affine r;
+  jac_to_affine(r, acc);
+  u32 w16[16];
+  affine_to_words(w16, r);
+  store_words16(out + 16ull * i, w16);
+}
+
+// out = sum of n affine points (one block)
+__global__ void __launch_bounds__(256) k_ec_sum(const u32 *__restrict__ pts, u32 n, u32 *__restrict__ out) {
+  __shared__ u32 s_val[256 * LDS_STRIDE];
+  xyzz acc;
+  xyzz_set_inf(acc);
+  for (u32 i = threadIdx.x; i < n; i += 256u) {
+    affine P;
+    load_affine(P, pts + 16ull * i);
+    xyzz_madd_signed(acc, P, false);
+  }
+  block_tree_sum(acc, s_val);
+  if (threadIdx.x == 0) {
+    affine r;
+    xyzz_to_affine(r, acc);
+    u32 w16[16];
+    affine_to_words(w16, r);
+#pragma unroll
+    for (int k = 0; k < 16; k++) out[k] = w16[k];
+  }
+}
