@@ -76,7 +76,7 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, const Segs &segs) {
   g.B = 1u << (g.c - 1);
   g.G = g.W * g.B;
   g.L = ctx->opt_chunk > 0 ? (u32)ctx->opt_chunk : (n >= (1u << 19) ? 64u : (n >= (1u << 16) ? 32u : 16u));   // tools/tune_msm.py sweeps
-  g.nv = (g.c + 4u) / 5u;
+  g.nv = (g.B <= 256u) ? 1u : (g.c + 4u) / 5u;     // small windows: direct weighted sum, one value per window
   MsmWs w;
   msm_layout(g, w, nullptr);
   int rc = ensure_lane(ctx, lane);
@@ -170,8 +170,12 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, const Segs &segs) {
   debug_sync(ctx, "ST_SEGSCAN", st);
   {
     StageTimer t(ctx, ST_BREDUCE, st);
-    hipLaunchKernelGGL(k_bucket_digit_sums, dim3(g.W * g.nv * 31), dim3(256), 0, st, g, w.buckets, w.D);
-    hipLaunchKernelGGL(k_weighted31, dim3(g.W * g.nv), dim3(64), 0, st, w.D, w.E);
+    if (g.B <= 256u) {
+      hipLaunchKernelGGL(k_window_weighted_small, dim3(g.W), dim3(g.B < 64u ? 64u : g.B), 0, st, g, w.buckets, w.E);
+    } else {
+      hipLaunchKernelGGL(k_bucket_digit_sums, dim3(g.W * g.nv * 31), dim3(256), 0, st, g, w.buckets, w.D);
+      hipLaunchKernelGGL(k_weighted31, dim3(g.W * g.nv), dim3(64), 0, st, w.D, w.E);
+    }
   }
   debug_sync(ctx, "ST_BREDUCE", st);
   {

@@ -472,6 +472,30 @@ __global__ void __launch_bounds__(64) k_weighted31(const u32 *__restrict__ D, u3
   if (tid == 0) xyzz_store_g(Eout + (u64)blockIdx.x * XYZZ_WORDS, val);
 }
 
+// ---- bucket reduction for small windows (B <= 256): one block of B threads per window
+// computes sum_b b * B[w][b] directly as sum_j Suffix_j (inclusive suffix scan + tree sum,
+// 2 log2(B) dependent additions) -- shorter than digit sums + k_weighted31 when B is small.
+// Eout[w] then has nv = 1.
+__global__ void __launch_bounds__(256) k_window_weighted_small(MsmGeom g, const u32 *__restrict__ buckets, u32 *__restrict__ Eout) {
+  __shared__ u32 s_val[256 * LDS_STRIDE];
+  const u32 tid = threadIdx.x, w = blockIdx.x;
+  xyzz val;
+  if (tid < g.B) xyzz_load_g(val, buckets + ((u64)w * g.B + tid) * XYZZ_WORDS);      // bucket b = tid + 1
+  else xyzz_set_inf(val);
+  for (u32 d = 1; d < g.B; d <<= 1) {
+    xyzz_store(s_val + tid * LDS_STRIDE, val);
+    __syncthreads();
+    if (tid + d < g.B) {
+      xyzz other;
+      xyzz_load(other, s_val + (tid + d) * LDS_STRIDE);
+      xyzz_add(val, val, other);
+    }
+    __syncthreads();
+  }
+  block_tree_sum(val, s_val);
+  if (tid == 0) xyzz_store_g(Eout + (u64)w * XYZZ_WORDS, val);
+}
+
 // ---- tail: result = sum_w 2^(c w) sum_v 32^v E[w][v], to canonical affine -----------------
 BPMI_HD void msm_tail_combine(u32 out_words[16], const u32 *E, u32 W, u32 nv, u32 c) {
   // ONE Horner chain over bit positions: E[w][v] carries weight 2^(c*w + 5*v), so walking

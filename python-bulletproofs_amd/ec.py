@@ -87,8 +87,10 @@ class Point:
 
     def __mul__(self, k):
         k = int(k) % secp256k1.q
+        # a one-term MSM: ~0.4 ms of launch latency, against ~2 ms for one lane walking the
+        # 257-step ladder of bpmi_ec_mul_batch (which pays off only for many points at once)
         eng = _engine.default_engine()
-        return Point.from_le64(eng.ec_mul_batch_bytes(self.to_le64(), k.to_bytes(32, "little"), 1))
+        return Point.from_le64(eng.msm_bytes(self.to_le64(), k.to_bytes(32, "little"), 1))
 
     __rmul__ = __mul__
 
