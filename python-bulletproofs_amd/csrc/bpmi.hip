@@ -41,6 +41,7 @@ using namespace bpmi;
 #include "msm_kernels.hpp"
 #include "point_kernels.hpp"
 #include "scalar_kernels.hpp"
+#include "host_tail.hpp"
 #include "msm_host.hpp"
 
 // ------------------------------------------------------------------------------------

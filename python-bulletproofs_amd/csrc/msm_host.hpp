@@ -207,9 +207,7 @@ static int msm_finish(bpmi_ctx *ctx, int lane, uint8_t out[64]) {
   if (pd.tail == 1) {
     memcpy(out, pin, 64);
   } else {
-    u32 w16[16];
-    msm_tail_combine(w16, (const u32 *)pin, pd.W, pd.nv, pd.c);
-    memcpy(out, w16, 64);
+    bpmi_host::tail_combine(out, (const u32 *)pin, pd.W, pd.nv, pd.c);     // host_tail.hpp
   }
   pd.active = false;
   debug_sync(ctx, "ST_TAIL", st);
