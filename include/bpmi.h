@@ -58,8 +58,13 @@ void bpmi_ctx_destroy(bpmi_ctx *ctx);
 const char *bpmi_last_error(const bpmi_ctx *ctx);
 int bpmi_sync(bpmi_ctx *ctx);
 
-/* tuning knobs (0 = automatic): MSM window bits c in [2,16]; where the O(256)
- * sequential window-combine tail runs: 0 auto, 1 device kernel, 2 host thread */
+/* tuning knobs (0 = automatic):
+ *   "window_bits"  MSM window bits c in [2,16]
+ *   "chunk"        sorted entries added per thread in the accumulate kernel
+ *   "tail"         where the O(256) sequential window-combine tail runs: 1 device kernel,
+ *                  2 host thread (default; the result is consumed on the host anyway)
+ *   "ipa_big_m"    base length from which the IPA prover folds its generators 16-way at
+ *                  once instead of deferring the fold into the MSM scalars (default 2^18) */
 int bpmi_set_option(bpmi_ctx *ctx, const char *name, int64_t value);
 
 /* ---- device buffers (so callers need no other GPU runtime) ------------------- */
@@ -96,6 +101,13 @@ int bpmi_ec_lincomb2_batch_dev(bpmi_ctx *ctx, const void *d_p1, const void *d_p2
  * and folds the per-GPU partial results of a sharded MSM. */
 int bpmi_ec_sum(bpmi_ctx *ctx, const uint8_t *pts, uint64_t n, uint8_t out[64]);
 
+/* out[i] = the point encoded by comp[33*i .. 33*i+33) in SEC1 compressed form (0x02 | 0x03,
+ * then x big-endian; 33 zero bytes = identity); ok[i] = 1 when the encoding is valid
+ * (known tag, x < p, x^3 + 7 a square), else out[i] = identity and ok[i] = 0.
+ * Replaces bytes_to_point / b64_to_point (src/utils/utils.py:114-131) in bulk, e.g. for
+ * the 19 points of every proof of a batch that arrives as bytes. */
+int bpmi_ec_decompress_batch(bpmi_ctx *ctx, const uint8_t *comp, uint64_t n, uint8_t *out, uint8_t *ok);
+
 /* ---- bulk scalar (mod q) operations ------------------------------------------------
  * out = sum_i a[i] * b[i] mod q       replaces inner_product (src/utils/utils.py:134-137) */
 int bpmi_sc_dot(bpmi_ctx *ctx, const uint8_t *a, const uint8_t *b, uint64_t n, uint8_t out[32]);
@@ -109,8 +121,11 @@ int bpmi_sc_fold_dev(bpmi_ctx *ctx, const void *d_lo, const void *d_hi, const ui
 
 /* ---- inner-product argument prover, split at the Fiat-Shamir edge ----------------------
  * One object = one run of FastNIProver2.prove (src/innerproduct/inner_product_prover.py:70-110).
- * g, h: n points; a, b: n scalars; u: one point; all copied to the device once and
- * halved in place every round (device-resident ping-pong buffers).
+ * g, h: n points; a, b: n scalars; u: one point; all copied to the device once and kept
+ * there.  a and b are halved in place every round; the generator fold is DEFERRED: L and R
+ * are MSMs over the unfolded generators with the fold coefficients multiplied into the
+ * scalars (the prover's outputs never contain the folded generators), and large bases are
+ * materialised 16-way at once.
  *   bpmi_ipa_round_LR : cl, cr, L, R of the current round          (:96-99)
  *   --- host: transcript.add_list_points([L, R]); x = H(transcript) (:102-106) ---
  *   bpmi_ipa_fold     : g, h, a, b <- folded with x, x^-1           (:107-110)

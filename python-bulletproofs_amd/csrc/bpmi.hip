@@ -262,6 +262,27 @@ int bpmi_ec_sum(bpmi_ctx *ctx, const uint8_t *pts, uint64_t n, uint8_t out[64]) 
   return BPMI_OK;
 }
 
+int bpmi_ec_decompress_batch(bpmi_ctx *ctx, const uint8_t *comp, uint64_t n, uint8_t *out, uint8_t *ok) {
+  if (!ctx || (n && (!comp || !out || !ok))) return ctx ? fail(ctx, BPMI_E_ARG, "null argument") : BPMI_E_ARG;
+  if (n > BPMI_MAX_N) return fail(ctx, BPMI_E_ARG, "n exceeds BPMI_MAX_N");
+  if (n == 0) return BPMI_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  int rc = ensure_stage_in(ctx, 98 * n + 1024);
+  if (rc) return rc;
+  char *din = (char *)ctx->stage_in, *dout = din + align_up(33 * n, 256), *dok = dout + align_up(64 * n, 256);
+  HIPCHK(ctx, hipMemcpyAsync(din, comp, 33 * n, hipMemcpyHostToDevice, ctx->stream));
+  {
+    StageTimer t(ctx, ST_MISC);
+    hipLaunchKernelGGL(k_ec_decompress, dim3((u32)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const uint8_t *)din, (u32)n,
+                       (u32 *)dout, (uint8_t *)dok);
+  }
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipMemcpyAsync(out, dout, 64 * n, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(ok, dok, n, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return BPMI_OK;
+}
+
 // ---- scalar ops -------------------------------------------------------------------------------
 static int sc_dot_dev_to(bpmi_ctx *ctx, const void *d_a, const void *d_b, uint64_t n, u32 *d_out, u32 *d_partial) {
   const u32 nb = (u32)std::min<uint64_t>((n + 255) / 256, 1024);

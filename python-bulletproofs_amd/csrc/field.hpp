@@ -233,4 +233,24 @@ BPMI_HD void fe_inv(fe &r, const fe &a) {
   for (int j = 0; j < 2; j++) fe_sqr(t1, t1); fe_mul(r, t1, a);
 }
 
+// r = a^((p+1)/4): a square root of a when a is a quadratic residue (p = 3 mod 4); the
+// caller checks r^2 == a.  Same addition-chain prefix as fe_inv; (p+1)/4 = 1^223 0 1^22 0000 11 00.
+BPMI_HD void fe_sqrt_candidate(fe &r, const fe &a) {
+  fe x2, x3, x6, x9, x11, x22, x44, x88, x176, x220, x223, t1;
+  fe_sqr(x2, a); fe_mul(x2, x2, a);
+  fe_sqr(x3, x2); fe_mul(x3, x3, a);
+  x6 = x3; for (int j = 0; j < 3; j++) fe_sqr(x6, x6); fe_mul(x6, x6, x3);
+  x9 = x6; for (int j = 0; j < 3; j++) fe_sqr(x9, x9); fe_mul(x9, x9, x3);
+  x11 = x9; for (int j = 0; j < 2; j++) fe_sqr(x11, x11); fe_mul(x11, x11, x2);
+  x22 = x11; for (int j = 0; j < 11; j++) fe_sqr(x22, x22); fe_mul(x22, x22, x11);
+  x44 = x22; for (int j = 0; j < 22; j++) fe_sqr(x44, x44); fe_mul(x44, x44, x22);
+  x88 = x44; for (int j = 0; j < 44; j++) fe_sqr(x88, x88); fe_mul(x88, x88, x44);
+  x176 = x88; for (int j = 0; j < 88; j++) fe_sqr(x176, x176); fe_mul(x176, x176, x88);
+  x220 = x176; for (int j = 0; j < 44; j++) fe_sqr(x220, x220); fe_mul(x220, x220, x44);
+  x223 = x220; for (int j = 0; j < 3; j++) fe_sqr(x223, x223); fe_mul(x223, x223, x3);
+  t1 = x223; for (int j = 0; j < 23; j++) fe_sqr(t1, t1); fe_mul(t1, t1, x22);
+  for (int j = 0; j < 6; j++) fe_sqr(t1, t1); fe_mul(t1, t1, x2);
+  fe_sqr(t1, t1); fe_sqr(r, t1);
+}
+
 }  // namespace bpmi

@@ -209,6 +209,57 @@ __global__ void __launch_bounds__(256, 3) k_ec_multifold(MultifoldJob ja, Multif
   store_words16(out + 16ull * i, w16);
 }
 
+// Batch decompression of SEC1 compressed points: in = n x 33 B (0x02 | 0x03, x big-endian;
+// 33 zero bytes = identity), out = n x 64 B wire format, ok[i] = 1 when the encoding is
+// valid.  Replaces bytes_to_point (/root/reference/src/utils/utils.py:119-131):
+// y = (x^3 + 7)^((p+1)/4), then the root with the requested parity.
+__global__ void __launch_bounds__(256, 3) k_ec_decompress(const uint8_t *__restrict__ in, u32 n, u32 *__restrict__ out, uint8_t *__restrict__ ok) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint8_t *src = in + 33ull * i;
+  const u32 tag = src[0];
+  u32 w[8];
+  u32 any = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {               // word k (little-endian) = bytes 32-4k-3 .. 32-4k of the big-endian x
+    const uint8_t *q = src + 1 + 28 - 4 * k;
+    w[k] = ((u32)q[0] << 24) | ((u32)q[1] << 16) | ((u32)q[2] << 8) | (u32)q[3];
+    any |= w[k];
+  }
+  u32 w16[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) w16[k] = 0;
+  bool valid;
+  if (tag == 0u) {
+    valid = (any == 0);                       // identity
+  } else if (tag == 2u || tag == 3u) {
+    // x must be < p:  x + (2^32 + 977) must not carry out of 256 bits
+    u64 c = (u64)w[0] + 977u; c >>= 32;
+    c += (u64)w[1] + 1u; c >>= 32;
+#pragma unroll
+    for (int k = 2; k < 8; k++) { c += w[k]; c >>= 32; }
+    valid = (c == 0);
+    fe x, y, a, t;
+    fe_from_words(x, w);
+    fe_sqr(t, x); fe_mul(a, t, x);
+    fe seven; fe_set_zero(seven); seven.v[0] = 7;
+    fe_add(a, a, seven); fe_carry(a, a);      // a = x^3 + 7
+    fe_sqrt_candidate(y, a);
+    fe_sqr(t, y);
+    valid = valid && fe_equal(t, a);          // a is a quadratic residue
+    fe cy;
+    fe_canon(cy, y);
+    if ((cy.v[0] & 1u) != (tag & 1u)) { fe_neg(t, cy); fe_canon(cy, t); }
+    fe cx;
+    fe_canon(cx, x);
+    if (valid) { fe_to_words(w16, cx); fe_to_words(w16 + 8, cy); }
+  } else {
+    valid = false;
+  }
+  store_words16(out + 16ull * i, w16);
+  ok[i] = valid ? 1 : 0;
+}
+
 // out = sum of n affine points (one block)
 __global__ void __launch_bounds__(256) k_ec_sum(const u32 *__restrict__ pts, u32 n, u32 *__restrict__ out) {
   __shared__ u32 s_val[256 * LDS_STRIDE];

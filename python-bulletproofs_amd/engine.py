@@ -115,6 +115,13 @@ class Engine:
         self._ck(self.lib.bpmi_ec_sum(self.ctx, pts, n, out))
         return out.raw
 
+    def ec_decompress_batch_bytes(self, comp, n):
+        """n x 33-byte SEC1 compressed points -> (n x 64-byte wire points, n validity flags)."""
+        out = ctypes.create_string_buffer(64 * n)
+        ok = ctypes.create_string_buffer(max(n, 1))
+        self._ck(self.lib.bpmi_ec_decompress_batch(self.ctx, comp, n, out, ok))
+        return out.raw, ok.raw[:n]
+
     def sc_dot_bytes(self, a, b, n):
         out = ctypes.create_string_buffer(32)
         self._ck(self.lib.bpmi_sc_dot(self.ctx, a, b, n, out))

@@ -4,6 +4,7 @@ from .rangeproof_aggreg_prover import AggregNIRangeProver
 from .rangeproof_aggreg_verifier import AggregRangeVerifier
 from .common import Proof
 from .batch import BatchRangeVerifier, batch_verify
+from .codec import proof_to_bytes, proofs_from_bytes
 
 __all__ = ["NIRangeProver", "RangeVerifier", "AggregNIRangeProver", "AggregRangeVerifier", "Proof",
-           "BatchRangeVerifier", "batch_verify"]
+           "BatchRangeVerifier", "batch_verify", "proof_to_bytes", "proofs_from_bytes"]

@@ -29,6 +29,7 @@ void t_fe_op(int op, const uint8_t *a, const uint8_t *b, uint8_t *out) {
     case 8: r = x; break;
     case 9: fe_sub(t, x, y); fe_sub(t, t, y); fe_sub(t, t, y); fe_carry(r, t); break;  // mag 7 carry
     case 10: fe_add(t, x, y); fe_sub_m2(r, x, t); fe_carry(r, r); break;              // x - (x+y) = -y
+    case 11: fe_sqrt_candidate(r, x); break;
     default: fe_set_zero(r);
   }
   store_fe(out, r);

@@ -65,6 +65,8 @@ def test_field_ops_random_and_edges(shim):
         if a % P:
             assert fe_op(shim, 5, a) == pow(a, -1, P)
     assert fe_op(shim, 5, 0) == 0
+    for a in EDGE + vals[:60]:
+        assert fe_op(shim, 11, a) == pow(a % P, (P + 1) // 4, P)
 
 
 def madd_chain(L, start, pts, negs):
