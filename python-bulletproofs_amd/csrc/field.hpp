@@ -107,45 +107,66 @@ BPMI_HD void fe_carry(fe &r, const fe &a) {
   r.v[8] = (a.v[8] & M24) + (u32)c;
 }
 
-// ---- product columns -> tight result ------------------------------------------------
-BPMI_HD void fe_fold_columns(fe &r, const u64 acc[17]) {
-  u32 t[18];
-  u64 c = 0;
-#pragma unroll
-  for (int k = 0; k < 17; k++) { c += acc[k]; t[k] = (u32)c & M29; c >>= 29; }
-  t[17] = (u32)c;
-  // 2^261 == 2^37 + 31264 (mod p): limb 9+k folds into limb k (x31264) and k+1 (x256)
+// acc += x * y (u32 x u32 -> u64, plus the 64-bit accumulator) = ONE v_mad_u64_u32.
+// (Spelling this as inline asm to force the carry of column k into the first multiply-add of
+// column k+1 was tried: hipcc pads every asm statement with an s_nop, which costs more than
+// the 64-bit adds it saves -- 447 vs 207 instructions per multiplication.  Plain C it is.)
+#define BPMI_MAC(acc, x, y) ((acc) += (u64)(x) * (y))
+
+// ---- product -> tight result ----------------------------------------------------------
+// The 17 product columns are accumulated as TWO carry chains (columns 0-8 and 9-16): the
+// carry out of column k is the initial value of column k+1's accumulator, i.e. it rides in
+// the 64-bit addend of the first v_mad_u64_u32 of that column for free (saves one 64-bit
+// add per column); two chains instead of one keep two independent dependency chains in
+// flight.  The carry out of the low chain (weight 2^261) is folded separately.
+#define BPMI_FE_COLUMN(S, K, EXPR_LOOP) \
+  { u64 s_ = (S); EXPR_LOOP; t[K] = (u32)s_ & M29; (S) = s_ >> 29; }
+
+BPMI_HD void fe_fold_limbs(fe &r, const u32 t[18], u64 c8) {
+  // t[0..8]: low limbs; t[9..17]: limbs of weight 2^261 * 2^(29(k-9)); c8 (< 2^36): carry
+  // out of column 8, also of weight 2^261.   2^261 == 2^37 + 31264 (mod p):
+  // high limb k folds into limb k (x31264) and limb k+1 (x256)
   u64 u[10];
+  const u32 k31264 = 31264u;
 #pragma unroll
-  for (int k = 0; k < 9; k++) u[k] = (u64)t[9 + k] * 31264u + t[k];
+  for (int k = 0; k < 9; k++) { u[k] = t[k]; BPMI_MAC(u[k], t[9 + k], k31264); }
 #pragma unroll
   for (int k = 1; k < 9; k++) u[k] += (u64)t[8 + k] << 8;
   u[9] = (u64)t[17] << 8;
+  u[0] += c8 * 31264u;
+  u[1] += c8 << 8;
   // everything at or above 2^256 (limb 8 bit 24) folds once more: 2^256 == 2^32 + 977
   const u64 H = (u[8] >> 24) + (u[9] << 5);
   u[8] &= M24;
   u[0] += H * 977u;
   u[1] += H << 3;
-  c = 0;
+  u64 c = 0;
 #pragma unroll
   for (int k = 0; k < 8; k++) { c += u[k]; r.v[k] = (u32)c & M29; c >>= 29; }
   r.v[8] = (u32)(c + u[8]);
 }
 
 BPMI_HD void fe_mul(fe &r, const fe &a, const fe &b) {
-  u64 acc[17];
+  u32 t[18];
+  u64 clo = 0, chi = 0;
 #pragma unroll
-  for (int k = 0; k < 17; k++) {
-    u64 s = 0;
+  for (int k = 0; k < 9; k++) {
+    u64 s = clo;
 #pragma unroll
-    for (int i = 0; i < 9; i++) {
-      const int j = k - i;
-      if (j < 0 || j > 8) continue;
-      s += (u64)a.v[i] * b.v[j];
-    }
-    acc[k] = s;
+    for (int i = 0; i <= k; i++) BPMI_MAC(s, a.v[i], b.v[k - i]);
+    t[k] = (u32)s & M29;
+    clo = s >> 29;
   }
-  fe_fold_columns(r, acc);
+#pragma unroll
+  for (int k = 9; k < 17; k++) {
+    u64 s = chi;
+#pragma unroll
+    for (int i = k - 8; i <= 8; i++) BPMI_MAC(s, a.v[i], b.v[k - i]);
+    t[k] = (u32)s & M29;
+    chi = s >> 29;
+  }
+  t[17] = (u32)chi;
+  fe_fold_limbs(r, t, clo);
 }
 
 // a of magnitude <= 2 (doubled limbs must fit 32 bits and 9 * 2 * m^2 * 2^58 < 2^64)
@@ -153,19 +174,26 @@ BPMI_HD void fe_sqr(fe &r, const fe &a) {
   u32 d[9];
 #pragma unroll
   for (int i = 0; i < 9; i++) d[i] = a.v[i] << 1;
-  u64 acc[17];
+  u32 t[18];
+  u64 clo = 0, chi = 0;
 #pragma unroll
-  for (int k = 0; k < 17; k++) {
-    u64 s = 0;
+  for (int k = 0; k < 9; k++) {
+    u64 s = clo;
 #pragma unroll
-    for (int i = 0; i < 9; i++) {
-      const int j = k - i;
-      if (j < 0 || j > 8 || i > j) continue;
-      s += (i == j) ? (u64)a.v[i] * a.v[j] : (u64)d[i] * a.v[j];
-    }
-    acc[k] = s;
+    for (int i = 0; 2 * i <= k; i++) { if (2 * i == k) BPMI_MAC(s, a.v[i], a.v[i]); else BPMI_MAC(s, d[i], a.v[k - i]); }
+    t[k] = (u32)s & M29;
+    clo = s >> 29;
   }
-  fe_fold_columns(r, acc);
+#pragma unroll
+  for (int k = 9; k < 17; k++) {
+    u64 s = chi;
+#pragma unroll
+    for (int i = k - 8; 2 * i <= k; i++) { if (2 * i == k) BPMI_MAC(s, a.v[i], a.v[i]); else BPMI_MAC(s, d[i], a.v[k - i]); }
+    t[k] = (u32)s & M29;
+    chi = s >> 29;
+  }
+  t[17] = (u32)chi;
+  fe_fold_limbs(r, t, clo);
 }
 
 // r = a * k for a small constant (k * mag(a) must stay < 8), lazy
