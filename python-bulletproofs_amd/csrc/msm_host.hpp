@@ -111,7 +111,7 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, const Segs &segs) {
     {
       StageTimer t(ctx, ST_SCATTER, st);
       const u32 ntiles = (g.n + TILE_SCALARS - 1) / TILE_SCALARS;
-      hipLaunchKernelGGL(k_partition, dim3(std::min<u32>(ntiles, 2048)), dim3(256), 0, st, segs, g, w.P, w.coarse_cursor, w.dig);
+      hipLaunchKernelGGL(k_partition, dim3(std::min<u32>(ntiles, 2048)), dim3(1024), 0, st, segs, g, w.P, w.coarse_cursor, w.dig);
       // level B over fixed-size tiles of the partitioned array (grid sized for the maximum E)
       const u32 nft = (u32)(((size_t)g.n * g.W + FINE_TILE - 1) / FINE_TILE);
       HIPCHK(ctx, hipMemsetAsync(w.hist, 0, 4ull * g.G, st));

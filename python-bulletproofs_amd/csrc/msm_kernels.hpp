@@ -87,25 +87,25 @@ __global__ void __launch_bounds__(256) k_coarse_hist(Segs segs, MsmGeom g, u32 P
   for (u32 p = threadIdx.x; p < P; p += 256u) { const u32 v = lh[p]; if (v) atomicAdd(&coarse_hist[p], v); }
 }
 // part[pos] = lo << 24 | sign << 23 | i   (n <= 2^23), grouped by partition
-__global__ void __launch_bounds__(256) k_partition(Segs segs, MsmGeom g, u32 P, u32 *__restrict__ coarse_cursor, u32 *__restrict__ part) {
+__global__ void __launch_bounds__(1024) k_partition(Segs segs, MsmGeom g, u32 P, u32 *__restrict__ coarse_cursor, u32 *__restrict__ part) {
   __shared__ u32 lh[PART_MAX];
   const u32 Bc = g.B >> 8;
   const u32 ntiles = (g.n + TILE_SCALARS - 1) / TILE_SCALARS;
   for (u32 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    for (u32 p = threadIdx.x; p < P; p += 256u) lh[p] = 0;
+    for (u32 p = threadIdx.x; p < P; p += blockDim.x) lh[p] = 0;
     __syncthreads();
     const u32 i0 = tile * TILE_SCALARS;
     const u32 i1 = (i0 + TILE_SCALARS < g.n) ? i0 + TILE_SCALARS : g.n;
-    for (u32 i = i0 + threadIdx.x; i < i1; i += 256u) {
+    for (u32 i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
       for_each_digit(segs, g, i, [&](u32 w, u32 b, u32) {
         if (b) atomicAdd(&lh[w * Bc + ((b - 1u) >> 8)], 1u);
       });
     }
     __syncthreads();
     // reserve this tile's range in every partition: count -> base position
-    for (u32 p = threadIdx.x; p < P; p += 256u) { const u32 v = lh[p]; if (v) lh[p] = atomicAdd(&coarse_cursor[p], v); }
+    for (u32 p = threadIdx.x; p < P; p += blockDim.x) { const u32 v = lh[p]; if (v) lh[p] = atomicAdd(&coarse_cursor[p], v); }
     __syncthreads();
-    for (u32 i = i0 + threadIdx.x; i < i1; i += 256u) {
+    for (u32 i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
       for_each_digit(segs, g, i, [&](u32 w, u32 b, u32 sign) {
         if (b) {
           const u32 k = b - 1u;
