@@ -173,7 +173,7 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, const Segs &segs) {
     if (g.B <= 256u) {
       hipLaunchKernelGGL(k_window_weighted_small, dim3(g.W), dim3(g.B < 64u ? 64u : g.B), 0, st, g, w.buckets, w.E);
     } else {
-      hipLaunchKernelGGL(k_bucket_digit_sums, dim3(g.W * g.nv * 31), dim3(256), 0, st, g, w.buckets, w.D);
+      hipLaunchKernelGGL(k_bucket_digit_sums, dim3(g.W * g.nv * 31), dim3(256), 0, st, g, w.buckets, w.D);   // 128 / 64 threads measured slower
       hipLaunchKernelGGL(k_weighted31, dim3(g.W * g.nv), dim3(64), 0, st, w.D, w.E);
     }
   }

@@ -438,7 +438,7 @@ __global__ void __launch_bounds__(256, 4) k_bucket_digit_sums(MsmGeom g, const u
   u32 last_cnt = 0;
   if (base_last <= g.B) { const u64 r = (u64)g.B - base_last + 1u; last_cnt = r < (1ull << sh) ? (u32)r : (1u << sh); }
   const u32 ecount = (hi_max << sh) + last_cnt;
-  for (u32 e = threadIdx.x; e < ecount; e += 256u) {
+  for (u32 e = threadIdx.x; e < ecount; e += blockDim.x) {
     const u32 lo = e & ((1u << sh) - 1u), hi = e >> sh;
     const u64 b = ((u64)hi << (sh + 5u)) | ((u64)d << sh) | lo;
     {
