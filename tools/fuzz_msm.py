@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Randomised differential test of the HIP MSM against the C oracle: random sizes, scalar
+shapes (uniform, tiny, near q/2 and q, repeated, zero), point shapes (duplicates, negated
+pairs, identities) and engine options (window bits, chunk length, tail placement).
+  python tools/fuzz_msm.py [seconds]"""
+import os
+import random
+import sys
+import time
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+import bulletproofs_amd  # noqa: E402,F401
+from bulletproofs_amd.engine import default_engine  # noqa: E402
+from oracle import cbind  # noqa: E402
+from oracle.ec import INF, secp256k1  # noqa: E402
+
+Q = secp256k1.q
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+seed = int(os.environ.get("FUZZ_SEED", "12345"))
+rnd = random.Random(seed)
+eng = default_engine()
+pool = cbind.ec_mul_batch([secp256k1.G] * 4096, [rnd.randrange(1, Q) for _ in range(4096)])
+half = (Q - 1) // 2
+
+
+def scalar(kind):
+    if kind == 0:
+        return rnd.randrange(Q)
+    if kind == 1:
+        return rnd.randrange(1 << rnd.choice((1, 8, 16, 20, 64, 128)))
+    if kind == 2:
+        return (half + rnd.randrange(-3, 4)) % Q
+    if kind == 3:
+        return (Q - 1 - rnd.randrange(0, 4)) % Q
+    if kind == 4:
+        return 0
+    return rnd.choice((1, 2, Q - 1, 1 << 255, (1 << 255) - 1, 1 << 240))
+
+
+t0 = time.time()
+cases = fails = 0
+while time.time() - t0 < budget:
+    n = rnd.choice((1, 2, 3, rnd.randrange(1, 64), rnd.randrange(1, 1500), rnd.randrange(1, 6000)))
+    pts = [rnd.choice(pool) for _ in range(n)]
+    shape = rnd.randrange(6)
+    if shape == 1:
+        pts = [pts[0]] * n
+    elif shape == 2:
+        pts = [p if i % 2 else -pts[i - 1] for i, p in enumerate(pts)]
+    elif shape == 3:
+        pts = [INF if rnd.random() < 0.3 else p for p in pts]
+    kind = rnd.randrange(7)
+    es = [scalar(kind if kind < 6 else rnd.randrange(6)) for _ in range(n)]
+    if rnd.random() < 0.2:
+        es = [es[0]] * n
+    opts = {"window_bits": rnd.choice((0, 0, 0, 2, 4, 5, 7, 8, 9, 10, 11, 13, 16)),
+            "chunk": rnd.choice((0, 0, 1, 2, 5, 16, 33, 64, 200)), "tail": rnd.choice((0, 1, 2))}
+    for k, v in opts.items():
+        eng.set_option(k, v)
+    pb, sb = cbind.pack_points(pts), cbind.pack_scalars(es)
+    got = eng.msm_bytes(pb, sb, n)
+    want = cbind.msm_bytes(pb, sb, n, 4)
+    cases += 1
+    if got != want:
+        fails += 1
+        print("MISMATCH n=%d shape=%d kind=%d opts=%s seed=%d case=%d" % (n, shape, kind, opts, seed, cases), flush=True)
+for k in ("window_bits", "chunk", "tail"):
+    eng.set_option(k, 0)
+print("fuzz: %d cases, %d mismatches, %.0f s, seed %d" % (cases, fails, time.time() - t0, seed))
+sys.exit(1 if fails else 0)
