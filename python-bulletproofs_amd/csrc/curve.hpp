@@ -90,17 +90,19 @@ BPMI_HD void xyzz_dbl(xyzz &r, const xyzz &a) {
   r.X = X3;
 }
 
-// acc += (x2, y2), affine addend that is NOT the identity (madd-2008-s): 8M + 2S
+// acc += (x2, y2), affine addend that is NOT the identity (madd-2008-s): 8M + 2S.
+// y2 may be LAZY (magnitude <= 2, e.g. 2p - y): it only feeds a multiplication on the main
+// path; the two rare branches that store or double it carry it first.
 BPMI_HD void xyzz_madd(xyzz &acc, const fe &x2, const fe &y2) {
-  if (xyzz_is_inf(acc)) { acc.X = x2; acc.Y = y2; fe_set_one(acc.ZZ); fe_set_one(acc.ZZZ); return; }
+  if (xyzz_is_inf(acc)) { acc.X = x2; fe_carry(acc.Y, y2); fe_set_one(acc.ZZ); fe_set_one(acc.ZZZ); return; }
   fe U2, S2, P, R, PP, PPP, Q, t, t2;
   fe_mul(U2, x2, acc.ZZ);
   fe_mul(S2, y2, acc.ZZZ);
   fe_sub(P, U2, acc.X); fe_carry(P, P);
   fe_sub(R, S2, acc.Y); fe_carry(R, R);
   if (fe_is_zero_tight(P)) {
-    if (fe_is_zero_tight(R)) { xyzz_dbl_affine(acc, x2, y2); return; }   // acc == addend
-    xyzz_set_inf(acc); return;                                             // acc == -addend
+    if (fe_is_zero_tight(R)) { fe_carry(t, y2); xyzz_dbl_affine(acc, x2, t); return; }   // acc == addend
+    xyzz_set_inf(acc); return;                                                             // acc == -addend
   }
   fe_sqr(PP, P);
   fe_mul(PPP, P, PP);
@@ -120,9 +122,8 @@ BPMI_HD void xyzz_madd(xyzz &acc, const fe &x2, const fe &y2) {
 // makes every wave execute two copies of the 8M+2S add with half the lanes masked.
 BPMI_HD void xyzz_madd_signed(xyzz &acc, const affine &P, bool negate) {
   if (affine_is_inf(P)) return;
-  fe ny, t;
-  fe_neg(t, P.y);
-  fe_carry(ny, t);
+  fe ny;
+  fe_neg(ny, P.y);                        // 2p - y, lazy (magnitude 2)
 #pragma unroll
   for (int k = 0; k < 9; k++) ny.v[k] = negate ? ny.v[k] : P.y.v[k];
   xyzz_madd(acc, P.x, ny);
