@@ -150,7 +150,7 @@ int bpmi_msm_dev(bpmi_ctx *ctx, const void *d_pts, const void *d_scalars, uint64
   if (!ctx || !out || (n && (!d_pts || !d_scalars))) return ctx ? fail(ctx, BPMI_E_ARG, "null argument") : BPMI_E_ARG;
   if (n > BPMI_MAX_N) return fail(ctx, BPMI_E_ARG, "n exceeds BPMI_MAX_N");
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  Segs s = {};
+  Segs s = segs_init();
   s.pts[0] = (const u32 *)d_pts; s.sc[0] = (const u32 *)d_scalars; s.n[0] = (u32)n; s.total = (u32)n;
   return msm_run(ctx, s, out);
 }
@@ -479,12 +479,12 @@ int bpmi_ipa_round_LR(bpmi_ipa *st, uint8_t L[64], uint8_t R[64]) {
     // bases are the current generators: L = <a_lo, g_hi> + <b_hi, h_lo> + cl*u  (:98) as ONE
     // three-segment MSM, R = <a_hi, g_lo> + <b_lo, h_hi> + cr*u  (:99)
     u32 *g_lo = st->g, *g_hi = st->g + 16 * np, *h_lo = st->h, *h_hi = st->h + 16 * np;
-    Segs sL = {};
+    Segs sL = segs_init();
     sL.pts[0] = g_hi; sL.sc[0] = a_lo; sL.n[0] = (u32)np;
     sL.pts[1] = h_lo; sL.sc[1] = b_hi; sL.n[1] = (u32)np;
     sL.pts[2] = st->u; sL.sc[2] = st->cl; sL.n[2] = 1;
     sL.total = (u32)(2 * np + 1);
-    Segs sR = {};
+    Segs sR = segs_init();
     sR.pts[0] = g_lo; sR.sc[0] = a_hi; sR.n[0] = (u32)np;
     sR.pts[1] = h_hi; sR.sc[1] = b_lo; sR.n[1] = (u32)np;
     sR.pts[2] = st->u; sR.sc[2] = st->cr; sR.n[2] = 1;
@@ -504,11 +504,16 @@ int bpmi_ipa_round_LR(bpmi_ipa *st, uint8_t L[64], uint8_t R[64]) {
         hipLaunchKernelGGL(k_ipa_expand, dim3((u32)((st->M + 255) / 256)), dim3(256), 0, ctx->stream, st->a, st->b,
                            st->cg[st->cur], st->ch[st->cur], (u32)st->M, logm, right, eg, eh);
       }
-      sg[right] = Segs{};
-      sg[right].pts[0] = st->g; sg[right].sc[0] = eg; sg[right].n[0] = (u32)st->M;
-      sg[right].pts[1] = st->h; sg[right].sc[1] = eh; sg[right].n[1] = (u32)st->M;
+      // only the non-zero half of every block of m logical positions takes part: for L the
+      // upper g-halves and lower h-halves (g_hi with a_lo, h_lo with b_hi), for R the opposite
+      sg[right] = segs_init();
+      sg[right].pts[0] = st->g; sg[right].sc[0] = eg; sg[right].n[0] = (u32)(st->M / 2);
+      sg[right].pts[1] = st->h; sg[right].sc[1] = eh; sg[right].n[1] = (u32)(st->M / 2);
+      sg[right].hlog[0] = sg[right].hlog[1] = logm - 1;
+      sg[right].phase[0] = right ? 0u : 1u;
+      sg[right].phase[1] = right ? 1u : 0u;
       sg[right].pts[2] = st->u; sg[right].sc[2] = right ? st->cr : st->cl; sg[right].n[2] = 1;
-      sg[right].total = (u32)(2 * st->M + 1);
+      sg[right].total = (u32)(st->M + 1);
     }
     rc = msm_run_pair(ctx, sg[0], L, sg[1], R);
     if (rc) return rc;

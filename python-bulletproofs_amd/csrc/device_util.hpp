@@ -16,7 +16,25 @@ struct Segs {
   const u32 *sc[3];
   u32 n[3];
   u32 total;
+  // Optional half-block selection per segment: with hlog[s] = h < 32 the logical element j of
+  // segment s is the physical element ((j >> h) << (h + 1)) | (phase[s] << h) | (j & (2^h - 1)),
+  // i.e. only the lower (phase 0) or upper (phase 1) half of every block of 2^(h+1) elements.
+  // The deferred-fold MSMs of the IPA use it to skip the half of the scalars that is zero by
+  // construction.  hlog[s] >= 32: dense (the default, set by segs_init).
+  u32 hlog[3];
+  u32 phase[3];
 };
+static inline Segs segs_init() {
+  Segs s;
+  memset(&s, 0, sizeof(s));
+  s.hlog[0] = s.hlog[1] = s.hlog[2] = 0xFFu;
+  return s;
+}
+__device__ __forceinline__ u32 seg_phys(const Segs &s, int k, u32 j) {
+  const u32 h = s.hlog[k];
+  if (h >= 32u) return j;
+  return ((j >> h) << (h + 1u)) | (s.phase[k] << h) | (j & ((1u << h) - 1u));
+}
 
 __device__ __forceinline__ void load_words16(u32 w[16], const u32 *p) {
   const uint4 *q = reinterpret_cast<const uint4 *>(p);
@@ -39,18 +57,18 @@ __device__ __forceinline__ void store_words8(u32 *p, const u32 w[8]) {
   for (int i = 0; i < 2; i++) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
 }
 __device__ __forceinline__ const u32 *seg_point(const Segs &s, u32 i) {
-  if (i < s.n[0]) return s.pts[0] + 16ull * i;
+  if (i < s.n[0]) return s.pts[0] + 16ull * seg_phys(s, 0, i);
   i -= s.n[0];
-  if (i < s.n[1]) return s.pts[1] + 16ull * i;
+  if (i < s.n[1]) return s.pts[1] + 16ull * seg_phys(s, 1, i);
   i -= s.n[1];
-  return s.pts[2] + 16ull * i;
+  return s.pts[2] + 16ull * seg_phys(s, 2, i);
 }
 __device__ __forceinline__ const u32 *seg_scalar(const Segs &s, u32 i) {
-  if (i < s.n[0]) return s.sc[0] + 8ull * i;
+  if (i < s.n[0]) return s.sc[0] + 8ull * seg_phys(s, 0, i);
   i -= s.n[0];
-  if (i < s.n[1]) return s.sc[1] + 8ull * i;
+  if (i < s.n[1]) return s.sc[1] + 8ull * seg_phys(s, 1, i);
   i -= s.n[1];
-  return s.sc[2] + 8ull * i;
+  return s.sc[2] + 8ull * seg_phys(s, 2, i);
 }
 __device__ __forceinline__ void load_affine(affine &P, const u32 *p) {
   u32 w[16];
