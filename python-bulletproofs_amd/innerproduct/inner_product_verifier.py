@@ -47,14 +47,17 @@ class Verifier2(_Checker):
             ss = [s * xi for s in ss] + [s * x for s in ss]
         return ss
 
-    def _ss_and_inverse(self, xs):
+    def _scaled_ss(self, xs, a, b):
+        """([a * s_i], [b * s_i^-1]) as plain integers mod q, by the same doubling."""
+        q = SUPERCURVE.q
         n = len(self.g)
-        ss, si = [ModP(1, SUPERCURVE.q)], [ModP(1, SUPERCURVE.q)]
+        sa, sb = [a % q], [b % q]
         for x in reversed(xs[: n.bit_length() - 1]):
-            xi = x.inv()
-            ss = [s * xi for s in ss] + [s * x for s in ss]
-            si = [s * x for s in si] + [s * xi for s in si]
-        return ss, si
+            xv = x.x % q
+            xi = pow(xv, -1, q)
+            sa = [s * xi % q for s in sa] + [s * xv % q for s in sa]
+            sb = [s * xv % q for s in sb] + [s * xi % q for s in sb]
+        return sa, sb
 
     def verify_transcript(self):
         pr = self.proof
@@ -70,11 +73,8 @@ class Verifier2(_Checker):
     def verify(self):
         self.verify_transcript()
         pr = self.proof
-        ss, ss_inv = self._ss_and_inverse(pr.xs)
-        lhs = PipSECP256k1.multiexp(
-            self.g + self.h + [self.u],
-            [pr.a * s for s in ss] + [pr.b * s for s in ss_inv] + [pr.a * pr.b],
-        )
+        sa, sb = self._scaled_ss(pr.xs, pr.a.x, pr.b.x)
+        lhs = PipSECP256k1.multiexp(self.g + self.h + [self.u], sa + sb + [pr.a * pr.b])
         # RHS = P + sum x_i^2 L_i + x_i^-2 R_i  as one MSM with P at scalar 1
         rhs = PipSECP256k1.multiexp(
             pr.Ls + pr.Rs + [self.P],

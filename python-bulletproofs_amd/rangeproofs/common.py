@@ -26,13 +26,13 @@ class Proof:
 def scaled_generators(hs, y):
     """hsp[i] = y^-i * hs[i] (reference rangeproof_prover.py:77): one batched GPU launch."""
     q = y.p
-    yinv = y.inv()
-    powers, cur = [], ModP(1, q)
+    yinv = pow(y.x, -1, q)
+    powers, cur = [], 1
     for _ in hs:
         powers.append(cur)
-        cur = cur * yinv
+        cur = cur * yinv % q
     eng = _engine.default_engine()
-    out = eng.ec_mul_batch_bytes(pack_points(hs), pack_scalars(powers, q), len(hs))
+    out = eng.ec_mul_batch_bytes(pack_points(hs), b"".join(v.to_bytes(32, "little") for v in powers), len(hs))
     return unpack_points(out, len(hs))
 
 
@@ -40,61 +40,85 @@ def z_term(z, i, n, aggregated):
     return (z ** (2 + i // n)) * (2 ** (i % n)) if aggregated else (z ** 2) * (2 ** i)
 
 
+def _z_terms(z, n, m, q, aggregated):
+    """[z^(2 + i//n) * 2^(i%n) mod q for i < n*m] (aggregated) or [z^2 * 2^i] (single, m = 1)."""
+    out = []
+    for j in range(m):
+        cur = pow(z, 2 + j, q) if aggregated else z * z % q
+        for _ in range(n):
+            out.append(cur)
+            cur = cur * 2 % q
+    return out
+
+
+def _powers(y, count, q):
+    out, cur = [], 1
+    for _ in range(count):
+        out.append(cur)
+        cur = cur * y % q
+    return out
+
+
 def prove(vs, n, g, h, gs, hs, gammas, u, group, seed, aggregated):
     """NIRangeProver.prove (rangeproof_prover.py:35-112) / AggregNIRangeProver.prove
-    (rangeproof_aggreg_prover.py:36-146)."""
+    (rangeproof_aggreg_prover.py:36-146).  The O(n m) scalar algebra runs on plain Python
+    integers mod q (every value the reference exposes -- transcript numbers, taux, mu, t_hat,
+    a, b -- is reduced there as well, so the results are identical); ModP objects appear
+    only where the reference's surface shows them."""
     q = group.q
-    nm = n * len(vs)
+    m = len(vs)
+    nm = n * m
     tr = Transcript(seed)
     aL = []
     for v in vs:
         aL += list(map(int, reversed(bin(v.x)[2:].zfill(n))))[:n]
     aR = [(bit - 1) % q for bit in aL]
-    alpha = mod_hash(b"alpha" + tr.digest, q)
+    alpha = mod_hash(b"alpha" + tr.digest, q).x
     # A = <aL, gs> + <aR, hs> + alpha*h as one MSM
     A = PipSECP256k1.multiexp(gs + hs + [h], aL + aR + [alpha])
-    sL = [mod_hash(str(i).encode() + tr.digest, q) for i in range(nm)]
-    sR = [mod_hash(str(i).encode() + tr.digest, q) for i in range(nm, 2 * nm)]
-    rho = mod_hash(str(2 * n).encode() + tr.digest, q)     # sic: 2*n also when aggregated (:61)
+    sL = [mod_hash(str(i).encode() + tr.digest, q).x for i in range(nm)]
+    sR = [mod_hash(str(i).encode() + tr.digest, q).x for i in range(nm, 2 * nm)]
+    rho = mod_hash(str(2 * n).encode() + tr.digest, q).x     # sic: 2*n also when aggregated (:61)
     S = PipSECP256k1.multiexp(gs + hs + [h], sL + sR + [rho])
     tr.add_list_points([A, S])
-    y = tr.get_modp(q)
-    tr.add_number(y)
-    z = tr.get_modp(q)
-    tr.add_number(z)
-    ypow, cur = [], ModP(1, q)
-    for _ in range(nm):
-        ypow.append(cur)
-        cur = cur * y
-    zt = [z_term(z, i, n, aggregated) for i in range(nm)]
-    ysr = [ypow[i] * sR[i] for i in range(nm)]
-    t1 = inner_product(sL, [ypow[i] * (aR[i] + z) + zt[i] for i in range(nm)]) + inner_product(
-        [aL[i] - z for i in range(nm)], ysr)
-    t2 = inner_product(sL, ysr)
-    tau1 = mod_hash(b"tau1" + tr.digest, q)
-    tau2 = mod_hash(b"tau2" + tr.digest, q)
+    yM = tr.get_modp(q)
+    tr.add_number(yM)
+    zM = tr.get_modp(q)
+    tr.add_number(zM)
+    y, z = yM.x, zM.x
+    ypow = _powers(y, nm, q)
+    zt = _z_terms(z, n, m, q, aggregated)
+    ysr = [ypow[i] * sR[i] % q for i in range(nm)]
+    # _get_polynomial_coeffs (:93-101 / aggreg :117-130)
+    t1 = (sum(sL[i] * (ypow[i] * (aR[i] + z) + zt[i]) for i in range(nm))
+          + sum((aL[i] - z) * ysr[i] for i in range(nm))) % q
+    t2 = sum(sL[i] * ysr[i] for i in range(nm)) % q
+    tau1 = mod_hash(b"tau1" + tr.digest, q).x
+    tau2 = mod_hash(b"tau2" + tr.digest, q).x
     T1 = commitment(g, h, t1, tau1)
     T2 = commitment(g, h, t2, tau2)
     tr.add_list_points([T1, T2])
-    x = tr.get_modp(q)
-    tr.add_number(x)
-    ls = [aL[i] - z + sL[i] * x for i in range(nm)]
-    rs = [ypow[i] * (aR[i] + z + sR[i] * x) + zt[i] for i in range(nm)]
-    t_hat = inner_product(ls, rs)
+    xM = tr.get_modp(q)
+    tr.add_number(xM)
+    x = xM.x
+    # _final_compute (:103-112 / aggreg :132-146)
+    ls = [(aL[i] - z + sL[i] * x) % q for i in range(nm)]
+    rs = [(ypow[i] * (aR[i] + z + sR[i] * x) + zt[i]) % q for i in range(nm)]
+    t_hat = sum(ls[i] * rs[i] for i in range(nm)) % q
     if aggregated:
-        blind = sum([(z ** (2 + j)) * gammas[j] for j in range(len(vs))])
+        blind = sum(pow(z, 2 + j, q) * gammas[j].x for j in range(m))
     else:
-        blind = (z ** 2) * gammas
-    taux = tau2 * (x ** 2) + tau1 * x + blind
-    mu = alpha + rho * x
-    hsp = scaled_generators(hs, y)
+        blind = z * z * gammas.x
+    taux = (tau2 * x * x + tau1 * x + blind) % q
+    mu = (alpha + rho * x) % q
+    hsp = scaled_generators(hs, yM)
     # P - mu*h = A + x*S + sum(-z)*gs + sum(z*y^i + zt_i)*hsp - mu*h, one MSM
     P_inner = PipSECP256k1.multiexp(
         gs + hsp + [A, S, h],
-        [-z for _ in range(nm)] + [(z * ypow[i]) + zt[i] for i in range(nm)] + [1, x, -mu],
+        [-z] * nm + [z * ypow[i] + zt[i] for i in range(nm)] + [1, x, -mu],
     )
-    inner = NIProver(gs, hsp, u, P_inner, t_hat, ls, rs, group).prove()
-    return Proof(taux, mu, t_hat, T1, T2, A, S, inner, tr.digest)
+    inner = NIProver(gs, hsp, u, P_inner, ModP(t_hat, q), ls, rs, group).prove()
+    return Proof(ModP(taux, q), ModP(mu, q), ModP(t_hat, q), T1, T2, A, S, inner, tr.digest)
 
 
 class VerifierBase:
@@ -117,14 +141,10 @@ class VerifierBase:
         self.x = ModP(int(items[7]), p)
 
     def _getP(self, x, y, z, A, S, gs, hsp, n, m=1, aggregated=False, extra_pts=(), extra_sc=()):
+        q = y.p
         nm = n * m
-        ypow, cur = [], ModP(1, y.p)
-        for _ in range(nm):
-            ypow.append(cur)
-            cur = cur * y
+        zi, ypow, zt = z.x, _powers(y.x, nm, q), _z_terms(z.x, n, m, q, aggregated)
         return PipSECP256k1.multiexp(
             gs + hsp + [A, S] + list(extra_pts),
-            [-z for _ in range(nm)]
-            + [(z * ypow[i]) + z_term(z, i, n, aggregated) for i in range(nm)]
-            + [1, x] + list(extra_sc),
+            [-zi] * nm + [zi * ypow[i] + zt[i] for i in range(nm)] + [1, x] + list(extra_sc),
         )

@@ -3,7 +3,7 @@ from ..ec import secp256k1
 from ..innerproduct.inner_product_verifier import Verifier1
 from ..pippenger import PipSECP256k1
 from ..utils.utils import ModP
-from .common import Proof, VerifierBase, scaled_generators
+from .common import Proof, VerifierBase, scaled_generators, _powers
 
 CURVE = secp256k1
 
@@ -18,10 +18,7 @@ class AggregRangeVerifier(VerifierBase):
         nm = len(gs)
         m = len(self.Vs)
         n = nm // m
-        ysum, cur = ModP(0, CURVE.q), ModP(1, CURVE.q)
-        for _ in range(nm):
-            ysum = ysum + cur
-            cur = cur * y
+        ysum = ModP(sum(_powers(y.x, nm, CURVE.q)) % CURVE.q, CURVE.q)
         delta_yz = (z - z ** 2) * ysum - sum([(z ** (j + 2)) * ModP(2 ** n - 1, CURVE.q) for j in range(1, m + 1)])
         hsp = scaled_generators(hs, y)
         lhs = PipSECP256k1.multiexp([g, h], [proof.t_hat, proof.taux])

@@ -3,7 +3,7 @@ from ..ec import secp256k1
 from ..innerproduct.inner_product_verifier import Verifier1
 from ..pippenger import PipSECP256k1
 from ..utils.utils import ModP
-from .common import Proof, VerifierBase, scaled_generators
+from .common import Proof, VerifierBase, scaled_generators, _powers
 
 CURVE = secp256k1
 
@@ -16,10 +16,7 @@ class RangeVerifier(VerifierBase):
         self.verify_transcript()
         g, h, gs, hs, x, y, z, proof = self.g, self.h, self.gs, self.hs, self.x, self.y, self.z, self.proof
         n = len(gs)
-        ysum, cur = ModP(0, CURVE.q), ModP(1, CURVE.q)
-        for _ in range(n):
-            ysum = ysum + cur
-            cur = cur * y
+        ysum = ModP(sum(_powers(y.x, n, CURVE.q)) % CURVE.q, CURVE.q)
         delta_yz = (z - z ** 2) * ysum - (z ** 3) * ModP(2 ** n - 1, CURVE.q)
         hsp = scaled_generators(hs, y)
         # t_hat*g + taux*h == z^2*V + delta*g + x*T1 + x^2*T2  (reference :73-76)
