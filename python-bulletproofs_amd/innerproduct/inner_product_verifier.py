@@ -33,8 +33,13 @@ class Verifier2(_Checker):
     """Protocol 2 verifier (reference :76-147): transcript re-derivation, the s-vector,
     one MSM of size 2n+1 and one of size 2 log n -- both on the GPU."""
 
-    def __init__(self, g, h, u, P, proof: Proof2):
+    def __init__(self, g, h, u, P, proof: Proof2, h_scale=None):
+        """h_scale (extension, not in the reference): integers c_i such that the statement
+        is over the generators c_i * h[i].  The range-proof verifiers pass h = hs and
+        c_i = y^-i instead of materialising hsp[i] = y^-i * hs[i] point by point
+        (rangeproof_verifier.py:72) -- the factors go into the MSM scalars, same result."""
         self.g, self.h, self.u, self.P, self.proof = g, h, u, P, proof
+        self.h_scale = h_scale
 
     def get_ss(self, xs):
         """s_i = prod_j xs[j]^(+1 if bit j (MSB first) of i is set else -1), i = 0..n-1
@@ -74,21 +79,28 @@ class Verifier2(_Checker):
         self.verify_transcript()
         pr = self.proof
         sa, sb = self._scaled_ss(pr.xs, pr.a.x, pr.b.x)
-        lhs = PipSECP256k1.multiexp(self.g + self.h + [self.u], sa + sb + [pr.a * pr.b])
-        # RHS = P + sum x_i^2 L_i + x_i^-2 R_i  as one MSM with P at scalar 1
-        rhs = PipSECP256k1.multiexp(
-            pr.Ls + pr.Rs + [self.P],
-            [x ** 2 for x in pr.xs] + [x.inv() ** 2 for x in pr.xs] + [1],
+        if self.h_scale is not None:
+            q = SUPERCURVE.q
+            sb = [v * c % q for v, c in zip(sb, self.h_scale)]
+        # LHS == RHS (reference :134-145) as ONE MSM that must be the identity:
+        #   sum a s_i g_i + sum b s_i^-1 h_i + (a b) u - P - sum (x_j^2 L_j + x_j^-2 R_j) = 0
+        q = SUPERCURVE.q
+        xsq = [x.x * x.x % q for x in pr.xs]
+        xisq = [pow(v, -1, q) for v in xsq]
+        total = PipSECP256k1.multiexp(
+            self.g + self.h + [self.u] + pr.Ls + pr.Rs + [self.P],
+            sa + sb + [pr.a * pr.b] + [-v for v in xsq] + [-v for v in xisq] + [-1],
         )
-        self.assertThat(lhs == rhs)
+        self.assertThat(total == Point.IDENTITY_ELEMENT)
         return True
 
 
 class Verifier1(_Checker):
     """Protocol 1 verifier (reference :20-58)."""
 
-    def __init__(self, g, h, u, P, c, proof1):
+    def __init__(self, g, h, u, P, c, proof1, h_scale=None):
         self.g, self.h, self.u, self.P, self.c, self.proof1 = g, h, u, P, c, proof1
+        self.h_scale = h_scale
 
     def verify_transcript(self):
         items = self.proof1.transcript.split(b"&")
@@ -97,6 +109,6 @@ class Verifier1(_Checker):
     def verify(self):
         self.verify_transcript()
         x = ModP(int(self.proof1.transcript.split(b"&")[1]), SUPERCURVE.q)
-        self.assertThat(self.proof1.P_new == self.P + (x * self.c) * self.u)
+        self.assertThat(self.proof1.P_new == PipSECP256k1.multiexp([self.P, self.u], [1, x * self.c]))
         self.assertThat(self.proof1.u_new == x * self.u)
-        return Verifier2(self.g, self.h, self.proof1.u_new, self.proof1.P_new, self.proof1.proof2).verify()
+        return Verifier2(self.g, self.h, self.proof1.u_new, self.proof1.P_new, self.proof1.proof2, self.h_scale).verify()

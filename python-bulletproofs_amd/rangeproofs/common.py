@@ -140,11 +140,14 @@ class VerifierBase:
         self.assertThat(items[6] == point_to_b64(proof.T2))
         self.x = ModP(int(items[7]), p)
 
-    def _getP(self, x, y, z, A, S, gs, hsp, n, m=1, aggregated=False, extra_pts=(), extra_sc=()):
+    def _getP(self, x, y, z, A, S, gs, hsp, n, m=1, aggregated=False, extra_pts=(), extra_sc=(), h_scale=None):
+        """A + x*S + sum(-z)*gs_i + sum(z*y^i + zt_i)*hsp_i (+ extras) as one MSM.  With
+        h_scale = [y^-i] the list `hsp` holds the UNSCALED hs and the factors ride in the
+        scalars."""
         q = y.p
         nm = n * m
         zi, ypow, zt = z.x, _powers(y.x, nm, q), _z_terms(z.x, n, m, q, aggregated)
-        return PipSECP256k1.multiexp(
-            gs + hsp + [A, S] + list(extra_pts),
-            [-zi] * nm + [zi * ypow[i] + zt[i] for i in range(nm)] + [1, x] + list(extra_sc),
-        )
+        hsc = [zi * ypow[i] + zt[i] for i in range(nm)]
+        if h_scale is not None:
+            hsc = [v * c % q for v, c in zip(hsc, h_scale)]
+        return PipSECP256k1.multiexp(gs + hsp + [A, S] + list(extra_pts), [-zi] * nm + hsc + [1, x] + list(extra_sc))

@@ -1,5 +1,5 @@
 """Aggregated range proof verifier (reference: src/rangeproofs/rangeproof_aggreg_verifier.py)."""
-from ..ec import secp256k1
+from ..ec import Point, secp256k1
 from ..innerproduct.inner_product_verifier import Verifier1
 from ..pippenger import PipSECP256k1
 from ..utils.utils import ModP
@@ -20,13 +20,14 @@ class AggregRangeVerifier(VerifierBase):
         n = nm // m
         ysum = ModP(sum(_powers(y.x, nm, CURVE.q)) % CURVE.q, CURVE.q)
         delta_yz = (z - z ** 2) * ysum - sum([(z ** (j + 2)) * ModP(2 ** n - 1, CURVE.q) for j in range(1, m + 1)])
-        hsp = scaled_generators(hs, y)
-        lhs = PipSECP256k1.multiexp([g, h], [proof.t_hat, proof.taux])
-        rhs = PipSECP256k1.multiexp(
-            list(self.Vs) + [g, proof.T1, proof.T2],
-            [z ** (j + 2) for j in range(m)] + [delta_yz, x, x ** 2],
+        # hsp[i] = y^-i * hs[i] is never materialised: y^-i goes into the MSM scalars
+        yscale = _powers(pow(y.x, -1, CURVE.q), nm, CURVE.q)
+        # t_hat*g + taux*h == sum z^(j+2) V_j + delta*g + x*T1 + x^2*T2  (reference :82-89), one MSM == identity
+        check = PipSECP256k1.multiexp(
+            [g, h] + list(self.Vs) + [proof.T1, proof.T2],
+            [proof.t_hat - delta_yz, proof.taux] + [-(z ** (j + 2)) for j in range(m)] + [-x, -(x ** 2)],
         )
-        self.assertThat(lhs == rhs)
-        P_inner = self._getP(x, y, z, proof.A, proof.S, gs, hsp, n, m, aggregated=True,
-                             extra_pts=[h], extra_sc=[-proof.mu])
-        return Verifier1(gs, hsp, self.u, P_inner, proof.t_hat, proof.innerProof).verify()
+        self.assertThat(check == Point.IDENTITY_ELEMENT)
+        P_inner = self._getP(x, y, z, proof.A, proof.S, gs, hs, n, m, aggregated=True,
+                             extra_pts=[h], extra_sc=[-proof.mu], h_scale=yscale)
+        return Verifier1(gs, hs, self.u, P_inner, proof.t_hat, proof.innerProof, h_scale=yscale).verify()

@@ -1,5 +1,5 @@
 """Single range proof verifier (reference: src/rangeproofs/rangeproof_verifier.py)."""
-from ..ec import secp256k1
+from ..ec import Point, secp256k1
 from ..innerproduct.inner_product_verifier import Verifier1
 from ..pippenger import PipSECP256k1
 from ..utils.utils import ModP
@@ -18,10 +18,12 @@ class RangeVerifier(VerifierBase):
         n = len(gs)
         ysum = ModP(sum(_powers(y.x, n, CURVE.q)) % CURVE.q, CURVE.q)
         delta_yz = (z - z ** 2) * ysum - (z ** 3) * ModP(2 ** n - 1, CURVE.q)
-        hsp = scaled_generators(hs, y)
+        # hsp[i] = y^-i * hs[i] is never materialised: y^-i goes into the MSM scalars
+        yscale = _powers(pow(y.x, -1, CURVE.q), n, CURVE.q)
         # t_hat*g + taux*h == z^2*V + delta*g + x*T1 + x^2*T2  (reference :73-76)
-        lhs = PipSECP256k1.multiexp([g, h], [proof.t_hat, proof.taux])
-        rhs = PipSECP256k1.multiexp([self.V, g, proof.T1, proof.T2], [z ** 2, delta_yz, x, x ** 2])
-        self.assertThat(lhs == rhs)
-        P_inner = self._getP(x, y, z, proof.A, proof.S, gs, hsp, n, extra_pts=[h], extra_sc=[-proof.mu])
-        return Verifier1(gs, hsp, self.u, P_inner, proof.t_hat, proof.innerProof).verify()
+        # t_hat*g + taux*h == z^2*V + delta*g + x*T1 + x^2*T2  (reference :73-76) as one MSM == identity
+        check = PipSECP256k1.multiexp([g, h, self.V, proof.T1, proof.T2],
+                                      [proof.t_hat - delta_yz, proof.taux, -(z ** 2), -x, -(x ** 2)])
+        self.assertThat(check == Point.IDENTITY_ELEMENT)
+        P_inner = self._getP(x, y, z, proof.A, proof.S, gs, hs, n, extra_pts=[h], extra_sc=[-proof.mu], h_scale=yscale)
+        return Verifier1(gs, hs, self.u, P_inner, proof.t_hat, proof.innerProof, h_scale=yscale).verify()
