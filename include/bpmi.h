@@ -134,6 +134,12 @@ int bpmi_ipa_create(bpmi_ctx *ctx, const uint8_t *g, const uint8_t *h, const uin
                     uint64_t n, const uint8_t u[64], bpmi_ipa **out);
 int bpmi_ipa_create_dev(bpmi_ctx *ctx, const void *d_g, const void *d_h, const void *d_a, const void *d_b,
                         uint64_t n, const uint8_t u[64], bpmi_ipa **out);
+/* As bpmi_ipa_create, for the generators h_scale[i] * h[i] (h_scale: n scalars, or NULL):
+ * the range-proof provers run the argument over hsp[i] = y^-i * hs[i]
+ * (src/rangeproofs/rangeproof_prover.py:77,88); the factors are multiplied into the MSM
+ * scalars instead of n point multiplications (large n: one batched multiplication). */
+int bpmi_ipa_create_scaled(bpmi_ctx *ctx, const uint8_t *g, const uint8_t *h, const uint8_t *a, const uint8_t *b,
+                           uint64_t n, const uint8_t u[64], const uint8_t *h_scale, bpmi_ipa **out);
 uint64_t bpmi_ipa_len(const bpmi_ipa *st);
 int bpmi_ipa_round_LR(bpmi_ipa *st, uint8_t L[64], uint8_t R[64]);
 int bpmi_ipa_fold(bpmi_ipa *st, const uint8_t x[32], const uint8_t xinv[32]);

@@ -34,6 +34,7 @@ SIGNATURES = {
     "bpmi_sc_fold": (_i, [_vp, _cp, _cp, _cp, _cp, _u64, _cp]),
     "bpmi_sc_fold_dev": (_i, [_vp, _vp, _vp, _cp, _cp, _u64, _vp]),
     "bpmi_ipa_create": (_i, [_vp, _cp, _cp, _cp, _cp, _u64, _cp, ctypes.POINTER(_vp)]),
+    "bpmi_ipa_create_scaled": (_i, [_vp, _cp, _cp, _cp, _cp, _u64, _cp, _cp, ctypes.POINTER(_vp)]),
     "bpmi_ipa_create_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _u64, _cp, ctypes.POINTER(_vp)]),
     "bpmi_ipa_len": (_u64, [_vp]),
     "bpmi_ipa_round_LR": (_i, [_vp, _cp, _cp]),

@@ -369,6 +369,8 @@ struct bpmi_ipa {
   u32 *cl, *cr;         // device, 32 B scalars (stay on device between dot and MSM)
   u32 *partial;         // device scratch for dots
   NafK *nafk[2];        // device, NAF tables for the multifold kernel
+  u32 *hscale_buf;      // device, room for n0 scalars
+  u32 *hscale;          // device, optional per-base scale of the h generators (n0 scalars) or nullptr
   void *block;          // one allocation
   std::vector<sc> hcg, hch;   // host copies of the coefficient tables while 2^d <= 16
   bool lr_done;
@@ -391,7 +393,7 @@ static int ipa_alloc(bpmi_ctx *ctx, uint64_t n, bpmi_ipa **out) {
   if (st->big_m < 32) st->big_m = 32;
   const size_t pts = align_up(64 * n, 256), scs = align_up(32 * n, 256);
   const size_t pts2 = align_up(64 * (n / 16 + 1), 256), coef = align_up(32 * n, 256);
-  const size_t bytes = pts * 2 + pts2 * 2 + scs * 6 + coef * 4 + 256 * 3 + 32 * 1024 + 2 * align_up(sizeof(NafK), 256);
+  const size_t bytes = pts * 2 + pts2 * 2 + scs * 7 + coef * 4 + 256 * 3 + 32 * 1024 + 2 * align_up(sizeof(NafK), 256);
   hipError_t e = hipMalloc(&st->block, bytes);
   if (e != hipSuccess) { delete st; return fail(ctx, BPMI_E_NOMEM, std::string("hipMalloc(ipa state): ") + hipGetErrorString(e)); }
   char *p = (char *)st->block;
@@ -405,6 +407,8 @@ static int ipa_alloc(bpmi_ctx *ctx, uint64_t n, bpmi_ipa **out) {
   st->eh = (u32 *)p; p += scs;
   st->eg2 = (u32 *)p; p += scs;
   st->eh2 = (u32 *)p; p += scs;
+  st->hscale = nullptr;
+  u32 *hscale_buf = (u32 *)p; p += scs;
   for (int k = 0; k < 2; k++) { st->cg[k] = (u32 *)p; p += coef; st->ch[k] = (u32 *)p; p += coef; }
   st->u = (u32 *)p; p += 256;
   st->cl = (u32 *)p; p += 256;
@@ -419,6 +423,7 @@ static int ipa_alloc(bpmi_ctx *ctx, uint64_t n, bpmi_ipa **out) {
   if (e != hipSuccess) { (void)hipFree(st->block); delete st; return fail(ctx, BPMI_E_HIP, std::string("ipa_alloc: ") + hipGetErrorString(e)); }
   sc o; memset(&o, 0, sizeof(o)); o.v[0] = 1;
   st->hcg.assign(1, o); st->hch.assign(1, o);
+  st->hscale_buf = hscale_buf;
   *out = st;
   return BPMI_OK;
 }
@@ -462,6 +467,26 @@ int bpmi_ipa_create(bpmi_ctx *ctx, const uint8_t *g, const uint8_t *h, const uin
   *out = st;
   return BPMI_OK;
 }
+int bpmi_ipa_create_scaled(bpmi_ctx *ctx, const uint8_t *g, const uint8_t *h, const uint8_t *a, const uint8_t *b, uint64_t n,
+                           const uint8_t u[64], const uint8_t *h_scale, bpmi_ipa **out) {
+  int rc = bpmi_ipa_create(ctx, g, h, a, b, n, u, out);
+  if (rc || !h_scale) return rc;
+  bpmi_ipa *st = *out;
+  if (n >= st->big_m) {
+    // large bases get folded by the shared-scalar ladder, which needs real points: scale them once
+    HIPCHK(ctx, hipMemcpyAsync(st->hscale_buf, h_scale, 32 * n, hipMemcpyHostToDevice, ctx->stream));
+    rc = bpmi_ec_mul_batch_dev(ctx, st->h, st->hscale_buf, n, st->h);
+    if (rc == BPMI_OK) { hipError_t e = hipStreamSynchronize(ctx->stream); if (e != hipSuccess) rc = fail(ctx, BPMI_E_HIP, hipGetErrorString(e)); }
+  } else {
+    // never folded: the factors ride in the scalars of every L / R MSM
+    hipError_t e = hipMemcpyAsync(st->hscale_buf, h_scale, 32 * n, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) rc = fail(ctx, BPMI_E_HIP, std::string("ipa_create_scaled: ") + hipGetErrorString(e));
+    else st->hscale = st->hscale_buf;
+  }
+  if (rc) { bpmi_ipa_destroy(st); *out = nullptr; }
+  return rc;
+}
 uint64_t bpmi_ipa_len(const bpmi_ipa *st) { return st ? st->n : 0; }
 
 int bpmi_ipa_round_LR(bpmi_ipa *st, uint8_t L[64], uint8_t R[64]) {
@@ -475,7 +500,7 @@ int bpmi_ipa_round_LR(bpmi_ipa *st, uint8_t L[64], uint8_t R[64]) {
   sc_dot_dev_to(ctx, a_lo, b_hi, np, st->cl, st->partial);
   sc_dot_dev_to(ctx, a_hi, b_lo, np, st->cr, st->partial);
   int rc;
-  if (st->d == 0) {
+  if (st->d == 0 && !st->hscale) {
     // bases are the current generators: L = <a_lo, g_hi> + <b_hi, h_lo> + cl*u  (:98) as ONE
     // three-segment MSM, R = <a_hi, g_lo> + <b_lo, h_hi> + cr*u  (:99)
     u32 *g_lo = st->g, *g_hi = st->g + 16 * np, *h_lo = st->h, *h_hi = st->h + 16 * np;
@@ -502,7 +527,7 @@ int bpmi_ipa_round_LR(bpmi_ipa *st, uint8_t L[64], uint8_t R[64]) {
       {
         StageTimer t(ctx, ST_SCFOLD);
         hipLaunchKernelGGL(k_ipa_expand, dim3((u32)((st->M + 255) / 256)), dim3(256), 0, ctx->stream, st->a, st->b,
-                           st->cg[st->cur], st->ch[st->cur], (u32)st->M, logm, right, eg, eh);
+                           st->cg[st->cur], st->ch[st->cur], st->hscale, (u32)st->M, logm, right, eg, eh);
       }
       // only the non-zero half of every block of m logical positions takes part: for L the
       // upper g-halves and lower h-halves (g_hi with a_lo, h_lo with b_hi), for R the opposite

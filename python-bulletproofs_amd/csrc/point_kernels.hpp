@@ -145,7 +145,7 @@ __global__ void __launch_bounds__(256) k_ipa_coef_update(const u32 *cg, const u3
 // scalars of the L (right = 0) or R (right = 1) MSM over the unfolded bases:
 //   L = <a_lo, g_hi> + <b_hi, h_lo>,  R = <a_hi, g_lo> + <b_lo, h_hi>   (:98-99)
 __global__ void __launch_bounds__(256) k_ipa_expand(const u32 *__restrict__ a, const u32 *__restrict__ b, const u32 *__restrict__ cg,
-                                                    const u32 *__restrict__ ch, u32 M, u32 logm, int right,
+                                                    const u32 *__restrict__ ch, const u32 *__restrict__ hscale, u32 M, u32 logm, int right,
                                                     u32 *__restrict__ eg, u32 *__restrict__ eh) {
   const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= M) return;
@@ -168,6 +168,10 @@ __global__ void __launch_bounds__(256) k_ipa_expand(const u32 *__restrict__ a, c
     load_words8(bv.v, b + 8ull * (right ? i - half : half + i));
     load_words8(c.v, ch + 8ull * t);
     sc_mul(rh, bv, c);
+    if (hscale) {                       // the h generators are hscale[k] * H[k] (never materialised)
+      load_words8(c.v, hscale + 8ull * k);
+      sc_mul(rh, rh, c);
+    }
   }
   store_words8(eg + 8ull * k, rg.v);
   store_words8(eh + 8ull * k, rh.v);

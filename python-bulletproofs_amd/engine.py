@@ -133,9 +133,12 @@ class Engine:
         return out.raw
 
     # ---- IPA prover state ----
-    def ipa_create(self, g, h, a, b, n, u):
+    def ipa_create(self, g, h, a, b, n, u, h_scale=None):
         st = ctypes.c_void_p()
-        self._ck(self.lib.bpmi_ipa_create(self.ctx, g, h, a, b, n, u, ctypes.byref(st)))
+        if h_scale is None:
+            self._ck(self.lib.bpmi_ipa_create(self.ctx, g, h, a, b, n, u, ctypes.byref(st)))
+        else:
+            self._ck(self.lib.bpmi_ipa_create_scaled(self.ctx, g, h, a, b, n, u, h_scale, ctypes.byref(st)))
         return IpaState(self, st.value)
 
     def ipa_create_dev(self, d_g, d_h, d_a, d_b, n, u):

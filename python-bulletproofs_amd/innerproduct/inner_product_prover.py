@@ -7,6 +7,7 @@ from typing import Optional
 
 from .. import engine as _engine
 from ..ec import Point, pack_points, pack_scalars
+from ..pippenger import PipSECP256k1
 from ..utils.transcript import Transcript
 from ..utils.utils import ModP
 from .inner_product_verifier import Proof1, Proof2
@@ -15,26 +16,31 @@ from .inner_product_verifier import Proof1, Proof2
 class NIProver:
     """Protocol 1 -> Protocol 2 reduction (reference :11-45)."""
 
-    def __init__(self, g, h, u, P, c, a, b, group, seed=b""):
+    def __init__(self, g, h, u, P, c, a, b, group, seed=b"", h_scale=None):
+        """h_scale (extension, not in the reference): integers c_i; the argument then runs
+        over the generators c_i * h[i] without materialising them (see Verifier2)."""
         assert len(g) == len(h) == len(a) == len(b)
         self.g, self.h, self.u, self.P, self.c, self.a, self.b = g, h, u, P, c, a, b
         self.group = group
+        self.h_scale = h_scale
         self.transcript = Transcript(seed)
 
     def prove(self) -> Proof1:
         x = self.transcript.get_modp(self.group.q)
         self.transcript.add_number(x)
-        P_new = self.P + (x * self.c) * self.u
+        P_new = PipSECP256k1.multiexp([self.P, self.u], [1, x * self.c])
         u_new = x * self.u
-        inner = FastNIProver2(self.g, self.h, u_new, P_new, self.a, self.b, self.group, self.transcript.digest)
+        inner = FastNIProver2(self.g, self.h, u_new, P_new, self.a, self.b, self.group, self.transcript.digest,
+                              h_scale=self.h_scale)
         return Proof1(u_new, P_new, inner.prove(), self.transcript.digest)
 
 
 class FastNIProver2:
     """Protocol 2 prover (reference :48-110)."""
 
-    def __init__(self, g, h, u, P, a, b, group, transcript: Optional[bytes] = None):
+    def __init__(self, g, h, u, P, a, b, group, transcript: Optional[bytes] = None, h_scale=None):
         assert len(g) == len(h) == len(a) == len(b)
+        self.h_scale = h_scale
         assert len(a) & (len(a) - 1) == 0
         self.n = len(a)
         self.log_n = self.n.bit_length() - 1
@@ -50,7 +56,8 @@ class FastNIProver2:
         q = self.group.q
         eng = _engine.default_engine()
         state = eng.ipa_create(pack_points(self.g), pack_points(self.h), pack_scalars(self.a, q),
-                               pack_scalars(self.b, q), self.n, self.u.to_le64())
+                               pack_scalars(self.b, q), self.n, self.u.to_le64(),
+                               None if self.h_scale is None else pack_scalars(self.h_scale, q))
         xs, Ls, Rs = [], [], []
         try:
             while len(state) > 1:

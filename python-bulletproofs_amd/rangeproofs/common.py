@@ -111,13 +111,14 @@ def prove(vs, n, g, h, gs, hs, gammas, u, group, seed, aggregated):
         blind = z * z * gammas.x
     taux = (tau2 * x * x + tau1 * x + blind) % q
     mu = (alpha + rho * x) % q
-    hsp = scaled_generators(hs, yM)
-    # P - mu*h = A + x*S + sum(-z)*gs + sum(z*y^i + zt_i)*hsp - mu*h, one MSM
+    # hsp[i] = y^-i * hs[i] (:77) is never materialised: y^-i goes into the scalars, both in
+    # P - mu*h = A + x*S + sum(-z)*gs + sum(z*y^i + zt_i)*hsp - mu*h (one MSM) and in the IPA
+    yscale = _powers(pow(y, -1, q), nm, q)
     P_inner = PipSECP256k1.multiexp(
-        gs + hsp + [A, S, h],
-        [-z] * nm + [z * ypow[i] + zt[i] for i in range(nm)] + [1, x, -mu],
+        gs + hs + [A, S, h],
+        [-z] * nm + [(z * ypow[i] + zt[i]) * yscale[i] % q for i in range(nm)] + [1, x, -mu],
     )
-    inner = NIProver(gs, hsp, u, P_inner, ModP(t_hat, q), ls, rs, group).prove()
+    inner = NIProver(gs, hs, u, P_inner, ModP(t_hat, q), ls, rs, group, h_scale=yscale).prove()
     return Proof(ModP(taux, q), ModP(mu, q), ModP(t_hat, q), T1, T2, A, S, inner, tr.digest)
 
 

@@ -165,3 +165,34 @@ def test_ipa_full_size_round_trip(gp):
             Verifier2(g, h, u, P, bad).verify()
     with pytest.raises(Exception, match="Proof invalid"):
         Verifier2(g, h, u, P + u, proof).verify()
+
+
+@pytest.mark.parametrize("n,big_m", [(1, 0), (2, 0), (256, 0), (1024, 256), (2048, 2048)])
+def test_ipa_scaled_generators(gp, n, big_m):
+    """bpmi_ipa_create_scaled: the argument over c_i * h[i] must equal the plain argument over
+    the materialised points, in both regimes (factors in the MSM scalars / one batched
+    multiplication for bases that get folded)."""
+    eng = gp.engine()
+    eng.set_option("ipa_big_m", big_m)
+    pts, _ = gp.rand_points(2 * n + 1, 70 + n)
+    g, h, u = pts[:n], pts[n:2 * n], pts[2 * n]
+    rnd = random.Random(n + 1)
+    a = [rnd.randrange(Q) for _ in range(n)]
+    b = [rnd.randrange(Q) for _ in range(n)]
+    scale = [rnd.randrange(1, Q) for _ in range(n)]
+    scale[0] = 1
+    hs = cbind.ec_mul_batch(h, scale)
+    st = eng.ipa_create(cbind.pack_points(g), cbind.pack_points(h), cbind.pack_scalars(a), cbind.pack_scalars(b), n,
+                        cbind.pack_points([u]), cbind.pack_scalars(scale))
+    ref = eng.ipa_create(cbind.pack_points(g), cbind.pack_points(hs), cbind.pack_scalars(a), cbind.pack_scalars(b), n,
+                         cbind.pack_points([u]))
+    while len(st) > 1:
+        assert st.round_LR() == ref.round_LR()
+        x = rnd.randrange(1, Q)
+        xi = pow(x, -1, Q)
+        st.fold(x, xi)
+        ref.fold(x, xi)
+    assert st.finish() == ref.finish()
+    st.close()
+    ref.close()
+    eng.set_option("ipa_big_m", 0)
