@@ -5,7 +5,7 @@
 // by the signed-digit bucket method; the result -- a canonical affine point -- is
 // schedule independent, so it is bit-identical to the reference's subset-table schedule):
 //   sort            (window, bucket) counting sort of (point index, sign):
-//                   n >= 2^13: k_coarse_hist / k_partition / k_fine_hist / k_fine_scatter --
+//                   n >= 2^16 (window bits >= 10): k_coarse_hist / k_partition / k_fine_hist / k_fine_scatter --
 //                   a two-level radix partition whose histograms and ranks live in LDS
 //                   (global atomics only reserve one range per tile and bin);
 //                   smaller n: k_digits_hist / k_scatter with global atomics
@@ -16,9 +16,13 @@
 //   k_segscan       block-wide segmented scan over partial records, 256 -> 2 per block,
 //                   repeated until one block is left
 //   k_bucket_digit_sums / k_weighted31   sum_b b*B[w][b] as base-32 digit sums + a
-//                   31-term suffix scan per (window, digit position)
+//                   31-term suffix scan per (window, digit position);
+//                   k_window_weighted_small for windows of <= 256 buckets
 //   tail            O(256) sequential doublings: window combine + to-affine
-//                   (device kernel or host thread, same formulas)
+//                   (host thread on 4x64-bit limbs, host_tail.hpp, or the one-lane device
+//                   kernel k_tail; same Horner chain)
+// This file: the C-ABI entry points and the IPA state object (deferred generator folding).
+// Kernels and host orchestration live in the *.hpp files included below (one translation unit).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
