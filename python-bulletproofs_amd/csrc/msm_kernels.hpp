@@ -438,6 +438,10 @@ __global__ void __launch_bounds__(256, 4) k_bucket_digit_sums(MsmGeom g, const u
   u32 last_cnt = 0;
   if (base_last <= g.B) { const u64 r = (u64)g.B - base_last + 1u; last_cnt = r < (1ull << sh) ? (u32)r : (1u << sh); }
   const u32 ecount = (hi_max << sh) + last_cnt;
+  if (ecount == 0) {                      // e.g. the top digit position, where only d = 1 occurs
+    if (threadIdx.x == 0) xyzz_store_g(D + (u64)blk * XYZZ_WORDS, acc);
+    return;
+  }
   for (u32 e = threadIdx.x; e < ecount; e += blockDim.x) {
     const u32 lo = e & ((1u << sh) - 1u), hi = e >> sh;
     const u64 b = ((u64)hi << (sh + 5u)) | ((u64)d << sh) | lo;
