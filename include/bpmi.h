@@ -144,6 +144,11 @@ uint64_t bpmi_ipa_len(const bpmi_ipa *st);
 int bpmi_ipa_round_LR(bpmi_ipa *st, uint8_t L[64], uint8_t R[64]);
 int bpmi_ipa_fold(bpmi_ipa *st, const uint8_t x[32], const uint8_t xinv[32]);
 int bpmi_ipa_finish(bpmi_ipa *st, uint8_t a[32], uint8_t b[32]);
+/* The CURRENT (folded) g, h (len points each) and a, b (len scalars each), len = bpmi_ipa_len:
+ * what the reference holds in gp, hp, ap, bp at the top of its loop (:84).  With folds
+ * deferred, every generator costs one MSM, so this is meant for short states (len <= 64):
+ * a prover sharded over GPUs hands its last element to the other ranks through it. */
+int bpmi_ipa_export(bpmi_ipa *st, uint8_t *g, uint8_t *h, uint8_t *a, uint8_t *b);
 void bpmi_ipa_destroy(bpmi_ipa *st);
 
 /* ---- per-stage device timing (HIP events on the ctx's stream) --------------------------

@@ -40,6 +40,7 @@ SIGNATURES = {
     "bpmi_ipa_round_LR": (_i, [_vp, _cp, _cp]),
     "bpmi_ipa_fold": (_i, [_vp, _cp, _cp]),
     "bpmi_ipa_finish": (_i, [_vp, _cp, _cp]),
+    "bpmi_ipa_export": (_i, [_vp, _cp, _cp, _cp, _cp]),
     "bpmi_ipa_destroy": (None, [_vp]),
     "bpmi_profile": (_i, [_vp, _i]),
     "bpmi_profile_reset": (_i, [_vp]),

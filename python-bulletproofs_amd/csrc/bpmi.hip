@@ -636,6 +636,41 @@ int bpmi_ipa_finish(bpmi_ipa *st, uint8_t a[32], uint8_t b[32]) {
   return BPMI_OK;
 }
 
+#define IPA_EXPORT_MAX 64
+int bpmi_ipa_export(bpmi_ipa *st, uint8_t *g, uint8_t *h, uint8_t *a, uint8_t *b) {
+  if (!st || !g || !h || !a || !b) return BPMI_E_ARG;
+  bpmi_ctx *ctx = st->ctx;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const uint64_t m = st->n;
+  HIPCHK(ctx, hipMemcpyAsync(a, st->a, 32 * m, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(b, st->b, 32 * m, hipMemcpyDeviceToHost, ctx->stream));
+  if (st->d == 0 && !st->hscale) {
+    // the bases are the current generators
+    HIPCHK(ctx, hipMemcpyAsync(g, st->g, 64 * m, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(h, st->h, 64 * m, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return BPMI_OK;
+  }
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (m > IPA_EXPORT_MAX) return fail(ctx, BPMI_E_STATE, "ipa export with deferred folds needs a current length <= 64");
+  // deferred folds: every current generator is one MSM over the unfolded bases
+  u32 logm = 0;
+  while ((1ull << logm) < m) logm++;
+  for (u32 pos = 0; pos < (u32)m; pos++) {
+    {
+      StageTimer t(ctx, ST_SCFOLD);
+      hipLaunchKernelGGL(k_ipa_export_scalars, dim3((u32)((st->M + 255) / 256)), dim3(256), 0, ctx->stream, st->cg[st->cur],
+                         st->ch[st->cur], st->hscale, (u32)st->M, logm, pos, st->eg, st->eh);
+    }
+    Segs sg = segs_init(), sh = segs_init();
+    sg.pts[0] = st->g; sg.sc[0] = st->eg; sg.n[0] = (u32)st->M; sg.total = (u32)st->M;
+    sh.pts[0] = st->h; sh.sc[0] = st->eh; sh.n[0] = (u32)st->M; sh.total = (u32)st->M;
+    int rc = msm_run_pair(ctx, sg, g + 64 * pos, sh, h + 64 * pos);
+    if (rc) return rc;
+  }
+  return BPMI_OK;
+}
+
 void bpmi_ipa_destroy(bpmi_ipa *st) {
   if (!st) return;
   (void)hipSetDevice(st->ctx->device);

@@ -176,6 +176,29 @@ __global__ void __launch_bounds__(256) k_ipa_expand(const u32 *__restrict__ a, c
   store_words8(eg + 8ull * k, rg.v);
   store_words8(eh + 8ull * k, rh.v);
 }
+// scalars that pick the current (folded) generator number `pos` out of the unfolded bases:
+//   g'[pos] = sum_t cg[t] * G[pos + t*m],  h'[pos] = sum_t ch[t] * hscale[.] * H[pos + t*m]
+__global__ void __launch_bounds__(256) k_ipa_export_scalars(const u32 *__restrict__ cg, const u32 *__restrict__ ch,
+                                                            const u32 *__restrict__ hscale, u32 M, u32 logm, u32 pos,
+                                                            u32 *__restrict__ eg, u32 *__restrict__ eh) {
+  const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= M) return;
+  const u32 i = k & ((1u << logm) - 1u), t = k >> logm;
+  sc rg, rh;
+#pragma unroll
+  for (int q = 0; q < 8; q++) rg.v[q] = rh.v[q] = 0;
+  if (i == pos) {
+    load_words8(rg.v, cg + 8ull * t);
+    load_words8(rh.v, ch + 8ull * t);
+    if (hscale) {
+      sc c;
+      load_words8(c.v, hscale + 8ull * k);
+      sc_mul(rh, rh, c);
+    }
+  }
+  store_words8(eg + 8ull * k, rg.v);
+  store_words8(eh + 8ull * k, rh.v);
+}
 // materialise 2^d-way folded generators: out[i] = sum_t coef[t] * G[i + t*m], i < m, as an
 // interleaved NAF ladder (shared scalars -> wave-uniform branches); two jobs (g and h) per launch
 #define MULTIFOLD_MAXK 16

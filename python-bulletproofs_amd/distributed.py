@@ -1,5 +1,6 @@
-"""Sharded MSM across the GPUs of one node: one process per GPU, torch.distributed
-(backend "nccl" = RCCL over xGMI; "gloo" in the CPU tests).
+"""Sharded MSM, sharded inner-product prover and sharded verdicts across the GPUs of one
+node: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI; "gloo" in
+the CPU tests).
 
 The MSM sum_i e_i * P_i is a sum over independent pairs, so it shards with no data-path
 exchange: every rank runs the full single-GPU MSM on its own contiguous shard and
@@ -79,3 +80,94 @@ def shard_verdicts(verify_one, items, group=None):
     parts = all_gather_bytes(bytes(mine), group)
     flat = b"".join(parts)
     return [bool(flat[i]) for i in range(len(items))]
+
+
+def cyclic_shard(seq, world, rank):
+    """Element i lives on rank i mod world: i and i + n/2 are then
+    on the same rank in every halving round while the local length is >= 2, and the folded
+    vector is again cyclic, so the inner-product argument never moves data between rounds."""
+    return seq[rank::world]
+
+
+class ShardedFastNIProver2:
+    """FastNIProver2 (reference src/innerproduct/inner_product_prover.py:48-110) with g, h, a, b
+    distributed cyclically over the ranks: every constructor vector is THIS rank's
+    cyclic_shard of the global one; u, P and the transcript are the same on all ranks.
+
+    Per round each rank computes the L and R of its own shard (the cl * u / cr * u terms are
+    linear in the shard too), ONE all_gather moves 128 bytes per rank, every rank folds the
+    partials with bpmi_ec_sum, hashes the same transcript and folds its shard with the same
+    challenge.  When one element per rank is left the ranks exchange it (bpmi_ipa_export,
+    192 bytes each) and all finish the last log2(world) rounds redundantly.  The Proof2 is
+    bit-identical to the single-GPU prover's."""
+
+    def __init__(self, g, h, u, P, a, b, group, transcript=None, h_scale=None, engine=None, process_group=None, state=None):
+        """state: an already device-resident IpaState over this rank's shard (engine.ipa_create_dev);
+        g, h, a, b are then ignored."""
+        from .utils.transcript import Transcript
+        if state is None:
+            assert len(g) == len(h) == len(a) == len(b)
+            assert len(a) & (len(a) - 1) == 0
+        self.state = state
+        self.g, self.h, self.u, self.P, self.a, self.b, self.group = g, h, u, P, a, b, group
+        self.h_scale = h_scale
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        assert self.world & (self.world - 1) == 0, "the cyclic layout needs a power-of-two number of ranks"
+        if engine is None:
+            from .engine import default_engine
+            engine = default_engine()
+        self.engine = engine
+        self.transcript = Transcript()
+        if transcript:
+            self.transcript.digest += transcript
+            self.init_transcript_length = len(transcript.split(b"&"))
+        else:
+            self.init_transcript_length = 1
+
+    def _rounds(self, state, xs, Ls, Rs, gather):
+        from .ec import Point
+        q = self.group.q
+        while len(state) > 1:
+            Lb, Rb = state.round_LR()
+            if gather:
+                parts = all_gather_bytes(Lb + Rb, self.pg)
+                k = len(parts)
+                Lb = self.engine.ec_sum_bytes(b"".join(p[:64] for p in parts), k)
+                Rb = self.engine.ec_sum_bytes(b"".join(p[64:] for p in parts), k)
+            L, R = Point.from_le64(Lb), Point.from_le64(Rb)
+            Ls.append(L)
+            Rs.append(R)
+            self.transcript.add_list_points([L, R])
+            x = self.transcript.get_modp(q)
+            xs.append(x)
+            self.transcript.add_number(x)
+            state.fold(x.x, x.inv().x)
+
+    def prove(self):
+        from .ec import pack_points, pack_scalars
+        from .innerproduct.inner_product_verifier import Proof2
+        from .utils.utils import ModP
+        q = self.group.q
+        eng = self.engine
+        ub = self.u.to_le64()
+        state = self.state
+        if state is None:
+            state = eng.ipa_create(pack_points(self.g), pack_points(self.h), pack_scalars(self.a, q),
+                                   pack_scalars(self.b, q), len(self.a), ub,
+                                   None if self.h_scale is None else pack_scalars(self.h_scale, q))
+        xs, Ls, Rs = [], [], []
+        try:
+            self._rounds(state, xs, Ls, Rs, gather=self.world > 1)
+            if self.world > 1:
+                g1, h1, a1, b1 = state.export()           # this rank's last element = global index `rank`
+                state.close()
+                parts = all_gather_bytes(g1 + h1 + a1 + b1, self.pg)
+                state = eng.ipa_create(b"".join(p[:64] for p in parts), b"".join(p[64:128] for p in parts),
+                                       b"".join(p[128:160] for p in parts), b"".join(p[160:192] for p in parts),
+                                       self.world, ub)
+                self._rounds(state, xs, Ls, Rs, gather=False)
+            a, b = state.finish()
+        finally:
+            state.close()
+        return Proof2(ModP(a, q), ModP(b, q), xs, Ls, Rs, self.transcript.digest, self.init_transcript_length)

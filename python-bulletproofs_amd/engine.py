@@ -56,7 +56,7 @@ class Engine:
     def __init__(self, device=None, stream=None):
         self.lib = _native.load()
         if device is None:
-            device = int(os.environ.get("LOCAL_RANK", "0")) if self.lib.bpmi_device_count() > 1 else 0
+            device = int(os.environ.get("LOCAL_RANK", "0")) % max(self.lib.bpmi_device_count(), 1)
         self.device = device
         self.ctx = self.lib.bpmi_ctx_create(device, stream)
         if not self.ctx:
@@ -184,6 +184,14 @@ class IpaState:
         b = ctypes.create_string_buffer(32)
         self.engine._ck(self.engine.lib.bpmi_ipa_finish(self.handle, a, b))
         return int.from_bytes(a.raw, "little"), int.from_bytes(b.raw, "little")
+
+    def export(self):
+        """(g, h, a, b) of the current round as packed bytes: len(self) points / scalars each."""
+        m = len(self)
+        g, h = ctypes.create_string_buffer(64 * m), ctypes.create_string_buffer(64 * m)
+        a, b = ctypes.create_string_buffer(32 * m), ctypes.create_string_buffer(32 * m)
+        self.engine._ck(self.engine.lib.bpmi_ipa_export(self.handle, g, h, a, b))
+        return g.raw, h.raw, a.raw, b.raw
 
     def close(self):
         if self.handle:

@@ -53,9 +53,65 @@ def batch_mode():
     dist.destroy_process_group()
 
 
+def ipa_mode(use_gpu):
+    """Sharded FastNIProver2 against the oracle's single-process restatement: cyclic shards,
+    one 128-byte all_gather per round, bit-identical Proof2 on every rank."""
+    from oracle import bp_ref
+    from bulletproofs_amd.distributed import ShardedFastNIProver2, cyclic_shard
+    from bulletproofs_amd.ec import Point as NPoint
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    Q = secp256k1.q
+    if use_gpu:
+        from bulletproofs_amd.engine import default_engine
+        eng = default_engine()
+        sizes = [(2, None), (64, None), (256, 7), (4096, None)]
+    else:
+        from oracle_engine import OracleEngine
+        eng = OracleEngine()
+        sizes = [(2, None), (4, 5), (32, None)]
+    rnd = random.Random(4242)
+    for n, hs_seed in sizes:
+        ks = [rnd.randrange(1, Q) for _ in range(2 * n + 1)]
+        pts = cbind.ec_mul_batch([secp256k1.G] * (2 * n + 1), ks)
+        g, h, u = pts[:n], pts[n:2 * n], pts[2 * n]
+        a = [rnd.randrange(Q) for _ in range(n)]
+        b = [rnd.randrange(Q) for _ in range(n)]
+        hsc = None if hs_seed is None else [pow(hs_seed, i, Q) for i in range(n)]
+        start = b"c2VlZA==&12345&"
+        conv = lambda ps: [NPoint.from_le64(point_to_le64(p)) for p in ps]
+        grp = type("G", (), {"q": Q})()
+        pr = ShardedFastNIProver2(cyclic_shard(conv(g), world, rank), cyclic_shard(conv(h), world, rank), conv([u])[0], None,
+                                  cyclic_shard(a, world, rank), cyclic_shard(b, world, rank), grp, start,
+                                  None if hsc is None else cyclic_shard(hsc, world, rank), engine=eng).prove()
+        if n <= 256:
+            hh = h if hsc is None else cbind.ec_mul_batch(h, hsc)
+            want = bp_ref.ipa2_prove(g, hh, u, None, [bp_ref.ModP(x, Q) for x in a], [bp_ref.ModP(x, Q) for x in b], Q, start,
+                                     multiexp=cbind.msm)
+            want_L = [(p.x, p.y) for p in want.Ls]
+            want_R = [(p.x, p.y) for p in want.Rs]
+            want_t = (want.a.x, want.b.x, [x.x for x in want.xs], want.transcript, want.start_transcript)
+        else:
+            from bulletproofs_amd.innerproduct import FastNIProver2
+            one = FastNIProver2(conv(g), conv(h), conv([u])[0], None, a, b, grp, start, hsc).prove()
+            want_L = [(p.x, p.y) for p in one.Ls]
+            want_R = [(p.x, p.y) for p in one.Rs]
+            want_t = (one.a.x, one.b.x, [x.x for x in one.xs], one.transcript, one.start_transcript)
+        assert [(p.x, p.y) for p in pr.Ls] == want_L, (rank, n)
+        assert [(p.x, p.y) for p in pr.Rs] == want_R, (rank, n)
+        assert (pr.a.x, pr.b.x, [x.x for x in pr.xs], pr.transcript, pr.start_transcript) == want_t, (rank, n)
+    dist.barrier()
+    if rank == 0:
+        print("DIST_IPA_OK world=%d" % world)
+    dist.destroy_process_group()
+
+
 def main():
-    if os.environ.get("BPMI_DIST_MODE") == "batch":
+    mode = os.environ.get("BPMI_DIST_MODE")
+    if mode == "batch":
         return batch_mode()
+    if mode in ("ipa", "ipa_gpu"):
+        return ipa_mode(mode == "ipa_gpu")
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     Q = secp256k1.q

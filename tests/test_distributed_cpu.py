@@ -27,3 +27,13 @@ def test_two_rank_gloo_sharded_msm():
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert "DIST_OK world=2" in r.stdout
+
+
+def test_two_rank_gloo_sharded_ipa_prover():
+    """ShardedFastNIProver2 on cyclic shards == the oracle's single-process FastNIProver2."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", BPMI_DIST_MODE="ipa")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29513", os.path.join(REPO, "tests", "dist_worker.py")]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "DIST_IPA_OK world=2" in r.stdout

@@ -131,6 +131,8 @@ def test_ipa_rounds_vs_oracle(gp, n, big_m):
         h = cbind.ec_lincomb2_batch(h[:half], h[half:], x, xi)
         a = cbind.sc_fold(a[:half], a[half:], x, xi)
         b = cbind.sc_fold(b[:half], b[half:], xi, x)
+        if half <= 8:      # bpmi_ipa_export: the folded generators the reference holds at :84
+            assert st.export() == (cbind.pack_points(g), cbind.pack_points(h), cbind.pack_scalars(a), cbind.pack_scalars(b))
     assert st.finish() == (a[0], b[0])
     st.close()
     eng.set_option("ipa_big_m", 0)
@@ -192,7 +194,40 @@ def test_ipa_scaled_generators(gp, n, big_m):
         xi = pow(x, -1, Q)
         st.fold(x, xi)
         ref.fold(x, xi)
+        if len(st) <= 4:
+            assert st.export() == ref.export()
+    if n == 1:
+        assert st.export() == ref.export()
     assert st.finish() == ref.finish()
     st.close()
     ref.close()
     eng.set_option("ipa_big_m", 0)
+
+
+def test_ipa_export_too_long_is_a_state_error(gp):
+    eng = gp.engine()
+    n = 256
+    pts, _ = gp.rand_points(2 * n + 1, 5)
+    st = eng.ipa_create(cbind.pack_points(pts[:n]), cbind.pack_points(pts[n:2 * n]), cbind.pack_scalars([1] * n),
+                        cbind.pack_scalars([2] * n), n, cbind.pack_points([pts[2 * n]]))
+    assert len(st.export()[0]) == 64 * n          # nothing folded yet: plain copies
+    st.round_LR()
+    st.fold(3, pow(3, -1, Q))
+    with pytest.raises(RuntimeError, match="export"):
+        st.export()                               # 128 deferred generators: refused, not computed
+    st.close()
+
+
+def test_two_rank_sharded_ipa_prover_on_one_gpu():
+    """ShardedFastNIProver2: two processes (gloo rendezvous, both on cuda:0, each with its own
+    bpmi ctx) prove over cyclic shards; the Proof2 equals the oracle's / the one-GPU prover's."""
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", BPMI_DIST_MODE="ipa_gpu")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29517", os.path.join(repo, "tests", "dist_worker.py")]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "DIST_IPA_OK world=2" in r.stdout
