@@ -63,7 +63,8 @@ static void msm_layout(const MsmGeom &g, MsmWs &w, char *base) {
 
 // Enqueue every GPU stage of one MSM on `lane` (0 = the ctx stream, 1 = the second lane),
 // including the device->pinned-host copy the tail needs; returns without synchronising.
-static int msm_enqueue(bpmi_ctx *ctx, int lane, const Segs &segs) {
+//   [w0, w0 + wcount): the windows this call handles (wcount = 0: all of them)
+static int msm_enqueue(bpmi_ctx *ctx, int lane, const Segs &segs, u32 w0 = 0, u32 wcount = 0) {
   const uint64_t n = segs.total;
   bpmi_ctx::PendingMsm &pd = ctx->pend[lane];
   pd.active = false;
@@ -72,7 +73,8 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, const Segs &segs) {
   MsmGeom g;
   g.n = (u32)n;
   g.c = pick_window_bits(ctx, n);
-  g.W = 255u / g.c + 1u;
+  g.W = wcount ? wcount : 255u / g.c + 1u;
+  g.w0 = w0;
   g.B = 1u << (g.c - 1);
   g.G = g.W * g.B;
   g.L = ctx->opt_chunk > 0 ? (u32)ctx->opt_chunk : (n >= (1u << 19) ? 64u : (n >= (1u << 16) ? 32u : 16u));   // tools/tune_msm.py sweeps
@@ -180,7 +182,7 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, const Segs &segs) {
   debug_sync(ctx, "ST_BREDUCE", st);
   {
     StageTimer t(ctx, ST_TAIL, st);
-    const int tail = ctx->opt_tail ? ctx->opt_tail : 2;
+    const int tail = wcount ? 2 : (ctx->opt_tail ? ctx->opt_tail : 2);      // window groups are combined on the host
     if (tail == 1) {
       hipLaunchKernelGGL(k_tail, dim3(1), dim3(64), 0, st, w.E, g.W, g.nv, g.c, w.out);
       rc = ensure_pin_lane(ctx, lane, 4096);
@@ -213,8 +215,34 @@ static int msm_finish(bpmi_ctx *ctx, int lane, uint8_t out[64]) {
   debug_sync(ctx, "ST_TAIL", st);
   return BPMI_OK;
 }
+// One MSM as two window groups, one per lane (option "split").  Measured on MI355X
+// (tools/try_split.py): the lanes' kernels barely overlap -- every stage is bound by the
+// same ALUs or by LDS atomics in blocks that cannot co-reside with the accumulation's --
+// so the gain is the kernels' tails only (+5 % at n = 2^20, -8 % at 2^19); off by default.
+static int msm_run_split(bpmi_ctx *ctx, const Segs &segs, uint8_t out[64]) {
+  const u32 c = pick_window_bits(ctx, segs.total), W = 255u / c + 1u, Wa = W / 2;
+  int rc = ensure_lane(ctx, 1);
+  if (rc) return rc;
+  HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+  HIPCHK(ctx, hipStreamWaitEvent(ctx->stream1, ctx->ev_fork, 0));
+  rc = msm_enqueue(ctx, 0, segs, 0, Wa);
+  if (rc) return rc;
+  rc = msm_enqueue(ctx, 1, segs, Wa, W - Wa);
+  if (rc) return rc;
+  bpmi_ctx::PendingMsm &p0 = ctx->pend[0], &p1 = ctx->pend[1];
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream1));
+  const size_t b0 = 4ull * XYZZ_WORDS * p0.W * p0.nv, b1 = 4ull * XYZZ_WORDS * p1.W * p1.nv;
+  std::vector<u32> E((b0 + b1) / 4);
+  memcpy(E.data(), ctx->pin, b0);
+  memcpy((char *)E.data() + b0, ctx->pin1, b1);
+  bpmi_host::tail_combine(out, E.data(), W, p0.nv, c);
+  p0.active = p1.active = false;
+  return BPMI_OK;
+}
 static int msm_run(bpmi_ctx *ctx, const Segs &segs, uint8_t out[64]) {
   if (segs.total > BPMI_MAX_N) return fail(ctx, BPMI_E_ARG, "n exceeds BPMI_MAX_N");
+  if (ctx->opt_split == 1 && segs.total >= 2) return msm_run_split(ctx, segs, out);
   int rc = msm_enqueue(ctx, 0, segs);
   if (rc) return rc;
   return msm_finish(ctx, 0, out);

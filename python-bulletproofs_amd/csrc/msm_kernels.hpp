@@ -8,7 +8,8 @@
 struct MsmGeom {
   u32 n;       // pairs
   u32 c;       // window bits
-  u32 W;       // windows
+  u32 W;       // windows handled by this launch sequence: [w0, w0 + W) of the recoding
+  u32 w0;      // first window (> 0 when one MSM is split into window groups on two lanes)
   u32 B;       // buckets per window = 2^(c-1)
   u32 G;       // W * B
   u32 L;       // entries per thread in k_accum_l0
@@ -28,7 +29,8 @@ __device__ __forceinline__ void for_each_digit(const Segs &segs, const MsmGeom &
   if (neg) sc_neg(s, s);
   u32 carry = 0;
   const u32 mask = (1u << g.c) - 1u;
-  for (u32 w = 0; w < g.W; w++) {
+  const u32 wend = g.w0 + g.W;
+  for (u32 w = 0; w < wend; w++) {
     const u32 t = (s.v[0] & mask) + carry;
     // shift the 256-bit register right by c (static register indexing)
 #pragma unroll
@@ -37,7 +39,7 @@ __device__ __forceinline__ void for_each_digit(const Segs &segs, const MsmGeom &
     u32 b, sign;
     if (t > g.B) { b = (1u << g.c) - t; sign = 1; carry = 1; }
     else { b = t; sign = 0; carry = 0; }
-    f(w, b, b ? (sign ^ (u32)neg) : 0u);
+    if (w >= g.w0) f(w - g.w0, b, b ? (sign ^ (u32)neg) : 0u);      // lower windows only feed the carry
   }
 }
 

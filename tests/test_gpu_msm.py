@@ -104,10 +104,13 @@ def test_msm_multiblock_segscan(gp, n, chunk, c):
         for tail in (1, 2):
             eng.set_option("tail", tail)
             assert eng.msm_bytes(pb, sb, n) == cbind.msm_bytes(pb, sb, n)
+        eng.set_option("split", 1)           # two window groups on two lanes (carry crosses the groups)
+        assert eng.msm_bytes(pb, sb, n) == cbind.msm_bytes(pb, sb, n)
     finally:
         eng.set_option("chunk", 0)
         eng.set_option("window_bits", 0)
         eng.set_option("tail", 0)
+        eng.set_option("split", 0)
 
 
 @pytest.mark.parametrize("logn", [16, 20])
@@ -137,6 +140,11 @@ def test_msm_full_size_properties(gp, logn):
     r_f = eng.msm_dev(d_pts, d_f, n)
     r_ef = eng.msm_dev(d_pts, d_ef, n)
     assert r_e == eng.msm_dev(d_pts, d_e, n)
+    eng.set_option("split", 1)
+    try:
+        assert r_e == eng.msm_dev(d_pts, d_e, n)
+    finally:
+        eng.set_option("split", 0)
     want = (sum(e * k for e, k in zip(es, ks)) % Q) * gp.G
     assert r_e == cbind.pack_points([want])
     assert eng.ec_sum_bytes(r_e + r_f, 2) == r_ef
