@@ -61,6 +61,7 @@ class BatchRangeVerifier:
         self.c_hs = [0] * self.n
         self._pts = []          # per-proof points, 64-byte strings
         self._scs = []          # matching scalars (ints mod q)
+        self._raw_pts, self._raw_scs, self._raw_count = [], [], 0     # merged states: already packed
         self.count = 0
 
     def _weight(self):
@@ -153,13 +154,87 @@ class BatchRangeVerifier:
         self._scs.extend(scs)
         self.count += 1
 
+    # ---- many proofs in wire format, host work spread over worker processes ---------------
+    def state(self):
+        """Everything add() has accumulated, as plain picklable data (see merge)."""
+        return (self.c_g, self.c_h, self.c_u, self._gs_const, self._hs_const, list(self.c_gs), list(self.c_hs),
+                b"".join(self._pts) + b"".join(self._raw_pts),
+                b"".join(_le32(v) for v in self._scs) + b"".join(self._raw_scs), len(self._scs) + self._raw_count, self.count)
+
+    def merge(self, st):
+        """Add another verifier's state() (same generators) to this one: the combination is
+        linear, so shards of a batch can be prepared anywhere and summed."""
+        c_g, c_h, c_u, gk, hk, c_gs, c_hs, pts, scs, nsc, count = st
+        assert len(c_gs) == self.n and len(pts) == 64 * nsc and len(scs) == 32 * nsc
+        self.c_g = (self.c_g + c_g) % Q
+        self.c_h = (self.c_h + c_h) % Q
+        self.c_u = (self.c_u + c_u) % Q
+        self._gs_const = (self._gs_const + gk) % Q
+        self._hs_const = (self._hs_const + hk) % Q
+        for i in range(self.n):
+            self.c_gs[i] += c_gs[i]
+            self.c_hs[i] += c_hs[i]
+        self._raw_pts.append(pts)
+        self._raw_scs.append(scs)
+        self._raw_count += nsc
+        self.count += count
+
+    def start_workers(self, workers):
+        """A pool of `workers` processes for add_wire (spawned, so they never inherit a GPU
+        context; they do integer and hash work only)."""
+        import multiprocessing as mp
+        from concurrent.futures import ProcessPoolExecutor
+        self.stop_workers()
+        gens = (self.g.to_le64(), self.h.to_le64(), self.u.to_le64(), b"".join(p.to_le64() for p in self.gs),
+                b"".join(p.to_le64() for p in self.hs))
+        self._pool = ProcessPoolExecutor(max_workers=workers, mp_context=mp.get_context("spawn"),
+                                         initializer=_worker_init, initargs=(gens,))
+        self._workers = workers
+        list(self._pool.map(_worker_ping, range(workers)))      # imports done before the first batch
+        return self
+
+    def stop_workers(self):
+        if getattr(self, "_pool", None) is not None:
+            self._pool.shutdown()
+        self._pool, self._workers = None, 0
+
+    def add_wire(self, Vs, blobs, decompress=None, chunk=256):
+        """Add len(blobs) single-value proofs given in wire format (codec.proof_to_bytes) with
+        their commitments Vs (Points).  All points of all proofs are decompressed in one GPU
+        launch; parsing, the transcript checks and the scalar algebra of add() run in the
+        worker pool (start_workers) when there is one, else in this process.
+        decompress(comp_bytes, n) -> (points_bytes, ok_flags): default the HIP engine's."""
+        from .codec import compressed_points
+        assert len(Vs) == len(blobs)
+        comp = [compressed_points(b) for b in blobs]
+        counts = [len(c) // 33 for c in comp]
+        dec = decompress or _engine.default_engine().ec_decompress_batch_bytes
+        pts, ok = dec(b"".join(comp), sum(counts))
+        if any(flag == 0 for flag in ok):
+            raise Exception("Proof invalid")
+        jobs, pos = [], 0
+        for lo in range(0, len(blobs), chunk):
+            hi = min(lo + chunk, len(blobs))
+            npts = sum(counts[lo:hi])
+            jobs.append((blobs[lo:hi], pts[64 * pos: 64 * (pos + npts)], b"".join(V.to_le64() for V in Vs[lo:hi])))
+            pos += npts
+        pool = getattr(self, "_pool", None)
+        if pool is None:
+            _worker_init((self.g.to_le64(), self.h.to_le64(), self.u.to_le64(), b"".join(p.to_le64() for p in self.gs),
+                          b"".join(p.to_le64() for p in self.hs)))
+            results = [_worker_add(*job) for job in jobs]
+        else:
+            results = list(pool.map(_worker_add, *zip(*jobs))) if jobs else []
+        for st in results:
+            self.merge(st)
+
     def partial(self):
         """The 64-byte value of this verifier's accumulated combination (one MSM)."""
         shared = [self.c_g, self.c_h, self.c_u] + [v + self._gs_const for v in self.c_gs] + \
             [v + self._hs_const for v in self.c_hs]
-        pts = self._shared_pts + b"".join(self._pts)
-        scs = b"".join(_le32(v) for v in shared) + b"".join(_le32(v) for v in self._scs)
-        npts = 3 + 2 * self.n + len(self._scs)
+        pts = self._shared_pts + b"".join(self._pts) + b"".join(self._raw_pts)
+        scs = b"".join(_le32(v) for v in shared) + b"".join(_le32(v) for v in self._scs) + b"".join(self._raw_scs)
+        npts = 3 + 2 * self.n + len(self._scs) + self._raw_count
         msm = self._msm or _engine.default_engine().msm_bytes
         return msm(pts, scs, npts)
 
@@ -179,3 +254,31 @@ def batch_verify(Vs, proofs, g, h, gs, hs, u, **kw):
     for V, pr in zip(Vs, proofs):
         bv.add(V, pr)
     return bv.verify()
+
+
+# ---- worker side of add_wire (module level: picklable by name) -------------------------------
+_worker_gens = None
+
+
+def _worker_init(gens):
+    global _worker_gens
+    g, h, u, gs, hs = gens
+    n = len(gs) // 64
+    _worker_gens = (Point.from_le64(g), Point.from_le64(h), [Point.from_le64(gs[64 * i: 64 * i + 64]) for i in range(n)],
+                    [Point.from_le64(hs[64 * i: 64 * i + 64]) for i in range(n)], Point.from_le64(u))
+
+
+def _worker_ping(i):
+    return i
+
+
+def _worker_add(blobs, pts, Vs):
+    from .codec import assemble, parse_blob
+    g, h, gs, hs, u = _worker_gens
+    bv = BatchRangeVerifier(g, h, gs, hs, u)
+    pos = 0
+    for j, blob in enumerate(blobs):
+        parsed = parse_blob(blob)
+        bv.add(Point.from_le64(Vs[64 * j: 64 * j + 64]), assemble(parsed, pts, pos))
+        pos += 6 + 2 * parsed[0]
+    return bv.state()

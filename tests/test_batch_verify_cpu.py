@@ -87,3 +87,54 @@ def test_two_rank_gloo_sharded_batch_verify():
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert "DIST_BATCH_OK world=2" in r.stdout
+
+
+def oracle_decompress(comp, n):
+    """Stand-in for bpmi_ec_decompress_batch on CPU: the oracle's bytes_to_point."""
+    from oracle.ec import INF, point_to_le64
+    out, ok = [], bytearray(n)
+    for i in range(n):
+        c = comp[33 * i: 33 * i + 33]
+        try:
+            P = INF if c == bytes(33) else R.bytes_to_point(c)
+            out.append(point_to_le64(P))
+            ok[i] = 1
+        except Exception:
+            out.append(bytes(64))
+    return b"".join(out), bytes(ok)
+
+
+@pytest.mark.parametrize("workers", [0, 2])
+def test_batch_wire_path_with_worker_processes(workers):
+    """add_wire: proofs arrive as bytes, the per-proof host work runs in spawned worker
+    processes, their states merge linearly; mixing add(), add_wire() and a corrupted proof."""
+    from bulletproofs_amd.rangeproofs.codec import proof_to_bytes
+    b = make_batch(7)
+    blobs = [proof_to_bytes(pr) for pr in b["proofs"]]
+    bv = BatchRangeVerifier(b["g"], b["h"], b["gs"], b["hs"], b["u"], msm=oracle_msm)
+    try:
+        if workers:
+            bv.start_workers(workers)
+        bv.add(b["Vs"][0], b["proofs"][0])
+        bv.add_wire(b["Vs"][1:6], blobs[1:6], decompress=oracle_decompress, chunk=2)
+        bv.add(b["Vs"][6], b["proofs"][6])
+        assert bv.count == 7
+        assert bv.verify() is True
+        # one flipped scalar byte inside a wire proof (t_hat): the batch is rejected
+        bad = bytearray(blobs[3])
+        bad[6 + 32 * 2 + 31] ^= 1
+        bv.reset()
+        bv.add_wire(b["Vs"][:6], blobs[:3] + [bytes(bad)] + blobs[4:6], decompress=oracle_decompress, chunk=4)
+        with pytest.raises(Exception, match="Proof invalid"):
+            bv.verify()
+        # a malformed blob / a transcript byte that does not match the proof's points: rejected on
+        # the host (in the worker), before any MSM
+        bv.reset()
+        with pytest.raises(Exception, match="Proof invalid"):
+            bv.add_wire(b["Vs"][2:3], [b"XX" + blobs[2]], decompress=oracle_decompress)
+        flipped = bytearray(blobs[2])
+        flipped[-3] ^= 1                      # inside the Protocol-2 transcript
+        with pytest.raises(Exception, match="Proof invalid"):
+            bv.add_wire(b["Vs"][2:3], [bytes(flipped)], decompress=oracle_decompress)
+    finally:
+        bv.stop_workers()

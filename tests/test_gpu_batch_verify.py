@@ -155,3 +155,37 @@ def test_batch_aggregated_proofs(gp):
         bv.add(Vs, pr)
     with pytest.raises(Exception, match="Proof invalid"):
         bv.verify()
+
+
+@pytest.mark.parametrize("workers", [0, 3])
+def test_batch_wire_path(gp, batch, workers):
+    """Proofs arrive serialised: one GPU launch decompresses every point, the host work runs in
+    spawned worker processes (or in-process), the merged combination is one MSM.  A proof that
+    was valid on its own but whose wire bytes were altered (scalar, point sign) must fail."""
+    from bulletproofs_amd.rangeproofs import BatchRangeVerifier
+    from bulletproofs_amd.rangeproofs.codec import proof_to_bytes
+    b = batch
+    blobs = [proof_to_bytes(pr) for pr in b["proofs"]]
+    bv = BatchRangeVerifier(b["g"], b["h"], b["gs"], b["hs"], b["u"])
+    try:
+        if workers:
+            bv.start_workers(workers)
+        bv.add_wire(b["Vs"], blobs, chunk=2)
+        bv.add(b["Vs"][0], b["proofs"][0])
+        assert bv.count == 7 and bv.verify() is True
+        k = blobs[4][5]
+        for off, what in ((6 + 32 * 1 + 31, "mu"), (6 + 32 * (5 + k), "sign of T1")):
+            bad = bytearray(blobs[4])
+            bad[off] ^= 1
+            bv.reset()
+            with pytest.raises(Exception, match="Proof invalid"):     # T1's transcript check or the MSM
+                bv.add_wire(b["Vs"], blobs[:4] + [bytes(bad)] + blobs[5:])
+                bv.verify()
+        bad = bytearray(blobs[1])
+        bad[6 + 32 * (5 + k) + 1: 6 + 32 * (5 + k) + 33] = (7).to_bytes(32, "big")      # x = 7: 7^3 + 7 = 350 is not a square mod p
+        bv.reset()
+        with pytest.raises(Exception, match="Proof invalid"):
+            bv.add_wire(b["Vs"][1:2], [bytes(bad)])
+            bv.verify()
+    finally:
+        bv.stop_workers()

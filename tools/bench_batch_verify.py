@@ -8,8 +8,9 @@ one node (one process per GPU):
 
 Every rank proves `distinct` proofs (seeded, identical on all ranks), cycles them to fill
 its shard of the batch, runs the host-side transcript checks and scalar preparation for its
-shard, evaluates ONE MSM (rangeproofs/batch.py), and the 64-byte partial values are
-combined with one all_gather + fold.  Prints one JSON line on rank 0."""
+shard -- by default on serialised proofs, in a pool of worker processes (add_wire) --
+evaluates ONE MSM (rangeproofs/batch.py), and the 64-byte partial values are combined with
+one all_gather + fold.  Prints one JSON line on rank 0."""
 import argparse
 import hashlib
 import json
@@ -25,6 +26,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--log-batch", type=int, default=14)
     ap.add_argument("--distinct", type=int, default=64)
+    ap.add_argument("--workers", type=int, default=-1,
+                    help="host worker processes per rank for the wire path (0: serial add() on proof objects; "
+                         "default: min(32, host cores / ranks))")
     args = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -61,11 +65,27 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
+    workers = args.workers if args.workers >= 0 else max(1, min(32, (os.cpu_count() or 1) // world))
     bv = BatchRangeVerifier(g, h, gs, hs, u)
-    for k in range(lo, hi):
-        V, pr = proofs[k % args.distinct]
-        bv.add(V, pr)
+    t_pool = 0.0
+    if workers:
+        # the proofs arrive as bytes (rangeproofs/codec.py); the pool is part of the service, not of a batch
+        from bulletproofs_amd.rangeproofs.codec import proof_to_bytes
+        wire = [proof_to_bytes(pr) for _, pr in proofs]
+        Vs_in = [proofs[k % args.distinct][0] for k in range(lo, hi)]
+        blobs_in = [wire[k % args.distinct] for k in range(lo, hi)]
+        t0 = time.perf_counter()
+        bv.start_workers(workers)
+        t_pool = time.perf_counter() - t0
+        if world > 1:
+            dist.barrier()
+    t0 = time.perf_counter()
+    if workers:
+        bv.add_wire(Vs_in, blobs_in)
+    else:
+        for k in range(lo, hi):
+            V, pr = proofs[k % args.distinct]
+            bv.add(V, pr)
     t_host = time.perf_counter() - t0
     ok = bv.verify(sharded=sharded if world > 1 else None)
     if world > 1:
@@ -80,7 +100,10 @@ def main():
         print(json.dumps({"metric": "range-proof verifies/sec (batched, 64-bit proofs)", "value": total / elapsed,
                           "unit": "verifies/s", "n_gpus": world, "batch": total, "seconds": elapsed,
                           "host_prep_s_rank0": t_host, "msm_points_rank0": 3 + 2 * n + 19 * (hi - lo), "ok": ok,
-                          "proves_per_s_one_gpu": args.distinct / t_prove}))
+                          "proves_per_s_one_gpu": args.distinct / t_prove, "host_workers_per_rank": workers,
+                          "input": "wire bytes (GPU batch decompression inside the timed region)" if workers else "proof objects",
+                          "worker_pool_startup_s": t_pool, "host_cores": os.cpu_count()}))
+    bv.stop_workers()
     if world > 1:
         dist.destroy_process_group()
 
