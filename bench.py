@@ -181,6 +181,15 @@ def main():
         dist.destroy_process_group()
 
 
+def cpu_quota():
+    """CPUs this container may use at once (cgroup v2 cpu.max), or None when unlimited."""
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        return None if quota == "max" else round(int(quota) / int(period), 2)
+    except Exception:
+        return None
+
+
 def cpu_baseline(logn, d_pts, d_sc):
     """The plain-C oracle MSM (bucket method, pthreads) on this host's cores over the
     first 2^logn pairs of the same synthetic workload."""
@@ -200,7 +209,7 @@ def cpu_baseline(logn, d_pts, d_sc):
         if time.perf_counter() - t0 > 12.0:          # ~12 s of CPU work (bounded sample)
             break
     dt = time.perf_counter() - t0
-    return {"value": m * reps / dt, "unit": "pairs/s", "cores": cores, "host_cores": os.cpu_count(), "kind": "port",
+    return {"value": m * reps / dt, "unit": "pairs/s", "cores": cores, "host_cores": os.cpu_count(), "host_cpu_quota": cpu_quota(), "kind": "port",
             "sample": "oracle/c bucket MSM, first 2^%d pairs of the same inputs, %d reps, %d threads" % (logn, reps, cores)}
 
 

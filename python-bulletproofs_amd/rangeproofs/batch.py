@@ -198,7 +198,7 @@ class BatchRangeVerifier:
             self._pool.shutdown()
         self._pool, self._workers = None, 0
 
-    def add_wire(self, Vs, blobs, decompress=None, chunk=256):
+    def add_wire(self, Vs, blobs, decompress=None, chunk=128):
         """Add len(blobs) single-value proofs given in wire format (codec.proof_to_bytes) with
         their commitments Vs (Points).  All points of all proofs are decompressed in one GPU
         launch; parsing, the transcript checks and the scalar algebra of add() run in the
@@ -269,6 +269,8 @@ def _worker_init(gens):
 
 
 def _worker_ping(i):
+    import time
+    time.sleep(0.25)        # long enough that the executor has to start one process per ping
     return i
 
 

@@ -65,7 +65,14 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    workers = args.workers if args.workers >= 0 else max(1, min(32, (os.cpu_count() or 1) // world))
+    usable = len(os.sched_getaffinity(0))
+    try:                                              # cgroup v2 CPU quota of the container, if any
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            usable = max(1, min(usable, int(quota) // int(period)))
+    except Exception:
+        pass
+    workers = args.workers if args.workers >= 0 else max(1, min(32, usable // world))
     bv = BatchRangeVerifier(g, h, gs, hs, u)
     t_pool = 0.0
     if workers:
@@ -102,7 +109,8 @@ def main():
                           "host_prep_s_rank0": t_host, "msm_points_rank0": 3 + 2 * n + 19 * (hi - lo), "ok": ok,
                           "proves_per_s_one_gpu": args.distinct / t_prove, "host_workers_per_rank": workers,
                           "input": "wire bytes (GPU batch decompression inside the timed region)" if workers else "proof objects",
-                          "worker_pool_startup_s": t_pool, "host_cores": os.cpu_count()}))
+                          "worker_pool_startup_s": t_pool, "host_cores": os.cpu_count(),
+                          "host_cores_usable": usable}))
     bv.stop_workers()
     if world > 1:
         dist.destroy_process_group()
