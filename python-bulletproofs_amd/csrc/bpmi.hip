@@ -155,9 +155,35 @@ int bpmi_msm_dev(bpmi_ctx *ctx, const void *d_pts, const void *d_scalars, uint64
   if (!ctx || !out || (n && (!d_pts || !d_scalars))) return ctx ? fail(ctx, BPMI_E_ARG, "null argument") : BPMI_E_ARG;
   if (n > BPMI_MAX_N) return fail(ctx, BPMI_E_ARG, "n exceeds BPMI_MAX_N");
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  Segs s = segs_init();
-  s.pts[0] = (const u32 *)d_pts; s.sc[0] = (const u32 *)d_scalars; s.n[0] = (u32)n; s.total = (u32)n;
-  return msm_run(ctx, s, out);
+  // The LDS partition sort packs a 23-bit pair index; longer inputs run as slices of 2^23
+  // pairs on alternating lanes (5.7e8 pairs/s each, against 3.7e8 for the global-atomic
+  // sort path at these sizes) and the slice results are added.
+  const uint64_t SLICE = 1ull << 23;
+  if (n <= SLICE || ctx->opt_c) {
+    Segs s = segs_init();
+    s.pts[0] = (const u32 *)d_pts; s.sc[0] = (const u32 *)d_scalars; s.n[0] = (u32)n; s.total = (u32)n;
+    return msm_run(ctx, s, out);
+  }
+  const uint64_t nsl = (n + SLICE - 1) / SLICE;
+  std::vector<uint8_t> parts(64 * nsl);
+  int rc = ensure_lane(ctx, 1);
+  if (rc) return rc;
+  HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+  HIPCHK(ctx, hipStreamWaitEvent(ctx->stream1, ctx->ev_fork, 0));
+  for (uint64_t k = 0; k < nsl; k++) {
+    const int lane = (int)(k & 1);
+    if (k >= 2) { rc = msm_finish(ctx, lane, parts.data() + 64 * (k - 2)); if (rc) return rc; }
+    const uint64_t lo = k * SLICE, cnt = std::min<uint64_t>(SLICE, n - lo);
+    Segs s = segs_init();
+    s.pts[0] = (const u32 *)d_pts + 16 * lo; s.sc[0] = (const u32 *)d_scalars + 8 * lo; s.n[0] = (u32)cnt; s.total = (u32)cnt;
+    rc = msm_enqueue(ctx, lane, s);
+    if (rc) return rc;
+  }
+  for (uint64_t k = (nsl >= 2 ? nsl - 2 : 0); k < nsl; k++) {
+    rc = msm_finish(ctx, (int)(k & 1), parts.data() + 64 * k);
+    if (rc) return rc;
+  }
+  return bpmi_ec_sum(ctx, parts.data(), nsl, out);
 }
 int bpmi_msm(bpmi_ctx *ctx, const uint8_t *pts, const uint8_t *scalars, uint64_t n, uint8_t out[64]) {
   if (!ctx || !out || (n && (!pts || !scalars))) return ctx ? fail(ctx, BPMI_E_ARG, "null argument") : BPMI_E_ARG;

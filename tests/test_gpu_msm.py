@@ -175,3 +175,38 @@ def test_msm_2e24_periodic_inputs(gp):
     d_p.free()
     d_e.free()
     assert big == eng.ec_mul_batch_bytes(small, (reps).to_bytes(32, "little"), 1)
+
+
+def test_msm_sliced_above_2e23(gp):
+    """n > 2^23 runs as slices of 2^23 pairs on alternating lanes whose results are added
+    (bpmi_msm_dev).  Size-independent check: with the points tiled from D distinct ones,
+    MSM(tiled, e) == MSM(distinct, column sums of e mod q); ragged last slice."""
+    import numpy as np
+    eng = gp.engine()
+    D = 1 << 12
+    n = (1 << 23) + (1 << 16) + 5 * D                 # 2 slices; a multiple of D
+    pts, _ = gp.rand_points(D, 99)
+    small = cbind.pack_points(pts)
+    rng = np.random.default_rng(3)
+    reps = n // D
+    e = rng.integers(0, 1 << 32, size=(reps, D, 8), dtype=np.uint64).astype(np.uint32)
+    e[:, :, 7] &= 0x7FFFFFFF
+    col = e.astype(np.uint64).sum(axis=0)
+    folded = []
+    for j in range(D):
+        v = 0
+        for k in range(7, -1, -1):
+            v = (v << 32) + int(col[j, k])
+        folded.append(v % Q)
+    d_pts = eng.alloc(64 * n)
+    tile = small * 64
+    for r in range(0, reps, 64):
+        d_pts.upload(tile[: 64 * D * min(64, reps - r)], 64 * D * r)
+    d_e = eng.upload(e.tobytes())
+    try:
+        got = eng.msm_dev(d_pts, d_e, n)
+        assert got == cbind.msm_bytes(small, cbind.pack_scalars(folded), D)
+        assert got == eng.msm_dev(d_pts, d_e, n)
+    finally:
+        d_pts.free()
+        d_e.free()
