@@ -15,9 +15,9 @@
 //                   bucket, the first/last run of a chunk become partial records
 //   k_segscan       block-wide segmented scan over partial records, 256 -> 2 per block,
 //                   repeated until one block is left
-//   k_bucket_digit_sums / k_weighted31   sum_b b*B[w][b] as base-32 digit sums + a
-//                   31-term suffix scan per (window, digit position);
-//                   k_window_weighted_small for windows of <= 256 buckets
+//   k_digit_sums (x2) / k_weighted16   sum_b b*B[w][b]: the bucket index split in two digits
+//                   twice (2 additions per element, sub-wave groups, shuffle butterflies),
+//                   then 16-term suffix scans; k_window_weighted_small for <= 256 buckets
 //   tail            O(256) sequential doublings: window combine + to-affine
 //                   (host thread on 4x64-bit limbs, host_tail.hpp, or the one-lane device
 //                   kernel k_tail; same Horner chain)

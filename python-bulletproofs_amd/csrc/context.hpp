@@ -31,7 +31,7 @@ struct bpmi_ctx {
   void *ws1 = nullptr; size_t ws1_bytes = 0;
   void *pin1 = nullptr; size_t pin1_bytes = 0;
   hipEvent_t ev_fork = nullptr;
-  struct PendingMsm { bool active = false; u32 W = 0, nv = 0, c = 0; int tail = 2; u32 *E = nullptr, *out = nullptr; } pend[2];
+  struct PendingMsm { bool active = false; u32 W = 0, nv = 0, c = 0; int tail = 2; u32 *E = nullptr, *out = nullptr; TailOffs to; } pend[2];
   void *stage_in = nullptr; size_t stage_in_bytes = 0;  // device staging for host-pointer entry points
   // options
   int opt_c = 0;        // window bits, 0 = auto

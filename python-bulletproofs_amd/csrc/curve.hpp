@@ -272,4 +272,8 @@ BPMI_HD void xyzz_load(xyzz &a, const u32 *src) {
   for (int k = 0; k < 9; k++) { a.X.v[k] = src[k]; a.Y.v[k] = src[9 + k]; a.ZZ.v[k] = src[18 + k]; a.ZZZ.v[k] = src[27 + k]; }
 }
 
+// bit offsets of the (<= 4) partial sums a bucket reduction leaves per MSM window:
+// window value = sum_v 2^(off[v]) E[v], off ascending, off[0] = 0
+struct TailOffs { u32 nv; u32 off[4]; };
+
 }  // namespace bpmi

@@ -109,16 +109,16 @@ static inline void pt_add(pt &r, const pt &a, const pt &b) {   // add-2008-s, co
   r.X = X3; r.Y = t;
 }
 // result = sum_w 2^(c w) sum_v 32^v E[w][v] as ONE Horner chain over bit positions
-static inline void tail_combine(uint8_t out[64], const bpmi::u32 *E, bpmi::u32 W, bpmi::u32 nv, bpmi::u32 c) {
+static inline void tail_combine(uint8_t out[64], const bpmi::u32 *E, bpmi::u32 W, bpmi::u32 c, const bpmi::TailOffs &to) {
   pt acc;
   pt_set_inf(acc);
   for (int w = (int)W - 1; w >= 0; w--) {
     int prev = (int)c;
-    for (int v = (int)nv - 1; v >= 0; v--) {
-      for (int k = prev; k > 5 * v; k--) pt_dbl(acc, acc);
-      prev = 5 * v;
+    for (int v = (int)to.nv - 1; v >= 0; v--) {
+      for (int k = prev; k > (int)to.off[v]; k--) pt_dbl(acc, acc);
+      prev = (int)to.off[v];
       pt e;
-      pt_load(e, E + ((size_t)w * nv + v) * 36);
+      pt_load(e, E + ((size_t)w * to.nv + v) * 36);
       pt_add(acc, acc, e);
     }
   }

@@ -26,7 +26,7 @@ struct MsmWs {
   u32 *dig, *hist, *off, *cursor, *bsum, *sidx, *buckets, *chunk_key, *coarse_hist, *coarse_off, *coarse_cursor;
   u32 P;          // partitions of sort path 2 (0 = path 1)
   u32 *rec_key[2], *rec_pt[2];
-  u32 *D, *E, *out;
+  u32 *D, *D2, *E, *out;
   size_t total;
   u32 nscan_blocks, rec0_max;
 };
@@ -55,10 +55,46 @@ static void msm_layout(const MsmGeom &g, MsmWs &w, char *base) {
   w.rec_pt[0] = take(4ull * XYZZ_WORDS * w.rec0_max);
   w.rec_key[1] = take(4ull * rec1_max);
   w.rec_pt[1] = take(4ull * XYZZ_WORDS * rec1_max);
-  w.D = take(4ull * XYZZ_WORDS * g.W * g.nv * 31);
-  w.E = take(4ull * XYZZ_WORDS * g.W * g.nv);
+  w.D = take(4ull * XYZZ_WORDS * g.W * (g.B > 256u ? (1u << ((g.c + 1u) / 2u)) + (1u << (g.c / 2u)) : 1u));   // stage-1 digit sums
+  w.D2 = take(4ull * XYZZ_WORDS * g.W * 64);                                                                  // stage-2 digit sums
+  w.E = take(4ull * XYZZ_WORDS * g.W * 4);
   w.out = take(64);
   w.total = o;
+}
+
+static u32 msb_index(u32 v) { u32 k = 0; while ((2u << k) <= v) k++; return k; }     // floor(log2 v), v >= 1
+static u32 digit_group_log(u32 elements, u32 epl) {          // lanes per sum: epl elements per lane, at most one wave
+  u32 gl = 0;
+  while (gl < 6 && (epl << gl) < elements) gl++;
+  return gl;
+}
+static u32 digit_job_blocks(const DigitJobs &J, u32 k) {
+  const uint64_t lanes = (uint64_t)J.cnt * J.j[k].nsums << J.j[k].gl_log;
+  return (u32)((lanes + 255) / 256);
+}
+// the two jobs (by lo, by hi) that split every array [in_off .. in_off + N) of `cnt` arrays at bit s;
+// results at out_off (2^s - 1 sums) and behind them (N >> s sums)
+static DigitJobs digit_jobs2(u32 cnt, u32 in_off, u32 in_stride, u32 N, u32 s, u32 out_off, u32 out_stride, u32 epl) {
+  DigitJobs J;
+  memset(&J, 0, sizeof(J));
+  J.cnt = cnt; J.njobs = 2;
+  for (u32 type = 0; type < 2; type++) {
+    DigitJob &j = J.j[type];
+    j.in_off = in_off; j.in_stride = in_stride; j.N = N; j.s = s; j.type = type;
+    j.nsums = type ? (N >> s) : ((1u << s) - 1u);
+    j.gl_log = digit_group_log(type ? (1u << s) : ((N - 1u) >> s) + 1u, epl);
+    j.out_off = out_off + (type ? (1u << s) - 1u : 0u); j.out_stride = out_stride;
+  }
+  J.j[0].blk0 = 0;
+  J.j[1].blk0 = digit_job_blocks(J, 0);
+  return J;
+}
+static DigitJobs digit_jobs_concat(const DigitJobs &a, const DigitJobs &b) {
+  DigitJobs J = a;
+  u32 blk = a.j[1].blk0 + digit_job_blocks(a, 1);
+  for (u32 k = 0; k < 2; k++) { J.j[2 + k] = b.j[k]; J.j[2 + k].blk0 = blk; blk += digit_job_blocks(b, k); }
+  J.njobs = 4;
+  return J;
 }
 
 // Enqueue every GPU stage of one MSM on `lane` (0 = the ctx stream, 1 = the second lane),
@@ -78,7 +114,7 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, const Segs &segs, u32 w0 = 0, u3
   g.B = 1u << (g.c - 1);
   g.G = g.W * g.B;
   g.L = ctx->opt_chunk > 0 ? (u32)ctx->opt_chunk : (n >= (1u << 19) ? 64u : (n >= (1u << 16) ? 32u : 16u));   // tools/tune_msm.py sweeps
-  g.nv = (g.B <= 256u) ? 1u : (g.c + 4u) / 5u;     // small windows: direct weighted sum, one value per window
+  g.nv = (g.B <= 256u) ? 1u : 4u;                  // partial sums per window handed to the tail
   MsmWs w;
   msm_layout(g, w, nullptr);
   int rc = ensure_lane(ctx, lane);
@@ -170,13 +206,35 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, const Segs &segs, u32 w0 = 0, u3
     }
   }
   debug_sync(ctx, "ST_SEGSCAN", st);
+  TailOffs to;
+  to.nv = 1; to.off[0] = to.off[1] = to.off[2] = to.off[3] = 0;
   {
     StageTimer t(ctx, ST_BREDUCE, st);
     if (g.B <= 256u) {
       hipLaunchKernelGGL(k_window_weighted_small, dim3(g.W), dim3(g.B < 64u ? 64u : g.B), 0, st, g, w.buckets, w.E);
     } else {
-      hipLaunchKernelGGL(k_bucket_digit_sums, dim3(g.W * g.nv * 31), dim3(256), 0, st, g, w.buckets, w.D);   // 128 / 64 threads measured slower
-      hipLaunchKernelGGL(k_weighted31, dim3(g.W * g.nv), dim3(64), 0, st, w.D, w.E);
+      // bucket index b in [1, B], B = 2^(c-1):  b = hi 2^s0 + lo, then each digit again in two
+      const u32 s0 = g.c / 2u, N0 = (1u << s0) - 1u, N1 = g.B >> s0;          // stage-1 arrays: D0[1..N0], D1[1..N1]
+      const u32 t0 = (s0 + 1u) / 2u, t1 = (msb_index(N1) + 1u) / 2u;          // stage-2 splits
+      const u32 stride1 = N0 + N1;
+      // stage 1 is throughput-bound: 16 elements per lane (measured best of 4 / 8 / 12 / 16); stage 2 is pure
+      // latency: one element per lane, 16-lane butterflies
+      DigitJobs j1 = digit_jobs2(g.W, 0, g.B, g.B, s0, 0, stride1, 16);
+      hipLaunchKernelGGL(k_digit_sums, dim3(j1.j[j1.njobs - 1].blk0 + digit_job_blocks(j1, j1.njobs - 1)), dim3(256), 0, st, w.buckets, w.D, j1);
+      // stage 2: D0 -> (D00, D01) at records [0, ..), D1 -> (D10, D11) behind them
+      DigitJobs ja = digit_jobs2(g.W, 0, stride1, N0, t0, 0, 64, 1);
+      const u32 used_a = ((1u << t0) - 1u) + (N0 >> t0);
+      DigitJobs jb = digit_jobs2(g.W, N0, stride1, N1, t1, used_a, 64, 1);
+      DigitJobs j2 = digit_jobs_concat(ja, jb);
+      hipLaunchKernelGGL(k_digit_sums, dim3(j2.j[j2.njobs - 1].blk0 + digit_job_blocks(j2, j2.njobs - 1)), dim3(256), 0, st, w.D, w.D2, j2);
+      FinalJobs f;
+      f.nr = 4; f.in_stride = 64; f.cnt = g.W;
+      f.in_off[0] = 0;                       f.N[0] = (1u << t0) - 1u;
+      f.in_off[1] = f.N[0];                  f.N[1] = N0 >> t0;
+      f.in_off[2] = used_a;                  f.N[2] = (1u << t1) - 1u;
+      f.in_off[3] = used_a + f.N[2];         f.N[3] = N1 >> t1;
+      hipLaunchKernelGGL(k_weighted16, dim3((g.W * 4u * 16u + 255u) / 256u), dim3(256), 0, st, w.D2, w.E, f);
+      to.nv = 4; to.off[0] = 0; to.off[1] = t0; to.off[2] = s0; to.off[3] = s0 + t1;
     }
   }
   debug_sync(ctx, "ST_BREDUCE", st);
@@ -184,7 +242,7 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, const Segs &segs, u32 w0 = 0, u3
     StageTimer t(ctx, ST_TAIL, st);
     const int tail = wcount ? 2 : (ctx->opt_tail ? ctx->opt_tail : 2);      // window groups are combined on the host
     if (tail == 1) {
-      hipLaunchKernelGGL(k_tail, dim3(1), dim3(64), 0, st, w.E, g.W, g.nv, g.c, w.out);
+      hipLaunchKernelGGL(k_tail, dim3(1), dim3(64), 0, st, w.E, g.W, g.c, to, w.out);
       rc = ensure_pin_lane(ctx, lane, 4096);
       if (rc) return rc;
       HIPCHK(ctx, hipMemcpyAsync(lane ? ctx->pin1 : ctx->pin, w.out, 64, hipMemcpyDeviceToHost, st));
@@ -194,7 +252,7 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, const Segs &segs, u32 w0 = 0, u3
       if (rc) return rc;
       HIPCHK(ctx, hipMemcpyAsync(lane ? ctx->pin1 : ctx->pin, w.E, eb, hipMemcpyDeviceToHost, st));
     }
-    pd.active = true; pd.W = g.W; pd.nv = g.nv; pd.c = g.c; pd.tail = tail;
+    pd.active = true; pd.W = g.W; pd.nv = g.nv; pd.c = g.c; pd.tail = tail; pd.to = to;
   }
   HIPCHK(ctx, hipGetLastError());
   return BPMI_OK;
@@ -209,7 +267,7 @@ static int msm_finish(bpmi_ctx *ctx, int lane, uint8_t out[64]) {
   if (pd.tail == 1) {
     memcpy(out, pin, 64);
   } else {
-    bpmi_host::tail_combine(out, (const u32 *)pin, pd.W, pd.nv, pd.c);     // host_tail.hpp
+    bpmi_host::tail_combine(out, (const u32 *)pin, pd.W, pd.c, pd.to);     // host_tail.hpp
   }
   pd.active = false;
   debug_sync(ctx, "ST_TAIL", st);
@@ -236,7 +294,7 @@ static int msm_run_split(bpmi_ctx *ctx, const Segs &segs, uint8_t out[64]) {
   std::vector<u32> E((b0 + b1) / 4);
   memcpy(E.data(), ctx->pin, b0);
   memcpy((char *)E.data() + b0, ctx->pin1, b1);
-  bpmi_host::tail_combine(out, E.data(), W, p0.nv, c);
+  bpmi_host::tail_combine(out, E.data(), W, c, p0.to);
   p0.active = p1.active = false;
   return BPMI_OK;
 }

@@ -13,7 +13,7 @@ struct MsmGeom {
   u32 B;       // buckets per window = 2^(c-1)
   u32 G;       // W * B
   u32 L;       // entries per thread in k_accum_l0
-  u32 nv;      // base-32 digit positions of a bucket index (ceil(c / 5))
+  u32 nv;      // partial sums per window that the bucket reduction hands to the tail (1 or 4)
 };
 
 // Signed-digit recoding of scalar i: calls f(w, b, sign) for every window, b = |digit|
@@ -422,65 +422,104 @@ __device__ __forceinline__ void block_tree_sum(xyzz &val, u32 *s_val) {
   }
 }
 
-// ---- bucket reduction, step 1: D[w][v][d] = sum of buckets b in [1,B] whose base-32 digit v is d
-// grid = W * nv * 31 blocks of 256
-__global__ void __launch_bounds__(256, 4) k_bucket_digit_sums(MsmGeom g, const u32 *__restrict__ buckets, u32 *__restrict__ D) {
-  __shared__ u32 s_val[256 * LDS_STRIDE];
-  const u32 blk = blockIdx.x;
-  const u32 d = blk % 31u + 1u;
-  const u32 v = (blk / 31u) % g.nv;
-  const u32 w = blk / (31u * g.nv);
-  const u32 sh = 5u * v;
+// ---- bucket reduction by two-position digit sums, sub-wave groups, cross-lane trees ----------
+// For an array X[1..N] and a split s:  sum_b b X[b] = sum_lo lo D0[lo] + 2^s sum_hi hi D1[hi]
+//   D0[lo] = sum of X[hi 2^s + lo] over hi      (lo = 1 .. 2^s - 1)
+//   D1[hi] = sum of X[hi 2^s + lo] over lo      (hi = 1 .. N >> s)
+// i.e. TWO additions per element; applying it twice takes a window's 2^(c-1) buckets to four
+// arrays of <= 16 sums, which k_weighted16 finishes.  Every sum belongs to a group of
+// 2^gl_log lanes of one wave: each lane adds its share serially (about 8 elements), then a
+// butterfly of __shfl_xor exchanges folds the group -- no LDS, no block barrier.
+struct DigitJob {
+  u32 in_off, in_stride;     // array a starts at record a * in_stride + in_off of X
+  u32 N, s, type;            // entries, split bits, 0 = D0 (by lo) / 1 = D1 (by hi)
+  u32 gl_log;                // lanes per sum = 2^gl_log (<= 64)
+  u32 nsums;                 // sums per array: 2^s - 1 (type 0) or N >> s (type 1)
+  u32 out_off, out_stride;   // sum idx (1-based) of array a -> record a * out_stride + out_off + idx - 1 of D
+  u32 blk0;                  // first block of this job
+};
+struct DigitJobs { DigitJob j[4]; u32 njobs, cnt; };
+
+__device__ __forceinline__ void xyzz_shfl_xor(xyzz &r, const xyzz &a, int mask) {
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    r.X.v[i] = (u32)__shfl_xor((int)a.X.v[i], mask, 64);
+    r.Y.v[i] = (u32)__shfl_xor((int)a.Y.v[i], mask, 64);
+    r.ZZ.v[i] = (u32)__shfl_xor((int)a.ZZ.v[i], mask, 64);
+    r.ZZZ.v[i] = (u32)__shfl_xor((int)a.ZZZ.v[i], mask, 64);
+  }
+}
+__device__ __forceinline__ void xyzz_shfl_down16(xyzz &r, const xyzz &a, int d) {      // within groups of 16 lanes
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    r.X.v[i] = (u32)__shfl_down((int)a.X.v[i], d, 16);
+    r.Y.v[i] = (u32)__shfl_down((int)a.Y.v[i], d, 16);
+    r.ZZ.v[i] = (u32)__shfl_down((int)a.ZZ.v[i], d, 16);
+    r.ZZZ.v[i] = (u32)__shfl_down((int)a.ZZZ.v[i], d, 16);
+  }
+}
+
+__global__ void __launch_bounds__(256) k_digit_sums(const u32 *__restrict__ X, u32 *__restrict__ D, DigitJobs jobs) {
+  u32 ji = 0;
+  for (u32 k = 1; k < jobs.njobs; k++) if (blockIdx.x >= jobs.j[k].blk0) ji = k;
+  const DigitJob J = jobs.j[ji];
+  const u32 t = (blockIdx.x - J.blk0) * blockDim.x + threadIdx.x;
+  const u32 GL = 1u << J.gl_log;
+  const u32 sum_id = t >> J.gl_log, l = t & (GL - 1u);
+  const bool active = sum_id < jobs.cnt * J.nsums;
+  const u32 a = sum_id / J.nsums, idx = sum_id % J.nsums + 1u;
   xyzz acc;
   xyzz_set_inf(acc);
-  // element e -> b = (hi << (sh+5)) | (d << sh) | lo,  lo = low `sh` bits of e, hi = e >> sh
-  // valid (hi, lo): all lo for hi < hi_max, and lo <= B - base for hi == hi_max
-  const u32 hi_max = g.B >> (sh + 5u);
-  const u64 base_last = ((u64)hi_max << (sh + 5u)) | ((u64)d << sh);
-  u32 last_cnt = 0;
-  if (base_last <= g.B) { const u64 r = (u64)g.B - base_last + 1u; last_cnt = r < (1ull << sh) ? (u32)r : (1u << sh); }
-  const u32 ecount = (hi_max << sh) + last_cnt;
-  if (ecount == 0) {                      // e.g. the top digit position, where only d = 1 occurs
-    if (threadIdx.x == 0) xyzz_store_g(D + (u64)blk * XYZZ_WORDS, acc);
-    return;
-  }
-  for (u32 e = threadIdx.x; e < ecount; e += blockDim.x) {
-    const u32 lo = e & ((1u << sh) - 1u), hi = e >> sh;
-    const u64 b = ((u64)hi << (sh + 5u)) | ((u64)d << sh) | lo;
-    {
-      xyzz x;
-      xyzz_load_g(x, buckets + ((u64)w * g.B + (b - 1u)) * XYZZ_WORDS);
-      xyzz_add(acc, acc, x);
+  if (active) {
+    const u32 *base = X + ((u64)a * J.in_stride + J.in_off) * XYZZ_WORDS;
+    if (J.type == 0) {
+      for (u32 hi = l; ((hi << J.s) | idx) <= J.N; hi += GL) {
+        xyzz x;
+        xyzz_load_g(x, base + (u64)(((hi << J.s) | idx) - 1u) * XYZZ_WORDS);
+        xyzz_add(acc, acc, x);
+      }
+    } else {
+      for (u32 lo = l; lo < (1u << J.s) && ((idx << J.s) | lo) <= J.N; lo += GL) {
+        xyzz x;
+        xyzz_load_g(x, base + (u64)(((idx << J.s) | lo) - 1u) * XYZZ_WORDS);
+        xyzz_add(acc, acc, x);
+      }
     }
   }
-  block_tree_sum(acc, s_val);
-  if (threadIdx.x == 0) xyzz_store_g(D + (u64)blk * XYZZ_WORDS, acc);
+  for (u32 m = 1; m < GL; m <<= 1) {
+    xyzz other;
+    xyzz_shfl_xor(other, acc, (int)m);
+    xyzz_add(acc, acc, other);
+  }
+  if (active && l == 0) xyzz_store_g(D + ((u64)a * J.out_stride + J.out_off + idx - 1u) * XYZZ_WORDS, acc);
 }
-// ---- step 2: E[w][v] = sum_{d=1..31} d * D[w][v][d]  (suffix scan + sum over 32 lanes)
-// grid = W * nv blocks of 64
-__global__ void __launch_bounds__(64) k_weighted31(const u32 *__restrict__ D, u32 *__restrict__ Eout) {
-  __shared__ u32 s_val[64 * LDS_STRIDE];
-  const u32 tid = threadIdx.x;
+// E[a][r] = sum_{d=1..N_r} d * X_r[d] for the (<= 4) arrays r of every a, N_r <= 16: one group of
+// 16 lanes per array -- inclusive suffix scan (4 steps), then the sum of all suffixes (4 steps)
+struct FinalJobs { u32 in_off[4], N[4]; u32 nr, in_stride, cnt; };
+__global__ void __launch_bounds__(256) k_weighted16(const u32 *__restrict__ X, u32 *__restrict__ Eout, FinalJobs f) {
+  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  const u32 grp = t >> 4, l = t & 15u;
+  const bool active = grp < f.cnt * f.nr;
+  const u32 a = grp / f.nr, r = grp % f.nr;
   xyzz val;
-  if (tid < 31u) xyzz_load_g(val, D + ((u64)blockIdx.x * 31u + tid) * XYZZ_WORDS); else xyzz_set_inf(val);
-  // inclusive suffix scan: val[l] = sum_{j >= l} D[j]
-  for (u32 d = 1; d < 32; d <<= 1) {
-    xyzz_store(s_val + tid * LDS_STRIDE, val);
-    __syncthreads();
-    if (tid + d < 31u) {
-      xyzz other;
-      xyzz_load(other, s_val + (tid + d) * LDS_STRIDE);
-      xyzz_add(val, val, other);
-    }
-    __syncthreads();
+  xyzz_set_inf(val);
+  if (active && l < f.N[r]) xyzz_load_g(val, X + ((u64)a * f.in_stride + f.in_off[r] + l) * XYZZ_WORDS);
+  for (u32 d = 1; d < 16; d <<= 1) {
+    xyzz other;
+    xyzz_shfl_down16(other, val, (int)d);
+    if (l + d < 16u) xyzz_add(val, val, other);
   }
-  block_tree_sum(val, s_val);
-  if (tid == 0) xyzz_store_g(Eout + (u64)blockIdx.x * XYZZ_WORDS, val);
+  for (u32 m = 1; m < 16; m <<= 1) {
+    xyzz other;
+    xyzz_shfl_xor(other, val, (int)m);
+    xyzz_add(val, val, other);
+  }
+  if (active && l == 0) xyzz_store_g(Eout + (u64)grp * XYZZ_WORDS, val);
 }
 
 // ---- bucket reduction for small windows (B <= 256): one block of B threads per window
 // computes sum_b b * B[w][b] directly as sum_j Suffix_j (inclusive suffix scan + tree sum,
-// 2 log2(B) dependent additions) -- shorter than digit sums + k_weighted31 when B is small.
+// 2 log2(B) dependent additions) -- shorter than the digit-sum stages when B is small.
 // Eout[w] then has nv = 1.
 __global__ void __launch_bounds__(256) k_window_weighted_small(MsmGeom g, const u32 *__restrict__ buckets, u32 *__restrict__ Eout) {
   __shared__ u32 s_val[256 * LDS_STRIDE];
@@ -502,19 +541,19 @@ __global__ void __launch_bounds__(256) k_window_weighted_small(MsmGeom g, const 
   if (tid == 0) xyzz_store_g(Eout + (u64)w * XYZZ_WORDS, val);
 }
 
-// ---- tail: result = sum_w 2^(c w) sum_v 32^v E[w][v], to canonical affine -----------------
-BPMI_HD void msm_tail_combine(u32 out_words[16], const u32 *E, u32 W, u32 nv, u32 c) {
-  // ONE Horner chain over bit positions: E[w][v] carries weight 2^(c*w + 5*v), so walking
-  // t from the top bit down costs c*W doublings in total (not c*W + 5*nv*W)
+// ---- tail: result = sum_w 2^(c w) sum_v 2^(off[v]) E[w][v], to canonical affine -------------
+BPMI_HD void msm_tail_combine(u32 out_words[16], const u32 *E, u32 W, u32 c, const TailOffs &to) {
+  // ONE Horner chain over bit positions: E[w][v] carries weight 2^(c*w + off[v]), so walking
+  // from the top bit down costs c*W doublings in total
   xyzz acc;
   xyzz_set_inf(acc);
   for (int w = (int)W - 1; w >= 0; w--) {
     int prev = (int)c;                              // bit offset (within the window) already reached
-    for (int v = (int)nv - 1; v >= 0; v--) {
-      for (int k = prev; k > 5 * v; k--) xyzz_dbl(acc, acc);
-      prev = 5 * v;
+    for (int v = (int)to.nv - 1; v >= 0; v--) {
+      for (int k = prev; k > (int)to.off[v]; k--) xyzz_dbl(acc, acc);
+      prev = (int)to.off[v];
       xyzz e;
-      xyzz_load(e, E + ((u64)w * nv + v) * XYZZ_WORDS);
+      xyzz_load(e, E + ((u64)w * to.nv + v) * XYZZ_WORDS);
       xyzz_add(acc, acc, e);
     }
   }
@@ -522,10 +561,10 @@ BPMI_HD void msm_tail_combine(u32 out_words[16], const u32 *E, u32 W, u32 nv, u3
   xyzz_to_affine(r, acc);
   affine_to_words(out_words, r);
 }
-__global__ void k_tail(const u32 *__restrict__ E, u32 W, u32 nv, u32 c, u32 *__restrict__ out) {
+__global__ void k_tail(const u32 *__restrict__ E, u32 W, u32 c, TailOffs to, u32 *__restrict__ out) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     u32 w16[16];
-    msm_tail_combine(w16, E, W, nv, c);
+    msm_tail_combine(w16, E, W, c, to);
 #pragma unroll
     for (int i = 0; i < 16; i++) out[i] = w16[i];
   }
