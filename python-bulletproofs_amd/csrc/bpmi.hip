@@ -5,11 +5,12 @@
 // by the signed-digit bucket method; the result -- a canonical affine point -- is
 // schedule independent, so it is bit-identical to the reference's subset-table schedule):
 //   sort            (window, bucket) counting sort of (point index, sign):
-//                   n >= 2^16 (window bits >= 10): k_coarse_hist / k_partition / k_fine_hist / k_fine_scatter --
+//                   n >= 2^16 (window bits >= 10): k_coarse_hist / k_partition / k_fine_sort_part --
 //                   a two-level radix partition whose histograms and ranks live in LDS
-//                   (global atomics only reserve one range per tile and bin);
+//                   (global atomics only reserve one range per tile and partition; level B
+//                   sorts one partition per block and writes one contiguous range);
 //                   smaller n: k_digits_hist / k_scatter with global atomics
-//   k_scan_*        exclusive scans of the histograms -> run offsets
+//   k_scan_*        exclusive scans of the (coarse) histograms -> run offsets
 //   k_accum_l0      every thread adds exactly L sorted entries (perfectly balanced for
 //                   ANY digit distribution); runs that end inside a chunk go to their
 //                   bucket, the first/last run of a chunk become partial records

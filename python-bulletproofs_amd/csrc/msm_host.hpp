@@ -149,16 +149,15 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, const Segs &segs, u32 w0 = 0, u3
     {
       StageTimer t(ctx, ST_SCATTER, st);
       const u32 ntiles = (g.n + TILE_SCALARS - 1) / TILE_SCALARS;
-      hipLaunchKernelGGL(k_partition, dim3(std::min<u32>(ntiles, 2048)), dim3(1024), 0, st, segs, g, w.P, w.coarse_cursor, w.dig);
-      // level B over fixed-size tiles of the partitioned array (grid sized for the maximum E)
+      hipLaunchKernelGGL(k_partition, dim3(std::min<u32>(ntiles, 2048)), dim3(1024), 0, st, segs, g, w.P, w.coarse_off, w.coarse_cursor, w.dig, w.hist,
+                         w.coarse_hist + PART_MAX);
+      // level B: one block per partition; writes off[0..G), the chunk keys and the sorted entries
+      // (heavy partitions: counted and scattered by the tile kernels, which return at once when there are none)
       const u32 nft = (u32)(((size_t)g.n * g.W + FINE_TILE - 1) / FINE_TILE);
-      HIPCHK(ctx, hipMemsetAsync(w.hist, 0, 4ull * g.G, st));
-      hipLaunchKernelGGL(k_fine_hist, dim3(nft), dim3(256), 0, st, g, w.P, w.coarse_off, w.dig, w.coarse_off + w.P, w.hist);
-      hipLaunchKernelGGL(k_scan_partials, dim3(w.nscan_blocks), dim3(256), 0, st, w.hist, g.G, w.bsum);
-      hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, w.bsum, w.nscan_blocks, w.off, g.G);
-      hipLaunchKernelGGL(k_scan_final, dim3(w.nscan_blocks), dim3(256), 0, st, w.hist, g.G, w.bsum, w.off, w.cursor);
-      hipLaunchKernelGGL(k_fine_scatter, dim3(nft), dim3(256), 0, st, g, w.P, w.coarse_off, w.dig, w.coarse_off + w.P, w.cursor, w.sidx);
-      hipLaunchKernelGGL(k_chunk_keys, dim3((g.G + 255) / 256), dim3(256), 0, st, g, w.off, w.chunk_key);
+      const u32 *any_heavy = w.coarse_hist + PART_MAX;
+      hipLaunchKernelGGL(k_fine_hist_heavy, dim3(nft), dim3(256), 0, st, g, w.P, w.coarse_off, w.dig, w.coarse_off + w.P, any_heavy, w.hist);
+      hipLaunchKernelGGL(k_fine_sort_part, dim3(w.P), dim3(FINE_THREADS), 0, st, g, w.coarse_off, w.dig, w.hist, w.off, w.cursor, w.chunk_key, w.sidx);
+      hipLaunchKernelGGL(k_fine_scatter_heavy, dim3(nft), dim3(256), 0, st, g, w.P, w.coarse_off, w.dig, w.coarse_off + w.P, any_heavy, w.cursor, w.sidx);
     }
     debug_sync(ctx, "ST_SCATTER", st);
   } else {

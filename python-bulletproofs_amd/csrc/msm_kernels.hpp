@@ -74,6 +74,7 @@ __global__ void __launch_bounds__(256) k_digits_hist(Segs segs, MsmGeom g, u32 *
 // by lo entirely in LDS.  No per-element global atomic anywhere.
 #define PART_MAX 2048          // W * (B / 256) <= 2048 for every c in [10, 16]
 #define TILE_SCALARS 4096      // scalars per block-iteration in level A
+#define FINE_CAP 12288          // entries of a partition that level B sorts in one block's LDS
 __global__ void __launch_bounds__(256) k_coarse_hist(Segs segs, MsmGeom g, u32 P, u32 *__restrict__ coarse_hist) {
   __shared__ u32 lh[PART_MAX];
   for (u32 p = threadIdx.x; p < P; p += 256u) lh[p] = 0;
@@ -89,10 +90,20 @@ __global__ void __launch_bounds__(256) k_coarse_hist(Segs segs, MsmGeom g, u32 P
   for (u32 p = threadIdx.x; p < P; p += 256u) { const u32 v = lh[p]; if (v) atomicAdd(&coarse_hist[p], v); }
 }
 // part[pos] = lo << 24 | sign << 23 | i   (n <= 2^23), grouped by partition
-__global__ void __launch_bounds__(1024) k_partition(Segs segs, MsmGeom g, u32 P, u32 *__restrict__ coarse_cursor, u32 *__restrict__ part) {
+// Also prepares level B's path for HEAVY partitions (more than FINE_CAP entries; only skewed
+// digit distributions have them): zeroes their rows of the fine histogram and raises
+// *any_heavy, which the two k_fine_*_heavy kernels test before doing anything.
+__global__ void __launch_bounds__(1024) k_partition(Segs segs, MsmGeom g, u32 P, const u32 *__restrict__ coarse_off, u32 *__restrict__ coarse_cursor,
+                                                    u32 *__restrict__ part, u32 *__restrict__ fine_hist, u32 *__restrict__ any_heavy) {
   __shared__ u32 lh[PART_MAX];
   const u32 Bc = g.B >> 8;
   const u32 ntiles = (g.n + TILE_SCALARS - 1) / TILE_SCALARS;
+  for (u32 p = blockIdx.x; p < P; p += gridDim.x) {
+    if (coarse_off[p + 1] - coarse_off[p] > FINE_CAP) {        // block-uniform
+      if (threadIdx.x < 256u) fine_hist[p * 256u + threadIdx.x] = 0;
+      if (threadIdx.x == 0) *any_heavy = 1u;
+    }
+  }
   for (u32 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     for (u32 p = threadIdx.x; p < P; p += blockDim.x) lh[p] = 0;
     __syncthreads();
@@ -123,17 +134,65 @@ __global__ void __launch_bounds__(1024) k_partition(Segs segs, MsmGeom g, u32 P,
 __device__ __forceinline__ void fill_chunk_keys(u32 *__restrict__ chunk_key, u32 L, u32 key, u32 lo, u32 hi) {
   for (u32 t = (lo + L - 1u) / L; (u64)t * L < hi; t++) chunk_key[t] = key;
 }
-// Level B works on fixed-size TILES of the partitioned array (not one block per
-// partition), so a partition -- or a single bucket -- of any size is spread over many
-// blocks: balanced for every digit distribution (e.g. a top window that holds only the
-// recoding carry puts n/2 entries into one bucket).
-//   k_fine_hist     per tile: LDS histogram over fine buckets -> global fine histogram
-//   (k_scan_*)      -> off[], cursor[]
-//   k_fine_scatter  per tile: LDS histogram again, reserve one range per touched bucket,
-//                   scatter with LDS cursors
-// The LDS table covers FINE_BINS consecutive buckets starting at the tile's first one
-// (16 partitions); entries beyond it (only when many tiny partitions share a tile) use a
-// global atomic directly.
+// Level B, one block per partition: the partition's entries are counting-sorted by the low 8
+// key bits.  Its output range [base, base + m) is known from level A, so no global atomic and
+// no global histogram are needed: the bucket offsets off[] (and the chunk keys) come out of
+// the block's own 256-bin prefix sum, and the sorted entries are staged in LDS and written
+// as ONE contiguous, fully coalesced range (scattered 4-byte stores were the cost of a
+// tile-based version: 0.125 ms of its 0.15 ms at n = 2^20).  For a partition larger than the
+// staging buffer the block only turns the counts of k_fine_hist_heavy into offsets.
+#define FINE_THREADS 512
+__global__ void __launch_bounds__(FINE_THREADS) k_fine_sort_part(MsmGeom g, const u32 *__restrict__ coarse_off, const u32 *__restrict__ part,
+                                                                  const u32 *__restrict__ fine_hist, u32 *__restrict__ off, u32 *__restrict__ cursor,
+                                                                  u32 *__restrict__ chunk_key, u32 *__restrict__ sidx) {
+  __shared__ u32 bins[256];
+  __shared__ u32 s_out[FINE_CAP];
+  const u32 p = blockIdx.x, tid = threadIdx.x;
+  const u32 base = coarse_off[p], m = coarse_off[p + 1] - base;
+  const bool heavy = m > FINE_CAP;               // counted by k_fine_hist_heavy, scattered by k_fine_scatter_heavy
+  if (tid < 256u) bins[tid] = heavy ? fine_hist[p * 256u + tid] : 0u;
+  __syncthreads();
+  if (!heavy) {
+    for (u32 i = tid; i < m; i += FINE_THREADS) atomicAdd(&bins[part[base + i] >> 24], 1u);
+    __syncthreads();
+  }
+  // exclusive prefix over the 256 bins (threads 0..255; Hillis-Steele in place)
+  u32 cnt = 0;
+  if (tid < 256u) cnt = bins[tid];
+  for (u32 d = 1; d < 256u; d <<= 1) {
+    u32 v = 0;
+    if (tid < 256u && tid >= d) v = bins[tid - d];
+    __syncthreads();
+    if (tid < 256u) bins[tid] += v;
+    __syncthreads();
+  }
+  if (tid < 256u) {
+    const u32 start = bins[tid] - cnt;
+    const u32 key = p * 256u + tid;
+    off[key] = base + start;
+    fill_chunk_keys(chunk_key, g.L, key, base + start, base + start + cnt);
+    if (heavy) cursor[key] = base + start;
+  }
+  if (heavy) return;
+  __syncthreads();
+  if (tid < 256u) bins[tid] -= cnt;            // bins = tile-local write cursor of every bucket
+  __syncthreads();
+  for (u32 i = tid; i < m; i += FINE_THREADS) {
+    const u32 e = part[base + i];
+    s_out[atomicAdd(&bins[e >> 24], 1u)] = (e & 0x7FFFFFu) | ((e & 0x800000u) << 8);
+  }
+  __syncthreads();
+  for (u32 i = tid; i < m; i += FINE_THREADS) sidx[base + i] = s_out[i];
+}
+// Heavy partitions (skewed digit distributions, e.g. half of all scalars in {0, 1}) are spread
+// over fixed-size TILES of the partitioned array instead, so a partition -- or a single bucket
+// -- of any size is shared by many blocks:
+//   k_fine_hist_heavy     per tile: LDS histogram over fine buckets -> global fine histogram
+//   (k_fine_sort_part)    -> off[], cursor[], chunk keys of the heavy partitions' buckets
+//   k_fine_scatter_heavy  per tile: LDS histogram again, reserve one range per touched bucket,
+//                         scatter with LDS cursors
+// Both return at once when no partition is heavy.  The LDS table covers FINE_BINS consecutive
+// buckets from the tile's first one; entries beyond it use a global atomic directly.
 #define FINE_TILE 4096
 #define FINE_BINS 4096
 struct FineTile {
@@ -141,7 +200,6 @@ struct FineTile {
   u32 p_first;       // partition of position j0
 };
 __device__ __forceinline__ FineTile fine_tile_setup(const u32 *__restrict__ coarse_off, u32 P, u32 E, u32 *s_off) {
-  // s_off[0..P] = coarse_off (LDS copy for the partition walk)
   for (u32 i = threadIdx.x; i <= P; i += 256u) s_off[i] = coarse_off[i];
   __syncthreads();
   FineTile t;
@@ -153,54 +211,66 @@ __device__ __forceinline__ FineTile fine_tile_setup(const u32 *__restrict__ coar
   t.p_first = lo;
   return t;
 }
-__global__ void __launch_bounds__(256) k_fine_hist(MsmGeom g, u32 P, const u32 *__restrict__ coarse_off, const u32 *__restrict__ part,
-                                                   const u32 *__restrict__ offE, u32 *__restrict__ fine_hist) {
+__global__ void __launch_bounds__(256) k_fine_hist_heavy(MsmGeom g, u32 P, const u32 *__restrict__ coarse_off, const u32 *__restrict__ part,
+                                                         const u32 *__restrict__ offE, const u32 *__restrict__ any_heavy, u32 *__restrict__ fine_hist) {
   __shared__ u32 s_off[PART_MAX + 1];
   __shared__ u32 bins[FINE_BINS];
+  if (!*any_heavy) return;
   const u32 E = offE[0];
   if (blockIdx.x * FINE_TILE >= E) return;
   const FineTile t = fine_tile_setup(coarse_off, P, E, s_off);
   for (u32 i = threadIdx.x; i < FINE_BINS; i += 256u) bins[i] = 0;
   __syncthreads();
   const u32 g_first = t.p_first * 256u;
-  u32 pcur = t.p_first;
+  u32 pcur = t.p_first, bound = s_off[pcur + 1];
+  bool heavy = bound - s_off[pcur] > FINE_CAP;
   for (u32 j = t.j0 + threadIdx.x; j < t.j1; j += 256u) {
-    while (j >= s_off[pcur + 1]) pcur++;
-    const u32 key = pcur * 256u + (part[j] >> 24);
-    const u32 rel = key - g_first;
-    if (rel < FINE_BINS) atomicAdd(&bins[rel], 1u); else atomicAdd(&fine_hist[key], 1u);
+    while (j >= bound) { pcur++; bound = s_off[pcur + 1]; heavy = bound - s_off[pcur] > FINE_CAP; }
+    if (heavy) {
+      const u32 key = pcur * 256u + (part[j] >> 24);
+      const u32 rel = key - g_first;
+      if (rel < FINE_BINS) atomicAdd(&bins[rel], 1u); else atomicAdd(&fine_hist[key], 1u);
+    }
   }
   __syncthreads();
   for (u32 i = threadIdx.x; i < FINE_BINS; i += 256u) { const u32 v = bins[i]; if (v) atomicAdd(&fine_hist[g_first + i], v); }
 }
-__global__ void __launch_bounds__(256) k_fine_scatter(MsmGeom g, u32 P, const u32 *__restrict__ coarse_off, const u32 *__restrict__ part,
-                                                      const u32 *__restrict__ offE, u32 *__restrict__ cursor, u32 *__restrict__ sidx) {
+__global__ void __launch_bounds__(256) k_fine_scatter_heavy(MsmGeom g, u32 P, const u32 *__restrict__ coarse_off, const u32 *__restrict__ part,
+                                                            const u32 *__restrict__ offE, const u32 *__restrict__ any_heavy, u32 *__restrict__ cursor,
+                                                            u32 *__restrict__ sidx) {
   __shared__ u32 s_off[PART_MAX + 1];
   __shared__ u32 bins[FINE_BINS];
+  if (!*any_heavy) return;
   const u32 E = offE[0];
   if (blockIdx.x * FINE_TILE >= E) return;
   const FineTile t = fine_tile_setup(coarse_off, P, E, s_off);
   for (u32 i = threadIdx.x; i < FINE_BINS; i += 256u) bins[i] = 0;
   __syncthreads();
   const u32 g_first = t.p_first * 256u;
-  u32 pcur = t.p_first;
+  u32 pcur = t.p_first, bound = s_off[pcur + 1];
+  bool heavy = bound - s_off[pcur] > FINE_CAP;
   for (u32 j = t.j0 + threadIdx.x; j < t.j1; j += 256u) {
-    while (j >= s_off[pcur + 1]) pcur++;
-    const u32 rel = pcur * 256u + (part[j] >> 24) - g_first;
-    if (rel < FINE_BINS) atomicAdd(&bins[rel], 1u);
+    while (j >= bound) { pcur++; bound = s_off[pcur + 1]; heavy = bound - s_off[pcur] > FINE_CAP; }
+    if (heavy) {
+      const u32 rel = pcur * 256u + (part[j] >> 24) - g_first;
+      if (rel < FINE_BINS) atomicAdd(&bins[rel], 1u);
+    }
   }
   __syncthreads();
   // reserve this tile's range in every touched bucket: count -> base position
   for (u32 i = threadIdx.x; i < FINE_BINS; i += 256u) { const u32 v = bins[i]; if (v) bins[i] = atomicAdd(&cursor[g_first + i], v); }
   __syncthreads();
-  pcur = t.p_first;
+  pcur = t.p_first; bound = s_off[pcur + 1];
+  heavy = bound - s_off[pcur] > FINE_CAP;
   for (u32 j = t.j0 + threadIdx.x; j < t.j1; j += 256u) {
-    while (j >= s_off[pcur + 1]) pcur++;
-    const u32 e = part[j];
-    const u32 key = pcur * 256u + (e >> 24);
-    const u32 rel = key - g_first;
-    const u32 pos = (rel < FINE_BINS) ? atomicAdd(&bins[rel], 1u) : atomicAdd(&cursor[key], 1u);
-    sidx[pos] = (e & 0x7FFFFFu) | ((e & 0x800000u) << 8);
+    while (j >= bound) { pcur++; bound = s_off[pcur + 1]; heavy = bound - s_off[pcur] > FINE_CAP; }
+    if (heavy) {
+      const u32 e = part[j];
+      const u32 key = pcur * 256u + (e >> 24);
+      const u32 rel = key - g_first;
+      const u32 pos = (rel < FINE_BINS) ? atomicAdd(&bins[rel], 1u) : atomicAdd(&cursor[key], 1u);
+      sidx[pos] = (e & 0x7FFFFFu) | ((e & 0x800000u) << 8);
+    }
   }
 }
 // path 1 equivalent of the chunk-key fill: one thread per bucket
