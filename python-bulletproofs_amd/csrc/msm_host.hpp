@@ -140,10 +140,7 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, const Segs &segs, u32 w0 = 0, u3
     {
       StageTimer t(ctx, ST_SCAN, st);
       // exclusive scan of <= 2048 partition counts; total -> coarse_off[P] and off[G]
-      hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(256), 0, st, w.coarse_hist, w.P, w.bsum);
-      hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, w.bsum, 1u, w.off, g.G);
-      hipLaunchKernelGGL(k_scan_final, dim3(1), dim3(256), 0, st, w.coarse_hist, w.P, w.bsum, w.coarse_off, w.coarse_cursor);
-      HIPCHK(ctx, hipMemcpyAsync(w.coarse_off + w.P, w.off + g.G, 4, hipMemcpyDeviceToDevice, st));
+      hipLaunchKernelGGL(k_coarse_scan, dim3(1), dim3(1024), 0, st, w.coarse_hist, w.P, w.coarse_off, w.coarse_cursor, w.off + g.G);
     }
     debug_sync(ctx, "ST_SCAN", st);
     {

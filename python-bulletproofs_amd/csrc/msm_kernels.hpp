@@ -89,6 +89,26 @@ __global__ void __launch_bounds__(256) k_coarse_hist(Segs segs, MsmGeom g, u32 P
   __syncthreads();
   for (u32 p = threadIdx.x; p < P; p += 256u) { const u32 v = lh[p]; if (v) atomicAdd(&coarse_hist[p], v); }
 }
+// exclusive scan of the <= PART_MAX partition counts in one block:
+// coarse_off[0..P] (coarse_off[P] = total), coarse_cursor = copy, off[G] = total
+__global__ void __launch_bounds__(1024) k_coarse_scan(const u32 *__restrict__ coarse_hist, u32 P, u32 *__restrict__ coarse_off,
+                                                      u32 *__restrict__ coarse_cursor, u32 *__restrict__ offG) {
+  __shared__ u32 sh[1024];
+  const u32 tid = threadIdx.x;
+  const u32 a = (2u * tid < P) ? coarse_hist[2u * tid] : 0u, b = (2u * tid + 1u < P) ? coarse_hist[2u * tid + 1u] : 0u;
+  sh[tid] = a + b;
+  __syncthreads();
+  for (u32 d = 1; d < 1024u; d <<= 1) {
+    const u32 v = tid >= d ? sh[tid - d] : 0u;
+    __syncthreads();
+    sh[tid] += v;
+    __syncthreads();
+  }
+  const u32 excl = sh[tid] - (a + b);
+  if (2u * tid < P) { coarse_off[2u * tid] = excl; coarse_cursor[2u * tid] = excl; }
+  if (2u * tid + 1u < P) { coarse_off[2u * tid + 1u] = excl + a; coarse_cursor[2u * tid + 1u] = excl + a; }
+  if (tid == 1023u) { coarse_off[P] = sh[1023]; *offG = sh[1023]; }
+}
 // part[pos] = lo << 24 | sign << 23 | i   (n <= 2^23), grouped by partition
 // Also prepares level B's path for HEAVY partitions (more than FINE_CAP entries; only skewed
 // digit distributions have them): zeroes their rows of the fine histogram and raises
