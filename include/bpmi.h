@@ -63,6 +63,7 @@ int bpmi_sync(bpmi_ctx *ctx);
  *   "chunk"        sorted entries added per thread in the accumulate kernel
  *   "tail"         where the O(256) sequential window-combine tail runs: 1 device kernel,
  *                  2 host thread (default; the result is consumed on the host anyway)
+ *   "small_n"      largest n that runs on the one-launch small-MSM kernel (-1: never; default 4096)
  *   "split"        1: run one MSM as two window groups on the ctx's two lanes (default 0)
  *   "ipa_big_m"    base length from which the IPA prover folds its generators 16-way at
  *                  once instead of deferring the fold into the MSM scalars (default 2^18) */

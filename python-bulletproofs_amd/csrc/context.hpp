@@ -37,6 +37,7 @@ struct bpmi_ctx {
   int opt_c = 0;        // window bits, 0 = auto
   int opt_tail = 0;     // 0 auto, 1 device, 2 host
   int opt_chunk = 0;    // entries per thread in k_accum_l0, 0 = auto
+  int opt_small = 0;    // largest n handled by the one-launch small-MSM kernel (0 = default, -1 = never)
   int opt_split = 0;    // 1: one MSM as two window groups, one per lane (measured: +5 % at 2^20, -8 % at 2^19; off)
   int64_t opt_ipa_big = 0;   // base length from which the IPA folds generators 16-way (0 = default 2^18)
   // profiling

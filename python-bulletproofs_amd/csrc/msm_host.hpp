@@ -22,6 +22,8 @@ static u32 pick_window_bits(const bpmi_ctx *ctx, uint64_t n) {
   return (u32)(c < 4 ? 4 : c);
 }
 
+#define SMALL_N_DEFAULT 4096     // tools/tune_msm.py: one-launch kernel against the bucket pipeline
+
 struct MsmWs {
   u32 *dig, *hist, *off, *cursor, *bsum, *sidx, *buckets, *chunk_key, *coarse_hist, *coarse_off, *coarse_cursor;
   u32 P;          // partitions of sort path 2 (0 = path 1)
@@ -108,7 +110,9 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, const Segs &segs, u32 w0 = 0, u3
   if (n > BPMI_MAX_N) return fail(ctx, BPMI_E_ARG, "n exceeds BPMI_MAX_N");
   MsmGeom g;
   g.n = (u32)n;
-  g.c = pick_window_bits(ctx, n);
+  const uint64_t small_max = ctx->opt_small < 0 ? 0 : (ctx->opt_small ? (uint64_t)ctx->opt_small : SMALL_N_DEFAULT);
+  const bool small = n <= small_max && ctx->opt_c == 0 && wcount == 0;
+  g.c = small ? SMALL_C : pick_window_bits(ctx, n);
   g.W = wcount ? wcount : 255u / g.c + 1u;
   g.w0 = w0;
   g.B = 1u << (g.c - 1);
@@ -123,6 +127,26 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, const Segs &segs, u32 w0 = 0, u3
   if (rc) return rc;
   msm_layout(g, w, (char *)(lane ? ctx->ws1 : ctx->ws));
   hipStream_t st = lane_stream(ctx, lane);
+  TailOffs to;
+  to.nv = 1; to.off[0] = to.off[1] = to.off[2] = to.off[3] = 0;
+  if (small) {
+    g.nv = 1;
+    {
+      StageTimer t(ctx, ST_ACCUM, st);
+      const u32 threads = (u32)std::min<uint64_t>(256, (n + 63) / 64 * 64);
+      const u32 S = (u32)std::min<uint64_t>(64, (n + 255) / 256);
+      hipLaunchKernelGGL(k_msm_small, dim3(g.W, S), dim3(threads), 0, st, segs, g, S > 1 ? w.buckets : w.E);
+      if (S > 1) hipLaunchKernelGGL(k_small_combine, dim3(g.W), dim3(64), 0, st, w.buckets, S, w.E);
+    }
+    debug_sync(ctx, "k_msm_small", st);
+    const size_t eb = 4ull * XYZZ_WORDS * g.W;
+    rc = ensure_pin_lane(ctx, lane, eb);
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(lane ? ctx->pin1 : ctx->pin, w.E, eb, hipMemcpyDeviceToHost, st));
+    pd.active = true; pd.W = g.W; pd.nv = 1; pd.c = g.c; pd.tail = 2; pd.to = to;
+    HIPCHK(ctx, hipGetLastError());
+    return BPMI_OK;
+  }
   const u32 nblk_n = (u32)std::min<uint64_t>((n + 255) / 256, 8192);
   {
     StageTimer t(ctx, ST_MISC, st);
@@ -202,8 +226,6 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, const Segs &segs, u32 w0 = 0, u3
     }
   }
   debug_sync(ctx, "ST_SEGSCAN", st);
-  TailOffs to;
-  to.nv = 1; to.off[0] = to.off[1] = to.off[2] = to.off[3] = 0;
   {
     StageTimer t(ctx, ST_BREDUCE, st);
     if (g.B <= 256u) {

@@ -631,6 +631,72 @@ __global__ void __launch_bounds__(256) k_window_weighted_small(MsmGeom g, const 
   if (tid == 0) xyzz_store_g(Eout + (u64)w * XYZZ_WORDS, val);
 }
 
+// ---- small MSMs (n <= a few thousand): latency, not throughput, is what counts ------------
+// One dependent point addition costs 5-8 us when a wave issues alone, so the bucket pipeline
+// (sort, L sequential additions per thread, segmented scan, bucket reduction: >= 60
+// dependent additions and a dozen launches) bottoms out near 0.5 ms however small n is.
+// Here window w (8 bits, signed digits) is ONE block: every thread multiplies its point by
+// the digit |d| <= 128 (at most 7 doublings + 7 additions, Jacobian), and the block adds the
+// terms up with shuffle butterflies: depth ~ 12 + log2(n), one or two launches, E[w] to the same tail.
+#define SMALL_C 8
+// grid = (W, S): block (w, s) covers the points i = s * blockDim + tid (+ k * S * blockDim) and
+// writes its partial sum to out[w * S + s]; k_small_combine adds the S partials of a window.
+__global__ void __launch_bounds__(256) k_msm_small(Segs segs, MsmGeom g, u32 *__restrict__ out) {
+  __shared__ u32 s_val[4 * LDS_STRIDE];
+  const u32 w = blockIdx.x, tid = threadIdx.x;
+  xyzz acc;
+  xyzz_set_inf(acc);
+  for (u32 i = blockIdx.y * blockDim.x + tid; i < g.n; i += gridDim.y * blockDim.x) {
+    u32 b = 0, sign = 0;
+    for_each_digit(segs, g, i, [&](u32 ww, u32 bb, u32 sg) { if (ww == w) { b = bb; sign = sg; } });
+    affine P;
+    load_affine(P, seg_point(segs, i));
+    if (b == 0 || affine_is_inf(P)) continue;
+    jac q;
+    q.X = P.x; q.Y = P.y; fe_set_one(q.Z);
+    int top = 31 - __clz((int)b);
+    for (int bit = top - 1; bit >= 0; bit--) {
+      jac_dbl(q, q);
+      if ((b >> bit) & 1u) jac_madd(q, P.x, P.y);
+    }
+    xyzz t;
+    t.X = q.X;
+    if (sign) { fe ny; fe_neg(ny, q.Y); fe_carry(t.Y, ny); } else t.Y = q.Y;
+    fe_sqr(t.ZZ, q.Z);
+    fe_mul(t.ZZZ, t.ZZ, q.Z);
+    xyzz_add(acc, acc, t);
+  }
+  for (u32 m = 1; m < 64u; m <<= 1) {
+    xyzz other;
+    xyzz_shfl_xor(other, acc, (int)m);
+    xyzz_add(acc, acc, other);
+  }
+  const u32 wave = tid >> 6, nwaves = blockDim.x >> 6;
+  if ((tid & 63u) == 0) xyzz_store(s_val + wave * LDS_STRIDE, acc);
+  __syncthreads();
+  if (wave == 0) {
+    if (tid < nwaves) xyzz_load(acc, s_val + tid * LDS_STRIDE); else xyzz_set_inf(acc);
+    for (u32 m = 1; m < 4u; m <<= 1) {
+      xyzz other;
+      xyzz_shfl_xor(other, acc, (int)m);
+      xyzz_add(acc, acc, other);
+    }
+    if (tid == 0) xyzz_store_g(out + ((u64)w * gridDim.y + blockIdx.y) * XYZZ_WORDS, acc);
+  }
+}
+// E[w] = sum of the S (<= 64) partials of window w: one wave per window
+__global__ void __launch_bounds__(64) k_small_combine(const u32 *__restrict__ part, u32 S, u32 *__restrict__ E) {
+  const u32 w = blockIdx.x, l = threadIdx.x;
+  xyzz acc;
+  if (l < S) xyzz_load_g(acc, part + ((u64)w * S + l) * XYZZ_WORDS); else xyzz_set_inf(acc);
+  for (u32 m = 1; m < S; m <<= 1) {
+    xyzz other;
+    xyzz_shfl_xor(other, acc, (int)m);
+    xyzz_add(acc, acc, other);
+  }
+  if (l == 0) xyzz_store_g(E + (u64)w * XYZZ_WORDS, acc);
+}
+
 // ---- tail: result = sum_w 2^(c w) sum_v 2^(off[v]) E[w][v], to canonical affine -------------
 BPMI_HD void msm_tail_combine(u32 out_words[16], const u32 *E, u32 W, u32 c, const TailOffs &to) {
   // ONE Horner chain over bit positions: E[w][v] carries weight 2^(c*w + off[v]), so walking
