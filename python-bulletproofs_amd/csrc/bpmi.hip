@@ -19,6 +19,7 @@
 //   k_digit_sums (x2) / k_weighted16   sum_b b*B[w][b]: the bucket index split in two digits
 //                   twice (2 additions per element, sub-wave groups, shuffle butterflies),
 //                   then 16-term suffix scans; k_window_weighted_small for <= 256 buckets
+//   k_msm_small     n <= 4096: digit multiples per thread + butterfly sums (latency path)
 //   tail            O(256) sequential doublings: window combine + to-affine
 //                   (host thread on 4x64-bit limbs, host_tail.hpp, or the one-lane device
 //                   kernel k_tail; same Horner chain)
