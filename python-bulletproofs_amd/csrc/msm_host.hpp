@@ -151,8 +151,10 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, const Segs &segs, u32 w0 = 0, u3
   {
     StageTimer t(ctx, ST_MISC, st);
     if (w.P) HIPCHK(ctx, hipMemsetAsync(w.coarse_hist, 0, 4ull * (PART_MAX + 1), st));
-    else HIPCHK(ctx, hipMemsetAsync(w.hist, 0, 4ull * g.G, st));
-    HIPCHK(ctx, hipMemsetAsync(w.buckets, 0, 4ull * XYZZ_WORDS * g.G, st));
+    else {
+      HIPCHK(ctx, hipMemsetAsync(w.hist, 0, 4ull * g.G, st));
+      HIPCHK(ctx, hipMemsetAsync(w.buckets, 0, 4ull * XYZZ_WORDS * g.G, st));      // path 2: k_fine_sort_part clears the empty buckets
+    }
   }
   debug_sync(ctx, "ST_MISC", st);
   if (w.P) {
@@ -177,7 +179,7 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, const Segs &segs, u32 w0 = 0, u3
       const u32 nft = (u32)(((size_t)g.n * g.W + FINE_TILE - 1) / FINE_TILE);
       const u32 *any_heavy = w.coarse_hist + PART_MAX;
       hipLaunchKernelGGL(k_fine_hist_heavy, dim3(nft), dim3(256), 0, st, g, w.P, w.coarse_off, w.dig, w.coarse_off + w.P, any_heavy, w.hist);
-      hipLaunchKernelGGL(k_fine_sort_part, dim3(w.P), dim3(FINE_THREADS), 0, st, g, w.coarse_off, w.dig, w.hist, w.off, w.cursor, w.chunk_key, w.sidx);
+      hipLaunchKernelGGL(k_fine_sort_part, dim3(w.P), dim3(FINE_THREADS), 0, st, g, w.coarse_off, w.dig, w.hist, w.off, w.cursor, w.chunk_key, w.sidx, w.buckets);
       hipLaunchKernelGGL(k_fine_scatter_heavy, dim3(nft), dim3(256), 0, st, g, w.P, w.coarse_off, w.dig, w.coarse_off + w.P, any_heavy, w.cursor, w.sidx);
     }
     debug_sync(ctx, "ST_SCATTER", st);

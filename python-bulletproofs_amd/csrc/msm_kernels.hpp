@@ -164,7 +164,7 @@ __device__ __forceinline__ void fill_chunk_keys(u32 *__restrict__ chunk_key, u32
 #define FINE_THREADS 512
 __global__ void __launch_bounds__(FINE_THREADS) k_fine_sort_part(MsmGeom g, const u32 *__restrict__ coarse_off, const u32 *__restrict__ part,
                                                                   const u32 *__restrict__ fine_hist, u32 *__restrict__ off, u32 *__restrict__ cursor,
-                                                                  u32 *__restrict__ chunk_key, u32 *__restrict__ sidx) {
+                                                                  u32 *__restrict__ chunk_key, u32 *__restrict__ sidx, u32 *__restrict__ buckets) {
   __shared__ u32 bins[256];
   __shared__ u32 s_out[FINE_CAP];
   const u32 p = blockIdx.x, tid = threadIdx.x;
@@ -192,6 +192,11 @@ __global__ void __launch_bounds__(FINE_THREADS) k_fine_sort_part(MsmGeom g, cons
     off[key] = base + start;
     fill_chunk_keys(chunk_key, g.L, key, base + start, base + start + cnt);
     if (heavy) cursor[key] = base + start;
+    if (cnt == 0) {          // nobody will write this bucket: make it the identity here (no memset of all buckets)
+      xyzz inf;
+      xyzz_set_inf(inf);
+      xyzz_store_g(buckets + (u64)key * XYZZ_WORDS, inf);
+    }
   }
   if (heavy) return;
   __syncthreads();
