@@ -26,6 +26,8 @@ static u32 pick_window_bits(const bpmi_ctx *ctx, uint64_t n) {
 
 struct MsmWs {
   u32 *dig, *hist, *off, *cursor, *bsum, *sidx, *buckets, *chunk_key, *coarse_hist, *coarse_off, *coarse_cursor;
+  unsigned short *dig16;      // path 2: recoded digits, window-major
+  unsigned char *negs;        // path 2: 1 = the scalar was replaced by q - s
   u32 P;          // partitions of sort path 2 (0 = path 1)
   u32 *rec_key[2], *rec_pt[2];
   u32 *D, *D2, *E, *out;
@@ -51,6 +53,8 @@ static void msm_layout(const MsmGeom &g, MsmWs &w, char *base) {
   w.coarse_cursor = take(4ull * (PART_MAX + 1));
   w.dig = take(4ull * nW);                   // path 1: digits; path 2: partitioned entries
   w.sidx = take(4ull * nW);
+  w.dig16 = (unsigned short *)take(w.P ? 2ull * nW : 0);
+  w.negs = (unsigned char *)take(w.P ? g.n : 0);
   w.chunk_key = take(4ull * (w.rec0_max / 2 + 1));
   w.buckets = take(4ull * XYZZ_WORDS * g.G);
   w.rec_key[0] = take(4ull * w.rec0_max);
@@ -160,7 +164,7 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, const Segs &segs, u32 w0 = 0, u3
   if (w.P) {
     {
       StageTimer t(ctx, ST_DIGITS, st);
-      hipLaunchKernelGGL(k_coarse_hist, dim3(std::min<u32>(nblk_n, 512)), dim3(256), 0, st, segs, g, w.P, w.coarse_hist);
+      hipLaunchKernelGGL(k_coarse_hist, dim3(std::min<u32>(nblk_n, 512)), dim3(256), 0, st, segs, g, w.P, w.coarse_hist, w.dig16, w.negs);
     }
     debug_sync(ctx, "ST_DIGITS", st);
     {
@@ -171,9 +175,9 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, const Segs &segs, u32 w0 = 0, u3
     debug_sync(ctx, "ST_SCAN", st);
     {
       StageTimer t(ctx, ST_SCATTER, st);
-      const u32 ntiles = (g.n + TILE_SCALARS - 1) / TILE_SCALARS;
-      hipLaunchKernelGGL(k_partition, dim3(std::min<u32>(ntiles, 2048)), dim3(1024), 0, st, segs, g, w.P, w.coarse_off, w.coarse_cursor, w.dig, w.hist,
-                         w.coarse_hist + PART_MAX);
+      const u32 TS = g.n >= (1u << 19) ? PT_MAX : 4096u;          // scalars per level-A tile: long runs once there are enough tiles
+      hipLaunchKernelGGL(k_partition, dim3((g.n + TS - 1) / TS, g.W), dim3(1024), 0, st, g, w.P, TS, w.coarse_off, w.coarse_cursor, w.dig16, w.negs, w.dig,
+                         w.hist, w.coarse_hist + PART_MAX);
       // level B: one block per partition; writes off[0..G), the chunk keys and the sorted entries
       // (heavy partitions: counted and scattered by the tile kernels, which return at once when there are none)
       const u32 nft = (u32)(((size_t)g.n * g.W + FINE_TILE - 1) / FINE_TILE);

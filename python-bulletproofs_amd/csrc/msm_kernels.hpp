@@ -21,6 +21,29 @@ struct MsmGeom {
 //   s > (q-1)/2  ->  use q - s on the negated point: halves the digit range, keeps
 //   s < 2^255 so W*c >= 256 never overflows, and turns the range-proof scalar q-1
 //   (aR, rangeproof_prover.py:43-45) into the single digit -1.
+//   for_each_digit_raw reports the digit's own sign and returns whether the scalar was negated
+//   (final sign = digit sign ^ negated); a digit of magnitude B is never negative.
+template <typename F>
+__device__ __forceinline__ bool for_each_digit_raw(const Segs &segs, const MsmGeom &g, u32 i, F f) {
+  sc s;
+  load_words8(s.v, seg_scalar(segs, i));
+  const bool neg = sc_is_high(s);
+  if (neg) sc_neg(s, s);
+  u32 carry = 0;
+  const u32 mask = (1u << g.c) - 1u;
+  const u32 wend = g.w0 + g.W;
+  for (u32 w = 0; w < wend; w++) {
+    const u32 t = (s.v[0] & mask) + carry;
+#pragma unroll
+    for (int k = 0; k < 7; k++) s.v[k] = (u32)((((u64)s.v[k + 1] << 32) | s.v[k]) >> g.c);
+    s.v[7] >>= g.c;
+    u32 b, sign;
+    if (t > g.B) { b = (1u << g.c) - t; sign = 1; carry = 1; }
+    else { b = t; sign = 0; carry = 0; }
+    if (w >= g.w0) f(w - g.w0, b, b ? sign : 0u);
+  }
+  return neg;
+}
 template <typename F>
 __device__ __forceinline__ void for_each_digit(const Segs &segs, const MsmGeom &g, u32 i, F f) {
   sc s;
@@ -73,18 +96,25 @@ __global__ void __launch_bounds__(256) k_digits_hist(Segs segs, MsmGeom g, u32 *
 // (tile, partition); level B gives every partition to one block, which counting-sorts it
 // by lo entirely in LDS.  No per-element global atomic anywhere.
 #define PART_MAX 2048          // W * (B / 256) <= 2048 for every c in [10, 16]
-#define TILE_SCALARS 4096      // scalars per block-iteration in level A
 #define FINE_CAP 12288          // entries of a partition that level B sorts in one block's LDS
-__global__ void __launch_bounds__(256) k_coarse_hist(Segs segs, MsmGeom g, u32 P, u32 *__restrict__ coarse_hist) {
+// The recoded digits are kept, 16 bits each, window-major: dig16[w * n + i] = (b - 1) | digit sign << 15,
+// DIG_NONE for b = 0 (a negative digit has b <= 2^(c-1) - 1, so that code is free), and one byte
+// per scalar says whether it was negated.  Level A then reads one window of one tile as a
+// contiguous 2-byte stream instead of recoding the scalars.
+#define DIG_NONE 0xFFFFu
+__global__ void __launch_bounds__(256) k_coarse_hist(Segs segs, MsmGeom g, u32 P, u32 *__restrict__ coarse_hist, unsigned short *__restrict__ dig16,
+                                                     unsigned char *__restrict__ negs) {
   __shared__ u32 lh[PART_MAX];
   for (u32 p = threadIdx.x; p < P; p += 256u) lh[p] = 0;
   __syncthreads();
   const u32 Bc = g.B >> 8;
   const u32 stride = gridDim.x * blockDim.x;
   for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < g.n; i += stride) {
-    for_each_digit(segs, g, i, [&](u32 w, u32 b, u32) {
+    const bool neg = for_each_digit_raw(segs, g, i, [&](u32 w, u32 b, u32 dsign) {
+      dig16[(u64)w * g.n + i] = (unsigned short)(b ? ((b - 1u) | (dsign << 15)) : DIG_NONE);
       if (b) atomicAdd(&lh[w * Bc + ((b - 1u) >> 8)], 1u);
     });
+    negs[i] = neg ? 1 : 0;
   }
   __syncthreads();
   for (u32 p = threadIdx.x; p < P; p += 256u) { const u32 v = lh[p]; if (v) atomicAdd(&coarse_hist[p], v); }
@@ -109,45 +139,71 @@ __global__ void __launch_bounds__(1024) k_coarse_scan(const u32 *__restrict__ co
   if (2u * tid + 1u < P) { coarse_off[2u * tid + 1u] = excl + a; coarse_cursor[2u * tid + 1u] = excl + a; }
   if (tid == 1023u) { coarse_off[P] = sh[1023]; *offG = sh[1023]; }
 }
-// part[pos] = lo << 24 | sign << 23 | i   (n <= 2^23), grouped by partition
+// Level A.  part[pos] = lo << 24 | sign << 23 | i   (n <= 2^23), grouped by partition.
+// One block = one window of one tile of TS scalars: count the window's B/256 partitions in LDS,
+// reserve one range per partition (the only global atomics), rank the entries into an LDS
+// staging buffer in partition order and write every partition's run with consecutive lanes.
+// With TS = 16384 a run is ~128 entries = 512 contiguous bytes; the earlier version (all W
+// windows of a 4096-scalar tile per block, direct stores) produced 128-byte runs written by
+// scattered lanes and cost 323 MB of HBM writes for 67 MB of entries (profiles/, PMC).
 // Also prepares level B's path for HEAVY partitions (more than FINE_CAP entries; only skewed
 // digit distributions have them): zeroes their rows of the fine histogram and raises
 // *any_heavy, which the two k_fine_*_heavy kernels test before doing anything.
-__global__ void __launch_bounds__(1024) k_partition(Segs segs, MsmGeom g, u32 P, const u32 *__restrict__ coarse_off, u32 *__restrict__ coarse_cursor,
+#define PT_MAX 16384
+__global__ void __launch_bounds__(1024) k_partition(MsmGeom g, u32 P, u32 TS, const u32 *__restrict__ coarse_off, u32 *__restrict__ coarse_cursor,
+                                                    const unsigned short *__restrict__ dig16, const unsigned char *__restrict__ negs,
                                                     u32 *__restrict__ part, u32 *__restrict__ fine_hist, u32 *__restrict__ any_heavy) {
-  __shared__ u32 lh[PART_MAX];
-  const u32 Bc = g.B >> 8;
-  const u32 ntiles = (g.n + TILE_SCALARS - 1) / TILE_SCALARS;
-  for (u32 p = blockIdx.x; p < P; p += gridDim.x) {
+  __shared__ u32 cnt[128], excl[128], delta[128];
+  __shared__ u32 s_out[PT_MAX];
+  const u32 Bc = g.B >> 8, w = blockIdx.y, tid = threadIdx.x;
+  const u32 lin = blockIdx.y * gridDim.x + blockIdx.x, nblk = gridDim.x * gridDim.y;
+  for (u32 p = lin; p < P; p += nblk) {
     if (coarse_off[p + 1] - coarse_off[p] > FINE_CAP) {        // block-uniform
-      if (threadIdx.x < 256u) fine_hist[p * 256u + threadIdx.x] = 0;
-      if (threadIdx.x == 0) *any_heavy = 1u;
+      if (tid < 256u) fine_hist[p * 256u + tid] = 0;
+      if (tid == 0) *any_heavy = 1u;
     }
   }
-  for (u32 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    for (u32 p = threadIdx.x; p < P; p += blockDim.x) lh[p] = 0;
+  const u32 i0 = blockIdx.x * TS;
+  const u32 i1 = (i0 + TS < g.n) ? i0 + TS : g.n;
+  const unsigned short *dw = dig16 + (u64)w * g.n;
+  if (tid < 128u) cnt[tid] = 0;
+  __syncthreads();
+  for (u32 i = i0 + tid; i < i1; i += blockDim.x) {
+    const u32 code = dw[i];
+    if (code != DIG_NONE) atomicAdd(&cnt[(code & 0x7FFFu) >> 8], 1u);
+  }
+  __syncthreads();
+  // exclusive prefix over the (<= 128) partition counts of this window
+  u32 c = 0;
+  if (tid < 128u) { c = tid < Bc ? cnt[tid] : 0u; excl[tid] = c; }
+  __syncthreads();
+  for (u32 d = 1; d < 128u; d <<= 1) {
+    u32 v = 0;
+    if (tid < 128u && tid >= d) v = excl[tid - d];
     __syncthreads();
-    const u32 i0 = tile * TILE_SCALARS;
-    const u32 i1 = (i0 + TILE_SCALARS < g.n) ? i0 + TILE_SCALARS : g.n;
-    for (u32 i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
-      for_each_digit(segs, g, i, [&](u32 w, u32 b, u32) {
-        if (b) atomicAdd(&lh[w * Bc + ((b - 1u) >> 8)], 1u);
-      });
+    if (tid < 128u) excl[tid] += v;
+    __syncthreads();
+  }
+  if (tid < 128u) {
+    const u32 start = excl[tid] - c;
+    excl[tid] = start;
+    cnt[tid] = start;                                          // LDS write cursor of the partition
+    if (c) delta[tid] = atomicAdd(&coarse_cursor[w * Bc + tid], c) - start;
+  }
+  __syncthreads();
+  for (u32 i = i0 + tid; i < i1; i += blockDim.x) {
+    const u32 code = dw[i];
+    if (code != DIG_NONE) {
+      const u32 k = code & 0x7FFFu;
+      s_out[atomicAdd(&cnt[k >> 8], 1u)] = ((k & 255u) << 24) | (((code >> 15) ^ negs[i]) << 23) | i;
     }
-    __syncthreads();
-    // reserve this tile's range in every partition: count -> base position
-    for (u32 p = threadIdx.x; p < P; p += blockDim.x) { const u32 v = lh[p]; if (v) lh[p] = atomicAdd(&coarse_cursor[p], v); }
-    __syncthreads();
-    for (u32 i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
-      for_each_digit(segs, g, i, [&](u32 w, u32 b, u32 sign) {
-        if (b) {
-          const u32 k = b - 1u;
-          const u32 pos = atomicAdd(&lh[w * Bc + (k >> 8)], 1u);
-          part[pos] = ((k & 255u) << 24) | (sign << 23) | i;
-        }
-      });
-    }
-    __syncthreads();
+  }
+  __syncthreads();
+  // partition p's run: staged at [excl[p], cnt[p]), goes to part[delta[p] + j]
+  const u32 wave = tid >> 6, lane = tid & 63u, nwaves = blockDim.x >> 6;
+  for (u32 p = wave; p < Bc; p += nwaves) {
+    const u32 lo = excl[p], hi = cnt[p], dl = delta[p];
+    for (u32 j = lo + lane; j < hi; j += 64u) part[dl + j] = s_out[j];
   }
 }
 // chunk_key[t] = bucket that contains sorted position t * L (for every chunk start inside [lo, hi))

@@ -210,3 +210,28 @@ def test_msm_sliced_above_2e23(gp):
     finally:
         d_pts.free()
         d_e.free()
+
+
+@pytest.mark.parametrize("c", [10, 13, 16])
+def test_msm_digit_of_magnitude_B_both_signs(gp, c):
+    """Signed recoding edge: a digit of magnitude exactly B = 2^(c-1) is always a positive digit,
+    but the scalar may have been replaced by q - s, so the ENTRY's sign can be either; the sort's
+    16-bit digit code keeps the two signs apart (digit sign in the code, negation flag per scalar)."""
+    eng = gp.engine()
+    n = 3000
+    B = 1 << (c - 1)
+    pts, _ = gp.rand_points(n, 17)
+    rnd = random.Random(c)
+    es = []
+    for i in range(n):
+        r = 0
+        for w in range(rnd.randrange(1, 6)):
+            r |= (B if rnd.random() < 0.7 else rnd.randrange(1 << c)) << (c * rnd.randrange(0, 200 // c))
+        r %= Q // 2
+        es.append(r if i % 2 else Q - r)              # odd i: digits of r; even i: negated scalar, same digits
+    pb, sb = cbind.pack_points(pts), cbind.pack_scalars(es)
+    try:
+        eng.set_option("window_bits", c)
+        assert eng.msm_bytes(pb, sb, n) == cbind.msm_bytes(pb, sb, n)
+    finally:
+        eng.set_option("window_bits", 0)
