@@ -7,14 +7,13 @@
 // ------------------------------------------------------------------------------------
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-// Window bits from the tools/tune_msm.py sweeps on MI355X (profiles/r01_tune_msm.txt).
+// Window bits from the tools/tune_msm.py sweeps on MI355X (profiles/r01_tune_msm_after_sort_and_reduce_rewrites.txt).
 // Besides the usual bucket-count trade-off, windows whose TOP window holds only a few
 // bits (255 mod c small: c = 15, 14, 12, 11) concentrate a whole window's digits in a
-// handful of buckets, so c in {8, 13, 16} (top window 7, 8, 15 bits) are preferred.
+// handful of buckets, so c in {8, 16} (top window 7, 15 bits) are preferred.
 static u32 pick_window_bits(const bpmi_ctx *ctx, uint64_t n) {
   if (ctx->opt_c >= 2 && ctx->opt_c <= 16) return (u32)ctx->opt_c;
-  if (n >= (1u << 18)) return 16;
-  if (n >= (1u << 16)) return 13;
+  if (n >= (1u << 15)) return 16;      // the LDS sort and the two-digit bucket reduction made 2^15 buckets per window cheap
   if (n >= (1u << 10)) return 8;
   u32 lg = 0;
   while ((1ull << (lg + 1)) <= n) lg++;
@@ -121,7 +120,7 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, const Segs &segs, u32 w0 = 0, u3
   g.w0 = w0;
   g.B = 1u << (g.c - 1);
   g.G = g.W * g.B;
-  g.L = ctx->opt_chunk > 0 ? (u32)ctx->opt_chunk : (n >= (1u << 19) ? 64u : (n >= (1u << 16) ? 32u : 16u));   // tools/tune_msm.py sweeps
+  g.L = ctx->opt_chunk > 0 ? (u32)ctx->opt_chunk : (n >= (1u << 19) ? 64u : (n >= (1u << 18) ? 32u : 16u));   // tools/tune_msm.py sweeps
   g.nv = (g.B <= 256u) ? 1u : 4u;                  // partial sums per window handed to the tail
   MsmWs w;
   msm_layout(g, w, nullptr);
