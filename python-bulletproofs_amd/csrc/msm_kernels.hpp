@@ -526,9 +526,13 @@ __global__ void __launch_bounds__(256) k_segscan(MsmGeom g, const u32 *__restric
   s_key[tid] = key;
   __syncthreads();
   for (u32 d = 1; d < 256; d <<= 1) {
+    // the records are in bucket order, so equal keys are contiguous: when no thread of the block
+    // finds its key at distance d, none will at 2d, 4d, ... (uniform scalars stop after d = 1 or 2)
+    const bool act = valid && tid >= d && s_key[tid - d] == key;
+    if (!__syncthreads_or(act)) break;
     xyzz_store(s_val + tid * LDS_STRIDE, val);
     __syncthreads();
-    if (valid && tid >= d && s_key[tid - d] == key) {
+    if (act) {
       xyzz other;
       xyzz_load(other, s_val + (tid - d) * LDS_STRIDE);
       xyzz_add(val, other, val);
