@@ -32,6 +32,8 @@ if REPO not in sys.path:
 Q = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 ALGO_BYTES_PER_PAIR = 96
+MULS_PER_MADD = 10.5           # XYZZ mixed addition 8M + 2S plus its carries/subtractions, in multiplication-equivalents
+FE_MUL_PEAK_G = 171.0          # measured fe_mul ceiling, G multiplications/s (profiles/r01_fe_microbench.txt)
 
 
 def synth_scalars(n, seed):
@@ -145,6 +147,7 @@ def main():
     acc_avg_s = acc_ms / max(acc_calls, 1) / 1e3
     achieved_gbs = ALGO_BYTES_PER_PAIR * n / acc_avg_s / 1e9 if acc_avg_s > 0 else 0.0
     stages = {k: round(v[0] / max(v[1], 1), 4) for k, v in prof.items() if v[1]}
+    windows = 16 if n >= (1 << 15) else 32          # pick_window_bits (csrc/msm_host.hpp): c = 16 -> 16 windows
 
     out = {
         "metric": "Pippenger MSM scalar-point pairs/sec at n=2^20",
@@ -167,6 +170,14 @@ def main():
                      "traffic_source": "profiles/r01_pmc_traffic_msm_n2e20.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)",
                      "kernel": "k_accum_l0 (msm_accumulate)", "kernel_avg_ms": acc_avg_s * 1e3,
                      "note": "integer-ALU bound path: 96 algorithmic B/pair vs ~1.8e5 integer ops/pair"},
+        # the honest utilisation figure for this path (SURVEY section 8d asks for it beside the prescribed
+        # HBM fraction): field multiplications per second of the dominant kernel against the
+        # measured ceiling of the same fe_mul in isolation (tools/fe_microbench.hip)
+        "alu_roofline": {"kernel": "k_accum_l0", "unit": "G field-mul/s",
+                         "achieved": n * windows * MULS_PER_MADD / acc_avg_s / 1e9 if acc_avg_s > 0 else 0.0,
+                         "peak": FE_MUL_PEAK_G, "frac": (n * windows * MULS_PER_MADD / acc_avg_s / 1e9 / FE_MUL_PEAK_G) if acc_avg_s > 0 else 0.0,
+                         "work": "%d windows x n mixed additions x %.1f multiplication-equivalents (8M + 2S)" % (windows, MULS_PER_MADD),
+                         "peak_source": "profiles/r01_fe_microbench.txt (9x29-bit limbs, v_mad_u64_u32)"},
         "stage_ms_per_msm": stages,
         "hip_event_ms_per_step": ev_ms / args.steps,
         "input_setup_s": round(t_in, 2),
