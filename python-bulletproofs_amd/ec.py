@@ -38,7 +38,7 @@ secp256k1 = Curve(
 
 
 class Point:
-    __slots__ = ("x", "y", "curve")
+    __slots__ = ("x", "y", "curve", "_le")        # points are immutable by convention; _le caches the wire form
     IDENTITY_ELEMENT = None
 
     def __init__(self, x, y, curve=secp256k1):
@@ -48,12 +48,14 @@ class Point:
         elif not curve.is_point_on_curve((x, y)):
             raise ValueError("coordinates are not on curve %s" % curve)
         self.x, self.y, self.curve = x, y, curve
+        self._le = None
 
     @classmethod
     def _raw(cls, x, y):
         pt = cls.__new__(cls)
         pt.x, pt.y = x, y
         pt.curve = secp256k1 if (x or y) else None
+        pt._le = None
         return pt
 
     # -- representation-level ------------------------------------------------
@@ -69,11 +71,16 @@ class Point:
         return Point._raw(self.x, (-self.y) % self.curve.p)
 
     def to_le64(self):
-        return self.x.to_bytes(32, "little") + self.y.to_bytes(32, "little")
+        b = self._le
+        if b is None:
+            b = self._le = self.x.to_bytes(32, "little") + self.y.to_bytes(32, "little")
+        return b
 
     @classmethod
     def from_le64(cls, b):
-        return cls._raw(int.from_bytes(b[:32], "little"), int.from_bytes(b[32:64], "little"))
+        pt = cls._raw(int.from_bytes(b[:32], "little"), int.from_bytes(b[32:64], "little"))
+        pt._le = bytes(b[:64])
+        return pt
 
     # -- group operations: on the GPU ----------------------------------------------
     def __add__(self, other):
