@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised differential test of the HIP MSM against the C oracle: random sizes, scalar
 shapes (uniform, tiny, near q/2 and q, repeated, zero), point shapes (duplicates, negated
-pairs, identities) and engine options (window bits, chunk length, tail placement).
+pairs, identities) and engine options (window bits, chunk length, tail placement, window-group
+split, small-MSM threshold); a few percent of the cases are large enough for the LDS sort path.
   python tools/fuzz_msm.py [seconds]"""
 import os
 import random
@@ -42,6 +43,11 @@ t0 = time.time()
 cases = fails = 0
 while time.time() - t0 < budget:
     n = rnd.choice((1, 2, 3, rnd.randrange(1, 64), rnd.randrange(1, 1500), rnd.randrange(1, 6000)))
+    r = rnd.random()
+    if r < 0.04:
+        n = rnd.randrange(30000, 90000)            # default options: c = 16, LDS sort, 4096-scalar level-A tiles
+    elif r < 0.05:
+        n = rnd.randrange(1 << 19, (1 << 19) + 70000)   # 16384-scalar level-A tiles, L = 64
     pts = [rnd.choice(pool) for _ in range(n)]
     shape = rnd.randrange(6)
     if shape == 1:
@@ -55,7 +61,11 @@ while time.time() - t0 < budget:
     if rnd.random() < 0.2:
         es = [es[0]] * n
     opts = {"window_bits": rnd.choice((0, 0, 0, 2, 4, 5, 7, 8, 9, 10, 11, 13, 16)),
-            "chunk": rnd.choice((0, 0, 1, 2, 5, 16, 33, 64, 200)), "tail": rnd.choice((0, 1, 2))}
+            "chunk": rnd.choice((0, 0, 1, 2, 5, 16, 33, 64, 200)), "tail": rnd.choice((0, 1, 2)),
+            "split": rnd.choice((0, 0, 0, 1)), "small_n": rnd.choice((0, 0, -1, 100, 65536))}
+    if n > 20000:
+        opts["window_bits"] = rnd.choice((0, 0, 13, 16))
+        opts["chunk"] = rnd.choice((0, 0, 16, 64))
     for k, v in opts.items():
         eng.set_option(k, v)
     pb, sb = cbind.pack_points(pts), cbind.pack_scalars(es)
@@ -65,7 +75,7 @@ while time.time() - t0 < budget:
     if got != want:
         fails += 1
         print("MISMATCH n=%d shape=%d kind=%d opts=%s seed=%d case=%d" % (n, shape, kind, opts, seed, cases), flush=True)
-for k in ("window_bits", "chunk", "tail"):
+for k in ("window_bits", "chunk", "tail", "split", "small_n"):
     eng.set_option(k, 0)
 print("fuzz: %d cases, %d mismatches, %.0f s, seed %d" % (cases, fails, time.time() - t0, seed))
 sys.exit(1 if fails else 0)
