@@ -92,6 +92,7 @@ void bpmi_ctx_destroy(bpmi_ctx *ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   for (auto &e : ctx->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+  for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
   if (ctx->ws) (void)hipFree(ctx->ws);
   if (ctx->stage_in) (void)hipFree(ctx->stage_in);
   if (ctx->pin) (void)hipHostFree(ctx->pin);
@@ -715,7 +716,7 @@ static void prof_drain(bpmi_ctx *ctx) {
   for (auto &e : ctx->evs) {
     float ms = 0;
     if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) { ctx->prof_ms[e.stage] += ms; ctx->prof_calls[e.stage]++; }
-    (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b);
+    ctx->ev_pool.push_back(e.a); ctx->ev_pool.push_back(e.b);
   }
   ctx->evs.clear();
 }

@@ -43,6 +43,7 @@ struct bpmi_ctx {
   // profiling
   bool prof = false;
   std::vector<EvPair> evs;
+  std::vector<hipEvent_t> ev_pool;      // recycled timing events (creating one costs more than recording it)
   double prof_ms[BPMI_NSTAGES] = {0};
   uint64_t prof_calls[BPMI_NSTAGES] = {0};
 };
@@ -74,9 +75,15 @@ struct StageTimer {
   bpmi_ctx *ctx; int stage; hipStream_t stream; hipEvent_t a = nullptr, b = nullptr;
   StageTimer(bpmi_ctx *c, int s, hipStream_t st = nullptr) : ctx(c), stage(s), stream(st ? st : c->stream) {
     if (ctx->prof) {
-      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
+      a = take(); b = take();
+      if (!a || !b) { a = b = nullptr; return; }
       (void)hipEventRecord(a, stream);
     }
+  }
+  hipEvent_t take() {
+    if (!ctx->ev_pool.empty()) { hipEvent_t e = ctx->ev_pool.back(); ctx->ev_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    return hipEventCreate(&e) == hipSuccess ? e : nullptr;
   }
   ~StageTimer() {
     if (ctx->prof && a) { (void)hipEventRecord(b, stream); ctx->evs.push_back({stage, a, b}); }
