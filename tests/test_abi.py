@@ -63,3 +63,20 @@ def test_product_never_imports_oracle():
                 src = open(os.path.join(root, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
                 assert "bp_oracle" not in src, f
+
+
+def test_header_is_plain_c99(tmp_path):
+    """include/bpmi.h is the drop-in boundary: it must compile as C (no C++ or torch types) and a C
+    program must link against libbpmi.so through it (no GPU needed for either)."""
+    import subprocess
+    src = tmp_path / "use_abi.c"
+    src.write_text('#include "bpmi.h"\n#include <stdio.h>\n'
+                   'int main(void) { printf("%d %d\\n", bpmi_version(), BPMI_NSTAGES); return bpmi_last_error(0) ? 0 : 1; }\n')
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    inc = os.path.join(repo, "include")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc, "-fsyntax-only", str(src)])
+    lib = os.path.join(repo, "python-bulletproofs_amd", "libbpmi.so")
+    if os.path.exists(lib):
+        exe = tmp_path / "use_abi"
+        subprocess.check_call(["gcc", "-std=c99", "-I", inc, str(src), "-o", str(exe), lib, "-Wl,-rpath," + os.path.dirname(lib),
+                               "-Wl,--allow-shlib-undefined"])
