@@ -125,27 +125,16 @@ class ShardedFastNIProver2:
         else:
             self.init_transcript_length = 1
 
-    def _rounds(self, state, xs, Ls, Rs, gather):
-        from .ec import Point
-        q = self.group.q
-        while len(state) > 1:
-            Lb, Rb = state.round_LR()
-            if gather:
-                parts = all_gather_bytes(Lb + Rb, self.pg)
-                k = len(parts)
-                Lb = self.engine.ec_sum_bytes(b"".join(p[:64] for p in parts), k)
-                Rb = self.engine.ec_sum_bytes(b"".join(p[64:] for p in parts), k)
-            L, R = Point.from_le64(Lb), Point.from_le64(Rb)
-            Ls.append(L)
-            Rs.append(R)
-            self.transcript.add_list_points([L, R])
-            x = self.transcript.get_modp(q)
-            xs.append(x)
-            self.transcript.add_number(x)
-            state.fold(x.x, x.inv().x)
+    def _combine(self, Lb, Rb):
+        """This rank's partial L, R -> the global ones: ONE all_gather of 128 bytes per rank."""
+        parts = all_gather_bytes(Lb + Rb, self.pg)
+        k = len(parts)
+        return (self.engine.ec_sum_bytes(b"".join(p[:64] for p in parts), k),
+                self.engine.ec_sum_bytes(b"".join(p[64:] for p in parts), k))
 
     def prove(self):
         from .ec import pack_points, pack_scalars
+        from .innerproduct._rounds import run_rounds
         from .innerproduct.inner_product_verifier import Proof2
         from .utils.utils import ModP
         q = self.group.q
@@ -158,7 +147,7 @@ class ShardedFastNIProver2:
                                    None if self.h_scale is None else pack_scalars(self.h_scale, q))
         xs, Ls, Rs = [], [], []
         try:
-            self._rounds(state, xs, Ls, Rs, gather=self.world > 1)
+            run_rounds(state, self.transcript, q, xs, Ls, Rs, self._combine if self.world > 1 else None)
             if self.world > 1:
                 g1, h1, a1, b1 = state.export()           # this rank's last element = global index `rank`
                 state.close()
@@ -166,7 +155,7 @@ class ShardedFastNIProver2:
                 state = eng.ipa_create(b"".join(p[:64] for p in parts), b"".join(p[64:128] for p in parts),
                                        b"".join(p[128:160] for p in parts), b"".join(p[160:192] for p in parts),
                                        self.world, ub)
-                self._rounds(state, xs, Ls, Rs, gather=False)
+                run_rounds(state, self.transcript, q, xs, Ls, Rs)
             a, b = state.finish()
         finally:
             state.close()

@@ -6,10 +6,11 @@ Fiat-Shamir hash, and x, x^-1 (32 bytes each) go down for the fold."""
 from typing import Optional
 
 from .. import engine as _engine
-from ..ec import Point, pack_points, pack_scalars
+from ..ec import pack_points, pack_scalars
 from ..pippenger import PipSECP256k1
 from ..utils.transcript import Transcript
 from ..utils.utils import ModP
+from ._rounds import run_rounds
 from .inner_product_verifier import Proof1, Proof2
 
 
@@ -60,16 +61,7 @@ class FastNIProver2:
                                None if self.h_scale is None else pack_scalars(self.h_scale, q))
         xs, Ls, Rs = [], [], []
         try:
-            while len(state) > 1:
-                Lb, Rb = state.round_LR()                      # reference :96-99
-                L, R = Point.from_le64(Lb), Point.from_le64(Rb)
-                Ls.append(L)
-                Rs.append(R)
-                self.transcript.add_list_points([L, R])        # :102
-                x = self.transcript.get_modp(q)                # :104
-                xs.append(x)
-                self.transcript.add_number(x)
-                state.fold(x.x, x.inv().x)                     # :107-110
+            run_rounds(state, self.transcript, q, xs, Ls, Rs)
             a, b = state.finish()
         finally:
             state.close()

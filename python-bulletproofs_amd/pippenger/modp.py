@@ -1,51 +1,58 @@
-"""Counting test-group element (reference: src/pippenger/modp.py:1-53): an integer mod p
-whose class-level `num_of_mult` counts every multiplication."""
+"""A group element for TESTING multi-exponentiation algorithms: an integer modulo p that counts,
+in the class attribute `num_of_mult`, how many multiplications have been performed on such
+elements since the last `reset()` (reference: src/pippenger/modp.py:1-53).  The reference's
+benchmark notebook uses the count to compare Pippenger with the naive product; here the same
+count pins the oracle's restatement of the reference algorithm (tests/golden/modp_group.json).
+
+Semantics kept from the reference: mixing with a plain int is allowed and leaves the result
+UNREDUCED (only ModP-ModP operations reduce), `**` is square-and-multiply built from counted
+multiplications, equality compares value and modulus."""
+import operator
 
 
 class ModP:
     num_of_mult = 0
 
+    def __init__(self, x, p):
+        self.x = x
+        self.p = p
+
     @classmethod
     def reset(cls):
         cls.num_of_mult = 0
 
-    def __init__(self, x, p):
-        self.x, self.p = x, p
+    # one place for the int / ModP distinction
+    def _combine(self, other, op):
+        if isinstance(other, int):
+            return ModP(op(self.x, other), self.p)
+        assert other.p == self.p
+        return ModP(op(self.x, other.x) % self.p, self.p)
 
-    def _other(self, y):
-        if isinstance(y, int):
-            return y, False
-        assert self.p == y.p
-        return y.x, True
+    def __add__(self, other):
+        return self._combine(other, operator.add)
 
-    def __add__(self, y):
-        v, red = self._other(y)
-        return ModP((self.x + v) % self.p if red else self.x + v, self.p)
+    def __sub__(self, other):
+        return self._combine(other, operator.sub)
 
-    def __sub__(self, y):
-        v, red = self._other(y)
-        return ModP((self.x - v) % self.p if red else self.x - v, self.p)
+    def __mul__(self, other):
+        ModP.num_of_mult += 1
+        return self._combine(other, operator.mul)
 
-    def __mul__(self, y):
-        type(self).num_of_mult += 1
-        v, red = self._other(y)
-        return ModP((self.x * v) % self.p if red else self.x * v, self.p)
-
-    def __pow__(self, n):
-        acc = ModP(self.x, self.p)
-        for bit in bin(n)[3:]:          # square-and-multiply so the counter sees each mult
-            acc = acc * acc
+    def __pow__(self, exponent):
+        result = ModP(self.x, self.p)
+        for bit in format(exponent, "b")[1:]:
+            result = result * result
             if bit == "1":
-                acc = acc * self
-        return acc
+                result = result * self
+        return result
 
     def __neg__(self):
         return ModP(self.p - self.x, self.p)
 
-    def __eq__(self, y):
-        return self.x == y.x and self.p == y.p
+    def __eq__(self, other):
+        return (self.x, self.p) == (other.x, other.p)
 
-    def __repr__(self):
-        return str(self.x)
+    def __str__(self):
+        return "%d" % self.x
 
-    __str__ = __repr__
+    __repr__ = __str__
