@@ -49,6 +49,7 @@ using namespace bpmi;
 #include "scalar_kernels.hpp"
 #include "host_tail.hpp"
 #include "msm_host.hpp"
+#include "rp_batch_host.hpp"
 
 // ------------------------------------------------------------------------------------
 // C-ABI
@@ -708,6 +709,45 @@ void bpmi_ipa_destroy(bpmi_ipa *st) {
   (void)hipStreamSynchronize(st->ctx->stream);
   (void)hipFree(st->block);
   delete st;
+}
+
+// ---- batch verification of range proofs: host-side preparation ---------------------------------------
+int bpmi_rp_batch_prepare(uint32_t n_gens, uint64_t n_proofs, const uint8_t *blobs, const uint64_t *blob_off, const uint8_t *weights,
+                          int threads, uint8_t *v_scalars, uint8_t *pt_scalars, uint8_t *shared, uint8_t *comp_out, int64_t *first_bad) {
+  if (!blobs || !blob_off || !weights || !v_scalars || !pt_scalars || !shared || !first_bad) return BPMI_E_ARG;
+  if (n_gens < 2 || (n_gens & (n_gens - 1)) || n_gens > 65536) return BPMI_E_ARG;
+  uint32_t k = 0;
+  while ((1u << k) < n_gens) k++;
+  *first_bad = -1;
+  const size_t nacc = 5 + 2 * (size_t)n_gens;
+  if (threads < 1) threads = 1;
+  if ((uint64_t)threads > n_proofs) threads = n_proofs ? (int)n_proofs : 1;
+  std::vector<uint64_t> pt_off(n_proofs + 1);
+  for (uint64_t g = 0; g <= n_proofs; g++) pt_off[g] = g * (6 + 2 * (uint64_t)k);
+  std::vector<std::vector<rp::Sq>> acc(threads, std::vector<rp::Sq>(nacc, rp::q_small(0)));
+  std::vector<uint64_t> bad(threads, UINT64_MAX);
+  auto work = [&](int t) {
+    const uint64_t lo = n_proofs * t / threads, hi = n_proofs * (t + 1) / threads;
+    // sub-chunks bound the scratch memory and keep one modular inversion per ~512 proofs
+    for (uint64_t a = lo; a < hi; a += 512) {
+      const uint64_t b = a + 512 < hi ? a + 512 : hi;
+      uint64_t bd = UINT64_MAX;
+      if (!rp::run_chunk(n_gens, k, blobs, blob_off, weights, a, b, pt_off.data(), v_scalars, pt_scalars, comp_out, acc[t].data(), &bd)) { bad[t] = bd; return; }
+    }
+  };
+  if (threads == 1) work(0);
+  else {
+    std::vector<std::thread> th;
+    for (int t = 0; t < threads; t++) th.emplace_back(work, t);
+    for (auto &x : th) x.join();
+  }
+  for (int t = 0; t < threads; t++) if (bad[t] != UINT64_MAX && (*first_bad < 0 || (int64_t)bad[t] < *first_bad)) *first_bad = (int64_t)bad[t];
+  for (size_t i = 0; i < nacc; i++) {
+    rp::Sq sum = rp::q_small(0);
+    for (int t = 0; t < threads; t++) rp::q_add(sum, sum, acc[t][i]);
+    rp::q_to_le(shared + 32 * i, sum);
+  }
+  return BPMI_OK;
 }
 
 // ---- profiling -----------------------------------------------------------------------------------

@@ -1,0 +1,86 @@
+"""bpmi_rp_batch_prepare (csrc/rp_batch_host.hpp, host code of libbpmi) against its Python twin
+BatchRangeVerifier.add: the same weights in, the same numbers out -- every per-proof MSM scalar and
+every shared-generator coefficient -- and the same verdict on corrupted proofs.  No GPU involved:
+decompression is the oracle's, the MSM is the C oracle's."""
+import random
+
+import pytest
+
+import bulletproofs_amd  # noqa: F401
+from bulletproofs_amd.rangeproofs.batch import BatchRangeVerifier
+from bulletproofs_amd.rangeproofs.codec import proof_to_bytes
+
+from helpers import Q
+from test_batch_verify_cpu import make_batch, oracle_decompress, oracle_msm
+
+
+def both(b, Vs, blobs, proofs, seed):
+    r1, r2 = random.Random(seed), random.Random(seed)
+    py = BatchRangeVerifier(b["g"], b["h"], b["gs"], b["hs"], b["u"], msm=oracle_msm, rng=lambda: r1.getrandbits(320))
+    for V, pr in zip(Vs, proofs):
+        py.add(V, pr)
+    nat = BatchRangeVerifier(b["g"], b["h"], b["gs"], b["hs"], b["u"], msm=oracle_msm, rng=lambda: r2.getrandbits(320))
+    nat.add_wire_native(Vs, blobs, decompress=oracle_decompress, threads=3)
+    return py, nat
+
+
+@pytest.mark.parametrize("n", [2, 8, 64])
+def test_native_prepare_equals_python_add(n):
+    b = make_batch(7, n=n)
+    blobs = [proof_to_bytes(pr) for pr in b["proofs"]]
+    py, nat = both(b, b["Vs"], blobs, b["proofs"], seed=n)
+    assert (py.c_g, py.c_h, py.c_u, py._gs_const, py._hs_const) == (nat.c_g, nat.c_h, nat.c_u, nat._gs_const, nat._hs_const)
+    assert [v % Q for v in py.c_gs] == [v % Q for v in nat.c_gs]
+    assert [v % Q for v in py.c_hs] == [v % Q for v in nat.c_hs]
+    k = n.bit_length() - 1
+    per = 7 + 2 * k
+    want = [v % Q for v in py._scs]                   # per proof: V T1 T2 A S P_new u_new Ls Rs
+    v_sc, p_sc = nat._raw_scs
+    for j in range(7):
+        got_v = int.from_bytes(v_sc[32 * j: 32 * j + 32], "little")
+        got_p = [int.from_bytes(p_sc[32 * (j * (per - 1) + t): 32 * (j * (per - 1) + t) + 32], "little") for t in range(per - 1)]
+        w = want[per * j: per * (j + 1)]
+        # native order of the points: T1 T2 A S u_new P_new Ls Rs
+        assert got_v == w[0]
+        assert got_p[:4] == w[1:5] and got_p[4] == w[6] and got_p[5] == w[5] and got_p[6:] == w[7:]
+    assert py.verify() is True and nat.verify() is True
+
+
+def test_native_prepare_rejects_what_python_rejects():
+    b = make_batch(4, n=8)
+    blobs = [proof_to_bytes(pr) for pr in b["proofs"]]
+    k = 3
+    ints_end = 6 + 32 * (5 + k)
+    pts_end = ints_end + 33 * (6 + 2 * k)
+    rnd = random.Random(1)
+    cases = 0
+    for trial in range(120):
+        j = rnd.randrange(4)
+        bad = bytearray(blobs[j])
+        region = rnd.choice(("scalar", "transcript", "header", "tail"))
+        if region == "scalar":
+            pos = rnd.randrange(6, ints_end)
+        elif region == "transcript":
+            pos = rnd.randrange(pts_end, len(bad))
+        elif region == "header":
+            pos = rnd.randrange(0, 6)
+        else:
+            pos = len(bad) - 1 - rnd.randrange(0, 40)
+        bad[pos] ^= 1 << rnd.randrange(8)
+        mutated = blobs[:j] + [bytes(bad)] + blobs[j + 1:]
+        nat = BatchRangeVerifier(b["g"], b["h"], b["gs"], b["hs"], b["u"], msm=oracle_msm)
+        try:
+            nat.add_wire_native(b["Vs"], mutated, decompress=oracle_decompress, threads=2)
+            nat_ok = nat.verify()
+        except Exception as e:
+            nat_ok = str(e)
+        py = BatchRangeVerifier(b["g"], b["h"], b["gs"], b["hs"], b["u"], msm=oracle_msm)
+        try:
+            py.add_wire(b["Vs"], mutated, decompress=oracle_decompress)
+            py_ok = py.verify()
+        except Exception:
+            py_ok = "rejected"
+        assert (nat_ok is True) == (py_ok is True), (trial, region, pos, nat_ok, py_ok)
+        assert nat_ok is not True          # every single-bit flip here must be caught
+        cases += 1
+    assert cases == 120

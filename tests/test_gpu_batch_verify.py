@@ -189,3 +189,24 @@ def test_batch_wire_path(gp, batch, workers):
             bv.verify()
     finally:
         bv.stop_workers()
+
+
+def test_batch_wire_path_native(gp, batch):
+    """add_wire_native: GPU decompression, per-proof host work in libbpmi (transcript checks and
+    scalars), one MSM; mixed with add() in the same verifier; altered wire bytes are rejected."""
+    from bulletproofs_amd.rangeproofs import BatchRangeVerifier
+    from bulletproofs_amd.rangeproofs.codec import proof_to_bytes
+    b = batch
+    blobs = [proof_to_bytes(pr) for pr in b["proofs"]]
+    bv = BatchRangeVerifier(b["g"], b["h"], b["gs"], b["hs"], b["u"])
+    bv.add_wire_native(b["Vs"], blobs, threads=2)
+    bv.add(b["Vs"][0], b["proofs"][0])
+    assert bv.count == 7 and bv.verify() is True
+    k = blobs[4][5]
+    for off in (6 + 32 * 1 + 31, 6 + 32 * (5 + k), 6 + 32 * (5 + k) + 33 * 3 + 20, len(blobs[4]) - 2):   # mu, sign of T1, x of S, last x
+        bad = bytearray(blobs[4])
+        bad[off] ^= 1
+        bv.reset()
+        with pytest.raises(Exception, match="Proof invalid"):
+            bv.add_wire_native(b["Vs"], blobs[:4] + [bytes(bad)] + blobs[5:], threads=3)
+            bv.verify()

@@ -26,6 +26,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--log-batch", type=int, default=14)
     ap.add_argument("--distinct", type=int, default=64)
+    ap.add_argument("--native", type=int, default=1,
+                    help="1 (default): per-proof host work in libbpmi (bpmi_rp_batch_prepare, --workers = host threads); "
+                         "0: in Python (worker processes)")
     ap.add_argument("--workers", type=int, default=-1,
                     help="host worker processes per rank for the wire path (0: serial add() on proof objects; "
                          "default: min(32, host cores / ranks))")
@@ -82,12 +85,15 @@ def main():
         Vs_in = [proofs[k % args.distinct][0] for k in range(lo, hi)]
         blobs_in = [wire[k % args.distinct] for k in range(lo, hi)]
         t0 = time.perf_counter()
-        bv.start_workers(workers)
+        if not args.native:
+            bv.start_workers(workers)
         t_pool = time.perf_counter() - t0
         if world > 1:
             dist.barrier()
     t0 = time.perf_counter()
-    if workers:
+    if workers and args.native:
+        bv.add_wire_native(Vs_in, blobs_in, threads=workers)
+    elif workers:
         bv.add_wire(Vs_in, blobs_in)
     else:
         for k in range(lo, hi):
@@ -109,6 +115,7 @@ def main():
                           "host_prep_s_rank0": t_host, "msm_points_rank0": 3 + 2 * n + 19 * (hi - lo), "ok": ok,
                           "proves_per_s_one_gpu": args.distinct / t_prove, "host_workers_per_rank": workers,
                           "input": "wire bytes (GPU batch decompression inside the timed region)" if workers else "proof objects",
+                          "host_work": ("native, %d threads" % workers) if (workers and args.native) else ("python, %d processes" % workers if workers else "python, in-process"),
                           "worker_pool_startup_s": t_pool, "host_cores": os.cpu_count(),
                           "host_cores_usable": usable}))
     bv.stop_workers()
