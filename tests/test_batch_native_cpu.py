@@ -84,3 +84,27 @@ def test_native_prepare_rejects_what_python_rejects():
         assert nat_ok is not True          # every single-bit flip here must be caught
         cases += 1
     assert cases == 120
+
+
+def test_native_parser_under_sanitizers(tmp_path):
+    """The parser of untrusted proof bytes, compiled for the host with ASan + UBSan, must survive
+    20 000 corrupted inputs (bit flips, truncation, trailing bytes, length fields, garbage) without a
+    report; unmodified proofs are the only ones it accepts."""
+    import os
+    import struct
+    import subprocess
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(repo, "tests", "csrc_host", "rp_fuzz.cpp")
+    inc = os.path.join(repo, "python-bulletproofs_amd", "csrc")
+    exe = str(tmp_path / "rp_fuzz")
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                           "-I", inc, src, "-o", exe, "-lpthread"])
+    b = make_batch(5, n=8)
+    blobs = [proof_to_bytes(pr) for pr in b["proofs"]]
+    data = struct.pack("<I", len(blobs)) + b"".join(struct.pack("<I", len(x)) + x for x in blobs)
+    path = tmp_path / "proofs.bin"
+    path.write_bytes(data)
+    r = subprocess.run([exe, str(path), "8", "20000"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-3000:]
+    accepted = int(r.stdout.split()[1])
+    assert 1500 < accepted < 4500, r.stdout          # kind 0 (1 in 8) is the unmodified proof; almost nothing else gets through
