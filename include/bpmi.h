@@ -85,6 +85,10 @@ int bpmi_download(bpmi_ctx *ctx, void *host, const void *dptr, size_t bytes);
  * n == 0 gives the identity (pippenger.py:28-29). */
 int bpmi_msm(bpmi_ctx *ctx, const uint8_t *pts, const uint8_t *scalars, uint64_t n, uint8_t out[64]);
 int bpmi_msm_dev(bpmi_ctx *ctx, const void *d_pts, const void *d_scalars, uint64_t n, uint8_t out[64]);
+/* Two independent MSMs (n0, n1 <= 2^23) from host buffers, overlapped on the ctx's two lanes: pairs
+ * such as A / S (rangeproof_prover.py:52,60) and T1 / T2 (:71-72) cost one round trip instead of two. */
+int bpmi_msm2(bpmi_ctx *ctx, const uint8_t *pts0, const uint8_t *scalars0, uint64_t n0, uint8_t out0[64], const uint8_t *pts1,
+              const uint8_t *scalars1, uint64_t n1, uint8_t out1[64]);
 
 /* ---- batched point operations ----------------------------------------------------
  * out[i] = scalars[i] * pts[i]       replaces `ModP * Point` / `int * Point`

@@ -22,6 +22,7 @@ SIGNATURES = {
     "bpmi_upload": (_i, [_vp, _vp, _cp, _sz]),
     "bpmi_download": (_i, [_vp, _vp, _vp, _sz]),
     "bpmi_msm": (_i, [_vp, _cp, _cp, _u64, _cp]),
+    "bpmi_msm2": (_i, [_vp, _cp, _cp, _u64, _cp, _cp, _cp, _u64, _cp]),
     "bpmi_msm_dev": (_i, [_vp, _vp, _vp, _u64, _cp]),
     "bpmi_ec_mul_batch": (_i, [_vp, _cp, _cp, _u64, _cp]),
     "bpmi_ec_mul_batch_dev": (_i, [_vp, _vp, _vp, _u64, _vp]),

@@ -204,6 +204,25 @@ int bpmi_msm(bpmi_ctx *ctx, const uint8_t *pts, const uint8_t *scalars, uint64_t
   return bpmi_msm_dev(ctx, dp, ds, n, out);
 }
 
+// two independent MSMs from host buffers, overlapped on the ctx's two lanes (one staging upload,
+// one synchronisation): the A / S and T1 / T2 pairs of a range proof, L / R outside the IPA object
+int bpmi_msm2(bpmi_ctx *ctx, const uint8_t *pts0, const uint8_t *sc0, uint64_t n0, uint8_t out0[64], const uint8_t *pts1,
+              const uint8_t *sc1, uint64_t n1, uint8_t out1[64]) {
+  if (!ctx || !out0 || !out1 || (n0 && (!pts0 || !sc0)) || (n1 && (!pts1 || !sc1))) return ctx ? fail(ctx, BPMI_E_ARG, "null argument") : BPMI_E_ARG;
+  if (n0 > (1ull << 23) || n1 > (1ull << 23)) return fail(ctx, BPMI_E_ARG, "bpmi_msm2 takes at most 2^23 pairs per MSM");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const size_t o_s0 = align_up(64 * n0, 256), o_p1 = o_s0 + align_up(32 * n0, 256), o_s1 = o_p1 + align_up(64 * n1, 256);
+  int rc = ensure_stage_in(ctx, o_s1 + 32 * n1 + 512);
+  if (rc) return rc;
+  char *d = (char *)ctx->stage_in;
+  if (n0) { HIPCHK(ctx, hipMemcpyAsync(d, pts0, 64 * n0, hipMemcpyHostToDevice, ctx->stream)); HIPCHK(ctx, hipMemcpyAsync(d + o_s0, sc0, 32 * n0, hipMemcpyHostToDevice, ctx->stream)); }
+  if (n1) { HIPCHK(ctx, hipMemcpyAsync(d + o_p1, pts1, 64 * n1, hipMemcpyHostToDevice, ctx->stream)); HIPCHK(ctx, hipMemcpyAsync(d + o_s1, sc1, 32 * n1, hipMemcpyHostToDevice, ctx->stream)); }
+  Segs a = segs_init(), b = segs_init();
+  a.pts[0] = (const u32 *)d; a.sc[0] = (const u32 *)(d + o_s0); a.n[0] = (u32)n0; a.total = (u32)n0;
+  b.pts[0] = (const u32 *)(d + o_p1); b.sc[0] = (const u32 *)(d + o_s1); b.n[0] = (u32)n1; b.total = (u32)n1;
+  return msm_run_pair(ctx, a, out0, b, out1);
+}
+
 // ---- batched point ops --------------------------------------------------------------------
 int bpmi_ec_mul_batch_dev(bpmi_ctx *ctx, const void *d_pts, const void *d_scalars, uint64_t n, void *d_out) {
   if (!ctx || (n && (!d_pts || !d_scalars || !d_out))) return ctx ? fail(ctx, BPMI_E_ARG, "null argument") : BPMI_E_ARG;

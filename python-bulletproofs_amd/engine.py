@@ -95,6 +95,12 @@ class Engine:
         self._ck(self.lib.bpmi_msm(self.ctx, pts, scalars, n, out))
         return out.raw
 
+    def msm2_bytes(self, pts0, scalars0, n0, pts1, scalars1, n1):
+        """Two independent MSMs overlapped on the engine's two lanes -> (64 bytes, 64 bytes)."""
+        o0, o1 = ctypes.create_string_buffer(64), ctypes.create_string_buffer(64)
+        self._ck(self.lib.bpmi_msm2(self.ctx, pts0, scalars0, n0, o0, pts1, scalars1, n1, o1))
+        return o0.raw, o1.raw
+
     def msm_dev(self, d_pts, d_scalars, n):
         out = ctypes.create_string_buffer(64)
         self._ck(self.lib.bpmi_msm_dev(self.ctx, _ptr(d_pts), _ptr(d_scalars), n, out))

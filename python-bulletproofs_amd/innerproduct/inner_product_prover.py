@@ -29,8 +29,8 @@ class NIProver:
     def prove(self) -> Proof1:
         x = self.transcript.get_modp(self.group.q)
         self.transcript.add_number(x)
-        P_new = PipSECP256k1.multiexp([self.P, self.u], [1, x * self.c])
-        u_new = x * self.u
+        # P' = P + (x c) u and u' = x u, independent of each other: one round trip
+        P_new, u_new = PipSECP256k1.multiexp2([self.P, self.u], [1, x * self.c], [self.u], [x])
         inner = FastNIProver2(self.g, self.h, u_new, P_new, self.a, self.b, self.group, self.transcript.digest,
                               h_scale=self.h_scale)
         return Proof1(u_new, P_new, inner.prove(), self.transcript.digest)

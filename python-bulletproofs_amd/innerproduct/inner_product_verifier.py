@@ -109,6 +109,7 @@ class Verifier1(_Checker):
     def verify(self):
         self.verify_transcript()
         x = ModP(int(self.proof1.transcript.split(b"&")[1]), SUPERCURVE.q)
-        self.assertThat(self.proof1.P_new == PipSECP256k1.multiexp([self.P, self.u], [1, x * self.c]))
-        self.assertThat(self.proof1.u_new == x * self.u)
+        P_want, u_want = PipSECP256k1.multiexp2([self.P, self.u], [1, x * self.c], [self.u], [x])
+        self.assertThat(self.proof1.P_new == P_want)
+        self.assertThat(self.proof1.u_new == u_want)
         return Verifier2(self.g, self.h, self.proof1.u_new, self.proof1.P_new, self.proof1.proof2, self.h_scale).verify()

@@ -49,6 +49,19 @@ class Pippenger:
             out = eng.msm_bytes(pack_points(gs), scalars, n)
         return Point.from_le64(out)
 
+    def multiexp2(self, gs0, es0, gs1, es1):
+        """(multiexp(gs0, es0), multiexp(gs1, es1)) for two independent sums; on secp256k1 they are
+        overlapped on the engine's two lanes (bpmi_msm2).  Not in the reference: its callers compute
+        such pairs (A and S, T1 and T2) one after the other."""
+        if len(gs0) != len(es0) or len(gs1) != len(es1):
+            raise Exception("Different number of group elements and exponents")
+        native = isinstance(self.G, EC) and self.G.curve is secp256k1
+        if not native or not gs0 or not gs1 or isinstance(gs0, DevicePoints) or isinstance(gs1, DevicePoints):
+            return self.multiexp(gs0, es0), self.multiexp(gs1, es1)
+        o0, o1 = _engine.default_engine().msm2_bytes(pack_points(gs0), pack_scalars(es0, self.order), len(gs0),
+                                                     pack_points(gs1), pack_scalars(es1, self.order), len(gs1))
+        return Point.from_le64(o0), Point.from_le64(o1)
+
     # -- any other group: generic 4-bit windowed product -------------------------
     def _multiexp_generic(self, gs, es):
         G = self.G

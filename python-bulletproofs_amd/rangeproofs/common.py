@@ -74,12 +74,13 @@ def prove(vs, n, g, h, gs, hs, gammas, u, group, seed, aggregated):
         aL += list(map(int, reversed(bin(v.x)[2:].zfill(n))))[:n]
     aR = [(bit - 1) % q for bit in aL]
     alpha = mod_hash(b"alpha" + tr.digest, q).x
-    # A = <aL, gs> + <aR, hs> + alpha*h as one MSM
-    A = PipSECP256k1.multiexp(gs + hs + [h], aL + aR + [alpha])
     sL = [mod_hash(str(i).encode() + tr.digest, q).x for i in range(nm)]
     sR = [mod_hash(str(i).encode() + tr.digest, q).x for i in range(nm, 2 * nm)]
     rho = mod_hash(str(2 * n).encode() + tr.digest, q).x     # sic: 2*n also when aggregated (:61)
-    S = PipSECP256k1.multiexp(gs + hs + [h], sL + sR + [rho])
+    # A = <aL, gs> + <aR, hs> + alpha*h and S = <sL, gs> + <sR, hs> + rho*h: two MSMs over the same
+    # points, independent of each other, overlapped on the engine's two lanes
+    base = gs + hs + [h]
+    A, S = PipSECP256k1.multiexp2(base, aL + aR + [alpha], base, sL + sR + [rho])
     tr.add_list_points([A, S])
     yM = tr.get_modp(q)
     tr.add_number(yM)
@@ -95,8 +96,7 @@ def prove(vs, n, g, h, gs, hs, gammas, u, group, seed, aggregated):
     t2 = sum(sL[i] * ysr[i] for i in range(nm)) % q
     tau1 = mod_hash(b"tau1" + tr.digest, q).x
     tau2 = mod_hash(b"tau2" + tr.digest, q).x
-    T1 = commitment(g, h, t1, tau1)
-    T2 = commitment(g, h, t2, tau2)
+    T1, T2 = PipSECP256k1.multiexp2([g, h], [t1, tau1], [g, h], [t2, tau2])      # = commitment(g, h, t_i, tau_i), as a pair
     tr.add_list_points([T1, T2])
     xM = tr.get_modp(q)
     tr.add_number(xM)
@@ -141,7 +141,7 @@ class VerifierBase:
         self.assertThat(items[6] == point_to_b64(proof.T2))
         self.x = ModP(int(items[7]), p)
 
-    def _getP(self, x, y, z, A, S, gs, hsp, n, m=1, aggregated=False, extra_pts=(), extra_sc=(), h_scale=None):
+    def _getP(self, x, y, z, A, S, gs, hsp, n, m=1, aggregated=False, extra_pts=(), extra_sc=(), h_scale=None, terms_only=False):
         """A + x*S + sum(-z)*gs_i + sum(z*y^i + zt_i)*hsp_i (+ extras) as one MSM.  With
         h_scale = [y^-i] the list `hsp` holds the UNSCALED hs and the factors ride in the
         scalars."""
@@ -151,4 +151,7 @@ class VerifierBase:
         hsc = [zi * ypow[i] + zt[i] for i in range(nm)]
         if h_scale is not None:
             hsc = [v * c % q for v, c in zip(hsc, h_scale)]
-        return PipSECP256k1.multiexp(gs + hsp + [A, S] + list(extra_pts), [-zi] * nm + hsc + [1, x] + list(extra_sc))
+        pts, scs = gs + hsp + [A, S] + list(extra_pts), [-zi] * nm + hsc + [1, x] + list(extra_sc)
+        if terms_only:
+            return pts, scs
+        return PipSECP256k1.multiexp(pts, scs)

@@ -23,11 +23,13 @@ class AggregRangeVerifier(VerifierBase):
         # hsp[i] = y^-i * hs[i] is never materialised: y^-i goes into the MSM scalars
         yscale = _powers(pow(y.x, -1, CURVE.q), nm, CURVE.q)
         # t_hat*g + taux*h == sum z^(j+2) V_j + delta*g + x*T1 + x^2*T2  (reference :82-89), one MSM == identity
-        check = PipSECP256k1.multiexp(
+        # ... overlapped with the independent MSM for P (:91-106) on the engine's second lane
+        p_pts, p_scs = self._getP(x, y, z, proof.A, proof.S, gs, hs, n, m, aggregated=True,
+                                  extra_pts=[h], extra_sc=[-proof.mu], h_scale=yscale, terms_only=True)
+        check, P_inner = PipSECP256k1.multiexp2(
             [g, h] + list(self.Vs) + [proof.T1, proof.T2],
             [proof.t_hat - delta_yz, proof.taux] + [-(z ** (j + 2)) for j in range(m)] + [-x, -(x ** 2)],
+            p_pts, p_scs,
         )
         self.assertThat(check == Point.IDENTITY_ELEMENT)
-        P_inner = self._getP(x, y, z, proof.A, proof.S, gs, hs, n, m, aggregated=True,
-                             extra_pts=[h], extra_sc=[-proof.mu], h_scale=yscale)
         return Verifier1(gs, hs, self.u, P_inner, proof.t_hat, proof.innerProof, h_scale=yscale).verify()

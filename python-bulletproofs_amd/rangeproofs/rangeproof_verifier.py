@@ -20,10 +20,11 @@ class RangeVerifier(VerifierBase):
         delta_yz = (z - z ** 2) * ysum - (z ** 3) * ModP(2 ** n - 1, CURVE.q)
         # hsp[i] = y^-i * hs[i] is never materialised: y^-i goes into the MSM scalars
         yscale = _powers(pow(y.x, -1, CURVE.q), n, CURVE.q)
-        # t_hat*g + taux*h == z^2*V + delta*g + x*T1 + x^2*T2  (reference :73-76)
-        # t_hat*g + taux*h == z^2*V + delta*g + x*T1 + x^2*T2  (reference :73-76) as one MSM == identity
-        check = PipSECP256k1.multiexp([g, h, self.V, proof.T1, proof.T2],
-                                      [proof.t_hat - delta_yz, proof.taux, -(z ** 2), -x, -(x ** 2)])
+        # t_hat*g + taux*h == z^2*V + delta*g + x*T1 + x^2*T2  (reference :73-76) as one MSM == identity,
+        # overlapped with the (independent) MSM for P (:78-95) on the engine's second lane
+        p_pts, p_scs = self._getP(x, y, z, proof.A, proof.S, gs, hs, n, extra_pts=[h], extra_sc=[-proof.mu], h_scale=yscale,
+                                  terms_only=True)
+        check, P_inner = PipSECP256k1.multiexp2([g, h, self.V, proof.T1, proof.T2],
+                                                [proof.t_hat - delta_yz, proof.taux, -(z ** 2), -x, -(x ** 2)], p_pts, p_scs)
         self.assertThat(check == Point.IDENTITY_ELEMENT)
-        P_inner = self._getP(x, y, z, proof.A, proof.S, gs, hs, n, extra_pts=[h], extra_sc=[-proof.mu], h_scale=yscale)
         return Verifier1(gs, hs, self.u, P_inner, proof.t_hat, proof.innerProof, h_scale=yscale).verify()

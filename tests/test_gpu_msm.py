@@ -235,3 +235,24 @@ def test_msm_digit_of_magnitude_B_both_signs(gp, c):
         assert eng.msm_bytes(pb, sb, n) == cbind.msm_bytes(pb, sb, n)
     finally:
         eng.set_option("window_bits", 0)
+
+
+def test_msm2_pairs(gp):
+    """bpmi_msm2 / Pippenger.multiexp2: two independent MSMs on the two lanes == each one alone,
+    for small / large / empty / unequal sizes."""
+    from bulletproofs_amd.pippenger import PipSECP256k1
+    eng = gp.engine()
+    rnd = random.Random(8)
+    pts, _ = gp.rand_points(6000, 21)
+    for n0, n1 in ((1, 1), (2, 130), (129, 12), (5000, 3), (6000, 6000), (70, 0)):
+        a = [rnd.randrange(Q) for _ in range(n0)]
+        b = [rnd.randrange(Q) for _ in range(n1)]
+        p0, p1 = pts[:n0], pts[6000 - n1:] if n1 else []
+        if n1:
+            o0, o1 = eng.msm2_bytes(cbind.pack_points(p0), cbind.pack_scalars(a), n0, cbind.pack_points(p1), cbind.pack_scalars(b), n1)
+            assert o0 == cbind.msm_bytes(cbind.pack_points(p0), cbind.pack_scalars(a), n0)
+            assert o1 == cbind.msm_bytes(cbind.pack_points(p1), cbind.pack_scalars(b), n1)
+        g0, g1 = PipSECP256k1.multiexp2(gp.to_gpu_list(p0), a, gp.to_gpu_list(p1), b)
+        assert gp.same_point(g0, cbind.msm(p0, a)) and gp.same_point(g1, cbind.msm(p1, b) if n1 else INF)
+    with pytest.raises(Exception, match="Different number"):
+        PipSECP256k1.multiexp2(gp.to_gpu_list(pts[:2]), [1], [], [])
