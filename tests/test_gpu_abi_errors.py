@@ -76,3 +76,18 @@ def test_profile_interface(gp):
     eng.profile(False)
     assert prof["msm_accumulate"][1] == 2 and prof["msm_accumulate"][0] > 0
     assert set(prof) >= {"msm_digits_hist", "msm_scatter", "msm_tail", "ec_lincomb2", "sc_dot"}
+
+
+def test_c_program_through_the_abi_only(tmp_path):
+    """examples/msm_c_abi.c: a C99 program that uses nothing but include/bpmi.h and libbpmi.so (device
+    memory from bpmi_malloc, inputs built with bpmi_ec_mul_batch_dev) runs an MSM of 2^16 pairs and
+    checks it against the known answer -- the C-ABI is sufficient on its own."""
+    import os
+    import subprocess
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(repo, "python-bulletproofs_amd")
+    exe = str(tmp_path / "msm_c_abi")
+    subprocess.check_call(["gcc", "-O2", "-std=c99", "-Wall", "-I", os.path.join(repo, "include"), os.path.join(repo, "examples", "msm_c_abi.c"),
+                           "-o", exe, os.path.join(libdir, "libbpmi.so"), "-Wl,-rpath," + libdir, "-Wl,--allow-shlib-undefined"])
+    r = subprocess.run([exe, "16"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "known-answer ok" in r.stdout, r.stdout + r.stderr
