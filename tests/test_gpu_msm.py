@@ -256,3 +256,25 @@ def test_msm2_pairs(gp):
         assert gp.same_point(g0, cbind.msm(p0, a)) and gp.same_point(g1, cbind.msm(p1, b) if n1 else INF)
     with pytest.raises(Exception, match="Different number"):
         PipSECP256k1.multiexp2(gp.to_gpu_list(pts[:2]), [1], [], [])
+
+
+@pytest.mark.parametrize("shape", ["all_same", "two_values", "bits01", "small_range"])
+def test_msm_heavy_partitions(gp, shape):
+    """Skewed digit distributions on the LDS-sort path: partitions with more than 12 288 entries
+    are counted and scattered by the tile kernels (k_fine_hist_heavy / k_fine_scatter_heavy) instead of
+    one block's LDS; mixed with light partitions in the same MSM."""
+    eng = gp.engine()
+    n = 40000
+    pts, _ = gp.rand_points(n, 23)
+    rnd = random.Random(len(shape))
+    if shape == "all_same":
+        es = [rnd.randrange(Q)] * n
+    elif shape == "two_values":
+        vals = [12345678901234567890123, Q - 5]
+        es = [vals[rnd.randrange(2)] for _ in range(n)]
+    elif shape == "bits01":                       # the aL / aR vectors of a range proof
+        es = [rnd.randrange(2) for _ in range(n // 2)] + [(rnd.randrange(2) - 1) % Q for _ in range(n - n // 2)]
+    else:
+        es = [rnd.randrange(1 << 20) if i % 3 else rnd.randrange(Q) for i in range(n)]
+    pb, sb = cbind.pack_points(pts), cbind.pack_scalars(es)
+    assert eng.msm_bytes(pb, sb, n) == cbind.msm_bytes(pb, sb, n)
