@@ -113,7 +113,7 @@ def main():
 
     for _ in range(args.warmup):
         result = step()
-    eng.profile(True)
+    eng.profile(2)              # HIP events around the dominant kernel only: each recorded event is a ~10 us bubble
     eng.profile_reset()
     barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -126,6 +126,12 @@ def main():
     elapsed = time.perf_counter() - t0
     ev_ms = ev0.elapsed_time(ev1)
     prof = eng.profile_read()
+    # per-stage breakdown: a few extra, UNTIMED steps with events around every stage
+    eng.profile(1)
+    eng.profile_reset()
+    for _ in range(min(5, args.steps)):
+        step()
+    prof_all = eng.profile_read()
     eng.profile(False)
 
     if world > 1:
@@ -146,7 +152,7 @@ def main():
     acc_ms, acc_calls = prof["msm_accumulate"]
     acc_avg_s = acc_ms / max(acc_calls, 1) / 1e3
     achieved_gbs = ALGO_BYTES_PER_PAIR * n / acc_avg_s / 1e9 if acc_avg_s > 0 else 0.0
-    stages = {k: round(v[0] / max(v[1], 1), 4) for k, v in prof.items() if v[1]}
+    stages = {k: round(v[0] / max(v[1], 1), 4) for k, v in prof_all.items() if v[1]}
     windows = 16 if n >= (1 << 15) else 32          # pick_window_bits (csrc/msm_host.hpp): c = 16 -> 16 windows
 
     out = {

@@ -178,7 +178,8 @@ int bpmi_rp_batch_prepare(uint32_t n_gens, uint64_t n_proofs, const uint8_t *blo
 
 /* ---- per-stage device timing (HIP events on the ctx's stream) --------------------------
  * After bpmi_profile(ctx, 1) every MSM records HIP events around each kernel
- * stage; bpmi_profile_read returns accumulated milliseconds and launch counts
+ * stage (enable = 2: around the dominant stage, msm_accumulate, only -- every recorded event costs
+ * a ~10 us bubble between two kernels, so a timed run should use 2); bpmi_profile_read returns accumulated milliseconds and launch counts
  * per stage since the last reset.  Stage names: bpmi_profile_stage_name(i). */
 #define BPMI_NSTAGES 12
 int bpmi_profile(bpmi_ctx *ctx, int enable);

@@ -783,6 +783,7 @@ int bpmi_profile(bpmi_ctx *ctx, int enable) {
   if (!ctx) return BPMI_E_ARG;
   prof_drain(ctx);
   ctx->prof = enable != 0;
+  ctx->prof_only = enable == 2 ? ST_ACCUM : -1;
   return BPMI_OK;
 }
 int bpmi_profile_reset(bpmi_ctx *ctx) {

@@ -42,6 +42,7 @@ struct bpmi_ctx {
   int64_t opt_ipa_big = 0;   // base length from which the IPA folds generators 16-way (0 = default 2^18)
   // profiling
   bool prof = false;
+  int prof_only = -1;      // >= 0: time only this stage (every event record costs a ~10 us bubble between kernels)
   std::vector<EvPair> evs;
   std::vector<hipEvent_t> ev_pool;      // recycled timing events (creating one costs more than recording it)
   double prof_ms[BPMI_NSTAGES] = {0};
@@ -74,7 +75,7 @@ static void debug_sync(bpmi_ctx *ctx, const char *what, hipStream_t stream = nul
 struct StageTimer {
   bpmi_ctx *ctx; int stage; hipStream_t stream; hipEvent_t a = nullptr, b = nullptr;
   StageTimer(bpmi_ctx *c, int s, hipStream_t st = nullptr) : ctx(c), stage(s), stream(st ? st : c->stream) {
-    if (ctx->prof) {
+    if (ctx->prof && (ctx->prof_only < 0 || ctx->prof_only == stage)) {
       a = take(); b = take();
       if (!a || !b) { a = b = nullptr; return; }
       (void)hipEventRecord(a, stream);

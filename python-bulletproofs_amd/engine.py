@@ -154,7 +154,8 @@ class Engine:
 
     # ---- profiling ----
     def profile(self, enable=True):
-        self._ck(self.lib.bpmi_profile(self.ctx, 1 if enable else 0))
+        """True / 1: HIP events around every stage; 2: around the dominant stage only; False: off."""
+        self._ck(self.lib.bpmi_profile(self.ctx, int(enable)))
 
     def profile_reset(self):
         self._ck(self.lib.bpmi_profile_reset(self.ctx))
