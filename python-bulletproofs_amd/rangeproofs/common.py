@@ -5,13 +5,11 @@ blinding factors enter taux; likewise the two verifiers.  Scalar algebra is O(n 
 host-side integer work (out of scope for the GPU); every
 group operation goes to the engine, fused into as few MSMs as the algebra allows."""
 from .. import engine as _engine
-from ..ec import Point, pack_points, pack_scalars, unpack_points
+from ..ec import pack_points, unpack_points
 from ..innerproduct.inner_product_prover import NIProver
-from ..innerproduct.inner_product_verifier import Verifier1
 from ..pippenger import PipSECP256k1
-from ..utils.commitments import commitment
 from ..utils.transcript import Transcript
-from ..utils.utils import ModP, inner_product, mod_hash, point_to_b64
+from ..utils.utils import ModP, mod_hash, point_to_b64
 
 
 class Proof:

@@ -3,7 +3,7 @@ from ..ec import Point, secp256k1
 from ..innerproduct.inner_product_verifier import Verifier1
 from ..pippenger import PipSECP256k1
 from ..utils.utils import ModP
-from .common import Proof, VerifierBase, scaled_generators, _powers
+from .common import Proof, VerifierBase, _powers
 
 CURVE = secp256k1
 
