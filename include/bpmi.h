@@ -158,13 +158,14 @@ int bpmi_ipa_export(bpmi_ipa *st, uint8_t *g, uint8_t *h, uint8_t *a, uint8_t *b
 void bpmi_ipa_destroy(bpmi_ipa *st);
 
 /* ---- batch verification of range proofs: host-side preparation (no GPU work, no ctx) ---------------
- * For n_proofs single-value range proofs over n_gens generator pairs in the wire format of
+ * For n_proofs range proofs -- values_per_proof = 1: single-value proofs; m > 1: aggregated proofs of m values
+ * each, n_gens = m x bits -- over n_gens generator pairs in the wire format of
  * python-bulletproofs_amd/rangeproofs/codec.py (blob i = blobs[blob_off[i] .. blob_off[i+1])):
  * parses every proof, runs the byte-level transcript checks of RangeVerifier / Verifier1 / Verifier2
  * (src/rangeproofs/rangeproof_verifier.py:42-53, src/innerproduct/inner_product_verifier.py:31-43,
  * 104-125) and computes, with the caller's random weights (4 scalars per proof, LE, in [1, q)), the
  * scalars of the ONE multi-scalar multiplication that is the identity iff every proof verifies:
- *   v_scalars   n_proofs x 32 B        for the commitments V_i
+ *   v_scalars   n_proofs x values_per_proof x 32 B   for the commitments V_i (V_i,0 .. V_i,m-1)
  *   pt_scalars  n_proofs x (6 + 2k) x 32 B, k = log2 n_gens, for each proof's points in wire order
  *               (T1 T2 A S u_new P_new L_1..L_k R_1..R_k)
  *   shared      (5 + 2 n_gens) x 32 B: coefficients of g, h, u, the constant added to every gs_i and
@@ -173,8 +174,8 @@ void bpmi_ipa_destroy(bpmi_ipa *st);
  *               in the same order, ready for bpmi_ec_decompress_batch
  * *first_bad = index of the first proof that failed parsing or a transcript check, or -1.  `threads`
  * host threads share the proofs.  The native twin of BatchRangeVerifier.add (rangeproofs/batch.py). */
-int bpmi_rp_batch_prepare(uint32_t n_gens, uint64_t n_proofs, const uint8_t *blobs, const uint64_t *blob_off, const uint8_t *weights,
-                          int threads, uint8_t *v_scalars, uint8_t *pt_scalars, uint8_t *shared, uint8_t *comp_out, int64_t *first_bad);
+int bpmi_rp_batch_prepare(uint32_t n_gens, uint32_t values_per_proof, uint64_t n_proofs, const uint8_t *blobs, const uint64_t *blob_off,
+                          const uint8_t *weights, int threads, uint8_t *v_scalars, uint8_t *pt_scalars, uint8_t *shared, uint8_t *comp_out, int64_t *first_bad);
 
 /* ---- per-stage device timing (HIP events on the ctx's stream) --------------------------
  * After bpmi_profile(ctx, 1) every MSM records HIP events around each kernel

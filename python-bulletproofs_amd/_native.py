@@ -42,7 +42,7 @@ SIGNATURES = {
     "bpmi_ipa_fold": (_i, [_vp, _cp, _cp]),
     "bpmi_ipa_finish": (_i, [_vp, _cp, _cp]),
     "bpmi_ipa_export": (_i, [_vp, _cp, _cp, _cp, _cp]),
-    "bpmi_rp_batch_prepare": (_i, [ctypes.c_uint32, _u64, _cp, ctypes.c_void_p, _cp, _i, _cp, _cp, _cp, _cp, ctypes.c_void_p]),
+    "bpmi_rp_batch_prepare": (_i, [ctypes.c_uint32, ctypes.c_uint32, _u64, _cp, ctypes.c_void_p, _cp, _i, _cp, _cp, _cp, _cp, ctypes.c_void_p]),
     "bpmi_ipa_destroy": (None, [_vp]),
     "bpmi_profile": (_i, [_vp, _i]),
     "bpmi_profile_reset": (_i, [_vp]),

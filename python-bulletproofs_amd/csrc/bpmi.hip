@@ -731,10 +731,12 @@ void bpmi_ipa_destroy(bpmi_ipa *st) {
 }
 
 // ---- batch verification of range proofs: host-side preparation ---------------------------------------
-int bpmi_rp_batch_prepare(uint32_t n_gens, uint64_t n_proofs, const uint8_t *blobs, const uint64_t *blob_off, const uint8_t *weights,
-                          int threads, uint8_t *v_scalars, uint8_t *pt_scalars, uint8_t *shared, uint8_t *comp_out, int64_t *first_bad) {
+int bpmi_rp_batch_prepare(uint32_t n_gens, uint32_t values_per_proof, uint64_t n_proofs, const uint8_t *blobs, const uint64_t *blob_off,
+                          const uint8_t *weights, int threads, uint8_t *v_scalars, uint8_t *pt_scalars, uint8_t *shared, uint8_t *comp_out, int64_t *first_bad) {
   if (!blobs || !blob_off || !weights || !v_scalars || !pt_scalars || !shared || !first_bad) return BPMI_E_ARG;
   if (n_gens < 2 || (n_gens & (n_gens - 1)) || n_gens > 65536) return BPMI_E_ARG;
+  const uint32_t m = values_per_proof;
+  if (m < 1 || n_gens % m) return BPMI_E_ARG;
   uint32_t k = 0;
   while ((1u << k) < n_gens) k++;
   *first_bad = -1;
@@ -751,7 +753,7 @@ int bpmi_rp_batch_prepare(uint32_t n_gens, uint64_t n_proofs, const uint8_t *blo
     for (uint64_t a = lo; a < hi; a += 512) {
       const uint64_t b = a + 512 < hi ? a + 512 : hi;
       uint64_t bd = UINT64_MAX;
-      if (!rp::run_chunk(n_gens, k, blobs, blob_off, weights, a, b, pt_off.data(), v_scalars, pt_scalars, comp_out, acc[t].data(), &bd)) { bad[t] = bd; return; }
+      if (!rp::run_chunk(n_gens, k, m, blobs, blob_off, weights, a, b, pt_off.data(), v_scalars, pt_scalars, comp_out, acc[t].data(), &bd)) { bad[t] = bd; return; }
     }
   };
   if (threads == 1) work(0);

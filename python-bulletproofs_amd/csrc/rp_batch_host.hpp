@@ -1,6 +1,6 @@
 // rp_batch_host.hpp -- part of libbpmi (included by bpmi.hip; one translation unit).  HOST code.
-// Per-proof preparation of the random-linear-combination batch verifier for single-value range
-// proofs in wire format (python-bulletproofs_amd/rangeproofs/batch.py, codec.py): parsing, the
+// Per-proof preparation of the random-linear-combination batch verifier for range
+// proofs (single-value or aggregated) in wire format (python-bulletproofs_amd/rangeproofs/batch.py, codec.py): parsing, the
 // three byte-level transcript checks of the reference's verifiers, and the weighted scalars of the
 // ONE MSM that the GPU then evaluates.  It is the native twin of BatchRangeVerifier.add(): the
 // Python version costs ~150 us per proof, the GPU ~1 us, so at 2^14 proofs the interpreter was
@@ -328,7 +328,8 @@ static inline bool check_transcripts(const Parsed &P, Challenges &C, Items &it) 
 // Everything add() accumulates for one proof.  out_v: 1 scalar (for V); out_p: (6 + 2k) scalars in the
 // wire order of the points (T1 T2 A S u_new P_new Ls Rs); acc: c_g c_h c_u gs_const hs_const c_gs[n] c_hs[n].
 struct Work { std::vector<Sq> sg, sh, tmp; };
-static inline void accumulate(const Parsed &P, const Challenges &C, const Sq w[4], const Sq *xinvs, const Sq &yinv, uint32_t n,
+// m = values per proof (1: single proof; > 1: aggregated, n = m * bits per value)
+static inline void accumulate(const Parsed &P, const Challenges &C, const Sq w[4], const Sq *xinvs, const Sq &yinv, uint32_t n, uint32_t m,
                               Sq *acc, Sq *out_v, Sq *out_p, Work &W) {
   const uint32_t k = P.k;
   Sq t, u;
@@ -357,13 +358,24 @@ static inline void accumulate(const Parsed &P, const Challenges &C, const Sq w[4
   q_add(acc[3], acc[3], w2z);                                   // gs_const
   q_sub(acc[4], acc[4], w2z);                                   // hs_const
   q_add(r2, yinv, yinv);                                        // 2 / y
-  q_mul(geo, w[1], z2);                                         // w2 z^2 (2/y)^i
+  const uint32_t bits = n / m;
+  Sq yn_inv = q_small(1);
+  for (uint32_t i = 0; i < bits; i++) q_mul(yn_inv, yn_inv, yinv);     // y^-bits
+  W.tmp.resize(m);                                               // z^(2 + j)
+  W.tmp[0] = z2;
+  for (uint32_t j = 1; j < m; j++) q_mul(W.tmp[j], W.tmp[j - 1], C.z);
   Sq *c_gs = acc + 5, *c_hs = acc + 5 + n;
-  for (uint32_t i = 0; i < n; i++) {
-    q_add(c_gs[i], c_gs[i], W.sg[i]);
-    q_sub(t, W.sh[i], geo);
-    q_add(c_hs[i], c_hs[i], t);
-    q_mul(geo, geo, r2);
+  Sq blk = q_small(1);
+  for (uint32_t j = 0, i = 0; j < m; j++) {
+    q_mul(geo, w[1], W.tmp[j]);
+    q_mul(geo, geo, blk);                                       // w2 z^(2+j) 2^(i % bits) y^-i at i = bits j
+    for (uint32_t e = 0; e < bits; e++, i++) {
+      q_add(c_gs[i], c_gs[i], W.sg[i]);
+      q_sub(t, W.sh[i], geo);
+      q_add(c_hs[i], c_hs[i], t);
+      q_mul(geo, geo, r2);
+    }
+    q_mul(blk, blk, yn_inv);
   }
   // sum_{i<n} y^i by doubling; delta = (z - z^2) ysum - z^3 (2^n - 1)
   Sq ysum = q_small(1), ypw = C.y, one = q_small(1);
@@ -373,20 +385,22 @@ static inline void accumulate(const Parsed &P, const Challenges &C, const Sq w[4
     q_sqr(ypw, ypw);
   }
   Sq two_n = q_small(1), two = q_small(2);
-  for (uint32_t i = 0; i < n; i++) q_mul(two_n, two_n, two);    // 2^n mod q (n <= 1024)
+  for (uint32_t i = 0; i < bits; i++) q_mul(two_n, two_n, two);  // 2^bits mod q
   q_sub(two_n, two_n, one);
-  Sq delta, z3;
+  // delta = (z - z^2) ysum - (2^bits - 1) sum_{j=1..m} z^(j+2)
+  Sq delta, zsum = q_small(0), zp;
   q_sub(t, C.z, z2);
   q_mul(delta, t, ysum);
-  q_mul(z3, z2, C.z);
-  q_mul(t, z3, two_n);
+  q_mul(zp, z2, C.z);                                            // z^3
+  for (uint32_t j = 1; j <= m; j++) { q_add(zsum, zsum, zp); q_mul(zp, zp, C.z); }
+  q_mul(t, zsum, two_n);
   q_sub(delta, delta, t);
   // c_g += w1 (t_hat - delta); c_h += w1 taux + w2 mu; c_u -= w2 x_ip t_hat + w3 x_ip
   q_sub(t, P.t_hat, delta); q_mul(t, t, w[0]); q_add(acc[0], acc[0], t);
   q_mul(t, w[0], P.taux); q_mul(u, w[1], P.mu); q_add(t, t, u); q_add(acc[1], acc[1], t);
   q_mul(t, w[1], C.x_ip); q_mul(t, t, P.t_hat); q_mul(u, w[2], C.x_ip); q_add(t, t, u); q_sub(acc[2], acc[2], t);
   // per-proof points: V: -w1 z^2 | T1: -w1 x | T2: -w1 x^2 | A: -w2 | S: -w2 x | u_new: w3 + w4 a b | P_new: w2 - w4
-  q_mul(t, w[0], z2); q_neg(*out_v, t);
+  for (uint32_t j = 0; j < m; j++) { q_mul(t, w[0], W.tmp[j]); q_neg(out_v[j], t); }
   q_mul(t, w[0], C.x); q_neg(out_p[0], t);
   q_mul(t, t, C.x); q_neg(out_p[1], t);
   q_neg(out_p[2], w[1]);
@@ -400,7 +414,7 @@ static inline void accumulate(const Parsed &P, const Challenges &C, const Sq w[4
 }
 
 // proofs [lo, hi): returns false at the first invalid proof (its index in *bad)
-static inline bool run_chunk(uint32_t n, uint32_t k, const uint8_t *blobs, const u64 *off, const uint8_t *weights, u64 lo, u64 hi,
+static inline bool run_chunk(uint32_t n, uint32_t k, uint32_t m, const uint8_t *blobs, const u64 *off, const uint8_t *weights, u64 lo, u64 hi,
                              const u64 *pt_off, uint8_t *v_scalars, uint8_t *pt_scalars, uint8_t *comp_out, Sq *acc, u64 *bad) {
   const u64 cnt = hi - lo;
   std::vector<Parsed> P(cnt);
@@ -431,14 +445,13 @@ static inline bool run_chunk(uint32_t n, uint32_t k, const uint8_t *blobs, const
     q_mul(rinv, rinv, val[idx]);
   }
   Work W;
-  std::vector<Sq> outp(6 + 2 * k);
+  std::vector<Sq> outp(6 + 2 * k), ov(m);
   for (u64 j = 0; j < cnt; j++) {
     const u64 g = lo + j;
     Sq w[4];
     for (int t = 0; t < 4; t++) q_from_le(w[t], weights + (g * 4 + t) * 32);
-    Sq ov;
-    accumulate(P[j], C[j], w, &inv[j * per], inv[j * per + k], n, acc, &ov, outp.data(), W);
-    q_to_le(v_scalars + 32 * g, ov);
+    accumulate(P[j], C[j], w, &inv[j * per], inv[j * per + k], n, m, acc, ov.data(), outp.data(), W);
+    for (uint32_t t = 0; t < m; t++) q_to_le(v_scalars + 32 * (g * m + t), ov[t]);
     for (uint32_t t = 0; t < 6 + 2 * k; t++) q_to_le(pt_scalars + 32 * (pt_off[g] + t), outp[t]);
   }
   return true;

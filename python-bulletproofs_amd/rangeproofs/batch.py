@@ -233,7 +233,8 @@ class BatchRangeVerifier:
         """add_wire with the per-proof host work in native code (bpmi_rp_batch_prepare, csrc/
         rp_batch_host.hpp: parsing, the three transcript checks, the weighted scalars; `threads` host
         threads): ~150 us of interpreter per proof become a few microseconds, and nothing in this
-        function loops over proofs in Python.  Single-value proofs only; same verdicts as add()
+        function loops over proofs in Python.  Vs: one commitment per proof, or -- aggregated proofs --
+        one list of m commitments per proof (the same m for the whole call).  Same verdicts as add()
         except that numbers in transcripts must be canonical decimal."""
         import ctypes
         import os
@@ -245,6 +246,12 @@ class BatchRangeVerifier:
             return
         k = self.n.bit_length() - 1
         npts = count * (6 + 2 * k)
+        aggregated = isinstance(Vs[0], (list, tuple))
+        m = len(Vs[0]) if aggregated else 1
+        if aggregated:
+            if any(len(v) != m for v in Vs) or m < 1 or self.n % m:
+                raise Exception("Proof invalid")
+            Vs = [V for group in Vs for V in group]
         if getattr(self, "_custom_rng", False):
             weights = b"".join(self._weight().to_bytes(32, "little") for _ in range(4 * count))
         else:                                   # 248 random bits each: < q by construction (zero with probability 2^-248)
@@ -252,14 +259,14 @@ class BatchRangeVerifier:
             w[31::32] = bytes(4 * count)
             weights = bytes(w)
         offs = (ctypes.c_uint64 * (count + 1))(0, *accumulate(map(len, blobs)))
-        v_sc = ctypes.create_string_buffer(32 * count)
+        v_sc = ctypes.create_string_buffer(32 * count * m)
         p_sc = ctypes.create_string_buffer(32 * npts)
         shared = ctypes.create_string_buffer(32 * (5 + 2 * self.n))
         comp = ctypes.create_string_buffer(33 * npts)
         bad = ctypes.c_int64(-1)
         if threads is None:
             threads = min(32, len(os.sched_getaffinity(0)))
-        rc = _native.load().bpmi_rp_batch_prepare(self.n, count, b"".join(blobs), ctypes.cast(offs, ctypes.c_void_p), weights, threads,
+        rc = _native.load().bpmi_rp_batch_prepare(self.n, m, count, b"".join(blobs), ctypes.cast(offs, ctypes.c_void_p), weights, threads,
                                                   v_sc, p_sc, shared, comp, ctypes.cast(ctypes.pointer(bad), ctypes.c_void_p))
         if rc != 0:
             raise Exception("bpmi_rp_batch_prepare failed (%d)" % rc)
@@ -283,7 +290,7 @@ class BatchRangeVerifier:
         self._raw_scs.append(v_sc.raw)
         self._raw_pts.append(pts)
         self._raw_scs.append(p_sc.raw)
-        self._raw_count += count + npts
+        self._raw_count += count * m + npts
         self.count += count
 
     def partial(self):

@@ -44,7 +44,7 @@ int main(int argc, char **argv) {
     std::vector<uint8_t> w(128, 7), vs(32), ps(32 * (6 + 2 * k)), comp(33 * (6 + 2 * k));
     std::vector<rp::Sq> acc(5 + 2 * n_gens, rp::q_small(0));
     uint64_t bad = 0;
-    if (rp::run_chunk(n_gens, k, b.data(), off.data(), w.data(), 0, 1, pt_off.data(), vs.data(), ps.data(), comp.data(), acc.data(), &bad)) accepted++;
+    if (rp::run_chunk(n_gens, k, 1, b.data(), off.data(), w.data(), 0, 1, pt_off.data(), vs.data(), ps.data(), comp.data(), acc.data(), &bad)) accepted++;
   }
   printf("accepted %ld of %ld\n", accepted, iters);
   return 0;

@@ -108,3 +108,46 @@ def test_native_parser_under_sanitizers(tmp_path):
     assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-3000:]
     accepted = int(r.stdout.split()[1])
     assert 1500 < accepted < 4500, r.stdout          # kind 0 (1 in 8) is the unmodified proof; almost nothing else gets through
+
+
+@pytest.mark.parametrize("m,bits", [(2, 4), (4, 8), (1, 8)])
+def test_native_prepare_aggregated_equals_python_add(m, bits):
+    """Aggregated proofs (m values per proof): native preparation == BatchRangeVerifier.add on a list
+    of commitments, scalar by scalar; m = 1 as a list takes the same route as a single proof."""
+    from oracle import bp_ref as R
+    from oracle import cbind
+    from helpers import gens
+    from test_batch_verify_cpu import convert_proof, gpt
+    nm = m * bits
+    gs, hs = gens(nm, b"ags"), gens(nm, b"ahs")
+    g, h, u = (R.elliptic_hash(s) for s in (b"ag", b"ah", b"au"))
+    rnd = random.Random(m * 100 + bits)
+    Vs_all, proofs = [], []
+    for k in range(3):
+        vs = [R.Zq(rnd.randrange(2 ** bits), Q) for _ in range(m)]
+        gammas = [R.mod_hash(b"ga%d-%d" % (k, j), Q) for j in range(m)]
+        Vs_all.append([gpt(R.commitment(g, h, v, ga)) for v, ga in zip(vs, gammas)])
+        proofs.append(convert_proof(R.aggreg_range_prove(vs, bits, g, h, gs, hs, gammas, u, seed=b"as%d" % k, multiexp=cbind.msm)))
+    G = dict(g=gpt(g), h=gpt(h), u=gpt(u), gs=[gpt(p) for p in gs], hs=[gpt(p) for p in hs])
+    blobs = [proof_to_bytes(pr) for pr in proofs]
+    r1, r2 = random.Random(5), random.Random(5)
+    py = BatchRangeVerifier(G["g"], G["h"], G["gs"], G["hs"], G["u"], msm=oracle_msm, rng=lambda: r1.getrandbits(320))
+    for V, pr in zip(Vs_all, proofs):
+        py.add(V, pr)
+    nat = BatchRangeVerifier(G["g"], G["h"], G["gs"], G["hs"], G["u"], msm=oracle_msm, rng=lambda: r2.getrandbits(320))
+    nat.add_wire_native(Vs_all, blobs, decompress=oracle_decompress, threads=2)
+    assert (py.c_g, py.c_h, py.c_u, py._gs_const, py._hs_const) == (nat.c_g, nat.c_h, nat.c_u, nat._gs_const, nat._hs_const)
+    assert [v % Q for v in py.c_gs] == [v % Q for v in nat.c_gs]
+    assert [v % Q for v in py.c_hs] == [v % Q for v in nat.c_hs]
+    k = nm.bit_length() - 1
+    per = m + 6 + 2 * k
+    want = [v % Q for v in py._scs]
+    v_sc, p_sc = nat._raw_scs
+    for j in range(3):
+        w = want[per * j: per * (j + 1)]
+        got_v = [int.from_bytes(v_sc[32 * (j * m + t): 32 * (j * m + t) + 32], "little") for t in range(m)]
+        got_p = [int.from_bytes(p_sc[32 * (j * (6 + 2 * k) + t): 32 * (j * (6 + 2 * k) + t) + 32], "little") for t in range(6 + 2 * k)]
+        assert got_v == w[:m]
+        wp = w[m:]
+        assert got_p[:4] == wp[:4] and got_p[4] == wp[5] and got_p[5] == wp[4] and got_p[6:] == wp[6:]
+    assert py.verify() is True and nat.verify() is True

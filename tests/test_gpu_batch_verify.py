@@ -155,6 +155,18 @@ def test_batch_aggregated_proofs(gp):
         bv.add(Vs, pr)
     with pytest.raises(Exception, match="Proof invalid"):
         bv.verify()
+    # the same through the wire format and the native preparation (lists of m commitments per proof)
+    from bulletproofs_amd.rangeproofs.codec import proof_to_bytes
+    blobs = [proof_to_bytes(pr) for _, pr in items]
+    bv.reset()
+    bv.add_wire_native([Vs for Vs, _ in items], blobs, threads=2)
+    assert bv.count == 3 and bv.verify() is True
+    bv.reset()
+    bad_Vs = [list(Vs) for Vs, _ in items]
+    bad_Vs[1][2] = bad_Vs[1][2] + g
+    bv.add_wire_native(bad_Vs, blobs, threads=2)
+    with pytest.raises(Exception, match="Proof invalid"):
+        bv.verify()
 
 
 @pytest.mark.parametrize("workers", [0, 3])
