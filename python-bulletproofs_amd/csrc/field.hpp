@@ -114,59 +114,59 @@ BPMI_HD void fe_carry(fe &r, const fe &a) {
 #define BPMI_MAC(acc, x, y) ((acc) += (u64)(x) * (y))
 
 // ---- product -> tight result ----------------------------------------------------------
-// The 17 product columns are accumulated as TWO carry chains (columns 0-8 and 9-16): the
-// carry out of column k is the initial value of column k+1's accumulator, i.e. it rides in
-// the 64-bit addend of the first v_mad_u64_u32 of that column for free (saves one 64-bit
-// add per column); two chains instead of one keep two independent dependency chains in
-// flight.  The carry out of the low chain (weight 2^261) is folded separately.
-#define BPMI_FE_COLUMN(S, K, EXPR_LOOP) \
-  { u64 s_ = (S); EXPR_LOOP; t[K] = (u32)s_ & M29; (S) = s_ >> 29; }
-
-BPMI_HD void fe_fold_limbs(fe &r, const u32 t[18], u64 c8) {
-  // t[0..8]: low limbs; t[9..17]: limbs of weight 2^261 * 2^(29(k-9)); c8 (< 2^36): carry
-  // out of column 8, also of weight 2^261.   2^261 == 2^37 + 31264 (mod p):
-  // high limb k folds into limb k (x31264) and limb k+1 (x256)
-  u64 u[10];
-  const u32 k31264 = 31264u;
+// The 17 product columns are two carry chains.  The HIGH chain (columns 9..16) runs first and
+// leaves limbs th[0..7] (29 bits each) plus its carry-out t17; since
+//     2^261 == 2^37 + 31264 (mod p)   and   2^37 = 2^8 * 2^29,
+// a limb of weight 2^(29 (9 + j)) adds 31264 x itself to column j and 256 x itself to column
+// j + 1.  Those two terms are simply two more multiply-adds INTO THE RUNNING 64-bit
+// ACCUMULATOR of the low chain's columns, so the fold needs no temporaries, no zero-extended
+// copies and no second carry pass: the low chain's own carry propagation normalises products
+// and fold together.  (t17 sits at column 17 = 8 + 9: 31264 x t17 goes to column 8, and its
+// 256 x t17 part, column 9, folds once more into columns 0 and 1.)  What is left afterwards is
+// the carry out of column 8 and the 5 bits of limb 8 above 2^256, both reduced with
+// 2^256 == 2^32 + 977 and a 32-bit ripple.  173 instructions per multiplication against 207
+// for separate extract / fold / carry passes.
+//   bounds: mag(a) mag(b) <= 7  =>  a column of products < 63 * 2^58; the fold terms add < 2^56;
+//   t17 < 2^33; carry out of column 8 < 2^36.
+BPMI_HD void fe_reduce_tail(fe &r, u32 t[9], u64 c8) {
+  // V = units of 2^256 above limb 8's 24 bits: 2^261 = 32 * 2^256
+  const u64 V = (u64)(t[8] >> 24) + (c8 << 5);               // < 2^42
+  u64 c = (u64)t[0] + V * 977u;
+  r.v[0] = (u32)c & M29; c >>= 29;
+  c += (u64)t[1] + (V << 3);                                 // 2^32 = 8 * 2^29
+  r.v[1] = (u32)c & M29;
+  u32 cc = (u32)(c >> 29);                                   // < 2^17: 32-bit from here on
 #pragma unroll
-  for (int k = 0; k < 9; k++) { u[k] = t[k]; BPMI_MAC(u[k], t[9 + k], k31264); }
-#pragma unroll
-  for (int k = 1; k < 9; k++) u[k] += (u64)t[8 + k] << 8;
-  u[9] = (u64)t[17] << 8;
-  u[0] += c8 * 31264u;
-  u[1] += c8 << 8;
-  // everything at or above 2^256 (limb 8 bit 24) folds once more: 2^256 == 2^32 + 977
-  const u64 H = (u[8] >> 24) + (u[9] << 5);
-  u[8] &= M24;
-  u[0] += H * 977u;
-  u[1] += H << 3;
-  u64 c = 0;
-#pragma unroll
-  for (int k = 0; k < 8; k++) { c += u[k]; r.v[k] = (u32)c & M29; c >>= 29; }
-  r.v[8] = (u32)(c + u[8]);
+  for (int k = 2; k < 8; k++) { const u32 x = t[k] + cc; r.v[k] = x & M29; cc = x >> 29; }
+  r.v[8] = (t[8] & M24) + cc;
 }
 
 BPMI_HD void fe_mul(fe &r, const fe &a, const fe &b) {
-  u32 t[18];
-  u64 clo = 0, chi = 0;
+  u32 th[8], t[9];
+  u64 c = 0;
+#pragma unroll
+  for (int k = 9; k < 17; k++) {
+    u64 s = c;
+#pragma unroll
+    for (int i = k - 8; i <= 8; i++) BPMI_MAC(s, a.v[i], b.v[k - i]);
+    th[k - 9] = (u32)s & M29;
+    c = s >> 29;
+  }
+  const u32 t17 = (u32)c;
+  c = 0;
 #pragma unroll
   for (int k = 0; k < 9; k++) {
-    u64 s = clo;
+    u64 s = c;
+    if (k == 0) BPMI_MAC(s, t17, 31264u * 256u);            // 256 t17 at column 9 -> 31264 x at column 0
+    if (k == 1) BPMI_MAC(s, t17, 65536u);                    //                    -> 256 x at column 1
+    if (k < 8) BPMI_MAC(s, th[k], 31264u); else BPMI_MAC(s, t17, 31264u);
+    if (k >= 1) BPMI_MAC(s, th[k - 1], 256u);
 #pragma unroll
     for (int i = 0; i <= k; i++) BPMI_MAC(s, a.v[i], b.v[k - i]);
     t[k] = (u32)s & M29;
-    clo = s >> 29;
+    c = s >> 29;
   }
-#pragma unroll
-  for (int k = 9; k < 17; k++) {
-    u64 s = chi;
-#pragma unroll
-    for (int i = k - 8; i <= 8; i++) BPMI_MAC(s, a.v[i], b.v[k - i]);
-    t[k] = (u32)s & M29;
-    chi = s >> 29;
-  }
-  t[17] = (u32)chi;
-  fe_fold_limbs(r, t, clo);
+  fe_reduce_tail(r, t, c);
 }
 
 // a of magnitude <= 2 (doubled limbs must fit 32 bits and 9 * 2 * m^2 * 2^58 < 2^64)
@@ -174,26 +174,31 @@ BPMI_HD void fe_sqr(fe &r, const fe &a) {
   u32 d[9];
 #pragma unroll
   for (int i = 0; i < 9; i++) d[i] = a.v[i] << 1;
-  u32 t[18];
-  u64 clo = 0, chi = 0;
+  u32 th[8], t[9];
+  u64 c = 0;
+#pragma unroll
+  for (int k = 9; k < 17; k++) {
+    u64 s = c;
+#pragma unroll
+    for (int i = k - 8; 2 * i <= k; i++) { if (2 * i == k) BPMI_MAC(s, a.v[i], a.v[i]); else BPMI_MAC(s, d[i], a.v[k - i]); }
+    th[k - 9] = (u32)s & M29;
+    c = s >> 29;
+  }
+  const u32 t17 = (u32)c;
+  c = 0;
 #pragma unroll
   for (int k = 0; k < 9; k++) {
-    u64 s = clo;
+    u64 s = c;
+    if (k == 0) BPMI_MAC(s, t17, 31264u * 256u);
+    if (k == 1) BPMI_MAC(s, t17, 65536u);
+    if (k < 8) BPMI_MAC(s, th[k], 31264u); else BPMI_MAC(s, t17, 31264u);
+    if (k >= 1) BPMI_MAC(s, th[k - 1], 256u);
 #pragma unroll
     for (int i = 0; 2 * i <= k; i++) { if (2 * i == k) BPMI_MAC(s, a.v[i], a.v[i]); else BPMI_MAC(s, d[i], a.v[k - i]); }
     t[k] = (u32)s & M29;
-    clo = s >> 29;
+    c = s >> 29;
   }
-#pragma unroll
-  for (int k = 9; k < 17; k++) {
-    u64 s = chi;
-#pragma unroll
-    for (int i = k - 8; 2 * i <= k; i++) { if (2 * i == k) BPMI_MAC(s, a.v[i], a.v[i]); else BPMI_MAC(s, d[i], a.v[k - i]); }
-    t[k] = (u32)s & M29;
-    chi = s >> 29;
-  }
-  t[17] = (u32)chi;
-  fe_fold_limbs(r, t, clo);
+  fe_reduce_tail(r, t, c);
 }
 
 // r = a * k for a small constant (k * mag(a) must stay < 8), lazy

@@ -7,6 +7,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
+
+#include "../python-bulletproofs_amd/csrc/field.hpp"      // the product's own fe_mul / fe_sqr (variants 8, 9)
 typedef uint32_t u32; typedef uint64_t u64; typedef unsigned __int128 u128;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 
@@ -168,7 +170,12 @@ template <int V>
 __global__ void __launch_bounds__(256) kmul(fe8* out, const fe8* a, const fe8* b, int iters) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   fe8 x = a[i], y = b[i];
-  if (V == 3 || V == 7) {
+  if (V == 8 || V == 9) {
+    bpmi::fe X, Y;
+    bpmi::fe_from_words(X, x.v); bpmi::fe_from_words(Y, y.v);
+    for (int it = 0; it < iters; it++) { if (V == 8) bpmi::fe_mul(X, X, Y); else bpmi::fe_sqr(X, X); }
+    bpmi::fe_canon(X, X); bpmi::fe_to_words(x.v, X);
+  } else if (V == 3 || V == 7) {
     fe9 X, Y; to9(X, x); to9(Y, y);
     for (int it = 0; it < iters; it++) { if (V == 3) mul9(X, X, Y); else sqr9(X, X); }
     canon9(X); from9(x, X);
@@ -276,7 +283,7 @@ int main() {
     int bad = 0;
     for (int i = 0; i < nchk; i++) {
       u64 x[4], y[4]; memcpy(x, ha[i].v, 32); memcpy(y, hb[i].v, 32);
-      for (int it = 0; it < viters; it++) { if (V == 7) h_mulmod(x, x, x); else h_mulmod(x, x, y); }
+      for (int it = 0; it < viters; it++) { if (V == 7 || V == 9) h_mulmod(x, x, x); else h_mulmod(x, x, y); }
       if (memcmp(x, ho[i].v, 32) != 0) { if (bad < 3) printf("  MISMATCH %s idx %d\n", name, i); bad++; }
     }
     printf("check %-28s %s (%d bad of %d)\n", name, bad ? "FAIL" : "ok", bad, nchk);
@@ -289,6 +296,8 @@ int main() {
   RUNMUL(4, "V4 8x32 asm mad+addc")
   RUNMUL(3, "V3 9x29 carry-free mul")
   RUNMUL(7, "V7 9x29 carry-free sqr")
+  RUNMUL(8, "V8 field.hpp fe_mul (fused fold)")
+  RUNMUL(9, "V9 field.hpp fe_sqr (fused fold)")
 #define RUNRAW(OP, name, per) { float best = 1e9; for (int rep = 0; rep < 3; rep++) { CK(hipEventRecord(e0)); hipLaunchKernelGGL(kraw<OP>, dim3(nthreads / 256), dim3(256), 0, 0, draw, 2000); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms; } \
     double ops = (double)nthreads * 2000 * 16 * per; printf("raw   %-28s %.3f ms -> %.2f T lane-ops/s  (%.2f cycles/wave-instr/SIMD @2.4GHz)\n", name, best, ops / best / 1e9, 2.4e9 * 256 * 4 * 64 / (ops / best * 1e3)); }
   RUNRAW(0, "v_mad_u64_u32", 1)
