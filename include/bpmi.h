@@ -106,6 +106,8 @@ int bpmi_ec_lincomb2_batch_dev(bpmi_ctx *ctx, const void *d_p1, const void *d_p2
  * (fastecdsa Point.__add__; e.g. `A + x*S + multiexp(...)`, rangeproof_prover.py:78-87),
  * and folds the per-GPU partial results of a sharded MSM. */
 int bpmi_ec_sum(bpmi_ctx *ctx, const uint8_t *pts, uint64_t n, uint8_t out[64]);
+/* the same for points already in device memory (e.g. the receive buffer of an all_gather) */
+int bpmi_ec_sum_dev(bpmi_ctx *ctx, const void *d_pts, uint64_t n, uint8_t out[64]);
 
 /* out[i] = the point encoded by comp[33*i .. 33*i+33) in SEC1 compressed form (0x02 | 0x03,
  * then x big-endian; 33 zero bytes = identity); ok[i] = 1 when the encoding is valid

@@ -317,6 +317,22 @@ int bpmi_ec_sum(bpmi_ctx *ctx, const uint8_t *pts, uint64_t n, uint8_t out[64]) 
   return BPMI_OK;
 }
 
+int bpmi_ec_sum_dev(bpmi_ctx *ctx, const void *d_pts, uint64_t n, uint8_t out[64]) {
+  if (!ctx || !out || (n && !d_pts)) return ctx ? fail(ctx, BPMI_E_ARG, "null argument") : BPMI_E_ARG;
+  if (n > BPMI_MAX_N) return fail(ctx, BPMI_E_ARG, "n exceeds BPMI_MAX_N");
+  if (n == 0) { memset(out, 0, 64); return BPMI_OK; }
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  int rc = ensure_stage_in(ctx, 512);
+  if (rc) return rc;
+  {
+    StageTimer t(ctx, ST_MISC);
+    hipLaunchKernelGGL(k_ec_sum, dim3(1), dim3(256), 0, ctx->stream, (const u32 *)d_pts, (u32)n, (u32 *)ctx->stage_in);
+  }
+  HIPCHK(ctx, hipMemcpyAsync(out, ctx->stage_in, 64, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return BPMI_OK;
+}
+
 int bpmi_ec_decompress_batch(bpmi_ctx *ctx, const uint8_t *comp, uint64_t n, uint8_t *out, uint8_t *ok) {
   if (!ctx || (n && (!comp || !out || !ok))) return ctx ? fail(ctx, BPMI_E_ARG, "null argument") : BPMI_E_ARG;
   if (n > BPMI_MAX_N) return fail(ctx, BPMI_E_ARG, "n exceeds BPMI_MAX_N");

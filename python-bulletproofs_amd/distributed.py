@@ -50,12 +50,23 @@ class ShardedMSM:
         self.msm = msm or engine.msm_bytes
         self.fold = fold or engine.ec_sum_bytes
         self.msm_dev = getattr(engine, "msm_dev", None)
+        self.fold_dev = getattr(engine, "ec_sum_dev", None) if fold is None else None
         self.group = group
 
     def combine(self, partial: bytes) -> bytes:
         """partial = this rank's 64-byte partial result -> the global result on every rank."""
         if not dist.is_initialized() or dist.get_world_size(self.group) == 1:
             return partial
+        if self.fold_dev is not None and dist.get_backend(self.group) == "nccl":
+            # RCCL: gather straight into one device buffer and fold it there -- no copy of the
+            # partials back to the host and up again
+            world = dist.get_world_size(self.group)
+            dev = torch.device("cuda", torch.cuda.current_device())
+            mine = torch.frombuffer(bytearray(partial), dtype=torch.uint8).to(dev)
+            flat = torch.empty(world * 64, dtype=torch.uint8, device=dev)
+            dist.all_gather_into_tensor(flat, mine, group=self.group)
+            torch.cuda.current_stream().synchronize()
+            return self.fold_dev(flat, world)
         parts = all_gather_bytes(partial, self.group)
         return self.fold(b"".join(parts), len(parts))
 

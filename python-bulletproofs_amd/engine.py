@@ -121,6 +121,11 @@ class Engine:
         self._ck(self.lib.bpmi_ec_sum(self.ctx, pts, n, out))
         return out.raw
 
+    def ec_sum_dev(self, d_pts, n):
+        out = ctypes.create_string_buffer(64)
+        self._ck(self.lib.bpmi_ec_sum_dev(self.ctx, _ptr(d_pts), n, out))
+        return out.raw
+
     def ec_decompress_batch_bytes(self, comp, n):
         """n x 33-byte SEC1 compressed points -> (n x 64-byte wire points, n validity flags)."""
         out = ctypes.create_string_buffer(64 * n)

@@ -90,3 +90,15 @@ def test_inner_product_and_commitments(gp):
     assert gp.same_point(commitment(g, h, a[0], b[0]), a[0].x * pts[0] + b[0].x * pts[1])
     vc = vector_commitment(gp.to_gpu_list(pts[:4]), gp.to_gpu_list(pts[4:]), a[:4], b[:4])
     assert gp.same_point(vc, R.multiexp_naive(pts, [v.x for v in a[:4] + b[:4]]))
+
+
+def test_ec_sum_dev_matches_host_pointer_version(gp):
+    eng = gp.engine()
+    pts, _ = gp.rand_points(37, 4)
+    buf = cbind.pack_points(pts + [INF, pts[3]])
+    d = eng.upload(buf)
+    try:
+        assert eng.ec_sum_dev(d, 39) == eng.ec_sum_bytes(buf, 39)
+        assert eng.ec_sum_dev(d, 0) == bytes(64)
+    finally:
+        d.free()

@@ -32,6 +32,9 @@ assert parts[rank] == part and len(parts) == world
 got = eng.ec_sum_bytes(b"".join(parts), world)
 want = eng.msm_bytes(allpts, pack(es), n * world)
 assert got == want, "sharded MSM != full MSM"
+assert sm.combine(part) == want, "ShardedMSM.combine (device-side fold) != full MSM"
+d = eng.upload(b"".join(parts))
+assert eng.ec_sum_dev(d, world) == want
 kg = (sum(e * k for e, k in zip(es, ks)) % Q)
 assert want == eng.ec_mul_batch_bytes(G, kg.to_bytes(32, "little"), 1)
 dist.barrier()
