@@ -67,12 +67,19 @@ def main():
             raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: libbpmi has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    local_dev = local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        # RCCL ("nccl") is the backend of record; BENCH_DIST_BACKEND=gloo exists only to dry-run the N > 1
+        # control flow with several ranks sharing ONE GPU (RCCL refuses duplicate devices)
+        backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import bulletproofs_amd  # noqa: F401
     from bulletproofs_amd.engine import Engine
@@ -81,7 +88,7 @@ def main():
     # and the library's own HIP events time the stream the kernels are launched on
     stream = torch.cuda.Stream(dev)
     torch.cuda.set_stream(stream)
-    eng = Engine(device=local_rank, stream=stream.cuda_stream)
+    eng = Engine(device=local_dev, stream=stream.cuda_stream)
 
     n = 1 << args.logn
     # ---- synthetic inputs, resident in HBM ------------------------------------------
@@ -135,7 +142,7 @@ def main():
     eng.profile(False)
 
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
