@@ -33,7 +33,8 @@ Q = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 ALGO_BYTES_PER_PAIR = 96
 MULS_PER_MADD = 10.5           # XYZZ mixed addition 8M + 2S plus its carries/subtractions, in multiplication-equivalents
-FE_MUL_PEAK_G = 171.0          # measured fe_mul ceiling, G multiplications/s (profiles/r01_fe_microbench.txt)
+FE_MUL_PEAK_G = 183.0          # measured ceiling of the product's own fe_mul in isolation, G multiplications/s
+                               # (profiles/r01_fe_microbench.txt, variant V8)
 
 
 def synth_scalars(n, seed):
@@ -190,7 +191,7 @@ def main():
                          "achieved": n * windows * MULS_PER_MADD / acc_avg_s / 1e9 if acc_avg_s > 0 else 0.0,
                          "peak": FE_MUL_PEAK_G, "frac": (n * windows * MULS_PER_MADD / acc_avg_s / 1e9 / FE_MUL_PEAK_G) if acc_avg_s > 0 else 0.0,
                          "work": "%d windows x n mixed additions x %.1f multiplication-equivalents (8M + 2S)" % (windows, MULS_PER_MADD),
-                         "peak_source": "profiles/r01_fe_microbench.txt (9x29-bit limbs, v_mad_u64_u32)"},
+                         "peak_source": "profiles/r01_fe_microbench.txt (V8: field.hpp fe_mul, 9x29-bit limbs, v_mad_u64_u32)"},
         "stage_ms_per_msm": stages,
         "hip_event_ms_per_step": ev_ms / args.steps,
         "input_setup_s": round(t_in, 2),

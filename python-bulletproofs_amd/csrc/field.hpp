@@ -113,6 +113,18 @@ BPMI_HD void fe_carry(fe &r, const fe &a) {
 // the 64-bit adds it saves -- 447 vs 207 instructions per multiplication.  Plain C it is.)
 #define BPMI_MAC(acc, x, y) ((acc) += (u64)(x) * (y))
 
+// 2^8 and 2^16 as multiplier operands the optimiser cannot see through: with literal powers of two
+// it rewrites the multiply-add as zero-extend + 64-bit shift + 64-bit add (3 instructions); read
+// from a (never modified) device variable they stay ONE v_mad_u64_u32 with an SGPR operand.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ u32 bpmi_k256 = 256u, bpmi_k65536 = 65536u;
+#define BPMI_K256 bpmi_k256
+#define BPMI_K65536 bpmi_k65536
+#else
+#define BPMI_K256 256u
+#define BPMI_K65536 65536u
+#endif
+
 // ---- product -> tight result ----------------------------------------------------------
 // The 17 product columns are two carry chains.  The HIGH chain (columns 9..16) runs first and
 // leaves limbs th[0..7] (29 bits each) plus its carry-out t17; since
@@ -158,9 +170,9 @@ BPMI_HD void fe_mul(fe &r, const fe &a, const fe &b) {
   for (int k = 0; k < 9; k++) {
     u64 s = c;
     if (k == 0) BPMI_MAC(s, t17, 31264u * 256u);            // 256 t17 at column 9 -> 31264 x at column 0
-    if (k == 1) BPMI_MAC(s, t17, 65536u);                    //                    -> 256 x at column 1
+    if (k == 1) BPMI_MAC(s, t17, BPMI_K65536);               //                    -> 256 x at column 1
     if (k < 8) BPMI_MAC(s, th[k], 31264u); else BPMI_MAC(s, t17, 31264u);
-    if (k >= 1) BPMI_MAC(s, th[k - 1], 256u);
+    if (k >= 1) BPMI_MAC(s, th[k - 1], BPMI_K256);
 #pragma unroll
     for (int i = 0; i <= k; i++) BPMI_MAC(s, a.v[i], b.v[k - i]);
     t[k] = (u32)s & M29;
@@ -190,9 +202,9 @@ BPMI_HD void fe_sqr(fe &r, const fe &a) {
   for (int k = 0; k < 9; k++) {
     u64 s = c;
     if (k == 0) BPMI_MAC(s, t17, 31264u * 256u);
-    if (k == 1) BPMI_MAC(s, t17, 65536u);
+    if (k == 1) BPMI_MAC(s, t17, BPMI_K65536);
     if (k < 8) BPMI_MAC(s, th[k], 31264u); else BPMI_MAC(s, t17, 31264u);
-    if (k >= 1) BPMI_MAC(s, th[k - 1], 256u);
+    if (k >= 1) BPMI_MAC(s, th[k - 1], BPMI_K256);
 #pragma unroll
     for (int i = 0; 2 * i <= k; i++) { if (2 * i == k) BPMI_MAC(s, a.v[i], a.v[i]); else BPMI_MAC(s, d[i], a.v[k - i]); }
     t[k] = (u32)s & M29;
