@@ -153,7 +153,7 @@ BPMI_HD void fe_reduce_tail(fe &r, u32 t[9], u64 c8) {
   r.v[8] = (t[8] & M24) + cc;
 }
 
-BPMI_HD void fe_mul(fe &r, const fe &a, const fe &b) {
+BPMI_HD void fe_mul_c(fe &r, const fe &a, const fe &b) {
   u32 th[8], t[9];
   u64 c = 0;
 #pragma unroll
@@ -182,7 +182,7 @@ BPMI_HD void fe_mul(fe &r, const fe &a, const fe &b) {
 }
 
 // a of magnitude <= 2 (doubled limbs must fit 32 bits and 9 * 2 * m^2 * 2^58 < 2^64)
-BPMI_HD void fe_sqr(fe &r, const fe &a) {
+BPMI_HD void fe_sqr_c(fe &r, const fe &a) {
   u32 d[9];
 #pragma unroll
   for (int i = 0; i < 9; i++) d[i] = a.v[i] << 1;
@@ -211,6 +211,186 @@ BPMI_HD void fe_sqr(fe &r, const fe &a) {
     c = s >> 29;
   }
   fe_reduce_tail(r, t, c);
+}
+
+// ---- GENERATED by tools/gen_fe_mul_asm.py: device bodies of fe_mul / fe_sqr ----
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void fe_mul_dev(fe &r, const fe &a, const fe &b) {
+  u32 th[8], t[9];
+  u64 c = 0, sink_;
+  const u32 k31264 = 31264u, k256 = 256u, k65536 = 65536u, kf = 31264u * 256u;
+  { u64 s = c;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0"
+        : "+v"(s), "=&s"(sink_) : "v"(a.v[1]), "v"(b.v[8]), "v"(a.v[2]), "v"(b.v[7]), "v"(a.v[3]), "v"(b.v[6]), "v"(a.v[4]), "v"(b.v[5]), "v"(a.v[5]), "v"(b.v[4]), "v"(a.v[6]), "v"(b.v[3]), "v"(a.v[7]), "v"(b.v[2]), "v"(a.v[8]), "v"(b.v[1]));
+    th[0] = (u32)s & M29; c = s >> 29; }
+  { u64 s = c;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0"
+        : "+v"(s), "=&s"(sink_) : "v"(a.v[2]), "v"(b.v[8]), "v"(a.v[3]), "v"(b.v[7]), "v"(a.v[4]), "v"(b.v[6]), "v"(a.v[5]), "v"(b.v[5]), "v"(a.v[6]), "v"(b.v[4]), "v"(a.v[7]), "v"(b.v[3]), "v"(a.v[8]), "v"(b.v[2]));
+    th[1] = (u32)s & M29; c = s >> 29; }
+  { u64 s = c;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0"
+        : "+v"(s), "=&s"(sink_) : "v"(a.v[3]), "v"(b.v[8]), "v"(a.v[4]), "v"(b.v[7]), "v"(a.v[5]), "v"(b.v[6]), "v"(a.v[6]), "v"(b.v[5]), "v"(a.v[7]), "v"(b.v[4]), "v"(a.v[8]), "v"(b.v[3]));
+    th[2] = (u32)s & M29; c = s >> 29; }
+  { u64 s = c;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0"
+        : "+v"(s), "=&s"(sink_) : "v"(a.v[4]), "v"(b.v[8]), "v"(a.v[5]), "v"(b.v[7]), "v"(a.v[6]), "v"(b.v[6]), "v"(a.v[7]), "v"(b.v[5]), "v"(a.v[8]), "v"(b.v[4]));
+    th[3] = (u32)s & M29; c = s >> 29; }
+  { u64 s = c;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0"
+        : "+v"(s), "=&s"(sink_) : "v"(a.v[5]), "v"(b.v[8]), "v"(a.v[6]), "v"(b.v[7]), "v"(a.v[7]), "v"(b.v[6]), "v"(a.v[8]), "v"(b.v[5]));
+    th[4] = (u32)s & M29; c = s >> 29; }
+  { u64 s = c;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0"
+        : "+v"(s), "=&s"(sink_) : "v"(a.v[6]), "v"(b.v[8]), "v"(a.v[7]), "v"(b.v[7]), "v"(a.v[8]), "v"(b.v[6]));
+    th[5] = (u32)s & M29; c = s >> 29; }
+  { u64 s = c;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0"
+        : "+v"(s), "=&s"(sink_) : "v"(a.v[7]), "v"(b.v[8]), "v"(a.v[8]), "v"(b.v[7]));
+    th[6] = (u32)s & M29; c = s >> 29; }
+  { u64 s = c;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0"
+        : "+v"(s), "=&s"(sink_) : "v"(a.v[8]), "v"(b.v[8]));
+    th[7] = (u32)s & M29; c = s >> 29; }
+  const u32 t17 = (u32)c;
+  c = 0;
+  { u64 s = c;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0"
+        : "+v"(s), "=&s"(sink_) : "v"(t17), "s"(kf), "v"(th[0]), "s"(k31264), "v"(a.v[0]), "v"(b.v[0]));
+    t[0] = (u32)s & M29; c = s >> 29; }
+  { u64 s = c;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0"
+        : "+v"(s), "=&s"(sink_) : "v"(t17), "s"(k65536), "v"(th[1]), "s"(k31264), "v"(th[0]), "s"(k256), "v"(a.v[0]), "v"(b.v[1]), "v"(a.v[1]), "v"(b.v[0]));
+    t[1] = (u32)s & M29; c = s >> 29; }
+  { u64 s = c;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0"
+        : "+v"(s), "=&s"(sink_) : "v"(th[2]), "s"(k31264), "v"(th[1]), "s"(k256), "v"(a.v[0]), "v"(b.v[2]), "v"(a.v[1]), "v"(b.v[1]), "v"(a.v[2]), "v"(b.v[0]));
+    t[2] = (u32)s & M29; c = s >> 29; }
+  { u64 s = c;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0"
+        : "+v"(s), "=&s"(sink_) : "v"(th[3]), "s"(k31264), "v"(th[2]), "s"(k256), "v"(a.v[0]), "v"(b.v[3]), "v"(a.v[1]), "v"(b.v[2]), "v"(a.v[2]), "v"(b.v[1]), "v"(a.v[3]), "v"(b.v[0]));
+    t[3] = (u32)s & M29; c = s >> 29; }
+  { u64 s = c;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0"
+        : "+v"(s), "=&s"(sink_) : "v"(th[4]), "s"(k31264), "v"(th[3]), "s"(k256), "v"(a.v[0]), "v"(b.v[4]), "v"(a.v[1]), "v"(b.v[3]), "v"(a.v[2]), "v"(b.v[2]), "v"(a.v[3]), "v"(b.v[1]), "v"(a.v[4]), "v"(b.v[0]));
+    t[4] = (u32)s & M29; c = s >> 29; }
+  { u64 s = c;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0"
+        : "+v"(s), "=&s"(sink_) : "v"(th[5]), "s"(k31264), "v"(th[4]), "s"(k256), "v"(a.v[0]), "v"(b.v[5]), "v"(a.v[1]), "v"(b.v[4]), "v"(a.v[2]), "v"(b.v[3]), "v"(a.v[3]), "v"(b.v[2]), "v"(a.v[4]), "v"(b.v[1]), "v"(a.v[5]), "v"(b.v[0]));
+    t[5] = (u32)s & M29; c = s >> 29; }
+  { u64 s = c;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0"
+        : "+v"(s), "=&s"(sink_) : "v"(th[6]), "s"(k31264), "v"(th[5]), "s"(k256), "v"(a.v[0]), "v"(b.v[6]), "v"(a.v[1]), "v"(b.v[5]), "v"(a.v[2]), "v"(b.v[4]), "v"(a.v[3]), "v"(b.v[3]), "v"(a.v[4]), "v"(b.v[2]), "v"(a.v[5]), "v"(b.v[1]), "v"(a.v[6]), "v"(b.v[0]));
+    t[6] = (u32)s & M29; c = s >> 29; }
+  { u64 s = c;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0"
+        : "+v"(s), "=&s"(sink_) : "v"(th[7]), "s"(k31264), "v"(th[6]), "s"(k256), "v"(a.v[0]), "v"(b.v[7]), "v"(a.v[1]), "v"(b.v[6]), "v"(a.v[2]), "v"(b.v[5]), "v"(a.v[3]), "v"(b.v[4]), "v"(a.v[4]), "v"(b.v[3]), "v"(a.v[5]), "v"(b.v[2]), "v"(a.v[6]), "v"(b.v[1]), "v"(a.v[7]), "v"(b.v[0]));
+    t[7] = (u32)s & M29; c = s >> 29; }
+  { u64 s = c;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0"
+        : "+v"(s), "=&s"(sink_) : "v"(t17), "s"(k31264), "v"(th[7]), "s"(k256), "v"(a.v[0]), "v"(b.v[8]), "v"(a.v[1]), "v"(b.v[7]), "v"(a.v[2]), "v"(b.v[6]), "v"(a.v[3]), "v"(b.v[5]), "v"(a.v[4]), "v"(b.v[4]), "v"(a.v[5]), "v"(b.v[3]), "v"(a.v[6]), "v"(b.v[2]), "v"(a.v[7]), "v"(b.v[1]), "v"(a.v[8]), "v"(b.v[0]));
+    t[8] = (u32)s & M29; c = s >> 29; }
+  (void)sink_;
+  fe_reduce_tail(r, t, c);
+}
+__device__ __forceinline__ void fe_sqr_dev(fe &r, const fe &a) {
+  u32 th[8], t[9];
+  u64 c = 0, sink_;
+  const u32 k31264 = 31264u, k256 = 256u, k65536 = 65536u, kf = 31264u * 256u;
+  u32 d[9];
+#pragma unroll
+  for (int i = 0; i < 9; i++) d[i] = a.v[i] << 1;
+  { u64 s = c;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0"
+        : "+v"(s), "=&s"(sink_) : "v"(d[1]), "v"(a.v[8]), "v"(d[2]), "v"(a.v[7]), "v"(d[3]), "v"(a.v[6]), "v"(d[4]), "v"(a.v[5]));
+    th[0] = (u32)s & M29; c = s >> 29; }
+  { u64 s = c;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0"
+        : "+v"(s), "=&s"(sink_) : "v"(d[2]), "v"(a.v[8]), "v"(d[3]), "v"(a.v[7]), "v"(d[4]), "v"(a.v[6]), "v"(a.v[5]), "v"(a.v[5]));
+    th[1] = (u32)s & M29; c = s >> 29; }
+  { u64 s = c;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0"
+        : "+v"(s), "=&s"(sink_) : "v"(d[3]), "v"(a.v[8]), "v"(d[4]), "v"(a.v[7]), "v"(d[5]), "v"(a.v[6]));
+    th[2] = (u32)s & M29; c = s >> 29; }
+  { u64 s = c;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0"
+        : "+v"(s), "=&s"(sink_) : "v"(d[4]), "v"(a.v[8]), "v"(d[5]), "v"(a.v[7]), "v"(a.v[6]), "v"(a.v[6]));
+    th[3] = (u32)s & M29; c = s >> 29; }
+  { u64 s = c;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0"
+        : "+v"(s), "=&s"(sink_) : "v"(d[5]), "v"(a.v[8]), "v"(d[6]), "v"(a.v[7]));
+    th[4] = (u32)s & M29; c = s >> 29; }
+  { u64 s = c;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0"
+        : "+v"(s), "=&s"(sink_) : "v"(d[6]), "v"(a.v[8]), "v"(a.v[7]), "v"(a.v[7]));
+    th[5] = (u32)s & M29; c = s >> 29; }
+  { u64 s = c;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0"
+        : "+v"(s), "=&s"(sink_) : "v"(d[7]), "v"(a.v[8]));
+    th[6] = (u32)s & M29; c = s >> 29; }
+  { u64 s = c;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0"
+        : "+v"(s), "=&s"(sink_) : "v"(a.v[8]), "v"(a.v[8]));
+    th[7] = (u32)s & M29; c = s >> 29; }
+  const u32 t17 = (u32)c;
+  c = 0;
+  { u64 s = c;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0"
+        : "+v"(s), "=&s"(sink_) : "v"(t17), "s"(kf), "v"(th[0]), "s"(k31264), "v"(a.v[0]), "v"(a.v[0]));
+    t[0] = (u32)s & M29; c = s >> 29; }
+  { u64 s = c;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0"
+        : "+v"(s), "=&s"(sink_) : "v"(t17), "s"(k65536), "v"(th[1]), "s"(k31264), "v"(th[0]), "s"(k256), "v"(d[0]), "v"(a.v[1]));
+    t[1] = (u32)s & M29; c = s >> 29; }
+  { u64 s = c;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0"
+        : "+v"(s), "=&s"(sink_) : "v"(th[2]), "s"(k31264), "v"(th[1]), "s"(k256), "v"(d[0]), "v"(a.v[2]), "v"(a.v[1]), "v"(a.v[1]));
+    t[2] = (u32)s & M29; c = s >> 29; }
+  { u64 s = c;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0"
+        : "+v"(s), "=&s"(sink_) : "v"(th[3]), "s"(k31264), "v"(th[2]), "s"(k256), "v"(d[0]), "v"(a.v[3]), "v"(d[1]), "v"(a.v[2]));
+    t[3] = (u32)s & M29; c = s >> 29; }
+  { u64 s = c;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0"
+        : "+v"(s), "=&s"(sink_) : "v"(th[4]), "s"(k31264), "v"(th[3]), "s"(k256), "v"(d[0]), "v"(a.v[4]), "v"(d[1]), "v"(a.v[3]), "v"(a.v[2]), "v"(a.v[2]));
+    t[4] = (u32)s & M29; c = s >> 29; }
+  { u64 s = c;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0"
+        : "+v"(s), "=&s"(sink_) : "v"(th[5]), "s"(k31264), "v"(th[4]), "s"(k256), "v"(d[0]), "v"(a.v[5]), "v"(d[1]), "v"(a.v[4]), "v"(d[2]), "v"(a.v[3]));
+    t[5] = (u32)s & M29; c = s >> 29; }
+  { u64 s = c;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0"
+        : "+v"(s), "=&s"(sink_) : "v"(th[6]), "s"(k31264), "v"(th[5]), "s"(k256), "v"(d[0]), "v"(a.v[6]), "v"(d[1]), "v"(a.v[5]), "v"(d[2]), "v"(a.v[4]), "v"(a.v[3]), "v"(a.v[3]));
+    t[6] = (u32)s & M29; c = s >> 29; }
+  { u64 s = c;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0"
+        : "+v"(s), "=&s"(sink_) : "v"(th[7]), "s"(k31264), "v"(th[6]), "s"(k256), "v"(d[0]), "v"(a.v[7]), "v"(d[1]), "v"(a.v[6]), "v"(d[2]), "v"(a.v[5]), "v"(d[3]), "v"(a.v[4]));
+    t[7] = (u32)s & M29; c = s >> 29; }
+  { u64 s = c;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0"
+        : "+v"(s), "=&s"(sink_) : "v"(t17), "s"(k31264), "v"(th[7]), "s"(k256), "v"(d[0]), "v"(a.v[8]), "v"(d[1]), "v"(a.v[7]), "v"(d[2]), "v"(a.v[6]), "v"(d[3]), "v"(a.v[5]), "v"(a.v[4]), "v"(a.v[4]));
+    t[8] = (u32)s & M29; c = s >> 29; }
+  (void)sink_;
+  fe_reduce_tail(r, t, c);
+}
+#endif
+// ---- end GENERATED ----
+
+// The device runs the generated bodies (same columns, same fold, multiply-adds chained by hand);
+// the host -- unit tests, host tail helpers -- runs the C bodies above.  tests/test_gpu_*.py and the
+// fuzzers compare the device results with the oracle, tests/test_csrc_host.py the C bodies.
+BPMI_HD void fe_mul(fe &r, const fe &a, const fe &b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  fe_mul_dev(r, a, b);
+#else
+  fe_mul_c(r, a, b);
+#endif
+}
+BPMI_HD void fe_sqr(fe &r, const fe &a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  fe_sqr_dev(r, a);
+#else
+  fe_sqr_c(r, a);
+#endif
 }
 
 // r = a * k for a small constant (k * mag(a) must stay < 8), lazy
