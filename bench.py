@@ -33,7 +33,7 @@ Q = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 ALGO_BYTES_PER_PAIR = 96
 MULS_PER_MADD = 10.5           # XYZZ mixed addition 8M + 2S plus its carries/subtractions, in multiplication-equivalents
-FE_MUL_PEAK_G = 183.0          # measured ceiling of the product's own fe_mul in isolation, G multiplications/s
+FE_MUL_PEAK_G = 196.0          # measured ceiling of the product's own fe_mul in isolation, G multiplications/s
                                # (profiles/r01_fe_microbench.txt, variant V8)
 
 
