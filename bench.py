@@ -1,27 +1,41 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark: Pippenger MSM scalar-point pairs/s at n = 2^20 over
-secp256k1 on MI355X (BASELINE.json metric, config "MSM n=2^20").
+secp256k1 on MI355X, plus the second half of BASELINE.json's metric (range-proof verifies/s,
+config C5) and the inner-product-argument prover of config C3 as `extra`.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--logn 20]
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--logn 20] [--scaling weak|strong]
 
-One "step" = one MSM of n pairs per GPU with scalars and points already resident in
-HBM (the result, 64 bytes, comes back to the host every step).  With N > 1 every rank
-owns its own shard of n pairs (weak scaling: the global MSM has N*n pairs); per step the
-per-rank partial points are exchanged with ONE all_gather of 64 bytes over RCCL and
-folded with bpmi_ec_sum, so every rank ends the step holding the global result.
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment: this process touches no GPU; it
+starts `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same args>`
+as a CHILD process (one rank per GPU over RCCL), relays rank 0's JSON line and exits with the
+child's code.  Under torch.distributed.run (the driver's own launch form) it is a rank.
 
-Prints ONE JSON line on rank 0 (see the driver contract in the task statement), with
-  roofline     -- the dominant kernel (msm_accumulate) against the HBM roofline that
-                  north_star prescribes: algorithmic bytes = 96 B/pair (32-B scalar +
-                  64-B affine point), duration from HIP events on the launch stream;
-  cpu_baseline -- the plain-C oracle MSM ("port") timed on this host's cores on a
-                  bounded sample (n = 2^16) of the same workload.
+One "step" = one MSM of n pairs per GPU with scalars and points already resident in HBM; the
+64-byte result comes back to the host every step.  Steps are pipelined two deep through
+bpmi_msm_dev_enqueue / bpmi_msm_finish: the host tail of step k (and, with N > 1, the
+all_gather of the 64-byte partials + bpmi_ec_sum fold) overlaps the kernels of step k + 1;
+all K results are complete inside the timed region.
+  weak   (default): every rank owns its own n pairs; the global MSM has N*n pairs.
+  strong: ONE MSM of n pairs split N ways (n/N pairs per rank), north_star's "large MSMs
+          shard across the GPUs of one node".
+
+Prints ONE JSON line on rank 0 (driver contract), with
+  roofline     -- the dominant kernel (k_accum_l0) against the HBM roofline that north_star
+                  prescribes: algorithmic bytes = 96 B/pair, duration from HIP events on the
+                  launch stream inside the timed region;
+  alu_roofline -- the honest utilisation figure for this integer path: multiply-add lane
+                  operations per second against the raw v_mad_u64_u32 rate of the chip;
+  cpu_baseline -- the plain-C oracle MSM ("port") on this host's cores, bounded sample;
+  result_ok    -- the timed MSM's 64 bytes against the known answer (sum e_i k_i) * G;
+  extra        -- C5 batch verification (verifies/s) and C3 IPA prover (seconds), each with its
+                  own roofline object.
 """
 import argparse
 import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -31,20 +45,55 @@ if REPO not in sys.path:
 
 Q = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
-ALGO_BYTES_PER_PAIR = 96
-MULS_PER_MADD = 10.5           # XYZZ mixed addition 8M + 2S plus its carries/subtractions, in multiplication-equivalents
-FE_MUL_PEAK_G = 196.0          # measured ceiling of the product's own fe_mul in isolation, G multiplications/s
-                               # (profiles/r01_fe_microbench.txt, variant V8)
+ALGO_BYTES_PER_PAIR = 96       # 32-B scalar + 64-B affine point
+IPA_ALGO_BYTES_PER_ELEMENT = 960   # whole proof, per element of the n-vector
+# multiply-add content of one bucket update (xyzz_madd, csrc/curve.hpp): v_mad_u64_u32 per wave-lane, counted in
+# the ISA of k_accum_l0 (profiles/r02_isa_k_accum_l0.txt); and the chip's raw rate for that instruction
+MADS_PER_MADD = None           # filled from profiles/r02_isa_counts.json when present
+RAW_MAD_TOPS = 28.85           # T lane-ops/s, tools/fe_microbench.hip (profiles/r01_fe_microbench.txt)
+MULS_PER_MADD = 10.5           # 8M + 2S plus carries/subtractions in multiplication-equivalents
+FE_MUL_PEAK_G = 196.0          # the product's own fe_mul in isolation, G multiplications/s (r01_fe_microbench.txt, V8)
 
 
 def synth_scalars(n, seed):
-    """e_i = SHA-256("bpmi/scalar" || seed || LE64(i)) mod q."""
+    """e_i = SHA-256("bpmi/scalar" || seed || LE64(i)) mod q -> (bytes, list of ints)."""
     pre = b"bpmi/scalar" + seed.to_bytes(8, "little")
     out = bytearray(32 * n)
+    vals = [0] * n
+    sha = hashlib.sha256
     for i in range(n):
-        v = int.from_bytes(hashlib.sha256(pre + i.to_bytes(8, "little")).digest(), "big") % Q
+        v = int.from_bytes(sha(pre + i.to_bytes(8, "little")).digest(), "big") % Q
+        vals[i] = v
         out[32 * i: 32 * i + 32] = v.to_bytes(32, "little")
-    return bytes(out)
+    return bytes(out), vals
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(args, argv):
+    """--gpus N > 1 outside torch.distributed.run: start the N ranks as a child process.  Nothing in this
+    process has touched a GPU (no torch.cuda call, no libbpmi call), and it never execs."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + argv
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line, flush=True)
+    return proc.returncode if (proc.returncode or line is not None) else 1
 
 
 def main():
@@ -53,9 +102,17 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--logn", type=int, default=20)
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the C5 / C3 extra measurements")
+    ap.add_argument("--no-pipeline", action="store_true", help="synchronous bpmi_msm_dev per step instead of the two-deep pipeline")
+    ap.add_argument("--soak-seconds", type=float, default=6.0,
+                    help="untimed MSMs after the timed region, so that an external sampler (rocm-smi every few seconds) sees the GPU busy")
     ap.add_argument("--cpu-logn", type=int, default=16)
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
@@ -64,13 +121,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE is %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: libbpmi has no CPU fallback")
     local_dev = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
+    backend = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -81,6 +138,7 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+        assert dist.get_world_size() == args.gpus, "rendezvous gave %d ranks, --gpus says %d" % (dist.get_world_size(), args.gpus)
 
     import bulletproofs_amd  # noqa: F401
     from bulletproofs_amd.engine import Engine
@@ -91,78 +149,109 @@ def main():
     torch.cuda.set_stream(stream)
     eng = Engine(device=local_dev, stream=stream.cuda_stream)
 
-    n = 1 << args.logn
+    n_total = 1 << args.logn
+    n = n_total if args.scaling == "weak" else n_total // world      # pairs on this rank
     # ---- synthetic inputs, resident in HBM ------------------------------------------
-    # points P_i = k_i * G generated ON THE GPU (bpmi_ec_mul_batch), k_i and e_i from SHA-256
+    # points P_i = k_i * G generated ON THE GPU (bpmi_ec_mul_batch), k_i and e_i from SHA-256.
+    # weak: rank r draws its own n pairs (seeds 1000 + r / r); strong: every rank derives the same
+    # n_total-pair problem and keeps the contiguous shard [rank * n, (rank + 1) * n).
     G64 = (0x79BE667EF9DCBBAC55A06295CE870B07029BFCDB2DCE28D959F2815B16F81798).to_bytes(32, "little") + \
           (0x483ADA7726A3C4655DA4FBFC0E1108A8FD17B448A68554199C47D08FFB10D4B8).to_bytes(32, "little")
     t_in = time.time()
-    d_k = torch.frombuffer(bytearray(synth_scalars(n, 1000 + rank)), dtype=torch.uint8).to(dev)
+    if args.scaling == "weak":
+        kb, kv = synth_scalars(n, 1000 + rank)
+        eb, ev = synth_scalars(n, rank)
+    else:
+        kb, kv = synth_scalars(n_total, 1000)
+        eb, ev = synth_scalars(n_total, 0)
+        lo = rank * n
+        kb, kv, eb, ev = kb[32 * lo: 32 * (lo + n)], kv[lo: lo + n], eb[32 * lo: 32 * (lo + n)], ev[lo: lo + n]
+    d_k = torch.frombuffer(bytearray(kb), dtype=torch.uint8).to(dev)
     d_G = torch.frombuffer(bytearray(G64), dtype=torch.uint8).to(dev).repeat(n)
     d_pts = torch.empty(64 * n, dtype=torch.uint8, device=dev)
     eng._ck(eng.lib.bpmi_ec_mul_batch_dev(eng.ctx, d_G.data_ptr(), d_k.data_ptr(), n, d_pts.data_ptr()))
     eng.sync()
     del d_G, d_k
-    d_sc = torch.frombuffer(bytearray(synth_scalars(n, rank)), dtype=torch.uint8).to(dev)
+    d_sc = torch.frombuffer(bytearray(eb), dtype=torch.uint8).to(dev)
+    # known answer of this rank's shard: sum e_i * P_i = (sum e_i k_i mod q) * G, one scalar multiplication
+    # by a different kernel (k_ec_mul_batch: a double-and-add ladder, no buckets)
+    local_dlog = sum(e * k for e, k in zip(ev, kv)) % Q
+    del kb, kv, eb, ev
     t_in = time.time() - t_in
 
     from bulletproofs_amd.distributed import ShardedMSM
     sharded = ShardedMSM(engine=eng)
-
-    def step():
-        # per-rank MSM on the local shard, then (N > 1) ONE all_gather of the 64-byte
-        # partials + bpmi_ec_sum fold: every rank ends the step with the global result
-        return sharded.multiexp_local_dev(d_pts, d_sc, n)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        result = step()
+    def run_steps(k):
+        """k MSM steps; every step's global result is complete when this returns."""
+        res = None
+        if args.no_pipeline:
+            for _ in range(k):
+                res = sharded.multiexp_local_dev(d_pts, d_sc, n)
+            return res
+        # two-deep pipeline: MSM j + 1 is queued before MSM j is finished (host tail) and combined
+        # (N > 1: ONE all_gather of the 64-byte partials + bpmi_ec_sum fold on every rank)
+        if k:
+            eng.msm_dev_enqueue(0, d_pts, d_sc, n)
+        for j in range(k):
+            if j + 1 < k:
+                eng.msm_dev_enqueue((j + 1) & 1, d_pts, d_sc, n)
+            res = sharded.combine(eng.msm_finish(j & 1))
+        return res
+
+    result = run_steps(args.warmup)
     eng.profile(2)              # HIP events around the dominant kernel only: each recorded event is a ~10 us bubble
     eng.profile_reset()
     barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ev0.record(stream)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        result = step()
+    result = run_steps(args.steps)
     ev1.record(stream)
     barrier()
     elapsed = time.perf_counter() - t0
     ev_ms = ev0.elapsed_time(ev1)
     prof = eng.profile_read()
-    # per-stage breakdown: a few extra, UNTIMED steps with events around every stage
+    # per-stage breakdown: a few extra, UNTIMED synchronous steps with events around every stage
     eng.profile(1)
     eng.profile_reset()
     for _ in range(min(5, args.steps)):
-        step()
+        sharded.multiexp_local_dev(d_pts, d_sc, n)
     prof_all = eng.profile_read()
     eng.profile(False)
 
+    n_ranks_seen = 1
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+        cpu_side = dist.get_backend() != "nccl"
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if cpu_side else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+        ones = torch.ones(1, dtype=torch.int64, device="cpu" if cpu_side else dev)
+        dist.all_reduce(ones)
+        n_ranks_seen = int(ones.item())
+        dl = [None] * world
+        dist.all_gather_object(dl, local_dlog)
+        global_dlog = sum(dl) % Q
+    else:
+        global_dlog = local_dlog
+    expect = eng.ec_mul_batch_bytes(G64, global_dlog.to_bytes(32, "little"), 1)
+    result_ok = bool(result == expect)
 
     pairs_per_s = world * n * args.steps / elapsed
-    # dominant kernel: msm_accumulate (one launch per MSM processes all n pairs)
-    traffic = None
-    try:   # per-launch HBM bytes of the dominant kernel from the committed rocprofv3 --pmc passes
-        with open(os.path.join(REPO, "profiles", "r01_pmc_traffic_msm_n2e20.json")) as f:
-            for row in json.load(f)["kernels"]:
-                if row["kernel"] == "k_accum_l0" and args.logn == 20:
-                    traffic = row["hbm_bytes_per_launch_guide_corrected"]
-    except (OSError, KeyError, ValueError):
-        pass
     acc_ms, acc_calls = prof["msm_accumulate"]
     acc_avg_s = acc_ms / max(acc_calls, 1) / 1e3
     achieved_gbs = ALGO_BYTES_PER_PAIR * n / acc_avg_s / 1e9 if acc_avg_s > 0 else 0.0
     stages = {k: round(v[0] / max(v[1], 1), 4) for k, v in prof_all.items() if v[1]}
     windows = 16 if n >= (1 << 15) else 32          # pick_window_bits (csrc/msm_host.hpp): c = 16 -> 16 windows
+    isa = isa_counts()
+    traffic, traffic_src = committed_traffic(args.logn if args.scaling == "weak" or world == 1 else -1)
 
+    madds_per_launch = n * windows
     out = {
         "metric": "Pippenger MSM scalar-point pairs/sec at n=2^20",
         "value": pairs_per_s,
@@ -172,38 +261,256 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": args.scaling,
         "vs_baseline": None,
         "dtype": "u32x9 (29-bit limbs, 256-bit modular integer)",
         "data": "synthetic",
-        "config": {"workload": "MSM n=2^%d per GPU over secp256k1, uniform 256-bit scalars (SHA-256), points k_i*G, "
-                               "inputs resident in HBM, 64-byte result to host every step" % args.logn,
-                   "pairs_per_gpu": n, "sharding": "pairs across ranks, one all_gather of 64 B partials per step"},
+        "config": {"workload": ("MSM n=2^%d per GPU" % args.logn if args.scaling == "weak" else "ONE MSM n=2^%d split over %d GPUs" % (args.logn, world)) +
+                               " over secp256k1, uniform 256-bit scalars (SHA-256), points k_i*G, inputs resident in HBM, "
+                               "64-byte result to host every step",
+                   "pairs_per_gpu": n, "sharding": "pairs across ranks, one all_gather of 64 B partials per step",
+                   "pipeline": "synchronous" if args.no_pipeline else "two MSMs in flight (bpmi_msm_dev_enqueue / bpmi_msm_finish)"},
+        "n_ranks_seen": n_ranks_seen,
+        "dist_backend": backend,
+        "result_ok": result_ok,
+        "result_check": "timed MSM result == (sum e_i k_i mod q) * G computed by k_ec_mul_batch (different kernel), outside the timed region",
         "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                     "traffic_source": "profiles/r01_pmc_traffic_msm_n2e20.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)",
+                     "traffic_measured_in_run": False,
+                     "traffic_source": traffic_src,
                      "kernel": "k_accum_l0 (msm_accumulate)", "kernel_avg_ms": acc_avg_s * 1e3,
-                     "note": "integer-ALU bound path: 96 algorithmic B/pair vs ~1.8e5 integer ops/pair"},
-        # the honest utilisation figure for this path (SURVEY section 8d asks for it beside the prescribed
-        # HBM fraction): field multiplications per second of the dominant kernel against the
-        # measured ceiling of the same fe_mul in isolation (tools/fe_microbench.hip)
+                     "note": "integer-ALU bound path: 96 algorithmic B/pair vs ~1.5e4 multiply-adds/pair"},
         "alu_roofline": {"kernel": "k_accum_l0", "unit": "G field-mul/s",
-                         "achieved": n * windows * MULS_PER_MADD / acc_avg_s / 1e9 if acc_avg_s > 0 else 0.0,
-                         "peak": FE_MUL_PEAK_G, "frac": (n * windows * MULS_PER_MADD / acc_avg_s / 1e9 / FE_MUL_PEAK_G) if acc_avg_s > 0 else 0.0,
+                         "achieved": madds_per_launch * MULS_PER_MADD / acc_avg_s / 1e9 if acc_avg_s > 0 else 0.0,
+                         "peak": FE_MUL_PEAK_G, "frac": (madds_per_launch * MULS_PER_MADD / acc_avg_s / 1e9 / FE_MUL_PEAK_G) if acc_avg_s > 0 else 0.0,
                          "work": "%d windows x n mixed additions x %.1f multiplication-equivalents (8M + 2S)" % (windows, MULS_PER_MADD),
-                         "peak_source": "profiles/r01_fe_microbench.txt (V8: field.hpp fe_mul, 9x29-bit limbs, v_mad_u64_u32)"},
+                         "peak_source": "profiles/r01_fe_microbench.txt (V8: the product's own fe_mul in isolation; NOT a hardware peak)"},
         "stage_ms_per_msm": stages,
         "hip_event_ms_per_step": ev_ms / args.steps,
         "input_setup_s": round(t_in, 2),
         "result_x_lo": result[:8].hex(),
     }
+    if isa and acc_avg_s > 0:
+        mads = isa["v_mad_u64_u32_per_madd"]
+        lane_mads = madds_per_launch * mads / acc_avg_s / 1e12
+        out["alu_roofline"]["frac_vs_raw_mad"] = lane_mads / RAW_MAD_TOPS
+        out["alu_roofline"]["raw_mad"] = {"achieved_T_lane_ops": lane_mads, "peak_T_lane_ops": RAW_MAD_TOPS,
+                                          "mads_per_madd": mads, "instructions_per_madd": isa["instructions_per_madd"],
+                                          "source": "profiles/r02_isa_counts.json (ISA of k_accum_l0's main path), "
+                                                    "profiles/r01_fe_microbench.txt (raw v_mad_u64_u32 rate)"}
+
+    if not args.no_extra:
+        out["extra"] = {}
+        for name, fn in (("C5_batch_verify", extra_c5), ("C3_ipa_prover", extra_c3)):
+            try:
+                out["extra"][name] = fn(eng, world, rank, dev)
+            except Exception as e:      # an extra must never cost the headline line
+                out["extra"][name] = {"error": "%s: %s" % (type(e).__name__, e)}
+            barrier()
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args.cpu_logn, d_pts, d_sc)
+        out["cpu_baseline"] = cpu_baseline(args.cpu_logn, d_pts, d_sc, eng)
+
+    # soak: keep the GPU visibly busy for an external sampler; not part of any reported number
+    t_s = time.perf_counter()
+    while time.perf_counter() - t_s < args.soak_seconds:
+        run_steps(8)
+    barrier()
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def isa_counts():
+    try:
+        with open(os.path.join(REPO, "profiles", "r02_isa_counts.json")) as f:
+            return json.load(f)["k_accum_l0_madd_main_path"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+def committed_traffic(logn):
+    """Per-launch HBM bytes of the dominant kernel from the committed rocprofv3 --pmc passes (NOT measured in this run)."""
+    for name in ("r02_pmc_traffic_msm_n2e20.json", "r01_pmc_traffic_msm_n2e20.json"):
+        try:
+            with open(os.path.join(REPO, "profiles", name)) as f:
+                for row in json.load(f)["kernels"]:
+                    if row["kernel"] == "k_accum_l0" and logn == 20:
+                        return row["hbm_bytes_per_launch_guide_corrected"], "profiles/%s (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes; committed file, not this run)" % name
+        except (OSError, KeyError, ValueError):
+            pass
+    return None, None
+
+
+# ---- extra: config C5, batch verification of 2^14 64-bit range proofs -----------------------------
+def extra_c5(eng, world, rank, dev, log_batch=14, distinct=64):
+    """verifies/s of the random-linear-combination batch verifier on wire-format proofs:
+    bytes -> GPU decompression of 19 points per proof -> native host preparation (transcript
+    re-hashes, scalars) -> ONE MSM over 3 + 2*64 + 19*batch points; sharded by proof over the ranks.
+    Replaces a loop of RangeVerifier.verify (/root/reference/src/rangeproofs/rangeproof_verifier.py:55-99,
+    src/innerproduct/inner_product_verifier.py:127-147)."""
+    import torch
+    import torch.distributed as dist
+    from bulletproofs_amd.distributed import ShardedMSM, shard_bounds
+    from bulletproofs_amd.ec import secp256k1
+    from bulletproofs_amd.engine import set_default_engine
+    from bulletproofs_amd.rangeproofs import BatchRangeVerifier, NIRangeProver
+    from bulletproofs_amd.rangeproofs.codec import proof_to_bytes
+    from bulletproofs_amd.utils import ModP, commitment, elliptic_hash, mod_hash
+    set_default_engine(eng)
+    nbits = 64
+    gs = [elliptic_hash(str(i).encode() + b"gs") for i in range(nbits)]
+    hs = [elliptic_hash(str(i).encode() + b"hs") for i in range(nbits)]
+    g, h, u = elliptic_hash(b"g"), elliptic_hash(b"h"), elliptic_hash(b"u")
+    proofs = []
+    t0 = time.perf_counter()
+    for j in range(distinct):
+        v = ModP(int.from_bytes(hashlib.sha256(b"v%d" % j).digest()[:8], "big"), Q)
+        gamma = mod_hash(b"gamma%d" % j, Q)
+        proofs.append((commitment(g, h, v, gamma), NIRangeProver(v, nbits, g, h, gs, hs, gamma, u, secp256k1, b"seed%d" % j).prove()))
+    t_prove = time.perf_counter() - t0
+    wire = [proof_to_bytes(pr) for _, pr in proofs]
+    total = 1 << log_batch
+    lo, hi = shard_bounds(total, world, rank)
+    Vs_in = [proofs[k % distinct][0] for k in range(lo, hi)]
+    blobs_in = [wire[k % distinct] for k in range(lo, hi)]
+    usable = usable_cpus()
+    threads = max(1, min(32, usable // world))
+    sharded = ShardedMSM(engine=eng)
+
+    def one_batch(corrupt=False):
+        bv = BatchRangeVerifier(g, h, gs, hs, u)
+        blobs = blobs_in
+        if corrupt:           # flip one bit of a scalar in one proof of this rank's shard: the batch must reject
+            bad = bytearray(blobs_in[len(blobs_in) // 2])
+            bad[len(bad) // 2] ^= 1
+            blobs = list(blobs_in)
+            blobs[len(blobs) // 2] = bytes(bad)
+        try:
+            bv.add_wire_native(Vs_in, blobs, threads=threads)
+            return bool(bv.verify(sharded=sharded if world > 1 else None))
+        except Exception:
+            return False
+
+    one_batch()                                        # warm (workspaces, pinned buffers)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    eng.profile(1)
+    eng.profile_reset()
+    reps = 3
+    t0 = time.perf_counter()
+    oks = [one_batch() for _ in range(reps)]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = (time.perf_counter() - t0) / reps
+    prof = eng.profile_read()
+    eng.profile(False)
+    rejected = not one_batch(corrupt=True)
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if dist.get_backend() != "nccl" else dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    msm_pairs = 3 + 2 * nbits + 19 * (hi - lo)
+    stage_ms = {k: v[0] / reps for k, v in prof.items() if v[1]}
+    dom = max(stage_ms, key=stage_ms.get) if stage_ms else None
+    acc_s = stage_ms.get("msm_accumulate", 0.0) / 1e3
+    wire_bytes = sum(len(b) for b in blobs_in)
+    return {"metric": "range-proof verifies/sec (batched, 64-bit proofs, wire bytes in)", "value": total / elapsed, "unit": "verifies/s",
+            "batch": total, "seconds_per_batch": elapsed, "accepted": all(oks), "corrupted_batch_rejected": rejected,
+            "host_threads_per_rank": threads, "host_cores_usable": usable, "msm_pairs_per_rank": msm_pairs,
+            "proves_per_s_one_gpu": distinct / t_prove,
+            "gpu_stage_ms_per_batch": {k: round(v, 4) for k, v in stage_ms.items()},
+            "roofline": {"bound": "hbm", "kernel": "k_accum_l0 (msm_accumulate) of the one batch MSM", "kernel_ms": acc_s * 1e3,
+                         "achieved": (ALGO_BYTES_PER_PAIR * msm_pairs / acc_s / 1e9) if acc_s > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": (ALGO_BYTES_PER_PAIR * msm_pairs / acc_s / 1e9 / HBM_PEAK_GBS) if acc_s > 0 else None,
+                         "dominant_gpu_stage": dom, "traffic": None,
+                         "note": "host-bound: %.1f of %.1f ms per batch are GPU stages; wire input %.1f MB per batch"
+                                 % (sum(stage_ms.values()), elapsed * 1e3, wire_bytes / 1e6)}}
+
+
+# ---- extra: config C3, inner-product-argument prover n = 2^20 ----------------------------------------
+def extra_c3(eng, world, rank, dev, logn=20):
+    """Seconds per FastNIProver2.prove at n = 2^20 (/root/reference/src/innerproduct/inner_product_prover.py:70-110):
+    g, h, a, b resident in HBM, 20 rounds of (c_L, c_R, L, R) -> host Fiat-Shamir -> fold.  With N > 1 the
+    vectors are sharded cyclically (ShardedFastNIProver2) and the proof is the same one."""
+    import torch
+    import torch.distributed as dist
+    from bulletproofs_amd.distributed import ShardedFastNIProver2
+    from bulletproofs_amd.ec import secp256k1
+    from bulletproofs_amd.innerproduct import FastNIProver2
+    from bulletproofs_amd.utils import elliptic_hash
+    n = 1 << logn
+    nl = n // world
+    G64 = secp256k1.G.to_le64()
+
+    def dev_points(seed):
+        kb, _ = synth_scalars(nl, seed)
+        d_k = eng.upload(kb)
+        d_G = eng.upload(G64 * nl)
+        d_p = eng.alloc(64 * nl)
+        eng._ck(eng.lib.bpmi_ec_mul_batch_dev(eng.ctx, d_G.ptr, d_k.ptr, nl, d_p.ptr))
+        eng.sync()
+        d_G.free()
+        d_k.free()
+        return d_p
+
+    # rank r holds the elements i = r (mod world) of the global vectors: seeds depend on the rank
+    d_g, d_h = dev_points(3000 + rank), dev_points(4000 + rank)
+    d_a, d_b = eng.upload(synth_scalars(nl, 5000 + rank)[0]), eng.upload(synth_scalars(nl, 6000 + rank)[0])
+    u = elliptic_hash(b"bench-u")
+
+    def prove(profile):
+        st = eng.ipa_create_dev(d_g, d_h, d_a, d_b, nl, u.to_le64())
+        if profile:
+            eng.profile(1)
+            eng.profile_reset()
+        t0 = time.perf_counter()
+        pr = ShardedFastNIProver2(None, None, u, None, None, None, secp256k1, transcript=b"bench", engine=eng, state=st).prove()
+        dt = time.perf_counter() - t0
+        return dt, pr
+
+    prove(False)                         # warm
+    if world > 1:
+        dist.barrier()
+    times = []
+    for _ in range(3):
+        dt, pr = prove(False)
+        times.append(dt)
+    dt_prof, pr2 = prove(True)           # one more with stage timers (slower: every event is a bubble)
+    prof = eng.profile_read()
+    eng.profile(False)
+    secs = min(times)
+    if world > 1:
+        tt = torch.tensor([secs], dtype=torch.float64, device="cpu" if dist.get_backend() != "nccl" else dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        secs = float(tt.item())
+    stage_ms = {k: v[0] for k, v in prof.items() if v[1]}
+    dom = max(stage_ms, key=stage_ms.get) if stage_ms else None
+    dom_s = stage_ms.get(dom, 0.0) / 1e3 if dom else 0.0
+    algo = IPA_ALGO_BYTES_PER_ELEMENT * n
+    same = (pr.transcript == pr2.transcript)
+    for d in (d_g, d_h, d_a, d_b):
+        d.free()
+    return {"metric": "inner-product-argument prover seconds at n=2^%d" % logn, "value": secs, "unit": "s", "higher_is_better": False,
+            "runs_s": [round(t, 5) for t in times], "rounds": len(pr.xs), "deterministic": bool(same),
+            "transcript_sha256": hashlib.sha256(pr.transcript).hexdigest()[:16],
+            "gpu_stage_ms_per_proof_with_timers": {k: round(v, 3) for k, v in stage_ms.items()},
+            "seconds_with_stage_timers": dt_prof,
+            "roofline": {"bound": "hbm", "kernel": "stage %s (sum over the proof's launches)" % dom, "kernel_ms": dom_s * 1e3,
+                         "achieved": algo / secs / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": algo / secs / 1e9 / HBM_PEAK_GBS,
+                         "traffic": None,
+                         "note": "960 algorithmic B per element over the whole proof (SURVEY 8d) / wall seconds of the proof; integer-ALU bound"}}
+
+
+def usable_cpus():
+    usable = len(os.sched_getaffinity(0))
+    q = cpu_quota()
+    if q:
+        usable = max(1, min(usable, int(q)))
+    return usable
 
 
 def cpu_quota():
@@ -215,9 +522,9 @@ def cpu_quota():
         return None
 
 
-def cpu_baseline(logn, d_pts, d_sc):
+def cpu_baseline(logn, d_pts, d_sc, eng):
     """The plain-C oracle MSM (bucket method, pthreads) on this host's cores over the
-    first 2^logn pairs of the same synthetic workload."""
+    first 2^logn pairs of the same synthetic workload; its result is also compared with the GPU's."""
     from oracle import cbind
     m = 1 << logn
     pts = bytes(d_pts[: 64 * m].cpu().numpy().tobytes())
@@ -229,13 +536,15 @@ def cpu_baseline(logn, d_pts, d_sc):
     t0 = time.perf_counter()
     reps = 0
     while True:
-        cbind.msm_bytes(pts, scs, m, cores)
+        ref = cbind.msm_bytes(pts, scs, m, cores)
         reps += 1
         if time.perf_counter() - t0 > 12.0:          # ~12 s of CPU work (bounded sample)
             break
     dt = time.perf_counter() - t0
+    gpu = eng.msm_dev(d_pts, d_sc, m)
     return {"value": m * reps / dt, "unit": "pairs/s", "cores": cores, "host_cores": os.cpu_count(), "host_cpu_quota": cpu_quota(), "kind": "port",
-            "sample": "oracle/c bucket MSM, first 2^%d pairs of the same inputs, %d reps, %d threads" % (logn, reps, cores)}
+            "sample": "oracle/c bucket MSM, first 2^%d pairs of the same inputs, %d reps, %d threads" % (logn, reps, cores),
+            "sample_matches_gpu": bool(gpu == ref)}
 
 
 if __name__ == "__main__":

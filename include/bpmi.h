@@ -13,8 +13,11 @@
  *   - field elements / scalars: 32 bytes little-endian (= 4 x u64 LE limbs);
  *     affine point: x || y (64 bytes); the identity is 64 zero bytes
  *     ((0,0) is not on y^2 = x^3 + 7);
- *   - scalars handed in must already be reduced to [0, q) -- the Python wrapper
- *     does the `% order` of pippenger.py:26 and the length check of :23-24;
+ *   - scalars of the MSM / scalar-multiplication entry points (bpmi_msm*, bpmi_ec_mul_batch*)
+ *     may be any 256-bit value: the kernels reduce them mod q as they load them (the `% order`
+ *     of pippenger.py:26; the Python wrapper also does it, with the length check of :23-24).
+ *     The mod-q entry points (bpmi_sc_*, the a / b vectors and challenges of bpmi_ipa_*) expect
+ *     values in [0, q);
  *   - every function returns 0 on success or a negative BPMI_E_* code, never
  *     throws, never aborts; bpmi_last_error(ctx) gives the message
  *     (ctx == NULL: the message of the last failed bpmi_ctx_create);
@@ -85,6 +88,15 @@ int bpmi_download(bpmi_ctx *ctx, void *host, const void *dptr, size_t bytes);
  * n == 0 gives the identity (pippenger.py:28-29). */
 int bpmi_msm(bpmi_ctx *ctx, const uint8_t *pts, const uint8_t *scalars, uint64_t n, uint8_t out[64]);
 int bpmi_msm_dev(bpmi_ctx *ctx, const void *d_pts, const void *d_scalars, uint64_t n, uint8_t out[64]);
+/* The same MSM (n <= 2^23, device pointers) split into an asynchronous pair: `enqueue` queues every kernel
+ * and the device->host copy of the window sums on the ctx stream and returns; `finish` waits for that
+ * MSM only (its own completion event), runs the host part of the tail and writes the result.  Two slots
+ * (0, 1) may be in flight: a caller that alternates them overlaps the host tail -- and its own work between
+ * two MSMs, e.g. the exchange of per-GPU partial results -- of MSM k with the kernels of MSM k + 1.  The
+ * inputs must stay valid and unmodified until `finish`; while a slot is pending, a synchronous call that
+ * needs it fails with BPMI_E_STATE. */
+int bpmi_msm_dev_enqueue(bpmi_ctx *ctx, int slot, const void *d_pts, const void *d_scalars, uint64_t n);
+int bpmi_msm_finish(bpmi_ctx *ctx, int slot, uint8_t out[64]);
 /* Two independent MSMs (n0, n1 <= 2^23) from host buffers, overlapped on the ctx's two lanes: pairs
  * such as A / S (rangeproof_prover.py:52,60) and T1 / T2 (:71-72) cost one round trip instead of two. */
 int bpmi_msm2(bpmi_ctx *ctx, const uint8_t *pts0, const uint8_t *scalars0, uint64_t n0, uint8_t out0[64], const uint8_t *pts1,
@@ -127,6 +139,25 @@ int bpmi_sc_fold(bpmi_ctx *ctx, const uint8_t *lo, const uint8_t *hi, const uint
 int bpmi_sc_fold_dev(bpmi_ctx *ctx, const void *d_lo, const void *d_hi, const uint8_t x[32], const uint8_t y[32],
                      uint64_t n, void *d_out);
 
+/* The verifier's s-vector with the proof's final scalars folded in, n = 2^k entries each:
+ *   s_i = prod_j xs[j]^(+1 if bit (k-1-j) of i is set, else -1)   (Verifier2.get_ss,
+ *   src/innerproduct/inner_product_verifier.py:91-102),  sa[i] = a s_i,  sb[i] = b s_i^-1 scale[i]
+ * (the `a * s_i` / `b * s_i^-1` lists of :131-133; scale: n scalars or NULL -- hsp_i = y^-i hs_i of
+ * src/rangeproofs/rangeproof_verifier.py:72 rides in the scalars).  xs, xinvs: k challenges and their
+ * inverses.  2-3 multiplications per element on the device instead of the reference's k per element. */
+int bpmi_sc_svector(bpmi_ctx *ctx, const uint8_t *xs, const uint8_t *xinvs, uint32_t k, const uint8_t a[32], const uint8_t b[32],
+                    const uint8_t *scale, uint8_t *sa, uint8_t *sb);
+
+/* Verifier2.verify's two sides (src/innerproduct/inner_product_verifier.py:127-147) as ONE multi-scalar
+ * multiplication over generators that are already in device memory (n = 2^k points each, d_hscale: n scalars or NULL):
+ *   out = sum_i sa[i] g_i + sum_i sb[i] h_i + sum_t extra_scalars[t] * extra_pts[t]
+ * with sa, sb as in bpmi_sc_svector, computed on the device and consumed there (no host loop over n, no
+ * round trip of the 2n scalars).  The caller passes u, the L_j, R_j and P with their scalars
+ * (a b, -x_j^2, -x_j^-2, -1) as the extra terms and accepts iff out is the identity (64 zero bytes). */
+int bpmi_ipa_verify_dev(bpmi_ctx *ctx, const void *d_g, const void *d_h, const void *d_hscale, uint64_t n, const uint8_t *xs,
+                        const uint8_t *xinvs, uint32_t k, const uint8_t a[32], const uint8_t b[32], const uint8_t *extra_pts,
+                        const uint8_t *extra_scalars, uint64_t n_extra, uint8_t out[64]);
+
 /* ---- inner-product argument prover, split at the Fiat-Shamir edge ----------------------
  * One object = one run of FastNIProver2.prove (src/innerproduct/inner_product_prover.py:70-110).
  * g, h: n points; a, b: n scalars; u: one point; all copied to the device once and kept
@@ -162,7 +193,8 @@ void bpmi_ipa_destroy(bpmi_ipa *st);
 /* ---- batch verification of range proofs: host-side preparation (no GPU work, no ctx) ---------------
  * For n_proofs range proofs -- values_per_proof = 1: single-value proofs; m > 1: aggregated proofs of m values
  * each, n_gens = m x bits -- over n_gens generator pairs in the wire format of
- * python-bulletproofs_amd/rangeproofs/codec.py (blob i = blobs[blob_off[i] .. blob_off[i+1])):
+ * python-bulletproofs_amd/rangeproofs/codec.py (blob i = blobs[blob_off[i] .. blob_off[i+1]); the offsets must be
+ * non-decreasing and end inside blobs[0 .. blobs_len), else BPMI_E_ARG):
  * parses every proof, runs the byte-level transcript checks of RangeVerifier / Verifier1 / Verifier2
  * (src/rangeproofs/rangeproof_verifier.py:42-53, src/innerproduct/inner_product_verifier.py:31-43,
  * 104-125) and computes, with the caller's random weights (4 scalars per proof, LE, in [1, q)), the
@@ -176,7 +208,7 @@ void bpmi_ipa_destroy(bpmi_ipa *st);
  *               in the same order, ready for bpmi_ec_decompress_batch
  * *first_bad = index of the first proof that failed parsing or a transcript check, or -1.  `threads`
  * host threads share the proofs.  The native twin of BatchRangeVerifier.add (rangeproofs/batch.py). */
-int bpmi_rp_batch_prepare(uint32_t n_gens, uint32_t values_per_proof, uint64_t n_proofs, const uint8_t *blobs, const uint64_t *blob_off,
+int bpmi_rp_batch_prepare(uint32_t n_gens, uint32_t values_per_proof, uint64_t n_proofs, const uint8_t *blobs, uint64_t blobs_len, const uint64_t *blob_off,
                           const uint8_t *weights, int threads, uint8_t *v_scalars, uint8_t *pt_scalars, uint8_t *shared, uint8_t *comp_out, int64_t *first_bad);
 
 /* ---- per-stage device timing (HIP events on the ctx's stream) --------------------------

@@ -377,8 +377,11 @@ def Proof2(a, b, xs, Ls, Rs, transcript, start_transcript=0):  # :61-73
     )
 
 
-def ipa2_prove(g, h, u, P, a, b, q=Q, transcript=None, multiexp=None):
-    """FastNIProver2 (src/innerproduct/inner_product_prover.py:48-110)."""
+def ipa2_prove(g, h, u, P, a, b, q=Q, transcript=None, multiexp=None, ecops=None):
+    """FastNIProver2 (src/innerproduct/inner_product_prover.py:48-110).
+    ecops (optional, config-size test cases only): an object with lincomb2(p1, p2, k1, k2) -> [k1*p1[i] + k2*p2[i]]
+    and mul_batch(points, scalars) -> [scalars[i]*points[i]] that computes the SAME element-wise expressions in
+    bulk (oracle/cbind.py: the plain-C affine group law); without it every element is a Python `int * Point`."""
     assert len(g) == len(h) == len(a) == len(b)
     assert len(a) & (len(a) - 1) == 0
     tr = Transcript()
@@ -401,14 +404,18 @@ def ipa2_prove(g, h, u, P, a, b, q=Q, transcript=None, multiexp=None):
         xs.append(x)
         tr.add_number(x)
         xi = x.inv()
-        g = [xi * g[i] + x * g[half + i] for i in range(half)]  # :107
-        h = [x * h[i] + xi * h[half + i] for i in range(half)]  # :108
+        if ecops is not None:
+            g = ecops.lincomb2(g[:half], g[half:], xi, x)  # :107
+            h = ecops.lincomb2(h[:half], h[half:], x, xi)  # :108
+        else:
+            g = [xi * g[i] + x * g[half + i] for i in range(half)]  # :107
+            h = [x * h[i] + xi * h[half + i] for i in range(half)]  # :108
         a = [x * a[i] + xi * a[half + i] for i in range(half)]  # :109
         b = [xi * b[i] + x * b[half + i] for i in range(half)]  # :110
     return Proof2(a[0], b[0], xs, Ls, Rs, tr.digest, init_len)
 
 
-def ipa1_prove(g, h, u, P, c, a, b, q=Q, seed=b"", multiexp=None):
+def ipa1_prove(g, h, u, P, c, a, b, q=Q, seed=b"", multiexp=None, ecops=None):
     """NIProver (src/innerproduct/inner_product_prover.py:11-45)."""
     assert len(g) == len(h) == len(a) == len(b)
     tr = Transcript(seed)
@@ -416,7 +423,7 @@ def ipa1_prove(g, h, u, P, c, a, b, q=Q, seed=b"", multiexp=None):
     tr.add_number(x)
     P_new = P + (x * c) * u
     u_new = x * u
-    p2 = ipa2_prove(g, h, u_new, P_new, a, b, q, tr.digest, multiexp)
+    p2 = ipa2_prove(g, h, u_new, P_new, a, b, q, tr.digest, multiexp, ecops)
     return Proof1(u_new, P_new, p2, tr.digest)
 
 
@@ -492,7 +499,7 @@ def _zpow_term(z, i, n):
     return (z ** (2 + i // n)) * (2 ** (i % n))
 
 
-def range_prove_generic(vs, n, g, h, gs, hs, gammas, u, q=Q, seed=b"", multiexp=None):
+def range_prove_generic(vs, n, g, h, gs, hs, gammas, u, q=Q, seed=b"", multiexp=None, ecops=None):
     """NIRangeProver.prove (src/rangeproofs/rangeproof_prover.py:35-112) for
     len(vs) == 1, AggregNIRangeProver.prove (rangeproof_aggreg_prover.py:36-146)
     otherwise.  The two differ only in the z-power term and in gamma handling;
@@ -540,7 +547,10 @@ def range_prove_generic(vs, n, g, h, gs, hs, gammas, u, q=Q, seed=b"", multiexp=
     taux = tau2 * (x**2) + tau1 * x + gsum
     mu = alpha + rho * x
     yinv = y.inv()
-    hsp = [(yinv**i) * hs[i] for i in range(nm)]  # :77 / aggreg :82
+    if ecops is not None:
+        hsp = ecops.mul_batch(hs, [yinv**i for i in range(nm)])  # :77 / aggreg :82
+    else:
+        hsp = [(yinv**i) * hs[i] for i in range(nm)]  # :77 / aggreg :82
     P = (
         A
         + x * S
@@ -549,16 +559,16 @@ def range_prove_generic(vs, n, g, h, gs, hs, gammas, u, q=Q, seed=b"", multiexp=
             [-z for _ in range(nm)] + [(z * ypow[i]) + _zpow_term(z, i, n) for i in range(nm)],
         )
     )
-    inner = ipa1_prove(gs, hsp, u, P + (-mu) * h, t_hat, ls, rs, q, b"", mexp)
+    inner = ipa1_prove(gs, hsp, u, P + (-mu) * h, t_hat, ls, rs, q, b"", mexp, ecops)
     return RangeProof(taux, mu, t_hat, T1, T2, A, S, inner, tr.digest)
 
 
-def range_prove(v, n, g, h, gs, hs, gamma, u, q=Q, seed=b"", multiexp=None):
-    return range_prove_generic([v], n, g, h, gs, hs, gamma, u, q, seed, multiexp)
+def range_prove(v, n, g, h, gs, hs, gamma, u, q=Q, seed=b"", multiexp=None, ecops=None):
+    return range_prove_generic([v], n, g, h, gs, hs, gamma, u, q, seed, multiexp, ecops)
 
 
-def aggreg_range_prove(vs, n, g, h, gs, hs, gammas, u, q=Q, seed=b"", multiexp=None):
-    return range_prove_generic(list(vs), n, g, h, gs, hs, list(gammas), u, q, seed, multiexp)
+def aggreg_range_prove(vs, n, g, h, gs, hs, gammas, u, q=Q, seed=b"", multiexp=None, ecops=None):
+    return range_prove_generic(list(vs), n, g, h, gs, hs, list(gammas), u, q, seed, multiexp, ecops)
 
 
 def _range_transcript(proof):

@@ -99,3 +99,29 @@ def sc_fold(lo, hi, x, xinv):
     out = ctypes.create_string_buffer(32 * n)
     lib().orc_sc_fold(pack_scalars(lo), pack_scalars(hi), pack_scalars([x]), pack_scalars([xinv]), n, out)
     return [int.from_bytes(out.raw[32 * i: 32 * i + 32], "little") for i in range(n)]
+
+
+class BulkEC:
+    """`ecops` for oracle.bp_ref at configuration sizes: the element-wise `int * Point` / fold expressions of
+    the reference computed in bulk by the C restatement of the affine group law."""
+
+    def __init__(self, threads=None):
+        self.threads = threads
+
+    def mul_batch(self, pts, scalars):
+        return ec_mul_batch(pts, [int(s % Q) for s in scalars], self.threads)
+
+    def lincomb2(self, p1, p2, k1, k2):
+        return ec_lincomb2_batch(p1, p2, int(k1 % Q), int(k2 % Q), self.threads)
+
+
+def sc_dot_bytes(a, b, n):
+    out = ctypes.create_string_buffer(32)
+    lib().orc_sc_dot(a, b, n, out)
+    return out.raw
+
+
+def sc_fold_bytes(lo, hi, x, xinv, n):
+    out = ctypes.create_string_buffer(32 * n)
+    lib().orc_sc_fold(lo, hi, int(x % Q).to_bytes(32, "little"), int(xinv % Q).to_bytes(32, "little"), n, out)
+    return out.raw

@@ -24,6 +24,8 @@ SIGNATURES = {
     "bpmi_msm": (_i, [_vp, _cp, _cp, _u64, _cp]),
     "bpmi_msm2": (_i, [_vp, _cp, _cp, _u64, _cp, _cp, _cp, _u64, _cp]),
     "bpmi_msm_dev": (_i, [_vp, _vp, _vp, _u64, _cp]),
+    "bpmi_msm_dev_enqueue": (_i, [_vp, _i, _vp, _vp, _u64]),
+    "bpmi_msm_finish": (_i, [_vp, _i, _cp]),
     "bpmi_ec_mul_batch": (_i, [_vp, _cp, _cp, _u64, _cp]),
     "bpmi_ec_mul_batch_dev": (_i, [_vp, _vp, _vp, _u64, _vp]),
     "bpmi_ec_lincomb2_batch": (_i, [_vp, _cp, _cp, _cp, _cp, _u64, _cp]),
@@ -35,6 +37,8 @@ SIGNATURES = {
     "bpmi_sc_dot_dev": (_i, [_vp, _vp, _vp, _u64, _cp]),
     "bpmi_sc_fold": (_i, [_vp, _cp, _cp, _cp, _cp, _u64, _cp]),
     "bpmi_sc_fold_dev": (_i, [_vp, _vp, _vp, _cp, _cp, _u64, _vp]),
+    "bpmi_sc_svector": (_i, [_vp, _cp, _cp, ctypes.c_uint32, _cp, _cp, _cp, _cp, _cp]),
+    "bpmi_ipa_verify_dev": (_i, [_vp, _vp, _vp, _vp, _u64, _cp, _cp, ctypes.c_uint32, _cp, _cp, _cp, _cp, _u64, _cp]),
     "bpmi_ipa_create": (_i, [_vp, _cp, _cp, _cp, _cp, _u64, _cp, ctypes.POINTER(_vp)]),
     "bpmi_ipa_create_scaled": (_i, [_vp, _cp, _cp, _cp, _cp, _u64, _cp, _cp, ctypes.POINTER(_vp)]),
     "bpmi_ipa_create_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _u64, _cp, ctypes.POINTER(_vp)]),
@@ -43,7 +47,7 @@ SIGNATURES = {
     "bpmi_ipa_fold": (_i, [_vp, _cp, _cp]),
     "bpmi_ipa_finish": (_i, [_vp, _cp, _cp]),
     "bpmi_ipa_export": (_i, [_vp, _cp, _cp, _cp, _cp]),
-    "bpmi_rp_batch_prepare": (_i, [ctypes.c_uint32, ctypes.c_uint32, _u64, _cp, ctypes.c_void_p, _cp, _i, _cp, _cp, _cp, _cp, ctypes.c_void_p]),
+    "bpmi_rp_batch_prepare": (_i, [ctypes.c_uint32, ctypes.c_uint32, _u64, _cp, _u64, ctypes.c_void_p, _cp, _i, _cp, _cp, _cp, _cp, ctypes.c_void_p]),
     "bpmi_ipa_destroy": (None, [_vp]),
     "bpmi_profile": (_i, [_vp, _i]),
     "bpmi_profile_reset": (_i, [_vp]),

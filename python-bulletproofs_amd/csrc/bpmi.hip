@@ -100,7 +100,7 @@ void bpmi_ctx_destroy(bpmi_ctx *ctx) {
   if (ctx->stream1) { (void)hipStreamSynchronize(ctx->stream1); (void)hipStreamDestroy(ctx->stream1); }
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ws1) (void)hipFree(ctx->ws1);
-  if (ctx->pin1) (void)hipHostFree(ctx->pin1);
+  for (auto &pd : ctx->pend) { if (pd.pin) (void)hipHostFree(pd.pin); if (pd.done) (void)hipEventDestroy(pd.done); }
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -181,7 +181,7 @@ int bpmi_msm_dev(bpmi_ctx *ctx, const void *d_pts, const void *d_scalars, uint64
     const uint64_t lo = k * SLICE, cnt = std::min<uint64_t>(SLICE, n - lo);
     Segs s = segs_init();
     s.pts[0] = (const u32 *)d_pts + 16 * lo; s.sc[0] = (const u32 *)d_scalars + 8 * lo; s.n[0] = (u32)cnt; s.total = (u32)cnt;
-    rc = msm_enqueue(ctx, lane, s);
+    rc = msm_enqueue(ctx, lane, lane, s);
     if (rc) return rc;
   }
   for (uint64_t k = (nsl >= 2 ? nsl - 2 : 0); k < nsl; k++) {
@@ -189,6 +189,30 @@ int bpmi_msm_dev(bpmi_ctx *ctx, const void *d_pts, const void *d_scalars, uint64
     if (rc) return rc;
   }
   return bpmi_ec_sum(ctx, parts.data(), nsl, out);
+}
+// Asynchronous pair: enqueue returns as soon as the MSM's kernels and its device->host copy are queued on
+// the ctx stream; finish waits for THAT MSM only and runs the host part of its tail.  Two slots, so the
+// host tail (and the caller's own work, e.g. the exchange of partial results) of MSM k overlaps the
+// kernels of MSM k + 1.
+int bpmi_msm_dev_enqueue(bpmi_ctx *ctx, int slot, const void *d_pts, const void *d_scalars, uint64_t n) {
+  if (!ctx || (n && (!d_pts || !d_scalars))) return ctx ? fail(ctx, BPMI_E_ARG, "null argument") : BPMI_E_ARG;
+  if (slot < 0 || slot > 1) return fail(ctx, BPMI_E_ARG, "slot must be 0 or 1");
+  if (n > (1ull << 23)) return fail(ctx, BPMI_E_ARG, "bpmi_msm_dev_enqueue takes at most 2^23 pairs (use bpmi_msm_dev)");
+  if (ctx->opt_split) return fail(ctx, BPMI_E_STATE, "option split is not available with the asynchronous entry points");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  Segs s = segs_init();
+  s.pts[0] = (const u32 *)d_pts; s.sc[0] = (const u32 *)d_scalars; s.n[0] = (u32)n; s.total = (u32)n;
+  int rc = msm_enqueue(ctx, 0, slot, s);
+  if (rc == BPMI_OK) ctx->pend[slot].async = true;
+  return rc;
+}
+int bpmi_msm_finish(bpmi_ctx *ctx, int slot, uint8_t out[64]) {
+  if (!ctx || !out) return ctx ? fail(ctx, BPMI_E_ARG, "null argument") : BPMI_E_ARG;
+  if (slot < 0 || slot > 1) return fail(ctx, BPMI_E_ARG, "slot must be 0 or 1");
+  if (!ctx->pend[slot].async) return fail(ctx, BPMI_E_STATE, "no MSM was enqueued in this slot");
+  ctx->pend[slot].async = false;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  return msm_finish(ctx, slot, out);
 }
 int bpmi_msm(bpmi_ctx *ctx, const uint8_t *pts, const uint8_t *scalars, uint64_t n, uint8_t out[64]) {
   if (!ctx || !out || (n && (!pts || !scalars))) return ctx ? fail(ctx, BPMI_E_ARG, "null argument") : BPMI_E_ARG;
@@ -419,6 +443,88 @@ int bpmi_sc_fold(bpmi_ctx *ctx, const uint8_t *lo, const uint8_t *hi, const uint
   HIPCHK(ctx, hipMemcpyAsync(out, dout, 32 * n, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return BPMI_OK;
+}
+
+// ---- IPA verifier: s-vector on the device + ONE multi-segment MSM ---------------------------------------------
+// layout in ctx->stage_in: sa (32 n) | sb (32 n) | x table (64 k) | half tables | extra area
+struct SvecLayout { u32 *sa, *sb, *xt, *tab; char *extra; u32 k, kl; };
+static int svector_layout(bpmi_ctx *ctx, uint64_t n, u32 k, size_t extra_bytes, SvecLayout &L) {
+  const u32 kl = k / 2, kh = k - kl;
+  const size_t ntab = ((size_t)1 << kl) + ((size_t)1 << kh);
+  const size_t o_sb = align_up(32 * n, 256), o_xt = o_sb + align_up(32 * n, 256), o_tab = o_xt + align_up(64 * (size_t)(k ? k : 1), 256),
+               o_ex = o_tab + align_up(64 * ntab, 256);
+  int rc = ensure_stage_in(ctx, o_ex + extra_bytes + 512);
+  if (rc) return rc;
+  char *base = (char *)ctx->stage_in;
+  L.sa = (u32 *)base; L.sb = (u32 *)(base + o_sb); L.xt = (u32 *)(base + o_xt); L.tab = (u32 *)(base + o_tab); L.extra = base + o_ex;
+  L.k = k; L.kl = kl;
+  return BPMI_OK;
+}
+static int svector_launch(bpmi_ctx *ctx, const SvecLayout &L, const void *d_scale, uint64_t n, const uint8_t *xs, const uint8_t *xinvs,
+                          const uint8_t a[32], const uint8_t b[32]) {
+  const u32 k = L.k;
+  const size_t ntab = ((size_t)1 << L.kl) + ((size_t)1 << (k - L.kl));
+  std::vector<uint8_t> xt(64 * (size_t)(k ? k : 1));
+  for (u32 j = 0; j < k; j++) { memcpy(&xt[64 * j], xs + 32 * j, 32); memcpy(&xt[64 * j + 32], xinvs + 32 * j, 32); }
+  HIPCHK(ctx, hipMemcpyAsync(L.xt, xt.data(), xt.size(), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));          // xt is owned by this frame
+  Sc2 ab;
+  memcpy(ab.k1, a, 32); memcpy(ab.k2, b, 32);
+  {
+    StageTimer t(ctx, ST_SCFOLD);
+    hipLaunchKernelGGL(k_sc_svector_tables, dim3((u32)((ntab + 255) / 256)), dim3(256), 0, ctx->stream, L.xt, k, L.kl, ab, L.tab);
+    hipLaunchKernelGGL(k_sc_svector, dim3((u32)((n + 255) / 256)), dim3(256), 0, ctx->stream, L.tab, k, L.kl, (const u32 *)d_scale, (u32)n, L.sa, L.sb);
+  }
+  HIPCHK(ctx, hipGetLastError());
+  return BPMI_OK;
+}
+static bool log2_exact(uint64_t n, u32 &k) { k = 0; while ((1ull << k) < n) k++; return n && (1ull << k) == n; }
+
+int bpmi_sc_svector(bpmi_ctx *ctx, const uint8_t *xs, const uint8_t *xinvs, uint32_t k, const uint8_t a[32], const uint8_t b[32],
+                    const uint8_t *scale, uint8_t *sa, uint8_t *sb) {
+  if (!ctx || !a || !b || !sa || !sb || (k && (!xs || !xinvs))) return ctx ? fail(ctx, BPMI_E_ARG, "null argument") : BPMI_E_ARG;
+  if (k > 24) return fail(ctx, BPMI_E_ARG, "k must be <= 24");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const uint64_t n = 1ull << k;
+  SvecLayout L;
+  int rc = svector_layout(ctx, n, k, scale ? 32 * n : 0, L);
+  if (rc) return rc;
+  if (scale) HIPCHK(ctx, hipMemcpyAsync(L.extra, scale, 32 * n, hipMemcpyHostToDevice, ctx->stream));
+  rc = svector_launch(ctx, L, scale ? L.extra : nullptr, n, xs, xinvs, a, b);
+  if (rc) return rc;
+  HIPCHK(ctx, hipMemcpyAsync(sa, L.sa, 32 * n, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(sb, L.sb, 32 * n, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return BPMI_OK;
+}
+
+int bpmi_ipa_verify_dev(bpmi_ctx *ctx, const void *d_g, const void *d_h, const void *d_hscale, uint64_t n, const uint8_t *xs, const uint8_t *xinvs,
+                        uint32_t k, const uint8_t a[32], const uint8_t b[32], const uint8_t *extra_pts, const uint8_t *extra_scalars,
+                        uint64_t n_extra, uint8_t out[64]) {
+  if (!ctx || !d_g || !d_h || !a || !b || !out || (k && (!xs || !xinvs)) || (n_extra && (!extra_pts || !extra_scalars)))
+    return ctx ? fail(ctx, BPMI_E_ARG, "null argument") : BPMI_E_ARG;
+  u32 kk;
+  if (!log2_exact(n, kk) || kk != k || n > (1ull << 22)) return fail(ctx, BPMI_E_ARG, "n must be 2^k, k <= 22");
+  if (n_extra > (1u << 20)) return fail(ctx, BPMI_E_ARG, "too many extra points");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const size_t o_es = align_up(64 * n_extra, 256);
+  SvecLayout L;
+  int rc = svector_layout(ctx, n, k, o_es + 32 * n_extra, L);
+  if (rc) return rc;
+  rc = svector_launch(ctx, L, d_hscale, n, xs, xinvs, a, b);
+  if (rc) return rc;
+  u32 *d_sa = L.sa, *d_sb = L.sb;
+  char *d_ex = L.extra;
+  if (n_extra) {
+    HIPCHK(ctx, hipMemcpyAsync(d_ex, extra_pts, 64 * n_extra, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(d_ex + o_es, extra_scalars, 32 * n_extra, hipMemcpyHostToDevice, ctx->stream));
+  }
+  Segs s = segs_init();
+  s.pts[0] = (const u32 *)d_g; s.sc[0] = d_sa; s.n[0] = (u32)n;
+  s.pts[1] = (const u32 *)d_h; s.sc[1] = d_sb; s.n[1] = (u32)n;
+  s.pts[2] = (const u32 *)d_ex; s.sc[2] = (const u32 *)(d_ex + o_es); s.n[2] = (u32)n_extra;
+  s.total = (u32)(2 * n + n_extra);
+  return msm_run(ctx, s, out);
 }
 
 // ---- IPA prover state ---------------------------------------------------------------------------
@@ -747,7 +853,7 @@ void bpmi_ipa_destroy(bpmi_ipa *st) {
 }
 
 // ---- batch verification of range proofs: host-side preparation ---------------------------------------
-int bpmi_rp_batch_prepare(uint32_t n_gens, uint32_t values_per_proof, uint64_t n_proofs, const uint8_t *blobs, const uint64_t *blob_off,
+int bpmi_rp_batch_prepare(uint32_t n_gens, uint32_t values_per_proof, uint64_t n_proofs, const uint8_t *blobs, uint64_t blobs_len, const uint64_t *blob_off,
                           const uint8_t *weights, int threads, uint8_t *v_scalars, uint8_t *pt_scalars, uint8_t *shared, uint8_t *comp_out, int64_t *first_bad) {
   if (!blobs || !blob_off || !weights || !v_scalars || !pt_scalars || !shared || !first_bad) return BPMI_E_ARG;
   if (n_gens < 2 || (n_gens & (n_gens - 1)) || n_gens > 65536) return BPMI_E_ARG;
@@ -756,6 +862,9 @@ int bpmi_rp_batch_prepare(uint32_t n_gens, uint32_t values_per_proof, uint64_t n
   uint32_t k = 0;
   while ((1u << k) < n_gens) k++;
   *first_bad = -1;
+  // the offset table comes from the caller, the proofs from the network: never read outside blobs[0, blobs_len)
+  if (blob_off[0] > blobs_len) return BPMI_E_ARG;
+  for (uint64_t g = 0; g < n_proofs; g++) if (blob_off[g] > blob_off[g + 1] || blob_off[g + 1] > blobs_len) return BPMI_E_ARG;
   const size_t nacc = 5 + 2 * (size_t)n_gens;
   if (threads < 1) threads = 1;
   if ((uint64_t)threads > n_proofs) threads = n_proofs ? (int)n_proofs : 1;

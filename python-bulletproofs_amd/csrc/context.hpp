@@ -29,9 +29,14 @@ struct bpmi_ctx {
   // throughput-bound stages of the other
   hipStream_t stream1 = nullptr;
   void *ws1 = nullptr; size_t ws1_bytes = 0;
-  void *pin1 = nullptr; size_t pin1_bytes = 0;
   hipEvent_t ev_fork = nullptr;
-  struct PendingMsm { bool active = false; u32 W = 0, nv = 0, c = 0; int tail = 2; u32 *E = nullptr, *out = nullptr; TailOffs to; } pend[2];
+  // One in-flight MSM: its own pinned host buffer (what the tail reads) and its own completion event, so
+  // that finishing it never waits for work enqueued behind it (bpmi_msm_dev_enqueue / bpmi_msm_finish
+  // keep two MSMs in flight on ONE stream: the host tail of MSM k overlaps the kernels of MSM k + 1).
+  struct PendingMsm {
+    bool active = false; u32 W = 0, nv = 0, c = 0; int tail = 2; TailOffs to;
+    void *pin = nullptr; size_t pin_bytes = 0; hipEvent_t done = nullptr; bool async = false;
+  } pend[2];
   void *stage_in = nullptr; size_t stage_in_bytes = 0;  // device staging for host-pointer entry points
   // options
   int opt_c = 0;        // window bits, 0 = auto
@@ -115,7 +120,7 @@ static int ensure_ws_lane(bpmi_ctx *ctx, int lane, size_t bytes) {
   ctx->ws1_bytes = want;
   return BPMI_OK;
 }
-static int ensure_pin_lane(bpmi_ctx *ctx, int lane, size_t bytes);
+static int ensure_pin_slot(bpmi_ctx *ctx, int slot, size_t bytes);
 static int ensure_stage_in(bpmi_ctx *ctx, size_t bytes) {
   if (bytes <= ctx->stage_in_bytes) return BPMI_OK;
   if (ctx->stage_in) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(ctx->stage_in)); ctx->stage_in = nullptr; ctx->stage_in_bytes = 0; }
@@ -131,11 +136,14 @@ static int ensure_pin(bpmi_ctx *ctx, size_t bytes) {
   return BPMI_OK;
 }
 
-static int ensure_pin_lane(bpmi_ctx *ctx, int lane, size_t bytes) {
-  if (lane == 0) return ensure_pin(ctx, bytes);
-  if (bytes <= ctx->pin1_bytes) return BPMI_OK;
-  if (ctx->pin1) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream1)); HIPCHK(ctx, hipHostFree(ctx->pin1)); ctx->pin1 = nullptr; ctx->pin1_bytes = 0; }
-  HIPCHK(ctx, hipHostMalloc(&ctx->pin1, bytes, hipHostMallocDefault));
-  ctx->pin1_bytes = bytes;
+// pinned buffer + completion event of pending-MSM slot `slot`
+static int ensure_pin_slot(bpmi_ctx *ctx, int slot, size_t bytes) {
+  bpmi_ctx::PendingMsm &pd = ctx->pend[slot];
+  if (!pd.done) HIPCHK(ctx, hipEventCreateWithFlags(&pd.done, hipEventDisableTiming));
+  if (bytes <= pd.pin_bytes) return BPMI_OK;
+  if (bytes < 16384) bytes = 16384;
+  if (pd.pin) { HIPCHK(ctx, hipEventSynchronize(pd.done)); HIPCHK(ctx, hipHostFree(pd.pin)); pd.pin = nullptr; pd.pin_bytes = 0; }
+  HIPCHK(ctx, hipHostMalloc(&pd.pin, bytes, hipHostMallocDefault));
+  pd.pin_bytes = bytes;
   return BPMI_OK;
 }

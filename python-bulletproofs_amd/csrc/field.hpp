@@ -108,9 +108,11 @@ BPMI_HD void fe_carry(fe &r, const fe &a) {
 }
 
 // acc += x * y (u32 x u32 -> u64, plus the 64-bit accumulator) = ONE v_mad_u64_u32.
-// (Spelling this as inline asm to force the carry of column k into the first multiply-add of
-// column k+1 was tried: hipcc pads every asm statement with an s_nop, which costs more than
-// the 64-bit adds it saves -- 447 vs 207 instructions per multiplication.  Plain C it is.)
+// The C bodies below (fe_mul_c / fe_sqr_c) are what the HOST compiles (unit tests, host tail).  On the
+// device the generated bodies further down run instead: one inline-asm statement per product column
+// chains the multiply-adds through the running accumulator, because the compiler otherwise adds the
+// carry of column k with a separate 64-bit addition.  (A first attempt with one asm statement per
+// multiply-add was slower -- hipcc pads every asm statement with an s_nop; per column it pays.)
 #define BPMI_MAC(acc, x, y) ((acc) += (u64)(x) * (y))
 
 // 2^8 and 2^16 as multiplier operands the optimiser cannot see through: with literal powers of two

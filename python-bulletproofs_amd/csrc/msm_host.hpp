@@ -102,12 +102,14 @@ static DigitJobs digit_jobs_concat(const DigitJobs &a, const DigitJobs &b) {
   return J;
 }
 
-// Enqueue every GPU stage of one MSM on `lane` (0 = the ctx stream, 1 = the second lane),
-// including the device->pinned-host copy the tail needs; returns without synchronising.
+// Enqueue every GPU stage of one MSM on `lane` (0 = the ctx stream, 1 = the second lane: stream +
+// workspace), including the device->pinned-host copy the tail needs, into pending slot `slot`
+// (pinned buffer + completion event); returns without synchronising.
 //   [w0, w0 + wcount): the windows this call handles (wcount = 0: all of them)
-static int msm_enqueue(bpmi_ctx *ctx, int lane, const Segs &segs, u32 w0 = 0, u32 wcount = 0) {
+static int msm_enqueue(bpmi_ctx *ctx, int lane, int slot, const Segs &segs, u32 w0 = 0, u32 wcount = 0) {
   const uint64_t n = segs.total;
-  bpmi_ctx::PendingMsm &pd = ctx->pend[lane];
+  bpmi_ctx::PendingMsm &pd = ctx->pend[slot];
+  if (pd.active) return fail(ctx, BPMI_E_STATE, "an MSM is still pending in this slot (bpmi_msm_finish it first)");
   pd.active = false;
   if (n == 0) return BPMI_OK;
   if (n > BPMI_MAX_N) return fail(ctx, BPMI_E_ARG, "n exceeds BPMI_MAX_N");
@@ -143,9 +145,10 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, const Segs &segs, u32 w0 = 0, u3
     }
     debug_sync(ctx, "k_msm_small", st);
     const size_t eb = 4ull * XYZZ_WORDS * g.W;
-    rc = ensure_pin_lane(ctx, lane, eb);
+    rc = ensure_pin_slot(ctx, slot, eb);
     if (rc) return rc;
-    HIPCHK(ctx, hipMemcpyAsync(lane ? ctx->pin1 : ctx->pin, w.E, eb, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(pd.pin, w.E, eb, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipEventRecord(pd.done, st));
     pd.active = true; pd.W = g.W; pd.nv = 1; pd.c = g.c; pd.tail = 2; pd.to = to;
     HIPCHK(ctx, hipGetLastError());
     return BPMI_OK;
@@ -266,34 +269,34 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, const Segs &segs, u32 w0 = 0, u3
     const int tail = wcount ? 2 : (ctx->opt_tail ? ctx->opt_tail : 2);      // window groups are combined on the host
     if (tail == 1) {
       hipLaunchKernelGGL(k_tail, dim3(1), dim3(64), 0, st, w.E, g.W, g.c, to, w.out);
-      rc = ensure_pin_lane(ctx, lane, 4096);
+      rc = ensure_pin_slot(ctx, slot, 4096);
       if (rc) return rc;
-      HIPCHK(ctx, hipMemcpyAsync(lane ? ctx->pin1 : ctx->pin, w.out, 64, hipMemcpyDeviceToHost, st));
+      HIPCHK(ctx, hipMemcpyAsync(pd.pin, w.out, 64, hipMemcpyDeviceToHost, st));
     } else {
       const size_t eb = 4ull * XYZZ_WORDS * g.W * g.nv;
-      rc = ensure_pin_lane(ctx, lane, eb);
+      rc = ensure_pin_slot(ctx, slot, eb);
       if (rc) return rc;
-      HIPCHK(ctx, hipMemcpyAsync(lane ? ctx->pin1 : ctx->pin, w.E, eb, hipMemcpyDeviceToHost, st));
+      HIPCHK(ctx, hipMemcpyAsync(pd.pin, w.E, eb, hipMemcpyDeviceToHost, st));
     }
+    HIPCHK(ctx, hipEventRecord(pd.done, st));
     pd.active = true; pd.W = g.W; pd.nv = g.nv; pd.c = g.c; pd.tail = tail; pd.to = to;
   }
   HIPCHK(ctx, hipGetLastError());
   return BPMI_OK;
 }
-// Wait for the lane and run the host part of the tail; out = the MSM result.
-static int msm_finish(bpmi_ctx *ctx, int lane, uint8_t out[64]) {
-  bpmi_ctx::PendingMsm &pd = ctx->pend[lane];
+// Wait for the slot's MSM (its completion event: work enqueued behind it keeps running) and run the
+// host part of the tail; out = the MSM result.
+static int msm_finish(bpmi_ctx *ctx, int slot, uint8_t out[64]) {
+  bpmi_ctx::PendingMsm &pd = ctx->pend[slot];
   if (!pd.active) { memset(out, 0, 64); return BPMI_OK; }      // n == 0
-  hipStream_t st = lane_stream(ctx, lane);
-  HIPCHK(ctx, hipStreamSynchronize(st));
-  const void *pin = lane ? ctx->pin1 : ctx->pin;
+  pd.active = false;
+  HIPCHK(ctx, hipEventSynchronize(pd.done));
+  const void *pin = pd.pin;
   if (pd.tail == 1) {
     memcpy(out, pin, 64);
   } else {
     bpmi_host::tail_combine(out, (const u32 *)pin, pd.W, pd.c, pd.to);     // host_tail.hpp
   }
-  pd.active = false;
-  debug_sync(ctx, "ST_TAIL", st);
   return BPMI_OK;
 }
 // One MSM as two window groups, one per lane (option "split").  Measured on MI355X
@@ -306,17 +309,17 @@ static int msm_run_split(bpmi_ctx *ctx, const Segs &segs, uint8_t out[64]) {
   if (rc) return rc;
   HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
   HIPCHK(ctx, hipStreamWaitEvent(ctx->stream1, ctx->ev_fork, 0));
-  rc = msm_enqueue(ctx, 0, segs, 0, Wa);
+  rc = msm_enqueue(ctx, 0, 0, segs, 0, Wa);
   if (rc) return rc;
-  rc = msm_enqueue(ctx, 1, segs, Wa, W - Wa);
-  if (rc) return rc;
+  rc = msm_enqueue(ctx, 1, 1, segs, Wa, W - Wa);
+  if (rc) { ctx->pend[0].active = false; return rc; }
   bpmi_ctx::PendingMsm &p0 = ctx->pend[0], &p1 = ctx->pend[1];
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream1));
   const size_t b0 = 4ull * XYZZ_WORDS * p0.W * p0.nv, b1 = 4ull * XYZZ_WORDS * p1.W * p1.nv;
   std::vector<u32> E((b0 + b1) / 4);
-  memcpy(E.data(), ctx->pin, b0);
-  memcpy((char *)E.data() + b0, ctx->pin1, b1);
+  memcpy(E.data(), p0.pin, b0);
+  memcpy((char *)E.data() + b0, p1.pin, b1);
   bpmi_host::tail_combine(out, E.data(), W, c, p0.to);
   p0.active = p1.active = false;
   return BPMI_OK;
@@ -324,7 +327,7 @@ static int msm_run_split(bpmi_ctx *ctx, const Segs &segs, uint8_t out[64]) {
 static int msm_run(bpmi_ctx *ctx, const Segs &segs, uint8_t out[64]) {
   if (segs.total > BPMI_MAX_N) return fail(ctx, BPMI_E_ARG, "n exceeds BPMI_MAX_N");
   if (ctx->opt_split == 1 && segs.total >= 2) return msm_run_split(ctx, segs, out);
-  int rc = msm_enqueue(ctx, 0, segs);
+  int rc = msm_enqueue(ctx, 0, 0, segs);
   if (rc) return rc;
   return msm_finish(ctx, 0, out);
 }
@@ -336,10 +339,10 @@ static int msm_run_pair(bpmi_ctx *ctx, const Segs &s0, uint8_t out0[64], const S
   if (rc) return rc;
   HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
   HIPCHK(ctx, hipStreamWaitEvent(ctx->stream1, ctx->ev_fork, 0));
-  rc = msm_enqueue(ctx, 0, s0);
+  rc = msm_enqueue(ctx, 0, 0, s0);
   if (rc) return rc;
-  rc = msm_enqueue(ctx, 1, s1);
-  if (rc) return rc;
+  rc = msm_enqueue(ctx, 1, 1, s1);
+  if (rc) { (void)hipStreamSynchronize(ctx->stream); ctx->pend[0].active = false; return rc; }
   rc = msm_finish(ctx, 0, out0);
   const int rc1 = msm_finish(ctx, 1, out1);
   return rc ? rc : rc1;

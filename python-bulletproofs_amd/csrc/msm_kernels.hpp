@@ -27,6 +27,7 @@ template <typename F>
 __device__ __forceinline__ bool for_each_digit_raw(const Segs &segs, const MsmGeom &g, u32 i, F f) {
   sc s;
   load_words8(s.v, seg_scalar(segs, i));
+  sc_reduce_once(s);
   const bool neg = sc_is_high(s);
   if (neg) sc_neg(s, s);
   u32 carry = 0;
@@ -48,6 +49,7 @@ template <typename F>
 __device__ __forceinline__ void for_each_digit(const Segs &segs, const MsmGeom &g, u32 i, F f) {
   sc s;
   load_words8(s.v, seg_scalar(segs, i));
+  sc_reduce_once(s);
   const bool neg = sc_is_high(s);
   if (neg) sc_neg(s, s);
   u32 carry = 0;

@@ -14,6 +14,7 @@ __global__ void __launch_bounds__(256, 3) k_ec_mul_batch(const u32 *__restrict__
   load_affine(P, pts + 16ull * i);
   sc s;
   load_words8(s.v, scs + 8ull * i);
+  sc_reduce_once(s);
   const bool neg = sc_is_high(s);
   if (neg) sc_neg(s, s);
   jac acc;

@@ -47,6 +47,16 @@ BPMI_HD u32 words_sub(u32 r[8], const u32 a[8], const u32 b[8]) {
   }
   return (u32)br;
 }
+// s in [0, 2^256) -> s mod q (one conditional subtraction: 2^256 < 2q).  The MSM / ladder kernels apply it
+// to every scalar they load, so a C caller that hands in an unreduced scalar gets the reference's
+// `e % order` (pippenger.py:26) instead of a wrapped borrow in the sign recoding.
+BPMI_HD void sc_reduce_once(sc &s) {
+  const u32 q[8] = BPMI_SC_Q;
+  u32 t[8];
+  const u32 br = words_sub(t, s.v, q);
+#pragma unroll
+  for (int i = 0; i < 8; i++) s.v[i] = br ? s.v[i] : t[i];
+}
 BPMI_HD void sc_neg(sc &r, const sc &a) {   // q - a (a != 0)
   const u32 q[8] = BPMI_SC_Q;
   if (sc_is_zero(a)) { r = a; return; }

@@ -67,3 +67,55 @@ __global__ void __launch_bounds__(256) k_sc_fold(const u32 *lo, const u32 *hi, S
   sc_add(t, t, s);
   store_words8(out + 8ull * i, t.v);
 }
+
+// The verifier's s-vector with the proof's final scalars folded in (Verifier2.get_ss,
+// /root/reference/src/innerproduct/inner_product_verifier.py:91-102, and the `a * s_i`, `b / s_i` lists of :131-133):
+//   s_i = prod_j x_j^(+1 if bit (k-1-j) of i is set else -1),  sa[i] = a s_i,  sb[i] = b s_i^-1 (c_i)
+// with c_i an optional per-generator scale (hsp_i = y^-i hs_i folded into the scalars).  The index splits as
+// i = hi 2^kl + lo: a first launch fills the two half tables (<= 2^ceil(k/2) entries, <= k/2 + 1 multiplications each),
+// the second multiplies them -- 2 (3 with c_i) multiplications per element instead of 2k, and no host loop over n.
+// xt: k pairs (x_j, x_j^-1), 16 words each.  tab: [0, 2^kl): (s_lo, s_lo^-1) interleaved; then [.., + 2^kh): (a s_hi, b s_hi^-1).
+__global__ void __launch_bounds__(256) k_sc_svector_tables(const u32 *__restrict__ xt, u32 k, u32 kl, Sc2 ab, u32 *__restrict__ tab) {
+  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  const u32 nlo = 1u << kl, nhi = 1u << (k - kl);
+  if (t >= nlo + nhi) return;
+  const bool is_hi = t >= nlo;
+  const u32 idx = is_hi ? t - nlo : t;
+  sc f, g;                        // f -> s, g -> s^-1
+#pragma unroll
+  for (int q = 0; q < 8; q++) { f.v[q] = is_hi ? ab.k1[q] : (q == 0 ? 1u : 0u); g.v[q] = is_hi ? ab.k2[q] : (q == 0 ? 1u : 0u); }
+  // the low half covers index bits [0, kl) = challenges j in [k - kl, k); the high half bits [kl, k) = j in [0, k - kl)
+  const u32 j0 = is_hi ? 0u : k - kl, j1 = is_hi ? k - kl : k;
+  const u32 width = j1 - j0;
+  for (u32 j = j0; j < j1; j++) {
+    const u32 bit = (idx >> (width - 1u - (j - j0))) & 1u;        // MSB first inside the half
+    sc x, xi;
+    load_words8(x.v, xt + 16ull * j);
+    load_words8(xi.v, xt + 16ull * j + 8);
+    sc_mul(f, f, bit ? x : xi);
+    sc_mul(g, g, bit ? xi : x);
+  }
+  store_words8(tab + 16ull * t, f.v);
+  store_words8(tab + 16ull * t + 8, g.v);
+}
+__global__ void __launch_bounds__(256) k_sc_svector(const u32 *__restrict__ tab, u32 k, u32 kl, const u32 *__restrict__ scale, u32 n,
+                                                    u32 *__restrict__ sa, u32 *__restrict__ sb) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const u32 nlo = 1u << kl;
+  const u32 lo = i & (nlo - 1u), hi = i >> kl;
+  sc fl, gl, fh, gh, r;
+  load_words8(fl.v, tab + 16ull * lo);
+  load_words8(gl.v, tab + 16ull * lo + 8);
+  load_words8(fh.v, tab + 16ull * (nlo + hi));
+  load_words8(gh.v, tab + 16ull * (nlo + hi) + 8);
+  sc_mul(r, fl, fh);
+  store_words8(sa + 8ull * i, r.v);
+  sc_mul(r, gl, gh);
+  if (scale) {
+    sc c;
+    load_words8(c.v, scale + 8ull * i);
+    sc_mul(r, r, c);
+  }
+  store_words8(sb + 8ull * i, r.v);
+}

@@ -55,8 +55,8 @@ class ShardedMSM:
 
     def combine(self, partial: bytes) -> bytes:
         """partial = this rank's 64-byte partial result -> the global result on every rank."""
-        if not dist.is_initialized() or dist.get_world_size(self.group) == 1:
-            return partial
+        if not dist.is_initialized():
+            return partial            # a lone process; with a process group -- even of one rank -- the collective runs
         if self.fold_dev is not None and dist.get_backend(self.group) == "nccl":
             # RCCL: gather straight into one device buffer and fold it there -- no copy of the
             # partials back to the host and up again

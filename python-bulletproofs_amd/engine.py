@@ -106,6 +106,16 @@ class Engine:
         self._ck(self.lib.bpmi_msm_dev(self.ctx, _ptr(d_pts), _ptr(d_scalars), n, out))
         return out.raw
 
+    def msm_dev_enqueue(self, slot, d_pts, d_scalars, n):
+        """Queue one MSM (device pointers, n <= 2^23) in pending slot 0 or 1 and return at once."""
+        self._ck(self.lib.bpmi_msm_dev_enqueue(self.ctx, slot, _ptr(d_pts), _ptr(d_scalars), n))
+
+    def msm_finish(self, slot):
+        """Wait for the MSM of `slot` only and return its 64-byte result."""
+        out = ctypes.create_string_buffer(64)
+        self._ck(self.lib.bpmi_msm_finish(self.ctx, slot, out))
+        return out.raw
+
     def ec_mul_batch_bytes(self, pts, scalars, n):
         out = ctypes.create_string_buffer(64 * n)
         self._ck(self.lib.bpmi_ec_mul_batch(self.ctx, pts, scalars, n, out))
@@ -141,6 +151,21 @@ class Engine:
     def sc_fold_bytes(self, lo, hi, x, y, n):
         out = ctypes.create_string_buffer(32 * n)
         self._ck(self.lib.bpmi_sc_fold(self.ctx, lo, hi, x, y, n, out))
+        return out.raw
+
+    def sc_svector_bytes(self, xs, xinvs, k, a, b, scale=None):
+        """(sa, sb) of bpmi_sc_svector as packed bytes, 2^k scalars each."""
+        n = 1 << k
+        sa, sb = ctypes.create_string_buffer(32 * n), ctypes.create_string_buffer(32 * n)
+        self._ck(self.lib.bpmi_sc_svector(self.ctx, xs, xinvs, k, sc_bytes(a), sc_bytes(b), scale, sa, sb))
+        return sa.raw, sb.raw
+
+    def ipa_verify_dev(self, d_g, d_h, n, xs, xinvs, a, b, extra_pts, extra_scalars, n_extra, d_hscale=None):
+        """The 64-byte value of Verifier2's combined check over device-resident generators (identity = accept)."""
+        out = ctypes.create_string_buffer(64)
+        k = n.bit_length() - 1
+        self._ck(self.lib.bpmi_ipa_verify_dev(self.ctx, _ptr(d_g), _ptr(d_h), None if d_hscale is None else _ptr(d_hscale), n, xs, xinvs, k,
+                                              sc_bytes(a), sc_bytes(b), extra_pts, extra_scalars, n_extra, out))
         return out.raw
 
     # ---- IPA prover state ----

@@ -1,6 +1,7 @@
 """Inner-product argument: proof containers and verifiers
 (reference: src/innerproduct/inner_product_verifier.py)."""
-from ..ec import Point, secp256k1
+from .. import engine as _engine
+from ..ec import Point, pack_points, pack_scalars, secp256k1
 from ..pippenger import PipSECP256k1
 from ..utils.utils import ModP, mod_hash, point_to_b64
 
@@ -64,10 +65,13 @@ class Verifier2(_Checker):
             sb = [s * xv % q for s in sb] + [s * xi % q for s in sb]
         return sa, sb
 
-    def verify_transcript(self):
+    def verify_transcript(self, log_n=None):
         pr = self.proof
-        log_n = len(self.g).bit_length() - 1
+        if log_n is None:
+            log_n = len(self.g).bit_length() - 1
         items = pr.transcript.split(b"&")
+        self.assertThat(len(pr.xs) >= log_n and len(pr.Ls) >= log_n and len(pr.Rs) >= log_n)
+        self.assertThat(len(items) >= pr.start_transcript + 3 * log_n)
         k = pr.start_transcript
         for i in range(log_n):
             self.assertThat(items[k + 3 * i] == point_to_b64(pr.Ls[i]))
@@ -75,9 +79,46 @@ class Verifier2(_Checker):
             rehash = str(mod_hash(b"&".join(items[: k + 3 * i + 2]) + b"&", SUPERCURVE.q)).encode()
             self.assertThat(str(pr.xs[i]).encode() == items[k + 3 * i + 2] == rehash)
 
+    # from this length on the s-vector is computed on the GPU and consumed there (bpmi_ipa_verify_dev)
+    DEVICE_SVECTOR_MIN_N = 1024
+
+    def _extra_terms(self):
+        """u, L_j, R_j, P with the scalars a b, -x_j^2, -x_j^-2, -1 (reference :134-145, both sides in one sum)."""
+        pr, q = self.proof, SUPERCURVE.q
+        xv = [x.x % q for x in pr.xs]
+        xi = [pow(v, -1, q) for v in xv]
+        pts = [self.u] + list(pr.Ls) + list(pr.Rs) + [self.P]
+        scs = [pr.a.x * pr.b.x] + [-v * v for v in xv] + [-v * v for v in xi] + [-1]
+        return xv, xi, pts, scs
+
+    def verify_dev(self, d_g, d_h, n, d_hscale=None, engine=None):
+        """verify() for generators that already live in device memory (n points each; d_hscale: n scalars
+        or None): transcript re-derivation on the host, everything of size n on the GPU."""
+        q = SUPERCURVE.q
+        pr = self.proof
+        k = n.bit_length() - 1
+        self.verify_transcript(k)
+        xv, xi, pts, scs = self._extra_terms()
+        eng = engine or _engine.default_engine()
+        total = eng.ipa_verify_dev(d_g, d_h, n, pack_scalars(xv[:k], q), pack_scalars(xi[:k], q), pr.a.x, pr.b.x,
+                                   pack_points(pts), pack_scalars(scs, q), len(pts), d_hscale)
+        self.assertThat(total == bytes(64))
+        return True
+
     def verify(self):
         self.verify_transcript()
         pr = self.proof
+        n = len(self.g)
+        if n >= self.DEVICE_SVECTOR_MIN_N and n & (n - 1) == 0:
+            eng = _engine.default_engine()
+            d_g, d_h = eng.upload(pack_points(self.g)), eng.upload(pack_points(self.h))
+            d_s = None if self.h_scale is None else eng.upload(pack_scalars(self.h_scale, SUPERCURVE.q))
+            try:
+                return self.verify_dev(d_g, d_h, n, d_s, eng)
+            finally:
+                for d in (d_g, d_h, d_s):
+                    if d is not None:
+                        d.free()
         sa, sb = self._scaled_ss(pr.xs, pr.a.x, pr.b.x)
         if self.h_scale is not None:
             q = SUPERCURVE.q

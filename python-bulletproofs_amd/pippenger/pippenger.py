@@ -2,8 +2,8 @@
 (src/pippenger/pippenger.py:8-61).
 
 For EC(secp256k1) the whole product runs on the MI355X through libbpmi (bpmi_msm);
-there is no CPU path for that group.  For any other Group (e.g. MultIntModP) a small
-generic windowed product written against Group.mult / Group.square is used -- that is
+there is no CPU path for that group.  For any other Group (e.g. MultIntModP) the reference's
+bit-matrix schedule runs on the host, written against Group.mult / Group.square -- that is
 the operator API itself, not a fallback for the EC path.
 """
 from .. import engine as _engine
@@ -62,29 +62,71 @@ class Pippenger:
                                                      pack_points(gs1), pack_scalars(es1, self.order), len(gs1))
         return Point.from_le64(o0), Point.from_le64(o1)
 
-    # -- any other group: generic 4-bit windowed product -------------------------
+    # -- any other group: the reference's own schedule on the host ------------------------------
     def _multiexp_generic(self, gs, es):
+        """Pippenger's bit-matrix multi-exponentiation as the reference parametrises it
+        (src/pippenger/pippenger.py:22-94), written against Group.mult / Group.square only, so that
+        for a counting group such as MultIntModP the NUMBER of group operations equals the
+        reference's as well as the result (tests/golden/modp_group.json pins both):
+
+          * every base g_i is expanded into its s successive squarings g_i^(2^j), j < s, and the
+            lamb-bit exponent is read as a t-column bit matrix per expanded base
+            (s = isqrt(lamb // N) + 1, t = isqrt(lamb N) + 1; :33-53);
+          * the M = N s expanded bases are cut into groups of b = floor(log2 M - log2 log2 M) and
+            every group gets the table of all its subset products -- one multiplication per subset
+            of two or more elements (:66-81);
+          * column k of the matrix costs one table lookup + multiplication per group with a
+            non-empty subset (:83-92), and the t column values are combined by Horner's rule with
+            s squarings per step (:56-59).
+        """
+        from math import floor, isqrt, log2
         G = self.G
-        es = [e % G.order for e in es]
-        if not gs:
+        order = G.order
+        es = [e % order for e in es]
+        N = len(gs)
+        if N == 0:
             return G.unit
-        c = 4
-        nwin = (self.lamb + c - 1) // c
-        acc = G.unit
-        for w in range(nwin - 1, -1, -1):
-            for _ in range(c):
+        s = isqrt(self.lamb // N) + 1
+        t = isqrt(self.lamb * N) + 1
+        # expanded bases and, per expanded base, its matrix row packed into one integer:
+        # bit k of row (i, j) = bit (j + s k) of e_i
+        bases, rows = [], []
+        for g, e in zip(gs, es):
+            for j in range(s):
+                if j:
+                    g = G.square(g)
+                bases.append(g)
+                row, k, bits = 0, 0, e >> j
+                while bits:
+                    row |= (bits & 1) << k
+                    bits >>= s
+                    k += 1
+                rows.append(row)
+        M = len(bases)
+        b = (floor(log2(M) - log2(log2(M))) if M > 1 else 0) or 1
+        # subset tables by the lowest-set-bit recurrence: T[mask] = T[mask without its lowest bit] * base(lowest bit)
+        tables = []
+        for lo in range(0, M, b):
+            members = bases[lo: lo + b]
+            T = [None] * (1 << len(members))
+            for mask in range(1, len(T)):
+                low = (mask & -mask).bit_length() - 1
+                rest = mask & (mask - 1)
+                T[mask] = members[low] if not rest else G.mult(T[rest], members[low])
+            tables.append((lo, len(members), T))
+        columns = []
+        for k in range(t):
+            value = G.unit
+            for lo, width, T in tables:
+                mask = 0
+                for j in range(width):
+                    mask |= ((rows[lo + j] >> k) & 1) << j
+                if mask:
+                    value = G.mult(value, T[mask])
+            columns.append(value)
+        acc = columns[-1]
+        for k in range(t - 2, -1, -1):
+            for _ in range(s):
                 acc = G.square(acc)
-            buckets = [None] * (1 << c)
-            for g, e in zip(gs, es):
-                d = (e >> (c * w)) & ((1 << c) - 1)
-                if d:
-                    buckets[d] = g if buckets[d] is None else G.mult(buckets[d], g)
-            run = total = None
-            for d in range((1 << c) - 1, 0, -1):
-                if buckets[d] is not None:
-                    run = buckets[d] if run is None else G.mult(run, buckets[d])
-                if run is not None:
-                    total = run if total is None else G.mult(total, run)
-            if total is not None:
-                acc = G.mult(acc, total)
+            acc = G.mult(acc, columns[k])
         return acc

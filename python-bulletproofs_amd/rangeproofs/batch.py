@@ -102,6 +102,7 @@ class BatchRangeVerifier:
         for v in vals:
             pre.append(acc)
             acc = acc * v % q
+        rv.assertThat(acc != 0)                               # a zero challenge has no inverse: a bad proof, as on the native path
         inv = pow(acc, -1, q)
         invs = [0] * len(vals)
         for k in range(len(vals) - 1, -1, -1):
@@ -266,7 +267,8 @@ class BatchRangeVerifier:
         bad = ctypes.c_int64(-1)
         if threads is None:
             threads = min(32, len(os.sched_getaffinity(0)))
-        rc = _native.load().bpmi_rp_batch_prepare(self.n, m, count, b"".join(blobs), ctypes.cast(offs, ctypes.c_void_p), weights, threads,
+        joined = b"".join(blobs)
+        rc = _native.load().bpmi_rp_batch_prepare(self.n, m, count, joined, len(joined), ctypes.cast(offs, ctypes.c_void_p), weights, threads,
                                                   v_sc, p_sc, shared, comp, ctypes.cast(ctypes.pointer(bad), ctypes.c_void_p))
         if rc != 0:
             raise Exception("bpmi_rp_batch_prepare failed (%d)" % rc)

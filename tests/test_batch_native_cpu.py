@@ -151,3 +151,33 @@ def test_native_prepare_aggregated_equals_python_add(m, bits):
         wp = w[m:]
         assert got_p[:4] == wp[:4] and got_p[4] == wp[5] and got_p[5] == wp[4] and got_p[6:] == wp[6:]
     assert py.verify() is True and nat.verify() is True
+
+
+def test_native_prepare_checks_the_offset_table():
+    """bpmi_rp_batch_prepare never reads outside blobs[0, blobs_len): an offset table that is not monotonic or runs
+    past the buffer is BPMI_E_ARG (-3), not a host out-of-bounds read."""
+    import ctypes
+    from bulletproofs_amd import _native
+    lib = _native.load()
+    b = make_batch(2, n=8)
+    blobs = [proof_to_bytes(pr) for pr in b["proofs"]]
+    joined = b"".join(blobs)
+    k = 3
+    npts = 2 * (6 + 2 * k)
+    w = bytes([1] + [0] * 31) * 8
+
+    def call(offsets, blobs_len):
+        offs = (ctypes.c_uint64 * 3)(*offsets)
+        v_sc, p_sc = ctypes.create_string_buffer(64), ctypes.create_string_buffer(32 * npts)
+        shared, comp = ctypes.create_string_buffer(32 * (5 + 16)), ctypes.create_string_buffer(33 * npts)
+        bad = ctypes.c_int64(-1)
+        return lib.bpmi_rp_batch_prepare(8, 1, 2, joined, blobs_len, ctypes.cast(offs, ctypes.c_void_p), w, 1, v_sc, p_sc, shared, comp,
+                                         ctypes.cast(ctypes.pointer(bad), ctypes.c_void_p)), bad.value
+
+    good = [0, len(blobs[0]), len(joined)]
+    assert call(good, len(joined)) == (0, -1)
+    assert call(good, len(joined) - 1)[0] == -3                       # last blob would end past the buffer
+    assert call([0, len(joined) + 5, len(joined)], len(joined))[0] == -3
+    assert call([len(blobs[0]), 0, len(joined)], len(joined))[0] == -3    # not monotonic
+    rc, first_bad = call([0, len(blobs[0]) - 7, len(joined)], len(joined))   # in bounds but cut in the wrong place: a bad proof, not a crash
+    assert rc == 0 and first_bad == 0

@@ -1,0 +1,266 @@
+"""BASELINE.json's configurations AT THEIR FULL SIZES through the product path (C-ABI -> HIP), each
+against the oracle:
+
+  C2 / headline  MSM n = 2^20: bytes-equal to the C oracle's bucket MSM on all host threads
+  C3  inner-product-argument prover n = 2^20: first two and last two rounds' L, R vs the C oracle,
+      the proof accepted by Verifier2 over the ORIGINAL generators, a mutation rejected
+  C4  aggregated range proof m = 128 x 64-bit: every proof field equal to oracle.bp_ref
+      (bulk EC through the C oracle), accepted, wrong commitment rejected
+  C5  batch verification of 2^14 x 64-bit proofs from wire bytes: accepted; one corrupted blob
+      rejected; two half-batch partials fold to the identity (the multi-GPU sharding)
+
+(reference: src/pippenger/pippenger.py:22-61, src/innerproduct/inner_product_prover.py:70-110,
+src/rangeproofs/rangeproof_aggreg_prover.py:36-115, rangeproof_aggreg_verifier.py:55-108,
+rangeproof_verifier.py:55-99).  The oracle's pure-Python EC cannot reach these sizes in minutes, so its
+bulk EC goes through oracle/c (pinned to the reference goldens by tests/test_oracle_c.py)."""
+import copy
+import hashlib
+import os
+import random
+
+import pytest
+
+from helpers import Q, gens
+from oracle import bp_ref as R
+from oracle import cbind
+
+pytestmark = pytest.mark.gpu
+
+G64 = cbind.pack_points([cbind.secp256k1.G])
+
+
+@pytest.fixture(scope="module")
+def gp():
+    import gpu_common
+    return gpu_common
+
+
+def rand_scalars(n, seed):
+    """n x 32 bytes little-endian, every value < 2^255 < q."""
+    b = bytearray(random.Random(seed).randbytes(32 * n))
+    b[31::32] = bytes(v & 0x7F for v in b[31::32])
+    return bytes(b)
+
+
+def gpu_points(eng, n, seed):
+    """n valid points k_i * G (k_i pseudo-random), as wire bytes."""
+    return eng.ec_mul_batch_bytes(G64 * n, rand_scalars(n, seed), n)
+
+
+def test_c2_headline_msm_2e20_equals_c_oracle(gp):
+    eng = gp.engine()
+    n = 1 << 20
+    pts = gpu_points(eng, n, 20)
+    scs = bytearray(random.Random(21).randbytes(32 * n))      # full 256-bit values: some >= q (reduced on load)
+    scs[0:32] = bytes(32)
+    scs[32:64] = (1).to_bytes(32, "little")
+    scs[64:96] = (Q - 1).to_bytes(32, "little")
+    scs = bytes(scs)
+    reduced = b"".join((int.from_bytes(scs[32 * i: 32 * i + 32], "little") % Q).to_bytes(32, "little") for i in range(n))
+    want = cbind.msm_bytes(pts, reduced, n)
+    assert eng.msm_bytes(pts, scs, n) == want
+    d_p, d_s = eng.upload(pts), eng.upload(scs)
+    assert eng.msm_dev(d_p, d_s, n) == want
+    # the asynchronous pair, two in flight, equals the synchronous call
+    eng.msm_dev_enqueue(0, d_p, d_s, n)
+    eng.msm_dev_enqueue(1, d_p, d_s, n // 2)
+    assert eng.msm_finish(0) == want
+    assert eng.msm_finish(1) == cbind.msm_bytes(pts[: 32 * n], reduced[: 16 * n], n // 2)
+    d_p.free()
+    d_s.free()
+
+
+def test_c3_ipa_prover_2e20(gp):
+    from bulletproofs_amd.ec import Point
+    from bulletproofs_amd.innerproduct import Verifier2
+    from bulletproofs_amd.innerproduct._rounds import run_rounds
+    from bulletproofs_amd.innerproduct.inner_product_verifier import Proof2
+    from bulletproofs_amd.utils import ModP, Transcript
+    eng = gp.engine()
+    n = 1 << 20
+    half = n // 2
+    g, h = gpu_points(eng, n, 30), gpu_points(eng, n, 31)
+    u = gpu_points(eng, 1, 32)
+    a, b = rand_scalars(n, 33), rand_scalars(n, 34)
+    pt = lambda buf, lo, hi: buf[64 * lo: 64 * hi]
+    sc = lambda buf, lo, hi: buf[32 * lo: 32 * hi]
+    ints = lambda buf: [int.from_bytes(buf[32 * i: 32 * i + 32], "little") for i in range(len(buf) // 32)]
+    pack = cbind.pack_scalars
+    # the statement P = <a, g> + <b, h> + <a, b> u by the C oracle (2^21 + 1 pairs)
+    c = cbind.sc_dot_bytes(a, b, n)
+    Pb = cbind.msm_bytes(g + h + u, a + b + c, 2 * n + 1)
+    d_g, d_h, d_a, d_b = eng.upload(g), eng.upload(h), eng.upload(a), eng.upload(b)
+    st = eng.ipa_create_dev(d_g, d_h, d_a, d_b, n, u)
+    tr = Transcript(b"c3")
+    xs, Ls, Rs = [], [], []
+
+    def one_round():
+        Lb, Rb = st.round_LR()
+        L, Rr = Point.from_le64(Lb), Point.from_le64(Rb)
+        Ls.append(L)
+        Rs.append(Rr)
+        tr.add_list_points([L, Rr])
+        x = tr.get_modp(Q)
+        xs.append(x)
+        tr.add_number(x)
+        st.fold(x.x, x.inv().x)
+        return Lb, Rb, x.x, x.inv().x
+
+    # ---- round 1 against the oracle (reference :96-99) --------------------------------------
+    L1, R1, x1, xi1 = one_round()
+    cl = cbind.sc_dot_bytes(sc(a, 0, half), sc(b, half, n), half)
+    cr = cbind.sc_dot_bytes(sc(a, half, n), sc(b, 0, half), half)
+    assert L1 == cbind.msm_bytes(pt(g, half, n) + pt(h, 0, half) + u, sc(a, 0, half) + sc(b, half, n) + cl, n + 1)
+    assert R1 == cbind.msm_bytes(pt(g, 0, half) + pt(h, half, n) + u, sc(a, half, n) + sc(b, 0, half) + cr, n + 1)
+    # ---- round 2: folded a, b by the C oracle (:109-110); g' = xi g_lo + x g_hi and h' = x h_lo + xi h_hi (:107-108)
+    # enter linearly, so <a'_lo, g'_hi> is an MSM over the ORIGINAL generators with Python-integer coefficients
+    a2 = cbind.sc_fold_bytes(sc(a, 0, half), sc(a, half, n), x1, xi1, half)
+    b2 = cbind.sc_fold_bytes(sc(b, 0, half), sc(b, half, n), xi1, x1, half)
+    q4 = half // 2
+    L2, R2, x2, xi2 = one_round()
+    cl2 = cbind.sc_dot_bytes(sc(a2, 0, q4), sc(b2, q4, half), q4)
+    cr2 = cbind.sc_dot_bytes(sc(a2, q4, half), sc(b2, 0, q4), q4)
+    alo, ahi, blo, bhi = ints(sc(a2, 0, q4)), ints(sc(a2, q4, half)), ints(sc(b2, 0, q4)), ints(sc(b2, q4, half))
+    # L = <a'_lo, g'_hi> + <b'_hi, h'_lo> + cl u ;  g'_hi[i] = xi g[q4+i] + x g[half+q4+i],  h'_lo[i] = x h[i] + xi h[half+i]
+    wantL = cbind.msm_bytes(
+        pt(g, q4, half) + pt(g, half + q4, n) + pt(h, 0, q4) + pt(h, half, half + q4) + u,
+        pack([v * xi1 for v in alo]) + pack([v * x1 for v in alo]) + pack([v * x1 for v in bhi]) + pack([v * xi1 for v in bhi]) + cl2,
+        4 * q4 + 1)
+    wantR = cbind.msm_bytes(
+        pt(g, 0, q4) + pt(g, half, half + q4) + pt(h, q4, half) + pt(h, half + q4, n) + u,
+        pack([v * xi1 for v in ahi]) + pack([v * x1 for v in ahi]) + pack([v * x1 for v in blo]) + pack([v * xi1 for v in blo]) + cr2,
+        4 * q4 + 1)
+    assert L2 == wantL and R2 == wantR
+    # ---- middle rounds with the real transcript; the last two rounds against the oracle on the exported state
+    while len(st) > 4:
+        one_round()
+    for m in (4, 2):
+        ge, he, ae, be = st.export()
+        assert len(st) == m
+        hm = m // 2
+        Lb, Rb, _, _ = one_round()
+        gl, hl = cbind.unpack_points(ge, m), cbind.unpack_points(he, m)
+        al, bl = ints(ae), ints(be)
+        clm, crm = cbind.sc_dot(al[:hm], bl[hm:]), cbind.sc_dot(al[hm:], bl[:hm])
+        uo = cbind.unpack_points(u, 1)
+        assert Lb == cbind.pack_points([cbind.msm(gl[hm:] + hl[:hm] + uo, al[:hm] + bl[hm:] + [clm])])
+        assert Rb == cbind.pack_points([cbind.msm(gl[:hm] + hl[hm:] + uo, al[hm:] + bl[:hm] + [crm])])
+    fa, fb = st.finish()
+    st.close()
+    assert len(xs) == 20
+    # ---- the whole proof is accepted over the ORIGINAL generators (pins every fold), mutations are not
+    proof = Proof2(ModP(fa, Q), ModP(fb, Q), xs, Ls, Rs, tr.digest, 1)
+    ver = Verifier2(None, None, Point.from_le64(u), Point.from_le64(Pb), proof)
+    assert ver.verify_dev(d_g, d_h, n, engine=eng) is True
+    bad = copy.copy(proof)
+    bad.a = proof.a + ModP(1, Q)
+    with pytest.raises(Exception, match="Proof invalid"):
+        Verifier2(None, None, Point.from_le64(u), Point.from_le64(Pb), bad).verify_dev(d_g, d_h, n, engine=eng)
+    bad = copy.copy(proof)
+    bad.Ls = list(proof.Ls)
+    bad.Ls[7] = proof.Rs[7]
+    with pytest.raises(Exception, match="Proof invalid"):
+        Verifier2(None, None, Point.from_le64(u), Point.from_le64(Pb), bad).verify_dev(d_g, d_h, n, engine=eng)
+    # ---- and the product's own prover object gives the same proof from the same device buffers
+    from bulletproofs_amd.distributed import ShardedFastNIProver2
+    from bulletproofs_amd.ec import secp256k1
+    st2 = eng.ipa_create_dev(d_g, d_h, d_a, d_b, n, u)
+    pr2 = ShardedFastNIProver2(None, None, Point.from_le64(u), None, None, None, secp256k1, transcript=None, engine=eng, state=st2)
+    pr2.transcript = Transcript(b"c3")
+    p2 = pr2.prove()
+    assert p2.transcript == proof.transcript and p2.a.x == fa and p2.b.x == fb
+    for d in (d_g, d_h, d_a, d_b):
+        d.free()
+
+
+def test_c4_aggregated_128x64_equals_oracle(gp):
+    from bulletproofs_amd.ec import secp256k1
+    from bulletproofs_amd.rangeproofs import AggregNIRangeProver, AggregRangeVerifier
+    from bulletproofs_amd.utils import ModP, commitment
+    from test_gpu_rangeproofs import check_range_proof
+    m, n = 128, 64
+    nm = n * m
+    ogs, ohs = gens(nm, b"c4gs"), gens(nm, b"c4hs")
+    og, oh, ou = (R.elliptic_hash(s) for s in (b"c4g", b"c4h", b"c4u"))
+    vals = [int.from_bytes(hashlib.sha256(b"c4v%d" % j).digest()[:8], "big") for j in range(m)]
+    gam = [int(R.mod_hash(b"c4gamma%d" % j, Q)) for j in range(m)]
+    # ---- oracle: the reference algorithm (oracle.bp_ref), bulk EC through the C restatement
+    ops = cbind.BulkEC()
+    want = R.aggreg_range_prove([R.Zq(v, Q) for v in vals], n, og, oh, ogs, ohs, [R.Zq(x, Q) for x in gam], ou, Q, b"c4seed",
+                                multiexp=cbind.msm, ecops=ops)
+    # ---- product
+    gs, hs = gp.to_gpu_list(ogs), gp.to_gpu_list(ohs)
+    g, h, u = gp.to_gpu(og), gp.to_gpu(oh), gp.to_gpu(ou)
+    vs = [ModP(v, Q) for v in vals]
+    gammas = [ModP(x, Q) for x in gam]
+    Vs = [commitment(g, h, vs[j], gammas[j]) for j in range(m)]
+    pr = AggregNIRangeProver(vs, n, g, h, gs, hs, gammas, u, secp256k1, b"c4seed").prove()
+    hexpt = lambda p: ["%x" % p.x, "%x" % p.y]
+    w2 = want.innerProof.proof2
+    wd = {"taux": "%x" % (want.taux.x % Q), "mu": "%x" % (want.mu.x % Q), "t_hat": "%x" % (want.t_hat.x % Q),
+          "T1": hexpt(want.T1), "T2": hexpt(want.T2), "A": hexpt(want.A), "S": hexpt(want.S), "transcript": want.transcript.decode(),
+          "inner": {"u_new": hexpt(want.innerProof.u_new), "P_new": hexpt(want.innerProof.P_new),
+                    "transcript": want.innerProof.transcript.decode(),
+                    "proof2": {"a": "%x" % w2.a.x, "b": "%x" % w2.b.x, "xs": ["%x" % x.x for x in w2.xs],
+                               "Ls": [hexpt(p) for p in w2.Ls], "Rs": [hexpt(p) for p in w2.Rs],
+                               "transcript": w2.transcript.decode(), "start_transcript": w2.start_transcript}}}
+    assert len(w2.xs) == 13
+    check_range_proof(gp, pr, wd)
+    assert AggregRangeVerifier(Vs, g, h, gs, hs, u, pr).verify() is True
+    bad = list(Vs)
+    bad[77] = commitment(g, h, vs[77] + 1, gammas[77])
+    with pytest.raises(Exception, match="Proof invalid"):
+        AggregRangeVerifier(bad, g, h, gs, hs, u, pr).verify()
+
+
+def test_c5_batch_verify_2e14_from_wire(gp):
+    from bulletproofs_amd.ec import secp256k1
+    from bulletproofs_amd.rangeproofs import BatchRangeVerifier, NIRangeProver, RangeVerifier
+    from bulletproofs_amd.rangeproofs.codec import proof_to_bytes
+    from bulletproofs_amd.utils import ModP, commitment, mod_hash
+    eng = gp.engine()
+    n, total, distinct = 64, 1 << 14, 48
+    gs, hs = gp.to_gpu_list(gens(n, b"c5gs")), gp.to_gpu_list(gens(n, b"c5hs"))
+    g, h, u = (gp.to_gpu(R.elliptic_hash(s)) for s in (b"c5g", b"c5h", b"c5u"))
+    Vd, wire = [], []
+    for j in range(distinct):
+        v = ModP(int.from_bytes(hashlib.sha256(b"c5v%d" % j).digest()[:8], "big"), Q)
+        gamma = mod_hash(b"c5gamma%d" % j, Q)
+        V = commitment(g, h, v, gamma)
+        pr = NIRangeProver(v, n, g, h, gs, hs, gamma, u, secp256k1, b"c5seed%d" % j).prove()
+        if j < 3:      # the individual verifier (parity-tested against the reference goldens) accepts what the batch will see
+            assert RangeVerifier(V, g, h, gs, hs, u, pr).verify() is True
+        Vd.append(V)
+        wire.append(proof_to_bytes(pr))
+    Vs = [Vd[k % distinct] for k in range(total)]
+    blobs = [wire[k % distinct] for k in range(total)]
+    threads = min(32, len(os.sched_getaffinity(0)))
+    bv = BatchRangeVerifier(g, h, gs, hs, u)
+    bv.add_wire_native(Vs, blobs, threads=threads)
+    assert bv.count == total and bv.verify() is True
+    # one corrupted blob anywhere in the batch -> rejected
+    k_bad = 9001
+    for pos in (40, len(blobs[k_bad]) // 2):        # a scalar byte (algebraic failure), a byte further in (point / transcript)
+        mutated = bytearray(blobs[k_bad])
+        mutated[pos] ^= 0x01
+        bad = list(blobs)
+        bad[k_bad] = bytes(mutated)
+        bv = BatchRangeVerifier(g, h, gs, hs, u)
+        with pytest.raises(Exception, match="Proof invalid"):
+            bv.add_wire_native(Vs, bad, threads=threads)
+            bv.verify()
+    # a commitment that does not belong to its proof -> rejected (only the MSM can notice)
+    Vs_bad = list(Vs)
+    Vs_bad[123] = Vd[(123 + 1) % distinct]
+    bv = BatchRangeVerifier(g, h, gs, hs, u)
+    bv.add_wire_native(Vs_bad, blobs, threads=threads)
+    with pytest.raises(Exception, match="Proof invalid"):
+        bv.verify()
+    # the multi-GPU sharding on one GPU: two half batches with independent weights -> partials that fold to the identity
+    parts = []
+    for lo, hi in ((0, total // 2), (total // 2, total)):
+        half = BatchRangeVerifier(g, h, gs, hs, u)
+        half.add_wire_native(Vs[lo:hi], blobs[lo:hi], threads=threads)
+        parts.append(half.partial())
+    assert parts[0] == bytes(64) and parts[1] == bytes(64)      # each shard is itself a valid batch
+    assert eng.ec_sum_bytes(parts[0] + parts[1], 2) == bytes(64)

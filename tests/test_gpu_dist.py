@@ -1,0 +1,43 @@
+"""The RCCL ("nccl") code path of bulletproofs_amd.distributed on the GPU box's single GPU: a one-rank
+process group still runs all_gather_into_tensor -> bpmi_ec_sum_dev, the device-side branch of
+ShardedMSM.combine that the CPU (gloo) tests cannot reach; and bench.py's own launcher (`--gpus 2`
+outside torch.distributed.run) with two gloo ranks time-sharing the GPU."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_rccl_world1_allgather_and_device_fold():
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(REPO, "tools", "nccl_selftest.py")]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "NCCL_SELFTEST_OK world=1" in r.stdout
+
+
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` (no torchrun, no WORLD_SIZE): the parent starts the ranks as a child process and
+    relays ONE JSON line.  gloo backend so that two ranks may share this box's single GPU."""
+    env = dict(os.environ, BENCH_DIST_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--logn", "16",
+           "--no-extra", "--soak-seconds", "0"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["n_ranks_seen"] == 2 and out["result_ok"] is True
+    assert out["value"] > 0 and out["scaling"] == "weak"
+    # strong scaling: one 2^16 MSM split over the two ranks, same known-answer check
+    r = subprocess.run(cmd + ["--scaling", "strong"], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["scaling"] == "strong" and out["result_ok"] is True and out["config"]["pairs_per_gpu"] == 1 << 15

@@ -102,3 +102,80 @@ def test_ec_sum_dev_matches_host_pointer_version(gp):
         assert eng.ec_sum_dev(d, 0) == bytes(64)
     finally:
         d.free()
+
+
+def test_unreduced_scalars_are_reduced_on_load(gp):
+    """A C caller may hand bpmi_msm / bpmi_ec_mul_batch any 256-bit scalar: s = q, q + 5, 2^256 - 1 behave as
+    s mod q (the reference's `e % order`, src/pippenger/pippenger.py:26), in every MSM path and in the ladder."""
+    eng = gp.engine()
+    pts, _ = gp.rand_points(5000, 21)
+    rnd = random.Random(22)
+    raw = [Q, Q + 5, 2 ** 256 - 1, Q - 1, 0, 2 ** 255, Q + (Q - 1) // 2] + [rnd.randrange(2 ** 256) for _ in range(5000 - 7)]
+    rawb = b"".join(v.to_bytes(32, "little") for v in raw)
+    red = [v % Q for v in raw]
+    for n in (1, 3, 7, 300, 5000):                     # small-MSM kernel, and the bucket pipeline above 4096
+        want = cbind.msm_bytes(cbind.pack_points(pts[:n]), cbind.pack_scalars(red[:n]), n)
+        assert eng.msm_bytes(cbind.pack_points(pts[:n]), rawb[: 32 * n], n) == want, n
+    eng.set_option("small_n", -1)                       # force the bucket pipeline at small n too
+    try:
+        assert eng.msm_bytes(cbind.pack_points(pts[:300]), rawb[: 32 * 300], 300) == \
+            cbind.msm_bytes(cbind.pack_points(pts[:300]), cbind.pack_scalars(red[:300]), 300)
+    finally:
+        eng.set_option("small_n", 0)
+    got = eng.ec_mul_batch_bytes(cbind.pack_points(pts[:64]), rawb[: 32 * 64], 64)
+    assert got == cbind.pack_points(cbind.ec_mul_batch(pts[:64], red[:64]))
+
+
+@pytest.mark.parametrize("k", [0, 1, 2, 3, 5, 8, 11, 14])
+def test_sc_svector_vs_reference_get_ss(gp, k):
+    """bpmi_sc_svector against the oracle's restatement of Verifier2.get_ss
+    (/root/reference/src/innerproduct/inner_product_verifier.py:91-102), with the final a, b and an optional
+    per-generator scale folded in."""
+    from oracle import bp_ref as R
+    eng = gp.engine()
+    rnd = random.Random(100 + k)
+    n = 1 << k
+    xs = [rnd.randrange(1, Q) for _ in range(k)]
+    xi = [pow(x, -1, Q) for x in xs]
+    a, b = rnd.randrange(Q), rnd.randrange(Q)
+    ss = [int(s.x) for s in R.get_ss([R.Zq(x, Q) for x in xs], n)]
+    assert len(ss) == n
+    sa, sb = eng.sc_svector_bytes(cbind.pack_scalars(xs), cbind.pack_scalars(xi), k, a, b)
+    assert sa == cbind.pack_scalars([a * s for s in ss])
+    assert sb == cbind.pack_scalars([b * pow(s, -1, Q) for s in ss])
+    scale = [rnd.randrange(Q) for _ in range(n)]
+    sa2, sb2 = eng.sc_svector_bytes(cbind.pack_scalars(xs), cbind.pack_scalars(xi), k, a, b, cbind.pack_scalars(scale))
+    assert sa2 == sa and sb2 == cbind.pack_scalars([b * pow(s, -1, Q) * c for s, c in zip(ss, scale)])
+
+
+def test_verifier2_device_path_equals_host_path(gp):
+    """Verifier2.verify switches to bpmi_ipa_verify_dev from n = 1024: same verdicts as the host s-vector path
+    (forced by raising the threshold) on a valid proof, with h_scale, and on mutations."""
+    import copy
+    from bulletproofs_amd.ec import secp256k1
+    from bulletproofs_amd.innerproduct import FastNIProver2, Verifier2
+    from bulletproofs_amd.utils import ModP, inner_product, vector_commitment
+    n = 2048
+    pts, _ = gp.rand_points(2 * n + 1, 77)
+    g, h, u = gp.to_gpu_list(pts[:n]), gp.to_gpu_list(pts[n:2 * n]), gp.to_gpu(pts[2 * n])
+    rnd = random.Random(78)
+    a = [ModP(rnd.randrange(Q), Q) for _ in range(n)]
+    b = [ModP(rnd.randrange(Q), Q) for _ in range(n)]
+    scale = [rnd.randrange(1, Q) for _ in range(n)]
+    for hs in (None, scale):
+        hh = h if hs is None else gp.to_gpu_list(cbind.ec_mul_batch(pts[n:2 * n], scale))
+        Pt = vector_commitment(g, hh, a, b) + inner_product(a, b) * u
+        proof = FastNIProver2(g, h, u, Pt, a, b, secp256k1, h_scale=hs).prove()
+        bad = copy.copy(proof)
+        bad.b = proof.b + ModP(1, Q)
+        for threshold in (1024, 1 << 30):
+            old = Verifier2.DEVICE_SVECTOR_MIN_N
+            Verifier2.DEVICE_SVECTOR_MIN_N = threshold
+            try:
+                assert Verifier2(g, h, u, Pt, proof, h_scale=hs).verify() is True
+                with pytest.raises(Exception, match="Proof invalid"):
+                    Verifier2(g, h, u, Pt, bad, h_scale=hs).verify()
+                with pytest.raises(Exception, match="Proof invalid"):
+                    Verifier2(g, h, u, Pt + u, proof, h_scale=hs).verify()
+            finally:
+                Verifier2.DEVICE_SVECTOR_MIN_N = old

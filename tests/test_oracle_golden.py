@@ -197,3 +197,17 @@ def test_aggregated_rangeproof_golden(k):
         bad[1] = R.commitment(g, h, vs[1] + 1, gammas[1])
         with pytest.raises(Exception, match="Proof invalid"):
             R.aggreg_range_verify(bad, g, h, gs, hs, u, pr, mexp)
+
+
+@pytest.mark.parametrize("k", range(3))
+def test_aggregated_rangeproof_golden_with_bulk_ec(k):
+    """The `ecops` variant of the restatement (element-wise EC expressions evaluated in bulk by oracle/c; used by the
+    configuration-size GPU tests) gives the reference's bytes as well."""
+    from oracle import cbind
+    c = load_golden("rangeproofs.json")["aggregated"][k]
+    m = c["m"]
+    s, n, gs, hs, g, h, u = range_inputs(c, m)
+    vs = [R.Zq(int(v, 16), Q) for v in c["vs"]]
+    gammas = [R.mod_hash(str(j).encode() + s[5], Q) for j in range(m)]
+    pr = R.aggreg_range_prove(vs, n, g, h, gs, hs, gammas, u, seed=s[6], multiexp=cbind.msm, ecops=cbind.BulkEC(2))
+    check_range_proof(pr, c["proof"])
