@@ -211,6 +211,15 @@ void bpmi_ipa_destroy(bpmi_ipa *st);
 int bpmi_rp_batch_prepare(uint32_t n_gens, uint32_t values_per_proof, uint64_t n_proofs, const uint8_t *blobs, uint64_t blobs_len, const uint64_t *blob_off,
                           const uint8_t *weights, int threads, uint8_t *v_scalars, uint8_t *pt_scalars, uint8_t *shared, uint8_t *comp_out, int64_t *first_bad);
 
+/* ---- self-test hook (not part of the drop-in surface) ---------------------------------------------------
+ * Runs one member of the device's field-multiplication family on n operand tuples given as RAW 9 x 29-bit
+ * limb vectors (9 uint32 each, any lazy magnitude the routine allows) and returns the raw result limbs:
+ * op 0 a*b, 1 a^2, 2 a*b + c, 3 a^2 + c, 4 a*b + c*d, 5 carry(a), 6 canonical(a).  tests/test_gpu_field.py
+ * compares them with the host build of the same header, limb for limb -- the arithmetic under every
+ * `Point + Point` of the reference (src/pippenger/group.py:31-32) is pinned at its worst-case bounds. */
+int bpmi_debug_fe_op(bpmi_ctx *ctx, int op, const uint32_t *a, const uint32_t *b, const uint32_t *c, const uint32_t *d, uint64_t n,
+                     uint32_t *out);
+
 /* ---- per-stage device timing (HIP events on the ctx's stream) --------------------------
  * After bpmi_profile(ctx, 1) every MSM records HIP events around each kernel
  * stage (enable = 2: around the dominant stage, msm_accumulate, only -- every recorded event costs

@@ -49,6 +49,7 @@ SIGNATURES = {
     "bpmi_ipa_export": (_i, [_vp, _cp, _cp, _cp, _cp]),
     "bpmi_rp_batch_prepare": (_i, [ctypes.c_uint32, ctypes.c_uint32, _u64, _cp, _u64, ctypes.c_void_p, _cp, _i, _cp, _cp, _cp, _cp, ctypes.c_void_p]),
     "bpmi_ipa_destroy": (None, [_vp]),
+    "bpmi_debug_fe_op": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _u64, _vp]),
     "bpmi_profile": (_i, [_vp, _i]),
     "bpmi_profile_reset": (_i, [_vp]),
     "bpmi_profile_read": (_i, [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_u64)]),

@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbpmi.so")
 SOURCES = ["bpmi.hip"]
-HEADERS = ["field.hpp", "curve.hpp", "scalar.hpp", "context.hpp", "device_util.hpp", "msm_kernels.hpp",
+HEADERS = ["field.hpp", "field_gen.hpp", "curve.hpp", "scalar.hpp", "context.hpp", "device_util.hpp", "msm_kernels.hpp",
            "point_kernels.hpp", "scalar_kernels.hpp", "msm_host.hpp", "host_tail.hpp", "rp_batch_host.hpp", os.path.join("..", "..", "include", "bpmi.h")]
 
 

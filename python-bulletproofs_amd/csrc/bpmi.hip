@@ -896,6 +896,26 @@ int bpmi_rp_batch_prepare(uint32_t n_gens, uint32_t values_per_proof, uint64_t n
   return BPMI_OK;
 }
 
+// ---- self-test hook ----------------------------------------------------------------------------------------------
+int bpmi_debug_fe_op(bpmi_ctx *ctx, int op, const uint32_t *a, const uint32_t *b, const uint32_t *c, const uint32_t *d, uint64_t n, uint32_t *out) {
+  if (!ctx || !a || !b || !c || !d || !out) return ctx ? fail(ctx, BPMI_E_ARG, "null argument") : BPMI_E_ARG;
+  if (n == 0) return BPMI_OK;
+  if (n > (1u << 22)) return fail(ctx, BPMI_E_ARG, "n too large");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const size_t bytes = 36 * n, stride = align_up(bytes, 256);
+  int rc = ensure_stage_in(ctx, 5 * stride + 512);
+  if (rc) return rc;
+  char *base = (char *)ctx->stage_in;
+  const uint32_t *src[4] = {a, b, c, d};
+  for (int k = 0; k < 4; k++) HIPCHK(ctx, hipMemcpyAsync(base + k * stride, src[k], bytes, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_debug_fe_op, dim3((u32)((n + 255) / 256)), dim3(256), 0, ctx->stream, op, (const u32 *)base, (const u32 *)(base + stride),
+                     (const u32 *)(base + 2 * stride), (const u32 *)(base + 3 * stride), (u32)n, (u32 *)(base + 4 * stride));
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipMemcpyAsync(out, base + 4 * stride, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return BPMI_OK;
+}
+
 // ---- profiling -----------------------------------------------------------------------------------
 static void prof_drain(bpmi_ctx *ctx) {
   (void)hipStreamSynchronize(ctx->stream);

@@ -20,7 +20,13 @@ struct xyzz { fe X, Y, ZZ, ZZZ; };       // tight limbs; identity = ZZ == 0
 BPMI_HD void xyzz_set_inf(xyzz &r) {
   fe_set_zero(r.X); fe_set_zero(r.Y); fe_set_zero(r.ZZ); fe_set_zero(r.ZZZ);
 }
+// a necessary condition for a loose / tight value to be 0 (mod p): its limb 4 is 0 or 2^29 - 1 (the limbs of 0 and p).
+// One compare pair instead of the 27-operation exact test; the exact test runs only behind it (probability 2^-28).
+BPMI_HD bool fe_maybe_zero(const fe &a) { return (a.v[4] == 0u) | (a.v[4] == M29); }
 BPMI_HD bool xyzz_is_inf(const xyzz &a) { return fe_is_zero_tight(a.ZZ); }
+// the same for the accumulation loops, where the answer is almost always "no": ZZ is a multiplication result
+// (never 0 mod p for a finite point) or the exact zeros of xyzz_set_inf
+BPMI_HD bool xyzz_is_inf_fast(const xyzz &a) { return fe_maybe_zero(a.ZZ) && fe_is_zero_tight(a.ZZ); }
 BPMI_HD bool affine_is_inf(const affine &a) {
   u32 z = 0;
 #pragma unroll
@@ -90,30 +96,31 @@ BPMI_HD void xyzz_dbl(xyzz &r, const xyzz &a) {
   r.X = X3;
 }
 
-// acc += (x2, y2), affine addend that is NOT the identity (madd-2008-s): 8M + 2S.
-// y2 may be LAZY (magnitude <= 2, e.g. 2p - y): it only feeds a multiplication on the main
-// path; the two rare branches that store or double it carry it first.
+// acc += (x2, y2), affine addend that is NOT the identity (madd-2008-s): 8M + 2S in NINE reductions.
+// y2 may be LAZY (magnitude <= 2, e.g. 2p - y): it only feeds a multiplication on the main path; the two rare
+// branches that store or double it carry it first.  The subtractions ride in the reductions:
+//   P  = x2 ZZ  + (2p - X)                 fe_mul_add        R  = y2 ZZZ + (2p - Y)         fe_mul_add
+//   X3 = R^2 + (8p - PPP - 2Q)             fe_sqr_add        Y3 = R (Q - X3 + 2p) + (2p - Y) PPP   fe_mul2
 BPMI_HD void xyzz_madd(xyzz &acc, const fe &x2, const fe &y2) {
-  if (xyzz_is_inf(acc)) { acc.X = x2; fe_carry(acc.Y, y2); fe_set_one(acc.ZZ); fe_set_one(acc.ZZZ); return; }
-  fe U2, S2, P, R, PP, PPP, Q, t, t2;
-  fe_mul(U2, x2, acc.ZZ);
-  fe_mul(S2, y2, acc.ZZZ);
-  fe_sub(P, U2, acc.X); fe_carry(P, P);
-  fe_sub(R, S2, acc.Y); fe_carry(R, R);
-  if (fe_is_zero_tight(P)) {
-    if (fe_is_zero_tight(R)) { fe_carry(t, y2); xyzz_dbl_affine(acc, x2, t); return; }   // acc == addend
-    xyzz_set_inf(acc); return;                                                             // acc == -addend
+  if (xyzz_is_inf_fast(acc)) { acc.X = x2; fe_carry(acc.Y, y2); fe_set_one(acc.ZZ); fe_set_one(acc.ZZZ); return; }
+  fe nX, nY, P, R, PP, PPP, Q, t;
+  fe_neg(nX, acc.X);                                      // 2p - X: a column addend
+  fe_neg(nY, acc.Y);                                      // 2p - Y: addend now, magnitude-2 factor of Y3 later
+  fe_mul_add(P, x2, acc.ZZ, nX);                          // U2 - X1
+  fe_mul_add(R, y2, acc.ZZZ, nY);                         // S2 - Y1
+  if (fe_maybe_zero(P)) {
+    if (fe_is_zero_tight(P)) {
+      if (fe_is_zero_tight(R)) { fe_carry(t, y2); xyzz_dbl_affine(acc, x2, t); return; }   // acc == addend
+      xyzz_set_inf(acc); return;                                                             // acc == -addend
+    }
   }
   fe_sqr(PP, P);
   fe_mul(PPP, P, PP);
   fe_mul(Q, acc.X, PP);
-  fe_sqr(t, R);
-  fe_sub(t, t, PPP); fe_sub(t, t, Q); fe_sub(t, t, Q);   // mag 7
-  fe_carry(acc.X, t);
-  fe_sub(t, Q, acc.X);                                    // mag 3
-  fe_mul(t, R, t);
-  fe_mul(t2, acc.Y, PPP);
-  fe_sub(t, t, t2); fe_carry(acc.Y, t);
+  fe_bias8_sub_a_2b(t, PPP, Q);                           // 8p - PPP - 2Q
+  fe_sqr_add(acc.X, R, t);                                // X3
+  fe_sub(t, Q, acc.X);                                    // Q - X3 + 2p, magnitude 3
+  fe_mul2(acc.Y, R, t, nY, PPP);                          // Y3 = R (Q - X3) - Y1 PPP      (3 + 2 <= 7)
   fe_mul(acc.ZZ, acc.ZZ, PP);
   fe_mul(acc.ZZZ, acc.ZZZ, PPP);
 }
@@ -209,7 +216,7 @@ BPMI_HD void jac_dbl(jac &r, const jac &a) {
   fe_carry(r.X, t);
   fe_sub(t, D, r.X);                     // mag 3
   fe_mul(t, E, t);
-  fe_mul_small(C, C, 8); fe_carry(C, C); // 8C
+  fe_carry(C, C); fe_mul_small(C, C, 8); fe_carry(C, C); // 8C (C is a loose square: 8 x its limb 0 would pass 2^32)
   fe_sub(t, t, C); fe_carry(r.Y, t);
 }
 // acc += (x2, y2), affine addend that is NOT the identity: 8M + 3S, complete

@@ -9,9 +9,11 @@
 // (< 2^58 each) accumulate in one u64 column with no carry handling at all.
 //
 // Magnitudes.  A value has magnitude m when every limb is < m * 2^29.
-//   tight  = magnitude 1, limb 8 <= 2^24 + 2^20        (output of mul/sqr/carry)
+//   tight  = magnitude 1, limb 8 <= 2^24 + 2^20        (output of fe_carry)
+//   loose  = limb 0 < 2^29 + 2^22, limb 1 < 2^29 + 2^15, limbs 2..7 < 2^29, limb 8 < 2^24 (output of the
+//            multiplication family; counts as magnitude 1 -- every bound below has the 1 % of room it needs)
 //   fe_add / fe_sub are LAZY (no carry): magnitudes add; fe_sub adds 2 (a bias of 2p)
-//   fe_mul / fe_sqr need  mag(a) * mag(b) <= 7   (9 * 7 * 2^58 < 2^64)
+//   the multiplication family needs  9 * (sum of mag(a) mag(b) over its products) <= 63
 // Values are kept only weakly reduced (any representative < 2^257); fe_canon gives
 // the unique representative in [0, p) for comparison and output.
 //
@@ -42,6 +44,9 @@ constexpr u32 M24 = 0x00FFFFFFu;
 #define BPMI_FE_BIAS2 {0x3FFFF85Eu, 0x3FFFFFEEu, 0x3FFFFFFEu, 0x3FFFFFFEu, 0x3FFFFFFEu, 0x3FFFFFFEu, 0x3FFFFFFEu, 0x3FFFFFFEu, 0x01FFFFFEu}
 // 4p written so that a magnitude-2 value can be subtracted
 #define BPMI_FE_BIAS4 {0x5FFFF0BCu, 0x5FFFFFDDu, 0x5FFFFFFDu, 0x5FFFFFFDu, 0x5FFFFFFDu, 0x5FFFFFFDu, 0x5FFFFFFDu, 0x5FFFFFFDu, 0x03FFFFFDu}
+// 8p written with every limb about 6 * 2^29 (< 2^32): three loose values can be subtracted from it and the
+// difference is still a valid 32-bit column addend
+#define BPMI_FE_BIAS8 {0xBFFFE178u, 0xBFFFFFBAu, 0xBFFFFFFAu, 0xBFFFFFFAu, 0xBFFFFFFAu, 0xBFFFFFFAu, 0xBFFFFFFAu, 0xBFFFFFFAu, 0x07FFFFFAu}
 
 BPMI_HD void fe_set_zero(fe &r) {
 #pragma unroll
@@ -76,7 +81,7 @@ BPMI_HD void fe_add(fe &r, const fe &a, const fe &b) {
 #pragma unroll
   for (int k = 0; k < 9; k++) r.v[k] = a.v[k] + b.v[k];
 }
-// r = a - b + 2p ; b must be tight; mag(r) = mag(a) + 2
+// r = a - b + 2p ; b tight or loose; mag(r) = mag(a) + 2
 BPMI_HD void fe_sub(fe &r, const fe &a, const fe &b) {
   const u32 bias[9] = BPMI_FE_BIAS2;
 #pragma unroll
@@ -88,7 +93,13 @@ BPMI_HD void fe_sub_m2(fe &r, const fe &a, const fe &b) {
 #pragma unroll
   for (int k = 0; k < 9; k++) r.v[k] = a.v[k] + bias[k] - b.v[k];
 }
-// r = 2p - a ; a tight; mag 2
+// r = 8p - a - 2b, as a column addend (limbs in [2^31, 2^32)); a, b loose
+BPMI_HD void fe_bias8_sub_a_2b(fe &r, const fe &a, const fe &b) {
+  const u32 bias[9] = BPMI_FE_BIAS8;
+#pragma unroll
+  for (int k = 0; k < 9; k++) r.v[k] = bias[k] - a.v[k] - (b.v[k] << 1);
+}
+// r = 2p - a ; a tight or loose; mag 2
 BPMI_HD void fe_neg(fe &r, const fe &a) {
   const u32 bias[9] = BPMI_FE_BIAS2;
 #pragma unroll
@@ -107,295 +118,125 @@ BPMI_HD void fe_carry(fe &r, const fe &a) {
   r.v[8] = (a.v[8] & M24) + (u32)c;
 }
 
-// acc += x * y (u32 x u32 -> u64, plus the 64-bit accumulator) = ONE v_mad_u64_u32.
-// The C bodies below (fe_mul_c / fe_sqr_c) are what the HOST compiles (unit tests, host tail).  On the
-// device the generated bodies further down run instead: one inline-asm statement per product column
-// chains the multiply-adds through the running accumulator, because the compiler otherwise adds the
-// carry of column k with a separate 64-bit addition.  (A first attempt with one asm statement per
-// multiply-add was slower -- hipcc pads every asm statement with an s_nop; per column it pays.)
-#define BPMI_MAC(acc, x, y) ((acc) += (u64)(x) * (y))
-
-// 2^8 and 2^16 as multiplier operands the optimiser cannot see through: with literal powers of two
-// it rewrites the multiply-add as zero-extend + 64-bit shift + 64-bit add (3 instructions); read
-// from a (never modified) device variable they stay ONE v_mad_u64_u32 with an SGPR operand.
-#if defined(__HIP_DEVICE_COMPILE__)
-__device__ u32 bpmi_k256 = 256u, bpmi_k65536 = 65536u;
-#define BPMI_K256 bpmi_k256
-#define BPMI_K65536 bpmi_k65536
-#else
-#define BPMI_K256 256u
-#define BPMI_K65536 65536u
-#endif
-
-// ---- product -> tight result ----------------------------------------------------------
-// The 17 product columns are two carry chains.  The HIGH chain (columns 9..16) runs first and
-// leaves limbs th[0..7] (29 bits each) plus its carry-out t17; since
-//     2^261 == 2^37 + 31264 (mod p)   and   2^37 = 2^8 * 2^29,
-// a limb of weight 2^(29 (9 + j)) adds 31264 x itself to column j and 256 x itself to column
-// j + 1.  Those two terms are simply two more multiply-adds INTO THE RUNNING 64-bit
-// ACCUMULATOR of the low chain's columns, so the fold needs no temporaries, no zero-extended
-// copies and no second carry pass: the low chain's own carry propagation normalises products
-// and fold together.  (t17 sits at column 17 = 8 + 9: 31264 x t17 goes to column 8, and its
-// 256 x t17 part, column 9, folds once more into columns 0 and 1.)  What is left afterwards is
-// the carry out of column 8 and the 5 bits of limb 8 above 2^256, both reduced with
-// 2^256 == 2^32 + 977 and a 32-bit ripple.  173 instructions per multiplication against 207
-// for separate extract / fold / carry passes.
-//   bounds: mag(a) mag(b) <= 7  =>  a column of products < 63 * 2^58; the fold terms add < 2^56;
-//   t17 < 2^33; carry out of column 8 < 2^36.
-BPMI_HD void fe_reduce_tail(fe &r, u32 t[9], u64 c8) {
-  // V = units of 2^256 above limb 8's 24 bits: 2^261 = 32 * 2^256
-  const u64 V = (u64)(t[8] >> 24) + (c8 << 5);               // < 2^42
-  u64 c = (u64)t[0] + V * 977u;
-  r.v[0] = (u32)c & M29; c >>= 29;
-  c += (u64)t[1] + (V << 3);                                 // 2^32 = 8 * 2^29
-  r.v[1] = (u32)c & M29;
-  u32 cc = (u32)(c >> 29);                                   // < 2^17: 32-bit from here on
+// ---- the multiplication family: ONE reduction for a sum of limb products -----------------------------------
+//   fe_mul(r, a, b)            r = a b
+//   fe_sqr(r, a)               r = a^2
+//   fe_mul_add(r, a, b, add)   r = a b + add         add: any 9 limbs < 2^32 (e.g. BIAS - x: a fused subtraction)
+//   fe_sqr_add(r, a, add)      r = a^2 + add
+//   fe_mul2(r, a, b, c, d)     r = a b + c d
+// All of them build the 17 product columns (a column of products and addends must stay below 2^64:
+// 9 * (mag(a) mag(b) + mag(c) mag(d)) <= 63) and reduce ONCE, so a subtraction or a second product that feeds a
+// multiplication result costs no carry pass and no second reduction (the mixed addition needs 9 reductions
+// for its 8M + 2S instead of 10 plus four carry passes).
+//
+// The reduction (fe_mac_c below is its definition; csrc/field_gen.hpp is the same thing as chained v_mad_u64_u32):
+//   columns 9..16  s = 8 hi32(previous s) + products; the limb th = lo32(s) stays a DIRTY 32-bit value, which is all
+//                  the fold needs:  2^261 == 2^37 + 31264 (mod p), 2^37 = 2^8 2^29, so th[j] adds 31264 th[j] to
+//                  column j and 256 th[j] to column j + 1 (t17, the carry out of column 16, sits at column
+//                  17 = 8 + 9: 31264 t17 to column 8; its 256 t17 part, column 9, folds once more into columns 0, 1)
+//   column 8       raw sum; the bits above 2^24 (w, < 2^40) are units of 2^256 == 2^32 + 977 and are folded into
+//                  columns 0, 1, 2 BEFORE the low chain runs
+//   columns 0..7   s = carry + products + addend + fold terms; limb = s & M29, carry = s >> 29
+//   end            limb 8 keeps 24 bits of (column 8's 24 bits + the last carry); the < 2^12 above them go to limbs
+//                  0 and 1 WITHOUT a carry ripple.
+// Output ("loose"): limb 0 < 2^29 + 2^22, limb 1 < 2^29 + 2^15, limbs 2..7 < 2^29, limb 8 < 2^24; value < 2^256 + 2^45.
+// A loose value is a fine operand everywhere a tight one is (the biases below dominate its limbs, its magnitude is
+// 1.008); its limb vector is still unique for a given integer, so 0 (mod p) is exactly "all limbs 0" or "the limbs
+// of p" -- fe_is_zero_tight works on it unchanged.
+struct fe_dcols { u64 c[17]; };
+BPMI_HD void fe_cols_add_product(fe_dcols &q, const fe &a, const fe &b) {
 #pragma unroll
-  for (int k = 2; k < 8; k++) { const u32 x = t[k] + cc; r.v[k] = x & M29; cc = x >> 29; }
-  r.v[8] = (t[8] & M24) + cc;
+  for (int i = 0; i < 9; i++)
+#pragma unroll
+    for (int j = 0; j < 9; j++) q.c[i + j] += (u64)a.v[i] * b.v[j];
 }
-
-BPMI_HD void fe_mul_c(fe &r, const fe &a, const fe &b) {
-  u32 th[8], t[9];
-  u64 c = 0;
+BPMI_HD void fe_cols_reduce(fe &r, const fe_dcols &q) {
+  u32 th[8], t[8];
+  u64 s = q.c[9];
+  th[0] = (u32)s;
+  u32 hp = (u32)(s >> 32);
 #pragma unroll
-  for (int k = 9; k < 17; k++) {
-    u64 s = c;
-#pragma unroll
-    for (int i = k - 8; i <= 8; i++) BPMI_MAC(s, a.v[i], b.v[k - i]);
-    th[k - 9] = (u32)s & M29;
-    c = s >> 29;
+  for (int k = 10; k < 17; k++) {
+    s = q.c[k] + ((u64)hp << 3);
+    th[k - 9] = (u32)s;
+    hp = (u32)(s >> 32);
   }
-  const u32 t17 = (u32)c;
-  c = 0;
+  const u32 t17 = hp << 3;
+  s = q.c[8] + (u64)t17 * 31264u + (u64)th[7] * 256u;
+  const u32 s8m = (u32)s & M24;
+  const u64 w = s >> 24;
+  const u32 wl = (u32)w & M29, wh = (u32)(w >> 29);
+  s = 0;
 #pragma unroll
-  for (int k = 0; k < 9; k++) {
-    u64 s = c;
-    if (k == 0) BPMI_MAC(s, t17, 31264u * 256u);            // 256 t17 at column 9 -> 31264 x at column 0
-    if (k == 1) BPMI_MAC(s, t17, BPMI_K65536);               //                    -> 256 x at column 1
-    if (k < 8) BPMI_MAC(s, th[k], 31264u); else BPMI_MAC(s, t17, 31264u);
-    if (k >= 1) BPMI_MAC(s, th[k - 1], BPMI_K256);
-#pragma unroll
-    for (int i = 0; i <= k; i++) BPMI_MAC(s, a.v[i], b.v[k - i]);
+  for (int k = 0; k < 8; k++) {
+    s += q.c[k] + (u64)th[k] * 31264u;
+    if (k >= 1) s += (u64)th[k - 1] * 256u;
+    if (k == 0) s += (u64)t17 * (31264u * 256u) + (u64)wl * 977u;
+    if (k == 1) s += (u64)t17 * 65536u + ((u64)wl << 3) + (u64)wh * 977u;
+    if (k == 2) s += (u64)wh << 3;
     t[k] = (u32)s & M29;
-    c = s >> 29;
+    s >>= 29;
   }
-  fe_reduce_tail(r, t, c);
+  s += s8m;
+  const u32 v2 = (u32)(s >> 24);
+  r.v[0] = t[0] + v2 * 977u;
+  r.v[1] = t[1] + (v2 << 3);
+#pragma unroll
+  for (int k = 2; k < 8; k++) r.v[k] = t[k];
+  r.v[8] = (u32)s & M24;
+}
+// r = a b (+ c d) (+ add); c, d, add may be null
+BPMI_HD void fe_mac_c(fe &r, const fe &a, const fe &b, const fe *c, const fe *d, const fe *add) {
+  fe_dcols q;
+#pragma unroll
+  for (int k = 0; k < 17; k++) q.c[k] = (add && k < 9) ? add->v[k] : 0;
+  fe_cols_add_product(q, a, b);
+  if (c) fe_cols_add_product(q, *c, *d);
+  fe_cols_reduce(r, q);
 }
 
-// a of magnitude <= 2 (doubled limbs must fit 32 bits and 9 * 2 * m^2 * 2^58 < 2^64)
-BPMI_HD void fe_sqr_c(fe &r, const fe &a) {
-  u32 d[9];
-#pragma unroll
-  for (int i = 0; i < 9; i++) d[i] = a.v[i] << 1;
-  u32 th[8], t[9];
-  u64 c = 0;
-#pragma unroll
-  for (int k = 9; k < 17; k++) {
-    u64 s = c;
-#pragma unroll
-    for (int i = k - 8; 2 * i <= k; i++) { if (2 * i == k) BPMI_MAC(s, a.v[i], a.v[i]); else BPMI_MAC(s, d[i], a.v[k - i]); }
-    th[k - 9] = (u32)s & M29;
-    c = s >> 29;
-  }
-  const u32 t17 = (u32)c;
-  c = 0;
-#pragma unroll
-  for (int k = 0; k < 9; k++) {
-    u64 s = c;
-    if (k == 0) BPMI_MAC(s, t17, 31264u * 256u);
-    if (k == 1) BPMI_MAC(s, t17, BPMI_K65536);
-    if (k < 8) BPMI_MAC(s, th[k], 31264u); else BPMI_MAC(s, t17, 31264u);
-    if (k >= 1) BPMI_MAC(s, th[k - 1], BPMI_K256);
-#pragma unroll
-    for (int i = 0; 2 * i <= k; i++) { if (2 * i == k) BPMI_MAC(s, a.v[i], a.v[i]); else BPMI_MAC(s, d[i], a.v[k - i]); }
-    t[k] = (u32)s & M29;
-    c = s >> 29;
-  }
-  fe_reduce_tail(r, t, c);
-}
+#include "field_gen.hpp"      // inside namespace bpmi: the generated device bodies (tools/gen_field_asm.py)
 
-// ---- GENERATED by tools/gen_fe_mul_asm.py: device bodies of fe_mul / fe_sqr ----
-#if defined(__HIP_DEVICE_COMPILE__)
-__device__ __forceinline__ void fe_mul_dev(fe &r, const fe &a, const fe &b) {
-  u32 th[8], t[9];
-  u64 c = 0, sink_;
-  const u32 k31264 = 31264u, k256 = 256u, k65536 = 65536u, kf = 31264u * 256u;
-  { u64 s = c;
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0"
-        : "+v"(s), "=&s"(sink_) : "v"(a.v[1]), "v"(b.v[8]), "v"(a.v[2]), "v"(b.v[7]), "v"(a.v[3]), "v"(b.v[6]), "v"(a.v[4]), "v"(b.v[5]), "v"(a.v[5]), "v"(b.v[4]), "v"(a.v[6]), "v"(b.v[3]), "v"(a.v[7]), "v"(b.v[2]), "v"(a.v[8]), "v"(b.v[1]));
-    th[0] = (u32)s & M29; c = s >> 29; }
-  { u64 s = c;
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0"
-        : "+v"(s), "=&s"(sink_) : "v"(a.v[2]), "v"(b.v[8]), "v"(a.v[3]), "v"(b.v[7]), "v"(a.v[4]), "v"(b.v[6]), "v"(a.v[5]), "v"(b.v[5]), "v"(a.v[6]), "v"(b.v[4]), "v"(a.v[7]), "v"(b.v[3]), "v"(a.v[8]), "v"(b.v[2]));
-    th[1] = (u32)s & M29; c = s >> 29; }
-  { u64 s = c;
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0"
-        : "+v"(s), "=&s"(sink_) : "v"(a.v[3]), "v"(b.v[8]), "v"(a.v[4]), "v"(b.v[7]), "v"(a.v[5]), "v"(b.v[6]), "v"(a.v[6]), "v"(b.v[5]), "v"(a.v[7]), "v"(b.v[4]), "v"(a.v[8]), "v"(b.v[3]));
-    th[2] = (u32)s & M29; c = s >> 29; }
-  { u64 s = c;
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0"
-        : "+v"(s), "=&s"(sink_) : "v"(a.v[4]), "v"(b.v[8]), "v"(a.v[5]), "v"(b.v[7]), "v"(a.v[6]), "v"(b.v[6]), "v"(a.v[7]), "v"(b.v[5]), "v"(a.v[8]), "v"(b.v[4]));
-    th[3] = (u32)s & M29; c = s >> 29; }
-  { u64 s = c;
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0"
-        : "+v"(s), "=&s"(sink_) : "v"(a.v[5]), "v"(b.v[8]), "v"(a.v[6]), "v"(b.v[7]), "v"(a.v[7]), "v"(b.v[6]), "v"(a.v[8]), "v"(b.v[5]));
-    th[4] = (u32)s & M29; c = s >> 29; }
-  { u64 s = c;
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0"
-        : "+v"(s), "=&s"(sink_) : "v"(a.v[6]), "v"(b.v[8]), "v"(a.v[7]), "v"(b.v[7]), "v"(a.v[8]), "v"(b.v[6]));
-    th[5] = (u32)s & M29; c = s >> 29; }
-  { u64 s = c;
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0"
-        : "+v"(s), "=&s"(sink_) : "v"(a.v[7]), "v"(b.v[8]), "v"(a.v[8]), "v"(b.v[7]));
-    th[6] = (u32)s & M29; c = s >> 29; }
-  { u64 s = c;
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0"
-        : "+v"(s), "=&s"(sink_) : "v"(a.v[8]), "v"(b.v[8]));
-    th[7] = (u32)s & M29; c = s >> 29; }
-  const u32 t17 = (u32)c;
-  c = 0;
-  { u64 s = c;
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0"
-        : "+v"(s), "=&s"(sink_) : "v"(t17), "s"(kf), "v"(th[0]), "s"(k31264), "v"(a.v[0]), "v"(b.v[0]));
-    t[0] = (u32)s & M29; c = s >> 29; }
-  { u64 s = c;
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0"
-        : "+v"(s), "=&s"(sink_) : "v"(t17), "s"(k65536), "v"(th[1]), "s"(k31264), "v"(th[0]), "s"(k256), "v"(a.v[0]), "v"(b.v[1]), "v"(a.v[1]), "v"(b.v[0]));
-    t[1] = (u32)s & M29; c = s >> 29; }
-  { u64 s = c;
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0"
-        : "+v"(s), "=&s"(sink_) : "v"(th[2]), "s"(k31264), "v"(th[1]), "s"(k256), "v"(a.v[0]), "v"(b.v[2]), "v"(a.v[1]), "v"(b.v[1]), "v"(a.v[2]), "v"(b.v[0]));
-    t[2] = (u32)s & M29; c = s >> 29; }
-  { u64 s = c;
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0"
-        : "+v"(s), "=&s"(sink_) : "v"(th[3]), "s"(k31264), "v"(th[2]), "s"(k256), "v"(a.v[0]), "v"(b.v[3]), "v"(a.v[1]), "v"(b.v[2]), "v"(a.v[2]), "v"(b.v[1]), "v"(a.v[3]), "v"(b.v[0]));
-    t[3] = (u32)s & M29; c = s >> 29; }
-  { u64 s = c;
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0"
-        : "+v"(s), "=&s"(sink_) : "v"(th[4]), "s"(k31264), "v"(th[3]), "s"(k256), "v"(a.v[0]), "v"(b.v[4]), "v"(a.v[1]), "v"(b.v[3]), "v"(a.v[2]), "v"(b.v[2]), "v"(a.v[3]), "v"(b.v[1]), "v"(a.v[4]), "v"(b.v[0]));
-    t[4] = (u32)s & M29; c = s >> 29; }
-  { u64 s = c;
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0"
-        : "+v"(s), "=&s"(sink_) : "v"(th[5]), "s"(k31264), "v"(th[4]), "s"(k256), "v"(a.v[0]), "v"(b.v[5]), "v"(a.v[1]), "v"(b.v[4]), "v"(a.v[2]), "v"(b.v[3]), "v"(a.v[3]), "v"(b.v[2]), "v"(a.v[4]), "v"(b.v[1]), "v"(a.v[5]), "v"(b.v[0]));
-    t[5] = (u32)s & M29; c = s >> 29; }
-  { u64 s = c;
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0"
-        : "+v"(s), "=&s"(sink_) : "v"(th[6]), "s"(k31264), "v"(th[5]), "s"(k256), "v"(a.v[0]), "v"(b.v[6]), "v"(a.v[1]), "v"(b.v[5]), "v"(a.v[2]), "v"(b.v[4]), "v"(a.v[3]), "v"(b.v[3]), "v"(a.v[4]), "v"(b.v[2]), "v"(a.v[5]), "v"(b.v[1]), "v"(a.v[6]), "v"(b.v[0]));
-    t[6] = (u32)s & M29; c = s >> 29; }
-  { u64 s = c;
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0"
-        : "+v"(s), "=&s"(sink_) : "v"(th[7]), "s"(k31264), "v"(th[6]), "s"(k256), "v"(a.v[0]), "v"(b.v[7]), "v"(a.v[1]), "v"(b.v[6]), "v"(a.v[2]), "v"(b.v[5]), "v"(a.v[3]), "v"(b.v[4]), "v"(a.v[4]), "v"(b.v[3]), "v"(a.v[5]), "v"(b.v[2]), "v"(a.v[6]), "v"(b.v[1]), "v"(a.v[7]), "v"(b.v[0]));
-    t[7] = (u32)s & M29; c = s >> 29; }
-  { u64 s = c;
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0"
-        : "+v"(s), "=&s"(sink_) : "v"(t17), "s"(k31264), "v"(th[7]), "s"(k256), "v"(a.v[0]), "v"(b.v[8]), "v"(a.v[1]), "v"(b.v[7]), "v"(a.v[2]), "v"(b.v[6]), "v"(a.v[3]), "v"(b.v[5]), "v"(a.v[4]), "v"(b.v[4]), "v"(a.v[5]), "v"(b.v[3]), "v"(a.v[6]), "v"(b.v[2]), "v"(a.v[7]), "v"(b.v[1]), "v"(a.v[8]), "v"(b.v[0]));
-    t[8] = (u32)s & M29; c = s >> 29; }
-  (void)sink_;
-  fe_reduce_tail(r, t, c);
-}
-__device__ __forceinline__ void fe_sqr_dev(fe &r, const fe &a) {
-  u32 th[8], t[9];
-  u64 c = 0, sink_;
-  const u32 k31264 = 31264u, k256 = 256u, k65536 = 65536u, kf = 31264u * 256u;
-  u32 d[9];
-#pragma unroll
-  for (int i = 0; i < 9; i++) d[i] = a.v[i] << 1;
-  { u64 s = c;
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0"
-        : "+v"(s), "=&s"(sink_) : "v"(d[1]), "v"(a.v[8]), "v"(d[2]), "v"(a.v[7]), "v"(d[3]), "v"(a.v[6]), "v"(d[4]), "v"(a.v[5]));
-    th[0] = (u32)s & M29; c = s >> 29; }
-  { u64 s = c;
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0"
-        : "+v"(s), "=&s"(sink_) : "v"(d[2]), "v"(a.v[8]), "v"(d[3]), "v"(a.v[7]), "v"(d[4]), "v"(a.v[6]), "v"(a.v[5]), "v"(a.v[5]));
-    th[1] = (u32)s & M29; c = s >> 29; }
-  { u64 s = c;
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0"
-        : "+v"(s), "=&s"(sink_) : "v"(d[3]), "v"(a.v[8]), "v"(d[4]), "v"(a.v[7]), "v"(d[5]), "v"(a.v[6]));
-    th[2] = (u32)s & M29; c = s >> 29; }
-  { u64 s = c;
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0"
-        : "+v"(s), "=&s"(sink_) : "v"(d[4]), "v"(a.v[8]), "v"(d[5]), "v"(a.v[7]), "v"(a.v[6]), "v"(a.v[6]));
-    th[3] = (u32)s & M29; c = s >> 29; }
-  { u64 s = c;
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0"
-        : "+v"(s), "=&s"(sink_) : "v"(d[5]), "v"(a.v[8]), "v"(d[6]), "v"(a.v[7]));
-    th[4] = (u32)s & M29; c = s >> 29; }
-  { u64 s = c;
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0"
-        : "+v"(s), "=&s"(sink_) : "v"(d[6]), "v"(a.v[8]), "v"(a.v[7]), "v"(a.v[7]));
-    th[5] = (u32)s & M29; c = s >> 29; }
-  { u64 s = c;
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0"
-        : "+v"(s), "=&s"(sink_) : "v"(d[7]), "v"(a.v[8]));
-    th[6] = (u32)s & M29; c = s >> 29; }
-  { u64 s = c;
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0"
-        : "+v"(s), "=&s"(sink_) : "v"(a.v[8]), "v"(a.v[8]));
-    th[7] = (u32)s & M29; c = s >> 29; }
-  const u32 t17 = (u32)c;
-  c = 0;
-  { u64 s = c;
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0"
-        : "+v"(s), "=&s"(sink_) : "v"(t17), "s"(kf), "v"(th[0]), "s"(k31264), "v"(a.v[0]), "v"(a.v[0]));
-    t[0] = (u32)s & M29; c = s >> 29; }
-  { u64 s = c;
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0"
-        : "+v"(s), "=&s"(sink_) : "v"(t17), "s"(k65536), "v"(th[1]), "s"(k31264), "v"(th[0]), "s"(k256), "v"(d[0]), "v"(a.v[1]));
-    t[1] = (u32)s & M29; c = s >> 29; }
-  { u64 s = c;
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0"
-        : "+v"(s), "=&s"(sink_) : "v"(th[2]), "s"(k31264), "v"(th[1]), "s"(k256), "v"(d[0]), "v"(a.v[2]), "v"(a.v[1]), "v"(a.v[1]));
-    t[2] = (u32)s & M29; c = s >> 29; }
-  { u64 s = c;
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0"
-        : "+v"(s), "=&s"(sink_) : "v"(th[3]), "s"(k31264), "v"(th[2]), "s"(k256), "v"(d[0]), "v"(a.v[3]), "v"(d[1]), "v"(a.v[2]));
-    t[3] = (u32)s & M29; c = s >> 29; }
-  { u64 s = c;
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0"
-        : "+v"(s), "=&s"(sink_) : "v"(th[4]), "s"(k31264), "v"(th[3]), "s"(k256), "v"(d[0]), "v"(a.v[4]), "v"(d[1]), "v"(a.v[3]), "v"(a.v[2]), "v"(a.v[2]));
-    t[4] = (u32)s & M29; c = s >> 29; }
-  { u64 s = c;
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0"
-        : "+v"(s), "=&s"(sink_) : "v"(th[5]), "s"(k31264), "v"(th[4]), "s"(k256), "v"(d[0]), "v"(a.v[5]), "v"(d[1]), "v"(a.v[4]), "v"(d[2]), "v"(a.v[3]));
-    t[5] = (u32)s & M29; c = s >> 29; }
-  { u64 s = c;
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0"
-        : "+v"(s), "=&s"(sink_) : "v"(th[6]), "s"(k31264), "v"(th[5]), "s"(k256), "v"(d[0]), "v"(a.v[6]), "v"(d[1]), "v"(a.v[5]), "v"(d[2]), "v"(a.v[4]), "v"(a.v[3]), "v"(a.v[3]));
-    t[6] = (u32)s & M29; c = s >> 29; }
-  { u64 s = c;
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0"
-        : "+v"(s), "=&s"(sink_) : "v"(th[7]), "s"(k31264), "v"(th[6]), "s"(k256), "v"(d[0]), "v"(a.v[7]), "v"(d[1]), "v"(a.v[6]), "v"(d[2]), "v"(a.v[5]), "v"(d[3]), "v"(a.v[4]));
-    t[7] = (u32)s & M29; c = s >> 29; }
-  { u64 s = c;
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0"
-        : "+v"(s), "=&s"(sink_) : "v"(t17), "s"(k31264), "v"(th[7]), "s"(k256), "v"(d[0]), "v"(a.v[8]), "v"(d[1]), "v"(a.v[7]), "v"(d[2]), "v"(a.v[6]), "v"(d[3]), "v"(a.v[5]), "v"(a.v[4]), "v"(a.v[4]));
-    t[8] = (u32)s & M29; c = s >> 29; }
-  (void)sink_;
-  fe_reduce_tail(r, t, c);
-}
-#endif
-// ---- end GENERATED ----
-
-// The device runs the generated bodies (same columns, same fold, multiply-adds chained by hand);
-// the host -- unit tests, host tail helpers -- runs the C bodies above.  tests/test_gpu_*.py and the
-// fuzzers compare the device results with the oracle, tests/test_csrc_host.py the C bodies.
+// The device runs the generated bodies, the host -- unit tests, host tail helpers -- the C body.  They are the
+// same function: tests/test_csrc_host.py checks the C body against Python integers on adversarial limb patterns,
+// tests/test_gpu_field.py checks on the GPU that both give identical limbs.
 BPMI_HD void fe_mul(fe &r, const fe &a, const fe &b) {
 #if defined(__HIP_DEVICE_COMPILE__)
   fe_mul_dev(r, a, b);
 #else
-  fe_mul_c(r, a, b);
+  fe_mac_c(r, a, b, nullptr, nullptr, nullptr);
 #endif
 }
 BPMI_HD void fe_sqr(fe &r, const fe &a) {
 #if defined(__HIP_DEVICE_COMPILE__)
   fe_sqr_dev(r, a);
 #else
-  fe_sqr_c(r, a);
+  fe_mac_c(r, a, a, nullptr, nullptr, nullptr);
+#endif
+}
+BPMI_HD void fe_mul_add(fe &r, const fe &a, const fe &b, const fe &add) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  fe_mul_add_dev(r, a, b, add);
+#else
+  fe_mac_c(r, a, b, nullptr, nullptr, &add);
+#endif
+}
+BPMI_HD void fe_sqr_add(fe &r, const fe &a, const fe &add) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  fe_sqr_add_dev(r, a, add);
+#else
+  fe_mac_c(r, a, a, nullptr, nullptr, &add);
+#endif
+}
+BPMI_HD void fe_mul2(fe &r, const fe &a, const fe &b, const fe &c, const fe &d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  fe_mul2_dev(r, a, b, c, d);
+#else
+  fe_mac_c(r, a, b, &c, &d, nullptr);
 #endif
 }
 
-// r = a * k for a small constant (k * mag(a) must stay < 8), lazy
+// r = a * k for a small constant, lazy: k * mag(a) must stay < 8, and k <= 7 when a is loose (limb 0 < 2^29 + 2^22)
 BPMI_HD void fe_mul_small(fe &r, const fe &a, u32 k) {
 #pragma unroll
   for (int i = 0; i < 9; i++) r.v[i] = a.v[i] * k;

@@ -119,3 +119,27 @@ __global__ void __launch_bounds__(256) k_sc_svector(const u32 *__restrict__ tab,
   }
   store_words8(sb + 8ull * i, r.v);
 }
+
+// Self-test hook: the DEVICE bodies of the multiplication family (csrc/field_gen.hpp) on raw limbs, so that a
+// test can feed lazy magnitudes and compare the limbs with the host build of the same header (tests/test_gpu_field.py).
+// op 0 mul(a,b), 1 sqr(a), 2 mul_add(a,b,c), 3 sqr_add(a,c), 4 mul2(a,b,c,d), 5 carry(a), 6 canon(a)
+__global__ void __launch_bounds__(256) k_debug_fe_op(int op, const u32 *__restrict__ a, const u32 *__restrict__ b, const u32 *__restrict__ c,
+                                                     const u32 *__restrict__ d, u32 n, u32 *__restrict__ out) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  fe A, B, C, D, r;
+#pragma unroll
+  for (int k = 0; k < 9; k++) { A.v[k] = a[9ull * i + k]; B.v[k] = b[9ull * i + k]; C.v[k] = c[9ull * i + k]; D.v[k] = d[9ull * i + k]; }
+  switch (op) {
+    case 0: fe_mul(r, A, B); break;
+    case 1: fe_sqr(r, A); break;
+    case 2: fe_mul_add(r, A, B, C); break;
+    case 3: fe_sqr_add(r, A, C); break;
+    case 4: fe_mul2(r, A, B, C, D); break;
+    case 5: fe_carry(r, A); break;
+    case 6: fe_canon(r, A); break;
+    default: fe_set_zero(r);
+  }
+#pragma unroll
+  for (int k = 0; k < 9; k++) out[9ull * i + k] = r.v[k];
+}

@@ -34,6 +34,23 @@ void t_fe_op(int op, const uint8_t *a, const uint8_t *b, uint8_t *out) {
   }
   store_fe(out, r);
 }
+// the multiplication family on RAW limbs (any lazy magnitude the caller wants to try), raw loose limbs out:
+// op 0 mul(a,b), 1 sqr(a), 2 mul_add(a,b,add=c), 3 sqr_add(a,add=c), 4 mul2(a,b,c,d), 5 carry(a), 6 canon(a)
+void t_fe_raw(int op, const u32 *a, const u32 *b, const u32 *c, const u32 *d, u32 *out) {
+  fe A, B, C, D, r;
+  for (int k = 0; k < 9; k++) { A.v[k] = a[k]; B.v[k] = b[k]; C.v[k] = c[k]; D.v[k] = d[k]; }
+  switch (op) {
+    case 0: fe_mul(r, A, B); break;
+    case 1: fe_sqr(r, A); break;
+    case 2: fe_mul_add(r, A, B, C); break;
+    case 3: fe_sqr_add(r, A, C); break;
+    case 4: fe_mul2(r, A, B, C, D); break;
+    case 5: fe_carry(r, A); break;
+    case 6: fe_canon(r, A); break;
+    default: fe_set_zero(r);
+  }
+  for (int k = 0; k < 9; k++) out[k] = r.v[k];
+}
 int t_fe_is_zero(const uint8_t *a, const uint8_t *b) {  // is a - b == 0 ?
   fe x, y; load_fe(x, a); load_fe(y, b);
   return fe_equal(x, y) ? 1 : 0;

@@ -144,3 +144,109 @@ def test_jacobian_ladder_and_exceptions(shim):
         out = ctypes.create_string_buffer(64)
         shim.t_jac_madd_chain(b"".join(point_to_le64(p) for p in lst), bytes(negs), len(lst), out)
         assert point_from_le64(out.raw) == want
+
+
+# ---- the multiplication family on raw limbs: adversarial magnitudes, loose output bounds --------------------
+M29 = (1 << 29) - 1
+LOOSE_MAX = [M29 + (1 << 22), M29 + (1 << 15)] + [M29] * 6 + [(1 << 24) - 1]
+TIGHT_MAX = [M29] * 8 + [(1 << 24) + (1 << 20)]
+
+
+def limbs_value(l):
+    return sum(v << (29 * k) for k, v in enumerate(l))
+
+
+def fe_raw(L, op, a, b=None, c=None, d=None):
+    z = [0] * 9
+    arr = lambda v: (ctypes.c_uint32 * 9)(*(v if v is not None else z))
+    out = (ctypes.c_uint32 * 9)()
+    L.t_fe_raw(op, arr(a), arr(b), arr(c), arr(d), out)
+    return list(out)
+
+
+def assert_loose(l):
+    assert l[0] < (1 << 29) + (1 << 22) and l[1] < (1 << 29) + (1 << 15), l
+    assert all(v < (1 << 29) for v in l[2:8]) and l[8] < (1 << 24), l
+
+
+def scaled(pattern, m, limb8=None):
+    """a magnitude-m operand: every limb at its maximum"""
+    out = [min(v * m, 0xFFFFFFFF) for v in pattern]
+    if limb8 is not None:
+        out[8] = limb8
+    return out
+
+
+def mul_family_cases(rnd, count):
+    """(op, a, b, c, d, expected value mod p) with the largest limbs each variant allows, and random lazy values."""
+    cases = []
+    bias2 = [0x3FFFF85E, 0x3FFFFFEE] + [0x3FFFFFFE] * 6 + [0x01FFFFFE]
+    bias8 = [0xBFFFE178, 0xBFFFFFBA] + [0xBFFFFFFA] * 6 + [0x07FFFFFA]
+    full = [0xFFFFFFFF] * 9
+    for ma, mb in ((1, 1), (1, 7), (7, 1), (2, 3), (3, 2), (1, 3), (2, 2)):
+        for pat in (LOOSE_MAX, TIGHT_MAX):
+            # limb 8 of a lazy sum is small; the all-limbs-maximal pattern is the worst case for every column
+            a, b = scaled(pat, ma, pat[8] * ma), scaled(pat, mb, pat[8] * mb)
+            cases.append((0, a, b, None, None))
+            cases.append((2, a, b, full, None))                        # the largest possible addend
+            cases.append((2, a, b, bias8, None))
+    for m in (1, 2):
+        for pat in (LOOSE_MAX, TIGHT_MAX):
+            a = scaled(pat, m, pat[8] * m)
+            cases.append((1, a, None, None, None))
+            cases.append((3, a, None, full, None))
+    for (ma, mb, mc, md) in ((1, 3, 2, 1), (1, 1, 1, 1), (1, 4, 1, 3), (2, 2, 1, 3), (1, 7, 0, 0)):
+        for pat in (LOOSE_MAX, TIGHT_MAX):
+            cases.append((4, scaled(pat, ma, pat[8] * ma), scaled(pat, mb, pat[8] * mb), scaled(pat, mc, pat[8] * mc), scaled(pat, md, pat[8] * md)))
+    zero, one = [0] * 9, [1] + [0] * 8
+    plimbs = [0x1FFFFC2F, 0x1FFFFFF7] + [M29] * 6 + [0x00FFFFFF]
+    for x in (zero, one, plimbs, bias2):
+        cases += [(0, x, LOOSE_MAX, None, None), (0, x, x, None, None), (1, x, None, None, None), (4, x, one, plimbs, one), (2, zero, zero, x, None)]
+    for _ in range(count):
+        op = rnd.randrange(5)
+        def lazy(m):
+            return [rnd.randrange(m * (1 << 29)) for _ in range(8)] + [rnd.randrange(m * ((1 << 24) + (1 << 20)))]
+        if op == 0:
+            ma = rnd.randrange(1, 8)
+            cases.append((0, lazy(ma), lazy(max(1, 7 // ma)), None, None))
+        elif op == 1:
+            cases.append((1, lazy(rnd.randrange(1, 3)), None, None, None))
+        elif op == 2:
+            ma = rnd.randrange(1, 7)
+            cases.append((2, lazy(ma), lazy(max(1, 6 // ma)), [rnd.randrange(1 << 32) for _ in range(9)], None))
+        elif op == 3:
+            cases.append((3, lazy(rnd.randrange(1, 3)), None, [rnd.randrange(1 << 32) for _ in range(9)], None))
+        else:
+            cases.append((4, lazy(1), lazy(rnd.randrange(1, 4)), lazy(rnd.randrange(1, 3)), lazy(1)))
+    return cases
+
+
+def mul_family_expected(op, a, b, c, d):
+    va, vb, vc, vd = (limbs_value(x) if x is not None else 0 for x in (a, b, c, d))
+    return {0: va * vb, 1: va * va, 2: va * vb + vc, 3: va * va + vc, 4: va * vb + vc * vd}[op] % P
+
+
+def test_multiplication_family_raw_limbs(shim):
+    shim.t_fe_raw.argtypes = [ctypes.c_int] + [ctypes.POINTER(ctypes.c_uint32)] * 5
+    rnd = random.Random(77)
+    for op, a, b, c, d in mul_family_cases(rnd, 4000):
+        out = fe_raw(shim, op, a, b, c, d)
+        assert_loose(out)
+        assert limbs_value(out) % P == mul_family_expected(op, a, b, c, d), (op, a, b, c, d)
+        assert limbs_value(out) < (1 << 256) + (1 << 45)
+        # a loose value that is 0 (mod p) has exactly the limbs of 0 or of p
+        if limbs_value(out) % P == 0:
+            assert limbs_value(out) in (0, P)
+    # carry / canon accept loose and lazy inputs
+    for l in (LOOSE_MAX, TIGHT_MAX, [0xFFFFFFFF] * 9, [0] * 9):
+        t = fe_raw(shim, 5, l)
+        assert limbs_value(t) % P == limbs_value(l) % P and all(v < (1 << 29) for v in t[:8]) and t[8] <= (1 << 24) + (1 << 20)
+        cn = fe_raw(shim, 6, l)
+        assert limbs_value(cn) == limbs_value(l) % P
+
+
+def test_generated_device_bodies_are_current():
+    """csrc/field_gen.hpp is what tools/gen_field_asm.py emits today (the asm is never edited by hand)."""
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "gen_field_asm.py"), "--check"])
+    assert r.returncode == 0, "run `python tools/gen_field_asm.py` and commit csrc/field_gen.hpp"

@@ -110,7 +110,7 @@ def test_unreduced_scalars_are_reduced_on_load(gp):
     eng = gp.engine()
     pts, _ = gp.rand_points(5000, 21)
     rnd = random.Random(22)
-    raw = [Q, Q + 5, 2 ** 256 - 1, Q - 1, 0, 2 ** 255, Q + (Q - 1) // 2] + [rnd.randrange(2 ** 256) for _ in range(5000 - 7)]
+    raw = [Q, Q + 5, 2 ** 256 - 1, Q - 1, 0, 2 ** 255, 2 ** 256 - 2] + [rnd.randrange(2 ** 256) for _ in range(5000 - 7)]
     rawb = b"".join(v.to_bytes(32, "little") for v in raw)
     red = [v % Q for v in raw]
     for n in (1, 3, 7, 300, 5000):                     # small-MSM kernel, and the bucket pipeline above 4096
