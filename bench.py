@@ -106,9 +106,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the C5 / C3 extra measurements")
     ap.add_argument("--no-pipeline", action="store_true", help="synchronous bpmi_msm_dev per step instead of the two-deep pipeline")
+    ap.add_argument("--async-lanes", type=int, default=1, help="1: the two in-flight MSMs run on the engine's two lanes (streams)")
     ap.add_argument("--soak-seconds", type=float, default=6.0,
                     help="untimed MSMs after the timed region, so that an external sampler (rocm-smi every few seconds) sees the GPU busy")
     ap.add_argument("--cpu-logn", type=int, default=16)
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="bpmi_set_option passthrough (tuning experiments)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -148,6 +150,11 @@ def main():
     stream = torch.cuda.Stream(dev)
     torch.cuda.set_stream(stream)
     eng = Engine(device=local_dev, stream=stream.cuda_stream)
+    if args.async_lanes:
+        eng.set_option("async_lanes", 1)
+    for kv in args.opt:
+        name, value = kv.split("=")
+        eng.set_option(name, int(value))
 
     n_total = 1 << args.logn
     n = n_total if args.scaling == "weak" else n_total // world      # pairs on this rank

@@ -68,6 +68,9 @@ int bpmi_sync(bpmi_ctx *ctx);
  *                  2 host thread (default; the result is consumed on the host anyway)
  *   "small_n"      largest n that runs on the one-launch small-MSM kernel (-1: never; default 4096)
  *   "split"        1: run one MSM as two window groups on the ctx's two lanes (default 0)
+ *   "async_lanes"  1: slot 1 of bpmi_msm_dev_enqueue runs on the ctx's second lane (own stream and workspace), so
+ *                  the tail stages of one MSM overlap the sort / accumulate of the next (inputs must be complete
+ *                  before the first enqueue of a burst; default 0)
  *   "ipa_big_m"    base length from which the IPA prover folds its generators 16-way at
  *                  once instead of deferring the fold into the MSM scalars (default 2^18) */
 int bpmi_set_option(bpmi_ctx *ctx, const char *name, int64_t value);

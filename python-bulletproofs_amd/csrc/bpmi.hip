@@ -99,6 +99,7 @@ void bpmi_ctx_destroy(bpmi_ctx *ctx) {
   if (ctx->pin) (void)hipHostFree(ctx->pin);
   if (ctx->stream1) { (void)hipStreamSynchronize(ctx->stream1); (void)hipStreamDestroy(ctx->stream1); }
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+  for (auto e : ctx->ev_accum) if (e) (void)hipEventDestroy(e);
   if (ctx->ws1) (void)hipFree(ctx->ws1);
   for (auto &pd : ctx->pend) { if (pd.pin) (void)hipHostFree(pd.pin); if (pd.done) (void)hipEventDestroy(pd.done); }
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
@@ -122,6 +123,7 @@ int bpmi_set_option(bpmi_ctx *ctx, const char *name, int64_t value) {
   if (!strcmp(name, "tail")) { if (value < 0 || value > 2) return fail(ctx, BPMI_E_ARG, "tail must be 0, 1 or 2"); ctx->opt_tail = (int)value; return BPMI_OK; }
   if (!strcmp(name, "small_n")) { if (value < -1 || value > (1 << 16)) return fail(ctx, BPMI_E_ARG, "small_n must be -1 .. 65536"); ctx->opt_small = (int)value; return BPMI_OK; }
   if (!strcmp(name, "split")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "split must be 0 or 1"); ctx->opt_split = (int)value; return BPMI_OK; }
+  if (!strcmp(name, "async_lanes")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "async_lanes must be 0 or 1"); ctx->opt_async_lanes = (int)value; return BPMI_OK; }
   if (!strcmp(name, "chunk")) { if (value < 0 || value > 4096) return fail(ctx, BPMI_E_ARG, "chunk must be 0..4096"); ctx->opt_chunk = (int)value; return BPMI_OK; }
   if (!strcmp(name, "ipa_big_m")) { if (value < 0 || (value & (value - 1))) return fail(ctx, BPMI_E_ARG, "ipa_big_m must be 0 or a power of two"); ctx->opt_ipa_big = value; return BPMI_OK; }
   return fail(ctx, BPMI_E_ARG, std::string("unknown option ") + name);
@@ -202,7 +204,24 @@ int bpmi_msm_dev_enqueue(bpmi_ctx *ctx, int slot, const void *d_pts, const void 
   HIPCHK(ctx, hipSetDevice(ctx->device));
   Segs s = segs_init();
   s.pts[0] = (const u32 *)d_pts; s.sc[0] = (const u32 *)d_scalars; s.n[0] = (u32)n; s.total = (u32)n;
-  int rc = msm_enqueue(ctx, 0, slot, s);
+  // option async_lanes: slot 1 runs on the second lane (own stream + workspace), so the latency-bound tail stages of
+  // one MSM (segmented scan, bucket reduction: few waves) overlap the throughput stages of the next one
+  const int lane = (ctx->opt_async_lanes && slot == 1) ? 1 : 0;
+  int rc;
+  if (ctx->opt_async_lanes) {
+    rc = ensure_lane(ctx, 1);
+    if (rc) return rc;
+  }
+  if (lane == 1) {
+    if (!ctx->async_lane1_ordered) {       // order lane 1 after whatever produced the inputs on the ctx stream, once per idle period
+      HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+      HIPCHK(ctx, hipStreamWaitEvent(ctx->stream1, ctx->ev_fork, 0));
+      ctx->async_lane1_ordered = true;
+    }
+  }
+  ctx->chain_accum = ctx->opt_async_lanes != 0;
+  rc = msm_enqueue(ctx, lane, slot, s);
+  ctx->chain_accum = false;
   if (rc == BPMI_OK) ctx->pend[slot].async = true;
   return rc;
 }
@@ -211,6 +230,7 @@ int bpmi_msm_finish(bpmi_ctx *ctx, int slot, uint8_t out[64]) {
   if (slot < 0 || slot > 1) return fail(ctx, BPMI_E_ARG, "slot must be 0 or 1");
   if (!ctx->pend[slot].async) return fail(ctx, BPMI_E_STATE, "no MSM was enqueued in this slot");
   ctx->pend[slot].async = false;
+  if (!ctx->pend[0].async && !ctx->pend[1].async) { ctx->async_lane1_ordered = false; ctx->accum_chain_lane = -1; }
   HIPCHK(ctx, hipSetDevice(ctx->device));
   return msm_finish(ctx, slot, out);
 }

@@ -30,6 +30,12 @@ struct bpmi_ctx {
   hipStream_t stream1 = nullptr;
   void *ws1 = nullptr; size_t ws1_bytes = 0;
   hipEvent_t ev_fork = nullptr;
+  // software pipeline of the asynchronous MSM pair on two lanes: the accumulate kernel of an MSM waits for the
+  // accumulate kernel of the MSM enqueued before it (on the other lane), so the throughput-bound stage always has the
+  // whole GPU while the other lane's latency-bound tail (segmented scan, bucket reduction) and next sort run beside it
+  hipEvent_t ev_accum[2] = {nullptr, nullptr};
+  int accum_chain_lane = -1;     // lane whose ev_accum is the newest, -1: none pending
+  bool chain_accum = false;      // set by bpmi_msm_dev_enqueue around msm_enqueue
   // One in-flight MSM: its own pinned host buffer (what the tail reads) and its own completion event, so
   // that finishing it never waits for work enqueued behind it (bpmi_msm_dev_enqueue / bpmi_msm_finish
   // keep two MSMs in flight on ONE stream: the host tail of MSM k overlaps the kernels of MSM k + 1).
@@ -43,6 +49,8 @@ struct bpmi_ctx {
   int opt_tail = 0;     // 0 auto, 1 device, 2 host
   int opt_chunk = 0;    // entries per thread in k_accum_l0, 0 = auto
   int opt_small = 0;    // largest n handled by the one-launch small-MSM kernel (0 = default, -1 = never)
+  int opt_async_lanes = 0;   // 1: slot 1 of the asynchronous MSM pair runs on the second lane
+  bool async_lane1_ordered = false;
   int opt_split = 0;    // 1: one MSM as two window groups, one per lane (measured: +5 % at 2^20, -8 % at 2^19; off)
   int64_t opt_ipa_big = 0;   // base length from which the IPA folds generators 16-way (0 = default 2^18)
   // profiling
@@ -108,6 +116,7 @@ static int ensure_lane(bpmi_ctx *ctx, int lane) {
   if (lane == 0 || ctx->stream1) return BPMI_OK;
   HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream1, hipStreamNonBlocking));
   HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+  for (int k = 0; k < 2; k++) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_accum[k], hipEventDisableTiming));
   return BPMI_OK;
 }
 static hipStream_t lane_stream(bpmi_ctx *ctx, int lane) { return lane ? ctx->stream1 : ctx->stream; }

@@ -54,46 +54,40 @@ BPMI_HD void affine_neg(affine &r, const affine &a) {
   fe t; fe_neg(t, a.y); fe_carry(r.y, t);
 }
 
-// r = 2 * (x, y) for an affine point (mdbl-2008-s-1): 2M + 3S... here 3M + 3S with Y3's products
+// r = 2 * (x, y) for an affine point (mdbl-2008-s-1): 2M + 3S + the Y3 pair, six reductions; y tight or loose
 BPMI_HD void xyzz_dbl_affine(xyzz &r, const fe &x, const fe &y) {
-  fe U, V, W, S, M, t, t2;
-  fe_add(U, y, y);                       // mag 2
+  fe U, V, W, S, M, t, nW;
+  fe_add(U, y, y);                       // magnitude 2
   fe_sqr(V, U);                          // V = 4y^2
   fe_mul(W, U, V);                       // W = 8y^3
   fe_mul(S, x, V);
-  fe_sqr(t, x); fe_mul_small(M, t, 3);   // M = 3x^2, mag 3
-  fe_carry(M, M);
-  fe_sqr(t, M);                          // M^2
-  fe_sub(t, t, S); fe_sub(t, t, S);      // mag 5
-  fe_carry(r.X, t);
-  fe_sub(t, S, r.X);                     // mag 3
-  fe_mul(t, M, t);
-  fe_mul(t2, W, y);
-  fe_sub(t, t, t2); fe_carry(r.Y, t);
+  fe_sqr3(M, x);                         // M = 3x^2
+  fe_bias4_sub_2a(t, S);
+  fe_sqr_add(r.X, M, t);                 // X3 = M^2 - 2S
+  fe_sub(t, S, r.X);                     // S - X3 + 2p, magnitude 3
+  fe_neg(nW, W);
+  fe_mul2(r.Y, M, t, nW, y);             // Y3 = M (S - X3) - W y
   r.ZZ = V; r.ZZZ = W;
 }
 
-// r = 2 * a (dbl-2008-s-1, a = 0): 6M + 3S.  2-torsion does not exist on
+// r = 2 * a (dbl-2008-s-1, a = 0): 6M + 3S in eight reductions.  2-torsion does not exist on
 // secp256k1 (prime order), so Y == 0 only for the identity.
 BPMI_HD void xyzz_dbl(xyzz &r, const xyzz &a) {
   if (xyzz_is_inf(a)) { xyzz_set_inf(r); return; }
-  fe U, V, W, S, M, t, t2, X3;
+  fe U, V, W, S, M, t, nW, X3, Y3;
   fe_add(U, a.Y, a.Y);
   fe_sqr(V, U);
   fe_mul(W, U, V);
   fe_mul(S, a.X, V);
-  fe_sqr(t, a.X); fe_mul_small(M, t, 3); fe_carry(M, M);
-  fe_sqr(t, M);
-  fe_sub(t, t, S); fe_sub(t, t, S);
-  fe_carry(X3, t);
+  fe_sqr3(M, a.X);
+  fe_bias4_sub_2a(t, S);
+  fe_sqr_add(X3, M, t);
   fe_sub(t, S, X3);
-  fe_mul(t, M, t);
-  fe_mul(t2, W, a.Y);
-  fe_sub(t, t, t2);
+  fe_neg(nW, W);
+  fe_mul2(Y3, M, t, nW, a.Y);
   fe_mul(r.ZZ, V, a.ZZ);
   fe_mul(r.ZZZ, W, a.ZZZ);
-  fe_carry(r.Y, t);
-  r.X = X3;
+  r.X = X3; r.Y = Y3;
 }
 
 // acc += (x2, y2), affine addend that is NOT the identity (madd-2008-s): 8M + 2S in NINE reductions.
@@ -136,17 +130,17 @@ BPMI_HD void xyzz_madd_signed(xyzz &acc, const affine &P, bool negate) {
   xyzz_madd(acc, P.x, ny);
 }
 
-// r = a + b, both XYZZ (add-2008-s): 12M + 2S
+// r = a + b, both XYZZ (add-2008-s): 12M + 2S in thirteen reductions (the subtractions ride in them)
 BPMI_HD void xyzz_add(xyzz &r, const xyzz &a, const xyzz &b) {
   if (xyzz_is_inf(a)) { r = b; return; }
   if (xyzz_is_inf(b)) { r = a; return; }
-  fe U1, U2, S1, S2, P, R, PP, PPP, Q, t, t2, X3;
+  fe U1, S1, nU1, nS1, P, R, PP, PPP, Q, t, X3, Y3, zz;
   fe_mul(U1, a.X, b.ZZ);
-  fe_mul(U2, b.X, a.ZZ);
   fe_mul(S1, a.Y, b.ZZZ);
-  fe_mul(S2, b.Y, a.ZZZ);
-  fe_sub(P, U2, U1); fe_carry(P, P);
-  fe_sub(R, S2, S1); fe_carry(R, R);
+  fe_neg(nU1, U1);
+  fe_neg(nS1, S1);
+  fe_mul_add(P, b.X, a.ZZ, nU1);         // U2 - U1
+  fe_mul_add(R, b.Y, a.ZZZ, nS1);        // S2 - S1
   if (fe_is_zero_tight(P)) {
     if (fe_is_zero_tight(R)) { xyzz_dbl(r, a); return; }
     xyzz_set_inf(r); return;
@@ -154,17 +148,13 @@ BPMI_HD void xyzz_add(xyzz &r, const xyzz &a, const xyzz &b) {
   fe_sqr(PP, P);
   fe_mul(PPP, P, PP);
   fe_mul(Q, U1, PP);
-  fe_sqr(t, R);
-  fe_sub(t, t, PPP); fe_sub(t, t, Q); fe_sub(t, t, Q);
-  fe_carry(X3, t);
+  fe_bias8_sub_a_2b(t, PPP, Q);
+  fe_sqr_add(X3, R, t);                  // R^2 - PPP - 2Q
   fe_sub(t, Q, X3);
-  fe_mul(t, R, t);
-  fe_mul(t2, S1, PPP);
-  fe_sub(t, t, t2);
-  fe_mul(t2, a.ZZ, b.ZZ); fe_mul(r.ZZ, t2, PP);
-  fe_mul(t2, a.ZZZ, b.ZZZ); fe_mul(r.ZZZ, t2, PPP);
-  fe_carry(r.Y, t);
-  r.X = X3;
+  fe_mul2(Y3, R, t, nS1, PPP);           // R (Q - X3) - S1 PPP
+  fe_mul(zz, a.ZZ, b.ZZ); fe_mul(r.ZZ, zz, PP);
+  fe_mul(zz, a.ZZZ, b.ZZZ); fe_mul(r.ZZZ, zz, PPP);
+  r.X = X3; r.Y = Y3;
 }
 
 BPMI_HD void xyzz_neg(xyzz &r, const xyzz &a) {
@@ -194,44 +184,40 @@ struct jac { fe X, Y, Z; };              // tight limbs
 BPMI_HD void jac_set_inf(jac &r) { fe_set_zero(r.X); fe_set_one(r.Y); fe_set_zero(r.Z); }
 BPMI_HD bool jac_is_inf(const jac &a) { return fe_is_zero_tight(a.Z); }
 
-// r = 2a (dbl-2009-l, curve a = 0).  Z = 0 maps to Z = 0, so the identity needs no branch;
-// Y = 0 cannot occur (no 2-torsion on a prime-order curve).
+// r = 2a (dbl-2009-l, curve a = 0): 2M + 5S in seven reductions and one carry.  Z = 0 maps to Z = 0, so the
+// identity needs no branch; Y = 0 cannot occur (no 2-torsion on a prime-order curve).
 BPMI_HD void jac_dbl(jac &r, const jac &a) {
-  // statement order keeps at most ~6 field elements live (register pressure decides the
-  // occupancy of the ladder kernels)
-  fe A, B, C, D, E, t;
-  fe_mul(t, a.Y, a.Z);
-  fe_sqr(B, a.Y);
+  fe A, B, C, Dh, E, t, X3, Y3, Z3;
   fe_sqr(A, a.X);
-  fe_add(D, a.X, B);                     // mag 2
-  fe_add(r.Z, t, t); fe_carry(r.Z, r.Z); // Z3 = 2YZ   (a.Y, a.Z dead from here)
-  fe_sqr(D, D);                          // (X + B)^2
+  fe_sqr(B, a.Y);
+  fe_add(t, a.Y, a.Y);
+  fe_mul(Z3, t, a.Z);                    // Z3 = 2YZ
   fe_sqr(C, B);
-  fe_sub(D, D, A); fe_sub(D, D, C);      // mag 5
-  fe_carry(D, D);
-  fe_add(D, D, D); fe_carry(D, D);       // D = 2((X+B)^2 - A - C), tight
+  fe_add(t, a.X, B);                     // magnitude 2
+  fe_bias4_sub_a_b(E, A, C);
+  fe_sqr_add(Dh, t, E);                  // Dh = (X + B)^2 - A - C   (= D / 2)
   fe_mul_small(E, A, 3); fe_carry(E, E); // E = 3A, tight
-  fe_sqr(t, E);
-  fe_sub(t, t, D); fe_sub(t, t, D);      // mag 5
-  fe_carry(r.X, t);
-  fe_sub(t, D, r.X);                     // mag 3
-  fe_mul(t, E, t);
-  fe_carry(C, C); fe_mul_small(C, C, 8); fe_carry(C, C); // 8C (C is a loose square: 8 x its limb 0 would pass 2^32)
-  fe_sub(t, t, C); fe_carry(r.Y, t);
+  fe_bias8_sub_4a(t, Dh);
+  fe_sqr_add(X3, E, t);                  // X3 = E^2 - 2D
+  fe_dbl_sub(t, Dh, X3);                 // D - X3 + 2p, magnitude 4
+  fe_neg(C, C);                          // 2p - C
+  fe_mul_add8(Y3, E, t, C);              // Y3 = E (D - X3) - 8C
+  r.X = X3; r.Y = Y3; r.Z = Z3;
 }
-// acc += (x2, y2), affine addend that is NOT the identity: 8M + 3S, complete
+// acc += (x2, y2), affine addend that is NOT the identity: 8M + 3S in ten reductions, complete.
+// y2 may be lazy (magnitude <= 2).
 BPMI_HD void jac_madd(jac &acc, const fe &x2, const fe &y2) {
-  if (jac_is_inf(acc)) { acc.X = x2; acc.Y = y2; fe_set_one(acc.Z); return; }
-  fe H, R, HH, V, t;
-  fe_sqr(HH, acc.Z);                     // Z1Z1
-  fe_mul(H, x2, HH);                     // U2
+  if (jac_is_inf(acc)) { acc.X = x2; fe_carry(acc.Y, y2); fe_set_one(acc.Z); return; }
+  fe ZZ, nX, nY, H, R, HH, HHH, V, t;
+  fe_sqr(ZZ, acc.Z);                     // Z1Z1
+  fe_neg(nX, acc.X);
+  fe_neg(nY, acc.Y);
+  fe_mul_add(H, x2, ZZ, nX);             // H = U2 - X1
   fe_mul(t, y2, acc.Z);
-  fe_mul(R, t, HH);                      // S2
-  fe_sub(H, H, acc.X); fe_carry(H, H);   // H = U2 - X1
-  fe_sub(R, R, acc.Y); fe_carry(R, R);   // R = S2 - Y1
+  fe_mul_add(R, t, ZZ, nY);              // R = S2 - Y1
   if (fe_is_zero_tight(H)) {
     if (fe_is_zero_tight(R)) {           // acc == addend: double the affine point
-      jac d; d.X = x2; d.Y = y2; fe_set_one(d.Z);
+      jac d; d.X = x2; fe_carry(d.Y, y2); fe_set_one(d.Z);
       jac_dbl(acc, d);
       return;
     }
@@ -239,21 +225,17 @@ BPMI_HD void jac_madd(jac &acc, const fe &x2, const fe &y2) {
   }
   fe_sqr(HH, H);
   fe_mul(acc.Z, acc.Z, H);               // Z3
-  fe_mul(H, H, HH);                      // HHH
+  fe_mul(HHH, H, HH);
   fe_mul(V, acc.X, HH);
-  fe_mul(HH, acc.Y, H);                  // Y1 * HHH
-  fe_sqr(t, R);
-  fe_sub(t, t, H); fe_sub(t, t, V); fe_sub(t, t, V);   // mag 7
-  fe_carry(acc.X, t);
-  fe_sub(t, V, acc.X);                   // mag 3
-  fe_mul(t, R, t);
-  fe_sub(t, t, HH); fe_carry(acc.Y, t);
+  fe_bias8_sub_a_2b(t, HHH, V);
+  fe_sqr_add(acc.X, R, t);               // X3 = R^2 - HHH - 2V
+  fe_sub(t, V, acc.X);
+  fe_mul2(acc.Y, R, t, nY, HHH);         // Y3 = R (V - X3) - Y1 HHH
 }
-// y-sign as a select (see xyzz_madd_signed)
+// y-sign as a select (see xyzz_madd_signed); the negated y stays lazy
 BPMI_HD void jac_madd_signed(jac &acc, const fe &x2, const fe &y2, bool negate) {
-  fe ny, t;
-  fe_neg(t, y2);
-  fe_carry(ny, t);
+  fe ny;
+  fe_neg(ny, y2);
 #pragma unroll
   for (int k = 0; k < 9; k++) ny.v[k] = negate ? ny.v[k] : y2.v[k];
   jac_madd(acc, x2, ny);

@@ -99,6 +99,30 @@ BPMI_HD void fe_bias8_sub_a_2b(fe &r, const fe &a, const fe &b) {
 #pragma unroll
   for (int k = 0; k < 9; k++) r.v[k] = bias[k] - a.v[k] - (b.v[k] << 1);
 }
+// r = 4p - 2a, a column addend; a loose
+BPMI_HD void fe_bias4_sub_2a(fe &r, const fe &a) {
+  const u32 bias[9] = BPMI_FE_BIAS4;
+#pragma unroll
+  for (int k = 0; k < 9; k++) r.v[k] = bias[k] - (a.v[k] << 1);
+}
+// r = 4p - a - b, a column addend; a, b loose
+BPMI_HD void fe_bias4_sub_a_b(fe &r, const fe &a, const fe &b) {
+  const u32 bias[9] = BPMI_FE_BIAS4;
+#pragma unroll
+  for (int k = 0; k < 9; k++) r.v[k] = bias[k] - a.v[k] - b.v[k];
+}
+// r = 8p - 4a, a column addend; a loose
+BPMI_HD void fe_bias8_sub_4a(fe &r, const fe &a) {
+  const u32 bias[9] = BPMI_FE_BIAS8;
+#pragma unroll
+  for (int k = 0; k < 9; k++) r.v[k] = bias[k] - (a.v[k] << 2);
+}
+// r = 2a - b + 2p ; a, b loose; magnitude 4
+BPMI_HD void fe_dbl_sub(fe &r, const fe &a, const fe &b) {
+  const u32 bias[9] = BPMI_FE_BIAS2;
+#pragma unroll
+  for (int k = 0; k < 9; k++) r.v[k] = (a.v[k] << 1) + bias[k] - b.v[k];
+}
 // r = 2p - a ; a tight or loose; mag 2
 BPMI_HD void fe_neg(fe &r, const fe &a) {
   const u32 bias[9] = BPMI_FE_BIAS2;
@@ -124,6 +148,8 @@ BPMI_HD void fe_carry(fe &r, const fe &a) {
 //   fe_mul_add(r, a, b, add)   r = a b + add         add: any 9 limbs < 2^32 (e.g. BIAS - x: a fused subtraction)
 //   fe_sqr_add(r, a, add)      r = a^2 + add
 //   fe_mul2(r, a, b, c, d)     r = a b + c d
+//   fe_sqr3(r, a)              r = 3 a^2                 (the tangent slope numerator, without a lazy x3 and a carry)
+//   fe_mul_add8(r, a, b, add)  r = a b + 8 add           (the - 8 Y^4 of a Jacobian doubling as 8 (2p - Y^4))
 // All of them build the 17 product columns (a column of products and addends must stay below 2^64:
 // 9 * (mag(a) mag(b) + mag(c) mag(d)) <= 63) and reduce ONCE, so a subtraction or a second product that feeds a
 // multiplication result costs no carry pass and no second reduction (the mixed addition needs 9 reductions
@@ -144,11 +170,11 @@ BPMI_HD void fe_carry(fe &r, const fe &a) {
 // 1.008); its limb vector is still unique for a given integer, so 0 (mod p) is exactly "all limbs 0" or "the limbs
 // of p" -- fe_is_zero_tight works on it unchanged.
 struct fe_dcols { u64 c[17]; };
-BPMI_HD void fe_cols_add_product(fe_dcols &q, const fe &a, const fe &b) {
+BPMI_HD void fe_cols_add_product(fe_dcols &q, const fe &a, const fe &b, u32 times = 1) {
 #pragma unroll
   for (int i = 0; i < 9; i++)
 #pragma unroll
-    for (int j = 0; j < 9; j++) q.c[i + j] += (u64)a.v[i] * b.v[j];
+    for (int j = 0; j < 9; j++) q.c[i + j] += (u64)(a.v[i] * times) * b.v[j];
 }
 BPMI_HD void fe_cols_reduce(fe &r, const fe_dcols &q) {
   u32 th[8], t[8];
@@ -185,12 +211,12 @@ BPMI_HD void fe_cols_reduce(fe &r, const fe_dcols &q) {
   for (int k = 2; k < 8; k++) r.v[k] = t[k];
   r.v[8] = (u32)s & M24;
 }
-// r = a b (+ c d) (+ add); c, d, add may be null
-BPMI_HD void fe_mac_c(fe &r, const fe &a, const fe &b, const fe *c, const fe *d, const fe *add) {
+// r = times a b (+ c d) (+ add_scale add); c, d, add may be null
+BPMI_HD void fe_mac_c(fe &r, const fe &a, const fe &b, const fe *c, const fe *d, const fe *add, u32 times = 1, u32 add_scale = 1) {
   fe_dcols q;
 #pragma unroll
-  for (int k = 0; k < 17; k++) q.c[k] = (add && k < 9) ? add->v[k] : 0;
-  fe_cols_add_product(q, a, b);
+  for (int k = 0; k < 17; k++) q.c[k] = (add && k < 9) ? (u64)add->v[k] * add_scale : 0;
+  fe_cols_add_product(q, a, b, times);
   if (c) fe_cols_add_product(q, *c, *d);
   fe_cols_reduce(r, q);
 }
@@ -212,6 +238,20 @@ BPMI_HD void fe_sqr(fe &r, const fe &a) {
   fe_sqr_dev(r, a);
 #else
   fe_mac_c(r, a, a, nullptr, nullptr, nullptr);
+#endif
+}
+BPMI_HD void fe_sqr3(fe &r, const fe &a) {            // a loose or tight (6 x limb must fit 32 bits)
+#if defined(__HIP_DEVICE_COMPILE__)
+  fe_sqr3_dev(r, a);
+#else
+  fe_mac_c(r, a, a, nullptr, nullptr, nullptr, 3);
+#endif
+}
+BPMI_HD void fe_mul_add8(fe &r, const fe &a, const fe &b, const fe &add) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  fe_mul_add8_dev(r, a, b, add);
+#else
+  fe_mac_c(r, a, b, nullptr, nullptr, &add, 1, 8);
 #endif
 }
 BPMI_HD void fe_mul_add(fe &r, const fe &a, const fe &b, const fe &add) {

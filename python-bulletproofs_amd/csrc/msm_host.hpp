@@ -122,7 +122,9 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, int slot, const Segs &segs, u32 
   g.w0 = w0;
   g.B = 1u << (g.c - 1);
   g.G = g.W * g.B;
-  g.L = ctx->opt_chunk > 0 ? (u32)ctx->opt_chunk : (n >= (1u << 19) ? 64u : (n >= (1u << 18) ? 32u : 16u));   // tools/tune_msm.py sweeps
+  // tools/tune_msm.py sweeps; on the two-lane pipeline 86 entries per thread fill the 3 waves per SIMD exactly once at n = 2^20
+  // (profiles/r02_chunk_sweep_two_lanes.txt)
+  g.L = ctx->opt_chunk > 0 ? (u32)ctx->opt_chunk : (n >= (1u << 19) ? (ctx->chain_accum ? 86u : 64u) : (n >= (1u << 18) ? 32u : 16u));
   g.nv = (g.B <= 256u) ? 1u : 4u;                  // partial sums per window handed to the tail
   MsmWs w;
   msm_layout(g, w, nullptr);
@@ -209,12 +211,15 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, int slot, const Segs &segs, u32 
     }
     debug_sync(ctx, "ST_SCATTER", st);
   }
+  if (ctx->chain_accum && ctx->accum_chain_lane >= 0 && ctx->accum_chain_lane != lane)
+    HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_accum[ctx->accum_chain_lane], 0));
   {
     StageTimer t(ctx, ST_ACCUM, st);
     const u32 nthreads = w.rec0_max / 2;
     hipLaunchKernelGGL(k_accum_l0, dim3((nthreads + 255) / 256), dim3(256), 0, st, segs, g, w.off, w.chunk_key, w.sidx,
                        w.buckets, w.rec_key[0], w.rec_pt[0]);
   }
+  if (ctx->chain_accum) { HIPCHK(ctx, hipEventRecord(ctx->ev_accum[lane], st)); ctx->accum_chain_lane = lane; }
   debug_sync(ctx, "ST_ACCUM", st);
   {
     StageTimer t(ctx, ST_SEGSCAN, st);

@@ -66,6 +66,21 @@ def test_c2_headline_msm_2e20_equals_c_oracle(gp):
     eng.msm_dev_enqueue(1, d_p, d_s, n // 2)
     assert eng.msm_finish(0) == want
     assert eng.msm_finish(1) == cbind.msm_bytes(pts[: 32 * n], reduced[: 16 * n], n // 2)
+    # the same on two lanes with the accumulate kernels chained by events (option async_lanes): a burst of MSMs of
+    # different lengths, two in flight, every result equal to the synchronous one
+    eng.set_option("async_lanes", 1)
+    try:
+        sizes = [n, 5000, n // 2, 3, n // 4 + 17, 70000, n]
+        want_k = [eng.msm_dev(d_p, d_s, m) for m in sizes]
+        eng.msm_dev_enqueue(0, d_p, d_s, sizes[0])
+        got = []
+        for j in range(len(sizes)):
+            if j + 1 < len(sizes):
+                eng.msm_dev_enqueue((j + 1) & 1, d_p, d_s, sizes[j + 1])
+            got.append(eng.msm_finish(j & 1))
+        assert got == want_k and got[0] == want
+    finally:
+        eng.set_option("async_lanes", 0)
     d_p.free()
     d_s.free()
 

@@ -33,7 +33,7 @@ MAX_PAIRS = 14          # an asm statement takes at most 30 operands: accumulato
 
 def products(k, kind, A, B):
     """operand pairs (x, y) of column k of one limb product.  kind 'mul': A[i] * B[k-i];  'sqr': A squared, with the
-    doubled limbs D<A>[i] = 2 A[i] so that a symmetric pair costs one multiply-add."""
+    doubled limbs d<A>[i] = 2 A[i] so that a symmetric pair costs one multiply-add;  'sqr3': 3 A^2 (d = 6 A, diagonal 3 A)."""
     out = []
     lo, hi = max(0, k - 8), min(k, 8)
     if kind == "mul":
@@ -43,7 +43,7 @@ def products(k, kind, A, B):
         if i < j:
             out.append(("d%s[%d]" % (A, i), "%s.v[%d]" % (A, j)))
         elif i == j:
-            out.append(("%s.v[%d]" % (A, i), "%s.v[%d]" % (A, i)))
+            out.append((("%s.v[%d]" if kind == "sqr" else "t%s[%d]") % (A, i), "%s.v[%d]" % (A, i)))      # sqr3: (3 a_i) a_i
     return out
 
 
@@ -80,14 +80,17 @@ class Stmt:
         return text
 
 
-def body(prods, addend):
-    """prods: list of (kind, A, B).  addend: name of an fe whose limbs are added to columns 0..8, or None."""
+def body(prods, addend, add_kind="v1"):
+    """prods: list of (kind, A, B).  addend: name of an fe whose limbs (times 1, or 8 with add_kind "v8") are added to
+    columns 0..8, or None."""
     L = []
     L.append("  const u32 k31264 = 31264u, k256 = 256u, k65536 = 65536u, kf = 31264u * 256u, k977 = 977u;\n")
     L.append("  u64 s, sink_;\n  u32 th[8], t[8], hp;\n")
     for kind, A, B in prods:
         if kind == "sqr":
             L.append("  u32 d%s[9];\n#pragma unroll\n  for (int i = 0; i < 9; i++) d%s[i] = %s.v[i] << 1;\n" % (A, A, A))
+        if kind == "sqr3":
+            L.append("  u32 d%s[9], t%s[9];\n#pragma unroll\n  for (int i = 0; i < 9; i++) { t%s[i] = %s.v[i] * 3u; d%s[i] = t%s[i] << 1; }\n" % (A, A, A, A, A, A))
     # ---- high half: columns 9..16, dirty 32-bit limbs
     for k in range(9, 17):
         st = Stmt(True)
@@ -106,7 +109,7 @@ def body(prods, addend):
         for x, y in products(8, kind, A, B):
             st.add(x, y)
     if addend:
-        st.add("%s.v[8]" % addend, None, "v1")
+        st.add("%s.v[8]" % addend, None, add_kind)
     L.append(st.emit())
     L.append("  const u32 s8m = (u32)s & M24;\n  const u64 w = s >> 24;\n  const u32 wl = (u32)w & M29, wh = (u32)(w >> 29);\n")
     # ---- low chain: columns 0..7
@@ -128,7 +131,7 @@ def body(prods, addend):
             for x, y in products(k, kind, A, B):
                 st.add(x, y)
         if addend:
-            st.add("%s.v[%d]" % (addend, k), None, "v1")
+            st.add("%s.v[%d]" % (addend, k), None, add_kind)
         L.append(st.emit())
         L.append("  t[%d] = (u32)s & M29; s >>= 29;\n" % k)
     # ---- end: column 8 = its 24 kept bits + the last carry; the overflow goes to limbs 0 and 1, uncarried
@@ -143,11 +146,13 @@ def body(prods, addend):
 
 
 FUNCS = [
-    ("fe_mul_dev", "fe &r, const fe &a, const fe &b", [("mul", "a", "b")], None),
-    ("fe_sqr_dev", "fe &r, const fe &a", [("sqr", "a", None)], None),
-    ("fe_mul_add_dev", "fe &r, const fe &a, const fe &b, const fe &add", [("mul", "a", "b")], "add"),
-    ("fe_sqr_add_dev", "fe &r, const fe &a, const fe &add", [("sqr", "a", None)], "add"),
-    ("fe_mul2_dev", "fe &r, const fe &a, const fe &b, const fe &c, const fe &d", [("mul", "a", "b"), ("mul", "c", "d")], None),
+    ("fe_mul_dev", "fe &r, const fe &a, const fe &b", [("mul", "a", "b")], None, "v1"),
+    ("fe_sqr_dev", "fe &r, const fe &a", [("sqr", "a", None)], None, "v1"),
+    ("fe_sqr3_dev", "fe &r, const fe &a", [("sqr3", "a", None)], None, "v1"),
+    ("fe_mul_add_dev", "fe &r, const fe &a, const fe &b, const fe &add", [("mul", "a", "b")], "add", "v1"),
+    ("fe_mul_add8_dev", "fe &r, const fe &a, const fe &b, const fe &add", [("mul", "a", "b")], "add", "v8"),
+    ("fe_sqr_add_dev", "fe &r, const fe &a, const fe &add", [("sqr", "a", None)], "add", "v1"),
+    ("fe_mul2_dev", "fe &r, const fe &a, const fe &b, const fe &c, const fe &d", [("mul", "a", "b"), ("mul", "c", "d")], None, "v1"),
 ]
 
 
@@ -155,8 +160,8 @@ def generate():
     out = ["// field_gen.hpp -- GENERATED by tools/gen_field_asm.py; do not edit (tests/test_csrc_host.py checks it is current).\n",
            "// Device bodies of the field-multiplication family; the arithmetic is fe_mac_c of field.hpp, column for column.\n",
            "#pragma once\n", "#if defined(__HIP_DEVICE_COMPILE__)\n"]
-    for name, sig, prods, addend in FUNCS:
-        out.append("__device__ __forceinline__ void %s(%s) {\n%s}\n" % (name, sig, body(prods, addend)))
+    for name, sig, prods, addend, add_kind in FUNCS:
+        out.append("__device__ __forceinline__ void %s(%s) {\n%s}\n" % (name, sig, body(prods, addend, add_kind)))
     out.append("#endif\n")
     return "".join(out)
 
