@@ -95,19 +95,17 @@ BPMI_HD void xyzz_dbl(xyzz &r, const xyzz &a) {
 // branches that store or double it carry it first.  The subtractions ride in the reductions:
 //   P  = x2 ZZ  + (2p - X)                 fe_mul_add        R  = y2 ZZZ + (2p - Y)         fe_mul_add
 //   X3 = R^2 + (8p - PPP - 2Q)             fe_sqr_add        Y3 = R (Q - X3 + 2p) + (2p - Y) PPP   fe_mul2
-BPMI_HD void xyzz_madd(xyzz &acc, const fe &x2, const fe &y2) {
-  if (xyzz_is_inf_fast(acc)) { acc.X = x2; fe_carry(acc.Y, y2); fe_set_one(acc.ZZ); fe_set_one(acc.ZZZ); return; }
-  fe nX, nY, P, R, PP, PPP, Q, t;
+// the main path in two pieces, so that the exceptional cases can be tested between them (and so that
+// tools/isa_counts.py can compile exactly this code on its own)
+BPMI_HD void xyzz_madd_pr(fe &P, fe &R, fe &nY, const xyzz &acc, const fe &x2, const fe &y2) {
+  fe nX;
   fe_neg(nX, acc.X);                                      // 2p - X: a column addend
   fe_neg(nY, acc.Y);                                      // 2p - Y: addend now, magnitude-2 factor of Y3 later
   fe_mul_add(P, x2, acc.ZZ, nX);                          // U2 - X1
   fe_mul_add(R, y2, acc.ZZZ, nY);                         // S2 - Y1
-  if (fe_maybe_zero(P)) {
-    if (fe_is_zero_tight(P)) {
-      if (fe_is_zero_tight(R)) { fe_carry(t, y2); xyzz_dbl_affine(acc, x2, t); return; }   // acc == addend
-      xyzz_set_inf(acc); return;                                                             // acc == -addend
-    }
-  }
+}
+BPMI_HD void xyzz_madd_finish(xyzz &acc, const fe &P, const fe &R, const fe &nY) {
+  fe PP, PPP, Q, t;
   fe_sqr(PP, P);
   fe_mul(PPP, P, PP);
   fe_mul(Q, acc.X, PP);
@@ -117,6 +115,19 @@ BPMI_HD void xyzz_madd(xyzz &acc, const fe &x2, const fe &y2) {
   fe_mul2(acc.Y, R, t, nY, PPP);                          // Y3 = R (Q - X3) - Y1 PPP      (3 + 2 <= 7)
   fe_mul(acc.ZZ, acc.ZZ, PP);
   fe_mul(acc.ZZZ, acc.ZZZ, PPP);
+}
+BPMI_HD void xyzz_madd(xyzz &acc, const fe &x2, const fe &y2) {
+  if (xyzz_is_inf_fast(acc)) { acc.X = x2; fe_carry(acc.Y, y2); fe_set_one(acc.ZZ); fe_set_one(acc.ZZZ); return; }
+  fe P, R, nY;
+  xyzz_madd_pr(P, R, nY, acc, x2, y2);
+  if (fe_maybe_zero(P)) {
+    if (fe_is_zero_tight(P)) {
+      fe t;
+      if (fe_is_zero_tight(R)) { fe_carry(t, y2); xyzz_dbl_affine(acc, x2, t); return; }   // acc == addend
+      xyzz_set_inf(acc); return;                                                             // acc == -addend
+    }
+  }
+  xyzz_madd_finish(acc, P, R, nY);
 }
 // acc += P for an affine point that may be the identity, optionally negated
 // The sign is data (random per entry), so it must be a SELECT, not a branch: a branch

@@ -792,3 +792,21 @@ __global__ void k_tail(const u32 *__restrict__ E, u32 W, u32 c, TailOffs to, u32
     for (int i = 0; i < 16; i++) out[i] = w16[i];
   }
 }
+
+#if defined(BPMI_ISA_PROBE)
+// tools/isa_counts.py: the main path of the mixed addition on its own (no loads from the point array, no exceptional
+// cases), so that its instructions can be counted in the ISA.  Not part of the product build.
+__global__ void __launch_bounds__(256) k_isa_probe_madd(u32 *__restrict__ accs, const u32 *__restrict__ xy) {
+  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  xyzz acc;
+  xyzz_load(acc, accs + 36ull * t);
+  fe x2, y2, P, R, nY;
+#pragma unroll
+  for (int k = 0; k < 9; k++) { x2.v[k] = xy[18ull * t + k]; y2.v[k] = xy[18ull * t + 9 + k]; }
+  asm volatile("; BPMI_MARK madd_main_begin");
+  xyzz_madd_pr(P, R, nY, acc, x2, y2);
+  xyzz_madd_finish(acc, P, R, nY);
+  asm volatile("; BPMI_MARK madd_main_end");
+  xyzz_store(accs + 36ull * t, acc);
+}
+#endif

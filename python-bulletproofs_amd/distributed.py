@@ -41,32 +41,52 @@ def all_gather_bytes(data: bytes, group=None):
 
 class ShardedMSM:
     """msm(pts_bytes, scalar_bytes, n) -> 64 bytes and fold(points_bytes, k) -> 64 bytes are
-    the two engine operations used; by default they are the HIP engine's."""
+    the two engine operations used; by default they are the HIP engine's.
+
+    On RCCL the exchange runs on its OWN stream with its own small engine context (one more bpmi_ctx on that
+    stream): the all_gather of the 64-byte partials and the fold kernel never queue behind the MSM kernels
+    that the compute engine has already enqueued for the next step, so a pipelined caller
+    (bpmi_msm_dev_enqueue / bpmi_msm_finish, bench.py) keeps both of its MSMs in flight while it combines."""
 
     def __init__(self, engine=None, group=None, msm=None, fold=None):
         if engine is None and (msm is None or fold is None):
             from .engine import default_engine
             engine = default_engine()
+        self.engine = engine
         self.msm = msm or engine.msm_bytes
         self.fold = fold or engine.ec_sum_bytes
         self.msm_dev = getattr(engine, "msm_dev", None)
-        self.fold_dev = getattr(engine, "ec_sum_dev", None) if fold is None else None
+        self.device_fold = fold is None and hasattr(engine, "ec_sum_dev")
         self.group = group
+        self._comm = None
+
+    def _comm_setup(self, world):
+        """(stream, engine on that stream, pinned 64-byte staging, device send buffer, device receive buffer)"""
+        if self._comm is None or self._comm[4].numel() != 64 * world:
+            from .engine import Engine
+            dev = torch.device("cuda", torch.cuda.current_device())
+            stream = torch.cuda.Stream(dev)
+            eng2 = Engine(device=dev.index, stream=stream.cuda_stream)
+            pin = torch.empty(64, dtype=torch.uint8).pin_memory()
+            mine = torch.empty(64, dtype=torch.uint8, device=dev)
+            flat = torch.empty(64 * world, dtype=torch.uint8, device=dev)
+            self._comm = (stream, eng2, pin, mine, flat)
+        return self._comm
 
     def combine(self, partial: bytes) -> bytes:
         """partial = this rank's 64-byte partial result -> the global result on every rank."""
         if not dist.is_initialized():
             return partial            # a lone process; with a process group -- even of one rank -- the collective runs
-        if self.fold_dev is not None and dist.get_backend(self.group) == "nccl":
-            # RCCL: gather straight into one device buffer and fold it there -- no copy of the
-            # partials back to the host and up again
+        if self.device_fold and dist.get_backend(self.group) == "nccl":
+            # RCCL: gather straight into one device buffer and fold it there -- no copy of the partials back to
+            # the host and up again; everything on the exchange stream (see the class docstring)
             world = dist.get_world_size(self.group)
-            dev = torch.device("cuda", torch.cuda.current_device())
-            mine = torch.frombuffer(bytearray(partial), dtype=torch.uint8).to(dev)
-            flat = torch.empty(world * 64, dtype=torch.uint8, device=dev)
-            dist.all_gather_into_tensor(flat, mine, group=self.group)
-            torch.cuda.current_stream().synchronize()
-            return self.fold_dev(flat, world)
+            stream, eng2, pin, mine, flat = self._comm_setup(world)
+            pin.copy_(torch.frombuffer(bytearray(partial), dtype=torch.uint8))
+            with torch.cuda.stream(stream):
+                mine.copy_(pin, non_blocking=True)
+                dist.all_gather_into_tensor(flat, mine, group=self.group)
+            return eng2.ec_sum_dev(flat, world)     # same stream: ordered behind the collective; waits for this stream only
         parts = all_gather_bytes(partial, self.group)
         return self.fold(b"".join(parts), len(parts))
 
