@@ -47,7 +47,7 @@ def main():
     print(json.dumps({
         "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python3 bench.py --steps 3 --warmup 1 "
                    "--no-cpu-baseline (two separate passes; tools/pmc_traffic.py)",
-        "workload": "MSM n=2^20, c=16, L=64",
+        "workload": "MSM n=2^20, c=16, L=86 (two-lane pipeline)",
         "correction": "MI355X_MICROARCH.md section HBM: FETCH_SIZE counts 128-B requests as 64 B for wide coalesced reads -> x2; "
                       "WRITE_SIZE exact; unit KB",
         "note": "k_accum_l0 gathers 64-B points (4 x dwordx4 per lane from one random 64-B-aligned address): for that width the "
