@@ -80,6 +80,8 @@ int bpmi_malloc(bpmi_ctx *ctx, size_t bytes, void **dptr);
 int bpmi_free(bpmi_ctx *ctx, void *dptr);
 int bpmi_upload(bpmi_ctx *ctx, void *dptr, const void *host, size_t bytes);
 int bpmi_download(bpmi_ctx *ctx, void *host, const void *dptr, size_t bytes);
+/* device -> device, enqueued on the ctx stream (ordered with the ctx's other work) */
+int bpmi_memcpy_dev(bpmi_ctx *ctx, void *d_dst, const void *d_src, size_t bytes);
 
 /* ---- multi-scalar multiplication ------------------------------------------------
  * out = sum_i scalars[i] * pts[i].
@@ -100,6 +102,9 @@ int bpmi_msm_dev(bpmi_ctx *ctx, const void *d_pts, const void *d_scalars, uint64
  * needs it fails with BPMI_E_STATE. */
 int bpmi_msm_dev_enqueue(bpmi_ctx *ctx, int slot, const void *d_pts, const void *d_scalars, uint64_t n);
 int bpmi_msm_finish(bpmi_ctx *ctx, int slot, uint8_t out[64]);
+/* One MSM over up to three (points, scalars) arrays in different device buffers (2^23 pairs in total at most):
+ * `multiexp(gs + hs + ..., a + b + ...)` without the list concatenation of src/utils/commitments.py:13. */
+int bpmi_msm_segs_dev(bpmi_ctx *ctx, uint32_t nseg, const void *const *d_pts, const void *const *d_scalars, const uint64_t *n, uint8_t out[64]);
 /* Two independent MSMs (n0, n1 <= 2^23) from host buffers, overlapped on the ctx's two lanes: pairs
  * such as A / S (rangeproof_prover.py:52,60) and T1 / T2 (:71-72) cost one round trip instead of two. */
 int bpmi_msm2(bpmi_ctx *ctx, const uint8_t *pts0, const uint8_t *scalars0, uint64_t n0, uint8_t out0[64], const uint8_t *pts1,
@@ -130,6 +135,8 @@ int bpmi_ec_sum_dev(bpmi_ctx *ctx, const void *d_pts, uint64_t n, uint8_t out[64
  * Replaces bytes_to_point / b64_to_point (src/utils/utils.py:114-131) in bulk, e.g. for
  * the 19 points of every proof of a batch that arrives as bytes. */
 int bpmi_ec_decompress_batch(bpmi_ctx *ctx, const uint8_t *comp, uint64_t n, uint8_t *out, uint8_t *ok);
+/* the same with the decoded points left on the device (d_out: n x 64 bytes of device memory), ready to be MSM input */
+int bpmi_ec_decompress_batch_dev(bpmi_ctx *ctx, const uint8_t *comp, uint64_t n, void *d_out, uint8_t *ok);
 
 /* ---- bulk scalar (mod q) operations ------------------------------------------------
  * out = sum_i a[i] * b[i] mod q       replaces inner_product (src/utils/utils.py:134-137) */
@@ -200,7 +207,8 @@ void bpmi_ipa_destroy(bpmi_ipa *st);
  * non-decreasing and end inside blobs[0 .. blobs_len), else BPMI_E_ARG):
  * parses every proof, runs the byte-level transcript checks of RangeVerifier / Verifier1 / Verifier2
  * (src/rangeproofs/rangeproof_verifier.py:42-53, src/innerproduct/inner_product_verifier.py:31-43,
- * 104-125) and computes, with the caller's random weights (4 scalars per proof, LE, in [1, q)), the
+ * 104-125) and computes, with the caller's random weights (4 scalars per proof, LE, in [1, q); or weights = NULL and
+ * a fresh random 32-byte `seed`: the weights are then derived inside, SHA-256(seed || proof index || 0..3) cut to 248 bits), the
  * scalars of the ONE multi-scalar multiplication that is the identity iff every proof verifies:
  *   v_scalars   n_proofs x values_per_proof x 32 B   for the commitments V_i (V_i,0 .. V_i,m-1)
  *   pt_scalars  n_proofs x (6 + 2k) x 32 B, k = log2 n_gens, for each proof's points in wire order
@@ -212,7 +220,7 @@ void bpmi_ipa_destroy(bpmi_ipa *st);
  * *first_bad = index of the first proof that failed parsing or a transcript check, or -1.  `threads`
  * host threads share the proofs.  The native twin of BatchRangeVerifier.add (rangeproofs/batch.py). */
 int bpmi_rp_batch_prepare(uint32_t n_gens, uint32_t values_per_proof, uint64_t n_proofs, const uint8_t *blobs, uint64_t blobs_len, const uint64_t *blob_off,
-                          const uint8_t *weights, int threads, uint8_t *v_scalars, uint8_t *pt_scalars, uint8_t *shared, uint8_t *comp_out, int64_t *first_bad);
+                          const uint8_t *weights, const uint8_t *seed, int threads, uint8_t *v_scalars, uint8_t *pt_scalars, uint8_t *shared, uint8_t *comp_out, int64_t *first_bad);
 
 /* ---- self-test hook (not part of the drop-in surface) ---------------------------------------------------
  * Runs one member of the device's field-multiplication family on n operand tuples given as RAW 9 x 29-bit

@@ -33,6 +33,9 @@ SIGNATURES = {
     "bpmi_ec_sum": (_i, [_vp, _cp, _u64, _cp]),
     "bpmi_ec_sum_dev": (_i, [_vp, _vp, _u64, _cp]),
     "bpmi_ec_decompress_batch": (_i, [_vp, _cp, _u64, _cp, _cp]),
+    "bpmi_ec_decompress_batch_dev": (_i, [_vp, _vp, _u64, _vp, _vp]),
+    "bpmi_memcpy_dev": (_i, [_vp, _vp, _vp, _sz]),
+    "bpmi_msm_segs_dev": (_i, [_vp, ctypes.c_uint32, _vp, _vp, _vp, _cp]),
     "bpmi_sc_dot": (_i, [_vp, _cp, _cp, _u64, _cp]),
     "bpmi_sc_dot_dev": (_i, [_vp, _vp, _vp, _u64, _cp]),
     "bpmi_sc_fold": (_i, [_vp, _cp, _cp, _cp, _cp, _u64, _cp]),
@@ -47,7 +50,7 @@ SIGNATURES = {
     "bpmi_ipa_fold": (_i, [_vp, _cp, _cp]),
     "bpmi_ipa_finish": (_i, [_vp, _cp, _cp]),
     "bpmi_ipa_export": (_i, [_vp, _cp, _cp, _cp, _cp]),
-    "bpmi_rp_batch_prepare": (_i, [ctypes.c_uint32, ctypes.c_uint32, _u64, _cp, _u64, ctypes.c_void_p, _cp, _i, _cp, _cp, _cp, _cp, ctypes.c_void_p]),
+    "bpmi_rp_batch_prepare": (_i, [ctypes.c_uint32, ctypes.c_uint32, _u64, _vp, _u64, ctypes.c_void_p, _cp, _cp, _i, _cp, _cp, _cp, _cp, ctypes.c_void_p]),
     "bpmi_ipa_destroy": (None, [_vp]),
     "bpmi_debug_fe_op": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _u64, _vp]),
     "bpmi_profile": (_i, [_vp, _i]),

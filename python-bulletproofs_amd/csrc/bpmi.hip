@@ -124,6 +124,7 @@ int bpmi_set_option(bpmi_ctx *ctx, const char *name, int64_t value) {
   if (!strcmp(name, "small_n")) { if (value < -1 || value > (1 << 16)) return fail(ctx, BPMI_E_ARG, "small_n must be -1 .. 65536"); ctx->opt_small = (int)value; return BPMI_OK; }
   if (!strcmp(name, "split")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "split must be 0 or 1"); ctx->opt_split = (int)value; return BPMI_OK; }
   if (!strcmp(name, "async_lanes")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "async_lanes must be 0 or 1"); ctx->opt_async_lanes = (int)value; return BPMI_OK; }
+  if (!strcmp(name, "reduce_epl")) { if (value < 0 || value > 64) return fail(ctx, BPMI_E_ARG, "reduce_epl must be 0..64"); ctx->opt_epl = (int)value; return BPMI_OK; }
   if (!strcmp(name, "chunk")) { if (value < 0 || value > 4096) return fail(ctx, BPMI_E_ARG, "chunk must be 0..4096"); ctx->opt_chunk = (int)value; return BPMI_OK; }
   if (!strcmp(name, "ipa_big_m")) { if (value < 0 || (value & (value - 1))) return fail(ctx, BPMI_E_ARG, "ipa_big_m must be 0 or a power of two"); ctx->opt_ipa_big = value; return BPMI_OK; }
   return fail(ctx, BPMI_E_ARG, std::string("unknown option ") + name);
@@ -396,6 +397,53 @@ int bpmi_ec_decompress_batch(bpmi_ctx *ctx, const uint8_t *comp, uint64_t n, uin
   HIPCHK(ctx, hipMemcpyAsync(ok, dok, n, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return BPMI_OK;
+}
+
+// the same with the points left in device memory (d_out: n x 64 B on the ctx's device), e.g. straight into the point array of
+// the batch verifier's one MSM: no copy of the decompressed points to the host and back
+int bpmi_ec_decompress_batch_dev(bpmi_ctx *ctx, const uint8_t *comp, uint64_t n, void *d_out, uint8_t *ok) {
+  if (!ctx || (n && (!comp || !d_out || !ok))) return ctx ? fail(ctx, BPMI_E_ARG, "null argument") : BPMI_E_ARG;
+  if (n > BPMI_MAX_N) return fail(ctx, BPMI_E_ARG, "n exceeds BPMI_MAX_N");
+  if (n == 0) return BPMI_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  int rc = ensure_stage_in(ctx, 34 * n + 1024);
+  if (rc) return rc;
+  char *din = (char *)ctx->stage_in, *dok = din + align_up(33 * n, 256);
+  HIPCHK(ctx, hipMemcpyAsync(din, comp, 33 * n, hipMemcpyHostToDevice, ctx->stream));
+  {
+    StageTimer t(ctx, ST_MISC);
+    hipLaunchKernelGGL(k_ec_decompress, dim3((u32)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const uint8_t *)din, (u32)n, (u32 *)d_out, (uint8_t *)dok);
+  }
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipMemcpyAsync(ok, dok, n, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return BPMI_OK;
+}
+int bpmi_memcpy_dev(bpmi_ctx *ctx, void *d_dst, const void *d_src, size_t bytes) {
+  if (!ctx || (bytes && (!d_dst || !d_src))) return ctx ? fail(ctx, BPMI_E_ARG, "null argument") : BPMI_E_ARG;
+  if (!bytes) return BPMI_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  return BPMI_OK;
+}
+// one MSM over up to three (points, scalars) arrays that live in different device buffers -- no gather / concat
+int bpmi_msm_segs_dev(bpmi_ctx *ctx, uint32_t nseg, const void *const *d_pts, const void *const *d_scalars, const uint64_t *n, uint8_t out[64]) {
+  if (!ctx || !out || (nseg && (!d_pts || !d_scalars || !n))) return ctx ? fail(ctx, BPMI_E_ARG, "null argument") : BPMI_E_ARG;
+  if (nseg > 3) return fail(ctx, BPMI_E_ARG, "at most three segments");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  Segs s = segs_init();
+  uint64_t total = 0;
+  u32 k = 0;
+  for (u32 i = 0; i < nseg; i++) {
+    if (!n[i]) continue;
+    if (!d_pts[i] || !d_scalars[i]) return fail(ctx, BPMI_E_ARG, "null segment");
+    s.pts[k] = (const u32 *)d_pts[i]; s.sc[k] = (const u32 *)d_scalars[i]; s.n[k] = (u32)n[i];
+    total += n[i];
+    k++;
+  }
+  if (total > (1ull << 23)) return fail(ctx, BPMI_E_ARG, "bpmi_msm_segs_dev takes at most 2^23 pairs in total");
+  s.total = (u32)total;
+  return msm_run(ctx, s, out);
 }
 
 // ---- scalar ops -------------------------------------------------------------------------------
@@ -874,8 +922,9 @@ void bpmi_ipa_destroy(bpmi_ipa *st) {
 
 // ---- batch verification of range proofs: host-side preparation ---------------------------------------
 int bpmi_rp_batch_prepare(uint32_t n_gens, uint32_t values_per_proof, uint64_t n_proofs, const uint8_t *blobs, uint64_t blobs_len, const uint64_t *blob_off,
-                          const uint8_t *weights, int threads, uint8_t *v_scalars, uint8_t *pt_scalars, uint8_t *shared, uint8_t *comp_out, int64_t *first_bad) {
-  if (!blobs || !blob_off || !weights || !v_scalars || !pt_scalars || !shared || !first_bad) return BPMI_E_ARG;
+                          const uint8_t *weights, const uint8_t *seed, int threads, uint8_t *v_scalars, uint8_t *pt_scalars, uint8_t *shared, uint8_t *comp_out,
+                          int64_t *first_bad) {
+  if (!blobs || !blob_off || (!weights && !seed) || !v_scalars || !pt_scalars || !shared || !first_bad) return BPMI_E_ARG;
   if (n_gens < 2 || (n_gens & (n_gens - 1)) || n_gens > 65536) return BPMI_E_ARG;
   const uint32_t m = values_per_proof;
   if (m < 1 || n_gens % m) return BPMI_E_ARG;
@@ -898,7 +947,7 @@ int bpmi_rp_batch_prepare(uint32_t n_gens, uint32_t values_per_proof, uint64_t n
     for (uint64_t a = lo; a < hi; a += 512) {
       const uint64_t b = a + 512 < hi ? a + 512 : hi;
       uint64_t bd = UINT64_MAX;
-      if (!rp::run_chunk(n_gens, k, m, blobs, blob_off, weights, a, b, pt_off.data(), v_scalars, pt_scalars, comp_out, acc[t].data(), &bd)) { bad[t] = bd; return; }
+      if (!rp::run_chunk(n_gens, k, m, blobs, blob_off, weights, a, b, pt_off.data(), v_scalars, pt_scalars, comp_out, acc[t].data(), &bd, seed)) { bad[t] = bd; return; }
     }
   };
   if (threads == 1) work(0);

@@ -49,6 +49,7 @@ struct bpmi_ctx {
   int opt_tail = 0;     // 0 auto, 1 device, 2 host
   int opt_chunk = 0;    // entries per thread in k_accum_l0, 0 = auto
   int opt_small = 0;    // largest n handled by the one-launch small-MSM kernel (0 = default, -1 = never)
+  int opt_epl = 0;           // bucket reduction stage 1: elements per lane (0 = default 16)
   int opt_async_lanes = 0;   // 1: slot 1 of the asynchronous MSM pair runs on the second lane
   bool async_lane1_ordered = false;
   int opt_split = 0;    // 1: one MSM as two window groups, one per lane (measured: +5 % at 2^20, -8 % at 2^19; off)

@@ -250,7 +250,7 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, int slot, const Segs &segs, u32 
       const u32 stride1 = N0 + N1;
       // stage 1 is throughput-bound: 16 elements per lane (measured best of 4 / 8 / 12 / 16); stage 2 is pure
       // latency: one element per lane, 16-lane butterflies
-      DigitJobs j1 = digit_jobs2(g.W, 0, g.B, g.B, s0, 0, stride1, 16);
+      DigitJobs j1 = digit_jobs2(g.W, 0, g.B, g.B, s0, 0, stride1, ctx->opt_epl > 0 ? (u32)ctx->opt_epl : 16u);
       hipLaunchKernelGGL(k_digit_sums, dim3(j1.j[j1.njobs - 1].blk0 + digit_job_blocks(j1, j1.njobs - 1)), dim3(256), 0, st, w.buckets, w.D, j1);
       // stage 2: D0 -> (D00, D01) at records [0, ..), D1 -> (D10, D11) behind them
       DigitJobs ja = digit_jobs2(g.W, 0, stride1, N0, t0, 0, 64, 1);

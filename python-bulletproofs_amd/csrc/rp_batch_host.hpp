@@ -414,8 +414,24 @@ static inline void accumulate(const Parsed &P, const Challenges &C, const Sq w[4
 }
 
 // proofs [lo, hi): returns false at the first invalid proof (its index in *bad)
+// weights == nullptr: proof g's four weights are SHA-256(seed || LE64(g) || t), t = 0..3, cut to 248 bits (< q by
+// construction; 0 is replaced by 1) -- a fresh 32-byte seed per batch makes them unpredictable to whoever made the proofs
+static inline void derive_weight(Sq &w, const uint8_t seed[32], u64 g, int t) {
+  uint8_t msg[41], d[32];
+  memcpy(msg, seed, 32);
+  for (int i = 0; i < 8; i++) msg[32 + i] = (uint8_t)(g >> (8 * i));
+  msg[40] = (uint8_t)t;
+  Sha s;
+  sha_init(s);
+  sha_update(s, msg, 41);
+  sha_final_copy(s, d);
+  d[31] = 0;
+  memcpy(w.v, d, 32);
+  if (q_is_zero(w)) w = q_small(1);
+}
 static inline bool run_chunk(uint32_t n, uint32_t k, uint32_t m, const uint8_t *blobs, const u64 *off, const uint8_t *weights, u64 lo, u64 hi,
-                             const u64 *pt_off, uint8_t *v_scalars, uint8_t *pt_scalars, uint8_t *comp_out, Sq *acc, u64 *bad) {
+                             const u64 *pt_off, uint8_t *v_scalars, uint8_t *pt_scalars, uint8_t *comp_out, Sq *acc, u64 *bad,
+                             const uint8_t *seed = nullptr) {
   const u64 cnt = hi - lo;
   std::vector<Parsed> P(cnt);
   std::vector<Challenges> C(cnt);
@@ -449,7 +465,7 @@ static inline bool run_chunk(uint32_t n, uint32_t k, uint32_t m, const uint8_t *
   for (u64 j = 0; j < cnt; j++) {
     const u64 g = lo + j;
     Sq w[4];
-    for (int t = 0; t < 4; t++) q_from_le(w[t], weights + (g * 4 + t) * 32);
+    for (int t = 0; t < 4; t++) { if (weights) q_from_le(w[t], weights + (g * 4 + t) * 32); else derive_weight(w[t], seed, g, t); }
     accumulate(P[j], C[j], w, &inv[j * per], inv[j * per + k], n, m, acc, ov.data(), outp.data(), W);
     for (uint32_t t = 0; t < m; t++) q_to_le(v_scalars + 32 * (g * m + t), ov[t]);
     for (uint32_t t = 0; t < 6 + 2 * k; t++) q_to_le(pt_scalars + 32 * (pt_off[g] + t), outp[t]);

@@ -63,6 +63,10 @@ class BatchRangeVerifier:
         self._pts = []          # per-proof points, 64-byte strings
         self._scs = []          # matching scalars (ints mod q)
         self._raw_pts, self._raw_scs, self._raw_count = [], [], 0     # merged states: already packed
+        for d_p, d_s, _ in getattr(self, "_dev_chunks", ()):          # device-resident batches of add_wire_native
+            d_p.free()
+            d_s.free()
+        self._dev_chunks = []
         self.count = 0
 
     def _weight(self):
@@ -230,19 +234,31 @@ class BatchRangeVerifier:
         for st in results:
             self.merge(st)
 
-    def add_wire_native(self, Vs, blobs, decompress=None, threads=None):
+    def add_wire_native(self, Vs, blobs, decompress=None, threads=None, offsets=None):
         """add_wire with the per-proof host work in native code (bpmi_rp_batch_prepare, csrc/
         rp_batch_host.hpp: parsing, the three transcript checks, the weighted scalars; `threads` host
         threads): ~150 us of interpreter per proof become a few microseconds, and nothing in this
         function loops over proofs in Python.  Vs: one commitment per proof, or -- aggregated proofs --
         one list of m commitments per proof (the same m for the whole call).  Same verdicts as add()
-        except that numbers in transcripts must be canonical decimal."""
+        except that numbers in transcripts must be canonical decimal.
+
+        blobs: a list of wire proofs, or ONE bytes-like object holding them back to back together with
+        `offsets` (count + 1 positions) -- how proofs arrive from a socket; saves the join of the list.
+        With the default engine the decoded points never leave the GPU: they are decompressed straight into
+        the point array of the batch's MSM (bpmi_ec_decompress_batch_dev), and the random weights are
+        derived natively from one fresh 32-byte seed."""
         import ctypes
         import os
         from itertools import accumulate
         from .. import _native
-        assert len(Vs) == len(blobs)
-        count = len(blobs)
+        if offsets is None:
+            count = len(blobs)
+            offsets = [0, *accumulate(map(len, blobs))]
+            joined = b"".join(blobs)
+        else:
+            count = len(offsets) - 1
+            joined = blobs
+        assert len(Vs) == count
         if not count:
             return
         k = self.n.bit_length() - 1
@@ -253,31 +269,52 @@ class BatchRangeVerifier:
             if any(len(v) != m for v in Vs) or m < 1 or self.n % m:
                 raise Exception("Proof invalid")
             Vs = [V for group in Vs for V in group]
+        on_device = decompress is None and self._msm is None
+        weights = seed = None
         if getattr(self, "_custom_rng", False):
             weights = b"".join(self._weight().to_bytes(32, "little") for _ in range(4 * count))
-        else:                                   # 248 random bits each: < q by construction (zero with probability 2^-248)
-            w = bytearray(os.urandom(128 * count))
-            w[31::32] = bytes(4 * count)
-            weights = bytes(w)
-        offs = (ctypes.c_uint64 * (count + 1))(0, *accumulate(map(len, blobs)))
-        v_sc = ctypes.create_string_buffer(32 * count * m)
-        p_sc = ctypes.create_string_buffer(32 * npts)
-        shared = ctypes.create_string_buffer(32 * (5 + 2 * self.n))
-        comp = ctypes.create_string_buffer(33 * npts)
+        else:
+            seed = os.urandom(32)               # four 248-bit weights per proof are derived from it natively
+        offs = (ctypes.c_uint64 * (count + 1))(*offsets)
+        bufs = getattr(self, "_native_bufs", None)
+        if bufs is None or bufs[0] != (count, m, npts):      # scratch of a previous call of the same shape is reused (no zero-fill)
+            bufs = ((count, m, npts), (ctypes.c_char * (32 * count * m))(), (ctypes.c_char * (32 * npts))(),
+                    (ctypes.c_char * (32 * (5 + 2 * self.n)))(), (ctypes.c_char * (33 * npts))())
+            self._native_bufs = bufs
+        _, v_sc, p_sc, shared, comp = bufs
         bad = ctypes.c_int64(-1)
         if threads is None:
             threads = min(32, len(os.sched_getaffinity(0)))
-        joined = b"".join(blobs)
-        rc = _native.load().bpmi_rp_batch_prepare(self.n, m, count, joined, len(joined), ctypes.cast(offs, ctypes.c_void_p), weights, threads,
+        jbuf = (ctypes.c_char * len(joined)).from_buffer_copy(joined) if isinstance(joined, memoryview) else joined
+        rc = _native.load().bpmi_rp_batch_prepare(self.n, m, count, jbuf, len(joined), ctypes.cast(offs, ctypes.c_void_p), weights, seed, threads,
                                                   v_sc, p_sc, shared, comp, ctypes.cast(ctypes.pointer(bad), ctypes.c_void_p))
         if rc != 0:
             raise Exception("bpmi_rp_batch_prepare failed (%d)" % rc)
         if bad.value >= 0:
             raise Exception("Proof invalid")
-        dec = decompress or _engine.default_engine().ec_decompress_batch_bytes
-        pts, ok = dec(comp.raw, npts)
-        if 0 in bytes(ok):
-            raise Exception("Proof invalid")
+        vbytes = b"".join([V.to_le64() for V in Vs])
+        if on_device:
+            eng = _engine.default_engine()
+            nv = count * m
+            d_pts, d_scs = eng.alloc(64 * (nv + npts)), eng.alloc(32 * (nv + npts))
+            d_pts.upload(vbytes)
+            ok = ctypes.create_string_buffer(npts)
+            eng._ck(eng.lib.bpmi_ec_decompress_batch_dev(eng.ctx, ctypes.cast(comp, ctypes.c_void_p), npts, d_pts.ptr + 64 * nv, ctypes.cast(ok, ctypes.c_void_p)))
+            if 0 in ok.raw:
+                raise Exception("Proof invalid")
+            eng._ck(eng.lib.bpmi_upload(eng.ctx, d_scs.ptr, ctypes.cast(v_sc, ctypes.c_char_p), 32 * nv))
+            eng._ck(eng.lib.bpmi_upload(eng.ctx, d_scs.ptr + 32 * nv, ctypes.cast(p_sc, ctypes.c_char_p), 32 * npts))
+            self._dev_chunks.append((d_pts, d_scs, nv + npts))
+        else:
+            dec = decompress or _engine.default_engine().ec_decompress_batch_bytes
+            pts, ok = dec(comp.raw, npts)
+            if 0 in bytes(ok):
+                raise Exception("Proof invalid")
+            self._raw_pts.append(vbytes)
+            self._raw_scs.append(v_sc.raw)
+            self._raw_pts.append(pts)
+            self._raw_scs.append(p_sc.raw)
+            self._raw_count += count * m + npts
         sh = shared.raw
         vals = [int.from_bytes(sh[32 * i: 32 * i + 32], "little") for i in range(5 + 2 * self.n)]
         self.c_g = (self.c_g + vals[0]) % Q
@@ -288,11 +325,6 @@ class BatchRangeVerifier:
         for i in range(self.n):
             self.c_gs[i] += vals[5 + i]
             self.c_hs[i] += vals[5 + self.n + i]
-        self._raw_pts.append(b"".join([V.to_le64() for V in Vs]))
-        self._raw_scs.append(v_sc.raw)
-        self._raw_pts.append(pts)
-        self._raw_scs.append(p_sc.raw)
-        self._raw_count += count * m + npts
         self.count += count
 
     def partial(self):
@@ -302,8 +334,44 @@ class BatchRangeVerifier:
         pts = self._shared_pts + b"".join(self._pts) + b"".join(self._raw_pts)
         scs = b"".join(_le32(v) for v in shared) + b"".join(_le32(v) for v in self._scs) + b"".join(self._raw_scs)
         npts = 3 + 2 * self.n + len(self._scs) + self._raw_count
+        if self._dev_chunks:
+            return self._partial_dev(pts, scs, npts)
         msm = self._msm or _engine.default_engine().msm_bytes
         return msm(pts, scs, npts)
+
+    def _partial_dev(self, pts, scs, npts):
+        """One MSM over the host-side part (shared generators, proofs added as objects) and the device-resident chunks of
+        add_wire_native: up to three segments go to bpmi_msm_segs_dev as they are; more are packed into one buffer on the device."""
+        import ctypes
+        eng = _engine.default_engine()
+        chunks = list(self._dev_chunks)
+        if len(chunks) > 2:
+            total = sum(c[2] for c in chunks)
+            big_p, big_s = eng.alloc(64 * total), eng.alloc(32 * total)
+            pos = 0
+            for d_p, d_s, cnt in chunks:
+                eng._ck(eng.lib.bpmi_memcpy_dev(eng.ctx, big_p.ptr + 64 * pos, d_p.ptr, 64 * cnt))
+                eng._ck(eng.lib.bpmi_memcpy_dev(eng.ctx, big_s.ptr + 32 * pos, d_s.ptr, 32 * cnt))
+                pos += cnt
+            eng.sync()
+            for d_p, d_s, _ in chunks:
+                d_p.free()
+                d_s.free()
+            chunks = [(big_p, big_s, total)]
+            self._dev_chunks = chunks
+        d_hp, d_hs = eng.upload(pts), eng.upload(scs)
+        segs = [(d_hp, d_hs, npts)] + chunks
+        nseg = len(segs)
+        P = (ctypes.c_void_p * nseg)(*[s[0].ptr for s in segs])
+        S = (ctypes.c_void_p * nseg)(*[s[1].ptr for s in segs])
+        N = (ctypes.c_uint64 * nseg)(*[s[2] for s in segs])
+        out = ctypes.create_string_buffer(64)
+        try:
+            eng._ck(eng.lib.bpmi_msm_segs_dev(eng.ctx, nseg, P, S, N, out))
+        finally:
+            d_hp.free()
+            d_hs.free()
+        return out.raw
 
     def verify(self, sharded=None):
         """True if every added proof is valid; raises Exception("Proof invalid") otherwise.

@@ -171,7 +171,7 @@ def test_native_prepare_checks_the_offset_table():
         v_sc, p_sc = ctypes.create_string_buffer(64), ctypes.create_string_buffer(32 * npts)
         shared, comp = ctypes.create_string_buffer(32 * (5 + 16)), ctypes.create_string_buffer(33 * npts)
         bad = ctypes.c_int64(-1)
-        return lib.bpmi_rp_batch_prepare(8, 1, 2, joined, blobs_len, ctypes.cast(offs, ctypes.c_void_p), w, 1, v_sc, p_sc, shared, comp,
+        return lib.bpmi_rp_batch_prepare(8, 1, 2, joined, blobs_len, ctypes.cast(offs, ctypes.c_void_p), w, None, 1, v_sc, p_sc, shared, comp,
                                          ctypes.cast(ctypes.pointer(bad), ctypes.c_void_p)), bad.value
 
     good = [0, len(blobs[0]), len(joined)]
@@ -181,3 +181,67 @@ def test_native_prepare_checks_the_offset_table():
     assert call([len(blobs[0]), 0, len(joined)], len(joined))[0] == -3    # not monotonic
     rc, first_bad = call([0, len(blobs[0]) - 7, len(joined)], len(joined))   # in bounds but cut in the wrong place: a bad proof, not a crash
     assert rc == 0 and first_bad == 0
+
+
+def test_native_seed_derived_weights_equal_explicit_weights():
+    """weights = NULL + seed: the weights are SHA-256(seed || LE64(proof index) || t) cut to 248 bits; passing exactly those
+    weights explicitly gives the same scalars, byte for byte."""
+    import ctypes
+    import hashlib
+    from bulletproofs_amd import _native
+    lib = _native.load()
+    b = make_batch(5, n=8)
+    blobs = [proof_to_bytes(pr) for pr in b["proofs"]]
+    joined = b"".join(blobs)
+    count, k = 5, 3
+    npts = count * (6 + 2 * k)
+    offs = [0]
+    for x in blobs:
+        offs.append(offs[-1] + len(x))
+    seed = bytes(range(32))
+    derived = b""
+    for g in range(count):
+        for t in range(4):
+            d = bytearray(hashlib.sha256(seed + g.to_bytes(8, "little") + bytes([t])).digest())
+            d[31] = 0
+            derived += bytes(d)
+
+    def call(weights, sd):
+        o = (ctypes.c_uint64 * (count + 1))(*offs)
+        v_sc, p_sc = ctypes.create_string_buffer(32 * count), ctypes.create_string_buffer(32 * npts)
+        shared, comp = ctypes.create_string_buffer(32 * (5 + 16)), ctypes.create_string_buffer(33 * npts)
+        bad = ctypes.c_int64(-1)
+        rc = lib.bpmi_rp_batch_prepare(8, 1, count, joined, len(joined), ctypes.cast(o, ctypes.c_void_p), weights, sd, 2, v_sc, p_sc, shared, comp,
+                                       ctypes.cast(ctypes.pointer(bad), ctypes.c_void_p))
+        return rc, bad.value, v_sc.raw, p_sc.raw, shared.raw, comp.raw
+
+    a1 = call(None, seed)
+    a2 = call(derived, None)
+    assert a1[0] == 0 and a1[1] == -1 and a1 == a2
+    assert call(None, bytes(32))[2] != a1[2]                      # another seed, other weights
+    assert call(None, None)[0] == -3                              # neither weights nor seed
+
+
+def test_add_wire_native_accepts_one_buffer_with_offsets():
+    b = make_batch(4, n=8)
+    blobs = [proof_to_bytes(pr) for pr in b["proofs"]]
+    offs = [0]
+    for x in blobs:
+        offs.append(offs[-1] + len(x))
+    r = random.Random(9)
+    one = BatchRangeVerifier(b["g"], b["h"], b["gs"], b["hs"], b["u"], msm=oracle_msm, rng=lambda: r.getrandbits(320))
+    one.add_wire_native(b["Vs"], b"".join(blobs), decompress=oracle_decompress, threads=2, offsets=offs)
+    r = random.Random(9)
+    lst = BatchRangeVerifier(b["g"], b["h"], b["gs"], b["hs"], b["u"], msm=oracle_msm, rng=lambda: r.getrandbits(320))
+    lst.add_wire_native(b["Vs"], blobs, decompress=oracle_decompress, threads=2)
+    assert one.state() == lst.state() and one.verify() is True
+    # default weights (native, seed-derived): still a valid batch; a corrupted proof still fails
+    nat = BatchRangeVerifier(b["g"], b["h"], b["gs"], b["hs"], b["u"], msm=oracle_msm)
+    nat.add_wire_native(b["Vs"], blobs, decompress=oracle_decompress, threads=2)
+    assert nat.verify() is True
+    bad = bytearray(blobs[2])
+    bad[40] ^= 1
+    nat = BatchRangeVerifier(b["g"], b["h"], b["gs"], b["hs"], b["u"], msm=oracle_msm)
+    with pytest.raises(Exception, match="Proof invalid"):
+        nat.add_wire_native(b["Vs"], blobs[:2] + [bytes(bad)] + blobs[3:], decompress=oracle_decompress, threads=2)
+        nat.verify()

@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Where the milliseconds of one 2^14-proof batch verification go (config C5, one GPU): wall time of each step of
+BatchRangeVerifier.add_wire_native + verify."""
+import hashlib
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+import bulletproofs_amd  # noqa: E402,F401
+from bulletproofs_amd.ec import secp256k1  # noqa: E402
+from bulletproofs_amd.engine import default_engine  # noqa: E402
+from bulletproofs_amd.rangeproofs import BatchRangeVerifier, NIRangeProver  # noqa: E402
+from bulletproofs_amd.rangeproofs.codec import proof_to_bytes  # noqa: E402
+from bulletproofs_amd.utils import ModP, commitment, elliptic_hash, mod_hash  # noqa: E402
+
+Q = secp256k1.q
+eng = default_engine()
+n, total, distinct = 64, 1 << 14, 64
+gs = [elliptic_hash(str(i).encode() + b"gs") for i in range(n)]
+hs = [elliptic_hash(str(i).encode() + b"hs") for i in range(n)]
+g, h, u = elliptic_hash(b"g"), elliptic_hash(b"h"), elliptic_hash(b"u")
+Vd, wire = [], []
+for j in range(distinct):
+    v = ModP(int.from_bytes(hashlib.sha256(b"v%d" % j).digest()[:8], "big"), Q)
+    gamma = mod_hash(b"gamma%d" % j, Q)
+    Vd.append(commitment(g, h, v, gamma))
+    wire.append(proof_to_bytes(NIRangeProver(v, n, g, h, gs, hs, gamma, u, secp256k1, b"seed%d" % j).prove()))
+Vs = [Vd[k % distinct] for k in range(total)]
+blobs = [wire[k % distinct] for k in range(total)]
+threads = min(32, len(os.sched_getaffinity(0)))
+from itertools import accumulate
+wire_buf = b"".join(blobs)
+wire_off = [0, *accumulate(map(len, blobs))]
+import cProfile
+import pstats
+for rep in range(3):
+    bv = BatchRangeVerifier(g, h, gs, hs, u)
+    t0 = time.perf_counter()
+    if rep == 2:
+        pr = cProfile.Profile()
+        pr.enable()
+    bv.add_wire_native(Vs, wire_buf, threads=threads, offsets=wire_off)
+    t1 = time.perf_counter()
+    ok = bv.verify()
+    t2 = time.perf_counter()
+    if rep == 2:
+        pr.disable()
+    bv.reset()
+    print("rep %d: add_wire_native %.2f ms, verify %.2f ms, ok=%s, threads=%d" % (rep, (t1 - t0) * 1e3, (t2 - t1) * 1e3, ok, threads))
+pstats.Stats(pr).sort_stats("cumulative").print_stats(18)

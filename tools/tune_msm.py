@@ -17,14 +17,17 @@ def device_points(n, seed):
     eng._ck(eng.lib.bpmi_ec_mul_batch_dev(eng.ctx, d_G.ptr, d_k.ptr, n, d_p.ptr)); eng.sync(); d_G.free(); d_k.free()
     return d_p
 
+CS = [int(v) for v in os.environ.get("TUNE_C", "0,8,10,13,16").split(",")]
+CHUNKS = [int(v) for v in os.environ.get("TUNE_CHUNK", "16,32,64").split(",")]
+EPLS = [int(v) for v in os.environ.get("TUNE_EPL", "0").split(",")]
 for logn in [int(a) for a in sys.argv[1:]] or [20]:
     n = 1 << logn
     d_p, d_s = device_points(n, 1), eng.upload(sha_scalars(n, 2))
     ref = None
-    for c in (0, 8, 10, 13, 16):
+    for c, chunk, epl in [(c, ch, e) for c in CS for ch in CHUNKS for e in EPLS]:
         if c and not (4 <= c <= 16): continue
-        for chunk in (16, 32, 64):
-            eng.set_option("window_bits", c); eng.set_option("chunk", chunk)
+        if True:
+            eng.set_option("window_bits", c); eng.set_option("chunk", chunk); eng.set_option("reduce_epl", epl)
             r = eng.msm_dev(d_p, d_s, n)
             ref = ref or r
             assert r == ref
@@ -34,5 +37,5 @@ for logn in [int(a) for a in sys.argv[1:]] or [20]:
             dt = (time.perf_counter() - t) / reps
             pr = eng.profile_read(); eng.profile(False)
             st = {k.replace("msm_", ""): round(v[0] / v[1], 3) for k, v in pr.items() if v[1]}
-            print("n=2^%d c=%2d chunk=%3d  %.3f ms  %.3e pairs/s  %s" % (logn, c, chunk, dt * 1e3, n / dt, st), flush=True)
+            print("n=2^%d c=%2d chunk=%3d epl=%2d  %.3f ms  %.3e pairs/s  %s" % (logn, c, chunk, epl, dt * 1e3, n / dt, st), flush=True)
     d_p.free(); d_s.free()
