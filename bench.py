@@ -130,7 +130,10 @@ def main():
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
     backend = None
-    if world > 1:
+    # BENCH_FORCE_DIST=1: initialise the process group even for ONE rank, so that a single-GPU box exercises the RCCL branch
+    # of every collective this file uses (tests/test_gpu_dist.py)
+    use_dist = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # RCCL ("nccl") is the backend of record; BENCH_DIST_BACKEND=gloo exists only to dry-run the N > 1
@@ -190,7 +193,7 @@ def main():
     sharded = ShardedMSM(engine=eng)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -233,7 +236,7 @@ def main():
     eng.profile(False)
 
     n_ranks_seen = 1
-    if world > 1:
+    if use_dist:
         cpu_side = dist.get_backend() != "nccl"
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if cpu_side else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -325,7 +328,7 @@ def main():
     barrier()
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
@@ -399,14 +402,14 @@ def extra_c5(eng, world, rank, dev, log_batch=14, distinct=64):
             buf = bytes(bad)
         try:
             bv.add_wire_native(Vs_in, buf, threads=threads, offsets=wire_off)
-            ok = bool(bv.verify(sharded=sharded if world > 1 else None))
+            ok = bool(bv.verify(sharded=sharded if dist.is_initialized() else None))
         except Exception:
             ok = False
         bv.reset()            # frees the batch's device buffers
         return ok
 
     one_batch()                                        # warm (workspaces, pinned buffers)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize(dev)
     eng.profile(1)
@@ -414,14 +417,14 @@ def extra_c5(eng, world, rank, dev, log_batch=14, distinct=64):
     reps = 3
     t0 = time.perf_counter()
     oks = [one_batch() for _ in range(reps)]
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize(dev)
     elapsed = (time.perf_counter() - t0) / reps
     prof = eng.profile_read()
     eng.profile(False)
     rejected = not one_batch(corrupt=True)
-    if world > 1:
+    if dist.is_initialized():
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if dist.get_backend() != "nccl" else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -485,7 +488,7 @@ def extra_c3(eng, world, rank, dev, logn=20):
         return dt, pr
 
     prove(False)                         # warm
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     times = []
     for _ in range(3):
@@ -495,7 +498,7 @@ def extra_c3(eng, world, rank, dev, logn=20):
     prof = eng.profile_read()
     eng.profile(False)
     secs = min(times)
-    if world > 1:
+    if dist.is_initialized():
         tt = torch.tensor([secs], dtype=torch.float64, device="cpu" if dist.get_backend() != "nccl" else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         secs = float(tt.item())

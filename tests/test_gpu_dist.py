@@ -41,3 +41,19 @@ def test_bench_self_launches_its_ranks():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     assert out["scaling"] == "strong" and out["result_ok"] is True and out["config"]["pairs_per_gpu"] == 1 << 15
+
+
+def test_bench_collectives_on_rccl_with_one_rank():
+    """bench.py under torch.distributed.run with ONE rank and BENCH_FORCE_DIST=1: every collective of the N > 1 path (the
+    all_gather of partials on the exchange stream + device fold, the MAX all_reduce of the elapsed time, the gather of the
+    known-answer terms, the barriers, the sharded batch verifier's combine) runs on the real RCCL backend."""
+    env = dict(os.environ, BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2", "--logn", "18",
+           "--soak-seconds", "0", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["dist_backend"] == "nccl" and out["n_ranks_seen"] == 1 and out["result_ok"] is True
+    assert out["extra"]["C5_batch_verify"].get("accepted") is True and out["extra"]["C5_batch_verify"]["corrupted_batch_rejected"] is True
+    assert out["extra"]["C3_ipa_prover"].get("rounds") == 20

@@ -17,6 +17,9 @@ from bulletproofs_amd.utils import Transcript, elliptic_hash  # noqa: E402
 Q = secp256k1.q
 eng = default_engine()
 logn = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+for kv in sys.argv[2:]:
+    name, value = kv.split("=")
+    eng.set_option(name, int(value))
 n = 1 << logn
 
 
