@@ -203,6 +203,7 @@ int bpmi_msm_dev_enqueue(bpmi_ctx *ctx, int slot, const void *d_pts, const void 
   if (slot < 0 || slot > 1) return fail(ctx, BPMI_E_ARG, "slot must be 0 or 1");
   if (n > (1ull << 23)) return fail(ctx, BPMI_E_ARG, "bpmi_msm_dev_enqueue takes at most 2^23 pairs (use bpmi_msm_dev)");
   if (ctx->opt_split) return fail(ctx, BPMI_E_STATE, "option split is not available with the asynchronous entry points");
+  if (ctx->pend[slot].async) return fail(ctx, BPMI_E_STATE, "an MSM is still pending in this slot (bpmi_msm_finish it first)");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   Segs s = segs_init();
   s.pts[0] = (const u32 *)d_pts; s.sc[0] = (const u32 *)d_scalars; s.n[0] = (u32)n; s.total = (u32)n;

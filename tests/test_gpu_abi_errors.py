@@ -91,3 +91,37 @@ def test_c_program_through_the_abi_only(tmp_path):
                            "-o", exe, os.path.join(libdir, "libbpmi.so"), "-Wl,-rpath," + libdir, "-Wl,--allow-shlib-undefined"])
     r = subprocess.run([exe, "16"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "known-answer ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_async_pair_state_machine(gp):
+    """bpmi_msm_dev_enqueue / bpmi_msm_finish: slots, state errors, and the synchronous entry points while a slot is pending."""
+    eng = gp.engine()
+    lib, ctx = eng.lib, eng.ctx
+    pts, _ = gp.rand_points(6000, 91)
+    pb, sb = cbind.pack_points(pts), cbind.pack_scalars(list(range(1, 6001)))
+    d_p, d_s = eng.upload(pb), eng.upload(sb)
+    out = ctypes.create_string_buffer(64)
+    want = cbind.msm_bytes(pb, sb, 6000)
+    assert lib.bpmi_msm_finish(ctx, 0, out) == -5                       # nothing enqueued
+    assert lib.bpmi_msm_dev_enqueue(ctx, 2, d_p.ptr, d_s.ptr, 10) == -3   # no such slot
+    assert lib.bpmi_msm_dev_enqueue(ctx, 0, d_p.ptr, d_s.ptr, (1 << 23) + 1) == -3
+    assert lib.bpmi_msm_dev_enqueue(ctx, 0, d_p.ptr, d_s.ptr, 6000) == 0
+    assert lib.bpmi_msm_dev_enqueue(ctx, 0, d_p.ptr, d_s.ptr, 6000) == -5      # slot still pending
+    assert lib.bpmi_msm_dev(ctx, d_p.ptr, d_s.ptr, 6000, out) == -5            # the synchronous call needs slot 0
+    assert b"pending" in lib.bpmi_last_error(ctx)
+    assert lib.bpmi_msm_dev_enqueue(ctx, 1, d_p.ptr, d_s.ptr, 0) == 0          # n = 0 in the other slot
+    assert lib.bpmi_msm_finish(ctx, 0, out) == 0 and out.raw == want
+    assert lib.bpmi_msm_finish(ctx, 1, out) == 0 and out.raw == bytes(64)
+    assert lib.bpmi_msm_finish(ctx, 1, out) == -5
+    assert lib.bpmi_msm_dev(ctx, d_p.ptr, d_s.ptr, 6000, out) == 0 and out.raw == want
+    # three device segments in one MSM; argument errors
+    P = (ctypes.c_void_p * 3)(d_p.ptr, d_p.ptr + 64 * 1000, d_p.ptr + 64 * 2500)
+    S = (ctypes.c_void_p * 3)(d_s.ptr, d_s.ptr + 32 * 1000, d_s.ptr + 32 * 2500)
+    N = (ctypes.c_uint64 * 3)(1000, 1500, 3500)
+    assert lib.bpmi_msm_segs_dev(ctx, 3, P, S, N, out) == 0 and out.raw == want
+    N0 = (ctypes.c_uint64 * 3)(1000, 0, 0)
+    assert lib.bpmi_msm_segs_dev(ctx, 3, P, S, N0, out) == 0 and out.raw == cbind.msm_bytes(pb[:64000], sb[:32000], 1000)
+    assert lib.bpmi_msm_segs_dev(ctx, 4, P, S, N, out) == -3
+    assert lib.bpmi_msm_segs_dev(ctx, 0, None, None, None, out) == 0 and out.raw == bytes(64)
+    d_p.free()
+    d_s.free()
