@@ -206,12 +206,20 @@ def main():
             return res
         # two-deep pipeline: MSM j + 1 is queued before MSM j is finished (host tail) and combined
         # (N > 1: ONE all_gather of the 64-byte partials + bpmi_ec_sum fold on every rank)
+        # the exchange of step j is started (queued on its own stream) and collected one iteration later, so the host
+        # never waits for the fold kernel before it has fed the GPU its next MSM
         if k:
             eng.msm_dev_enqueue(0, d_pts, d_sc, n)
+        pending = None
         for j in range(k):
             if j + 1 < k:
                 eng.msm_dev_enqueue((j + 1) & 1, d_pts, d_sc, n)
-            res = sharded.combine(eng.msm_finish(j & 1))
+            part = eng.msm_finish(j & 1)
+            if pending is not None:
+                res = sharded.combine_wait(pending)
+            pending = sharded.combine_begin(part)
+        if pending is not None:
+            res = sharded.combine_wait(pending)
         return res
 
     result = run_steps(args.warmup)

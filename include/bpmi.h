@@ -128,6 +128,8 @@ int bpmi_ec_lincomb2_batch_dev(bpmi_ctx *ctx, const void *d_p1, const void *d_p2
 int bpmi_ec_sum(bpmi_ctx *ctx, const uint8_t *pts, uint64_t n, uint8_t out[64]);
 /* the same for points already in device memory (e.g. the receive buffer of an all_gather) */
 int bpmi_ec_sum_dev(bpmi_ctx *ctx, const void *d_pts, uint64_t n, uint8_t out[64]);
+/* ... and without the wait: the sum goes to d_out (64 bytes of device memory), ordered on the ctx stream; read it after bpmi_sync */
+int bpmi_ec_sum_dev_enqueue(bpmi_ctx *ctx, const void *d_pts, uint64_t n, void *d_out);
 
 /* out[i] = the point encoded by comp[33*i .. 33*i+33) in SEC1 compressed form (0x02 | 0x03,
  * then x big-endian; 33 zero bytes = identity); ok[i] = 1 when the encoding is valid

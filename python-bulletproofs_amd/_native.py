@@ -32,6 +32,7 @@ SIGNATURES = {
     "bpmi_ec_lincomb2_batch_dev": (_i, [_vp, _vp, _vp, _cp, _cp, _u64, _vp]),
     "bpmi_ec_sum": (_i, [_vp, _cp, _u64, _cp]),
     "bpmi_ec_sum_dev": (_i, [_vp, _vp, _u64, _cp]),
+    "bpmi_ec_sum_dev_enqueue": (_i, [_vp, _vp, _u64, _vp]),
     "bpmi_ec_decompress_batch": (_i, [_vp, _cp, _u64, _cp, _cp]),
     "bpmi_ec_decompress_batch_dev": (_i, [_vp, _vp, _u64, _vp, _vp]),
     "bpmi_memcpy_dev": (_i, [_vp, _vp, _vp, _sz]),

@@ -380,6 +380,21 @@ int bpmi_ec_sum_dev(bpmi_ctx *ctx, const void *d_pts, uint64_t n, uint8_t out[64
   return BPMI_OK;
 }
 
+// the fold without the wait: the canonical affine sum is written to d_out (64 B of device memory) by a kernel queued on the ctx
+// stream; the caller reads it after bpmi_sync / bpmi_download (a pipelined caller overlaps the fold of step j with step j + 1)
+int bpmi_ec_sum_dev_enqueue(bpmi_ctx *ctx, const void *d_pts, uint64_t n, void *d_out) {
+  if (!ctx || !d_out || (n && !d_pts)) return ctx ? fail(ctx, BPMI_E_ARG, "null argument") : BPMI_E_ARG;
+  if (n > BPMI_MAX_N) return fail(ctx, BPMI_E_ARG, "n exceeds BPMI_MAX_N");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  if (n == 0) { HIPCHK(ctx, hipMemsetAsync(d_out, 0, 64, ctx->stream)); return BPMI_OK; }
+  {
+    StageTimer t(ctx, ST_MISC);
+    hipLaunchKernelGGL(k_ec_sum, dim3(1), dim3(256), 0, ctx->stream, (const u32 *)d_pts, (u32)n, (u32 *)d_out);
+  }
+  HIPCHK(ctx, hipGetLastError());
+  return BPMI_OK;
+}
+
 int bpmi_ec_decompress_batch(bpmi_ctx *ctx, const uint8_t *comp, uint64_t n, uint8_t *out, uint8_t *ok) {
   if (!ctx || (n && (!comp || !out || !ok))) return ctx ? fail(ctx, BPMI_E_ARG, "null argument") : BPMI_E_ARG;
   if (n > BPMI_MAX_N) return fail(ctx, BPMI_E_ARG, "n exceeds BPMI_MAX_N");

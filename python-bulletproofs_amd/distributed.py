@@ -70,7 +70,7 @@ class ShardedMSM:
             pin = torch.empty(64, dtype=torch.uint8).pin_memory()
             mine = torch.empty(64, dtype=torch.uint8, device=dev)
             flat = torch.empty(64 * world, dtype=torch.uint8, device=dev)
-            self._comm = (stream, eng2, pin, mine, flat)
+            self._comm = (stream, eng2, pin, mine, flat, torch.empty(64, dtype=torch.uint8, device=dev), torch.empty(64, dtype=torch.uint8).pin_memory())
         return self._comm
 
     def combine(self, partial: bytes) -> bytes:
@@ -80,15 +80,36 @@ class ShardedMSM:
         if self.device_fold and dist.get_backend(self.group) == "nccl":
             # RCCL: gather straight into one device buffer and fold it there -- no copy of the partials back to
             # the host and up again; everything on the exchange stream (see the class docstring)
+            return self.combine_wait(self.combine_begin(partial))
+        parts = all_gather_bytes(partial, self.group)
+        return self.fold(b"".join(parts), len(parts))
+
+    def combine_begin(self, partial: bytes):
+        """Start combine() and return a handle for combine_wait(): on RCCL the copy up, the all_gather and the fold kernel
+        are only QUEUED on the exchange stream, so a pipelined caller can enqueue its next MSM before it waits -- the fold
+        kernel may have to wait for the running accumulate kernel to free a wave slot, and nobody should wait with it."""
+        if not dist.is_initialized():
+            return ("done", partial)
+        if self.device_fold and dist.get_backend(self.group) == "nccl":
             world = dist.get_world_size(self.group)
-            stream, eng2, pin, mine, flat = self._comm_setup(world)
+            stream, eng2, pin, mine, flat, d_out, pin_out = self._comm_setup(world)
             pin.copy_(torch.frombuffer(bytearray(partial), dtype=torch.uint8))
             with torch.cuda.stream(stream):
                 mine.copy_(pin, non_blocking=True)
                 dist.all_gather_into_tensor(flat, mine, group=self.group)
-            return eng2.ec_sum_dev(flat, world)     # same stream: ordered behind the collective; waits for this stream only
-        parts = all_gather_bytes(partial, self.group)
-        return self.fold(b"".join(parts), len(parts))
+                # same stream: the fold is ordered behind the collective
+                eng2._ck(eng2.lib.bpmi_ec_sum_dev_enqueue(eng2.ctx, flat.data_ptr(), world, d_out.data_ptr()))
+                pin_out.copy_(d_out, non_blocking=True)
+            return ("rccl", None)
+        return ("done", self.combine(partial))
+
+    def combine_wait(self, handle) -> bytes:
+        kind, value = handle
+        if kind == "done":
+            return value
+        stream, pin_out = self._comm[0], self._comm[6]
+        stream.synchronize()
+        return bytes(pin_out.numpy().tobytes())
 
     def multiexp_replicated(self, pts: bytes, scalars: bytes, n: int) -> bytes:
         """Every rank holds the full input; each computes its shard, then combine()."""
