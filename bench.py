@@ -42,6 +42,11 @@ import time
 REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
+# The two MSM lanes must sit on DIFFERENT hardware queues to overlap.  HIP maps streams onto GPU_MAX_HW_QUEUES (default 4)
+# queues round-robin in creation order; once RCCL and the framework have created theirs, both lanes can land on one queue and
+# the pipeline degrades to the one-lane rate (measured: 1.27 ms per step against 1.13 with 8 queues, profiles/r02_hw_queues.txt).
+# Must be set before the HIP runtime initialises, i.e. before torch is imported.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 Q = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
@@ -197,6 +202,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    host_t = [0.0, 0.0, 0.0, 0.0, 0]      # host seconds in: enqueue, finish (wait + tail), combine_wait, combine_begin; steps
+
     def run_steps(k):
         """k MSM steps; every step's global result is complete when this returns."""
         res = None
@@ -212,17 +219,24 @@ def main():
             eng.msm_dev_enqueue(0, d_pts, d_sc, n)
         pending = None
         for j in range(k):
+            ta = time.perf_counter()
             if j + 1 < k:
                 eng.msm_dev_enqueue((j + 1) & 1, d_pts, d_sc, n)
+            tb = time.perf_counter()
             part = eng.msm_finish(j & 1)
+            tc = time.perf_counter()
             if pending is not None:
                 res = sharded.combine_wait(pending)
+            td = time.perf_counter()
             pending = sharded.combine_begin(part)
+            te = time.perf_counter()
+            host_t[0] += tb - ta; host_t[1] += tc - tb; host_t[2] += td - tc; host_t[3] += te - td; host_t[4] += 1
         if pending is not None:
             res = sharded.combine_wait(pending)
         return res
 
     result = run_steps(args.warmup)
+    host_t[:] = [0.0, 0.0, 0.0, 0.0, 0]
     eng.profile(2)              # HIP events around the dominant kernel only: each recorded event is a ~10 us bubble
     eng.profile_reset()
     barrier()
@@ -233,6 +247,8 @@ def main():
     ev1.record(stream)
     barrier()
     elapsed = time.perf_counter() - t0
+    host_ms = {"enqueue": host_t[0], "finish_wait_and_tail": host_t[1], "combine_wait": host_t[2], "combine_begin": host_t[3]}
+    host_ms = {k_: round(v / max(host_t[4], 1) * 1e3, 4) for k_, v in host_ms.items()}
     ev_ms = ev0.elapsed_time(ev1)
     prof = eng.profile_read()
     # per-stage breakdown: a few extra, UNTIMED synchronous steps with events around every stage
@@ -305,6 +321,7 @@ def main():
                          "peak_source": "profiles/r01_fe_microbench.txt (V8: the product's own fe_mul in isolation; NOT a hardware peak)"},
         "stage_ms_per_msm": stages,
         "hip_event_ms_per_step": ev_ms / args.steps,
+        "host_ms_per_step": host_ms,
         "input_setup_s": round(t_in, 2),
         "result_x_lo": result[:8].hex(),
     }
