@@ -124,6 +124,7 @@ int bpmi_set_option(bpmi_ctx *ctx, const char *name, int64_t value) {
   if (!strcmp(name, "small_n")) { if (value < -1 || value > (1 << 16)) return fail(ctx, BPMI_E_ARG, "small_n must be -1 .. 65536"); ctx->opt_small = (int)value; return BPMI_OK; }
   if (!strcmp(name, "split")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "split must be 0 or 1"); ctx->opt_split = (int)value; return BPMI_OK; }
   if (!strcmp(name, "async_lanes")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "async_lanes must be 0 or 1"); ctx->opt_async_lanes = (int)value; return BPMI_OK; }
+  if (!strcmp(name, "fold_wnaf")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "fold_wnaf must be 0 or 1"); ctx->opt_fold_wnaf = (int)value; return BPMI_OK; }
   if (!strcmp(name, "pair_chain")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "pair_chain must be 0 or 1"); ctx->opt_pair_chain = (int)value; return BPMI_OK; }
   if (!strcmp(name, "reduce_epl")) { if (value < 0 || value > 64) return fail(ctx, BPMI_E_ARG, "reduce_epl must be 0..64"); ctx->opt_epl = (int)value; return BPMI_OK; }
   if (!strcmp(name, "chunk")) { if (value < 0 || value > 4096) return fail(ctx, BPMI_E_ARG, "chunk must be 0..4096"); ctx->opt_chunk = (int)value; return BPMI_OK; }
@@ -633,6 +634,7 @@ struct bpmi_ipa {
   NafK *nafk[2];        // device, NAF tables for the multifold kernel
   u32 *hscale_buf;      // device, room for n0 scalars
   u32 *hscale;          // device, optional per-base scale of the h generators (n0 scalars) or nullptr
+  void *wtab;           // tables + scratch of the width-4 NAF generator fold (allocated with the state when it will fold), or nullptr
   void *block;          // one allocation
   std::vector<sc> hcg, hch;   // host copies of the coefficient tables while 2^d <= 16
   bool lr_done;
@@ -686,6 +688,14 @@ static int ipa_alloc(bpmi_ctx *ctx, uint64_t n, bpmi_ipa **out) {
   sc o; memset(&o, 0, sizeof(o)); o.v[0] = 1;
   st->hcg.assign(1, o); st->hch.assign(1, o);
   st->hscale_buf = hscale_buf;
+  st->wtab = nullptr;
+  if (ctx->opt_fold_wnaf && n >= st->big_m && n >= 256) {
+    // 3 affine multiples (216 B) per base point and 432 B of scratch per point, for g and h, plus the two digit tables;
+    // if it does not fit the fold uses the plain NAF ladder
+    const uint64_t nthr = (n + ODDMUL_PER_THREAD - 1) / ODDMUL_PER_THREAD;
+    const size_t tab_bytes = align_up(3ull * n * 72, 256), scr_bytes = align_up(2ull * nthr * ODDMUL_PER_THREAD * 3 * 144, 256);
+    if (hipMalloc(&st->wtab, 2 * tab_bytes + scr_bytes + 2 * align_up(sizeof(WnafK), 256)) != hipSuccess) { (void)hipGetLastError(); st->wtab = nullptr; }
+  }
   *out = st;
   return BPMI_OK;
 }
@@ -706,7 +716,7 @@ int bpmi_ipa_create_dev(bpmi_ctx *ctx, const void *d_g, const void *d_h, const v
   if (e == hipSuccess) e = hipMemcpyAsync(st->b, d_b, 32 * n, hipMemcpyDeviceToDevice, s);
   if (e == hipSuccess) e = hipMemcpyAsync(st->u, u, 64, hipMemcpyHostToDevice, s);
   if (e == hipSuccess) e = hipStreamSynchronize(s);
-  if (e != hipSuccess) { (void)hipFree(st->block); delete st; return fail(ctx, BPMI_E_HIP, std::string("ipa_create copy: ") + hipGetErrorString(e)); }
+  if (e != hipSuccess) { (void)hipFree(st->block); if (st->wtab) (void)hipFree(st->wtab); delete st; return fail(ctx, BPMI_E_HIP, std::string("ipa_create copy: ") + hipGetErrorString(e)); }
   *out = st;
   return BPMI_OK;
 }
@@ -725,7 +735,7 @@ int bpmi_ipa_create(bpmi_ctx *ctx, const uint8_t *g, const uint8_t *h, const uin
   if (e == hipSuccess) e = hipMemcpyAsync(st->b, b, 32 * n, hipMemcpyHostToDevice, s);
   if (e == hipSuccess) e = hipMemcpyAsync(st->u, u, 64, hipMemcpyHostToDevice, s);
   if (e == hipSuccess) e = hipStreamSynchronize(s);
-  if (e != hipSuccess) { (void)hipFree(st->block); delete st; return fail(ctx, BPMI_E_HIP, std::string("ipa_create copy: ") + hipGetErrorString(e)); }
+  if (e != hipSuccess) { (void)hipFree(st->block); if (st->wtab) (void)hipFree(st->wtab); delete st; return fail(ctx, BPMI_E_HIP, std::string("ipa_create copy: ") + hipGetErrorString(e)); }
   *out = st;
   return BPMI_OK;
 }
@@ -851,21 +861,52 @@ int bpmi_ipa_fold(bpmi_ipa *st, const uint8_t x[32], const uint8_t xinv[32]) {
   if (st->M >= st->big_m && st->d == IPA_BIG_D && st->n > 1) {
     // materialise the 16-way folded generators: out[i] = sum_t coef[t] * base[i + t*m]
     const u32 K2 = 1u << st->d;
-    NafK ha, hb;
-    memset(&ha, 0, sizeof(ha)); memset(&hb, 0, sizeof(hb));
-    ha.top = hb.top = -1;
-    for (u32 t = 0; t < K2; t++) {
-      host_naf((const uint8_t *)st->hcg[t].v, ha.nz[t], ha.sg[t], ha.top);
-      host_naf((const uint8_t *)st->hch[t].v, hb.nz[t], hb.sg[t], hb.top);
-    }
-    HIPCHK(ctx, hipMemcpyAsync(st->nafk[0], &ha, sizeof(NafK), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(st->nafk[1], &hb, sizeof(NafK), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));     // ha / hb are stack objects
     MultifoldJob ja = {st->g, st->g2}, jb = {st->h, st->h2};
-    {
-      StageTimer t(ctx, ST_LINCOMB2);
-      hipLaunchKernelGGL(k_ec_multifold, dim3((u32)((2 * st->n + 255) / 256)), dim3(256), 0, ctx->stream, ja, jb, st->nafk[0], st->nafk[1],
-                         (u32)st->n, K2);
+    const uint64_t npts = st->M;
+    void *wtab = (ctx->opt_fold_wnaf && npts == st->n0) ? st->wtab : nullptr;      // sized for the first fold of the state
+    if (wtab) {
+      // width-4 NAF over affine tables of 3P, 5P, 7P (transient: 2 x 216 B + 2 x 432 B of scratch per base point)
+      const uint64_t nthr = (npts + ODDMUL_PER_THREAD - 1) / ODDMUL_PER_THREAD;
+      const size_t tab_bytes = align_up(3ull * npts * 72, 256), scr_bytes = align_up(2ull * nthr * ODDMUL_PER_THREAD * 3 * 144, 256),
+                   wn_bytes = align_up(sizeof(WnafK), 256);
+      {
+        u32 *tab_a = (u32 *)wtab, *tab_b = (u32 *)((char *)wtab + tab_bytes), *scr = (u32 *)((char *)wtab + 2 * tab_bytes);
+        WnafK *dwa = (WnafK *)((char *)wtab + 2 * tab_bytes + scr_bytes), *dwb = (WnafK *)((char *)dwa + wn_bytes);
+        static thread_local WnafK hwa, hwb;
+        memset(&hwa, 0, sizeof(hwa)); memset(&hwb, 0, sizeof(hwb));
+        hwa.top = hwb.top = -1;
+        for (u32 t = 0; t < K2; t++) {
+          host_wnaf4((const uint8_t *)st->hcg[t].v, hwa.dg[t], hwa.top);
+          host_wnaf4((const uint8_t *)st->hch[t].v, hwb.dg[t], hwb.top);
+        }
+        HIPCHK(ctx, hipMemcpyAsync(dwa, &hwa, sizeof(WnafK), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(dwb, &hwb, sizeof(WnafK), hipMemcpyHostToDevice, ctx->stream));
+        {
+          StageTimer t(ctx, ST_LINCOMB2);
+          hipLaunchKernelGGL(k_ec_odd_multiples, dim3((u32)((2 * nthr + 255) / 256)), dim3(256), 0, ctx->stream, st->g, st->h, (u32)npts, tab_a, tab_b, scr);
+          hipLaunchKernelGGL(k_ec_multifold_w4, dim3((u32)((2 * st->n + 255) / 256)), dim3(256), 0, ctx->stream, ja, jb, tab_a, tab_b, dwa, dwb,
+                             (u32)st->n, K2);
+        }
+        HIPCHK(ctx, hipGetLastError());
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));     // the host digit tables are thread-local statics
+      }
+    }
+    if (!wtab) {
+      NafK ha, hb;
+      memset(&ha, 0, sizeof(ha)); memset(&hb, 0, sizeof(hb));
+      ha.top = hb.top = -1;
+      for (u32 t = 0; t < K2; t++) {
+        host_naf((const uint8_t *)st->hcg[t].v, ha.nz[t], ha.sg[t], ha.top);
+        host_naf((const uint8_t *)st->hch[t].v, hb.nz[t], hb.sg[t], hb.top);
+      }
+      HIPCHK(ctx, hipMemcpyAsync(st->nafk[0], &ha, sizeof(NafK), hipMemcpyHostToDevice, ctx->stream));
+      HIPCHK(ctx, hipMemcpyAsync(st->nafk[1], &hb, sizeof(NafK), hipMemcpyHostToDevice, ctx->stream));
+      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));     // ha / hb are stack objects
+      {
+        StageTimer t(ctx, ST_LINCOMB2);
+        hipLaunchKernelGGL(k_ec_multifold, dim3((u32)((2 * st->n + 255) / 256)), dim3(256), 0, ctx->stream, ja, jb, st->nafk[0], st->nafk[1],
+                           (u32)st->n, K2);
+      }
     }
     HIPCHK(ctx, hipGetLastError());
     // the folded generators become the new bases
@@ -934,6 +975,7 @@ void bpmi_ipa_destroy(bpmi_ipa *st) {
   (void)hipSetDevice(st->ctx->device);
   (void)hipStreamSynchronize(st->ctx->stream);
   (void)hipFree(st->block);
+  if (st->wtab) (void)hipFree(st->wtab);
   delete st;
 }
 

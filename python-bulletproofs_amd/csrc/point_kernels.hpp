@@ -237,6 +237,133 @@ __global__ void __launch_bounds__(256, 3) k_ec_multifold(MultifoldJob ja, Multif
   store_words16(out + 16ull * i, w16);
 }
 
+// ---- the same fold with width-4 non-adjacent forms ------------------------------------------------------------------
+// A plain NAF has one non-zero digit in three, a width-4 NAF (digits 0, +-1, +-3, +-5, +-7) one in five: 16 x 51 instead
+// of 16 x 86 mixed additions per output -- if 3P, 5P, 7P of every base point exist in AFFINE form.  They are built
+// once per fold by k_ec_odd_multiples (2P, 3P = 2P + P, 4P, 5P = 4P + P, 6P = 2 (3P), 7P = 6P + P: three doublings and
+// three mixed additions per point in Jacobian coordinates, then ONE inversion per thread for the 48 Z coordinates of its
+// 16 points -- Montgomery's trick, prefix products in a scratch column) and read by k_ec_multifold_w4.
+//   tab: entry j (0: 3P, 1: 5P, 2: 7P) of point k at tab + ((j * npts) + k) * 18 limbs (x, y; all zero = identity)
+//   scratch: 4 x 9 limbs (X, Y, Z, prefix) per (point, j), column-major per thread
+#define ODDMUL_PER_THREAD 16
+__global__ void __launch_bounds__(256, 3) k_ec_odd_multiples(const u32 *__restrict__ base_a, const u32 *__restrict__ base_b, u32 npts,
+                                                            u32 *__restrict__ tab_a, u32 *__restrict__ tab_b, u32 *__restrict__ scratch) {
+  const u32 nthreads_per = (npts + ODDMUL_PER_THREAD - 1) / ODDMUL_PER_THREAD;
+  u32 tid = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool second = tid >= nthreads_per;
+  if (second) tid -= nthreads_per;
+  if (tid >= nthreads_per) return;
+  const u32 *base = second ? base_b : base_a;
+  u32 *tab = second ? tab_b : tab_a;
+  const u32 col = (second ? nthreads_per : 0u) + tid;                 // scratch column of this thread
+  const u32 ncols = 2u * nthreads_per;
+  auto rec = [&](u32 e) { return scratch + ((u64)e * ncols + col) * 36u; };      // e = r * 3 + j
+  fe pref;
+  fe_set_one(pref);
+  for (u32 r = 0; r < ODDMUL_PER_THREAD; r++) {
+    const u32 k = tid + r * nthreads_per;                               // strided: consecutive threads read consecutive points
+    affine P;
+    if (k < npts) load_affine(P, base + 16ull * k); else { fe_set_zero(P.x); fe_set_zero(P.y); }
+    const bool inf = affine_is_inf(P);
+    jac two, m[3];
+    if (!inf) {
+      jac one; one.X = P.x; one.Y = P.y; fe_set_one(one.Z);
+      jac_dbl(two, one);
+      m[0] = two; jac_madd(m[0], P.x, P.y);                             // 3P
+      jac four; jac_dbl(four, two);
+      m[1] = four; jac_madd(m[1], P.x, P.y);                            // 5P
+      jac six; jac_dbl(six, m[0]);
+      m[2] = six; jac_madd(m[2], P.x, P.y);                             // 7P
+    }
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      if (inf) { fe_set_zero(m[j].X); fe_set_zero(m[j].Y); fe_set_one(m[j].Z); }      // Z = 1 keeps the product chain alive
+      u32 *q = rec(r * 3 + j);
+#pragma unroll
+      for (int l = 0; l < 9; l++) { q[l] = m[j].X.v[l]; q[9 + l] = m[j].Y.v[l]; q[18 + l] = m[j].Z.v[l]; q[27 + l] = pref.v[l]; }
+      fe_mul(pref, pref, m[j].Z);
+    }
+  }
+  fe inv;
+  fe_inv(inv, pref);                                                     // 1 / (product of all 48 Z)
+  for (int e = ODDMUL_PER_THREAD * 3 - 1; e >= 0; e--) {
+    const u32 r = (u32)e / 3u, j = (u32)e % 3u, k = tid + r * nthreads_per;
+    const u32 *q = rec((u32)e);
+    fe X, Y, Z, pj, zi, zi2, zi3, x, y;
+#pragma unroll
+    for (int l = 0; l < 9; l++) { X.v[l] = q[l]; Y.v[l] = q[9 + l]; Z.v[l] = q[18 + l]; pj.v[l] = q[27 + l]; }
+    fe_mul(zi, inv, pj);                                                 // 1 / Z_e
+    fe_mul(inv, inv, Z);
+    fe_sqr(zi2, zi);
+    fe_mul(zi3, zi2, zi);
+    fe_mul(x, X, zi2);
+    fe_mul(y, Y, zi3);
+    fe_carry(x, x); fe_carry(y, y);                                      // tight limbs: the ladder negates y lazily
+    if (k < npts) {
+      u32 *o = tab + ((u64)j * npts + k) * 18u;
+#pragma unroll
+      for (int l = 0; l < 9; l++) { o[l] = x.v[l]; o[9 + l] = y.v[l]; }   // the identity gives X = Y = 0 -> (0, 0)
+    }
+  }
+}
+// digits of the K (<= 16) shared scalars, width-4 NAF: dg[t][pos] in {0, +-1, +-3, +-5, +-7}, pos <= top
+struct WnafK { signed char dg[MULTIFOLD_MAXK][264]; int top; };
+static void host_wnaf4(const uint8_t k32[32], signed char dg[264], int &top) {
+  u32 w[9];
+  memcpy(w, k32, 32);
+  w[8] = 0;
+  memset(dg, 0, 264);
+  for (int pos = 0; pos < 260; pos++) {
+    if (w[0] & 1u) {
+      int d = (int)(w[0] & 15u);                     // k mod 16
+      if (d > 8) d -= 16;                            // odd digit in [-7, 7]
+      dg[pos] = (signed char)d;
+      // k -= d
+      if (d > 0) { u64 br = (u64)d; for (int i = 0; i < 9 && br; i++) { const u64 t = (u64)w[i] - br; w[i] = (u32)t; br = (t >> 32) & 1u; } }
+      else { u64 c = (u64)(-d); for (int i = 0; i < 9 && c; i++) { const u64 t = (u64)w[i] + c; w[i] = (u32)t; c = t >> 32; } }
+      if (pos > top) top = pos;
+    }
+    for (int i = 0; i < 8; i++) w[i] = (w[i] >> 1) | (w[i + 1] << 31);
+    w[8] >>= 1;
+  }
+}
+__global__ void __launch_bounds__(256, 3) k_ec_multifold_w4(MultifoldJob ja, MultifoldJob jb, const u32 *__restrict__ tab_a, const u32 *__restrict__ tab_b,
+                                                            const WnafK *__restrict__ wa, const WnafK *__restrict__ wb, u32 m, u32 K) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool second = i >= m;
+  if (second) i -= m;
+  if (i >= m) return;
+  const u32 *base = second ? jb.base : ja.base;
+  const u32 *tab = second ? tab_b : tab_a;
+  u32 *out = second ? jb.out : ja.out;
+  const WnafK *nf = second ? wb : wa;
+  const u32 npts = m * K;
+  jac acc;
+  jac_set_inf(acc);
+  for (int pos = nf->top; pos >= 0; pos--) {
+    jac_dbl(acc, acc);
+#pragma unroll 1
+    for (u32 t = 0; t < K; t++) {
+      const int d = nf->dg[t][pos];                                       // the same for every thread of the job
+      if (d == 0) continue;
+      const u32 mag = (u32)(d < 0 ? -d : d), k = i + t * m;
+      affine P;
+      if (mag == 1u) load_affine(P, base + 16ull * k);
+      else {
+        const u32 *q = tab + ((u64)((mag >> 1) - 1u) * npts + k) * 18u;
+#pragma unroll
+        for (int l = 0; l < 9; l++) { P.x.v[l] = q[l]; P.y.v[l] = q[9 + l]; }
+      }
+      if (!affine_is_inf(P)) jac_madd_signed(acc, P.x, P.y, d < 0);
+    }
+  }
+  affine r;
+  jac_to_affine(r, acc);
+  u32 w16[16];
+  affine_to_words(w16, r);
+  store_words16(out + 16ull * i, w16);
+}
+
 // Batch decompression of SEC1 compressed points: in = n x 33 B (0x02 | 0x03, x big-endian;
 // 33 zero bytes = identity), out = n x 64 B wire format, ok[i] = 1 when the encoding is
 // valid.  Replaces bytes_to_point (/root/reference/src/utils/utils.py:119-131):
