@@ -4,7 +4,7 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libbpmi.so")
+LIB_PATH = os.environ.get("BPMI_LIB") or os.path.join(HERE, "libbpmi.so")      # BPMI_LIB: A/B experiments with two builds in one run
 NSTAGES = 12
 
 # name -> (restype, argtypes); this table is checked against include/bpmi.h by tests
