@@ -125,7 +125,6 @@ int bpmi_set_option(bpmi_ctx *ctx, const char *name, int64_t value) {
   if (!strcmp(name, "split")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "split must be 0 or 1"); ctx->opt_split = (int)value; return BPMI_OK; }
   if (!strcmp(name, "async_lanes")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "async_lanes must be 0 or 1"); ctx->opt_async_lanes = (int)value; return BPMI_OK; }
   if (!strcmp(name, "fold_wnaf")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "fold_wnaf must be 0 or 1"); ctx->opt_fold_wnaf = (int)value; return BPMI_OK; }
-  if (!strcmp(name, "pair_chain")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "pair_chain must be 0 or 1"); ctx->opt_pair_chain = (int)value; return BPMI_OK; }
   if (!strcmp(name, "reduce_epl")) { if (value < 0 || value > 64) return fail(ctx, BPMI_E_ARG, "reduce_epl must be 0..64"); ctx->opt_epl = (int)value; return BPMI_OK; }
   if (!strcmp(name, "chunk")) { if (value < 0 || value > 4096) return fail(ctx, BPMI_E_ARG, "chunk must be 0..4096"); ctx->opt_chunk = (int)value; return BPMI_OK; }
   if (!strcmp(name, "ipa_big_m")) { if (value < 0 || (value & (value - 1))) return fail(ctx, BPMI_E_ARG, "ipa_big_m must be 0 or a power of two"); ctx->opt_ipa_big = value; return BPMI_OK; }

@@ -50,7 +50,6 @@ struct bpmi_ctx {
   int opt_chunk = 0;    // entries per thread in k_accum_l0, 0 = auto
   int opt_small = 0;    // largest n handled by the one-launch small-MSM kernel (0 = default, -1 = never)
   int opt_fold_wnaf = 1;     // the IPA's 16-way generator fold: width-4 NAF over affine tables of odd multiples (0: plain NAF ladder)
-  int opt_pair_chain = 0;    // two large MSMs of a pair (L / R of an IPA round): chain their accumulate kernels (measured on C3: 2.43 ms per round against 2.35 unchained -- off)
   int opt_epl = 0;           // bucket reduction stage 1: elements per lane (0 = default 16)
   int opt_async_lanes = 0;   // 1: slot 1 of the asynchronous MSM pair runs on the second lane
   bool async_lane1_ordered = false;

@@ -93,22 +93,12 @@ class ShardedMSM:
         if self.device_fold and dist.get_backend(self.group) == "nccl":
             world = dist.get_world_size(self.group)
             stream, eng2, pin, mine, flat, d_out, pin_out = self._comm_setup(world)
-            import os
-            mode = os.environ.get("BPMI_COMBINE_DEBUG", "full")      # experiments only
-            if mode == "none":
-                return ("done", partial)
             pin.copy_(torch.frombuffer(bytearray(partial), dtype=torch.uint8))
             with torch.cuda.stream(stream):
                 mine.copy_(pin, non_blocking=True)
-                if mode != "fold_only":
-                    dist.all_gather_into_tensor(flat, mine, group=self.group)
-                else:
-                    flat[:64].copy_(mine)
+                dist.all_gather_into_tensor(flat, mine, group=self.group)
                 # same stream: the fold is ordered behind the collective
-                if mode != "nccl_only":
-                    eng2._ck(eng2.lib.bpmi_ec_sum_dev_enqueue(eng2.ctx, flat.data_ptr(), world, d_out.data_ptr()))
-                else:
-                    d_out.copy_(flat[:64])
+                eng2._ck(eng2.lib.bpmi_ec_sum_dev_enqueue(eng2.ctx, flat.data_ptr(), world, d_out.data_ptr()))
                 pin_out.copy_(d_out, non_blocking=True)
             return ("rccl", None)
         return ("done", self.combine(partial))
