@@ -427,7 +427,8 @@ def extra_c5(eng, world, rank, dev, log_batch=14, distinct=64):
             buf = bytes(bad)
         try:
             bv.add_wire_native(Vs_in, buf, threads=threads, offsets=wire_off)
-            ok = bool(bv.verify(sharded=sharded if dist.is_initialized() else None))
+            # the corrupted batch is verified locally: a rank that rejects before the exchange must not leave the others in a collective
+            ok = bool(bv.verify(sharded=sharded if (dist.is_initialized() and not corrupt) else None))
         except Exception:
             ok = False
         bv.reset()            # frees the batch's device buffers
