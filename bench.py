@@ -412,8 +412,13 @@ def extra_c5(eng, world, rank, dev, log_batch=14, distinct=64):
     blobs_in = [wire[k % distinct] for k in range(lo, hi)]
     # the proofs arrive as ONE receive buffer with an offset table (what a socket reader produces), not as 2^14 Python objects
     from itertools import accumulate
-    wire_buf = b"".join(blobs_in)
     wire_off = [0, *accumulate(map(len, blobs_in))]
+    wire_joined = b"".join(blobs_in)
+    wire_buf = eng.host_alloc(len(wire_joined))       # page-locked, as a receive buffer registered with the GPU would be
+    wire_buf.view[:] = wire_joined
+    v_packed = b"".join(V.to_le64() for V in Vs_in)   # commitments in the library's 64-byte point format
+    import ctypes
+    wire_off_c = (ctypes.c_uint64 * len(wire_off))(*wire_off)
     usable = usable_cpus()
     threads = max(1, min(32, usable // world))
     sharded = ShardedMSM(engine=eng)
@@ -422,11 +427,11 @@ def extra_c5(eng, world, rank, dev, log_batch=14, distinct=64):
         bv = BatchRangeVerifier(g, h, gs, hs, u)
         buf = wire_buf
         if corrupt:           # flip one bit inside one proof of this rank's shard: the batch must reject
-            bad = bytearray(wire_buf)
+            bad = bytearray(wire_joined)
             bad[(wire_off[len(blobs_in) // 2] + wire_off[len(blobs_in) // 2 + 1]) // 2] ^= 1
             buf = bytes(bad)
         try:
-            bv.add_wire_native(Vs_in, buf, threads=threads, offsets=wire_off)
+            bv.add_wire_native(v_packed, buf, threads=threads, offsets=wire_off_c)
             # the corrupted batch is verified locally: a rank that rejects before the exchange must not leave the others in a collective
             ok = bool(bv.verify(sharded=sharded if (dist.is_initialized() and not corrupt) else None))
         except Exception:

@@ -71,6 +71,9 @@ int bpmi_sync(bpmi_ctx *ctx);
  *   "async_lanes"  1: slot 1 of bpmi_msm_dev_enqueue runs on the ctx's second lane (own stream and workspace), so
  *                  the tail stages of one MSM overlap the sort / accumulate of the next (inputs must be complete
  *                  before the first enqueue of a burst; default 0)
+ *   "rp_lanes"     bpmi_rp_batch_prepare_dev: proofs per 64-lane wave (power of two; 0 = chosen so that a batch fills the
+ *                  chip's SIMDs: a wave costs the same whatever its active-lane count)
+ *   "rp_rows"      bpmi_rp_batch_prepare_dev: proofs per kernel launch (0 = as many as fit ~256 MB of scratch cells)
  *   "ipa_big_m"    base length from which the IPA prover folds its generators 16-way at
  *                  once instead of deferring the fold into the MSM scalars (default 2^18) */
 int bpmi_set_option(bpmi_ctx *ctx, const char *name, int64_t value);
@@ -223,6 +226,21 @@ void bpmi_ipa_destroy(bpmi_ipa *st);
  * host threads share the proofs.  The native twin of BatchRangeVerifier.add (rangeproofs/batch.py). */
 int bpmi_rp_batch_prepare(uint32_t n_gens, uint32_t values_per_proof, uint64_t n_proofs, const uint8_t *blobs, uint64_t blobs_len, const uint64_t *blob_off,
                           const uint8_t *weights, const uint8_t *seed, int threads, uint8_t *v_scalars, uint8_t *pt_scalars, uint8_t *shared, uint8_t *comp_out, int64_t *first_bad);
+
+/* The same preparation on the GPU (csrc/rp_batch_kernels.hpp; one lane per proof parses, re-hashes the transcripts and computes
+ * the weighted scalars).  `blobs` / `blob_off` / `weights` / `seed` / `shared` are HOST pointers with the meaning above (blobs may be
+ * page-locked memory from bpmi_host_alloc: the upload then runs at link speed); the outputs that feed the MSM stay on the device:
+ *   d_v_scalars   n_proofs x values_per_proof x 32 B      d_pt_scalars  n_proofs x (6 + 2k) x 32 B
+ *   d_points      n_proofs x (6 + 2k) x 64 B: the proofs' points, decoded where they lie in the blobs (wire order)
+ * *first_bad = smallest index of a proof that failed parsing, a transcript check, or has an invalid point encoding; -1 if none.
+ * A failed proof's scalars and contributions are zero.  Same numbers as bpmi_rp_batch_prepare for the same weights / seed
+ * (tests/test_gpu_batch_dev.py).  n_proofs <= 2^22, blobs_len <= 4 GiB per call. */
+int bpmi_rp_batch_prepare_dev(bpmi_ctx *ctx, uint32_t n_gens, uint32_t values_per_proof, uint64_t n_proofs, const uint8_t *blobs, uint64_t blobs_len,
+                              const uint64_t *blob_off, const uint8_t *weights, const uint8_t *seed, void *d_v_scalars, void *d_pt_scalars, void *d_points,
+                              uint8_t *shared, int64_t *first_bad);
+/* Page-locked host memory (hipHostMalloc) for buffers handed to the library repeatedly, e.g. the receive buffer of wire proofs. */
+int bpmi_host_alloc(bpmi_ctx *ctx, size_t bytes, void **out);
+int bpmi_host_free(bpmi_ctx *ctx, void *p);
 
 /* ---- self-test hook (not part of the drop-in surface) ---------------------------------------------------
  * Runs one member of the device's field-multiplication family on n operand tuples given as RAW 9 x 29-bit

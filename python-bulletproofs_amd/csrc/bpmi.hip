@@ -50,6 +50,7 @@ using namespace bpmi;
 #include "host_tail.hpp"
 #include "msm_host.hpp"
 #include "rp_batch_host.hpp"
+#include "rp_batch_kernels.hpp"
 
 // ------------------------------------------------------------------------------------
 // C-ABI
@@ -96,6 +97,7 @@ void bpmi_ctx_destroy(bpmi_ctx *ctx) {
   for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
   if (ctx->ws) (void)hipFree(ctx->ws);
   if (ctx->stage_in) (void)hipFree(ctx->stage_in);
+  if (ctx->rp_buf) (void)hipFree(ctx->rp_buf);
   if (ctx->pin) (void)hipHostFree(ctx->pin);
   if (ctx->stream1) { (void)hipStreamSynchronize(ctx->stream1); (void)hipStreamDestroy(ctx->stream1); }
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
@@ -124,6 +126,12 @@ int bpmi_set_option(bpmi_ctx *ctx, const char *name, int64_t value) {
   if (!strcmp(name, "small_n")) { if (value < -1 || value > (1 << 16)) return fail(ctx, BPMI_E_ARG, "small_n must be -1 .. 65536"); ctx->opt_small = (int)value; return BPMI_OK; }
   if (!strcmp(name, "split")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "split must be 0 or 1"); ctx->opt_split = (int)value; return BPMI_OK; }
   if (!strcmp(name, "async_lanes")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "async_lanes must be 0 or 1"); ctx->opt_async_lanes = (int)value; return BPMI_OK; }
+  if (!strcmp(name, "rp_rows")) { if (value < 0) return fail(ctx, BPMI_E_ARG, "rp_rows must be >= 0"); ctx->opt_rp_rows = (int)value; return BPMI_OK; }
+  if (!strcmp(name, "rp_lanes")) {
+    if (value != 0 && (value < 1 || value > 64 || (value & (value - 1)))) return fail(ctx, BPMI_E_ARG, "rp_lanes must be 0 or a power of two <= 64");
+    ctx->opt_rp_lanes = (int)value;
+    return BPMI_OK;
+  }
   if (!strcmp(name, "fold_wnaf")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "fold_wnaf must be 0 or 1"); ctx->opt_fold_wnaf = (int)value; return BPMI_OK; }
   if (!strcmp(name, "reduce_epl")) { if (value < 0 || value > 64) return fail(ctx, BPMI_E_ARG, "reduce_epl must be 0..64"); ctx->opt_epl = (int)value; return BPMI_OK; }
   if (!strcmp(name, "chunk")) { if (value < 0 || value > 4096) return fail(ctx, BPMI_E_ARG, "chunk must be 0..4096"); ctx->opt_chunk = (int)value; return BPMI_OK; }
@@ -1020,6 +1028,102 @@ int bpmi_rp_batch_prepare(uint32_t n_gens, uint32_t values_per_proof, uint64_t n
     for (int t = 0; t < threads; t++) rp::q_add(sum, sum, acc[t][i]);
     rp::q_to_le(shared + 32 * i, sum);
   }
+  return BPMI_OK;
+}
+
+// The same preparation on the GPU (rp_batch_kernels.hpp): the wire proofs are uploaded once, one lane per proof parses, hashes and
+// checks them, the weighted scalars are written straight into the caller's device scalar arrays, the proofs' points are decoded
+// where they lie in the blobs into d_points, and only the (5 + 2n) shared coefficients and the verdict come back.
+int bpmi_rp_batch_prepare_dev(bpmi_ctx *ctx, uint32_t n_gens, uint32_t values_per_proof, uint64_t n_proofs, const uint8_t *blobs, uint64_t blobs_len,
+                              const uint64_t *blob_off, const uint8_t *weights, const uint8_t *seed, void *d_v_scalars, void *d_pt_scalars, void *d_points,
+                              uint8_t *shared, int64_t *first_bad) {
+  if (!ctx) return BPMI_E_ARG;
+  if (!blobs || !blob_off || (!weights && !seed) || !d_v_scalars || !d_pt_scalars || !d_points || !shared || !first_bad) return fail(ctx, BPMI_E_ARG, "null argument");
+  if (n_gens < 2 || (n_gens & (n_gens - 1)) || n_gens > 65536) return fail(ctx, BPMI_E_ARG, "n_gens must be a power of two in [2, 65536]");
+  const uint32_t m = values_per_proof;
+  if (m < 1 || n_gens % m) return fail(ctx, BPMI_E_ARG, "values_per_proof must divide n_gens");
+  if (n_proofs == 0 || n_proofs > (1ull << 22)) return fail(ctx, BPMI_E_ARG, "n_proofs must be in [1, 2^22]");
+  if (blobs_len > (1ull << 32)) return fail(ctx, BPMI_E_ARG, "at most 4 GiB of proofs per call");
+  uint32_t k = 0;
+  while ((1u << k) < n_gens) k++;
+  *first_bad = -1;
+  if (blob_off[0] > blobs_len) return fail(ctx, BPMI_E_ARG, "offset table leaves the buffer");
+  for (uint64_t g = 0; g < n_proofs; g++) if (blob_off[g] > blob_off[g + 1] || blob_off[g + 1] > blobs_len) return fail(ctx, BPMI_E_ARG, "offset table leaves the buffer");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const u32 P = (u32)n_proofs, ncols = 5 + 2 * n_gens, per = 6 + 2 * k;
+  // device staging: blobs | offsets | weights | status
+  const size_t o_off = align_up(blobs_len + 64, 256), o_w = o_off + align_up(8 * ((size_t)P + 1), 256), o_st = o_w + (weights ? align_up(128 * (size_t)P, 256) : 0);
+  int rc = ensure_stage_in(ctx, o_st + align_up(2 * (size_t)P, 256));
+  if (rc) return rc;
+  char *din = (char *)ctx->stage_in;
+  HIPCHK(ctx, hipMemcpyAsync(din, blobs, blobs_len, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(din + o_off, blob_off, 8 * ((size_t)P + 1), hipMemcpyHostToDevice, ctx->stream));
+  if (weights) HIPCHK(ctx, hipMemcpyAsync(din + o_w, weights, 128 * (size_t)P, hipMemcpyHostToDevice, ctx->stream));
+  // contributions: at most ~256 MB of cells per launch
+  const size_t cell_row = 32 * (size_t)ncols;
+  u32 rows = (u32)std::min<size_t>(P, std::max<size_t>(1, ((size_t)256 << 20) / cell_row));
+  if (ctx->opt_rp_rows > 0) rows = std::min<u32>(rows, (u32)ctx->opt_rp_rows);
+  const size_t need = cell_row * rows + cell_row + 256;
+  if (need > ctx->rp_buf_bytes) {
+    if (ctx->rp_buf) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(ctx->rp_buf)); ctx->rp_buf = nullptr; ctx->rp_buf_bytes = 0; }
+    HIPCHK(ctx, hipMalloc(&ctx->rp_buf, need));
+    ctx->rp_buf_bytes = need;
+  }
+  u32 *d_contrib = (u32 *)ctx->rp_buf, *d_shared = d_contrib + 8 * (size_t)ncols * rows;
+  unsigned long long *d_bad = (unsigned long long *)(d_shared + 8 * (size_t)ncols);
+  HIPCHK(ctx, hipMemsetAsync(d_shared, 0, cell_row, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(d_bad, 0xFF, 8, ctx->stream));
+  rpd::Params q;
+  q.blobs = (const uint8_t *)din;
+  q.weights = weights ? (const uint8_t *)(din + o_w) : nullptr;
+  for (int i = 0; i < 8; i++) q.seed[i] = seed ? ((u32)seed[4 * i] << 24) | ((u32)seed[4 * i + 1] << 16) | ((u32)seed[4 * i + 2] << 8) | seed[4 * i + 3] : 0;
+  q.n = n_gens; q.k = k; q.m = m; q.Pall = P;
+  q.contrib = d_contrib;
+  q.bad = d_bad;
+  for (u32 base = 0; base < P; base += rows) {
+    const u32 cnt = std::min(rows, P - base);
+    u32 lanes = (u32)ctx->opt_rp_lanes;
+    if (!lanes) { lanes = 64; while (lanes > 8 && (cnt + lanes - 1) / lanes < 2048) lanes >>= 1; }
+    q.off = (const u64 *)(din + o_off) + base;
+    q.P = cnt; q.lanes = lanes; q.first = base;
+    q.v_scalars = (u32 *)d_v_scalars + 8 * (size_t)base * m;
+    q.pt_scalars = (u32 *)d_pt_scalars + 8 * (size_t)base * per;
+    q.status = (uint8_t *)(din + o_st) + base;
+    StageTimer t(ctx, ST_MISC);
+    hipLaunchKernelGGL(rpd::k_rp_prepare, dim3(2 * ((cnt + lanes - 1) / lanes)), dim3(64), 0, ctx->stream, q);
+    hipLaunchKernelGGL(rpd::k_rp_colsum, dim3(ncols), dim3(256), 0, ctx->stream, (const u32 *)d_contrib, cnt, d_shared);
+  }
+  HIPCHK(ctx, hipGetLastError());
+  {
+    StageTimer t(ctx, ST_MISC);
+    const u64 npts = (u64)P * per;
+    hipLaunchKernelGGL(k_ec_decompress_wire, dim3((u32)((npts + 255) / 256)), dim3(256), 0, ctx->stream, (const uint8_t *)din, (const u64 *)(din + o_off),
+                       (const uint8_t *)(din + o_st), k, P, (u64)0, (u32 *)d_points, d_bad);
+  }
+  HIPCHK(ctx, hipGetLastError());
+  rc = ensure_pin(ctx, cell_row + 64);
+  if (rc) return rc;
+  HIPCHK(ctx, hipMemcpyAsync(ctx->pin, d_shared, cell_row + 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  memcpy(shared, ctx->pin, cell_row);
+  unsigned long long bad;
+  memcpy(&bad, (char *)ctx->pin + cell_row, 8);
+  *first_bad = bad == ~0ull ? -1 : (int64_t)bad;
+  return BPMI_OK;
+}
+// page-locked host memory for buffers that are handed to the library again and again (e.g. the receive buffer of wire proofs:
+// uploads from it run at link speed and without a staging copy)
+int bpmi_host_alloc(bpmi_ctx *ctx, size_t bytes, void **out) {
+  if (!ctx || !out || !bytes) return ctx ? fail(ctx, BPMI_E_ARG, "null argument") : BPMI_E_ARG;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipHostMalloc(out, bytes, hipHostMallocDefault));
+  return BPMI_OK;
+}
+int bpmi_host_free(bpmi_ctx *ctx, void *p) {
+  if (!ctx) return BPMI_E_ARG;
+  if (!p) return BPMI_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipHostFree(p));
   return BPMI_OK;
 }
 

@@ -368,10 +368,7 @@ __global__ void __launch_bounds__(256, 3) k_ec_multifold_w4(MultifoldJob ja, Mul
 // 33 zero bytes = identity), out = n x 64 B wire format, ok[i] = 1 when the encoding is
 // valid.  Replaces bytes_to_point (/root/reference/src/utils/utils.py:119-131):
 // y = (x^3 + 7)^((p+1)/4), then the root with the requested parity.
-__global__ void __launch_bounds__(256, 3) k_ec_decompress(const uint8_t *__restrict__ in, u32 n, u32 *__restrict__ out, uint8_t *__restrict__ ok) {
-  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const uint8_t *src = in + 33ull * i;
+__device__ __forceinline__ bool ec_decompress_one(const uint8_t *src, u32 w16[16]) {
   const u32 tag = src[0];
   u32 w[8];
   u32 any = 0;
@@ -381,7 +378,6 @@ __global__ void __launch_bounds__(256, 3) k_ec_decompress(const uint8_t *__restr
     w[k] = ((u32)q[0] << 24) | ((u32)q[1] << 16) | ((u32)q[2] << 8) | (u32)q[3];
     any |= w[k];
   }
-  u32 w16[16];
 #pragma unroll
   for (int k = 0; k < 16; k++) w16[k] = 0;
   bool valid;
@@ -411,8 +407,34 @@ __global__ void __launch_bounds__(256, 3) k_ec_decompress(const uint8_t *__restr
   } else {
     valid = false;
   }
+  return valid;
+}
+__global__ void __launch_bounds__(256, 3) k_ec_decompress(const uint8_t *__restrict__ in, u32 n, u32 *__restrict__ out, uint8_t *__restrict__ ok) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u32 w16[16];
+  const bool valid = ec_decompress_one(in + 33ull * i, w16);
   store_words16(out + 16ull * i, w16);
   ok[i] = valid ? 1 : 0;
+}
+// the same for the points of wire proofs where they lie inside the blobs (rangeproofs/codec.py: (6 + 2k) encodings after the
+// 6-byte header and the 5 + k scalars); proofs that failed a role of the preparation
+// (status[g] or status[n_proofs + g] = 0) are skipped (their offsets are not trustworthy), an invalid
+// encoding records its proof in *bad (atomicMin; `first` = batch index of proof 0 of this launch)
+__global__ void __launch_bounds__(256, 3) k_ec_decompress_wire(const uint8_t *__restrict__ blobs, const u64 *__restrict__ off, const uint8_t *__restrict__ status,
+                                                               u32 k, u32 n_proofs, u64 first, u32 *__restrict__ out, unsigned long long *bad) {
+  const u32 per = 6 + 2 * k;
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_proofs * per) return;
+  const u32 g = i / per, t = i - g * per;
+  u32 w16[16];
+#pragma unroll
+  for (int j = 0; j < 16; j++) w16[j] = 0;
+  if (status[g] & status[(size_t)n_proofs + g]) {
+    const bool valid = ec_decompress_one(blobs + off[g] + 6 + 32 * (5 + k) + 33 * t, w16);
+    if (!valid) atomicMin(bad, (unsigned long long)(first + g));
+  }
+  store_words16(out + 16ull * i, w16);
 }
 
 // out = sum of n affine points (one block)

@@ -124,4 +124,54 @@ BPMI_HD void sc_mul(sc &r, const sc &a, const sc &b) {
   for (int i = 0; i < 8; i++) r.v[i] = f3[i];
 }
 
+// x / 2 mod q
+BPMI_HD void sc_half(sc &x) {
+  const u32 q[8] = BPMI_SC_Q;
+  const u32 odd = x.v[0] & 1u;
+  u32 t[9];
+  u64 c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) { c += (u64)x.v[i] + (odd ? q[i] : 0u); t[i] = (u32)c; c >>= 32; }
+  t[8] = (u32)c;
+#pragma unroll
+  for (int i = 0; i < 8; i++) x.v[i] = (t[i] >> 1) | (t[i + 1] << 31);
+}
+// r = a^-1 mod q (a in [1, q); a = 0 gives 0) by the binary extended Euclid: ~2 x 256 shift / subtract steps of ~100
+// instructions, against ~450 multiplications for a^(q-2).  Invariants: a x1 == u, a x2 == v (mod q); v stays odd; every
+// step halves u (after making it even by u -= v when it is odd), so u + v loses a bit per step and u = 0 is reached with
+// v = gcd = 1.  Not constant time: the inputs are public proof data.
+BPMI_HD void sc_inv(sc &r, const sc &a) {
+  const u32 q[8] = BPMI_SC_Q;
+  u32 u[8], v[8];
+  sc x1, x2;
+#pragma unroll
+  for (int i = 0; i < 8; i++) { u[i] = a.v[i]; v[i] = q[i]; x1.v[i] = i ? 0u : 1u; x2.v[i] = 0u; }
+  u32 nz = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) nz |= u[i];
+  while (nz) {
+    const bool odd = (u[0] & 1u) != 0;
+    u32 d[8];
+    const bool lt = words_sub(d, u, v) != 0;          // d = u - v (valid when u >= v)
+    if (odd && lt) {                                  // swap roles so that u >= v
+#pragma unroll
+      for (int i = 0; i < 8; i++) { const u32 t = u[i]; u[i] = v[i]; v[i] = t; const u32 s = x1.v[i]; x1.v[i] = x2.v[i]; x2.v[i] = s; }
+      words_sub(d, u, v);
+    }
+    if (odd) {
+#pragma unroll
+      for (int i = 0; i < 8; i++) u[i] = d[i];
+      sc nx2, t;
+      sc_neg(nx2, x2);
+      sc_add(t, x1, nx2);
+      x1 = t;
+    }
+    nz = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { u[i] = (u[i] >> 1) | (i < 7 ? u[i + 1] << 31 : 0u); nz |= u[i]; }
+    sc_half(x1);
+  }
+  r = x2;
+}
+
 }  // namespace bpmi

@@ -15,6 +15,28 @@ Q = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141
 P_FIELD = 2**256 - 2**32 - 977
 
 
+class HostBuffer:
+    """Page-locked host memory owned by an Engine (bpmi_host_alloc): `view` is a writable memoryview over it (recv_into it,
+    slice-assign into it), `ptr` its address.  Uploads from it need no staging copy."""
+
+    def __init__(self, engine, nbytes):
+        self.engine = engine
+        self.nbytes = nbytes
+        p = ctypes.c_void_p()
+        engine._ck(engine.lib.bpmi_host_alloc(engine.ctx, nbytes, ctypes.byref(p)))
+        self.ptr = p.value
+        self.view = memoryview((ctypes.c_char * nbytes).from_address(self.ptr)).cast("B")
+
+    def __len__(self):
+        return self.nbytes
+
+    def free(self):
+        if self.ptr:
+            self.view.release()
+            self.engine.lib.bpmi_host_free(self.engine.ctx, self.ptr)
+            self.ptr = None
+
+
 class EngineError(RuntimeError):
     pass
 
@@ -85,6 +107,9 @@ class Engine:
 
     def alloc(self, nbytes):
         return DeviceBuffer(self, nbytes)
+
+    def host_alloc(self, nbytes):
+        return HostBuffer(self, nbytes)
 
     def upload(self, data):
         return DeviceBuffer(self, max(len(data), 16)).upload(data)

@@ -234,19 +234,27 @@ class BatchRangeVerifier:
         for st in results:
             self.merge(st)
 
-    def add_wire_native(self, Vs, blobs, decompress=None, threads=None, offsets=None):
+    def add_wire_native(self, Vs, blobs, decompress=None, threads=None, offsets=None, prepare="auto"):
         """add_wire with the per-proof host work in native code (bpmi_rp_batch_prepare, csrc/
         rp_batch_host.hpp: parsing, the three transcript checks, the weighted scalars; `threads` host
         threads): ~150 us of interpreter per proof become a few microseconds, and nothing in this
         function loops over proofs in Python.  Vs: one commitment per proof, or -- aggregated proofs --
-        one list of m commitments per proof (the same m for the whole call).  Same verdicts as add()
-        except that numbers in transcripts must be canonical decimal.
+        one list of m commitments per proof (the same m for the whole call), or the commitments already
+        packed as count * m 64-byte points (bytes).  Same verdicts as add() except that numbers in
+        transcripts must be canonical decimal.
 
         blobs: a list of wire proofs, or ONE bytes-like object holding them back to back together with
-        `offsets` (count + 1 positions) -- how proofs arrive from a socket; saves the join of the list.
+        `offsets` (count + 1 positions) -- how proofs arrive from a socket; saves the join of the list.  The object may
+        be an engine.HostBuffer (page-locked memory, Engine.host_alloc): the upload of the device preparation then runs
+        at link speed.
         With the default engine the decoded points never leave the GPU: they are decompressed straight into
         the point array of the batch's MSM (bpmi_ec_decompress_batch_dev), and the random weights are
-        derived natively from one fresh 32-byte seed."""
+        derived natively from one fresh 32-byte seed.
+
+        prepare: "device" -- the preparation itself runs on the GPU too (bpmi_rp_batch_prepare_dev, csrc/rp_batch_kernels.hpp:
+        one lane per proof; the wire bytes are uploaded once and nothing but the 5 + 2n shared coefficients and the verdict
+        comes back); "host" -- bpmi_rp_batch_prepare on `threads` host threads; "auto" (default) -- device whenever the
+        default engine is in use.  Both produce the same numbers for the same weights."""
         import ctypes
         import os
         from itertools import accumulate
@@ -258,24 +266,37 @@ class BatchRangeVerifier:
         else:
             count = len(offsets) - 1
             joined = blobs
-        assert len(Vs) == count
         if not count:
             return
         k = self.n.bit_length() - 1
         npts = count * (6 + 2 * k)
-        aggregated = isinstance(Vs[0], (list, tuple))
-        m = len(Vs[0]) if aggregated else 1
-        if aggregated:
-            if any(len(v) != m for v in Vs) or m < 1 or self.n % m:
+        if isinstance(Vs, (bytes, bytearray, memoryview)):          # commitments already packed: count * m points of 64 bytes
+            vbytes = bytes(Vs)
+            m = len(vbytes) // (64 * count)
+            if m < 1 or len(vbytes) != 64 * count * m or self.n % m:
                 raise Exception("Proof invalid")
-            Vs = [V for group in Vs for V in group]
+        else:
+            assert len(Vs) == count
+            aggregated = isinstance(Vs[0], (list, tuple))
+            m = len(Vs[0]) if aggregated else 1
+            if aggregated:
+                if any(len(v) != m for v in Vs) or m < 1 or self.n % m:
+                    raise Exception("Proof invalid")
+                Vs = [V for group in Vs for V in group]
+            vbytes = b"".join([V.to_le64() for V in Vs])
         on_device = decompress is None and self._msm is None
         weights = seed = None
         if getattr(self, "_custom_rng", False):
             weights = b"".join(self._weight().to_bytes(32, "little") for _ in range(4 * count))
         else:
             seed = os.urandom(32)               # four 248-bit weights per proof are derived from it natively
-        offs = (ctypes.c_uint64 * (count + 1))(*offsets)
+        offs = offsets if isinstance(offsets, ctypes.Array) else (ctypes.c_uint64 * (count + 1))(*offsets)
+        if prepare == "auto":
+            prepare = "device" if on_device else "host"
+        if prepare == "device":
+            if not on_device:
+                raise ValueError("prepare='device' needs the default engine (no custom msm / decompress)")
+            return self._add_wire_device(vbytes, joined, offs, count, m, k, weights, seed)
         bufs = getattr(self, "_native_bufs", None)
         if bufs is None or bufs[0] != (count, m, npts):      # scratch of a previous call of the same shape is reused (no zero-fill)
             bufs = ((count, m, npts), (ctypes.c_char * (32 * count * m))(), (ctypes.c_char * (32 * npts))(),
@@ -285,6 +306,8 @@ class BatchRangeVerifier:
         bad = ctypes.c_int64(-1)
         if threads is None:
             threads = min(32, len(os.sched_getaffinity(0)))
+        if hasattr(joined, "ptr"):
+            joined = joined.view[:offsets[count]]
         jbuf = (ctypes.c_char * len(joined)).from_buffer_copy(joined) if isinstance(joined, memoryview) else joined
         rc = _native.load().bpmi_rp_batch_prepare(self.n, m, count, jbuf, len(joined), ctypes.cast(offs, ctypes.c_void_p), weights, seed, threads,
                                                   v_sc, p_sc, shared, comp, ctypes.cast(ctypes.pointer(bad), ctypes.c_void_p))
@@ -292,7 +315,6 @@ class BatchRangeVerifier:
             raise Exception("bpmi_rp_batch_prepare failed (%d)" % rc)
         if bad.value >= 0:
             raise Exception("Proof invalid")
-        vbytes = b"".join([V.to_le64() for V in Vs])
         if on_device:
             eng = _engine.default_engine()
             nv = count * m
@@ -315,7 +337,42 @@ class BatchRangeVerifier:
             self._raw_pts.append(pts)
             self._raw_scs.append(p_sc.raw)
             self._raw_count += count * m + npts
-        sh = shared.raw
+        self._absorb_shared(shared.raw, count)
+
+    def _add_wire_device(self, vbytes, joined, offs, count, m, k, weights, seed):
+        """add_wire_native with the preparation on the GPU: one call uploads the wire bytes, prepares every proof, decodes its
+        points into the batch's point array and returns the shared coefficients and the verdict."""
+        import ctypes
+        eng = _engine.default_engine()
+        nv, npts = count * m, count * (6 + 2 * k)
+        d_pts, d_scs = eng.alloc(64 * (nv + npts)), eng.alloc(32 * (nv + npts))
+        try:
+            d_pts.upload(vbytes)
+            shared = ctypes.create_string_buffer(32 * (5 + 2 * self.n))
+            bad = ctypes.c_int64(-1)
+            if isinstance(joined, bytes):
+                src = joined
+            elif hasattr(joined, "ptr"):                        # engine.HostBuffer: page-locked receive buffer
+                src = joined.ptr
+            else:
+                try:
+                    src = ctypes.addressof((ctypes.c_char * len(joined)).from_buffer(joined))
+                except TypeError:                               # read-only buffer
+                    src = bytes(joined)
+            nbytes = offs[count]
+            eng._ck(eng.lib.bpmi_rp_batch_prepare_dev(eng.ctx, self.n, m, count, src, nbytes, ctypes.cast(offs, ctypes.c_void_p), weights, seed,
+                                                      d_scs.ptr, d_scs.ptr + 32 * nv, d_pts.ptr + 64 * nv, shared,
+                                                      ctypes.cast(ctypes.pointer(bad), ctypes.c_void_p)))
+            if bad.value >= 0:
+                raise Exception("Proof invalid")
+        except BaseException:
+            d_pts.free()
+            d_scs.free()
+            raise
+        self._dev_chunks.append((d_pts, d_scs, nv + npts))
+        self._absorb_shared(shared.raw, count)
+
+    def _absorb_shared(self, sh, count):
         vals = [int.from_bytes(sh[32 * i: 32 * i + 32], "little") for i in range(5 + 2 * self.n)]
         self.c_g = (self.c_g + vals[0]) % Q
         self.c_h = (self.c_h + vals[1]) % Q

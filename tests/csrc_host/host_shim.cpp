@@ -5,6 +5,7 @@
 #include <string.h>
 #include "field.hpp"
 #include "curve.hpp"
+#include "scalar.hpp"
 using namespace bpmi;
 
 static void load_fe(fe &r, const uint8_t *b) { u32 w[8]; memcpy(w, b, 32); fe_from_words(r, w); }
@@ -50,6 +51,22 @@ void t_fe_raw(int op, const u32 *a, const u32 *b, const u32 *c, const u32 *d, u3
     default: fe_set_zero(r);
   }
   for (int k = 0; k < 9; k++) out[k] = r.v[k];
+}
+// arithmetic mod q (csrc/scalar.hpp) on canonical 32-byte little-endian values: op 0 mul, 1 add, 2 neg(a), 3 inv(a), 4 half(a),
+// 5 reduce_once(a)
+void t_sc_op(int op, const uint8_t *a, const uint8_t *b, uint8_t *out) {
+  sc x, y, r;
+  memcpy(x.v, a, 32); memcpy(y.v, b, 32);
+  switch (op) {
+    case 0: sc_mul(r, x, y); break;
+    case 1: sc_add(r, x, y); break;
+    case 2: sc_neg(r, x); break;
+    case 3: sc_inv(r, x); break;
+    case 4: r = x; sc_half(r); break;
+    case 5: r = x; sc_reduce_once(r); break;
+    default: memset(r.v, 0, 32);
+  }
+  memcpy(out, r.v, 32);
 }
 int t_fe_is_zero(const uint8_t *a, const uint8_t *b) {  // is a - b == 0 ?
   fe x, y; load_fe(x, a); load_fe(y, b);

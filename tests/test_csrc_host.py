@@ -31,7 +31,34 @@ def shim():
     L.t_xyzz_dbl_n.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p]
     L.t_jac_mul.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p]
     L.t_jac_madd_chain.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p]
+    L.t_sc_op.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p]
     return L
+
+
+def sc_op(L, op, a, b=0):
+    out = ctypes.create_string_buffer(32)
+    L.t_sc_op(op, a.to_bytes(32, "little"), b.to_bytes(32, "little"), out)
+    return int.from_bytes(out.raw, "little")
+
+
+def test_scalar_ops_mod_q(shim):
+    """csrc/scalar.hpp against Python integers: multiplication, addition, negation, halving and the binary-Euclid inverse
+    (the batch-preparation kernel's one inversion per proof) on edge values and random ones."""
+    q = secp256k1.q
+    rnd = random.Random(7)
+    edge = [0, 1, 2, 3, q - 1, q - 2, (q - 1) // 2, (q + 1) // 2, 2**128, 2**255 % q, 2**32 - 1, 2**64, (1 << 200) - 1,
+            0x14551231950B75FC4402DA1732FC9BEBF, q - 0x14551231950B75FC4402DA1732FC9BEBF]
+    vals = edge + [rnd.randrange(q) for _ in range(400)] + [rnd.randrange(2**40) for _ in range(20)] + [1 << k for k in range(0, 256, 7)]
+    for a in vals:
+        assert sc_op(shim, 2, a) == (-a) % q
+        assert sc_op(shim, 4, a) == a * pow(2, -1, q) % q
+        inv = sc_op(shim, 3, a)
+        assert inv == (pow(a, -1, q) if a else 0), hex(a)
+    for a, b in [(x, y) for x in edge for y in edge] + [(rnd.choice(vals), rnd.choice(vals)) for _ in range(2000)]:
+        assert sc_op(shim, 0, a, b) == a * b % q
+        assert sc_op(shim, 1, a, b) == (a + b) % q
+    for a in [q, q + 1, 2**256 - 1, 2**256 - 2, q - 1, 5]:
+        assert sc_op(shim, 5, a) == a % q
 
 
 def fe_op(L, op, a, b=0):

@@ -1,0 +1,251 @@
+"""bpmi_rp_batch_prepare_dev (csrc/rp_batch_kernels.hpp: parsing, SHA-256 transcript checks and the weighted scalars of the
+batch verifier, one GPU lane per proof) against its host twin bpmi_rp_batch_prepare (csrc/rp_batch_host.hpp, itself pinned to
+the Python / reference verifiers by tests/test_batch_native_cpu.py): same weights or seed in -> the same scalars, shared
+coefficients, decoded points and verdicts out, byte for byte."""
+import ctypes
+import hashlib
+import random
+
+import pytest
+
+import bulletproofs_amd  # noqa: F401
+from bulletproofs_amd import _native
+from bulletproofs_amd.rangeproofs.batch import BatchRangeVerifier
+from bulletproofs_amd.rangeproofs.codec import proof_to_bytes
+
+from helpers import Q
+from test_batch_verify_cpu import make_batch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from bulletproofs_amd.engine import default_engine
+    return default_engine()
+
+
+def offsets_of(blobs):
+    offs = [0]
+    for x in blobs:
+        offs.append(offs[-1] + len(x))
+    return offs
+
+
+def host_prepare(n, m, blobs, weights, seed, offs=None):
+    lib = _native.load()
+    count = len(blobs) if offs is None else len(offs) - 1
+    joined = b"".join(blobs) if offs is None else blobs
+    offs = offsets_of(blobs) if offs is None else offs
+    k = n.bit_length() - 1
+    npts = count * (6 + 2 * k)
+    o = (ctypes.c_uint64 * (count + 1))(*offs)
+    v_sc, p_sc = ctypes.create_string_buffer(32 * count * m), ctypes.create_string_buffer(32 * npts)
+    shared, comp = ctypes.create_string_buffer(32 * (5 + 2 * n)), ctypes.create_string_buffer(33 * npts)
+    bad = ctypes.c_int64(-1)
+    rc = lib.bpmi_rp_batch_prepare(n, m, count, joined, len(joined), ctypes.cast(o, ctypes.c_void_p), weights, seed, 2, v_sc, p_sc, shared, comp,
+                                   ctypes.cast(ctypes.pointer(bad), ctypes.c_void_p))
+    return rc, bad.value, v_sc.raw, p_sc.raw, shared.raw, comp.raw
+
+
+def dev_prepare(eng, n, m, blobs, weights, seed, offs=None):
+    count = len(blobs) if offs is None else len(offs) - 1
+    joined = b"".join(blobs) if offs is None else blobs
+    offs = offsets_of(blobs) if offs is None else offs
+    k = n.bit_length() - 1
+    npts = count * (6 + 2 * k)
+    o = (ctypes.c_uint64 * (count + 1))(*offs)
+    d_v, d_p, d_pts = eng.alloc(32 * count * m), eng.alloc(32 * npts), eng.alloc(64 * npts)
+    shared = ctypes.create_string_buffer(32 * (5 + 2 * n))
+    bad = ctypes.c_int64(-1)
+    try:
+        rc = eng.lib.bpmi_rp_batch_prepare_dev(eng.ctx, n, m, count, joined, len(joined), ctypes.cast(o, ctypes.c_void_p), weights, seed, d_v.ptr, d_p.ptr,
+                                               d_pts.ptr, shared, ctypes.cast(ctypes.pointer(bad), ctypes.c_void_p))
+        return rc, bad.value, d_v.download(), d_p.download(), shared.raw, d_pts.download()
+    finally:
+        for d in (d_v, d_p, d_pts):
+            d.free()
+
+
+def assert_same(eng, n, m, blobs, weights, seed):
+    h = host_prepare(n, m, blobs, weights, seed)
+    d = dev_prepare(eng, n, m, blobs, weights, seed)
+    assert h[0] == 0 and d[0] == 0 and h[1] == -1 and d[1] == -1
+    assert d[2] == h[2], "V scalars"
+    assert d[3] == h[3], "per-proof point scalars"
+    assert d[4] == h[4], "shared coefficients"
+    npts = len(h[5]) // 33
+    pts, ok = eng.ec_decompress_batch_bytes(h[5], npts)
+    assert 0 not in ok and d[5] == pts, "decoded points"
+
+
+@pytest.mark.parametrize("n", [2, 8, 64])
+def test_device_prepare_equals_host_prepare(eng, n):
+    b = make_batch(7, n=n)
+    blobs = [proof_to_bytes(pr) for pr in b["proofs"]]
+    rnd = random.Random(n)
+    weights = b"".join(rnd.randrange(1, Q).to_bytes(32, "little") for _ in range(4 * 7))
+    assert_same(eng, n, 1, blobs, weights, None)
+    assert_same(eng, n, 1, blobs, None, bytes(range(32)))
+    # weights >= q are reduced on both sides
+    big = b"".join((Q + rnd.randrange(1, 2 ** 100)).to_bytes(32, "little") for _ in range(4 * 7))
+    assert_same(eng, n, 1, blobs, big, None)
+
+
+def test_seed_weights_match_the_published_derivation(eng):
+    b = make_batch(5, n=8)
+    blobs = [proof_to_bytes(pr) for pr in b["proofs"]]
+    seed = hashlib.sha256(b"seed").digest()
+    derived = b""
+    for g in range(5):
+        for t in range(4):
+            dg = bytearray(hashlib.sha256(seed + g.to_bytes(8, "little") + bytes([t])).digest())
+            dg[31] = 0
+            derived += bytes(dg)
+    a = dev_prepare(eng, 8, 1, blobs, None, seed)
+    c = dev_prepare(eng, 8, 1, blobs, derived, None)
+    assert a[0] == 0 and a[1] == -1 and a == c
+
+
+@pytest.mark.parametrize("m,bits", [(2, 4), (4, 8), (1, 8)])
+def test_device_prepare_aggregated(eng, m, bits):
+    from oracle import bp_ref as R
+    from oracle import cbind
+    from helpers import gens
+    from test_batch_verify_cpu import convert_proof
+    nm = m * bits
+    gs, hs = gens(nm, b"ags"), gens(nm, b"ahs")
+    g, h, u = (R.elliptic_hash(s) for s in (b"ag", b"ah", b"au"))
+    rnd = random.Random(m * 100 + bits)
+    proofs = []
+    for k in range(3):
+        vs = [R.Zq(rnd.randrange(2 ** bits), Q) for _ in range(m)]
+        gammas = [R.mod_hash(b"ga%d-%d" % (k, j), Q) for j in range(m)]
+        proofs.append(convert_proof(R.aggreg_range_prove(vs, bits, g, h, gs, hs, gammas, u, seed=b"as%d" % k, multiexp=cbind.msm)))
+    blobs = [proof_to_bytes(pr) for pr in proofs]
+    weights = b"".join(rnd.randrange(1, Q).to_bytes(32, "little") for _ in range(12))
+    assert_same(eng, nm, m, blobs, weights, None)
+    assert_same(eng, nm, m, blobs, None, b"\x07" * 32)
+
+
+def test_many_proofs_any_lane_count_and_launch_size(eng):
+    """300 proofs (7 distinct ones repeated; the seed weights differ per index): the result does not depend on how many proofs a
+    wave takes or on how many go into one launch."""
+    b = make_batch(7, n=8)
+    base = [proof_to_bytes(pr) for pr in b["proofs"]]
+    blobs = [base[i % 7] for i in range(300)]
+    seed = b"\x21" * 32
+    want = host_prepare(8, 1, blobs, None, seed)
+    try:
+        for lanes, rows in ((0, 0), (1, 0), (64, 0), (16, 37), (0, 128)):
+            eng.set_option("rp_lanes", lanes)
+            eng.set_option("rp_rows", rows)
+            got = dev_prepare(eng, 8, 1, blobs, None, seed)
+            assert got[:5] == want[:5], (lanes, rows)
+    finally:
+        eng.set_option("rp_lanes", 0)
+        eng.set_option("rp_rows", 0)
+
+
+def test_corrupted_proofs_same_verdict_as_host(eng):
+    """Single-bit flips anywhere in a proof, truncation, trailing bytes, garbage: the device reports the same first failing
+    proof as the host twin (point encodings are judged by the decompression on both sides)."""
+    b = make_batch(4, n=8)
+    blobs = [proof_to_bytes(pr) for pr in b["proofs"]]
+    k = 3
+    ints_end = 6 + 32 * (5 + k)
+    pts_end = ints_end + 33 * (6 + 2 * k)
+    rnd = random.Random(11)
+    w = b"".join(rnd.randrange(1, Q).to_bytes(32, "little") for _ in range(16))
+    rejected = 0
+    for trial in range(160):
+        j = rnd.randrange(4)
+        bad = bytearray(blobs[j])
+        kind = rnd.choice(("scalar", "point", "transcript", "header", "tail", "truncate", "extend", "garbage", "two"))
+        if kind == "scalar":
+            bad[rnd.randrange(6, ints_end)] ^= 1 << rnd.randrange(8)
+        elif kind == "point":
+            bad[rnd.randrange(ints_end, pts_end)] ^= 1 << rnd.randrange(8)
+        elif kind == "transcript":
+            bad[rnd.randrange(pts_end, len(bad))] ^= 1 << rnd.randrange(8)
+        elif kind == "header":
+            bad[rnd.randrange(0, 6)] ^= 1 << rnd.randrange(8)
+        elif kind == "tail":
+            bad[len(bad) - 1 - rnd.randrange(0, 40)] ^= 1 << rnd.randrange(8)
+        elif kind == "truncate":
+            del bad[rnd.randrange(0, len(bad)):]
+        elif kind == "extend":
+            bad += bytes(rnd.randrange(256) for _ in range(rnd.randrange(1, 9)))
+        elif kind == "garbage":
+            bad = bytearray(rnd.randrange(256) for _ in range(rnd.randrange(0, 700)))
+        mutated = blobs[:j] + [bytes(bad)] + blobs[j + 1:]
+        if kind == "two":                                  # two bad proofs: the smaller index is reported
+            j2 = rnd.randrange(4)
+            b2 = bytearray(mutated[j2])
+            b2[rnd.randrange(6, ints_end)] ^= 0x10
+            mutated[j2] = bytes(b2)
+            b3 = bytearray(mutated[3])
+            b3[-1] ^= 1
+            mutated[3] = bytes(b3)
+        h = host_prepare(8, 1, mutated, w, None)
+        d = dev_prepare(eng, 8, 1, mutated, w, None)
+        assert h[0] == 0 and d[0] == 0
+        host_bad = h[1]
+        if host_bad < 0:                                   # the host twin leaves point encodings to the decompression
+            _, ok = eng.ec_decompress_batch_bytes(h[5], len(h[5]) // 33)
+            if 0 in ok:
+                host_bad = ok.index(0) // (6 + 2 * k)
+        assert d[1] == host_bad, (trial, kind, d[1], host_bad)
+        rejected += d[1] >= 0
+    assert rejected >= 140          # a flip inside a point's x can give another valid point: those fail in the MSM instead
+
+
+def test_offset_table_is_checked(eng):
+    b = make_batch(2, n=8)
+    blobs = [proof_to_bytes(pr) for pr in b["proofs"]]
+    joined = b"".join(blobs)
+    w = bytes([1] + [0] * 31) * 8
+    good = [0, len(blobs[0]), len(joined)]
+    assert dev_prepare(eng, 8, 1, joined, w, None, offs=good)[:2] == (0, -1)
+    assert dev_prepare(eng, 8, 1, joined[:-1], w, None, offs=good)[0] == -3
+    assert dev_prepare(eng, 8, 1, joined, w, None, offs=[0, len(joined) + 5, len(joined)])[0] == -3
+    assert dev_prepare(eng, 8, 1, joined, w, None, offs=[len(blobs[0]), 0, len(joined)])[0] == -3
+    rc, first_bad = dev_prepare(eng, 8, 1, joined, w, None, offs=[0, len(blobs[0]) - 7, len(joined)])[:2]
+    assert rc == 0 and first_bad == 0
+    assert dev_prepare(eng, 8, 1, joined, None, None, offs=good)[0] == -3      # neither weights nor seed
+    assert dev_prepare(eng, 12, 1, joined, w, None, offs=good)[0] == -3        # n_gens not a power of two
+
+
+def test_batch_verifier_end_to_end_on_the_device(eng):
+    b = make_batch(9, n=8)
+    blobs = [proof_to_bytes(pr) for pr in b["proofs"]]
+    for prepare in ("device", "host", "auto"):
+        bv = BatchRangeVerifier(b["g"], b["h"], b["gs"], b["hs"], b["u"])
+        bv.add_wire_native(b["Vs"], blobs, prepare=prepare)
+        bv.add_wire_native(b["Vs"][:4], blobs[:4], prepare=prepare)          # a second chunk in the same batch
+        assert bv.verify() is True
+        bv.reset()
+    # receive-buffer form: one bytearray + offsets
+    bv = BatchRangeVerifier(b["g"], b["h"], b["gs"], b["hs"], b["u"])
+    bv.add_wire_native(b["Vs"], bytearray(b"".join(blobs)), offsets=offsets_of(blobs), prepare="device")
+    assert bv.verify() is True
+    # page-locked receive buffer + commitments already packed as 64-byte points
+    joined = b"".join(blobs)
+    hb = eng.host_alloc(len(joined) + 100)
+    hb.view[:len(joined)] = joined
+    for prepare in ("device", "host"):
+        bv = BatchRangeVerifier(b["g"], b["h"], b["gs"], b["hs"], b["u"])
+        bv.add_wire_native(b"".join(V.to_le64() for V in b["Vs"]), hb, offsets=offsets_of(blobs), prepare=prepare)
+        assert bv.verify() is True
+        bv.reset()
+    hb.free()
+    # a wrong commitment passes the preparation and fails the MSM; a wrong transcript byte fails the preparation
+    bv = BatchRangeVerifier(b["g"], b["h"], b["gs"], b["hs"], b["u"])
+    bv.add_wire_native([b["Vs"][1]] + b["Vs"][1:], blobs, prepare="device")
+    with pytest.raises(Exception, match="Proof invalid"):
+        bv.verify()
+    bad = bytearray(blobs[5])
+    bad[-3] ^= 2
+    bv = BatchRangeVerifier(b["g"], b["h"], b["gs"], b["hs"], b["u"])
+    with pytest.raises(Exception, match="Proof invalid"):
+        bv.add_wire_native(b["Vs"], blobs[:5] + [bytes(bad)] + blobs[6:], prepare="device")

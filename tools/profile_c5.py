@@ -35,18 +35,28 @@ wire_buf = b"".join(blobs)
 wire_off = [0, *accumulate(map(len, blobs))]
 import cProfile
 import pstats
+PREPARE = os.environ.get("C5_PREPARE", "auto")          # device | host | auto
+if os.environ.get("C5_LANES"):
+    eng.set_option("rp_lanes", int(os.environ["C5_LANES"]))
+if PREPARE != "host":
+    eng.profile(1)
 for rep in range(3):
     bv = BatchRangeVerifier(g, h, gs, hs, u)
     t0 = time.perf_counter()
     if rep == 2:
         pr = cProfile.Profile()
         pr.enable()
-    bv.add_wire_native(Vs, wire_buf, threads=threads, offsets=wire_off)
+    bv.add_wire_native(Vs, wire_buf, threads=threads, offsets=wire_off, prepare=PREPARE)
     t1 = time.perf_counter()
     ok = bv.verify()
     t2 = time.perf_counter()
     if rep == 2:
         pr.disable()
     bv.reset()
+    print("prepare=%s" % PREPARE, end=" ")
     print("rep %d: add_wire_native %.2f ms, verify %.2f ms, ok=%s, threads=%d" % (rep, (t1 - t0) * 1e3, (t2 - t1) * 1e3, ok, threads))
 pstats.Stats(pr).sort_stats("cumulative").print_stats(18)
+if PREPARE != "host":
+    for name, (ms, cnt) in eng.profile_read().items():
+        if cnt:
+            print("  stage %-12s %8.3f ms over %d launches" % (name, ms, cnt))
