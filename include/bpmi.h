@@ -71,8 +71,9 @@ int bpmi_sync(bpmi_ctx *ctx);
  *   "async_lanes"  1: slot 1 of bpmi_msm_dev_enqueue runs on the ctx's second lane (own stream and workspace), so
  *                  the tail stages of one MSM overlap the sort / accumulate of the next (inputs must be complete
  *                  before the first enqueue of a burst; default 0)
- *   "rp_lanes"     bpmi_rp_batch_prepare_dev: proofs per 64-lane wave (power of two; 0 = chosen so that a batch fills the
- *                  chip's SIMDs: a wave costs the same whatever its active-lane count)
+ *   "rp_lanes"     bpmi_rp_batch_prepare_dev: proofs per 64-lane wave (power of two; 0 = 64, the fastest measured)
+ *   "rp_only_role" profiling only: 0 / 1 runs just the transcript / the algebra role of the preparation kernel (the call then
+ *                  verifies nothing); -1 (default) both
  *   "rp_rows"      bpmi_rp_batch_prepare_dev: proofs per kernel launch (0 = as many as fit ~256 MB of scratch cells)
  *   "ipa_big_m"    base length from which the IPA prover folds its generators 16-way at
  *                  once instead of deferring the fold into the MSM scalars (default 2^18) */

@@ -126,6 +126,7 @@ int bpmi_set_option(bpmi_ctx *ctx, const char *name, int64_t value) {
   if (!strcmp(name, "small_n")) { if (value < -1 || value > (1 << 16)) return fail(ctx, BPMI_E_ARG, "small_n must be -1 .. 65536"); ctx->opt_small = (int)value; return BPMI_OK; }
   if (!strcmp(name, "split")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "split must be 0 or 1"); ctx->opt_split = (int)value; return BPMI_OK; }
   if (!strcmp(name, "async_lanes")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "async_lanes must be 0 or 1"); ctx->opt_async_lanes = (int)value; return BPMI_OK; }
+  if (!strcmp(name, "rp_only_role")) { if (value < -1 || value > 1) return fail(ctx, BPMI_E_ARG, "rp_only_role must be -1, 0 or 1"); ctx->opt_rp_only_role = (int)value; return BPMI_OK; }
   if (!strcmp(name, "rp_rows")) { if (value < 0) return fail(ctx, BPMI_E_ARG, "rp_rows must be >= 0"); ctx->opt_rp_rows = (int)value; return BPMI_OK; }
   if (!strcmp(name, "rp_lanes")) {
     if (value != 0 && (value < 1 || value > 64 || (value & (value - 1)))) return fail(ctx, BPMI_E_ARG, "rp_lanes must be 0 or a power of two <= 64");
@@ -1060,30 +1061,30 @@ int bpmi_rp_batch_prepare_dev(bpmi_ctx *ctx, uint32_t n_gens, uint32_t values_pe
   HIPCHK(ctx, hipMemcpyAsync(din + o_off, blob_off, 8 * ((size_t)P + 1), hipMemcpyHostToDevice, ctx->stream));
   if (weights) HIPCHK(ctx, hipMemcpyAsync(din + o_w, weights, 128 * (size_t)P, hipMemcpyHostToDevice, ctx->stream));
   // contributions: at most ~256 MB of cells per launch
-  const size_t cell_row = 32 * (size_t)ncols;
+  const size_t cell_row = 36 * (size_t)ncols, out_row = 32 * (size_t)ncols;       // scratch cells are 9 limbs, the result 8 words
   u32 rows = (u32)std::min<size_t>(P, std::max<size_t>(1, ((size_t)256 << 20) / cell_row));
   if (ctx->opt_rp_rows > 0) rows = std::min<u32>(rows, (u32)ctx->opt_rp_rows);
-  const size_t need = cell_row * rows + cell_row + 256;
+  const size_t need = align_up(cell_row * rows, 256) + out_row + 256;
   if (need > ctx->rp_buf_bytes) {
     if (ctx->rp_buf) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(ctx->rp_buf)); ctx->rp_buf = nullptr; ctx->rp_buf_bytes = 0; }
     HIPCHK(ctx, hipMalloc(&ctx->rp_buf, need));
     ctx->rp_buf_bytes = need;
   }
-  u32 *d_contrib = (u32 *)ctx->rp_buf, *d_shared = d_contrib + 8 * (size_t)ncols * rows;
+  u32 *d_contrib = (u32 *)ctx->rp_buf, *d_shared = (u32 *)((char *)ctx->rp_buf + align_up(cell_row * rows, 256));
   unsigned long long *d_bad = (unsigned long long *)(d_shared + 8 * (size_t)ncols);
-  HIPCHK(ctx, hipMemsetAsync(d_shared, 0, cell_row, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(d_shared, 0, out_row, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(d_bad, 0xFF, 8, ctx->stream));
   rpd::Params q;
   q.blobs = (const uint8_t *)din;
   q.weights = weights ? (const uint8_t *)(din + o_w) : nullptr;
   for (int i = 0; i < 8; i++) q.seed[i] = seed ? ((u32)seed[4 * i] << 24) | ((u32)seed[4 * i + 1] << 16) | ((u32)seed[4 * i + 2] << 8) | seed[4 * i + 3] : 0;
-  q.n = n_gens; q.k = k; q.m = m; q.Pall = P;
+  q.n = n_gens; q.k = k; q.m = m; q.Pall = P; q.only_role = ctx->opt_rp_only_role;
   q.contrib = d_contrib;
   q.bad = d_bad;
   for (u32 base = 0; base < P; base += rows) {
     const u32 cnt = std::min(rows, P - base);
     u32 lanes = (u32)ctx->opt_rp_lanes;
-    if (!lanes) { lanes = 64; while (lanes > 8 && (cnt + lanes - 1) / lanes < 2048) lanes >>= 1; }
+    if (!lanes) lanes = 64;
     q.off = (const u64 *)(din + o_off) + base;
     q.P = cnt; q.lanes = lanes; q.first = base;
     q.v_scalars = (u32 *)d_v_scalars + 8 * (size_t)base * m;
@@ -1101,13 +1102,13 @@ int bpmi_rp_batch_prepare_dev(bpmi_ctx *ctx, uint32_t n_gens, uint32_t values_pe
                        (const uint8_t *)(din + o_st), k, P, (u64)0, (u32 *)d_points, d_bad);
   }
   HIPCHK(ctx, hipGetLastError());
-  rc = ensure_pin(ctx, cell_row + 64);
+  rc = ensure_pin(ctx, out_row + 64);
   if (rc) return rc;
-  HIPCHK(ctx, hipMemcpyAsync(ctx->pin, d_shared, cell_row + 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(ctx->pin, d_shared, out_row + 8, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  memcpy(shared, ctx->pin, cell_row);
+  memcpy(shared, ctx->pin, out_row);
   unsigned long long bad;
-  memcpy(&bad, (char *)ctx->pin + cell_row, 8);
+  memcpy(&bad, (char *)ctx->pin + out_row, 8);
   *first_bad = bad == ~0ull ? -1 : (int64_t)bad;
   return BPMI_OK;
 }

@@ -5,16 +5,19 @@
 // the batch's one MSM.  It is the device twin of rp_batch_host.hpp (same checks, same numbers: tests/test_gpu_batch_dev.py
 // compares the two byte for byte on the same weights); see that file for what each check means.
 //
-// Layout: the (5 + 2n) shared-generator contributions of proof g live at contrib[(col * P + g) * 8 words] (column-major
-// over proofs: lanes of a wave touch neighbouring 32-byte cells), summed over g by k_rp_colsum.  The s-vector doubling
+// Layout: the (5 + 2n) shared-generator contributions of proof g live in cells (col, g) of nine 29-bit limbs, limb-major
+// (contrib[(col * 9 + limb) * P + g]: the lanes of a wave touch neighbouring dwords), summed over g by k_rp_colsum.  The s-vector doubling
 // works in place inside those columns, so a lane needs no O(n) private memory.
-// Occupancy: a batch has ~2^14 proofs but the chip has 1024 SIMDs; the launch gives every wave only `lanes` proofs
-// (8..64) so that all SIMDs get work -- the instruction stream per wave costs the same whatever its active-lane count.
+// Occupancy: a wave's run time here is a latency chain (~1 ms: dependent multiply-adds, memory round trips) that does not
+// depend on how many of its lanes are active, and 2^14 proofs are only 2 x 256 full waves on 1024 SIMDs -- so full waves
+// (`lanes` = 64, the default) are the fastest launch; fewer proofs per wave only multiply the per-wave scratch and
+// instruction-cache traffic (measured: 32 the same, 16 x1.6, 8 x5.5; profiles/r02_C5_prepare_kernel.txt).
 #pragma once
 
 namespace rpd {
 
 using bpmi::sc;
+using bpmi::sq;
 using bpmi::u32;
 using bpmi::u64;
 
@@ -83,9 +86,32 @@ __device__ __noinline__ void sha_byte(Sha &s, u32 b) {          // odd bytes (pr
   sha_byte_inl(t, b);
   s = t;
 }
+// Unaligned 8-byte load.  Byte-at-a-time loops over proof data pay one memory round trip (~0.3 us, nothing else in the wave
+// to hide it) per byte; everything below that walks the wire bytes fetches eight at a time.  The load may cover up to 7 bytes
+// beyond the item it is used for: the staged batch has 64 bytes of slack after the last proof, and bytes outside the item
+// are never interpreted.
+__device__ __forceinline__ u64 ld8(const uint8_t *p) { u64 w; __builtin_memcpy(&w, p, 8); return w; }
+__device__ __forceinline__ void sha_word_inl(Sha &s, u32 w) {            // four bytes at a word boundary of the message
+#pragma unroll
+  for (int i = 0; i < 15; i++) s.w[i] = s.w[i + 1];
+  s.w[15] = w;
+  s.fill += 4;
+  s.len += 4;
+  if (s.fill == 64u) { sha_compress(s); s.fill = 0; }
+}
 __device__ __noinline__ void sha_update(Sha &s, const uint8_t *p, u32 n) {
   Sha t = s;
-  for (u32 i = 0; i < n; i++) sha_byte_inl(t, p[i]);
+  u32 i = 0;
+  while (i < n && (t.fill & 3u)) sha_byte_inl(t, p[i++]);                // up to the next word boundary of the message
+  for (; i + 8 <= n; i += 8) {
+    const u64 x = ld8(p + i);
+    sha_word_inl(t, __builtin_bswap32((u32)x));
+    sha_word_inl(t, __builtin_bswap32((u32)(x >> 32)));
+  }
+  if (i < n) {
+    const u64 x = ld8(p + i);
+    for (u32 j = 0; i < n; i++, j++) sha_byte_inl(t, (u32)(x >> (8 * j)) & 0xFFu);
+  }
   s = t;
 }
 // digest of a COPY of the state (the caller's state can go on absorbing), as the big-endian number it spells, and
@@ -128,40 +154,49 @@ __device__ __forceinline__ u32 b64_char(u32 v) {
   return v < 26 ? 'A' + v : v < 52 ? 'a' + (v - 26) : v < 62 ? '0' + (v - 52) : v == 62 ? '+' : '/';
 }
 // does the item [p, p + n) spell base64(encoding of the point)?  33 zero bytes in the wire format = identity = b"\x00"
+__device__ __forceinline__ u32 byte_of(const u64 w[], int i) { return (u32)(w[i >> 3] >> (8 * (i & 7))) & 0xFFu; }
 __device__ __noinline__ bool point_item_equals(const uint8_t *comp, const uint8_t *p, u32 n) {
-  u32 any = 0;
-  for (int i = 0; i < 33; i++) any |= comp[i];
-  if (!any) return n == 4 && p[0] == 'A' && p[1] == 'A' && p[2] == '=' && p[3] == '=';
+  u64 c[5], t[6];
+#pragma unroll
+  for (int i = 0; i < 5; i++) c[i] = ld8(comp + 8 * i);
+#pragma unroll
+  for (int i = 0; i < 6; i++) t[i] = ld8(p + 8 * i);
+  if (!(c[0] | c[1] | c[2] | c[3] | (c[4] & 0xFFu))) return n == 4 && (u32)t[0] == 0x3D3D4141u;      // "AA=="
   if (n != 44) return false;
   bool same = true;
+#pragma unroll
   for (int i = 0; i < 11; i++) {
-    const u32 v = ((u32)comp[3 * i] << 16) | ((u32)comp[3 * i + 1] << 8) | comp[3 * i + 2];
-    same &= p[4 * i] == b64_char((v >> 18) & 63) && p[4 * i + 1] == b64_char((v >> 12) & 63) && p[4 * i + 2] == b64_char((v >> 6) & 63) &&
-            p[4 * i + 3] == b64_char(v & 63);
+    const u32 v = (byte_of(c, 3 * i) << 16) | (byte_of(c, 3 * i + 1) << 8) | byte_of(c, 3 * i + 2);
+    same &= byte_of(t, 4 * i) == b64_char((v >> 18) & 63) && byte_of(t, 4 * i + 1) == b64_char((v >> 12) & 63) &&
+            byte_of(t, 4 * i + 2) == b64_char((v >> 6) & 63) && byte_of(t, 4 * i + 3) == b64_char(v & 63);
   }
   return same;
 }
-// canonical decimal -> value mod q (false: not canonical decimal, or >= 2^256); nine digits per multiplication pass
+// canonical decimal -> value mod q (false: not canonical decimal, or >= 2^256); eight digits per load and multiplication pass
 __device__ __noinline__ bool parse_decimal(sc &r, const uint8_t *p, u32 n) {
   if (n == 0 || n > 78 || (n > 1 && p[0] == '0')) return false;
   u32 t[9];
 #pragma unroll
   for (int k = 0; k < 9; k++) t[k] = 0;
-  u32 i = 0, take = n % 9u;
-  if (take == 0) take = 9;
+  u32 i = 0, take = n & 7u;
+  if (take == 0) take = 8;
+  bool digits = true;
   while (i < n) {
-    u32 val = 0;
+    const u64 x = ld8(p + i);
+    u32 val = 0, scale = 1;
     for (u32 j = 0; j < take; j++) {
-      const u32 d = (u32)p[i++] - '0';
-      if (d > 9u) return false;
+      const u32 d = ((u32)(x >> (8 * j)) & 0xFFu) - '0';
+      digits &= d <= 9u;
       val = val * 10u + d;
+      scale *= 10u;
     }
+    i += take;
     u64 c = val;
 #pragma unroll
-    for (int k = 0; k < 9; k++) { c += (u64)t[k] * 1000000000u; t[k] = (u32)c; c >>= 32; }
-    take = 9;
+    for (int k = 0; k < 9; k++) { c += (u64)t[k] * scale; t[k] = (u32)c; c >>= 32; }
+    take = 8;
   }
-  if (t[8]) return false;
+  if (!digits || t[8]) return false;
 #pragma unroll
   for (int k = 0; k < 8; k++) r.v[k] = t[k];
   bpmi::sc_reduce_once(r);
@@ -169,9 +204,10 @@ __device__ __noinline__ bool parse_decimal(sc &r, const uint8_t *p, u32 n) {
 }
 __device__ __forceinline__ bool sc_from_be(sc &r, const uint8_t *b) {          // 32 bytes big-endian; false when >= q
 #pragma unroll
-  for (int i = 0; i < 8; i++) {
-    const uint8_t *q = b + 28 - 4 * i;
-    r.v[i] = ((u32)q[0] << 24) | ((u32)q[1] << 16) | ((u32)q[2] << 8) | q[3];
+  for (int j = 0; j < 4; j++) {
+    const u64 x = __builtin_bswap64(ld8(b + 8 * j));
+    r.v[7 - 2 * j] = (u32)(x >> 32);
+    r.v[6 - 2 * j] = (u32)x;
   }
   const u32 qq[8] = BPMI_SC_Q;
   u32 t[8];
@@ -195,6 +231,19 @@ __device__ __forceinline__ void mulq(sc &r, const sc &a, const sc &b) { r = mulq
 __device__ __forceinline__ void addq(sc &r, const sc &a, const sc &b) { bpmi::sc_add(r, a, b); }
 __device__ __forceinline__ void negq(sc &r, const sc &a) { bpmi::sc_neg(r, a); }
 __device__ __forceinline__ void subq(sc &r, const sc &a, const sc &b) { sc t; bpmi::sc_neg(t, b); bpmi::sc_add(r, a, t); }
+// mod-q arithmetic of the algebra role: 9 x 29-bit limbs (scalar.hpp "sq").  The multiplication is the one out-of-line routine
+// (~270 instructions, ~70 call sites); its operands travel in registers: one struct (9 words) plus nine scalars -- two
+// structs would exceed the 16 registers the ABI gives to aggregate arguments and the second would go through scratch.
+__device__ __noinline__ sq mq_v(const sq a, u32 b0, u32 b1, u32 b2, u32 b3, u32 b4, u32 b5, u32 b6, u32 b7, u32 b8) {
+  const sq b = {{b0, b1, b2, b3, b4, b5, b6, b7, b8}};
+  sq r;
+  bpmi::sq_mul(r, a, b);
+  return r;
+}
+__device__ __forceinline__ void mq(sq &r, const sq &a, const sq &b) { r = mq_v(a, b.v[0], b.v[1], b.v[2], b.v[3], b.v[4], b.v[5], b.v[6], b.v[7], b.v[8]); }
+__device__ __forceinline__ sq to_sq(const sc &a) { sq r; bpmi::sq_from_sc(r, a); return r; }
+__device__ __noinline__ sc to_sc(const sq a) { sc r; bpmi::sq_to_sc(r, a); return r; }
+__device__ __forceinline__ void store_canon(u32 *p, const sq &a) { const sc c = to_sc(a); ::store_words8(p, c.v); }
 __device__ __noinline__ sc invq_v(const sc a) { sc r; bpmi::sc_inv(r, a); return r; }        // binary extended Euclid (scalar.hpp)
 __device__ __forceinline__ void invq(sc &r, const sc &a) { r = invq_v(a); }
 
@@ -206,10 +255,15 @@ struct Walk {
   bool have;      // there is a current item
 };
 __device__ __forceinline__ void walk_init(Walk &w, const uint8_t *p, u32 n) { w.p = p; w.n = n; w.pos = 0; w.have = true; }
-__device__ __forceinline__ u32 walk_end(const Walk &w) {        // end of the current item
+__device__ __forceinline__ u32 walk_end(const Walk &w) {        // end of the current item: the next '&' or the end of the transcript
   u32 e = w.pos;
-  while (e < w.n && w.p[e] != '&') e++;
-  return e;
+  while (e < w.n) {
+    const u64 x = ld8(w.p + e) ^ 0x2626262626262626ull;                                      // '&' bytes become zero
+    const u64 z = (x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull;               // lowest set bit marks the FIRST zero byte
+    if (z) { e += (u32)__builtin_ctzll(z) >> 3; break; }
+    e += 8;
+  }
+  return e < w.n ? e : w.n;
 }
 __device__ __forceinline__ void walk_next(Walk &w, u32 e) { w.have = e < w.n; w.pos = e + 1; }   // e = walk_end(w)
 
@@ -219,30 +273,47 @@ struct Params {
   const uint8_t *weights;    // P x 4 x 32 bytes, or null: derived from `seed`
   u32 seed[8];               // the 32 seed bytes as big-endian words
   u32 n, k, m, P, lanes;     // P: proofs of this launch
+  int only_role;             // profiling: -1 both roles (product), 0 / 1 = run only that role (the other reports success)
   u32 Pall;                  // proofs of the whole call (the two status arrays are Pall bytes apart)
   u64 first;                 // index of proof 0 of this launch inside the whole batch (seed weights depend on it)
-  u32 *contrib;              // (5 + 2n) x P cells of 8 words
+  u32 *contrib;              // (5 + 2n) x P cells of 9 limbs, limb-major (see cell_load)
   u32 *v_scalars, *pt_scalars;
   uint8_t *status;           // [g] verdict of the transcript role, [Pall + g] of the algebra role (1 = passed); points at this launch's proof 0
   unsigned long long *bad;   // atomicMin of the failing proof indices (whole-batch numbering)
 };
 
-__device__ __forceinline__ u32 *cell(const Params &q, u32 col, u32 g) { return q.contrib + ((size_t)col * q.P + g) * 8; }
-__device__ __forceinline__ void cell_load(sc &r, const Params &q, u32 col, u32 g) { ::load_words8(r.v, cell(q, col, g)); }
-__device__ __forceinline__ void cell_store(const Params &q, u32 col, u32 g, const sc &a) { ::store_words8(cell(q, col, g), a.v); }
+// cell (col, g) = 9 limbs of a loose sq; limb w lives at contrib[(col * 9 + w) * P + g]: every access of a wave is one
+// coalesced row of dwords
+typedef __attribute__((address_space(1))) u32 gu32;              // known-global pointer: global_load / global_store, not flat
+struct Cells { gu32 *base; size_t P; };                          // base = contrib + g
+__device__ __forceinline__ Cells cells_of(const Params &q, u32 g) { Cells c; c.base = (gu32 *)q.contrib + g; c.P = q.P; return c; }
+__device__ __forceinline__ void cell_load(sq &r, const Cells &c, u32 col) {
+  const gu32 *p = c.base + (size_t)col * 9 * c.P;
+#pragma unroll
+  for (int w = 0; w < 9; w++) r.v[w] = p[w * c.P];
+}
+__device__ __forceinline__ void cell_store(const Cells &c, u32 col, const sq &a) {
+  gu32 *p = c.base + (size_t)col * 9 * c.P;
+#pragma unroll
+  for (int w = 0; w < 9; w++) p[w * c.P] = a.v[w];
+}
 
-// SHA-256(seed || LE64(g) || t) with byte 31 cleared, read little-endian; 0 -> 1   (rp::derive_weight)
+// SHA-256(seed || LE64(g) || t) with byte 31 cleared, read little-endian; 0 -> 1   (rp::derive_weight).  The 41-byte message
+// is one padded block, built in place: 8 seed words, g, t and the 0x80 marker, zeros, the bit length 328.
 __device__ __noinline__ void derive_weight(sc &w, const u32 seed[8], u64 g, u32 t) {
   Sha s;
   sha_init(s);
-  for (int i = 0; i < 8; i++) for (int b = 3; b >= 0; b--) sha_byte(s, (seed[i] >> (8 * b)) & 0xFFu);
-  for (int i = 0; i < 8; i++) sha_byte(s, (u32)(g >> (8 * i)) & 0xFFu);
-  sha_byte(s, t);
-  sc d;
-  bool lt;
-  sha_final_number(s, d, lt);                      // d.v[7 - i] = digest word i
 #pragma unroll
-  for (int i = 0; i < 8; i++) w.v[i] = __builtin_bswap32(d.v[7 - i]);
+  for (int i = 0; i < 8; i++) s.w[i] = seed[i];
+  s.w[8] = __builtin_bswap32((u32)g);
+  s.w[9] = __builtin_bswap32((u32)(g >> 32));
+  s.w[10] = (t << 24) | 0x00800000u;
+#pragma unroll
+  for (int i = 11; i < 15; i++) s.w[i] = 0;
+  s.w[15] = 41u * 8u;
+  sha_compress(s);
+#pragma unroll
+  for (int i = 0; i < 8; i++) w.v[i] = __builtin_bswap32(s.h[i]);       // digest bytes read as a little-endian number
   w.v[7] &= 0x00FFFFFFu;
   if (bpmi::sc_is_zero(w)) w = sc_small(1);
 }
@@ -280,7 +351,7 @@ __device__ __forceinline__ bool parse_proof(Parsed &P, const uint8_t *blob, u32 
 }
 
 // ---- role 0: the byte-level transcript checks (rp::check_transcripts) ------------------------------------------------------
-__device__ __forceinline__ bool check_transcripts(const Parsed &P, u32 k) {
+__device__ __noinline__ bool check_transcripts(const Parsed &P, u32 k) {
   const uint8_t *comp = P.comp;
   bool ok = true;
   {
@@ -372,134 +443,140 @@ __device__ __forceinline__ bool read_challenges(const Parsed &P, sc &cx, sc &cy,
 }
 __device__ __forceinline__ void zero_outputs(const Params &q, u32 g) {
   const sc z = sc_small(0);
-  for (u32 c = 0; c < 5 + 2 * q.n; c++) cell_store(q, c, g, z);
+  const sq zq = bpmi::sq_small(0);
+  for (u32 c = 0; c < 5 + 2 * q.n; c++) cell_store(cells_of(q, g), c, zq);
   for (u32 j = 0; j < q.m; j++) ::store_words8(q.v_scalars + ((size_t)g * q.m + j) * 8, z.v);
   for (u32 j = 0; j < 6 + 2 * q.k; j++) ::store_words8(q.pt_scalars + ((size_t)g * (6 + 2 * q.k) + j) * 8, z.v);
 }
-__device__ __forceinline__ bool weighted_scalars(const Params &q, u32 g, const Parsed &P) {
+__device__ __noinline__ bool weighted_scalars(const Params &q, u32 g, const Parsed &P) {
   const u32 n = q.n, k = q.k, m = q.m;
-  sc cx, cy, cz, x_ip;
-  if (!read_challenges(P, cx, cy, cz, x_ip)) return false;
+  const Cells C = cells_of(q, g);
+  sc cxs, cys, czs, xips;
+  if (!read_challenges(P, cxs, cys, czs, xips)) return false;
+  const sq cx = to_sq(cxs), cy = to_sq(cys), cz = to_sq(czs), x_ip = to_sq(xips);
   // inverses of x_1 .. x_k and y: one inversion per proof (Montgomery's trick inside the lane)
-  sc xinv[16], yinv;
+  sq xs[16], xinv[16], yinv;
   {
-    sc pre[17], run = sc_small(1);
-    bool nonzero = true;
-    for (u32 t = 0; t <= k; t++) {
-      const sc v = t < k ? P.xs[t] : cy;
-      if (bpmi::sc_is_zero(v)) nonzero = false;            // a zero challenge cannot come out of mod_hash
-      pre[t] = run;
-      mulq(run, run, v);
-    }
+    sq pre[17], run = bpmi::sq_small(1);
+    bool nonzero = !bpmi::sc_is_zero(cys);                 // a zero challenge cannot come out of mod_hash
+    for (u32 t = 0; t < k; t++) { nonzero &= !bpmi::sc_is_zero(P.xs[t]); xs[t] = to_sq(P.xs[t]); }
     if (!nonzero) return false;
-    sc rinv;
-    invq(rinv, run);
+    for (u32 t = 0; t <= k; t++) {
+      pre[t] = run;
+      mq(run, run, t < k ? xs[t] : cy);
+    }
+    sc rinv_c;
+    invq(rinv_c, to_sc(run));
+    sq rinv = to_sq(rinv_c);
     for (int t = (int)k; t >= 0; t--) {
-      sc iv;
-      mulq(iv, rinv, pre[t]);
-      if (t == (int)k) { yinv = iv; mulq(rinv, rinv, cy); }
-      else { xinv[t] = iv; mulq(rinv, rinv, P.xs[t]); }
+      sq iv;
+      mq(iv, rinv, pre[t]);
+      if (t == (int)k) { yinv = iv; mq(rinv, rinv, cy); }
+      else { xinv[t] = iv; mq(rinv, rinv, xs[t]); }
     }
   }
-  sc w[4];
+  sq w[4];
   for (u32 t = 0; t < 4; t++) {
+    sc ws;
     if (q.weights) {
       const uint8_t *src = q.weights + ((size_t)(q.first + g) * 4 + t) * 32;
 #pragma unroll
-      for (int i = 0; i < 8; i++) w[t].v[i] = (u32)src[4 * i] | ((u32)src[4 * i + 1] << 8) | ((u32)src[4 * i + 2] << 16) | ((u32)src[4 * i + 3] << 24);
-      bpmi::sc_reduce_once(w[t]);
+      for (int i = 0; i < 4; i++) { const u64 x = ld8(src + 8 * i); ws.v[2 * i] = (u32)x; ws.v[2 * i + 1] = (u32)(x >> 32); }
+      bpmi::sc_reduce_once(ws);
     } else {
-      derive_weight(w[t], q.seed, q.first + g, t);
+      derive_weight(ws, q.seed, q.first + g, t);
     }
+    w[t] = to_sq(ws);
   }
-  sc t, u;
+  const sq pa = to_sq(P.a), pb = to_sq(P.b), t_hat = to_sq(P.t_hat);
+  sq t, u;
   const u32 SG = 5, SH = 5 + n;
   // s-vector by doubling with the weights folded in: sg_i = w4 a s_i, sh_i = w4 b s_i^-1 y^-i, in place in the columns
-  mulq(t, w[3], P.a); cell_store(q, SG, g, t);
-  mulq(t, w[3], P.b); cell_store(q, SH, g, t);
+  mq(t, w[3], pa); cell_store(C, SG, t);
+  mq(t, w[3], pb); cell_store(C, SH, t);
   {
-    sc ypow2 = yinv;
+    sq ypow2 = yinv;
     u32 len = 1;
     for (int j = (int)k - 1; j >= 0; j--) {
-      const sc xv = P.xs[j], xi = xinv[j];
-      sc hi_h;
-      mulq(hi_h, xi, ypow2);
+      const sq xv = xs[j], xi = xinv[j];
+      sq hi_h;
+      mq(hi_h, xi, ypow2);
       for (u32 i = 0; i < len; i++) {
-        sc s;
-        cell_load(s, q, SG + i, g);
-        mulq(t, s, xv); cell_store(q, SG + len + i, g, t);
-        mulq(t, s, xi); cell_store(q, SG + i, g, t);
-        cell_load(s, q, SH + i, g);
-        mulq(t, s, hi_h); cell_store(q, SH + len + i, g, t);
-        mulq(t, s, xv); cell_store(q, SH + i, g, t);
+        sq s;
+        cell_load(s, C, SG + i);
+        mq(t, s, xv); cell_store(C, SG + len + i, t);
+        mq(t, s, xi); cell_store(C, SG + i, t);
+        cell_load(s, C, SH + i);
+        mq(t, s, hi_h); cell_store(C, SH + len + i, t);
+        mq(t, s, xv); cell_store(C, SH + i, t);
       }
-      mulq(ypow2, ypow2, ypow2);
+      mq(ypow2, ypow2, ypow2);
       len <<= 1;
     }
   }
-  sc z2, w2z, geo, r2;
-  mulq(z2, cz, cz);
-  mulq(w2z, w[1], cz);
-  cell_store(q, 3, g, w2z);                                           // gs_const
-  negq(t, w2z); cell_store(q, 4, g, t);                               // hs_const
-  addq(r2, yinv, yinv);                                               // 2 / y
+  sq z2, w2z, geo, r2;
+  mq(z2, cz, cz);
+  mq(w2z, w[1], cz);
+  cell_store(C, 3, w2z);                                           // gs_const
+  bpmi::sq_neg(t, w2z); cell_store(C, 4, t);                       // hs_const
+  bpmi::sq_add(r2, yinv, yinv);                                       // 2 / y
   const u32 bits = n / m;
-  sc yn_inv = sc_small(1);                                            // y^-bits, square and multiply
+  sq yn_inv = bpmi::sq_small(1);                                      // y^-bits, square and multiply
   for (int i = 31 - __clz(bits); i >= 0; i--) {
-    mulq(yn_inv, yn_inv, yn_inv);
-    if ((bits >> i) & 1u) mulq(yn_inv, yn_inv, yinv);
+    mq(yn_inv, yn_inv, yn_inv);
+    if ((bits >> i) & 1u) mq(yn_inv, yn_inv, yinv);
   }
   {
-    sc blk = sc_small(1), zp = z2;                                    // zp = z^(2 + j)
+    sq blk = bpmi::sq_small(1), zp = z2;                              // zp = z^(2 + j)
     for (u32 j = 0, i = 0; j < m; j++) {
-      mulq(geo, w[1], zp);
-      mulq(geo, geo, blk);                                            // w2 z^(2+j) 2^(i % bits) y^-i at i = bits j
-      mulq(t, w[0], zp); negq(t, t);
-      ::store_words8(q.v_scalars + ((size_t)g * m + j) * 8, t.v);     // V_j: -w1 z^(2+j)
+      mq(geo, w[1], zp);
+      mq(geo, geo, blk);                                              // w2 z^(2+j) 2^(i % bits) y^-i at i = bits j
+      mq(t, w[0], zp); bpmi::sq_neg(t, t);
+      store_canon(q.v_scalars + ((size_t)g * m + j) * 8, t);          // V_j: -w1 z^(2+j)
       for (u32 e = 0; e < bits; e++, i++) {
-        sc s;
-        cell_load(s, q, SH + i, g);
-        subq(s, s, geo);
-        cell_store(q, SH + i, g, s);
-        mulq(geo, geo, r2);
+        sq s;
+        cell_load(s, C, SH + i);
+        bpmi::sq_sub(s, s, geo);
+        cell_store(C, SH + i, s);
+        mq(geo, geo, r2);
       }
-      mulq(blk, blk, yn_inv);
-      mulq(zp, zp, cz);
+      mq(blk, blk, yn_inv);
+      mq(zp, zp, cz);
     }
   }
   // sum_{i<n} y^i by doubling; delta = (z - z^2) ysum - (2^bits - 1) sum_{j=1..m} z^(j+2)
-  sc ysum = sc_small(1), ypw = cy;
-  const sc one = sc_small(1);
+  sq ysum = bpmi::sq_small(1), ypw = cy;
+  const sq one = bpmi::sq_small(1);
   for (u32 l2 = 1; l2 < n; l2 <<= 1) {
-    addq(t, one, ypw);
-    mulq(ysum, ysum, t);
-    mulq(ypw, ypw, ypw);
+    bpmi::sq_add(t, one, ypw);
+    mq(ysum, ysum, t);
+    mq(ypw, ypw, ypw);
   }
-  sc two_n = sc_small(1);
-  for (u32 i = 0; i < bits; i++) addq(two_n, two_n, two_n);           // 2^bits mod q
-  subq(two_n, two_n, one);
-  sc delta, zsum = sc_small(0), zp;
-  subq(t, cz, z2);
-  mulq(delta, t, ysum);
-  mulq(zp, z2, cz);                                                   // z^3
-  for (u32 j = 1; j <= m; j++) { addq(zsum, zsum, zp); mulq(zp, zp, cz); }
-  mulq(t, zsum, two_n);
-  subq(delta, delta, t);
+  sq two_n = bpmi::sq_small(1);
+  for (u32 i = 0; i < bits; i++) bpmi::sq_add(two_n, two_n, two_n);   // 2^bits mod q
+  bpmi::sq_sub(two_n, two_n, one);
+  sq delta, zsum = bpmi::sq_small(0), zp;
+  bpmi::sq_sub(t, cz, z2);
+  mq(delta, t, ysum);
+  mq(zp, z2, cz);                                                     // z^3
+  for (u32 j = 1; j <= m; j++) { bpmi::sq_add(zsum, zsum, zp); mq(zp, zp, cz); }
+  mq(t, zsum, two_n);
+  bpmi::sq_sub(delta, delta, t);
   // c_g: w1 (t_hat - delta); c_h: w1 taux + w2 mu; c_u: -(w2 x_ip t_hat + w3 x_ip)
-  subq(t, P.t_hat, delta); mulq(t, t, w[0]); cell_store(q, 0, g, t);
-  mulq(t, w[0], P.taux); mulq(u, w[1], P.mu); addq(t, t, u); cell_store(q, 1, g, t);
-  mulq(t, w[1], x_ip); mulq(t, t, P.t_hat); mulq(u, w[2], x_ip); addq(t, t, u); negq(t, t); cell_store(q, 2, g, t);
+  bpmi::sq_sub(t, t_hat, delta); mq(t, t, w[0]); cell_store(C, 0, t);
+  mq(t, w[0], to_sq(P.taux)); mq(u, w[1], to_sq(P.mu)); bpmi::sq_add(t, t, u); cell_store(C, 1, t);
+  mq(t, w[1], x_ip); mq(t, t, t_hat); mq(u, w[2], x_ip); bpmi::sq_add(t, t, u); bpmi::sq_neg(t, t); cell_store(C, 2, t);
   // per-proof points in wire order: T1: -w1 x | T2: -w1 x^2 | A: -w2 | S: -w2 x | u_new: w3 + w4 a b | P_new: w2 - w4 | Ls | Rs
   u32 *op = q.pt_scalars + (size_t)g * (6 + 2 * k) * 8;
-  mulq(t, w[0], cx); negq(u, t); ::store_words8(op, u.v);
-  mulq(t, t, cx); negq(u, t); ::store_words8(op + 8, u.v);
-  negq(u, w[1]); ::store_words8(op + 16, u.v);
-  mulq(t, w[1], cx); negq(u, t); ::store_words8(op + 24, u.v);
-  mulq(t, w[3], P.a); mulq(t, t, P.b); addq(u, w[2], t); ::store_words8(op + 32, u.v);
-  subq(u, w[1], w[3]); ::store_words8(op + 40, u.v);
+  mq(t, w[0], cx); bpmi::sq_neg(u, t); store_canon(op, u);
+  mq(t, t, cx); bpmi::sq_neg(u, t); store_canon(op + 8, u);
+  bpmi::sq_neg(u, w[1]); store_canon(op + 16, u);
+  mq(t, w[1], cx); bpmi::sq_neg(u, t); store_canon(op + 24, u);
+  mq(t, w[3], pa); mq(t, t, pb); bpmi::sq_add(u, w[2], t); store_canon(op + 32, u);
+  bpmi::sq_sub(u, w[1], w[3]); store_canon(op + 40, u);
   for (u32 j = 0; j < k; j++) {
-    mulq(t, w[3], P.xs[j]); mulq(t, t, P.xs[j]); negq(u, t); ::store_words8(op + (6 + j) * 8, u.v);
-    mulq(t, w[3], xinv[j]); mulq(t, t, xinv[j]); negq(u, t); ::store_words8(op + (6 + k + j) * 8, u.v);
+    mq(t, w[3], xs[j]); mq(t, t, xs[j]); bpmi::sq_neg(u, t); store_canon(op + (6 + j) * 8, u);
+    mq(t, w[3], xinv[j]); mq(t, t, xinv[j]); bpmi::sq_neg(u, t); store_canon(op + (6 + k + j) * 8, u);
   }
   return true;
 }
@@ -515,6 +592,7 @@ __global__ void __launch_bounds__(64) k_rp_prepare(Params q) {
   if (g >= q.P) return;
   const uint8_t *blob = q.blobs + q.off[g];
   const u32 blen = (u32)(q.off[g + 1] - q.off[g]);
+  if (q.only_role >= 0 && (u32)q.only_role != role) { q.status[(size_t)role * q.Pall + g] = 1; return; }
   Parsed P;
   bool ok = parse_proof(P, blob, blen, q.k);
   if (role == 0) {
@@ -527,32 +605,36 @@ __global__ void __launch_bounds__(64) k_rp_prepare(Params q) {
   if (!ok) atomicMin(q.bad, (unsigned long long)(q.first + g));
 }
 
-// shared[col] += sum over the P proofs of contrib[col][.]; one block per column
+// shared[col] += sum over the P proofs of cell (col, .): the nine limb rows are summed as plain 64-bit integers (P < 2^22 loose
+// limbs cannot overflow) and reduced mod q once; one block per column
 __global__ void __launch_bounds__(256) k_rp_colsum(const u32 *__restrict__ contrib, u32 P, u32 *__restrict__ shared) {
-  __shared__ u32 sh[256 * 8];
+  __shared__ u64 sh[256 * 9];
   const u32 col = blockIdx.x;
-  sc acc = sc_small(0);
+  u64 acc[9];
+#pragma unroll
+  for (int w = 0; w < 9; w++) acc[w] = 0;
+  const u32 *base = contrib + (size_t)col * 9 * P;
   for (u32 i = threadIdx.x; i < P; i += 256u) {
-    sc x;
-    ::load_words8(x.v, contrib + ((size_t)col * P + i) * 8);
-    addq(acc, acc, x);
+#pragma unroll
+    for (int w = 0; w < 9; w++) acc[w] += base[(size_t)w * P + i];
   }
   for (u32 d = 128; d > 0; d >>= 1) {
 #pragma unroll
-    for (int j = 0; j < 8; j++) sh[threadIdx.x * 8 + j] = acc.v[j];
+    for (int w = 0; w < 9; w++) sh[threadIdx.x * 9 + w] = acc[w];
     __syncthreads();
     if (threadIdx.x < d) {
-      sc o;
 #pragma unroll
-      for (int j = 0; j < 8; j++) o.v[j] = sh[(threadIdx.x + d) * 8 + j];
-      addq(acc, acc, o);
+      for (int w = 0; w < 9; w++) acc[w] += sh[(threadIdx.x + d) * 9 + w];
     }
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    sc cur;
+    sq total;
+    bpmi::sq_norm_cols(total, acc);              // limb 5 may end above "loose" here (the carry is < 2^22): sq_to_sc takes any 32-bit limbs
+    sc sum, cur;
+    bpmi::sq_to_sc(sum, total);
     ::load_words8(cur.v, shared + 8ull * col);
-    addq(cur, cur, acc);
+    addq(cur, cur, sum);
     ::store_words8(shared + 8ull * col, cur.v);
   }
 }

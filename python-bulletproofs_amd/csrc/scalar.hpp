@@ -174,4 +174,128 @@ BPMI_HD void sc_inv(sc &r, const sc &a) {
   r = x2;
 }
 
+// ---- the same field on 9 x 29-bit limbs ("sq"): for code whose time is modular MULTIPLICATIONS (the batch-preparation kernel:
+// ~400 per proof).  On 8 x 32-bit words every partial product needs its carry handled (sc_mul: ~720 instructions on the
+// device, 120 of them multiply-adds); with 29-bit limbs a column of nine 58-bit products fits a 64-bit accumulator, so a
+// column is ONE v_mad_u64_u32 chain and carries are resolved once per column (sq_mul: 156 multiply-adds, ~270 instructions).
+//   value = sum v[i] 2^(29 i);  "loose": every limb < 2^29 + 2^10 and value < 2^261 + 2^143 -- what every sq_* routine
+//   returns and accepts; canonical 32-byte form via sq_to_sc.
+//   2^261 == D (mod q), D = 32 (2^256 - q), 134 bits = 5 limbs: high limbs fold as products with D's limbs.
+struct sq { u32 v[9]; };
+#define BPMI_SQ_D {0x1937D7E0u, 0x0DA1732Fu, 0x1AFE2201u, 0x08C6542Du, 0x00028AA2u}
+// 64 q with two units lent from every limb to the one below: limb-wise >= any loose operand, so a + BIAS - b needs no borrow
+#define BPMI_SQ_BIAS64 {0x4D905040u, 0x44BD199Eu, 0x4A03BBFBu, 0x4E7357A2u, 0x5FFAEAB9u, 0x5FFFFFFDu, 0x5FFFFFFDu, 0x5FFFFFFDu, 0x3FFFFFFDu}
+
+BPMI_HD void sq_from_sc(sq &r, const sc &a) {
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    const int lo = 29 * i, w = lo >> 5, sh = lo & 31;
+    u32 v = a.v[w] >> sh;
+    if (sh > 3 && w + 1 < 8) v |= a.v[w + 1] << (32 - sh);
+    r.v[i] = v & M29;
+  }
+}
+BPMI_HD sq sq_small(u32 x) {             // x < 2^29
+  sq r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.v[i] = i ? 0u : x;
+  return r;
+}
+// columns t[0..9) (each < 2^63, total value < 2^271) -> loose limbs: one carry pass, the carry out of limb 8 (e < 2^10) comes
+// back as e * D into limbs 0..4, and a short second pass stops at limb 5
+BPMI_HD void sq_norm_cols(sq &r, const u64 t[9]) {
+  const u32 D[5] = BPMI_SQ_D;
+  u32 u[9];
+  u64 c = 0;
+#pragma unroll
+  for (int k = 0; k < 9; k++) { c += t[k]; u[k] = (u32)c & M29; c >>= 29; }
+  const u32 e = (u32)c;
+  c = 0;
+#pragma unroll
+  for (int k = 0; k < 5; k++) { c += (u64)e * D[k] + u[k]; r.v[k] = (u32)c & M29; c >>= 29; }
+  r.v[5] = u[5] + (u32)c;
+#pragma unroll
+  for (int k = 6; k < 9; k++) r.v[k] = u[k];
+}
+BPMI_HD void sq_add(sq &r, const sq &a, const sq &b) {
+  u64 t[9];
+#pragma unroll
+  for (int k = 0; k < 9; k++) t[k] = (u64)a.v[k] + b.v[k];
+  sq_norm_cols(r, t);
+}
+BPMI_HD void sq_sub(sq &r, const sq &a, const sq &b) {
+  const u32 B[9] = BPMI_SQ_BIAS64;
+  u64 t[9];
+#pragma unroll
+  for (int k = 0; k < 9; k++) t[k] = (u64)a.v[k] + (B[k] - b.v[k]);
+  sq_norm_cols(r, t);
+}
+BPMI_HD void sq_neg(sq &r, const sq &a) { const sq z = sq_small(0); sq_sub(r, z, a); }
+// C body of the multiplication (host, and the statement-by-statement model of the generated device body in scalar_gen.hpp):
+//   columns 9..16 of a*b, carried -> h[0..9);  columns 0..12 of lo + h*D, carried -> r[0..9), g[0..5);
+//   columns 0..8 of r + g*D -> sq_norm_cols
+BPMI_HD void sq_mul_c(sq &r, const sq &a, const sq &b) {
+  const u32 D[5] = BPMI_SQ_D;
+  u32 h[9], lo[9], g[5];
+  u64 c = 0;
+#pragma unroll
+  for (int k = 9; k < 17; k++) {
+#pragma unroll
+    for (int i = k - 8; i <= 8; i++) c += (u64)a.v[i] * b.v[k - i];
+    h[k - 9] = (u32)c & M29;
+    c >>= 29;
+  }
+  h[8] = (u32)c;
+  c = 0;
+#pragma unroll
+  for (int k = 0; k < 13; k++) {
+    if (k <= 8) {
+#pragma unroll
+      for (int i = 0; i <= k; i++) c += (u64)a.v[i] * b.v[k - i];
+    }
+#pragma unroll
+    for (int j = 0; j < 5; j++) { const int i = k - j; if (i >= 0 && i <= 8) c += (u64)h[i] * D[j]; }
+    if (k <= 8) lo[k] = (u32)c & M29; else g[k - 9] = (u32)c & M29;
+    c >>= 29;
+  }
+  g[4] = (u32)c;
+  u64 t[9];
+#pragma unroll
+  for (int k = 0; k < 9; k++) {
+    t[k] = lo[k];
+#pragma unroll
+    for (int j = 0; j < 5; j++) { const int i = k - j; if (i >= 0 && i <= 4) t[k] += (u64)g[i] * D[j]; }
+  }
+  sq_norm_cols(r, t);
+}
+#include "scalar_gen.hpp"
+BPMI_HD void sq_mul(sq &r, const sq &a, const sq &b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  sq_mul_dev(r, a, b);
+#else
+  sq_mul_c(r, a, b);
+#endif
+}
+// loose limbs -> the canonical value in [0, q) as 8 words
+BPMI_HD void sq_to_sc(sc &r, const sq &a) {
+  u32 w[9];
+#pragma unroll
+  for (int i = 0; i < 9; i++) w[i] = 0;
+  u64 c = 0;
+#pragma unroll
+  for (int i = 0; i < 10; i++) {                 // limb 9 = the carry out of limb 8
+    u32 limb;
+    if (i < 9) { c += a.v[i]; limb = (u32)c & M29; c >>= 29; } else limb = (u32)c;
+    const int lo = 29 * i, k = lo >> 5, sh = lo & 31;
+    w[k] |= limb << sh;
+    if (sh > 3 && k + 1 < 9) w[k + 1] |= limb >> (32 - sh);
+  }
+  u32 f[9];
+  sc_fold_once<1, 9>(f, w, w + 8);               // bits 256.. (< 2^7) times (2^256 - q)
+  sc_cond_sub_q(f);
+  sc_cond_sub_q(f);
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = f[i];
+}
+
 }  // namespace bpmi

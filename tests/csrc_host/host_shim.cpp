@@ -68,6 +68,28 @@ void t_sc_op(int op, const uint8_t *a, const uint8_t *b, uint8_t *out) {
   }
   memcpy(out, r.v, 32);
 }
+// the same field on 9 x 29-bit limbs (sq): op 0 mul, 1 add, 2 sub, 3 neg(a), 4 round trip.  a, b: RAW limbs (any loose
+// values the caller wants to try); out_limbs: the raw result limbs; out32: its canonical value
+void t_sq_raw(int op, const u32 *a, const u32 *b, u32 *out_limbs, uint8_t *out32) {
+  sq x, y, r;
+  for (int k = 0; k < 9; k++) { x.v[k] = a[k]; y.v[k] = b[k]; }
+  switch (op) {
+    case 0: sq_mul(r, x, y); break;
+    case 1: sq_add(r, x, y); break;
+    case 2: sq_sub(r, x, y); break;
+    case 3: sq_neg(r, x); break;
+    default: r = x;
+  }
+  for (int k = 0; k < 9; k++) out_limbs[k] = r.v[k];
+  sc c;
+  sq_to_sc(c, r);
+  memcpy(out32, c.v, 32);
+}
+void t_sq_from_sc(const uint8_t *a32, u32 *out_limbs) {
+  sc x; memcpy(x.v, a32, 32);
+  sq r; sq_from_sc(r, x);
+  for (int k = 0; k < 9; k++) out_limbs[k] = r.v[k];
+}
 int t_fe_is_zero(const uint8_t *a, const uint8_t *b) {  // is a - b == 0 ?
   fe x, y; load_fe(x, a); load_fe(y, b);
   return fe_equal(x, y) ? 1 : 0;

@@ -32,6 +32,8 @@ def shim():
     L.t_jac_mul.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p]
     L.t_jac_madd_chain.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p]
     L.t_sc_op.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p]
+    L.t_sq_raw.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_char_p]
+    L.t_sq_from_sc.argtypes = [ctypes.c_char_p, ctypes.c_void_p]
     return L
 
 
@@ -59,6 +61,56 @@ def test_scalar_ops_mod_q(shim):
         assert sc_op(shim, 1, a, b) == (a + b) % q
     for a in [q, q + 1, 2**256 - 1, 2**256 - 2, q - 1, 5]:
         assert sc_op(shim, 5, a) == a % q
+
+
+def test_scalar_29bit_limb_arithmetic(shim):
+    """The sq routines of csrc/scalar.hpp (9 x 29-bit limbs mod q, what the batch-preparation kernel multiplies with) against
+    Python integers: every result is correct mod q AND loose (limbs < 2^29 + 2^10), also from the largest loose inputs, and
+    long random chains of mul / add / sub / neg stay loose."""
+    q = secp256k1.q
+    rnd = random.Random(29)
+    u32x9 = ctypes.c_uint32 * 9
+    LOOSE = (1 << 29) + (1 << 10)
+
+    def value(limbs):
+        return sum(v << (29 * i) for i, v in enumerate(limbs))
+
+    def raw(op, a, b):
+        out_l, out_v = u32x9(), ctypes.create_string_buffer(32)
+        shim.t_sq_raw(op, u32x9(*a), u32x9(*b), out_l, out_v)
+        limbs = list(out_l)
+        assert all(v < LOOSE for v in limbs), (op, [hex(v) for v in limbs])
+        canon = int.from_bytes(out_v.raw, "little")
+        assert canon < q and canon == value(limbs) % q
+        return limbs, canon
+
+    def from_int(x):
+        out_l = u32x9()
+        shim.t_sq_from_sc(x.to_bytes(32, "little"), out_l)
+        assert value(list(out_l)) == x
+        return list(out_l)
+
+    top = [LOOSE - 1] * 9                                       # the largest loose operand
+    edge = [from_int(v) for v in (0, 1, 2, q - 1, q - 2, q, q + 1, 2**256 - 1, 2**255, (1 << 232) - 1, 1 << 232, 2**128)] + [top, [0] * 8 + [LOOSE - 1]]
+    edge += [[(1 << 29) - 1] * 9, [1 << 29] * 9, [LOOSE - 1] + [0] * 8]
+    rand = [from_int(rnd.randrange(2**256)) for _ in range(200)] + [[rnd.randrange(LOOSE) for _ in range(9)] for _ in range(200)]
+    pairs = [(a, b) for a in edge for b in edge] + [(rnd.choice(rand + edge), rnd.choice(rand + edge)) for _ in range(4000)]
+    for a, b in pairs:
+        va, vb = value(a), value(b)
+        assert raw(0, a, b)[1] == va * vb % q
+        assert raw(1, a, b)[1] == (va + vb) % q
+        assert raw(2, a, b)[1] == (va - vb) % q
+    for a in edge + rand:
+        assert raw(3, a, a)[1] == (-value(a)) % q
+        assert raw(4, a, a)[1] == value(a) % q
+    # chains: the loose invariant is closed under every operation
+    x, vx = top, value(top)
+    for step in range(3000):
+        y = rnd.choice(rand + edge)
+        op = rnd.randrange(4)
+        x, got = raw(op, x, y)
+        vx = [vx * value(y), vx + value(y), vx - value(y), -vx][op] % q
+        assert got == vx
 
 
 def fe_op(L, op, a, b=0):

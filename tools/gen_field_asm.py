@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Generates python-bulletproofs_amd/csrc/field_gen.hpp: the DEVICE bodies of the field-multiplication family
-of csrc/field.hpp (fe_mul, fe_sqr, fe_mul_add, fe_sqr_add, fe_mul2) for gfx950.
+of csrc/field.hpp (fe_mul, fe_sqr, fe_mul_add, fe_sqr_add, fe_mul2) for gfx950 -- and csrc/scalar_gen.hpp: the device
+body of sq_mul (csrc/scalar.hpp, arithmetic mod the group order q on 9 x 29-bit limbs; see sq_mul_body below).
 
     python tools/gen_field_asm.py            # rewrites csrc/field_gen.hpp
     python tools/gen_field_asm.py --check    # exit 1 if the committed file differs (tests/test_csrc_host.py runs this)
@@ -156,6 +157,64 @@ FUNCS = [
 ]
 
 
+# ---- arithmetic mod q on 9 x 29-bit limbs (csrc/scalar.hpp "sq"): the device body of sq_mul, statement for statement sq_mul_c ----
+OUT_SC = os.path.join(HERE, "..", "python-bulletproofs_amd", "csrc", "scalar_gen.hpp")
+
+
+def sq_mul_body():
+    L = []
+    L.append("  const u32 kd[5] = BPMI_SQ_D;\n  u64 s, sink_;\n  u32 h[9], lo[9], g[5], u[9];\n")
+    # columns 9..16 of a * b, carried: h[0..9)
+    for k in range(9, 17):
+        st = Stmt(k == 9)
+        for i in range(k - 8, 9):
+            st.add("a.v[%d]" % i, "b.v[%d]" % (k - i))
+        L.append(st.emit())
+        L.append("  h[%d] = (u32)s & M29; s >>= 29;\n" % (k - 9))
+    L.append("  h[8] = (u32)s;\n")
+    # columns 0..12 of lo(a * b) + h * D, carried: lo[0..9), g[0..5)
+    for k in range(13):
+        st = Stmt(k == 0)
+        if k <= 8:
+            for i in range(k + 1):
+                st.add("a.v[%d]" % i, "b.v[%d]" % (k - i))
+        for j in range(5):
+            i = k - j
+            if 0 <= i <= 8:
+                st.add("h[%d]" % i, "kd[%d]" % j, "vs")
+        L.append(st.emit())
+        L.append("  %s = (u32)s & M29; s >>= 29;\n" % ("lo[%d]" % k if k <= 8 else "g[%d]" % (k - 9)))
+    L.append("  g[4] = (u32)s;\n")
+    # columns 0..8 of lo + g * D, carried: u[0..9), e
+    for k in range(9):
+        st = Stmt(k == 0)
+        st.add("lo[%d]" % k, None, "v1")
+        for j in range(5):
+            i = k - j
+            if 0 <= i <= 4:
+                st.add("g[%d]" % i, "kd[%d]" % j, "vs")
+        L.append(st.emit())
+        L.append("  u[%d] = (u32)s & M29; s >>= 29;\n" % k)
+    L.append("  const u32 e = (u32)s;\n")
+    # e * D back into limbs 0..4; the second pass stops at limb 5 (loose output)
+    for k in range(5):
+        st = Stmt(k == 0)
+        st.add("u[%d]" % k, None, "v1")
+        st.add("e", "kd[%d]" % k, "vs")
+        L.append(st.emit())
+        L.append("  r.v[%d] = (u32)s & M29; s >>= 29;\n" % k)
+    L.append("  r.v[5] = u[5] + (u32)s;\n#pragma unroll\n  for (int k = 6; k < 9; k++) r.v[k] = u[k];\n  (void)sink_;\n")
+    return "".join(L)
+
+
+def generate_sc():
+    out = ["// scalar_gen.hpp -- GENERATED by tools/gen_field_asm.py; do not edit (tests/test_csrc_host.py checks it is current).\n",
+           "// Device body of sq_mul (arithmetic mod q on 9 x 29-bit limbs); the arithmetic is sq_mul_c of scalar.hpp, column for column.\n",
+           "#pragma once\n", "#if defined(__HIP_DEVICE_COMPILE__)\n",
+           "__device__ __forceinline__ void sq_mul_dev(sq &r, const sq &a, const sq &b) {\n%s}\n" % sq_mul_body(), "#endif\n"]
+    return "".join(out)
+
+
 def generate():
     out = ["// field_gen.hpp -- GENERATED by tools/gen_field_asm.py; do not edit (tests/test_csrc_host.py checks it is current).\n",
            "// Device bodies of the field-multiplication family; the arithmetic is fe_mac_c of field.hpp, column for column.\n",
@@ -167,10 +226,10 @@ def generate():
 
 
 if __name__ == "__main__":
-    text = generate()
+    files = [(OUT, generate()), (OUT_SC, generate_sc())]
     if "--check" in sys.argv:
-        cur = open(OUT).read() if os.path.exists(OUT) else ""
-        sys.exit(0 if cur == text else 1)
-    with open(OUT, "w") as f:
-        f.write(text)
-    print(os.path.normpath(OUT))
+        sys.exit(0 if all(os.path.exists(path) and open(path).read() == text for path, text in files) else 1)
+    for path, text in files:
+        with open(path, "w") as f:
+            f.write(text)
+        print(os.path.normpath(path))
