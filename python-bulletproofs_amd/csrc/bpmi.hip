@@ -414,7 +414,7 @@ int bpmi_ec_decompress_batch(bpmi_ctx *ctx, const uint8_t *comp, uint64_t n, uin
   char *din = (char *)ctx->stage_in, *dout = din + align_up(33 * n, 256), *dok = dout + align_up(64 * n, 256);
   HIPCHK(ctx, hipMemcpyAsync(din, comp, 33 * n, hipMemcpyHostToDevice, ctx->stream));
   {
-    StageTimer t(ctx, ST_MISC);
+    StageTimer t(ctx, ST_DECOMP);
     hipLaunchKernelGGL(k_ec_decompress, dim3((u32)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const uint8_t *)din, (u32)n,
                        (u32 *)dout, (uint8_t *)dok);
   }
@@ -437,7 +437,7 @@ int bpmi_ec_decompress_batch_dev(bpmi_ctx *ctx, const uint8_t *comp, uint64_t n,
   char *din = (char *)ctx->stage_in, *dok = din + align_up(33 * n, 256);
   HIPCHK(ctx, hipMemcpyAsync(din, comp, 33 * n, hipMemcpyHostToDevice, ctx->stream));
   {
-    StageTimer t(ctx, ST_MISC);
+    StageTimer t(ctx, ST_DECOMP);
     hipLaunchKernelGGL(k_ec_decompress, dim3((u32)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const uint8_t *)din, (u32)n, (u32 *)d_out, (uint8_t *)dok);
   }
   HIPCHK(ctx, hipGetLastError());
@@ -1090,13 +1090,13 @@ int bpmi_rp_batch_prepare_dev(bpmi_ctx *ctx, uint32_t n_gens, uint32_t values_pe
     q.v_scalars = (u32 *)d_v_scalars + 8 * (size_t)base * m;
     q.pt_scalars = (u32 *)d_pt_scalars + 8 * (size_t)base * per;
     q.status = (uint8_t *)(din + o_st) + base;
-    StageTimer t(ctx, ST_MISC);
+    StageTimer t(ctx, ST_RPPREP);
     hipLaunchKernelGGL(rpd::k_rp_prepare, dim3(2 * ((cnt + lanes - 1) / lanes)), dim3(64), 0, ctx->stream, q);
     hipLaunchKernelGGL(rpd::k_rp_colsum, dim3(ncols), dim3(256), 0, ctx->stream, (const u32 *)d_contrib, cnt, d_shared);
   }
   HIPCHK(ctx, hipGetLastError());
   {
-    StageTimer t(ctx, ST_MISC);
+    StageTimer t(ctx, ST_DECOMP);
     const u64 npts = (u64)P * per;
     hipLaunchKernelGGL(k_ec_decompress_wire, dim3((u32)((npts + 255) / 256)), dim3(256), 0, ctx->stream, (const uint8_t *)din, (const u64 *)(din + o_off),
                        (const uint8_t *)(din + o_st), k, P, (u64)0, (u32 *)d_points, d_bad);

@@ -7,11 +7,11 @@
 // ------------------------------------------------------------------------------------
 enum Stage {
   ST_DIGITS = 0, ST_SCAN, ST_SCATTER, ST_ACCUM, ST_SEGSCAN, ST_BREDUCE, ST_TAIL,
-  ST_MULBATCH, ST_LINCOMB2, ST_SCDOT, ST_SCFOLD, ST_MISC
+  ST_MULBATCH, ST_LINCOMB2, ST_SCDOT, ST_SCFOLD, ST_MISC, ST_RPPREP, ST_DECOMP
 };
 static const char *STAGE_NAMES[BPMI_NSTAGES] = {
   "msm_digits_hist", "msm_scan", "msm_scatter", "msm_accumulate", "msm_segscan", "msm_bucket_reduce",
-  "msm_tail", "ec_mul_batch", "ec_lincomb2", "sc_dot", "sc_fold", "misc"
+  "msm_tail", "ec_mul_batch", "ec_lincomb2", "sc_dot", "sc_fold", "misc", "rp_prepare", "ec_decompress"
 };
 
 struct EvPair { int stage; hipEvent_t a, b; };

@@ -42,18 +42,25 @@ def _le32(v):
 
 
 class BatchRangeVerifier:
-    def __init__(self, g, h, gs, hs, u, msm=None, rng=None):
+    def __init__(self, g, h, gs, hs, u, msm=None, rng=None, engine=None):
         """msm(points_bytes, scalar_bytes, n) -> 64 bytes; default: the HIP engine.
-        rng() -> int: source of the random weights; default: secrets (CSPRNG)."""
+        rng() -> int: source of the random weights; default: secrets (CSPRNG).
+        engine: the engine.Engine this verifier's GPU work runs on (default: the process-wide one).  Verifiers with
+        engines of their own can work from different threads at the same time -- the library calls release the GIL
+        -- so the upload of one batch overlaps the kernels of another."""
         assert len(gs) == len(hs)
         self.g, self.h, self.gs, self.hs, self.u = g, h, gs, hs, u
         self.n = len(gs)
         self._msm = msm
+        self._engine = engine
         self._rng = rng or (lambda: secrets.randbits(320))
         self._custom_rng = rng is not None
         self._shared_pts = g.to_le64() + h.to_le64() + u.to_le64() + b"".join(p.to_le64() for p in gs) + \
             b"".join(p.to_le64() for p in hs)
         self.reset()
+
+    def _eng(self):
+        return self._engine or _engine.default_engine()
 
     def reset(self):
         self.c_g = self.c_h = self.c_u = 0
@@ -214,7 +221,7 @@ class BatchRangeVerifier:
         assert len(Vs) == len(blobs)
         comp = [compressed_points(b) for b in blobs]
         counts = [len(c) // 33 for c in comp]
-        dec = decompress or _engine.default_engine().ec_decompress_batch_bytes
+        dec = decompress or self._eng().ec_decompress_batch_bytes
         pts, ok = dec(b"".join(comp), sum(counts))
         if 0 in bytes(ok):
             raise Exception("Proof invalid")
@@ -316,7 +323,7 @@ class BatchRangeVerifier:
         if bad.value >= 0:
             raise Exception("Proof invalid")
         if on_device:
-            eng = _engine.default_engine()
+            eng = self._eng()
             nv = count * m
             d_pts, d_scs = eng.alloc(64 * (nv + npts)), eng.alloc(32 * (nv + npts))
             d_pts.upload(vbytes)
@@ -328,7 +335,7 @@ class BatchRangeVerifier:
             eng._ck(eng.lib.bpmi_upload(eng.ctx, d_scs.ptr + 32 * nv, ctypes.cast(p_sc, ctypes.c_char_p), 32 * npts))
             self._dev_chunks.append((d_pts, d_scs, nv + npts))
         else:
-            dec = decompress or _engine.default_engine().ec_decompress_batch_bytes
+            dec = decompress or self._eng().ec_decompress_batch_bytes
             pts, ok = dec(comp.raw, npts)
             if 0 in bytes(ok):
                 raise Exception("Proof invalid")
@@ -343,7 +350,7 @@ class BatchRangeVerifier:
         """add_wire_native with the preparation on the GPU: one call uploads the wire bytes, prepares every proof, decodes its
         points into the batch's point array and returns the shared coefficients and the verdict."""
         import ctypes
-        eng = _engine.default_engine()
+        eng = self._eng()
         nv, npts = count * m, count * (6 + 2 * k)
         d_pts, d_scs = eng.alloc(64 * (nv + npts)), eng.alloc(32 * (nv + npts))
         try:
@@ -393,14 +400,14 @@ class BatchRangeVerifier:
         npts = 3 + 2 * self.n + len(self._scs) + self._raw_count
         if self._dev_chunks:
             return self._partial_dev(pts, scs, npts)
-        msm = self._msm or _engine.default_engine().msm_bytes
+        msm = self._msm or self._eng().msm_bytes
         return msm(pts, scs, npts)
 
     def _partial_dev(self, pts, scs, npts):
         """One MSM over the host-side part (shared generators, proofs added as objects) and the device-resident chunks of
         add_wire_native: up to three segments go to bpmi_msm_segs_dev as they are; more are packed into one buffer on the device."""
         import ctypes
-        eng = _engine.default_engine()
+        eng = self._eng()
         chunks = list(self._dev_chunks)
         if len(chunks) > 2:
             total = sum(c[2] for c in chunks)
