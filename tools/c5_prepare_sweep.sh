@@ -1,0 +1,11 @@
+#!/bin/bash
+# Evidence for the batch-preparation kernel (config C5, one GPU; run from the repo root ON THE GPU BOX):
+#   bash tools/c5_prepare_sweep.sh > gpurun_out/c5_prepare.txt
+# host vs device preparation, pageable vs page-locked receive buffer, proofs per wave, and each role alone.
+P="python3 tools/profile_c5.py"
+F='rep 2\|rp_prepare\|ec_decompress'
+echo "== preparation on the host (bpmi_rp_batch_prepare, 32 threads), bytes receive buffer"; C5_PREPARE=host $P 2>&1 | grep "rep 2"
+echo "== preparation on the device, bytes (pageable) receive buffer, commitments as Point objects"; C5_PREPARE=device $P 2>&1 | grep "$F"
+echo "== preparation on the device, page-locked receive buffer, commitments packed"; C5_PINNED=1 C5_PREPARE=device $P 2>&1 | grep "$F"
+for l in 8 16 32 64; do echo "== proofs per wave (rp_lanes) = $l"; C5_LANES=$l C5_PINNED=1 C5_PREPARE=device $P 2>&1 | grep "$F"; done
+for r in 0 1; do echo "== only role $r (0: transcripts / SHA-256, 1: algebra); not a verification"; C5_ONLY_ROLE=$r C5_PINNED=1 C5_PREPARE=device $P 2>&1 | grep "rp_prepare"; done
