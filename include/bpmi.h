@@ -248,7 +248,9 @@ int bpmi_host_free(bpmi_ctx *ctx, void *p);
  * limb vectors (9 uint32 each, any lazy magnitude the routine allows) and returns the raw result limbs:
  * op 0 a*b, 1 a^2, 2 a*b + c, 3 a^2 + c, 4 a*b + c*d, 5 carry(a), 6 canonical(a).  tests/test_gpu_field.py
  * compares them with the host build of the same header, limb for limb -- the arithmetic under every
- * `Point + Point` of the reference (src/pippenger/group.py:31-32) is pinned at its worst-case bounds. */
+ * `Point + Point` of the reference (src/pippenger/group.py:31-32) is pinned at its worst-case bounds.
+ * op 10..15: the mod-q limb arithmetic of the batch-preparation kernel (csrc/scalar.hpp "sq"): 10 a*b, 11 a+b, 12 a-b,
+ * 13 -a (raw limbs out); 14 canonical 8 words of a; 15 inverse of a's canonical value (8 words, binary Euclid). */
 int bpmi_debug_fe_op(bpmi_ctx *ctx, int op, const uint32_t *a, const uint32_t *b, const uint32_t *c, const uint32_t *d, uint64_t n,
                      uint32_t *out);
 

@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(256) k_sc_svector(const u32 *__restrict__ tab,
 
 // Self-test hook: the DEVICE bodies of the multiplication family (csrc/field_gen.hpp) on raw limbs, so that a
 // test can feed lazy magnitudes and compare the limbs with the host build of the same header (tests/test_gpu_field.py).
-// op 0 mul(a,b), 1 sqr(a), 2 mul_add(a,b,c), 3 sqr_add(a,c), 4 mul2(a,b,c,d), 5 carry(a), 6 canon(a)
+// op 0 mul(a,b), 1 sqr(a), 2 mul_add(a,b,c), 3 sqr_add(a,c), 4 mul2(a,b,c,d), 5 carry(a), 6 canon(a); 10..15: mod-q limb arithmetic (below)
 __global__ void __launch_bounds__(256) k_debug_fe_op(int op, const u32 *__restrict__ a, const u32 *__restrict__ b, const u32 *__restrict__ c,
                                                      const u32 *__restrict__ d, u32 n, u32 *__restrict__ out) {
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -139,6 +139,25 @@ __global__ void __launch_bounds__(256) k_debug_fe_op(int op, const u32 *__restri
     case 5: fe_carry(r, A); break;
     case 6: fe_canon(r, A); break;
     default: fe_set_zero(r);
+  }
+  if (op >= 10) {
+    // arithmetic mod q on 9 x 29-bit limbs (scalar.hpp "sq"; sq_mul is the generated chain of scalar_gen.hpp): 10 mul, 11 add,
+    // 12 sub, 13 neg(a) -> raw limbs; 14: canonical words of a (8 words + 0); 15: inverse of the canonical value of a
+    sq X, Y, R;
+#pragma unroll
+    for (int k = 0; k < 9; k++) { X.v[k] = A.v[k]; Y.v[k] = B.v[k]; R.v[k] = 0; }
+    sc cv;
+    switch (op) {
+      case 10: sq_mul(R, X, Y); break;
+      case 11: sq_add(R, X, Y); break;
+      case 12: sq_sub(R, X, Y); break;
+      case 13: sq_neg(R, X); break;
+      case 14: sq_to_sc(cv, X); for (int k = 0; k < 8; k++) R.v[k] = cv.v[k]; break;
+      case 15: { sc in; sq_to_sc(in, X); sc_inv(cv, in); for (int k = 0; k < 8; k++) R.v[k] = cv.v[k]; break; }
+      default: break;
+    }
+#pragma unroll
+    for (int k = 0; k < 9; k++) r.v[k] = R.v[k];
   }
 #pragma unroll
   for (int k = 0; k < 9; k++) out[9ull * i + k] = r.v[k];

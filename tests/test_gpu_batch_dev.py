@@ -249,3 +249,62 @@ def test_batch_verifier_end_to_end_on_the_device(eng):
     bv = BatchRangeVerifier(b["g"], b["h"], b["gs"], b["hs"], b["u"])
     with pytest.raises(Exception, match="Proof invalid"):
         bv.add_wire_native(b["Vs"], blobs[:5] + [bytes(bad)] + blobs[6:], prepare="device")
+
+
+def test_fuzz_single_proof_verdicts_equal_host(eng):
+    """1500 mutated proofs, one per call, so that every verdict is compared (not only the first failing index of a batch):
+    device preparation == host preparation + decompression flags.  Mutations: bit flips, byte overwrites, truncation,
+    extension, length-field edits, splices of another proof's transcript."""
+    b = make_batch(4, n=8)
+    blobs = [proof_to_bytes(pr) for pr in b["proofs"]]
+    k = 3
+    ints_end = 6 + 32 * (5 + k)
+    pts_end = ints_end + 33 * (6 + 2 * k)
+    rnd = random.Random(77)
+    w = b"".join(rnd.randrange(1, Q).to_bytes(32, "little") for _ in range(4))
+    accepted = 0
+    for trial in range(1500):
+        src = blobs[rnd.randrange(4)]
+        bad = bytearray(src)
+        kind = rnd.randrange(8)
+        if kind == 0:
+            pass                                            # unmodified
+        elif kind == 1:
+            for _ in range(rnd.randrange(1, 4)):
+                bad[rnd.randrange(len(bad))] ^= 1 << rnd.randrange(8)
+        elif kind == 2:
+            bad[rnd.randrange(len(bad))] = rnd.randrange(256)
+        elif kind == 3:
+            del bad[rnd.randrange(len(bad)):]
+        elif kind == 4:
+            bad += bytes(rnd.randrange(256) for _ in range(rnd.randrange(1, 12)))
+        elif kind == 5:                                     # one of the three length fields, or the start index
+            pos = pts_end + rnd.choice((0, 1))
+            if rnd.random() < 0.7:
+                t0 = pts_end + 2
+                l0 = int.from_bytes(src[t0:t0 + 4], "big")
+                t1 = t0 + 4 + l0
+                l1 = int.from_bytes(src[t1:t1 + 4], "big")
+                pos = rnd.choice((t0, t1, t1 + 4 + l1)) + rnd.randrange(4)
+            bad[pos] = (bad[pos] + rnd.choice((1, 255, 128))) & 0xFF
+        elif kind == 6:                                     # another proof's tail (its transcripts) behind this proof's head
+            other = blobs[rnd.randrange(4)]
+            cut = rnd.randrange(pts_end, len(bad))
+            bad = bytearray(bytes(bad[:cut]) + other[cut:])
+        else:                                               # an '&' or a digit changed inside a transcript
+            pos = rnd.randrange(pts_end + 14, len(bad))
+            bad[pos] = rnd.choice(b"&0123456789=")
+        blob = bytes(bad)
+        h = host_prepare(8, 1, [blob], w, None)
+        d = dev_prepare(eng, 8, 1, [blob], w, None)
+        assert h[0] == 0 and d[0] == 0
+        host_bad = h[1]
+        if host_bad < 0:
+            _, ok = eng.ec_decompress_batch_bytes(h[5], len(h[5]) // 33)
+            if 0 in ok:
+                host_bad = 0
+        assert d[1] == host_bad, (trial, kind, d[1], host_bad)
+        if host_bad < 0:
+            accepted += 1
+            assert d[2] == h[2] and d[3] == h[3] and d[4] == h[4]
+    assert 150 < accepted < 700          # the unmodified eighth, plus mutations that happen to leave the proof as it was

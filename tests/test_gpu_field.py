@@ -48,3 +48,60 @@ def test_device_multiplication_family_equals_host_limb_for_limb(shim):  # noqa: 
         eng._ck(eng.lib.bpmi_debug_fe_op(eng.ctx, op, arr, arr, arr, arr, n, out))
         for i, p in enumerate(pats):
             assert list(out)[9 * i: 9 * i + 9] == fe_raw(shim, op, p)
+
+
+def test_device_mod_q_limb_arithmetic_equals_host(shim):  # noqa: F811
+    """sq_mul_dev (csrc/scalar_gen.hpp, generated multiply-add chains), sq_add / sq_sub / sq_neg, the canonical form and the
+    binary-Euclid inverse ON THE DEVICE against the host build of the same header (itself pinned to Python integers in
+    tests/test_csrc_host.py): identical limbs, also from the largest loose operands."""
+    import gpu_common
+    from test_csrc_host import secp256k1
+    eng = gpu_common.engine()
+    q = secp256k1.q
+    rnd = random.Random(31)
+    u32x9 = ctypes.c_uint32 * 9
+    LOOSE = (1 << 29) + (1 << 10)
+    top = [LOOSE - 1] * 9
+
+    def host(op, a, b):
+        out_l, out_v = u32x9(), ctypes.create_string_buffer(32)
+        shim.t_sq_raw(op, u32x9(*a), u32x9(*b), out_l, out_v)
+        return list(out_l), int.from_bytes(out_v.raw, "little")
+
+    def value(limbs):
+        return sum(v << (29 * i) for i, v in enumerate(limbs))
+
+    edge = [top, [0] * 9, [1] + [0] * 8, [(1 << 29) - 1] * 9, [1 << 29] * 9, [0] * 8 + [LOOSE - 1], [LOOSE - 1] + [0] * 8]
+    edge += [[(v >> (29 * i)) & 0x1FFFFFFF for i in range(9)] for v in (q, q - 1, q + 1, 2**256 - 1, 2**255, 1 << 232)]
+    rand = [[rnd.randrange(LOOSE) for _ in range(9)] for _ in range(3000)] + [[rnd.randrange(1 << 29) for _ in range(8)] + [rnd.randrange(1 << 24)] for _ in range(3000)]
+    pairs = [(a, b) for a in edge for b in edge] + [(rnd.choice(rand + edge), rnd.choice(rand + edge)) for _ in range(20000)]
+    n = len(pairs)
+    A = (ctypes.c_uint32 * (9 * n))(*[v for a, _ in pairs for v in a])
+    B = (ctypes.c_uint32 * (9 * n))(*[v for _, b in pairs for v in b])
+    for dev_op, host_op, fn in ((10, 0, lambda x, y: x * y), (11, 1, lambda x, y: x + y), (12, 2, lambda x, y: x - y), (13, 3, lambda x, y: -x)):
+        out = (ctypes.c_uint32 * (9 * n))()
+        eng._ck(eng.lib.bpmi_debug_fe_op(eng.ctx, dev_op, A, B, A, A, n, out))
+        got = list(out)
+        for i, (a, b) in enumerate(pairs):
+            dev = got[9 * i: 9 * i + 9]
+            assert all(v < LOOSE for v in dev)
+            assert value(dev) % q == fn(value(a), value(b)) % q, (dev_op, a, b)
+            if i < 2500:
+                assert dev == host(host_op, a, b)[0], (dev_op, a, b)
+    # canonical form and inverse
+    out = (ctypes.c_uint32 * (9 * n))()
+    eng._ck(eng.lib.bpmi_debug_fe_op(eng.ctx, 14, A, B, A, A, n, out))
+    got = list(out)
+    canon = []
+    for i, (a, _) in enumerate(pairs):
+        w = got[9 * i: 9 * i + 8]
+        c = sum(v << (32 * k) for k, v in enumerate(w))
+        assert c == value(a) % q
+        canon.append(c)
+    m = 4000
+    out = (ctypes.c_uint32 * (9 * m))()
+    eng._ck(eng.lib.bpmi_debug_fe_op(eng.ctx, 15, A, B, A, A, m, out))
+    got = list(out)
+    for i in range(m):
+        inv = sum(v << (32 * k) for k, v in enumerate(got[9 * i: 9 * i + 8]))
+        assert inv == (pow(canon[i], -1, q) if canon[i] else 0)
