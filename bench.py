@@ -423,8 +423,10 @@ def extra_c5(eng, world, rank, dev, log_batch=14, distinct=64):
     threads = max(1, min(32, usable // world))
     sharded = ShardedMSM(engine=eng)
 
+    bv = BatchRangeVerifier(g, h, gs, hs, u, engine=eng)
+
     def one_batch(corrupt=False):
-        bv = BatchRangeVerifier(g, h, gs, hs, u, engine=eng)
+        bv.reset()            # keeps the previous batch's device buffers for this one
         buf = wire_buf
         if corrupt:           # flip one bit inside one proof of this rank's shard: the batch must reject
             bad = bytearray(wire_joined)
@@ -436,7 +438,6 @@ def extra_c5(eng, world, rank, dev, log_batch=14, distinct=64):
             ok = bool(bv.verify(sharded=sharded if (dist.is_initialized() and not corrupt) else None))
         except Exception:
             ok = False
-        bv.reset()            # frees the batch's device buffers
         return ok
 
     one_batch()                                        # warm (workspaces, pinned buffers)
@@ -460,10 +461,14 @@ def extra_c5(eng, world, rank, dev, log_batch=14, distinct=64):
     # exchange of the partials stays on this thread, in batch order, so every rank issues its collectives in the same order.
     from concurrent.futures import ThreadPoolExecutor
     from bulletproofs_amd.engine import Engine
-    eng_b = Engine(device=eng.device)
-    buf_b = eng_b.host_alloc(len(wire_joined))
-    buf_b.view[:] = wire_joined
-    slots = [(BatchRangeVerifier(g, h, gs, hs, u, engine=eng), wire_buf), (BatchRangeVerifier(g, h, gs, hs, u, engine=eng_b), buf_b)]
+    inflight = max(1, int(os.environ.get("BENCH_C5_INFLIGHT", "2")))
+    slots, extra_engines = [(bv, wire_buf)], []
+    for _ in range(inflight - 1):
+        e2 = Engine(device=eng.device)
+        b2 = e2.host_alloc(len(wire_joined))
+        b2.view[:] = wire_joined
+        extra_engines.append((e2, b2))
+        slots.append((BatchRangeVerifier(g, h, gs, hs, u, engine=e2), b2))
 
     def local_partial(slot):
         bv, buf = slots[slot]
@@ -481,25 +486,29 @@ def extra_c5(eng, world, rank, dev, log_batch=14, distinct=64):
             part = sharded.combine(part)
         return part == bytes(64)
 
-    pipe_batches = 8
-    with ThreadPoolExecutor(1) as ex_a, ThreadPoolExecutor(1) as ex_b:
-        lanes = (ex_a, ex_b)
-        for f in [lanes[i & 1].submit(local_partial, i & 1) for i in range(2)]:      # warm both slots
+    pipe_batches = 16 * inflight
+    lanes = [ThreadPoolExecutor(1) for _ in range(inflight)]                         # one thread per slot: a slot never runs two batches at once
+    try:
+        for f in [lanes[i].submit(local_partial, i) for i in range(inflight)]:       # warm every slot
             finish(f.result())
         if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
-        futs = [lanes[i & 1].submit(local_partial, i & 1) for i in range(pipe_batches)]
+        futs = [lanes[i % inflight].submit(local_partial, i % inflight) for i in range(pipe_batches)]
         oks += [finish(f.result()) for f in futs]
         if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize(dev)
         elapsed_pipe = (time.perf_counter() - t0) / pipe_batches
+    finally:
+        for ex in lanes:
+            ex.shutdown()
     for bv, _ in slots:
-        bv.reset()
-    buf_b.free()
-    eng_b.close()
+        bv.release()
+    for e2, b2 in extra_engines:
+        b2.free()
+        e2.close()
     if dist.is_initialized():
         tt = torch.tensor([elapsed, elapsed_pipe], dtype=torch.float64, device="cpu" if dist.get_backend() != "nccl" else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -511,7 +520,7 @@ def extra_c5(eng, world, rank, dev, log_batch=14, distinct=64):
     wire_bytes = len(wire_buf)
     gpu_ms = sum(stage_ms.values())
     return {"metric": "range-proof verifies/sec (batched, 64-bit proofs, wire bytes in)", "value": total / elapsed_pipe, "unit": "verifies/s",
-            "batch": total, "seconds_per_batch": elapsed_pipe, "batches_in_flight": 2, "batch_latency_s": elapsed,
+            "batch": total, "seconds_per_batch": elapsed_pipe, "batches_in_flight": inflight, "batch_latency_s": elapsed,
             "verifies_per_s_one_batch_at_a_time": total / elapsed, "preparation": "device (bpmi_rp_batch_prepare_dev)",
             "accepted": all(oks), "corrupted_batch_rejected": rejected,
             "host_threads_per_rank": threads, "host_cores_usable": usable, "msm_pairs_per_rank": msm_pairs,
@@ -522,8 +531,8 @@ def extra_c5(eng, world, rank, dev, log_batch=14, distinct=64):
                          "frac": (ALGO_BYTES_PER_PAIR * msm_pairs / acc_s / 1e9 / HBM_PEAK_GBS) if acc_s > 0 else None,
                          "dominant_gpu_stage": dom, "traffic": None,
                          "note": "GPU stages %.2f ms per batch (preparation kernel, point decoding, one MSM); one batch at a time takes %.2f ms "
-                                 "(+ the %.1f MB upload from the page-locked receive buffer and the syncs), two in flight %.2f ms per batch"
-                                 % (gpu_ms, elapsed * 1e3, wire_bytes / 1e6, elapsed_pipe * 1e3)}}
+                                 "(+ the %.1f MB upload from the page-locked receive buffer and the syncs), %d in flight %.2f ms per batch"
+                                 % (gpu_ms, elapsed * 1e3, wire_bytes / 1e6, inflight, elapsed_pipe * 1e3)}}
 
 
 # ---- extra: config C3, inner-product-argument prover n = 2^20 ----------------------------------------

@@ -70,11 +70,39 @@ class BatchRangeVerifier:
         self._pts = []          # per-proof points, 64-byte strings
         self._scs = []          # matching scalars (ints mod q)
         self._raw_pts, self._raw_scs, self._raw_count = [], [], 0     # merged states: already packed
-        for d_p, d_s, _ in getattr(self, "_dev_chunks", ()):          # device-resident batches of add_wire_native
-            d_p.free()
-            d_s.free()
+        # device-resident batches of add_wire_native: the buffers are kept for the next batch of the same shape (hipMalloc /
+        # hipFree per batch cost more than they look: hipFree waits for the whole device, which also stalls another
+        # verifier's batch in flight); release() returns them
+        spare = getattr(self, "_spare", [])
+        for d_p, d_s, _ in getattr(self, "_dev_chunks", ()):
+            if len(spare) < 2:
+                spare.append((d_p, d_s))
+            else:
+                d_p.free()
+                d_s.free()
+        self._spare = spare
         self._dev_chunks = []
         self.count = 0
+
+    def release(self):
+        """Free every device buffer this verifier holds (spares of reset(), the cached shared generators)."""
+        self.reset()
+        for d_p, d_s in self._spare:
+            d_p.free()
+            d_s.free()
+        self._spare = []
+        for name in ("_d_shared_pts", "_d_shared_scs"):
+            buf = getattr(self, name, None)
+            if buf is not None:
+                buf.free()
+                setattr(self, name, None)
+
+    def _chunk_buffers(self, eng, npairs):
+        for i, (d_p, d_s) in enumerate(self._spare):
+            if d_p.nbytes == 64 * npairs and d_s.nbytes == 32 * npairs and d_p.engine is eng:
+                del self._spare[i]
+                return d_p, d_s
+        return eng.alloc(64 * npairs), eng.alloc(32 * npairs)
 
     def _weight(self):
         w = self._rng() % Q
@@ -325,7 +353,7 @@ class BatchRangeVerifier:
         if on_device:
             eng = self._eng()
             nv = count * m
-            d_pts, d_scs = eng.alloc(64 * (nv + npts)), eng.alloc(32 * (nv + npts))
+            d_pts, d_scs = self._chunk_buffers(eng, nv + npts)
             d_pts.upload(vbytes)
             ok = ctypes.create_string_buffer(npts)
             eng._ck(eng.lib.bpmi_ec_decompress_batch_dev(eng.ctx, ctypes.cast(comp, ctypes.c_void_p), npts, d_pts.ptr + 64 * nv, ctypes.cast(ok, ctypes.c_void_p)))
@@ -352,7 +380,7 @@ class BatchRangeVerifier:
         import ctypes
         eng = self._eng()
         nv, npts = count * m, count * (6 + 2 * k)
-        d_pts, d_scs = eng.alloc(64 * (nv + npts)), eng.alloc(32 * (nv + npts))
+        d_pts, d_scs = self._chunk_buffers(eng, nv + npts)
         try:
             d_pts.upload(vbytes)
             shared = ctypes.create_string_buffer(32 * (5 + 2 * self.n))
@@ -423,7 +451,14 @@ class BatchRangeVerifier:
                 d_s.free()
             chunks = [(big_p, big_s, total)]
             self._dev_chunks = chunks
-        d_hp, d_hs = eng.upload(pts), eng.upload(scs)
+        only_shared = npts == 3 + 2 * self.n                      # nothing but the shared generators on the host side: the usual wire batch
+        if only_shared:
+            # the generators never change: they are uploaded once per verifier, their coefficients go into a buffer that is kept
+            if getattr(self, "_d_shared_pts", None) is None or self._d_shared_pts.engine is not eng:
+                self._d_shared_pts, self._d_shared_scs = eng.upload(pts), eng.alloc(max(len(scs), 16))
+            d_hp, d_hs = self._d_shared_pts, self._d_shared_scs.upload(scs)
+        else:
+            d_hp, d_hs = eng.upload(pts), eng.upload(scs)
         segs = [(d_hp, d_hs, npts)] + chunks
         nseg = len(segs)
         P = (ctypes.c_void_p * nseg)(*[s[0].ptr for s in segs])
@@ -433,8 +468,9 @@ class BatchRangeVerifier:
         try:
             eng._ck(eng.lib.bpmi_msm_segs_dev(eng.ctx, nseg, P, S, N, out))
         finally:
-            d_hp.free()
-            d_hs.free()
+            if not only_shared:
+                d_hp.free()
+                d_hs.free()
         return out.raw
 
     def verify(self, sharded=None):
