@@ -336,7 +336,7 @@ def main():
 
     if not args.no_extra:
         out["extra"] = {}
-        for name, fn in (("C5_batch_verify", extra_c5), ("C3_ipa_prover", extra_c3)):
+        for name, fn in (("C5_batch_verify", extra_c5), ("C3_ipa_prover", extra_c3), ("C4_aggregated_range_proof", extra_c4)):
             try:
                 out["extra"][name] = fn(eng, world, rank, dev)
             except Exception as e:      # an extra must never cost the headline line
@@ -607,6 +607,55 @@ def extra_c3(eng, world, rank, dev, logn=20):
                          "achieved": algo / secs / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": algo / secs / 1e9 / HBM_PEAK_GBS,
                          "traffic": None,
                          "note": "960 algorithmic B per element over the whole proof (SURVEY 8d) / wall seconds of the proof; integer-ALU bound"}}
+
+
+# ---- extra: config C4, aggregated range proof m = 128 x 64-bit ------------------------------------------
+def extra_c4(eng, world, rank, dev, m=128, nbits=64):
+    """Seconds to prove and to verify ONE aggregated range proof over m = 128 values of 64 bits
+    (/root/reference/src/rangeproofs/rangeproof_aggreg_prover.py:36-115, rangeproof_aggreg_verifier.py:55-108): vectors of
+    n m = 8192 generators, one large Pedersen MSM per commitment, a 13-round inner-product argument.  Not sharded: with N > 1
+    every rank runs the same proof (replicas) and rank 0's times are reported."""
+    import torch
+    from bulletproofs_amd.ec import Point
+    from bulletproofs_amd.engine import set_default_engine
+    from bulletproofs_amd.rangeproofs import AggregNIRangeProver, AggregRangeVerifier
+    from bulletproofs_amd.ec import secp256k1
+    from bulletproofs_amd.utils import ModP, commitment, elliptic_hash, mod_hash
+    set_default_engine(eng)
+    nm = nbits * m
+    G64 = secp256k1.G.to_le64()
+
+    def gen_points(seed):                       # nm generators k_i * G (the reference derives them by hashing to the curve; only their number matters here)
+        kb, _ = synth_scalars(nm, seed)
+        raw = eng.ec_mul_batch_bytes(G64 * nm, kb, nm)
+        return [Point.from_le64(raw[64 * i: 64 * i + 64]) for i in range(nm)]
+
+    gs, hs = gen_points(7000), gen_points(7001)
+    g, h, u = elliptic_hash(b"g"), elliptic_hash(b"h"), elliptic_hash(b"u")
+    vs = [ModP(int.from_bytes(hashlib.sha256(b"v%d" % j).digest()[:8], "big"), Q) for j in range(m)]
+    gammas = [mod_hash(b"gamma%d" % j, Q) for j in range(m)]
+    Vs = [commitment(g, h, vs[j], gammas[j]) for j in range(m)]
+    prove_s, verify_s = [], []
+    proof = None
+    for rep in range(3):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        proof = AggregNIRangeProver(vs, nbits, g, h, gs, hs, gammas, u, secp256k1, b"seed").prove()
+        t1 = time.perf_counter()
+        ok = AggregRangeVerifier(Vs, g, h, gs, hs, u, proof).verify()
+        t2 = time.perf_counter()
+        prove_s.append(t1 - t0)
+        verify_s.append(t2 - t1)
+    try:                                        # one commitment swapped for another value's: must be rejected
+        rejected = not AggregRangeVerifier([Vs[1]] + Vs[1:], g, h, gs, hs, u, proof).verify()
+    except Exception:
+        rejected = True
+    return {"metric": "aggregated range proof m=%d x %d-bit: seconds to prove / to verify" % (m, nbits), "value": min(prove_s), "unit": "s",
+            "higher_is_better": False, "prove_s": round(min(prove_s), 5), "verify_s": round(min(verify_s), 5),
+            "runs_prove_s": [round(t, 5) for t in prove_s], "runs_verify_s": [round(t, 5) for t in verify_s],
+            "verified": bool(ok), "wrong_commitment_rejected": bool(rejected), "generators": 2 * nm,
+            "note": "host side of the prover / verifier is the reference-shaped Python layer; MSMs, the inner-product argument and the "
+                    "verifier's s-vector run on the GPU"}
 
 
 def usable_cpus():
