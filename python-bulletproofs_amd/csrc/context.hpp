@@ -50,7 +50,7 @@ struct bpmi_ctx {
   int opt_chunk = 0;    // entries per thread in k_accum_l0, 0 = auto
   int opt_small = 0;    // largest n handled by the one-launch small-MSM kernel (0 = default, -1 = never)
   int opt_fold_wnaf = 1;     // the IPA's 16-way generator fold: width-4 NAF over affine tables of odd multiples (0: plain NAF ladder)
-  int opt_rp_only_role = -1; // profiling only: run one role of the batch preparation kernel (results are then NOT a verification)
+  int opt_rp_only_role = -1; // profiling only: run one role of the batch preparation kernel (the call then reports proof 0 as bad)
   int opt_rp_rows = 0;       // batch preparation: proofs per launch (0 = as many as fit ~256 MB of contribution cells)
   int opt_rp_lanes = 0;      // batch preparation kernel: proofs per wave (0 = chosen from the batch size)
   void *rp_buf = nullptr; size_t rp_buf_bytes = 0;   // batch preparation: per-proof contributions to the shared generators

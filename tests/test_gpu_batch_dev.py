@@ -308,3 +308,18 @@ def test_fuzz_single_proof_verdicts_equal_host(eng):
             accepted += 1
             assert d[2] == h[2] and d[3] == h[3] and d[4] == h[4]
     assert 150 < accepted < 700          # the unmodified eighth, plus mutations that happen to leave the proof as it was
+
+
+def test_one_role_profiling_run_never_reads_as_a_verification(eng):
+    """The profiling option that runs only one role of the kernel makes the call report proof 0 as bad, whatever it saw."""
+    b = make_batch(3, n=8)
+    blobs = [proof_to_bytes(pr) for pr in b["proofs"]]
+    seed = b"\x05" * 32
+    assert dev_prepare(eng, 8, 1, blobs, None, seed)[:2] == (0, -1)
+    try:
+        for role in (0, 1):
+            eng.set_option("rp_only_role", role)
+            assert dev_prepare(eng, 8, 1, blobs, None, seed)[:2] == (0, 0)
+    finally:
+        eng.set_option("rp_only_role", -1)
+    assert dev_prepare(eng, 8, 1, blobs, None, seed)[:2] == (0, -1)
