@@ -8,10 +8,10 @@
 // Layout: the (5 + 2n) shared-generator contributions of proof g live in cells (col, g) of nine 29-bit limbs, limb-major
 // (contrib[(col * 9 + limb) * P + g]: the lanes of a wave touch neighbouring dwords), summed over g by k_rp_colsum.  The s-vector doubling
 // works in place inside those columns, so a lane needs no O(n) private memory.
-// Occupancy: a wave's run time here is a latency chain (~1 ms: dependent multiply-adds, memory round trips) that does not
-// depend on how many of its lanes are active, and 2^14 proofs are only 2 x 256 full waves on 1024 SIMDs -- so full waves
-// (`lanes` = 64, the default) are the fastest launch; fewer proofs per wave only multiply the per-wave scratch and
-// instruction-cache traffic (measured: 32 the same, 16 x1.6, 8 x5.5; profiles/r02_C5_prepare_kernel.txt).
+// Occupancy: a wave issues ~230 000 instructions here at the wave64 minimum of 4 cycles each (profiles/
+// r02_C5_prepare_kernel_pmc.txt), and an instruction costs those 4 cycles whatever its active-lane count; 2^14 proofs are
+// only 2 x 256 full waves on 1024 SIMDs.  So full waves (`lanes` = 64, the default) are the fastest launch: 32 proofs per
+// wave take the same time, 16 x1.9, 8 x8 (profiles/r02_C5_prepare_kernel.txt).
 #pragma once
 
 namespace rpd {
@@ -37,11 +37,15 @@ __device__ __constant__ const u32 SHA_K[64] = {
     0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f,
     0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
 __device__ __forceinline__ u32 rotr(u32 x, int n) { return (x >> n) | (x << (32 - n)); }
-__device__ __forceinline__ void sha_compress(Sha &s) {
-  u32 w[16];
-#pragma unroll
-  for (int i = 0; i < 16; i++) w[i] = s.w[i];
-  u32 a = s.h[0], b = s.h[1], c = s.h[2], d = s.h[3], e = s.h[4], f = s.h[5], g = s.h[6], hh = s.h[7];
+// One compression, out of line, everything in registers: 24 scalar arguments (8 chaining words, 16 message words -- scalars
+// always travel in VGPRs, an aggregate of 24 words would go through scratch) and the 8 new chaining words back.  ONE copy of
+// the ~2000-instruction round function in the whole kernel: with the rounds inlined at every feeding site the hashing role's
+// hot code (~60 KB) did not fit the instruction cache that a pair of CUs share.
+struct H8 { u32 v[8]; };
+__device__ __noinline__ H8 sha_compress_v(u32 h0, u32 h1, u32 h2, u32 h3, u32 h4, u32 h5, u32 h6, u32 h7, u32 w0, u32 w1, u32 w2, u32 w3, u32 w4, u32 w5,
+                                          u32 w6, u32 w7, u32 w8, u32 w9, u32 w10, u32 w11, u32 w12, u32 w13, u32 w14, u32 w15) {
+  u32 w[16] = {w0, w1, w2, w3, w4, w5, w6, w7, w8, w9, w10, w11, w12, w13, w14, w15};
+  u32 a = h0, b = h1, c = h2, d = h3, e = h4, f = h5, g = h6, hh = h7;
 #pragma unroll
   for (int i = 0; i < 64; i++) {
     if (i >= 16) {
@@ -58,7 +62,14 @@ __device__ __forceinline__ void sha_compress(Sha &s) {
     const u32 t2 = S0 + mj;
     hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
   }
-  s.h[0] += a; s.h[1] += b; s.h[2] += c; s.h[3] += d; s.h[4] += e; s.h[5] += f; s.h[6] += g; s.h[7] += hh;
+  H8 r = {{h0 + a, h1 + b, h2 + c, h3 + d, h4 + e, h5 + f, h6 + g, h7 + hh}};
+  return r;
+}
+__device__ __forceinline__ void sha_compress(Sha &s) {
+  const H8 r = sha_compress_v(s.h[0], s.h[1], s.h[2], s.h[3], s.h[4], s.h[5], s.h[6], s.h[7], s.w[0], s.w[1], s.w[2], s.w[3], s.w[4], s.w[5], s.w[6],
+                              s.w[7], s.w[8], s.w[9], s.w[10], s.w[11], s.w[12], s.w[13], s.w[14], s.w[15]);
+#pragma unroll
+  for (int i = 0; i < 8; i++) s.h[i] = r.v[i];
 }
 __device__ __forceinline__ void sha_init(Sha &s) {
   const u32 H0[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
