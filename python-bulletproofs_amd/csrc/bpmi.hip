@@ -126,7 +126,7 @@ int bpmi_set_option(bpmi_ctx *ctx, const char *name, int64_t value) {
   if (!strcmp(name, "small_n")) { if (value < -1 || value > (1 << 16)) return fail(ctx, BPMI_E_ARG, "small_n must be -1 .. 65536"); ctx->opt_small = (int)value; return BPMI_OK; }
   if (!strcmp(name, "split")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "split must be 0 or 1"); ctx->opt_split = (int)value; return BPMI_OK; }
   if (!strcmp(name, "async_lanes")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "async_lanes must be 0 or 1"); ctx->opt_async_lanes = (int)value; return BPMI_OK; }
-  if (!strcmp(name, "rp_only_role")) { if (value < -1 || value > 1) return fail(ctx, BPMI_E_ARG, "rp_only_role must be -1, 0 or 1"); ctx->opt_rp_only_role = (int)value; return BPMI_OK; }
+  if (!strcmp(name, "rp_only_role")) { if (value < -1 || value > 3) return fail(ctx, BPMI_E_ARG, "rp_only_role must be in [-1, 3]"); ctx->opt_rp_only_role = (int)value; return BPMI_OK; }
   if (!strcmp(name, "rp_rows")) { if (value < 0) return fail(ctx, BPMI_E_ARG, "rp_rows must be >= 0"); ctx->opt_rp_rows = (int)value; return BPMI_OK; }
   if (!strcmp(name, "rp_lanes")) {
     if (value != 0 && (value < 1 || value > 64 || (value & (value - 1)))) return fail(ctx, BPMI_E_ARG, "rp_lanes must be 0 or a power of two <= 64");
@@ -1049,12 +1049,19 @@ int bpmi_rp_batch_prepare_dev(bpmi_ctx *ctx, uint32_t n_gens, uint32_t values_pe
   while ((1u << k) < n_gens) k++;
   *first_bad = -1;
   if (blob_off[0] > blobs_len) return fail(ctx, BPMI_E_ARG, "offset table leaves the buffer");
-  for (uint64_t g = 0; g < n_proofs; g++) if (blob_off[g] > blob_off[g + 1] || blob_off[g + 1] > blobs_len) return fail(ctx, BPMI_E_ARG, "offset table leaves the buffer");
+  uint64_t maxlen = 0;
+  for (uint64_t g = 0; g < n_proofs; g++) {
+    if (blob_off[g] > blob_off[g + 1] || blob_off[g + 1] > blobs_len) return fail(ctx, BPMI_E_ARG, "offset table leaves the buffer");
+    maxlen = std::max(maxlen, blob_off[g + 1] - blob_off[g]);
+  }
   HIPCHK(ctx, hipSetDevice(ctx->device));
   const u32 P = (u32)n_proofs, ncols = 5 + 2 * n_gens, per = 6 + 2 * k;
+  // the proofs as 8-byte words, word-major (k_rp_transpose): W rows of P words, 16 rows of zero padding for loads that run past a proof
+  const u32 W = (u32)((std::min<uint64_t>(maxlen, RP_MAX_PROOF_BYTES) + 7) / 8) + 16;
   // device staging: blobs | offsets | weights | status
-  const size_t o_off = align_up(blobs_len + 64, 256), o_w = o_off + align_up(8 * ((size_t)P + 1), 256), o_st = o_w + (weights ? align_up(128 * (size_t)P, 256) : 0);
-  int rc = ensure_stage_in(ctx, o_st + align_up(2 * (size_t)P, 256));
+  const size_t o_off = align_up(blobs_len + 128, 256);      // 128 bytes of slack: the kernel's batched 8-byte loads may run past the last proof
+  const size_t o_w = o_off + align_up(8 * ((size_t)P + 1), 256), o_st = o_w + (weights ? align_up(128 * (size_t)P, 256) : 0);
+  int rc = ensure_stage_in(ctx, o_st + align_up(RP_ROLES * (size_t)P, 256));
   if (rc) return rc;
   char *din = (char *)ctx->stage_in;
   HIPCHK(ctx, hipMemcpyAsync(din, blobs, blobs_len, hipMemcpyHostToDevice, ctx->stream));
@@ -1064,18 +1071,24 @@ int bpmi_rp_batch_prepare_dev(bpmi_ctx *ctx, uint32_t n_gens, uint32_t values_pe
   const size_t cell_row = 36 * (size_t)ncols, out_row = 32 * (size_t)ncols;       // scratch cells are 9 limbs, the result 8 words
   u32 rows = (u32)std::min<size_t>(P, std::max<size_t>(1, ((size_t)256 << 20) / cell_row));
   if (ctx->opt_rp_rows > 0) rows = std::min<u32>(rows, (u32)ctx->opt_rp_rows);
-  const size_t need = align_up(cell_row * rows, 256) + out_row + 256;
+  const size_t o_shared = align_up(cell_row * rows, 256), o_T = o_shared + align_up(out_row + 64, 256), T_bytes = 8 * (size_t)W * P;
+  const size_t need = o_T + T_bytes + 256;
   if (need > ctx->rp_buf_bytes) {
     if (ctx->rp_buf) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(ctx->rp_buf)); ctx->rp_buf = nullptr; ctx->rp_buf_bytes = 0; }
     HIPCHK(ctx, hipMalloc(&ctx->rp_buf, need));
     ctx->rp_buf_bytes = need;
   }
-  u32 *d_contrib = (u32 *)ctx->rp_buf, *d_shared = (u32 *)((char *)ctx->rp_buf + align_up(cell_row * rows, 256));
+  u32 *d_contrib = (u32 *)ctx->rp_buf, *d_shared = (u32 *)((char *)ctx->rp_buf + o_shared);
+  u64 *d_T = (u64 *)((char *)ctx->rp_buf + o_T);
   unsigned long long *d_bad = (unsigned long long *)(d_shared + 8 * (size_t)ncols);
   HIPCHK(ctx, hipMemsetAsync(d_shared, 0, out_row, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(d_bad, 0xFF, 8, ctx->stream));
+  {
+    StageTimer t(ctx, ST_RPPREP);
+    hipLaunchKernelGGL(rpd::k_rp_transpose, dim3((P + 63) / 64, (W + 63) / 64), dim3(256), 0, ctx->stream, (const uint8_t *)din, (const u64 *)(din + o_off), P, W, d_T);
+  }
   rpd::Params q;
-  q.blobs = (const uint8_t *)din;
+  q.Tstride = P;
   q.weights = weights ? (const uint8_t *)(din + o_w) : nullptr;
   for (int i = 0; i < 8; i++) q.seed[i] = seed ? ((u32)seed[4 * i] << 24) | ((u32)seed[4 * i + 1] << 16) | ((u32)seed[4 * i + 2] << 8) | seed[4 * i + 3] : 0;
   q.n = n_gens; q.k = k; q.m = m; q.Pall = P; q.only_role = ctx->opt_rp_only_role;
@@ -1086,12 +1099,13 @@ int bpmi_rp_batch_prepare_dev(bpmi_ctx *ctx, uint32_t n_gens, uint32_t values_pe
     u32 lanes = (u32)ctx->opt_rp_lanes;
     if (!lanes) lanes = 64;
     q.off = (const u64 *)(din + o_off) + base;
+    q.T = d_T + base;
     q.P = cnt; q.lanes = lanes; q.first = base;
     q.v_scalars = (u32 *)d_v_scalars + 8 * (size_t)base * m;
     q.pt_scalars = (u32 *)d_pt_scalars + 8 * (size_t)base * per;
     q.status = (uint8_t *)(din + o_st) + base;
     StageTimer t(ctx, ST_RPPREP);
-    hipLaunchKernelGGL(rpd::k_rp_prepare, dim3(2 * ((cnt + lanes - 1) / lanes)), dim3(64), 0, ctx->stream, q);
+    hipLaunchKernelGGL(rpd::k_rp_prepare, dim3(RP_ROLES * ((cnt + lanes - 1) / lanes)), dim3(64), 2 * k * 9 * 64 * sizeof(u32), ctx->stream, q);   // LDS: 2k slots of 9 limbs per lane
     hipLaunchKernelGGL(rpd::k_rp_colsum, dim3(ncols), dim3(256), 0, ctx->stream, (const u32 *)d_contrib, cnt, d_shared);
   }
   HIPCHK(ctx, hipGetLastError());

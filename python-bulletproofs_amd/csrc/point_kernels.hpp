@@ -419,7 +419,7 @@ __global__ void __launch_bounds__(256, 3) k_ec_decompress(const uint8_t *__restr
 }
 // the same for the points of wire proofs where they lie inside the blobs (rangeproofs/codec.py: (6 + 2k) encodings after the
 // 6-byte header and the 5 + k scalars); proofs that failed a role of the preparation
-// (status[g] or status[n_proofs + g] = 0) are skipped (their offsets are not trustworthy), an invalid
+// (any of its four status bytes, n_proofs apart, is 0) are skipped (their offsets are not trustworthy), an invalid
 // encoding records its proof in *bad (atomicMin; `first` = batch index of proof 0 of this launch)
 __global__ void __launch_bounds__(256, 3) k_ec_decompress_wire(const uint8_t *__restrict__ blobs, const u64 *__restrict__ off, const uint8_t *__restrict__ status,
                                                                u32 k, u32 n_proofs, u64 first, u32 *__restrict__ out, unsigned long long *bad) {
@@ -430,7 +430,7 @@ __global__ void __launch_bounds__(256, 3) k_ec_decompress_wire(const uint8_t *__
   u32 w16[16];
 #pragma unroll
   for (int j = 0; j < 16; j++) w16[j] = 0;
-  if (status[g] & status[(size_t)n_proofs + g]) {
+  if (status[g] & status[(size_t)n_proofs + g] & status[2 * (size_t)n_proofs + g] & status[3 * (size_t)n_proofs + g]) {
     const bool valid = ec_decompress_one(blobs + off[g] + 6 + 32 * (5 + k) + 33 * t, w16);
     if (!valid) atomicMin(bad, (unsigned long long)(first + g));
   }

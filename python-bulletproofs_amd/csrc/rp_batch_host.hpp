@@ -248,8 +248,9 @@ struct Parsed {
   uint32_t tl[3];
 };
 static inline uint32_t be32(const uint8_t *p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
+#define RP_HOST_MAX_PROOF_BYTES 32768u      // = RP_MAX_PROOF_BYTES of the device twin: a longer wire proof is invalid
 static inline bool parse_blob(Parsed &P, const uint8_t *blob, size_t n) {
-  if (n < 6 || memcmp(blob, "BPRP1", 5) != 0) return false;
+  if (n < 6 || n > RP_HOST_MAX_PROOF_BYTES || memcmp(blob, "BPRP1", 5) != 0) return false;
   P.k = blob[5];
   if (P.k > 16) return false;
   size_t o = 6;

@@ -1,17 +1,24 @@
 // rp_batch_kernels.hpp -- part of libbpmi (included by bpmi.hip; one translation unit).  DEVICE code.
-// The per-proof preparation of the batch range-proof verifier on the GPU: one lane per proof parses the wire blob,
-// re-hashes the three Fiat-Shamir transcripts (SHA-256), runs the byte-level checks of the reference's verifiers
-// (rangeproof_verifier.py:42-53, inner_product_verifier.py:31-43 and :104-125) and produces the weighted scalars of
-// the batch's one MSM.  It is the device twin of rp_batch_host.hpp (same checks, same numbers: tests/test_gpu_batch_dev.py
+// The per-proof preparation of the batch range-proof verifier on the GPU: a lane parses the wire blob of one proof,
+// re-hashes its Fiat-Shamir transcripts (SHA-256), runs the byte-level checks of the reference's verifiers
+// (rangeproof_verifier.py:42-53, inner_product_verifier.py:31-43 and :104-125) or produces the weighted scalars of the
+// batch's one MSM.  It is the device twin of rp_batch_host.hpp (same checks, same numbers: tests/test_gpu_batch_dev.py
 // compares the two byte for byte on the same weights); see that file for what each check means.
 //
-// Layout: the (5 + 2n) shared-generator contributions of proof g live in cells (col, g) of nine 29-bit limbs, limb-major
-// (contrib[(col * 9 + limb) * P + g]: the lanes of a wave touch neighbouring dwords), summed over g by k_rp_colsum.  The s-vector doubling
-// works in place inside those columns, so a lane needs no O(n) private memory.
-// Occupancy: a wave issues ~230 000 instructions here at the wave64 minimum of 4 cycles each (profiles/
-// r02_C5_prepare_kernel_pmc.txt), and an instruction costs those 4 cycles whatever its active-lane count; 2^14 proofs are
-// only 2 x 256 full waves on 1024 SIMDs.  So full waves (`lanes` = 64, the default) are the fastest launch: 32 proofs per
-// wave take the same time, 16 x1.9, 8 x8 (profiles/r02_C5_prepare_kernel.txt).
+// Shape of the work.  A proof is ~230 000 instructions of serial integer work and a batch has ~2^14 proofs: a wave64
+// instruction costs its 4 issue cycles whatever its active-lane count, so waves must be FULL (64 proofs each), and 2^14
+// proofs are then only 256 waves for 1024 SIMDs.  Hence four ROLES per proof, each a wave of its own (k_rp_prepare): the
+// Protocol-2 transcript | the range-proof and Protocol-1 transcripts | the gs side of the algebra with the per-proof
+// scalars | the hs side.  They share nothing but the input -- the algebra only needs the challenges a proof CLAIMS, the
+// transcript roles verify the claims -- so a proof's critical path is its longest role and every SIMD has a wave.
+// Input: k_rp_transpose first re-lays the batch as 8-byte words, word-major over the proofs (see BPtr), so that lanes
+// walking their own proofs read neighbouring words.
+// Output: the (5 + 2n) shared-generator contributions of proof g go to cells (col, g) of nine 29-bit limbs, limb-major
+// (contrib[(col * 9 + limb) * P + g]: a wave stores coalesced dword rows), summed over g by k_rp_colsum.  The s-vector is
+// generated element by element -- ONE multiplication each, the level products in LDS -- so a lane needs no O(n) private
+// memory and the cells are write-only.  Per-proof scalars go straight to the MSM's scalar array.
+// Measurements: profiles/r02_C5_prepare_kernel.txt (host vs device, proofs per wave, each role alone),
+// profiles/r02_C5_prepare_kernel_pmc.txt (instruction counts, active / wait cycles, per role).
 #pragma once
 
 namespace rpd {
@@ -97,11 +104,30 @@ __device__ __noinline__ void sha_byte(Sha &s, u32 b) {          // odd bytes (pr
   sha_byte_inl(t, b);
   s = t;
 }
-// Unaligned 8-byte load.  Byte-at-a-time loops over proof data pay one memory round trip (~0.3 us, nothing else in the wave
-// to hide it) per byte; everything below that walks the wire bytes fetches eight at a time.  The load may cover up to 7 bytes
-// beyond the item it is used for: the staged batch has 64 bytes of slack after the last proof, and bytes outside the item
-// are never interpreted.
-__device__ __forceinline__ u64 ld8(const uint8_t *p) { u64 w; __builtin_memcpy(&w, p, 8); return w; }
+// Where the proof bytes are read from.  Every lane walks its own proof, so against the wire buffer a wave's load is 64
+// scattered cache lines (measured: ~7 us per dependent round trip with all waves doing it).  k_rp_transpose therefore re-lays
+// the batch as 8-byte words, word-major over the proofs: T[w * stride + g] = bytes [8w, 8w + 8) of proof g, zero beyond the
+// proof's end.  Lanes that read the same word index of their proofs -- the normal case, the proofs have the same layout --
+// then touch neighbouring words: a load is a few coalesced 512-byte rows.  BPtr is a byte position inside one proof of that
+// array and stands in for `const uint8_t *` (p + n, p[i], ld8(p)); loads may run up to 80 bytes past the proof's end: the
+// array carries 16 zero rows of padding.
+struct BPtr {
+  const u64 *base;      // T + g
+  u32 stride;           // words between consecutive 8-byte words of one proof (= proofs in the array)
+  u32 off;              // byte offset inside the proof
+  __device__ __forceinline__ BPtr operator+(u32 n) const { BPtr r = *this; r.off += n; return r; }
+  __device__ __forceinline__ u32 operator[](u32 i) const {
+    const u32 o = off + i;
+    return (u32)(base[(size_t)(o >> 3) * stride] >> (8 * (o & 7u))) & 0xFFu;
+  }
+};
+__device__ __forceinline__ u64 ld8(const BPtr p) {                       // the 8 bytes at p, any alignment
+  const u64 *q = p.base + (size_t)(p.off >> 3) * p.stride;
+  const u32 s = 8 * (p.off & 7u);
+  const u64 a = q[0], b = q[p.stride];
+  return (a >> s) | ((b << (63 - s)) << 1);
+}
+__device__ __forceinline__ u64 ld8_raw(const uint8_t *p) { u64 w; __builtin_memcpy(&w, p, 8); return w; }      // plain memory (the weights)
 __device__ __forceinline__ void sha_word_inl(Sha &s, u32 w) {            // four bytes at a word boundary of the message
 #pragma unroll
   for (int i = 0; i < 15; i++) s.w[i] = s.w[i + 1];
@@ -110,10 +136,20 @@ __device__ __forceinline__ void sha_word_inl(Sha &s, u32 w) {            // four
   s.len += 4;
   if (s.fill == 64u) { sha_compress(s); s.fill = 0; }
 }
-__device__ __noinline__ void sha_update(Sha &s, const uint8_t *p, u32 n) {
+__device__ __noinline__ void sha_update(Sha &s, const BPtr p, u32 n) {
   Sha t = s;
   u32 i = 0;
   while (i < n && (t.fill & 3u)) sha_byte_inl(t, p[i++]);                // up to the next word boundary of the message
+  for (; i + 64 <= n; i += 64) {                                         // eight loads in flight per wait: every lane walks its
+    u64 x[8];                                                            // own proof, so a load is 64 cache lines and ~a microsecond
+#pragma unroll
+    for (int j = 0; j < 8; j++) x[j] = ld8(p + i + 8 * j);
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      sha_word_inl(t, __builtin_bswap32((u32)x[j]));
+      sha_word_inl(t, __builtin_bswap32((u32)(x[j] >> 32)));
+    }
+  }
   for (; i + 8 <= n; i += 8) {
     const u64 x = ld8(p + i);
     sha_word_inl(t, __builtin_bswap32((u32)x));
@@ -146,7 +182,7 @@ __device__ __noinline__ void sha_final_number(const Sha &s0, sc &r, bool &lt_q) 
 }
 // mod_hash(msg, q): the first i >= 1 with SHA-256(str(i) || msg) in [1, q) (src/utils/utils.py:84-97); `one` has
 // absorbed "1" and msg already (the case i = 1); the retry (probability ~2^-128) re-hashes msg[0, n) from scratch
-__device__ __noinline__ void mod_hash_q(sc &r, const Sha &one, const uint8_t *msg, u32 n) {
+__device__ __noinline__ void mod_hash_q(sc &r, const Sha &one, const BPtr msg, u32 n) {
   bool lt;
   sha_final_number(one, r, lt);
   for (u32 i = 2; !lt || bpmi::sc_is_zero(r); i++) {
@@ -166,7 +202,7 @@ __device__ __forceinline__ u32 b64_char(u32 v) {
 }
 // does the item [p, p + n) spell base64(encoding of the point)?  33 zero bytes in the wire format = identity = b"\x00"
 __device__ __forceinline__ u32 byte_of(const u64 w[], int i) { return (u32)(w[i >> 3] >> (8 * (i & 7))) & 0xFFu; }
-__device__ __noinline__ bool point_item_equals(const uint8_t *comp, const uint8_t *p, u32 n) {
+__device__ __noinline__ bool point_item_equals(const BPtr comp, const BPtr p, u32 n) {
   u64 c[5], t[6];
 #pragma unroll
   for (int i = 0; i < 5; i++) c[i] = ld8(comp + 8 * i);
@@ -183,29 +219,44 @@ __device__ __noinline__ bool point_item_equals(const uint8_t *comp, const uint8_
   }
   return same;
 }
-// canonical decimal -> value mod q (false: not canonical decimal, or >= 2^256); eight digits per load and multiplication pass
-__device__ __noinline__ bool parse_decimal(sc &r, const uint8_t *p, u32 n) {
+// canonical decimal -> value mod q (false: not canonical decimal, or >= 2^256).  All (up to 80) bytes are loaded at once;
+// eight digits become a number with three multiplications (first character in the lowest byte):
+//   pairs (x * 10 + (x >> 8)) & 0x00FF.., fours (* 100, >> 16), eight (* 10000, >> 32)
+__device__ __forceinline__ bool eight_digits(u64 x, u32 count, u32 &val) {          // the first `count` (1..8) bytes of x
+  x -= 0x3030303030303030ull;
+  if (count < 8) {                                   // right-align: the missing leading digits are zeros
+    const u32 sh = 8 * (8 - count);
+    x <<= sh;
+  }
+  const bool ok = (((x + 0x7676767676767676ull) | x) & 0x8080808080808080ull) == 0;
+  x = (x * 10 + (x >> 8)) & 0x00FF00FF00FF00FFull;
+  x = (x * 100 + (x >> 16)) & 0x0000FFFF0000FFFFull;
+  x = (x * 10000 + (x >> 32)) & 0x00000000FFFFFFFFull;
+  val = (u32)x;
+  return ok;
+}
+__device__ __noinline__ bool parse_decimal(sc &r, const BPtr p, u32 n) {
   if (n == 0 || n > 78 || (n > 1 && p[0] == '0')) return false;
+  u64 x[10];
+#pragma unroll
+  for (int c = 0; c < 10; c++) x[c] = ld8(p + 8 * c);                  // 80 bytes; only the first n are looked at
+  const u32 full = n >> 3, rem = n & 7u;
   u32 t[9];
 #pragma unroll
   for (int k = 0; k < 9; k++) t[k] = 0;
-  u32 i = 0, take = n & 7u;
-  if (take == 0) take = 8;
   bool digits = true;
-  while (i < n) {
-    const u64 x = ld8(p + i);
-    u32 val = 0, scale = 1;
-    for (u32 j = 0; j < take; j++) {
-      const u32 d = ((u32)(x >> (8 * j)) & 0xFFu) - '0';
-      digits &= d <= 9u;
-      val = val * 10u + d;
-      scale *= 10u;
-    }
-    i += take;
-    u64 c = val;
 #pragma unroll
-    for (int k = 0; k < 9; k++) { c += (u64)t[k] * scale; t[k] = (u32)c; c >>= 32; }
-    take = 8;
+  for (int c = 0; c < 10; c++) {
+    const u32 count = (u32)c < full ? 8u : ((u32)c == full ? rem : 0u);
+    if (count) {
+      u32 val;
+      digits &= eight_digits(x[c], count, val);
+      u32 scale = 100000000u;
+      if (count < 8) { scale = 1; for (u32 j = 0; j < count; j++) scale *= 10u; }
+      u64 cy = val;
+#pragma unroll
+      for (int k = 0; k < 9; k++) { cy += (u64)t[k] * scale; t[k] = (u32)cy; cy >>= 32; }
+    }
   }
   if (!digits || t[8]) return false;
 #pragma unroll
@@ -213,7 +264,7 @@ __device__ __noinline__ bool parse_decimal(sc &r, const uint8_t *p, u32 n) {
   bpmi::sc_reduce_once(r);
   return true;
 }
-__device__ __forceinline__ bool sc_from_be(sc &r, const uint8_t *b) {          // 32 bytes big-endian; false when >= q
+__device__ __forceinline__ bool sc_from_be(sc &r, const BPtr b) {          // 32 bytes big-endian; false when >= q
 #pragma unroll
   for (int j = 0; j < 4; j++) {
     const u64 x = __builtin_bswap64(ld8(b + 8 * j));
@@ -260,36 +311,46 @@ __device__ __forceinline__ void invq(sc &r, const sc &a) { r = invq_v(a); }
 
 // ---- items of a '&'-separated transcript, walked front to back ---------------------------------------------------
 struct Walk {
-  const uint8_t *p;
+  BPtr p;
   u32 n;
   u32 pos;        // start of the current item
   bool have;      // there is a current item
 };
-__device__ __forceinline__ void walk_init(Walk &w, const uint8_t *p, u32 n) { w.p = p; w.n = n; w.pos = 0; w.have = true; }
+__device__ __forceinline__ void walk_init(Walk &w, const BPtr p, u32 n) { w.p = p; w.n = n; w.pos = 0; w.have = true; }
+__device__ __forceinline__ u32 first_amp(u64 x) {               // index of the first '&' among the 8 bytes of x, 8 if none
+  x ^= 0x2626262626262626ull;                                                              // '&' bytes become zero
+  const u64 z = (x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull;               // lowest set bit marks the FIRST zero byte
+  return z ? (u32)__builtin_ctzll(z) >> 3 : 8u;
+}
 __device__ __forceinline__ u32 walk_end(const Walk &w) {        // end of the current item: the next '&' or the end of the transcript
   u32 e = w.pos;
   while (e < w.n) {
-    const u64 x = ld8(w.p + e) ^ 0x2626262626262626ull;                                      // '&' bytes become zero
-    const u64 z = (x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull;               // lowest set bit marks the FIRST zero byte
-    if (z) { e += (u32)__builtin_ctzll(z) >> 3; break; }
-    e += 8;
+    u64 x[4];                                                   // four loads in flight per wait
+#pragma unroll
+    for (int j = 0; j < 4; j++) x[j] = ld8(w.p + e + 8 * j);
+    u32 k = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) { if (k == 8u * j) k += first_amp(x[j]); }
+    e += k;
+    if (k < 32) break;
   }
   return e < w.n ? e : w.n;
 }
 __device__ __forceinline__ void walk_next(Walk &w, u32 e) { w.have = e < w.n; w.pos = e + 1; }   // e = walk_end(w)
 
 struct Params {
-  const uint8_t *blobs;
-  const u64 *off;            // P + 1 offsets into blobs
+  const u64 *T;              // the proofs of this launch as 8-byte words, word-major (k_rp_transpose); T points at proof 0 of the launch
+  u32 Tstride;               // proofs in the array (= Pall)
+  const u64 *off;            // P + 1 offsets into the wire buffer (only the lengths are used here)
   const uint8_t *weights;    // P x 4 x 32 bytes, or null: derived from `seed`
   u32 seed[8];               // the 32 seed bytes as big-endian words
   u32 n, k, m, P, lanes;     // P: proofs of this launch
-  int only_role;             // profiling: -1 both roles (product), 0 / 1 = run only that role (the other reports success)
+  int only_role;             // profiling: -1 all roles (product), 0..3 = run only that role (the others report success)
   u32 Pall;                  // proofs of the whole call (the two status arrays are Pall bytes apart)
   u64 first;                 // index of proof 0 of this launch inside the whole batch (seed weights depend on it)
   u32 *contrib;              // (5 + 2n) x P cells of 9 limbs, limb-major (see cell_load)
   u32 *v_scalars, *pt_scalars;
-  uint8_t *status;           // [g] verdict of the transcript role, [Pall + g] of the algebra role (1 = passed); points at this launch's proof 0
+  uint8_t *status;           // [role * Pall + g] = verdict of a role (1 = passed); points at this launch's proof 0
   unsigned long long *bad;   // atomicMin of the failing proof indices (whole-batch numbering)
 };
 
@@ -332,11 +393,11 @@ __device__ __noinline__ void derive_weight(sc &w, const u32 seed[8], u64 g, u32 
 // ---- one proof, structurally (rp::parse_blob): header, scalars < q, the three transcripts exactly fill the rest
 struct Parsed {
   sc taux, mu, t_hat, a, b, xs[16];
-  const uint8_t *comp;
-  const uint8_t *ts[3];
+  BPtr comp;
+  BPtr ts[3];
   u32 tl[3], start;
 };
-__device__ __forceinline__ bool parse_proof(Parsed &P, const uint8_t *blob, u32 blen, u32 k) {
+__device__ __forceinline__ bool parse_proof(Parsed &P, const BPtr blob, u32 blen, u32 k) {
   const u32 fixed = 6 + 32 * (5 + k) + 33 * (6 + 2 * k) + 2;
   if (!(blen >= fixed && blob[0] == 'B' && blob[1] == 'P' && blob[2] == 'R' && blob[3] == 'P' && blob[4] == '1' && blob[5] == k)) return false;
   bool ok = true;
@@ -361,12 +422,13 @@ __device__ __forceinline__ bool parse_proof(Parsed &P, const uint8_t *blob, u32 
   return ok && o == blen;
 }
 
-// ---- role 0: the byte-level transcript checks (rp::check_transcripts) ------------------------------------------------------
-__device__ __noinline__ bool check_transcripts(const Parsed &P, u32 k) {
-  const uint8_t *comp = P.comp;
+// ---- roles 0 / 1: the byte-level transcript checks (rp::check_transcripts) --------------------------------------------------
+// part 0: the Protocol-2 transcript (three quarters of the hashing); part 1: the range-proof and Protocol-1 transcripts
+__device__ __noinline__ bool check_transcripts(const Parsed &P, u32 k, u32 part) {
+  const BPtr comp = P.comp;
   bool ok = true;
-  {
-    const uint8_t *T1 = comp, *T2 = comp + 33, *A = comp + 66, *S = comp + 99;
+  if (part == 1) {
+    const BPtr T1 = comp, T2 = comp + 33, A = comp + 66, S = comp + 99;
     Walk w;
     walk_init(w, P.ts[0], P.tl[0]);
     u32 e = walk_end(w);                                             // item 0: not checked
@@ -374,7 +436,7 @@ __device__ __noinline__ bool check_transcripts(const Parsed &P, u32 k) {
     for (u32 j = 1; j < 8 && ok; j++) {
       if (!w.have) return false;
       e = walk_end(w);
-      const uint8_t *ip = w.p + w.pos;
+      const BPtr ip = w.p + w.pos;
       const u32 il = e - w.pos;
       sc num;
       if (j == 1) ok = point_item_equals(A, ip, il);
@@ -386,7 +448,7 @@ __device__ __noinline__ bool check_transcripts(const Parsed &P, u32 k) {
     }
     if (!ok) return false;
   }
-  {                                                                  // Protocol 1: item 1 = str(mod_hash(item 0 + "&"))
+  if (part == 1) {                                                   // Protocol 1: item 1 = str(mod_hash(item 0 + "&"))
     Walk w;
     walk_init(w, P.ts[1], P.tl[1]);
     u32 e = walk_end(w);
@@ -401,11 +463,11 @@ __device__ __noinline__ bool check_transcripts(const Parsed &P, u32 k) {
     e = walk_end(w);
     if (!(parse_decimal(x_ip, w.p + w.pos, e - w.pos) && sc_eq(x_ip, h))) return false;
   }
-  {                                                                  // Protocol 2: L_i, R_i, x_i per round
+  if (part == 0) {                                                   // Protocol 2: L_i, R_i, x_i per round
     Walk w;
     walk_init(w, P.ts[2], P.tl[2]);
     for (u32 j = 0; j < P.start && w.have; j++) walk_next(w, walk_end(w));
-    const uint8_t *Ls = comp + 33 * 6, *Rs = Ls + 33 * k;
+    const BPtr Ls = comp + 33 * 6, Rs = Ls + 33 * k;
     Sha run;
     sha_init(run);
     sha_byte(run, '1');
@@ -433,7 +495,7 @@ __device__ __noinline__ bool check_transcripts(const Parsed &P, u32 k) {
   return true;
 }
 
-// ---- role 1: the weighted scalars (rp::accumulate); the challenges are READ here, role 0 checks where they come from ---------
+// ---- roles 2 / 3: the weighted scalars (rp::accumulate); the challenges are READ here, roles 0 / 1 check where they come from -----
 __device__ __forceinline__ bool read_challenges(const Parsed &P, sc &cx, sc &cy, sc &cz, sc &x_ip) {
   Walk w;
   walk_init(w, P.ts[0], P.tl[0]);
@@ -452,14 +514,21 @@ __device__ __forceinline__ bool read_challenges(const Parsed &P, sc &cx, sc &cy,
   if (!w.have) return false;
   return parse_decimal(x_ip, w.p + w.pos, walk_end(w) - w.pos);
 }
-__device__ __forceinline__ void zero_outputs(const Params &q, u32 g) {
+__device__ __forceinline__ void zero_outputs(const Params &q, u32 g, u32 side) {
   const sc z = sc_small(0);
   const sq zq = bpmi::sq_small(0);
-  for (u32 c = 0; c < 5 + 2 * q.n; c++) cell_store(cells_of(q, g), c, zq);
+  const Cells C = cells_of(q, g);
+  if (side == 1) {
+    for (u32 c = 0; c < q.n; c++) cell_store(C, 5 + q.n + c, zq);
+    return;
+  }
+  for (u32 c = 0; c < 5 + q.n; c++) cell_store(C, c, zq);
   for (u32 j = 0; j < q.m; j++) ::store_words8(q.v_scalars + ((size_t)g * q.m + j) * 8, z.v);
   for (u32 j = 0; j < 6 + 2 * q.k; j++) ::store_words8(q.pt_scalars + ((size_t)g * (6 + 2 * q.k) + j) * 8, z.v);
 }
-__device__ __noinline__ bool weighted_scalars(const Params &q, u32 g, const Parsed &P) {
+// side 0: the gs columns, the five scalar columns and the per-proof point scalars; side 1: the hs columns.  Both sides start
+// from the same challenges, inverses and weights (recomputed: ~35 % of a side) and write disjoint outputs.
+__device__ __noinline__ bool weighted_scalars(const Params &q, u32 g, const Parsed &P, u32 side) {
   const u32 n = q.n, k = q.k, m = q.m;
   const Cells C = cells_of(q, g);
   sc cxs, cys, czs, xips;
@@ -492,66 +561,114 @@ __device__ __noinline__ bool weighted_scalars(const Params &q, u32 g, const Pars
     if (q.weights) {
       const uint8_t *src = q.weights + ((size_t)(q.first + g) * 4 + t) * 32;
 #pragma unroll
-      for (int i = 0; i < 4; i++) { const u64 x = ld8(src + 8 * i); ws.v[2 * i] = (u32)x; ws.v[2 * i + 1] = (u32)(x >> 32); }
+      for (int i = 0; i < 4; i++) { const u64 x = ld8_raw(src + 8 * i); ws.v[2 * i] = (u32)x; ws.v[2 * i + 1] = (u32)(x >> 32); }
       bpmi::sc_reduce_once(ws);
     } else {
       derive_weight(ws, q.seed, q.first + g, t);
     }
     w[t] = to_sq(ws);
   }
-  const sq pa = to_sq(P.a), pb = to_sq(P.b), t_hat = to_sq(P.t_hat);
   sq t, u;
   const u32 SG = 5, SH = 5 + n;
-  // s-vector by doubling with the weights folded in: sg_i = w4 a s_i, sh_i = w4 b s_i^-1 y^-i, in place in the columns
-  mq(t, w[3], pa); cell_store(C, SG, t);
-  mq(t, w[3], pb); cell_store(C, SH, t);
-  {
-    sq ypow2 = yinv;
-    u32 len = 1;
-    for (int j = (int)k - 1; j >= 0; j--) {
-      const sq xv = xs[j], xi = xinv[j];
-      sq hi_h;
-      mq(hi_h, xi, ypow2);
-      for (u32 i = 0; i < len; i++) {
-        sq s;
-        cell_load(s, C, SG + i);
-        mq(t, s, xv); cell_store(C, SG + len + i, t);
-        mq(t, s, xi); cell_store(C, SG + i, t);
-        cell_load(s, C, SH + i);
-        mq(t, s, hi_h); cell_store(C, SH + len + i, t);
-        mq(t, s, xv); cell_store(C, SH + i, t);
+  const u32 bits = n / m;
+  // The s-vector, element by element in index order.  With every inverse pulled into the starting value,
+  //   s_i = base * prod over the SET bits b of i of g1[k-1-b],
+  // clear bits cost nothing, and stepping from i - 1 to i is ONE multiplication: the carry of the increment sets bit
+  // p = ctz(i) and clears the bits below it, so s_i = lv[d0] * g1[d0] with d0 = k-1-p and lv[d] = the product over the
+  // top d index bits (the levels below d0 all become s_i).  n - 1 multiplications per vector instead of the 2n - 2 of
+  // doubling it in place, every element produced once, in registers, and nothing ever loaded back from the contribution
+  // cells.  lv and g1 live in LDS (2k slots of 9 limbs, limb-major over the 64 lanes: 27 KB per wave at k = 6, four waves
+  // per CU) -- LDS waits are counted apart from the global stores of the cells, so the loop never waits for a store.
+  extern __shared__ u32 lds_slots[];
+  const u32 lane = threadIdx.x;
+  auto slot_store = [&](u32 slot, const sq &x) {
+#pragma unroll
+    for (int wd = 0; wd < 9; wd++) lds_slots[(slot * 9 + wd) * 64 + lane] = x.v[wd];
+  };
+  auto slot_load = [&](sq &x, u32 slot) {
+#pragma unroll
+    for (int wd = 0; wd < 9; wd++) x.v[wd] = lds_slots[(slot * 9 + wd) * 64 + lane];
+  };
+  if (side == 1) {
+    // hs columns: sh_i = w4 b s_i^-1 y^-i = (w4 b prod_d x_d) * prod over set bits b of (x_(k-1-b)^-2 y^-(2^b)); then minus
+    // w2 z^(2+j) 2^(i % bits) y^-i
+    sq cur;
+    mq(cur, w[3], to_sq(P.b));
+    {
+      sq yp = yinv;
+      for (int d = (int)k - 1; d >= 0; d--) {
+        mq(cur, cur, xs[d]);
+        mq(t, xinv[d], xinv[d]);
+        mq(t, t, yp);
+        slot_store(k + d, t);
+        mq(yp, yp, yp);
       }
-      mq(ypow2, ypow2, ypow2);
-      len <<= 1;
+    }
+    for (u32 d = 0; d < k; d++) slot_store(d, cur);
+    sq z2, geo, r2;
+    mq(z2, cz, cz);
+    bpmi::sq_add(r2, yinv, yinv);                                     // 2 / y
+    sq yn_inv = bpmi::sq_small(1);                                    // y^-bits, square and multiply
+    for (int i = 31 - __clz(bits); i >= 0; i--) {
+      mq(yn_inv, yn_inv, yn_inv);
+      if ((bits >> i) & 1u) mq(yn_inv, yn_inv, yinv);
+    }
+    sq blk = bpmi::sq_small(1), zp = z2;                              // zp = z^(2 + j)
+    for (u32 i = 0, e = 0; i < n; i++) {
+      if (e == 0) {                                                   // a new value block: w2 z^(2+j) y^-(bits j)
+        mq(geo, w[1], zp);
+        mq(geo, geo, blk);
+        mq(blk, blk, yn_inv);
+        mq(zp, zp, cz);
+      }
+      if (i) {
+        const u32 d0 = k - 1 - (u32)__builtin_ctz(i);
+        sq f;
+        slot_load(cur, d0);
+        slot_load(f, k + d0);
+        mq(cur, cur, f);
+        for (u32 d = d0 + 1; d < k; d++) slot_store(d, cur);
+      }
+      bpmi::sq_sub(t, cur, geo);
+      cell_store(C, SH + i, t);
+      mq(geo, geo, r2);
+      if (++e == bits) e = 0;
+    }
+    return true;
+  }
+  // side 0 -- gs columns: sg_i = w4 a s_i = (w4 a prod_d x_d^-1) * prod over set bits b of x_(k-1-b)^2
+  const sq pa = to_sq(P.a), pb = to_sq(P.b), t_hat = to_sq(P.t_hat);
+  {
+    sq cur;
+    mq(cur, w[3], pa);
+    for (u32 d = 0; d < k; d++) {
+      mq(cur, cur, xinv[d]);
+      mq(t, xs[d], xs[d]);
+      slot_store(k + d, t);
+    }
+    for (u32 d = 0; d < k; d++) slot_store(d, cur);
+    for (u32 i = 0; i < n; i++) {
+      if (i) {
+        const u32 d0 = k - 1 - (u32)__builtin_ctz(i);
+        sq f;
+        slot_load(cur, d0);
+        slot_load(f, k + d0);
+        mq(cur, cur, f);
+        for (u32 d = d0 + 1; d < k; d++) slot_store(d, cur);
+      }
+      cell_store(C, SG + i, cur);
     }
   }
-  sq z2, w2z, geo, r2;
+  sq z2, w2z;
   mq(z2, cz, cz);
   mq(w2z, w[1], cz);
-  cell_store(C, 3, w2z);                                           // gs_const
-  bpmi::sq_neg(t, w2z); cell_store(C, 4, t);                       // hs_const
-  bpmi::sq_add(r2, yinv, yinv);                                       // 2 / y
-  const u32 bits = n / m;
-  sq yn_inv = bpmi::sq_small(1);                                      // y^-bits, square and multiply
-  for (int i = 31 - __clz(bits); i >= 0; i--) {
-    mq(yn_inv, yn_inv, yn_inv);
-    if ((bits >> i) & 1u) mq(yn_inv, yn_inv, yinv);
-  }
+  cell_store(C, 3, w2z);                                              // gs_const
+  bpmi::sq_neg(t, w2z); cell_store(C, 4, t);                          // hs_const
   {
-    sq blk = bpmi::sq_small(1), zp = z2;                              // zp = z^(2 + j)
-    for (u32 j = 0, i = 0; j < m; j++) {
-      mq(geo, w[1], zp);
-      mq(geo, geo, blk);                                              // w2 z^(2+j) 2^(i % bits) y^-i at i = bits j
+    sq zp = z2;                                                       // V_j: -w1 z^(2+j)
+    for (u32 j = 0; j < m; j++) {
       mq(t, w[0], zp); bpmi::sq_neg(t, t);
-      store_canon(q.v_scalars + ((size_t)g * m + j) * 8, t);          // V_j: -w1 z^(2+j)
-      for (u32 e = 0; e < bits; e++, i++) {
-        sq s;
-        cell_load(s, C, SH + i);
-        bpmi::sq_sub(s, s, geo);
-        cell_store(C, SH + i, s);
-        mq(geo, geo, r2);
-      }
-      mq(blk, blk, yn_inv);
+      store_canon(q.v_scalars + ((size_t)g * m + j) * 8, t);
       mq(zp, zp, cz);
     }
   }
@@ -592,28 +709,63 @@ __device__ __noinline__ bool weighted_scalars(const Params &q, u32 g, const Pars
   return true;
 }
 
-// Two waves per group of `lanes` proofs: even blocks run role 0 (hashing and byte checks), odd blocks role 1 (algebra).  The
-// roles share nothing but the input -- the challenges a proof CLAIMS are all the algebra needs, and role 0 verifies the claims
-// -- so they run side by side and the critical path of a proof is the longer role, not their sum.  status[g] / status[Pall + g]
-// = verdict of role 0 / role 1.  A proof whose algebra role fails gets all-zero outputs.
+// Four waves per group of `lanes` proofs, one per ROLE: 0 the Protocol-2 transcript, 1 the range-proof and Protocol-1
+// transcripts (hashing and byte checks), 2 / 3 the two sides of the algebra.  The roles share nothing but the input -- the
+// challenges a proof CLAIMS are all the algebra needs, and roles 0 / 1 verify the claims -- so they run side by side, a
+// proof's critical path is its longest role instead of their sum, and 2^14 proofs put a full wave on every one of the 1024
+// SIMDs.  status[role * Pall + g] = verdict of a role; a proof whose algebra role fails gets all-zero outputs from it.
+#define RP_ROLES 4
+// A wire proof longer than this is invalid (both here and in the host twin): it bounds the transposed array.  A 64-bit proof
+// is 2.6 KB, the largest shape the format allows (k = 16) under 8 KB.
+#define RP_MAX_PROOF_BYTES 32768u
 __global__ void __launch_bounds__(64) k_rp_prepare(Params q) {
   if (threadIdx.x >= q.lanes) return;
-  const u32 role = blockIdx.x & 1u;
-  const u32 g = (blockIdx.x >> 1) * q.lanes + threadIdx.x;
+  const u32 role = blockIdx.x & (RP_ROLES - 1);
+  const u32 g = (blockIdx.x / RP_ROLES) * q.lanes + threadIdx.x;
   if (g >= q.P) return;
-  const uint8_t *blob = q.blobs + q.off[g];
-  const u32 blen = (u32)(q.off[g + 1] - q.off[g]);
   if (q.only_role >= 0 && (u32)q.only_role != role) { q.status[(size_t)role * q.Pall + g] = 1; return; }
+  BPtr blob;
+  blob.base = q.T + g; blob.stride = q.Tstride; blob.off = 0;
+  const u64 blen64 = q.off[g + 1] - q.off[g];
+  const u32 blen = (u32)blen64;
   Parsed P;
-  bool ok = parse_proof(P, blob, blen, q.k);
-  if (role == 0) {
-    ok = ok && check_transcripts(P, q.k);
+  bool ok = blen64 <= RP_MAX_PROOF_BYTES && parse_proof(P, blob, blen, q.k);
+  if (role < 2) {
+    ok = ok && check_transcripts(P, q.k, role);
   } else {
-    ok = ok && weighted_scalars(q, g, P);
-    if (!ok) zero_outputs(q, g);
+    ok = ok && weighted_scalars(q, g, P, role - 2);
+    if (!ok) zero_outputs(q, g, role - 2);
   }
   q.status[(size_t)role * q.Pall + g] = ok ? 1 : 0;
   if (!ok) atomicMin(q.bad, (unsigned long long)(q.first + g));
+}
+
+// T[w * P + g] = bytes [8w, 8w + 8) of proof g for w < W, zero beyond the proof's end (or beyond RP_MAX_PROOF_BYTES).  64 x 64
+// tiles through LDS: rows (proofs) are read as 512 contiguous bytes, columns (word index) written as 512 contiguous bytes.
+__global__ void __launch_bounds__(256) k_rp_transpose(const uint8_t *__restrict__ blobs, const u64 *__restrict__ off, u32 P, u32 W, u64 *__restrict__ T) {
+  __shared__ u64 tile[64][65];
+  const u32 g0 = blockIdx.x * 64, w0 = blockIdx.y * 64, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  for (u32 r = wave; r < 64; r += 4) {
+    const u32 g = g0 + r;
+    u64 x = 0;
+    if (g < P) {
+      const u64 beg = off[g];
+      u64 len = off[g + 1] - beg;
+      if (len > RP_MAX_PROOF_BYTES) len = RP_MAX_PROOF_BYTES;
+      const u64 o = 8ull * (w0 + lane);
+      if (o < len) {
+        __builtin_memcpy(&x, blobs + beg + o, 8);
+        const u64 left = len - o;
+        if (left < 8) x &= (1ull << (8 * left)) - 1ull;
+      }
+    }
+    tile[r][lane] = x;
+  }
+  __syncthreads();
+  for (u32 c = wave; c < 64; c += 4) {
+    const u32 w = w0 + c, g = g0 + lane;
+    if (w < W && g < P) T[(size_t)w * P + g] = tile[lane][c];
+  }
 }
 
 // shared[col] += sum over the P proofs of cell (col, .): the nine limb rows are summed as plain 64-bit integers (P < 2^22 loose

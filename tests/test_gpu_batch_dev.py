@@ -317,9 +317,31 @@ def test_one_role_profiling_run_never_reads_as_a_verification(eng):
     seed = b"\x05" * 32
     assert dev_prepare(eng, 8, 1, blobs, None, seed)[:2] == (0, -1)
     try:
-        for role in (0, 1):
+        for role in (0, 1, 2, 3):
             eng.set_option("rp_only_role", role)
             assert dev_prepare(eng, 8, 1, blobs, None, seed)[:2] == (0, 0)
     finally:
         eng.set_option("rp_only_role", -1)
     assert dev_prepare(eng, 8, 1, blobs, None, seed)[:2] == (0, -1)
+
+
+def test_long_proofs_up_to_the_wire_limit(eng):
+    """Item 0 of the range-proof transcript is free text for the verifiers, so a valid proof can be long.  Up to the wire
+    format's limit (32 KiB per proof) host and device agree byte for byte (the transposed array then has 4096 rows);
+    beyond it both call the proof invalid."""
+    b = make_batch(3, n=8)
+    blobs = [proof_to_bytes(pr) for pr in b["proofs"]]
+    k = 3
+    t0 = 6 + 32 * (5 + k) + 33 * (6 + 2 * k) + 2
+
+    def padded(blob, extra):
+        l0 = int.from_bytes(blob[t0:t0 + 4], "big")
+        return blob[:t0] + (l0 + extra).to_bytes(4, "big") + b"x" * extra + blob[t0 + 4:]
+
+    w = b"".join((7 + i).to_bytes(32, "little") for i in range(12))
+    near = [blobs[0], padded(blobs[1], 32768 - len(blobs[1])), padded(blobs[2], 9001)]
+    assert len(near[1]) == 32768
+    assert_same(eng, 8, 1, near, w, None)
+    over = [blobs[0], padded(blobs[1], 32769 - len(blobs[1])), blobs[2]]
+    assert host_prepare(8, 1, over, w, None)[1] == 1
+    assert dev_prepare(eng, 8, 1, over, w, None)[1] == 1
