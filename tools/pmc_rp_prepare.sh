@@ -22,3 +22,4 @@ for k, v in acc.items():
     print("%-32s per launch %.4g  (%d launches)" % (k, sum(v) / len(v), len(v)))
 PY
 done
+rm -rf $OUT        # the raw counter traces are tens of MB; only the summary above is kept

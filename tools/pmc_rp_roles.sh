@@ -1,3 +1,7 @@
+#!/bin/bash
+# Per-role hardware counters of k_rp_prepare (config C5, 2^14 proofs; run from the repo root ON THE GPU BOX):
+#   bash tools/pmc_rp_roles.sh >> gpurun_out/pmc_rp_prepare.txt
+# One profiling run per role (option rp_only_role): instructions, lifetime and wait cycles of one wave of that role.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/pmc_roles
 mkdir -p $OUT
@@ -16,3 +20,4 @@ for k, v in acc.items():
     print("  %-20s per active wave %.4g" % (k, sum(v) / len(v) / 256))
 PY
 done
+rm -rf $OUT        # the raw counter traces are tens of MB; only the summary above is kept
