@@ -72,8 +72,9 @@ int bpmi_sync(bpmi_ctx *ctx);
  *                  the tail stages of one MSM overlap the sort / accumulate of the next (inputs must be complete
  *                  before the first enqueue of a burst; default 0)
  *   "rp_lanes"     bpmi_rp_batch_prepare_dev: proofs per 64-lane wave (power of two; 0 = 64, the fastest measured)
- *   "rp_only_role" profiling only: 0 / 1 runs just the transcript / the algebra role of the preparation kernel; such a call
- *                  reports proof 0 as bad whatever it saw, so it can never pass for a verification; -1 (default) both
+ *   "rp_only_role" profiling only: 0..3 runs just that role of the preparation kernel (Protocol-2 transcript | range-proof
+ *                  and Protocol-1 transcripts | gs side of the algebra | hs side); such a call reports proof 0 as bad
+ *                  whatever it saw, so it can never pass for a verification; -1 (default) all four
  *   "rp_rows"      bpmi_rp_batch_prepare_dev: proofs per kernel launch (0 = as many as fit ~256 MB of scratch cells)
  *   "ipa_big_m"    base length from which the IPA prover folds its generators 16-way at
  *                  once instead of deferring the fold into the MSM scalars (default 2^18) */
@@ -234,8 +235,9 @@ int bpmi_rp_batch_prepare(uint32_t n_gens, uint32_t values_per_proof, uint64_t n
  *   d_v_scalars   n_proofs x values_per_proof x 32 B      d_pt_scalars  n_proofs x (6 + 2k) x 32 B
  *   d_points      n_proofs x (6 + 2k) x 64 B: the proofs' points, decoded where they lie in the blobs (wire order)
  * *first_bad = smallest index of a proof that failed parsing, a transcript check, or has an invalid point encoding; -1 if none.
- * A failed proof's scalars and contributions are zero.  Same numbers as bpmi_rp_batch_prepare for the same weights / seed
- * (tests/test_gpu_batch_dev.py).  n_proofs <= 2^22, blobs_len <= 4 GiB per call. */
+ * When *first_bad >= 0 the device arrays and `shared` hold no usable result (the batch is rejected).  Otherwise: the same numbers
+ * as bpmi_rp_batch_prepare for the same weights / seed, byte for byte (tests/test_gpu_batch_dev.py).  A wire proof longer
+ * than 32 KiB is invalid (in both functions).  n_proofs <= 2^22, blobs_len <= 4 GiB per call.  One call at a time per ctx. */
 int bpmi_rp_batch_prepare_dev(bpmi_ctx *ctx, uint32_t n_gens, uint32_t values_per_proof, uint64_t n_proofs, const uint8_t *blobs, uint64_t blobs_len,
                               const uint64_t *blob_off, const uint8_t *weights, const uint8_t *seed, void *d_v_scalars, void *d_pt_scalars, void *d_points,
                               uint8_t *shared, int64_t *first_bad);

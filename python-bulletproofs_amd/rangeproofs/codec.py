@@ -10,6 +10,8 @@ Layout (integers big-endian):
   T1 T2 A S u_new P_new Ls[0..k) Rs[0..k)   (6 + 2k) x 33 B, SEC1 compressed; identity = 33 zero bytes
   start_transcript (2 B)
   len (4 B) | range-proof transcript ; len | Protocol-1 transcript ; len | Protocol-2 transcript
+A serialised proof is at most 32 KiB (a 64-bit proof is 2.6 KB): the native batch preparation, host and device, calls a longer
+one invalid.
 """
 import struct
 
