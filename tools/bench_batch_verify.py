@@ -27,8 +27,10 @@ def main():
     ap.add_argument("--log-batch", type=int, default=14)
     ap.add_argument("--distinct", type=int, default=64)
     ap.add_argument("--native", type=int, default=1,
-                    help="1 (default): per-proof host work in libbpmi (bpmi_rp_batch_prepare, --workers = host threads); "
+                    help="1 (default): per-proof work in libbpmi (see --prepare; --workers = host threads of the host variant); "
                          "0: in Python (worker processes)")
+    ap.add_argument("--prepare", choices=("device", "host"), default="device",
+                    help="with --native 1: per-proof preparation on the GPU (bpmi_rp_batch_prepare_dev, default) or on host threads")
     ap.add_argument("--workers", type=int, default=-1,
                     help="host worker processes per rank for the wire path (0: serial add() on proof objects; "
                          "default: min(32, host cores / ranks))")
@@ -90,9 +92,25 @@ def main():
         t_pool = time.perf_counter() - t0
         if world > 1:
             dist.barrier()
+    if workers and args.native:
+        # the service shape of bench.py's extra: one page-locked receive buffer + offsets, commitments packed, a warm batch first
+        # (staging buffers, workspaces), then the timed one
+        import ctypes
+        from itertools import accumulate
+        joined = b"".join(blobs_in)
+        offs = (ctypes.c_uint64 * (len(blobs_in) + 1))(0, *accumulate(map(len, blobs_in)))
+        hb = eng.host_alloc(len(joined))
+        hb.view[:] = joined
+        v_packed = b"".join(V.to_le64() for V in Vs_in)
+        bv.add_wire_native(v_packed, hb, threads=workers, offsets=offs, prepare=args.prepare)
+        assert bv.verify(sharded=sharded if world > 1 else None)
+        bv.reset()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
     if workers and args.native:
-        bv.add_wire_native(Vs_in, blobs_in, threads=workers)
+        bv.add_wire_native(v_packed, hb, threads=workers, offsets=offs, prepare=args.prepare)
     elif workers:
         bv.add_wire(Vs_in, blobs_in)
     else:
@@ -115,7 +133,9 @@ def main():
                           "host_prep_s_rank0": t_host, "msm_points_rank0": 3 + 2 * n + 19 * (hi - lo), "ok": ok,
                           "proves_per_s_one_gpu": args.distinct / t_prove, "host_workers_per_rank": workers,
                           "input": "wire bytes (GPU batch decompression inside the timed region)" if workers else "proof objects",
-                          "host_work": ("native, %d threads" % workers) if (workers and args.native) else ("python, %d processes" % workers if workers else "python, in-process"),
+                          "per_proof_work": (("GPU (bpmi_rp_batch_prepare_dev)" if args.prepare == "device" else "native host code, %d threads" % workers)
+                                             if (workers and args.native) else ("python, %d processes" % workers if workers else "python, in-process")),
+                          "timed": "one warm batch, one at a time (bench.py's extra also reports two in flight)" if (workers and args.native) else "one cold batch",
                           "worker_pool_startup_s": t_pool, "host_cores": os.cpu_count(),
                           "host_cores_usable": usable}))
     bv.stop_workers()
