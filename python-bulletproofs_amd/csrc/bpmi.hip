@@ -1094,6 +1094,8 @@ int bpmi_rp_batch_prepare_dev(bpmi_ctx *ctx, uint32_t n_gens, uint32_t values_pe
   q.n = n_gens; q.k = k; q.m = m; q.Pall = P; q.only_role = ctx->opt_rp_only_role;
   q.contrib = d_contrib;
   q.bad = d_bad;
+  const size_t lds_bytes = 2 * (size_t)k * 9 * 64 * sizeof(u32);            // 2k slots of 9 limbs per lane (the s-vector walk)
+  if (lds_bytes > 64 * 1024) HIPCHK(ctx, hipFuncSetAttribute((const void *)rpd::k_rp_prepare, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   for (u32 base = 0; base < P; base += rows) {
     const u32 cnt = std::min(rows, P - base);
     u32 lanes = (u32)ctx->opt_rp_lanes;
@@ -1105,7 +1107,7 @@ int bpmi_rp_batch_prepare_dev(bpmi_ctx *ctx, uint32_t n_gens, uint32_t values_pe
     q.pt_scalars = (u32 *)d_pt_scalars + 8 * (size_t)base * per;
     q.status = (uint8_t *)(din + o_st) + base;
     StageTimer t(ctx, ST_RPPREP);
-    hipLaunchKernelGGL(rpd::k_rp_prepare, dim3(RP_ROLES * ((cnt + lanes - 1) / lanes)), dim3(64), 2 * k * 9 * 64 * sizeof(u32), ctx->stream, q);   // LDS: 2k slots of 9 limbs per lane
+    hipLaunchKernelGGL(rpd::k_rp_prepare, dim3(RP_ROLES * ((cnt + lanes - 1) / lanes)), dim3(64), lds_bytes, ctx->stream, q);
     hipLaunchKernelGGL(rpd::k_rp_colsum, dim3(ncols), dim3(256), 0, ctx->stream, (const u32 *)d_contrib, cnt, d_shared);
   }
   HIPCHK(ctx, hipGetLastError());

@@ -345,3 +345,44 @@ def test_long_proofs_up_to_the_wire_limit(eng):
     over = [blobs[0], padded(blobs[1], 32769 - len(blobs[1])), blobs[2]]
     assert host_prepare(8, 1, over, w, None)[1] == 1
     assert dev_prepare(eng, 8, 1, over, w, None)[1] == 1
+
+
+@pytest.mark.parametrize("m,bits", [(128, 64), (256, 64)])
+def test_large_aggregated_proofs_device_equals_host(eng, m, bits):
+    """Aggregated proofs over n m = 8192 and 16 384 generators (k = 13, 14: the s-vector walk's LDS tables cross 64 KB per block
+    at k = 14): proofs made by the product's own prover, prepared by the device and by the host twin -- identical numbers --
+    and the batch verifies."""
+    import hashlib
+    from bulletproofs_amd.ec import Point, secp256k1
+    from bulletproofs_amd.rangeproofs import AggregNIRangeProver
+    from bulletproofs_amd.utils import ModP, commitment, elliptic_hash, mod_hash
+    nm = m * bits
+    G64 = secp256k1.G.to_le64()
+
+    def gens(seed):
+        ks = b"".join(hashlib.sha256(b"g%d-%d" % (seed, i)).digest()[:31] + b"\x00" for i in range(nm))
+        raw = eng.ec_mul_batch_bytes(G64 * nm, ks, nm)
+        return [Point.from_le64(raw[64 * i: 64 * i + 64]) for i in range(nm)]
+
+    gs, hs = gens(1), gens(2)
+    g, h, u = elliptic_hash(b"g"), elliptic_hash(b"h"), elliptic_hash(b"u")
+    blobs, Vs_all = [], []
+    for t in range(2):
+        vs = [ModP(int.from_bytes(hashlib.sha256(b"v%d-%d" % (t, j)).digest()[:8], "big"), Q) for j in range(m)]
+        gammas = [mod_hash(b"gamma%d-%d" % (t, j), Q) for j in range(m)]
+        Vs_all.append([commitment(g, h, vs[j], gammas[j]) for j in range(m)])
+        blobs.append(proof_to_bytes(AggregNIRangeProver(vs, bits, g, h, gs, hs, gammas, u, secp256k1, b"seed%d" % t).prove()))
+    seed = bytes(range(32))
+    hst = host_prepare(nm, m, blobs, None, seed)
+    dev = dev_prepare(eng, nm, m, blobs, None, seed)
+    assert hst[:2] == (0, -1) and dev[:2] == (0, -1)
+    assert dev[2] == hst[2] and dev[3] == hst[3] and dev[4] == hst[4]
+    bv = BatchRangeVerifier(g, h, gs, hs, u)
+    bv.add_wire_native(Vs_all, blobs, prepare="device")
+    assert bv.verify() is True
+    bv.release()
+    bad = BatchRangeVerifier(g, h, gs, hs, u)
+    bad.add_wire_native([Vs_all[1], Vs_all[1]], blobs, prepare="device")          # proof 0 against proof 1's commitments
+    with pytest.raises(Exception, match="Proof invalid"):
+        bad.verify()
+    bad.release()
