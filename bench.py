@@ -425,6 +425,12 @@ def extra_c5(eng, world, rank, dev, log_batch=14, distinct=64):
 
     bv = BatchRangeVerifier(g, h, gs, hs, u, engine=eng)
 
+    def finish(part):
+        failed = part is None
+        if dist.is_initialized():        # a rank whose batch failed still takes part in the exchange (with a point that cannot sum to the identity by accident): no rank is left waiting
+            part = sharded.combine(secp256k1.G.to_le64() if failed else part)
+        return (not failed) and part == bytes(64)
+
     def one_batch(corrupt=False):
         bv.reset()            # keeps the previous batch's device buffers for this one
         buf = wire_buf
@@ -434,11 +440,12 @@ def extra_c5(eng, world, rank, dev, log_batch=14, distinct=64):
             buf = bytes(bad)
         try:
             bv.add_wire_native(v_packed, buf, threads=threads, offsets=wire_off_c)
-            # the corrupted batch is verified locally: a rank that rejects before the exchange must not leave the others in a collective
-            ok = bool(bv.verify(sharded=sharded if (dist.is_initialized() and not corrupt) else None))
+            part = bv.partial()
         except Exception:
-            ok = False
-        return ok
+            part = None
+        if corrupt:           # verified locally: the verdict on this rank's own shard is what is being checked
+            return part == bytes(64)
+        return finish(part)
 
     one_batch()                                        # warm (workspaces, pinned buffers)
     if dist.is_initialized():
@@ -478,13 +485,6 @@ def extra_c5(eng, world, rank, dev, log_batch=14, distinct=64):
             return bv.partial()
         except Exception:
             return None
-
-    def finish(part):
-        if part is None:
-            return False
-        if dist.is_initialized():
-            part = sharded.combine(part)
-        return part == bytes(64)
 
     pipe_batches = 16 * inflight
     lanes = [ThreadPoolExecutor(1) for _ in range(inflight)]                         # one thread per slot: a slot never runs two batches at once
