@@ -114,8 +114,27 @@ def mod_sqrt(a, p):
     return (r, p - r)
 
 
+class PackedPoints(list):
+    """A list of points with its wire form (64 bytes per point) attached, for lists that go into several MSMs -- the
+    generators of a proof are packed once instead of once per call.  Immutable by convention: build a new one instead of
+    changing it."""
+
+    def __init__(self, pts, packed=None):
+        super().__init__(pts)
+        self.packed = packed if packed is not None else b"".join(map(Point.to_le64, self))
+
+    @classmethod
+    def join(cls, *parts):
+        pts = []
+        for part in parts:
+            pts.extend(part)
+        return cls(pts, b"".join(pack_points(part) for part in parts))
+
+
 def pack_points(pts):
-    return b"".join(p.to_le64() for p in pts)
+    if isinstance(pts, PackedPoints):
+        return pts.packed
+    return b"".join(map(Point.to_le64, pts))
 
 
 def pack_scalars(es, q=secp256k1.q):

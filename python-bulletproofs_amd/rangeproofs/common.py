@@ -4,8 +4,10 @@ in the power of z attached to bit i (z^2 for every bit vs z^(2 + i // n)) and in
 blinding factors enter taux; likewise the two verifiers.  Scalar algebra is O(n m)
 host-side integer work (out of scope for the GPU); every
 group operation goes to the engine, fused into as few MSMs as the algebra allows."""
+from hashlib import sha256
+
 from .. import engine as _engine
-from ..ec import pack_points, unpack_points
+from ..ec import PackedPoints, pack_points, unpack_points
 from ..innerproduct.inner_product_prover import NIProver
 from ..pippenger import PipSECP256k1
 from ..utils.transcript import Transcript
@@ -57,6 +59,17 @@ def _powers(y, count, q):
     return out
 
 
+def _mod_hash_ints(lo, hi, digest, q):
+    """[mod_hash(str(i) + digest, q).x for i in range(lo, hi)] without a ModP object and two calls per element: the first
+    candidate (counter 1) is taken inline, anything else goes through mod_hash itself."""
+    mask = (1 << q.bit_length()) - 1
+    out = []
+    for i in range(lo, hi):
+        c = int.from_bytes(sha256(b"1%d" % i + digest).digest(), "big") & mask
+        out.append(c if 0 < c < q else mod_hash(b"%d" % i + digest, q).x)
+    return out
+
+
 def prove(vs, n, g, h, gs, hs, gammas, u, group, seed, aggregated):
     """NIRangeProver.prove (rangeproof_prover.py:35-112) / AggregNIRangeProver.prove
     (rangeproof_aggreg_prover.py:36-146).  The O(n m) scalar algebra runs on plain Python
@@ -72,12 +85,13 @@ def prove(vs, n, g, h, gs, hs, gammas, u, group, seed, aggregated):
         aL += list(map(int, reversed(bin(v.x)[2:].zfill(n))))[:n]
     aR = [(bit - 1) % q for bit in aL]
     alpha = mod_hash(b"alpha" + tr.digest, q).x
-    sL = [mod_hash(str(i).encode() + tr.digest, q).x for i in range(nm)]
-    sR = [mod_hash(str(i).encode() + tr.digest, q).x for i in range(nm, 2 * nm)]
+    sL = _mod_hash_ints(0, nm, tr.digest, q)
+    sR = _mod_hash_ints(nm, 2 * nm, tr.digest, q)
     rho = mod_hash(str(2 * n).encode() + tr.digest, q).x     # sic: 2*n also when aggregated (:61)
     # A = <aL, gs> + <aR, hs> + alpha*h and S = <sL, gs> + <sR, hs> + rho*h: two MSMs over the same
     # points, independent of each other, overlapped on the engine's two lanes
-    base = gs + hs + [h]
+    gs, hs = PackedPoints(gs), PackedPoints(hs)                      # packed once for the four MSMs and the argument below
+    base = PackedPoints.join(gs, hs, [h])
     A, S = PipSECP256k1.multiexp2(base, aL + aR + [alpha], base, sL + sR + [rho])
     tr.add_list_points([A, S])
     yM = tr.get_modp(q)
@@ -113,7 +127,7 @@ def prove(vs, n, g, h, gs, hs, gammas, u, group, seed, aggregated):
     # P - mu*h = A + x*S + sum(-z)*gs + sum(z*y^i + zt_i)*hsp - mu*h (one MSM) and in the IPA
     yscale = _powers(pow(y, -1, q), nm, q)
     P_inner = PipSECP256k1.multiexp(
-        gs + hs + [A, S, h],
+        PackedPoints.join(gs, hs, [A, S, h]),
         [-z] * nm + [(z * ypow[i] + zt[i]) * yscale[i] % q for i in range(nm)] + [1, x, -mu],
     )
     inner = NIProver(gs, hs, u, P_inner, ModP(t_hat, q), ls, rs, group, h_scale=yscale).prove()
