@@ -386,3 +386,45 @@ def test_large_aggregated_proofs_device_equals_host(eng, m, bits):
     with pytest.raises(Exception, match="Proof invalid"):
         bad.verify()
     bad.release()
+
+
+def test_c_program_verifies_a_batch_through_the_abi_only(eng, tmp_path):
+    """examples/batch_verify_c_abi.c: a C99 program over include/bpmi.h and libbpmi.so alone verifies a batch of wire proofs
+    (page-locked receive buffer -> bpmi_rp_batch_prepare_dev -> shared coefficients -> bpmi_msm_segs_dev): a valid batch, one
+    with a flipped transcript bit (rejected before the MSM, with the proof's index) and one with exchanged commitments (the
+    MSM is not the identity)."""
+    import os
+    import struct
+    import subprocess
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(repo, "python-bulletproofs_amd")
+    exe = str(tmp_path / "batch_verify_c_abi")
+    subprocess.check_call(["gcc", "-O2", "-std=c99", "-Wall", "-Wextra", "-I", os.path.join(repo, "include"),
+                           os.path.join(repo, "examples", "batch_verify_c_abi.c"), "-o", exe, os.path.join(libdir, "libbpmi.so"),
+                           "-Wl,-rpath," + libdir, "-Wl,--allow-shlib-undefined"])
+    b = make_batch(6, n=8)
+    blobs = [proof_to_bytes(pr) for pr in b["proofs"]]
+
+    def write(path, blobs, Vs):
+        offs = offsets_of(blobs)
+        with open(path, "wb") as f:
+            f.write(struct.pack("<IIIQ", 8, 1, len(blobs), offs[-1]))
+            for pt in [b["g"], b["h"], b["u"]] + b["gs"] + b["hs"] + Vs:
+                f.write(pt.to_le64())
+            f.write(struct.pack("<%dQ" % len(offs), *offs))
+            f.write(b"".join(blobs))
+
+    good = str(tmp_path / "good.bin")
+    write(good, blobs, b["Vs"])
+    r = subprocess.run([exe, good, "3"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.count("VALID in") == 3 and "INVALID" not in r.stdout, r.stdout + r.stderr
+    flipped = bytearray(blobs[4])
+    flipped[-9] ^= 4
+    bad = str(tmp_path / "bad.bin")
+    write(bad, blobs[:4] + [bytes(flipped)] + blobs[5:], b["Vs"])
+    r = subprocess.run([exe, bad], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 1 and "proof 4 is invalid" in r.stdout, r.stdout + r.stderr
+    swapped = str(tmp_path / "swapped.bin")
+    write(swapped, blobs, [b["Vs"][1], b["Vs"][0]] + b["Vs"][2:])
+    r = subprocess.run([exe, swapped], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 1 and "INVALID" in r.stdout, r.stdout + r.stderr
