@@ -101,6 +101,7 @@ void bpmi_ctx_destroy(bpmi_ctx *ctx) {
   if (ctx->pin) (void)hipHostFree(ctx->pin);
   if (ctx->stream1) { (void)hipStreamSynchronize(ctx->stream1); (void)hipStreamDestroy(ctx->stream1); }
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+  if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   for (auto e : ctx->ev_accum) if (e) (void)hipEventDestroy(e);
   if (ctx->ws1) (void)hipFree(ctx->ws1);
   for (auto &pd : ctx->pend) { if (pd.pin) (void)hipHostFree(pd.pin); if (pd.done) (void)hipEventDestroy(pd.done); }
@@ -1083,6 +1084,20 @@ int bpmi_rp_batch_prepare_dev(bpmi_ctx *ctx, uint32_t n_gens, uint32_t values_pe
   unsigned long long *d_bad = (unsigned long long *)(d_shared + 8 * (size_t)ncols);
   HIPCHK(ctx, hipMemsetAsync(d_shared, 0, out_row, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(d_bad, 0xFF, 8, ctx->stream));
+  // point decoding on the second lane: it reads only the wire bytes, so it runs beside the preparation kernels (which put one
+  // low-occupancy wave on every SIMD and leave room for it)
+  rc = ensure_lane(ctx, 1);
+  if (rc) return rc;
+  HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+  HIPCHK(ctx, hipStreamWaitEvent(ctx->stream1, ctx->ev_fork, 0));
+  {
+    StageTimer t(ctx, ST_DECOMP, ctx->stream1);
+    const u64 npts = (u64)P * per;
+    hipLaunchKernelGGL(k_ec_decompress_wire, dim3((u32)((npts + 255) / 256)), dim3(256), 0, ctx->stream1, (const uint8_t *)din, (const u64 *)(din + o_off),
+                       k, P, (u64)0, (u32)RP_MAX_PROOF_BYTES, (u32 *)d_points, d_bad);
+  }
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->stream1));
   {
     StageTimer t(ctx, ST_RPPREP);
     hipLaunchKernelGGL(rpd::k_rp_transpose, dim3((P + 63) / 64, (W + 63) / 64), dim3(256), 0, ctx->stream, (const uint8_t *)din, (const u64 *)(din + o_off), P, W, d_T);
@@ -1111,13 +1126,7 @@ int bpmi_rp_batch_prepare_dev(bpmi_ctx *ctx, uint32_t n_gens, uint32_t values_pe
     hipLaunchKernelGGL(rpd::k_rp_colsum, dim3(ncols), dim3(256), 0, ctx->stream, (const u32 *)d_contrib, cnt, d_shared);
   }
   HIPCHK(ctx, hipGetLastError());
-  {
-    StageTimer t(ctx, ST_DECOMP);
-    const u64 npts = (u64)P * per;
-    hipLaunchKernelGGL(k_ec_decompress_wire, dim3((u32)((npts + 255) / 256)), dim3(256), 0, ctx->stream, (const uint8_t *)din, (const u64 *)(din + o_off),
-                       (const uint8_t *)(din + o_st), k, P, (u64)0, (u32 *)d_points, d_bad);
-  }
-  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
   rc = ensure_pin(ctx, out_row + 64);
   if (rc) return rc;
   HIPCHK(ctx, hipMemcpyAsync(ctx->pin, d_shared, out_row + 8, hipMemcpyDeviceToHost, ctx->stream));

@@ -29,7 +29,7 @@ struct bpmi_ctx {
   // throughput-bound stages of the other
   hipStream_t stream1 = nullptr;
   void *ws1 = nullptr; size_t ws1_bytes = 0;
-  hipEvent_t ev_fork = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;      // fork: lane 1 may start; join: lane 1's work is in (batch preparation)
   // software pipeline of the asynchronous MSM pair on two lanes: the accumulate kernel of an MSM waits for the
   // accumulate kernel of the MSM enqueued before it (on the other lane), so the throughput-bound stage always has the
   // whole GPU while the other lane's latency-bound tail (segmented scan, bucket reduction) and next sort run beside it
@@ -122,6 +122,7 @@ static int ensure_lane(bpmi_ctx *ctx, int lane) {
   if (lane == 0 || ctx->stream1) return BPMI_OK;
   HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream1, hipStreamNonBlocking));
   HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+  HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
   for (int k = 0; k < 2; k++) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_accum[k], hipEventDisableTiming));
   return BPMI_OK;
 }

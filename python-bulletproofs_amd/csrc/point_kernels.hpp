@@ -418,11 +418,12 @@ __global__ void __launch_bounds__(256, 3) k_ec_decompress(const uint8_t *__restr
   ok[i] = valid ? 1 : 0;
 }
 // the same for the points of wire proofs where they lie inside the blobs (rangeproofs/codec.py: (6 + 2k) encodings after the
-// 6-byte header and the 5 + k scalars); proofs that failed a role of the preparation
-// (any of its four status bytes, n_proofs apart, is 0) are skipped (their offsets are not trustworthy), an invalid
-// encoding records its proof in *bad (atomicMin; `first` = batch index of proof 0 of this launch)
-__global__ void __launch_bounds__(256, 3) k_ec_decompress_wire(const uint8_t *__restrict__ blobs, const u64 *__restrict__ off, const uint8_t *__restrict__ status,
-                                                               u32 k, u32 n_proofs, u64 first, u32 *__restrict__ out, unsigned long long *bad) {
+// 6-byte header and the 5 + k scalars).  It needs nothing from the preparation kernel -- it checks by itself that the blob
+// is long enough to hold the encodings and carries the header of a k-round proof -- so it runs beside it on the second
+// lane; a blob that fails that check is left to the preparation's verdict (its points are zero), an invalid encoding
+// records its proof in *bad (atomicMin; `first` = batch index of proof 0 of this launch)
+__global__ void __launch_bounds__(256, 3) k_ec_decompress_wire(const uint8_t *__restrict__ blobs, const u64 *__restrict__ off, u32 k, u32 n_proofs, u64 first,
+                                                               u32 max_len, u32 *__restrict__ out, unsigned long long *bad) {
   const u32 per = 6 + 2 * k;
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_proofs * per) return;
@@ -430,8 +431,12 @@ __global__ void __launch_bounds__(256, 3) k_ec_decompress_wire(const uint8_t *__
   u32 w16[16];
 #pragma unroll
   for (int j = 0; j < 16; j++) w16[j] = 0;
-  if (status[g] & status[(size_t)n_proofs + g] & status[2 * (size_t)n_proofs + g] & status[3 * (size_t)n_proofs + g]) {
-    const bool valid = ec_decompress_one(blobs + off[g] + 6 + 32 * (5 + k) + 33 * t, w16);
+  const uint8_t *blob = blobs + off[g];
+  const u64 len = off[g + 1] - off[g];
+  const u32 pts_at = 6 + 32 * (5 + k);
+  if (len >= pts_at + 33ull * per + 2 && len <= max_len && blob[0] == 'B' && blob[1] == 'P' && blob[2] == 'R' && blob[3] == 'P' && blob[4] == '1' &&
+      blob[5] == k) {
+    const bool valid = ec_decompress_one(blob + pts_at + 33 * t, w16);
     if (!valid) atomicMin(bad, (unsigned long long)(first + g));
   }
   store_words16(out + 16ull * i, w16);
