@@ -463,12 +463,12 @@ def extra_c5(eng, world, rank, dev, log_batch=14, distinct=64):
     prof = eng.profile_read()
     eng.profile(False)
     rejected = not one_batch(corrupt=True)
-    # Throughput: two batches in flight.  Two verifiers, each with an engine (stream, workspaces) and a receive buffer of its own,
-    # work from two threads (the library calls release the GIL): the upload of one batch overlaps the kernels of the other.  The
+    # Throughput: several batches in flight.  Verifiers with an engine (stream, workspaces) and a receive buffer of their own
+    # work from their own threads (the library calls release the GIL): the upload of one batch overlaps the kernels of the other.  The
     # exchange of the partials stays on this thread, in batch order, so every rank issues its collectives in the same order.
     from concurrent.futures import ThreadPoolExecutor
     from bulletproofs_amd.engine import Engine
-    inflight = max(1, int(os.environ.get("BENCH_C5_INFLIGHT", "2")))
+    inflight = max(1, int(os.environ.get("BENCH_C5_INFLIGHT", "3")))     # 3: 9.1-9.3e6 verifies/s run after run; 2: 7.9-9.2e6 (thread timing)
     slots, extra_engines = [(bv, wire_buf)], []
     for _ in range(inflight - 1):
         e2 = Engine(device=eng.device)
