@@ -46,8 +46,8 @@ __device__ __constant__ const u32 SHA_K[64] = {
 __device__ __forceinline__ u32 rotr(u32 x, int n) { return (x >> n) | (x << (32 - n)); }
 // One compression, out of line, everything in registers: 24 scalar arguments (8 chaining words, 16 message words -- scalars
 // always travel in VGPRs, an aggregate of 24 words would go through scratch) and the 8 new chaining words back.  ONE copy of
-// the ~2000-instruction round function in the whole kernel: with the rounds inlined at every feeding site the hashing role's
-// hot code (~60 KB) did not fit the instruction cache that a pair of CUs share.
+// the ~1750-instruction round function in the whole kernel instead of one per feeding site (the transcript roles' code is
+// 12 K instructions this way, 45 K with the rounds inlined).
 struct H8 { u32 v[8]; };
 __device__ __noinline__ H8 sha_compress_v(u32 h0, u32 h1, u32 h2, u32 h3, u32 h4, u32 h5, u32 h6, u32 h7, u32 w0, u32 w1, u32 w2, u32 w3, u32 w4, u32 w5,
                                           u32 w6, u32 w7, u32 w8, u32 w9, u32 w10, u32 w11, u32 w12, u32 w13, u32 w14, u32 w15) {
@@ -97,15 +97,15 @@ __device__ __forceinline__ void sha_byte_inl(Sha &s, u32 b) {
     if (s.fill == 64u) { sha_compress(s); s.fill = 0; }
   }
 }
-// The three routines below work on a private COPY of the state: the bytes come in through a char pointer, which may alias
-// anything, so updating the caller's object in place would force a store of the shift register per byte.
+// The routines below work on a private COPY of the state and write it back once: the caller's object lives in memory (it
+// is passed by reference to out-of-line code), the copy in registers.
 __device__ __noinline__ void sha_byte(Sha &s, u32 b) {          // odd bytes (prefixes, the weight derivation)
   Sha t = s;
   sha_byte_inl(t, b);
   s = t;
 }
 // Where the proof bytes are read from.  Every lane walks its own proof, so against the wire buffer a wave's load is 64
-// scattered cache lines (measured: ~7 us per dependent round trip with all waves doing it).  k_rp_transpose therefore re-lays
+// scattered cache lines (15 M L2 requests per 2^14 proofs; 5 M with the layout below).  k_rp_transpose therefore re-lays
 // the batch as 8-byte words, word-major over the proofs: T[w * stride + g] = bytes [8w, 8w + 8) of proof g, zero beyond the
 // proof's end.  Lanes that read the same word index of their proofs -- the normal case, the proofs have the same layout --
 // then touch neighbouring words: a load is a few coalesced 512-byte rows.  BPtr is a byte position inside one proof of that
@@ -140,8 +140,8 @@ __device__ __noinline__ void sha_update(Sha &s, const BPtr p, u32 n) {
   Sha t = s;
   u32 i = 0;
   while (i < n && (t.fill & 3u)) sha_byte_inl(t, p[i++]);                // up to the next word boundary of the message
-  for (; i + 64 <= n; i += 64) {                                         // eight loads in flight per wait: every lane walks its
-    u64 x[8];                                                            // own proof, so a load is 64 cache lines and ~a microsecond
+  for (; i + 64 <= n; i += 64) {                                         // eight loads in flight per wait (a lone wave per SIMD has
+    u64 x[8];                                                            // nothing else to overlap a memory round trip with)
 #pragma unroll
     for (int j = 0; j < 8; j++) x[j] = ld8(p + i + 8 * j);
 #pragma unroll
