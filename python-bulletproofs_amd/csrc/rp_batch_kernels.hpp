@@ -7,8 +7,8 @@
 //
 // Shape of the work.  A proof is ~230 000 instructions of serial integer work and a batch has ~2^14 proofs: a wave64
 // instruction costs its 4 issue cycles whatever its active-lane count, so waves must be FULL (64 proofs each), and 2^14
-// proofs are then only 256 waves for 1024 SIMDs.  Hence four ROLES per proof, each a wave of its own (k_rp_prepare): the
-// Protocol-2 transcript | the range-proof and Protocol-1 transcripts | the gs side of the algebra with the per-proof
+// proofs are then only 256 waves for 1024 SIMDs.  Hence four ROLES per proof, each a wave of its own (k_rp_prepare): the hash
+// chain of the Protocol-2 transcript | the other transcript checks | the gs side of the algebra with the per-proof
 // scalars | the hs side.  They share nothing but the input -- the algebra only needs the challenges a proof CLAIMS, the
 // transcript roles verify the claims -- so a proof's critical path is its longest role and every SIMD has a wave.
 // Input: k_rp_transpose first re-lays the batch as 8-byte words, word-major over the proofs (see BPtr), so that lanes
@@ -423,7 +423,8 @@ __device__ __forceinline__ bool parse_proof(Parsed &P, const BPtr blob, u32 blen
 }
 
 // ---- roles 0 / 1: the byte-level transcript checks (rp::check_transcripts) --------------------------------------------------
-// part 0: the Protocol-2 transcript (three quarters of the hashing); part 1: the range-proof and Protocol-1 transcripts
+// part 0: the hash chain of the Protocol-2 transcript (every x_i re-hashed from its prefix); part 1: the range-proof and
+// Protocol-1 transcripts and the text half of Protocol 2 (the L_i / R_i items against the proof's points)
 __device__ __noinline__ bool check_transcripts(const Parsed &P, u32 k, u32 part) {
   const BPtr comp = P.comp;
   bool ok = true;
@@ -463,15 +464,11 @@ __device__ __noinline__ bool check_transcripts(const Parsed &P, u32 k, u32 part)
     e = walk_end(w);
     if (!(parse_decimal(x_ip, w.p + w.pos, e - w.pos) && sc_eq(x_ip, h))) return false;
   }
-  if (part == 0) {                                                   // Protocol 2: L_i, R_i, x_i per round
+  if (part == 1) {                                                   // Protocol 2, the text half: items s+3i, s+3i+1 are base64(L_i), base64(R_i)
     Walk w;
     walk_init(w, P.ts[2], P.tl[2]);
     for (u32 j = 0; j < P.start && w.have; j++) walk_next(w, walk_end(w));
     const BPtr Ls = comp + 33 * 6, Rs = Ls + 33 * k;
-    Sha run;
-    sha_init(run);
-    sha_byte(run, '1');
-    u32 hashed = 0;
     for (u32 i = 0; i < k; i++) {
       if (!w.have) return false;
       u32 e = walk_end(w);
@@ -482,12 +479,29 @@ __device__ __noinline__ bool check_transcripts(const Parsed &P, u32 k, u32 part)
       ok = point_item_equals(Rs + 33 * i, w.p + w.pos, e - w.pos);
       walk_next(w, e);
       if (!ok || !w.have) return false;
+      walk_next(w, walk_end(w));                                     // x_i: part 0
+    }
+  }
+  if (part == 0) {                                                   // Protocol 2: L_i, R_i, x_i per round
+    Walk w;
+    walk_init(w, P.ts[2], P.tl[2]);
+    for (u32 j = 0; j < P.start && w.have; j++) walk_next(w, walk_end(w));
+    Sha run;
+    sha_init(run);
+    sha_byte(run, '1');
+    u32 hashed = 0;
+    for (u32 i = 0; i < k; i++) {
+      if (!w.have) return false;
+      walk_next(w, walk_end(w));                                     // L_i and R_i: compared with the proof's points by part 1
+      if (!w.have) return false;
+      walk_next(w, walk_end(w));
+      if (!w.have) return false;
       const u32 upto = w.pos;                                        // prefix incl. the '&' after R_i
       sha_update(run, P.ts[2] + hashed, upto - hashed);
       hashed = upto;
       sc h, xi;
       mod_hash_q(h, run, P.ts[2], upto);
-      e = walk_end(w);
+      const u32 e = walk_end(w);
       if (!(parse_decimal(xi, w.p + w.pos, e - w.pos) && sc_eq(xi, h) && sc_eq(xi, P.xs[i]))) return false;
       walk_next(w, e);
     }
