@@ -72,8 +72,8 @@ int bpmi_sync(bpmi_ctx *ctx);
  *                  the tail stages of one MSM overlap the sort / accumulate of the next (inputs must be complete
  *                  before the first enqueue of a burst; default 0)
  *   "rp_lanes"     bpmi_rp_batch_prepare_dev: proofs per 64-lane wave (power of two; 0 = 64, the fastest measured)
- *   "rp_only_role" profiling only: 0..3 runs just that role of the preparation kernel (Protocol-2 transcript | range-proof
- *                  and Protocol-1 transcripts | gs side of the algebra | hs side); such a call reports proof 0 as bad
+ *   "rp_only_role" profiling only: 0..3 runs just that role of the preparation kernel (Protocol-2 hash chain | the other
+ *                  transcript checks | gs side of the algebra | hs side); such a call reports proof 0 as bad
  *                  whatever it saw, so it can never pass for a verification; -1 (default) all four
  *   "rp_rows"      bpmi_rp_batch_prepare_dev: proofs per kernel launch (0 = as many as fit ~256 MB of scratch cells)
  *   "ipa_big_m"    base length from which the IPA prover folds its generators 16-way at

@@ -8,4 +8,4 @@ echo "== preparation on the host (bpmi_rp_batch_prepare, 32 threads), bytes rece
 echo "== preparation on the device, bytes (pageable) receive buffer, commitments as Point objects"; C5_PREPARE=device $P 2>&1 | grep "$F"
 echo "== preparation on the device, page-locked receive buffer, commitments packed"; C5_PINNED=1 C5_PREPARE=device $P 2>&1 | grep "$F"
 for l in 8 16 32 64; do echo "== proofs per wave (rp_lanes) = $l"; C5_LANES=$l C5_PINNED=1 C5_PREPARE=device $P 2>&1 | grep "$F"; done
-for r in 0 1 2 3; do echo "== only role $r (0: Protocol-2 transcript, 1: range-proof + Protocol-1 transcripts, 2: algebra gs side + scalars, 3: algebra hs side); not a verification"; C5_ONLY_ROLE=$r C5_PINNED=1 C5_PREPARE=device $P 2>&1 | grep "rp_prepare"; done
+for r in 0 1 2 3; do echo "== only role $r (0: Protocol-2 hash chain, 1: the other transcript checks, 2: algebra gs side + scalars, 3: algebra hs side); not a verification"; C5_ONLY_ROLE=$r C5_PINNED=1 C5_PREPARE=device $P 2>&1 | grep "rp_prepare"; done
