@@ -336,7 +336,10 @@ def main():
 
     if not args.no_extra:
         out["extra"] = {}
-        for name, fn in (("C5_batch_verify", extra_c5), ("C3_ipa_prover", extra_c3), ("C4_aggregated_range_proof", extra_c4)):
+        extras = [("C5_batch_verify", extra_c5), ("C3_ipa_prover", extra_c3), ("C4_aggregated_range_proof", extra_c4)]
+        if world > 1:         # the same verifier with 2^14 proofs per GPU: a rank's 2048-proof share of the fixed batch is mostly fixed latencies
+            extras.insert(1, ("C5_batch_verify_per_gpu_batches", lambda *a: extra_c5(*a, per_gpu=True)))
+        for name, fn in extras:
             try:
                 out["extra"][name] = fn(eng, world, rank, dev)
             except Exception as e:      # an extra must never cost the headline line
@@ -379,12 +382,13 @@ def committed_traffic(logn):
 
 
 # ---- extra: config C5, batch verification of 2^14 64-bit range proofs -----------------------------
-def extra_c5(eng, world, rank, dev, log_batch=14, distinct=64):
+def extra_c5(eng, world, rank, dev, log_batch=14, distinct=64, per_gpu=False):
     """verifies/s of the random-linear-combination batch verifier on wire-format proofs: bytes in a page-locked receive
     buffer -> one upload -> GPU preparation (parse, SHA-256 transcript re-hashes, weighted scalars; one lane per proof) ->
     GPU decoding of 19 points per proof -> ONE MSM over 3 + 2*64 + 19*batch points; sharded by proof over the ranks.
     Replaces a loop of RangeVerifier.verify (/root/reference/src/rangeproofs/rangeproof_verifier.py:55-99,
-    src/innerproduct/inner_product_verifier.py:127-147)."""
+    src/innerproduct/inner_product_verifier.py:127-147).  per_gpu: the batch is 2^log_batch proofs PER RANK (weak scaling; the
+    default is BASELINE's fixed 2^14 batch split over the ranks)."""
     import torch
     import torch.distributed as dist
     from bulletproofs_amd.distributed import ShardedMSM, shard_bounds
@@ -406,7 +410,7 @@ def extra_c5(eng, world, rank, dev, log_batch=14, distinct=64):
         proofs.append((commitment(g, h, v, gamma), NIRangeProver(v, nbits, g, h, gs, hs, gamma, u, secp256k1, b"seed%d" % j).prove()))
     t_prove = time.perf_counter() - t0
     wire = [proof_to_bytes(pr) for _, pr in proofs]
-    total = 1 << log_batch
+    total = (1 << log_batch) * (world if per_gpu else 1)
     lo, hi = shard_bounds(total, world, rank)
     Vs_in = [proofs[k % distinct][0] for k in range(lo, hi)]
     blobs_in = [wire[k % distinct] for k in range(lo, hi)]
@@ -421,7 +425,9 @@ def extra_c5(eng, world, rank, dev, log_batch=14, distinct=64):
     wire_off_c = (ctypes.c_uint64 * len(wire_off))(*wire_off)
     usable = usable_cpus()
     threads = max(1, min(32, usable // world))
-    sharded = ShardedMSM(engine=eng)
+    from bulletproofs_amd.engine import Engine
+    eng_x = Engine(device=eng.device)                 # the exchange folds the ranks' partials on an engine of its own: the batch slots' engines
+    sharded = ShardedMSM(engine=eng_x)                # are busy on other threads while this thread combines (one thread per engine at a time)
 
     bv = BatchRangeVerifier(g, h, gs, hs, u, engine=eng)
 
@@ -467,7 +473,6 @@ def extra_c5(eng, world, rank, dev, log_batch=14, distinct=64):
     # work from their own threads (the library calls release the GIL): the upload of one batch overlaps the kernels of the other.  The
     # exchange of the partials stays on this thread, in batch order, so every rank issues its collectives in the same order.
     from concurrent.futures import ThreadPoolExecutor
-    from bulletproofs_amd.engine import Engine
     inflight = max(1, int(os.environ.get("BENCH_C5_INFLIGHT", "3")))     # 3: 9.1-9.3e6 verifies/s run after run; 2: 7.9-9.2e6 (thread timing)
     slots, extra_engines = [(bv, wire_buf)], []
     for _ in range(inflight - 1):
@@ -509,6 +514,7 @@ def extra_c5(eng, world, rank, dev, log_batch=14, distinct=64):
     for e2, b2 in extra_engines:
         b2.free()
         e2.close()
+    wire_buf.free()
     if dist.is_initialized():
         tt = torch.tensor([elapsed, elapsed_pipe], dtype=torch.float64, device="cpu" if dist.get_backend() != "nccl" else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -520,7 +526,7 @@ def extra_c5(eng, world, rank, dev, log_batch=14, distinct=64):
     wire_bytes = len(wire_buf)
     gpu_ms = sum(stage_ms.values())
     return {"metric": "range-proof verifies/sec (batched, 64-bit proofs, wire bytes in)", "value": total / elapsed_pipe, "unit": "verifies/s",
-            "batch": total, "seconds_per_batch": elapsed_pipe, "batches_in_flight": inflight, "batch_latency_s": elapsed,
+            "batch": total, "scaling": "weak (2^%d proofs per GPU)" % log_batch if per_gpu else "strong (one batch of 2^%d split over the ranks)" % log_batch, "seconds_per_batch": elapsed_pipe, "batches_in_flight": inflight, "batch_latency_s": elapsed,
             "verifies_per_s_one_batch_at_a_time": total / elapsed, "preparation": "device (bpmi_rp_batch_prepare_dev)",
             "accepted": all(oks), "corrupted_batch_rejected": rejected,
             "host_threads_per_rank": threads, "host_cores_usable": usable, "msm_pairs_per_rank": msm_pairs,

@@ -36,6 +36,15 @@ def test_bench_self_launches_its_ranks():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["n_ranks_seen"] == 2 and out["result_ok"] is True
     assert out["value"] > 0 and out["scaling"] == "weak"
+    # the extras with two ranks: the batch verifier's shards are verified on worker threads while the main thread exchanges the
+    # partials (its own engine), the fixed 2^14 batch and the 2^14-per-GPU variant both accept and both reject a corrupted shard
+    r = subprocess.run([a for a in cmd if a != "--no-extra"] + ["--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=1200)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    for name, batch in (("C5_batch_verify", 1 << 14), ("C5_batch_verify_per_gpu_batches", 1 << 15)):
+        c5 = out["extra"][name]
+        assert c5.get("accepted") is True and c5["corrupted_batch_rejected"] is True and c5["batch"] == batch, c5
+    assert out["extra"]["C3_ipa_prover"].get("rounds") == 20 and out["extra"]["C4_aggregated_range_proof"].get("verified") is True
     # strong scaling: one 2^16 MSM split over the two ranks, same known-answer check
     r = subprocess.run(cmd + ["--scaling", "strong"], capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
