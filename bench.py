@@ -473,7 +473,9 @@ def extra_c5(eng, world, rank, dev, log_batch=14, distinct=64, per_gpu=False):
     # work from their own threads (the library calls release the GIL): the upload of one batch overlaps the kernels of the other.  The
     # exchange of the partials stays on this thread, in batch order, so every rank issues its collectives in the same order.
     from concurrent.futures import ThreadPoolExecutor
-    inflight = max(1, int(os.environ.get("BENCH_C5_INFLIGHT", "3")))     # 3: 9.1-9.3e6 verifies/s run after run; 2: 7.9-9.2e6 (thread timing)
+    # batches in flight: throughput keeps growing with the depth (one GPU: 2: 7.9-9.2e6 verifies/s, 3: 9.1-9.4e6, 4: 9.5-10.4e6,
+    # 6: 10.4-11.4e6, 8: 10.9-11.0e6, 10: 11.8-12.1e6); every slot is a host thread, so the default follows the CPUs this rank may use
+    inflight = max(1, int(os.environ.get("BENCH_C5_INFLIGHT", "0")) or min(8, max(2, usable // world)))
     slots, extra_engines = [(bv, wire_buf)], []
     for _ in range(inflight - 1):
         e2 = Engine(device=eng.device)
