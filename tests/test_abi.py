@@ -80,3 +80,20 @@ def test_header_is_plain_c99(tmp_path):
         exe = tmp_path / "use_abi"
         subprocess.check_call(["gcc", "-std=c99", "-I", inc, str(src), "-o", str(exe), lib, "-Wl,-rpath," + os.path.dirname(lib),
                                "-Wl,--allow-shlib-undefined"])
+
+
+def test_packed_points_and_bulk_hashes_equal_the_plain_forms():
+    """Host-layer shortcuts of the range-proof prover: PackedPoints carries exactly pack_points' bytes (also through join), and
+    the inlined bulk mod_hash gives mod_hash's values."""
+    import hashlib
+    from bulletproofs_amd.ec import PackedPoints, Point, pack_points, secp256k1
+    from bulletproofs_amd.rangeproofs.common import _mod_hash_ints
+    from bulletproofs_amd.utils.utils import mod_hash
+    pts = [Point._raw(secp256k1.gx + i, secp256k1.gy + 7 * i) for i in range(9)] + [Point.IDENTITY_ELEMENT]      # wire form only: any coordinates
+    plain = b"".join(p.to_le64() for p in pts)
+    assert pack_points(pts) == plain and pack_points(PackedPoints(pts)) == plain
+    joined = PackedPoints.join(PackedPoints(pts[:4]), pts[4:7], pts[7:])
+    assert list(joined) == pts and joined.packed == plain and pack_points(joined) == plain
+    q = secp256k1.q
+    digest = hashlib.sha256(b"transcript").digest() + b"&"
+    assert _mod_hash_ints(3, 40, digest, q) == [mod_hash(str(i).encode() + digest, q).x for i in range(3, 40)]
