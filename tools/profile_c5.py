@@ -17,7 +17,7 @@ from bulletproofs_amd.utils import ModP, commitment, elliptic_hash, mod_hash  # 
 
 Q = secp256k1.q
 eng = default_engine()
-n, total, distinct = 64, 1 << 14, 64
+n, total, distinct = 64, 1 << 14, int(os.environ.get("C5_DISTINCT", "64"))
 gs = [elliptic_hash(str(i).encode() + b"gs") for i in range(n)]
 hs = [elliptic_hash(str(i).encode() + b"hs") for i in range(n)]
 g, h, u = elliptic_hash(b"g"), elliptic_hash(b"h"), elliptic_hash(b"u")
