@@ -229,6 +229,11 @@ void bpmi_ipa_destroy(bpmi_ipa *st);
 int bpmi_rp_batch_prepare(uint32_t n_gens, uint32_t values_per_proof, uint64_t n_proofs, const uint8_t *blobs, uint64_t blobs_len, const uint64_t *blob_off,
                           const uint8_t *weights, const uint8_t *seed, int threads, uint8_t *v_scalars, uint8_t *pt_scalars, uint8_t *shared, uint8_t *comp_out, int64_t *first_bad);
 
+/* out[i - lo] = mod_hash(str(i) || tail, q) for i in [lo, hi), 32 bytes little-endian each -- the reference's seeded
+ * challenge / blinding derivation (src/utils/utils.py:84-97: the first counter c >= 1 with SHA-256(str(c) || msg) in [1, q)),
+ * in bulk: the range-proof provers draw 2 n m blinding scalars this way (rangeproof_prover.py:57-60).  Host code. */
+int bpmi_mod_hash_range(const uint8_t *tail, uint64_t tail_len, uint64_t lo, uint64_t hi, int threads, uint8_t *out);
+
 /* The same preparation on the GPU (csrc/rp_batch_kernels.hpp; one lane per proof parses, re-hashes the transcripts and computes
  * the weighted scalars).  `blobs` / `blob_off` / `weights` / `seed` / `shared` are HOST pointers with the meaning above (blobs may be
  * page-locked memory from bpmi_host_alloc: the upload then runs at link speed); the outputs that feed the MSM stay on the device:

@@ -1033,6 +1033,37 @@ int bpmi_rp_batch_prepare(uint32_t n_gens, uint32_t values_per_proof, uint64_t n
   return BPMI_OK;
 }
 
+// out[i - lo] = mod_hash(str(i) || tail, q) for i in [lo, hi), 32 bytes little-endian each: the reference's seeded "randomness"
+// (src/utils/utils.py:84-97; the provers draw their blinding vectors sL, sR this way, rangeproof_prover.py:57-60, one hash per
+// element) in native code.  Host code, no GPU involved; `threads` host threads share the range.
+int bpmi_mod_hash_range(const uint8_t *tail, uint64_t tail_len, uint64_t lo, uint64_t hi, int threads, uint8_t *out) {
+  if ((!tail && tail_len) || !out || hi < lo) return BPMI_E_ARG;
+  const uint64_t count = hi - lo;
+  if (threads < 1) threads = 1;
+  if ((uint64_t)threads > count) threads = count ? (int)count : 1;
+  auto work = [&](int t) {
+    std::vector<uint8_t> msg(20 + tail_len);
+    for (uint64_t i = lo + count * t / threads, e = lo + count * (t + 1) / threads; i < e; i++) {
+      const int dl = snprintf((char *)msg.data(), 21, "%llu", (unsigned long long)i);
+      if (tail_len) memcpy(msg.data() + dl, tail, tail_len);
+      rp::Sha one;
+      rp::sha_init(one);
+      rp::sha_update(one, (const uint8_t *)"1", 1);
+      rp::sha_update(one, msg.data(), dl + tail_len);
+      rp::Sq v;
+      rp::mod_hash_q(v, one, msg.data(), dl + tail_len);
+      rp::q_to_le(out + 32 * (i - lo), v);
+    }
+  };
+  if (threads == 1) work(0);
+  else {
+    std::vector<std::thread> th;
+    for (int t = 0; t < threads; t++) th.emplace_back(work, t);
+    for (auto &x : th) x.join();
+  }
+  return BPMI_OK;
+}
+
 // The same preparation on the GPU (rp_batch_kernels.hpp): the wire proofs are uploaded once, one lane per proof parses, hashes and
 // checks them, the weighted scalars are written straight into the caller's device scalar arrays, the proofs' points are decoded
 // where they lie in the blobs into d_points, and only the (5 + 2n) shared coefficients and the verdict come back.

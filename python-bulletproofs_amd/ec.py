@@ -137,7 +137,29 @@ def pack_points(pts):
     return b"".join(map(Point.to_le64, pts))
 
 
+class PackedScalars(list):
+    """A list of scalars (ints in [0, q)) with its wire form (32 bytes little-endian each) attached -- for vectors that are both
+    computed with on the host and handed to an MSM (the provers' blinding vectors arrive from native code as bytes already)."""
+
+    def __init__(self, es, packed=None):
+        super().__init__(es)
+        self.packed = packed if packed is not None else b"".join([e.to_bytes(32, "little") for e in self])
+
+    @classmethod
+    def from_bytes(cls, raw):
+        return cls([int.from_bytes(raw[i: i + 32], "little") for i in range(0, len(raw), 32)], bytes(raw))
+
+    @classmethod
+    def join(cls, *parts):
+        es = []
+        for part in parts:
+            es.extend(part)
+        return cls(es, b"".join(pack_scalars(part) for part in parts))
+
+
 def pack_scalars(es, q=secp256k1.q):
+    if isinstance(es, PackedScalars) and q == secp256k1.q:
+        return es.packed
     return b"".join((int(e % q)).to_bytes(32, "little") for e in es)
 
 

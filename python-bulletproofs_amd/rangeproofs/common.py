@@ -7,7 +7,7 @@ group operation goes to the engine, fused into as few MSMs as the algebra allows
 from hashlib import sha256
 
 from .. import engine as _engine
-from ..ec import PackedPoints, pack_points, unpack_points
+from ..ec import PackedPoints, PackedScalars, pack_points, secp256k1, unpack_points
 from ..innerproduct.inner_product_prover import NIProver
 from ..pippenger import PipSECP256k1
 from ..utils.transcript import Transcript
@@ -60,14 +60,26 @@ def _powers(y, count, q):
 
 
 def _mod_hash_ints(lo, hi, digest, q):
-    """[mod_hash(str(i) + digest, q).x for i in range(lo, hi)] without a ModP object and two calls per element: the first
-    candidate (counter 1) is taken inline, anything else goes through mod_hash itself."""
+    """[mod_hash(str(i) + digest, q).x for i in range(lo, hi)] as a PackedScalars: for the curve's order the hashes run in
+    native code (bpmi_mod_hash_range) and arrive as the bytes the MSM wants; any other modulus takes the Python loop."""
+    if q == secp256k1.q and hi > lo:
+        import ctypes
+        import os
+        from .. import _native
+        out = ctypes.create_string_buffer(32 * (hi - lo))
+        threads = max(1, min(8, len(os.sched_getaffinity(0)), (hi - lo) // 1024))
+        if _native.load().bpmi_mod_hash_range(digest, len(digest), lo, hi, threads, out) != 0:
+            raise RuntimeError("bpmi_mod_hash_range failed")
+        return PackedScalars.from_bytes(out.raw)
     mask = (1 << q.bit_length()) - 1
     out = []
     for i in range(lo, hi):
         c = int.from_bytes(sha256(b"1%d" % i + digest).digest(), "big") & mask
         out.append(c if 0 < c < q else mod_hash(b"%d" % i + digest, q).x)
     return out
+
+
+_BIT_LE = ((0).to_bytes(32, "little"), (1).to_bytes(32, "little"))
 
 
 def prove(vs, n, g, h, gs, hs, gammas, u, group, seed, aggregated):
@@ -84,6 +96,10 @@ def prove(vs, n, g, h, gs, hs, gammas, u, group, seed, aggregated):
     for v in vs:
         aL += list(map(int, reversed(bin(v.x)[2:].zfill(n))))[:n]
     aR = [(bit - 1) % q for bit in aL]
+    if q == secp256k1.q:                                              # bits and bits - 1: two constant encodings each
+        minus1 = (q - 1).to_bytes(32, "little")
+        aL = PackedScalars(aL, b"".join([_BIT_LE[bit] for bit in aL]))
+        aR = PackedScalars(aR, b"".join([minus1 if not bit else _BIT_LE[0] for bit in aL]))
     alpha = mod_hash(b"alpha" + tr.digest, q).x
     sL = _mod_hash_ints(0, nm, tr.digest, q)
     sR = _mod_hash_ints(nm, 2 * nm, tr.digest, q)
@@ -92,7 +108,7 @@ def prove(vs, n, g, h, gs, hs, gammas, u, group, seed, aggregated):
     # points, independent of each other, overlapped on the engine's two lanes
     gs, hs = PackedPoints(gs), PackedPoints(hs)                      # packed once for the four MSMs and the argument below
     base = PackedPoints.join(gs, hs, [h])
-    A, S = PipSECP256k1.multiexp2(base, aL + aR + [alpha], base, sL + sR + [rho])
+    A, S = PipSECP256k1.multiexp2(base, PackedScalars.join(aL, aR, [alpha]), base, PackedScalars.join(sL, sR, [rho]))
     tr.add_list_points([A, S])
     yM = tr.get_modp(q)
     tr.add_number(yM)
