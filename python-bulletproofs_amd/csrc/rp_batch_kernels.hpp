@@ -128,36 +128,46 @@ __device__ __forceinline__ u64 ld8(const BPtr p) {                       // the 
   return (a >> s) | ((b << (63 - s)) << 1);
 }
 __device__ __forceinline__ u64 ld8_raw(const uint8_t *p) { u64 w; __builtin_memcpy(&w, p, 8); return w; }      // plain memory (the weights)
-__device__ __forceinline__ void sha_word_inl(Sha &s, u32 w) {            // four bytes at a word boundary of the message
+// Feeding WITHOUT compressing: the lanes of a wave hash prefixes of slightly different lengths, so their 64-byte blocks fill
+// at different steps; a compression call at every feeding step would run once per distinct phase in the wave.  sha_update
+// and sha_final_number therefore fill a lane's block completely (however many words that takes for the lane) and compress
+// at ONE point per block, where every lane of the wave that has a full block takes part (measured before: the hash-chain
+// role issued about twice the instructions one lane needs).
+__device__ __forceinline__ void sha_push_byte(Sha &s, u32 b) {           // the caller guarantees fill < 64
+  s.cur = (s.cur << 8) | b;
+  s.fill++;
+  s.len++;
+  if ((s.fill & 3u) == 0) {
+#pragma unroll
+    for (int i = 0; i < 15; i++) s.w[i] = s.w[i + 1];
+    s.w[15] = s.cur;
+  }
+}
+__device__ __forceinline__ void sha_push_word(Sha &s, u32 w) {           // fill is a multiple of 4 and < 64
 #pragma unroll
   for (int i = 0; i < 15; i++) s.w[i] = s.w[i + 1];
   s.w[15] = w;
   s.fill += 4;
   s.len += 4;
-  if (s.fill == 64u) { sha_compress(s); s.fill = 0; }
 }
 __device__ __noinline__ void sha_update(Sha &s, const BPtr p, u32 n) {
   Sha t = s;
   u32 i = 0;
-  while (i < n && (t.fill & 3u)) sha_byte_inl(t, p[i++]);                // up to the next word boundary of the message
-  for (; i + 64 <= n; i += 64) {                                         // eight loads in flight per wait (a lone wave per SIMD has
-    u64 x[8];                                                            // nothing else to overlap a memory round trip with)
+  while (i < n) {
+    while (i < n && (t.fill & 3u)) sha_push_byte(t, p[i++]);              // up to the next word boundary of the message (<= 3 bytes)
+    if ((t.fill & 3u) == 0 && t.fill < 64u) {
+      const u32 nw = min((64u - t.fill) >> 2, (n - i) >> 2);             // words that fit this block and exist
+      u64 x[8];                                                          // loads in flight together (a lone wave per SIMD has nothing
+#pragma unroll                                                           // else to overlap a memory round trip with)
+      for (int j = 0; j < 8; j++) x[j] = ld8(p + i + 8 * j);
 #pragma unroll
-    for (int j = 0; j < 8; j++) x[j] = ld8(p + i + 8 * j);
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-      sha_word_inl(t, __builtin_bswap32((u32)x[j]));
-      sha_word_inl(t, __builtin_bswap32((u32)(x[j] >> 32)));
+      for (int j = 0; j < 16; j++)
+        if ((u32)j < nw) sha_push_word(t, __builtin_bswap32((u32)(x[j >> 1] >> (32 * (j & 1)))));
+      i += 4 * nw;
+      if (t.fill < 64u && n - i < 4u)                                    // the input ends inside this block: its last (< 4) bytes
+        while (i < n) sha_push_byte(t, p[i++]);
     }
-  }
-  for (; i + 8 <= n; i += 8) {
-    const u64 x = ld8(p + i);
-    sha_word_inl(t, __builtin_bswap32((u32)x));
-    sha_word_inl(t, __builtin_bswap32((u32)(x >> 32)));
-  }
-  if (i < n) {
-    const u64 x = ld8(p + i);
-    for (u32 j = 0; i < n; i++, j++) sha_byte_inl(t, (u32)(x >> (8 * j)) & 0xFFu);
+    if (t.fill == 64u) { sha_compress(t); t.fill = 0; }
   }
   s = t;
 }
@@ -166,13 +176,17 @@ __device__ __noinline__ void sha_update(Sha &s, const BPtr p, u32 n) {
 __device__ __noinline__ void sha_final_number(const Sha &s0, sc &r, bool &lt_q) {
   Sha s = s0;
   const u32 bits_hi = s.len >> 29, bits_lo = s.len << 3;
-  // padding: 0x80, zeros up to 56 mod 64, the bit length as 8 big-endian bytes -- one feeding site
-  u32 tail = 0;                                     // 0: before the length field; 1..8: length bytes emitted
-  for (u32 i = 0; tail < 8; i++) {
-    u32 b;
-    if (tail == 0 && (i == 0 || s.fill != 56u)) b = i == 0 ? 0x80u : 0u;
-    else { b = tail < 4 ? (bits_hi >> (8 * (3 - tail))) & 0xFFu : (bits_lo >> (8 * (7 - tail))) & 0xFFu; tail++; }
-    sha_byte_inl(s, b);
+  // padding: 0x80, zeros up to 56 mod 64, the bit length as 8 big-endian bytes; one or two blocks, compressed at one point
+  u32 emitted = 0;                                  // 0: nothing yet; 1: the 0x80 is out; 2..9: length bytes out (9 = done)
+  for (int blk = 0; blk < 2; blk++) {
+    while (emitted < 9u && s.fill < 64u) {
+      u32 b;
+      if (emitted == 0) { b = 0x80u; emitted = 1; }
+      else if (emitted == 1 && s.fill != 56u) b = 0u;
+      else { const u32 k = emitted - 1; b = k < 4 ? (bits_hi >> (8 * (3 - k))) & 0xFFu : (bits_lo >> (8 * (7 - k))) & 0xFFu; emitted++; }
+      sha_push_byte(s, b);
+    }
+    if (s.fill == 64u) { sha_compress(s); s.fill = 0; }
   }
 #pragma unroll
   for (int i = 0; i < 8; i++) r.v[i] = s.h[7 - i];
