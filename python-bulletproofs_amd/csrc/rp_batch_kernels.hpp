@@ -585,6 +585,7 @@ __device__ __noinline__ bool weighted_scalars(const Params &q, u32 g, const Pars
   }
   sq w[4];
   for (u32 t = 0; t < 4; t++) {
+    if (side == 1 && !(t & 1u)) { w[t] = bpmi::sq_small(0); continue; }       // the hs side uses w2 and w4 only
     sc ws;
     if (q.weights) {
       const uint8_t *src = q.weights + ((size_t)(q.first + g) * 4 + t) * 32;

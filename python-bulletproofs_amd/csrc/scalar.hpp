@@ -145,6 +145,32 @@ BPMI_HD void sc_half(sc &x) {
 // not branches: the lanes of a wave disagree on every condition.  Not constant time: the inputs are public proof data.
 #define BPMI_SC_NQINV 0x5588B13Fu          // -q^-1 mod 2^32
 BPMI_HD u32 sc_funnel_r(u32 lo, u32 hi, u32 s) { return (u32)((((u64)hi << 32) | lo) >> s); }      // s in [0, 31]
+// word-wise add / subtract with carry: on the device the clang builtins become one v_addc / v_subb each (the 64-bit
+// formulation below costs ~5 instructions per word there)
+BPMI_HD u32 sc_adc(u32 a, u32 b, u32 &c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  u32 co;
+  const u32 r = __builtin_addc(a, b, c, &co);
+  c = co;
+  return r;
+#else
+  const u64 t = (u64)a + b + c;
+  c = (u32)(t >> 32);
+  return (u32)t;
+#endif
+}
+BPMI_HD u32 sc_sbb(u32 a, u32 b, u32 &br) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  u32 bo;
+  const u32 r = __builtin_subc(a, b, br, &bo);
+  br = bo;
+  return r;
+#else
+  const u64 t = (u64)a - b - br;
+  br = (u32)(t >> 32) & 1u;
+  return (u32)t;
+#endif
+}
 BPMI_HD void sc_inv(sc &r, const sc &a) {
   const u32 q[8] = BPMI_SC_Q;
   u32 u[8], v[8], x1[8], x2[8];
@@ -161,28 +187,25 @@ BPMI_HD void sc_inv(sc &r, const sc &a) {
 #endif
     const u32 oddm = 0u - (u[0] & 1u);                               // all ones when u is odd
     // u < v ?  (borrow of u - v)
-    u64 br = 0;
+    u32 br = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) { const u64 t = (u64)u[i] - v[i] - br; br = (t >> 32) & 1; }
-    const u32 swm = oddm & (0u - (u32)br);                           // exchange the pairs: u odd and u < v
+    for (int i = 0; i < 8; i++) (void)sc_sbb(u[i], v[i], br);
+    const u32 swm = oddm & (0u - br);                                // exchange the pairs: u odd and u < v
 #pragma unroll
     for (int i = 0; i < 8; i++) {
       const u32 du = (u[i] ^ v[i]) & swm, dx = (x1[i] ^ x2[i]) & swm;
       u[i] ^= du; v[i] ^= du; x1[i] ^= dx; x2[i] ^= dx;
     }
     // u -= v and x1 = x1 - x2 mod q when u is odd
-    u64 bu = 0, bx = 0;
+    u32 bu = 0, bx = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-      const u64 t = (u64)u[i] - (v[i] & oddm) - bu;
-      u[i] = (u32)t; bu = (t >> 32) & 1;
-      const u64 w = (u64)x1[i] - (x2[i] & oddm) - bx;
-      x1[i] = (u32)w; bx = (w >> 32) & 1;
-    }
-    const u32 addm = 0u - (u32)bx;                                   // went below zero: add q back
-    u64 c = 0;
+    for (int i = 0; i < 8; i++) u[i] = sc_sbb(u[i], v[i] & oddm, bu);
 #pragma unroll
-    for (int i = 0; i < 8; i++) { c += (u64)x1[i] + (q[i] & addm); x1[i] = (u32)c; c >>= 32; }
+    for (int i = 0; i < 8; i++) x1[i] = sc_sbb(x1[i], x2[i] & oddm, bx);
+    const u32 addm = 0u - bx;                                        // went below zero: add q back
+    u32 c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) x1[i] = sc_adc(x1[i], q[i] & addm, c);
     nz = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) nz |= u[i];
@@ -191,19 +214,18 @@ BPMI_HD void sc_inv(sc &r, const sc &a) {
     tz = nz ? tz : 0u;
     const u32 m = (x1[0] * BPMI_SC_NQINV) & ((1u << tz) - 1u);      // x1 + m q has tz trailing zero bits
     u32 t9[9];
-    c = 0;
+    u64 cc = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) { c += (u64)m * q[i] + x1[i]; t9[i] = (u32)c; c >>= 32; }
-    t9[8] = (u32)c;
+    for (int i = 0; i < 8; i++) { cc += (u64)m * q[i] + x1[i]; t9[i] = (u32)cc; cc >>= 32; }
+    t9[8] = (u32)cc;
     u32 y[9];
 #pragma unroll
     for (int i = 0; i < 8; i++) { y[i] = sc_funnel_r(t9[i], t9[i + 1], tz); u[i] = sc_funnel_r(u[i], i < 7 ? u[i + 1] : 0u, tz); }
     y[8] = t9[8] >> tz;                                               // (x1 + m q) >> tz < 2 q
     // y -= q when y >= q
-    u32 sq_[8];
-    u64 bq = 0;
+    u32 sq_[8], bq = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) { const u64 w = (u64)y[i] - q[i] - bq; sq_[i] = (u32)w; bq = (w >> 32) & 1; }
+    for (int i = 0; i < 8; i++) sq_[i] = sc_sbb(y[i], q[i], bq);
     const u32 gem = 0u - (u32)((y[8] != 0) | (bq == 0));
 #pragma unroll
     for (int i = 0; i < 8; i++) x1[i] = (sq_[i] & gem) | (y[i] & ~gem);
