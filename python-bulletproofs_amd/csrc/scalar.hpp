@@ -17,6 +17,32 @@ struct sc { u32 v[8]; };
 // (q - 1) / 2
 #define BPMI_SC_HALF {0x681B20A0u, 0xDFE92F46u, 0x57A4501Du, 0x5D576E73u, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0x7FFFFFFFu}
 
+// word-wise add / subtract with carry: on the device the clang builtins become one v_addc / v_subb each (the 64-bit
+// formulation below costs ~5 instructions per word there)
+BPMI_HD u32 sc_adc(u32 a, u32 b, u32 &c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  u32 co;
+  const u32 r = __builtin_addc(a, b, c, &co);
+  c = co;
+  return r;
+#else
+  const u64 t = (u64)a + b + c;
+  c = (u32)(t >> 32);
+  return (u32)t;
+#endif
+}
+BPMI_HD u32 sc_sbb(u32 a, u32 b, u32 &br) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  u32 bo;
+  const u32 r = __builtin_subc(a, b, br, &bo);
+  br = bo;
+  return r;
+#else
+  const u64 t = (u64)a - b - br;
+  br = (u32)(t >> 32) & 1u;
+  return (u32)t;
+#endif
+}
 BPMI_HD bool sc_is_zero(const sc &a) {
   u32 z = 0;
 #pragma unroll
@@ -38,14 +64,10 @@ BPMI_HD bool sc_is_high(const sc &a) {   // a > (q-1)/2
 }
 // r = a - b over 2^256, returns borrow
 BPMI_HD u32 words_sub(u32 r[8], const u32 a[8], const u32 b[8]) {
-  u64 br = 0;
+  u32 br = 0;
 #pragma unroll
-  for (int i = 0; i < 8; i++) {
-    u64 t = (u64)a[i] - b[i] - br;
-    r[i] = (u32)t;
-    br = (t >> 32) & 1;
-  }
-  return (u32)br;
+  for (int i = 0; i < 8; i++) r[i] = sc_sbb(a[i], b[i], br);
+  return br;
 }
 // s in [0, 2^256) -> s mod q (one conditional subtraction: 2^256 < 2q).  The MSM / ladder kernels apply it
 // to every scalar they load, so a C caller that hands in an unreduced scalar gets the reference's
@@ -75,11 +97,10 @@ BPMI_HD void sc_cond_sub_q(u32 t[9]) {
   }
 }
 BPMI_HD void sc_add(sc &r, const sc &a, const sc &b) {
-  u32 t[9];
-  u64 c = 0;
+  u32 t[9], c = 0;
 #pragma unroll
-  for (int i = 0; i < 8; i++) { c += (u64)a.v[i] + b.v[i]; t[i] = (u32)c; c >>= 32; }
-  t[8] = (u32)c;
+  for (int i = 0; i < 8; i++) t[i] = sc_adc(a.v[i], b.v[i], c);
+  t[8] = c;
   sc_cond_sub_q(t);
 #pragma unroll
   for (int i = 0; i < 8; i++) r.v[i] = t[i];
@@ -145,32 +166,6 @@ BPMI_HD void sc_half(sc &x) {
 // not branches: the lanes of a wave disagree on every condition.  Not constant time: the inputs are public proof data.
 #define BPMI_SC_NQINV 0x5588B13Fu          // -q^-1 mod 2^32
 BPMI_HD u32 sc_funnel_r(u32 lo, u32 hi, u32 s) { return (u32)((((u64)hi << 32) | lo) >> s); }      // s in [0, 31]
-// word-wise add / subtract with carry: on the device the clang builtins become one v_addc / v_subb each (the 64-bit
-// formulation below costs ~5 instructions per word there)
-BPMI_HD u32 sc_adc(u32 a, u32 b, u32 &c) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  u32 co;
-  const u32 r = __builtin_addc(a, b, c, &co);
-  c = co;
-  return r;
-#else
-  const u64 t = (u64)a + b + c;
-  c = (u32)(t >> 32);
-  return (u32)t;
-#endif
-}
-BPMI_HD u32 sc_sbb(u32 a, u32 b, u32 &br) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  u32 bo;
-  const u32 r = __builtin_subc(a, b, br, &bo);
-  br = bo;
-  return r;
-#else
-  const u64 t = (u64)a - b - br;
-  br = (u32)(t >> 32) & 1u;
-  return (u32)t;
-#endif
-}
 BPMI_HD void sc_inv(sc &r, const sc &a) {
   const u32 q[8] = BPMI_SC_Q;
   u32 u[8], v[8], x1[8], x2[8];
