@@ -316,6 +316,8 @@ __device__ __noinline__ sq mq_v(const sq a, u32 b0, u32 b1, u32 b2, u32 b3, u32 
   bpmi::sq_mul(r, a, b);
   return r;
 }
+// inlined: for the per-element loops, whose cell stores would otherwise be waited for at every call boundary
+__device__ __forceinline__ void mq_inl(sq &r, const sq &a, const sq &b) { sq t; bpmi::sq_mul(t, a, b); r = t; }
 __device__ __forceinline__ void mq(sq &r, const sq &a, const sq &b) { r = mq_v(a, b.v[0], b.v[1], b.v[2], b.v[3], b.v[4], b.v[5], b.v[6], b.v[7], b.v[8]); }
 __device__ __forceinline__ sq to_sq(const sc &a) { sq r; bpmi::sq_from_sc(r, a); return r; }
 __device__ __noinline__ sc to_sc(const sq a) { sc r; bpmi::sq_to_sc(r, a); return r; }
@@ -655,12 +657,12 @@ __device__ __noinline__ bool weighted_scalars(const Params &q, u32 g, const Pars
         sq f;
         slot_load(cur, d0);
         slot_load(f, k + d0);
-        mq(cur, cur, f);
+        mq_inl(cur, cur, f);
         for (u32 d = d0 + 1; d < k; d++) slot_store(d, cur);
       }
       bpmi::sq_sub(t, cur, geo);
       cell_store(C, SH + i, t);
-      mq(geo, geo, r2);
+      mq_inl(geo, geo, r2);
       if (++e == bits) e = 0;
     }
     return true;
@@ -682,7 +684,7 @@ __device__ __noinline__ bool weighted_scalars(const Params &q, u32 g, const Pars
         sq f;
         slot_load(cur, d0);
         slot_load(f, k + d0);
-        mq(cur, cur, f);
+        mq_inl(cur, cur, f);
         for (u32 d = d0 + 1; d < k; d++) slot_store(d, cur);
       }
       cell_store(C, SG + i, cur);
