@@ -260,9 +260,13 @@ def main():
     eng.profile(False)
 
     n_ranks_seen = 1
+    ms_by_rank = [elapsed / args.steps * 1e3]
     if use_dist:
         cpu_side = dist.get_backend() != "nccl"
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if cpu_side else dev)
+        every = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(every, tt)
+        ms_by_rank = [float(t.item()) / args.steps * 1e3 for t in every]
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
         ones = torch.ones(1, dtype=torch.int64, device="cpu" if cpu_side else dev)
@@ -294,6 +298,7 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
+        "ms_per_step_by_rank": [round(v, 4) for v in ms_by_rank],
         "higher_is_better": True,
         "scaling": args.scaling,
         "vs_baseline": None,

@@ -59,6 +59,7 @@ class ShardedMSM:
         self.device_fold = fold is None and hasattr(engine, "ec_sum_dev")
         self.group = group
         self._comm = None
+        self._inflight = False      # the RCCL exchange uses ONE set of staging buffers: one combine_begin at a time
 
     def _comm_setup(self, world):
         """(stream, engine on that stream, pinned 64-byte staging, device send buffer, device receive buffer)"""
@@ -91,8 +92,12 @@ class ShardedMSM:
         if not dist.is_initialized():
             return ("done", partial)
         if self.device_fold and dist.get_backend(self.group) == "nccl":
+            if self._inflight:
+                raise RuntimeError("ShardedMSM.combine_begin: the previous exchange has not been collected (combine_wait) -- "
+                                   "its staging buffers are still in use")
             world = dist.get_world_size(self.group)
             stream, eng2, pin, mine, flat, d_out, pin_out = self._comm_setup(world)
+            self._inflight = True
             pin.copy_(torch.frombuffer(bytearray(partial), dtype=torch.uint8))
             with torch.cuda.stream(stream):
                 mine.copy_(pin, non_blocking=True)
@@ -109,6 +114,7 @@ class ShardedMSM:
             return value
         stream, pin_out = self._comm[0], self._comm[6]
         stream.synchronize()
+        self._inflight = False
         return bytes(pin_out.numpy().tobytes())
 
     def multiexp_replicated(self, pts: bytes, scalars: bytes, n: int) -> bytes:
@@ -166,7 +172,7 @@ class ShardedFastNIProver2:
         from .utils.transcript import Transcript
         if state is None:
             assert len(g) == len(h) == len(a) == len(b)
-            assert len(a) & (len(a) - 1) == 0
+            assert len(a) & (len(a) - 1) == 0          # 0 is allowed: a global vector shorter than the number of ranks (prove())
         self.state = state
         self.g, self.h, self.u, self.P, self.a, self.b, self.group = g, h, u, P, a, b, group
         self.h_scale = h_scale
@@ -191,6 +197,40 @@ class ShardedFastNIProver2:
         return (self.engine.ec_sum_bytes(b"".join(p[:64] for p in parts), k),
                 self.engine.ec_sum_bytes(b"".join(p[64:] for p in parts), k))
 
+    def _layout(self, n_local):
+        """Local lengths of all ranks (one 8-byte all_gather).  The cyclic layout needs the same power-of-two length
+        >= 1 on every rank; a global vector SHORTER than the number of ranks (some shards empty, the others one element)
+        is legal input -- the argument is then tiny and every rank runs all of it (see _prove_replicated)."""
+        lens = [int.from_bytes(p, "little") for p in all_gather_bytes(int(n_local).to_bytes(8, "little"), self.pg)]
+        if min(lens) == 0:
+            if max(lens) > 1 or self.state is not None:
+                raise ValueError("ShardedFastNIProver2: rank shards of lengths %r are not a cyclic layout "
+                                 "(a vector shorter than the %d ranks must be given as host lists, one element or none per rank)" % (lens, self.world))
+            return lens, True
+        if len(set(lens)) != 1:
+            raise ValueError("ShardedFastNIProver2: the cyclic layout needs equal shard lengths on all ranks, got %r" % (lens,))
+        return lens, False
+
+    def _prove_replicated(self, lens):
+        """Global length < number of ranks: the ranks that hold an element publish it (192 or 224 bytes), every rank
+        rebuilds the global vectors and runs the whole (at most log2(world) - 1 rounds) argument itself."""
+        from .ec import pack_points, pack_scalars
+        q = self.group.q
+        have = len(self.a) == 1
+        rec = bytes(224)
+        if have:
+            hs = 1 if self.h_scale is None else int(self.h_scale[0]) % q
+            rec = pack_points(self.g) + pack_points(self.h) + pack_scalars(self.a, q) + pack_scalars(self.b, q) + hs.to_bytes(32, "little")
+        parts = [p for p, ln in zip(all_gather_bytes(rec, self.pg), lens) if ln]
+        n = len(parts)
+        if n & (n - 1) or any(lens[i] == 0 for i in range(n)):
+            raise ValueError("ShardedFastNIProver2: %d elements on ranks %r are not a cyclic layout of a power-of-two vector"
+                             % (n, [i for i, ln in enumerate(lens) if ln]))
+        scaled = any(p[192:224] != (1).to_bytes(32, "little") for p in parts)
+        return self.engine.ipa_create(b"".join(p[:64] for p in parts), b"".join(p[64:128] for p in parts),
+                                      b"".join(p[128:160] for p in parts), b"".join(p[160:192] for p in parts), n, self.u.to_le64(),
+                                      b"".join(p[192:224] for p in parts) if scaled else None)
+
     def prove(self):
         from .ec import pack_points, pack_scalars
         from .innerproduct._rounds import run_rounds
@@ -200,14 +240,19 @@ class ShardedFastNIProver2:
         eng = self.engine
         ub = self.u.to_le64()
         state = self.state
-        if state is None:
+        replicated = False
+        if self.world > 1:
+            lens, replicated = self._layout(len(state) if state is not None else len(self.a))
+        if replicated:
+            state = self._prove_replicated(lens)
+        elif state is None:
             state = eng.ipa_create(pack_points(self.g), pack_points(self.h), pack_scalars(self.a, q),
                                    pack_scalars(self.b, q), len(self.a), ub,
                                    None if self.h_scale is None else pack_scalars(self.h_scale, q))
         xs, Ls, Rs = [], [], []
         try:
-            run_rounds(state, self.transcript, q, xs, Ls, Rs, self._combine if self.world > 1 else None)
-            if self.world > 1:
+            run_rounds(state, self.transcript, q, xs, Ls, Rs, self._combine if (self.world > 1 and not replicated) else None)
+            if self.world > 1 and not replicated:
                 g1, h1, a1, b1 = state.export()           # this rank's last element = global index `rank`
                 state.close()
                 parts = all_gather_bytes(g1 + h1 + a1 + b1, self.pg)

@@ -69,7 +69,7 @@ def ipa_mode(use_gpu):
     else:
         from oracle_engine import OracleEngine
         eng = OracleEngine()
-        sizes = [(2, None), (4, 5), (32, None)]
+        sizes = [(1, None), (2, None), (4, 5), (8, None), (32, None)]      # incl. vectors shorter than 4 / 8 ranks and one element per rank
     rnd = random.Random(4242)
     for n, hs_seed in sizes:
         ks = [rnd.randrange(1, Q) for _ in range(2 * n + 1)]

@@ -66,3 +66,27 @@ def test_bench_collectives_on_rccl_with_one_rank():
     assert out["dist_backend"] == "nccl" and out["n_ranks_seen"] == 1 and out["result_ok"] is True
     assert out["extra"]["C5_batch_verify"].get("accepted") is True and out["extra"]["C5_batch_verify"]["corrupted_batch_rejected"] is True
     assert out["extra"]["C3_ipa_prover"].get("rounds") == 20
+
+
+def test_bench_two_gpus_on_rccl_when_the_box_has_them():
+    """On a box with >= 2 GPUs (the driver's scaling node; the builder's boxes have one): `python bench.py --gpus 2` on the
+    real RCCL backend, weak and strong, with the extras -- the same command line SCALE_rNN.json is produced by, so a defect of the
+    N > 1 path shows up here first.  torch.cuda.device_count() does not initialise the GPU in this process."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    env.pop("BENCH_DIST_BACKEND", None)
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--soak-seconds", "0", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=1800)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["dist_backend"] == "nccl" and out["n_gpus"] == 2 and out["n_ranks_seen"] == 2 and out["result_ok"] is True
+    assert len(out["ms_per_step_by_rank"]) == 2
+    assert out["extra"]["C5_batch_verify"].get("accepted") is True and out["extra"]["C5_batch_verify"]["corrupted_batch_rejected"] is True
+    assert out["extra"]["C3_ipa_prover"].get("rounds") == 20
+    r = subprocess.run(cmd + ["--no-extra", "--scaling", "strong"], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["scaling"] == "strong" and out["result_ok"] is True
