@@ -114,7 +114,7 @@ def main():
     ap.add_argument("--async-lanes", type=int, default=1, help="1: the two in-flight MSMs run on the engine's two lanes (streams)")
     ap.add_argument("--soak-seconds", type=float, default=6.0,
                     help="untimed MSMs after the timed region, so that an external sampler (rocm-smi every few seconds) sees the GPU busy")
-    ap.add_argument("--cpu-logn", type=int, default=16)
+    ap.add_argument("--cpu-logn", type=int, default=0, help="CPU baseline on the first 2^k pairs; 0 = the bench size itself (--logn)")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="bpmi_set_option passthrough (tuning experiments)")
     args = ap.parse_args()
 
@@ -191,6 +191,8 @@ def main():
     # known answer of this rank's shard: sum e_i * P_i = (sum e_i k_i mod q) * G, one scalar multiplication
     # by a different kernel (k_ec_mul_batch: a double-and-add ladder, no buckets)
     local_dlog = sum(e * k for e, k in zip(ev, kv)) % Q
+    c2_n = min(n, 1 << 16)
+    c2_dlog = sum(e * k for e, k in zip(ev[:c2_n], kv[:c2_n])) % Q
     del kb, kv, eb, ev
     t_in = time.time() - t_in
 
@@ -341,7 +343,8 @@ def main():
 
     if not args.no_extra:
         out["extra"] = {}
-        extras = [("C5_batch_verify", extra_c5), ("C3_ipa_prover", extra_c3), ("C4_aggregated_range_proof", extra_c4)]
+        extras = [("C2_msm_2e16", lambda e_, w_, r_, d_: extra_c2(e_, w_, r_, d_, d_pts, d_sc, c2_n, c2_dlog, G64)),
+                  ("C5_batch_verify", extra_c5), ("C3_ipa_prover", extra_c3), ("C4_aggregated_range_proof", extra_c4)]
         if world > 1:         # the same verifier with 2^14 proofs per GPU: a rank's 2048-proof share of the fixed batch is mostly fixed latencies
             extras.insert(1, ("C5_batch_verify_per_gpu_batches", lambda *a: extra_c5(*a, per_gpu=True)))
         for name, fn in extras:
@@ -352,7 +355,7 @@ def main():
             barrier()
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args.cpu_logn, d_pts, d_sc, eng)
+        out["cpu_baseline"] = cpu_baseline(min(args.cpu_logn or args.logn, args.logn), d_pts, d_sc, eng)
 
     # soak: keep the GPU visibly busy for an external sampler; not part of any reported number
     t_s = time.perf_counter()
@@ -387,7 +390,7 @@ def committed_traffic(logn):
 
 
 # ---- extra: config C5, batch verification of 2^14 64-bit range proofs -----------------------------
-def extra_c5(eng, world, rank, dev, log_batch=14, distinct=64, per_gpu=False):
+def extra_c5(eng, world, rank, dev, log_batch=14, distinct=1024, per_gpu=False):
     """verifies/s of the random-linear-combination batch verifier on wire-format proofs: bytes in a page-locked receive
     buffer -> one upload -> GPU preparation (parse, SHA-256 transcript re-hashes, weighted scalars; one lane per proof) ->
     GPU decoding of 19 points per proof -> ONE MSM over 3 + 2*64 + 19*batch points; sharded by proof over the ranks.
@@ -436,6 +439,8 @@ def extra_c5(eng, world, rank, dev, log_batch=14, distinct=64, per_gpu=False):
 
     bv = BatchRangeVerifier(g, h, gs, hs, u, engine=eng)
 
+    errors = []
+
     def finish(part):
         failed = part is None
         if dist.is_initialized():        # a rank whose batch failed still takes part in the exchange (with a point that cannot sum to the identity by accident): no rank is left waiting
@@ -452,7 +457,10 @@ def extra_c5(eng, world, rank, dev, log_batch=14, distinct=64, per_gpu=False):
         try:
             bv.add_wire_native(v_packed, buf, threads=threads, offsets=wire_off_c)
             part = bv.partial()
-        except Exception:
+        except Exception as e:
+            # "Proof invalid" is a verdict (the batch holds a bad proof); anything else is a defect and is reported as such
+            if str(e) != "Proof invalid":
+                errors.append("%s: %s" % (type(e).__name__, e))
             part = None
         if corrupt:           # verified locally: the verdict on this rank's own shard is what is being checked
             return part == bytes(64)
@@ -495,7 +503,9 @@ def extra_c5(eng, world, rank, dev, log_batch=14, distinct=64, per_gpu=False):
         try:
             bv.add_wire_native(v_packed, buf, threads=threads, offsets=wire_off_c)
             return bv.partial()
-        except Exception:
+        except Exception as e:
+            if str(e) != "Proof invalid":
+                errors.append("%s: %s" % (type(e).__name__, e))
             return None
 
     pipe_batches = 16 * inflight
@@ -529,23 +539,119 @@ def extra_c5(eng, world, rank, dev, log_batch=14, distinct=64, per_gpu=False):
     msm_pairs = 3 + 2 * nbits + 19 * (hi - lo)
     stage_ms = {k: v[0] / reps for k, v in prof.items() if v[1]}
     dom = max(stage_ms, key=stage_ms.get) if stage_ms else None
-    acc_s = stage_ms.get("msm_accumulate", 0.0) / 1e3
-    wire_bytes = len(wire_buf)
+    dom_s = stage_ms.get(dom, 0.0) / 1e3 if dom else 0.0
+    wire_bytes = len(wire_joined)
     gpu_ms = sum(stage_ms.values())
-    return {"metric": "range-proof verifies/sec (batched, 64-bit proofs, wire bytes in)", "value": total / elapsed_pipe, "unit": "verifies/s",
+    # algorithmic bytes of the dominant stage per batch: the preparation and the point decoding read the wire bytes once
+    # (and write 32 B per scalar / 64 B per point); the MSM stages read 96 B per pair
+    stage_bytes = {"rp_prepare": wire_bytes + 32 * msm_pairs, "ec_decompress": 33 * 19 * (hi - lo) + 64 * 19 * (hi - lo)}
+    dom_bytes = stage_bytes.get(dom, ALGO_BYTES_PER_PAIR * msm_pairs)
+    cpu = None
+    if rank == 0 and world == 1 and not per_gpu and os.environ.get("BENCH_NO_CPU_BASELINE") != "1":
+        try:
+            cpu = c5_cpu_baseline(g, h, gs, hs, u, v_packed, wire_joined, wire_off_c, total, usable)
+        except Exception as e:
+            cpu = {"error": "%s: %s" % (type(e).__name__, e)}
+    out_extra = {"cpu_baseline": cpu} if cpu is not None else {}
+    if errors:
+        out_extra["errors"] = sorted(set(errors))[:4]
+    return {**out_extra, **{"metric": "range-proof verifies/sec (batched, 64-bit proofs, wire bytes in)", "value": total / elapsed_pipe, "unit": "verifies/s",
             "batch": total, "scaling": "weak (2^%d proofs per GPU)" % log_batch if per_gpu else "strong (one batch of 2^%d split over the ranks)" % log_batch, "seconds_per_batch": elapsed_pipe, "batches_in_flight": inflight, "batch_latency_s": elapsed,
             "verifies_per_s_one_batch_at_a_time": total / elapsed, "preparation": "device (bpmi_rp_batch_prepare_dev)",
             "accepted": all(oks), "corrupted_batch_rejected": rejected,
             "host_threads_per_rank": threads, "host_cores_usable": usable, "msm_pairs_per_rank": msm_pairs,
             "proves_per_s_one_gpu": distinct / t_prove,
             "gpu_stage_ms_per_batch": {k: round(v, 4) for k, v in stage_ms.items()},
-            "roofline": {"bound": "hbm", "kernel": "k_accum_l0 (msm_accumulate) of the one batch MSM", "kernel_ms": acc_s * 1e3,
-                         "achieved": (ALGO_BYTES_PER_PAIR * msm_pairs / acc_s / 1e9) if acc_s > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (ALGO_BYTES_PER_PAIR * msm_pairs / acc_s / 1e9 / HBM_PEAK_GBS) if acc_s > 0 else None,
-                         "dominant_gpu_stage": dom, "traffic": None,
-                         "note": "GPU stages %.2f ms per batch (preparation kernel, point decoding, one MSM); one batch at a time takes %.2f ms "
-                                 "(+ the %.1f MB upload from the page-locked receive buffer and the syncs), %d in flight %.2f ms per batch"
-                                 % (gpu_ms, elapsed * 1e3, wire_bytes / 1e6, inflight, elapsed_pipe * 1e3)}}
+            "roofline": {"bound": "hbm", "kernel": "stage %s (the dominant GPU stage of a batch)" % dom, "kernel_ms": dom_s * 1e3,
+                         "achieved": (dom_bytes / dom_s / 1e9) if dom_s > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": (dom_bytes / dom_s / 1e9 / HBM_PEAK_GBS) if dom_s > 0 else None,
+                         "algorithmic_bytes": dom_bytes, "dominant_gpu_stage": dom, "traffic": None,
+                         "note": "GPU stages %.2f ms per batch (preparation kernels, point decoding, one MSM); one batch at a time takes %.2f ms "
+                                 "(+ the %.1f MB upload from the page-locked receive buffer and the syncs), %d in flight %.2f ms per batch; integer-ALU bound like the MSM"
+                                 % (gpu_ms, elapsed * 1e3, wire_bytes / 1e6, inflight, elapsed_pipe * 1e3)}}}
+
+
+
+def c5_cpu_baseline(g, h, gs, hs, u, v_packed, wire_joined, wire_off_c, total, usable):
+    """verifies/s of the SAME batch verification with no GPU: libbpmi's host preparation (bpmi_rp_batch_prepare, the parity twin
+    of the device kernels; `usable` threads) + the C oracle's point decompression and bucket MSM on the same threads; and ONE
+    64-bit proof verified by the Python restatement of RangeVerifier.verify with the reference's own multiexp algorithm
+    (oracle.bp_ref, 1 core) -- what /root/reference/src/rangeproofs/rangeproof_verifier.py:55-99 costs per proof."""
+    from oracle import bp_ref as R, cbind
+    from oracle.ec import secp256k1 as osecp
+    from bulletproofs_amd.rangeproofs import BatchRangeVerifier
+    thr = max(1, usable)
+    bv = BatchRangeVerifier(g, h, gs, hs, u, msm=lambda p, s_, n_: cbind.msm_bytes(p, s_, n_, min(thr, 17)))
+    dec = lambda comp, n_: cbind.ec_decompress_batch_bytes(comp, n_, thr)
+    t0 = time.perf_counter()
+    reps = 0
+    ok = True
+    while True:
+        bv.reset()
+        bv.add_wire_native(v_packed, wire_joined, decompress=dec, threads=thr, offsets=wire_off_c, prepare="host")
+        ok = ok and bv.partial() == bytes(64)
+        reps += 1
+        if time.perf_counter() - t0 > 8.0:
+            break
+    dt = (time.perf_counter() - t0) / reps
+    # one proof, the reference's way
+    Qo = osecp.q
+    og = lambda P_: R.elliptic_hash(P_)
+    ogs = [R.elliptic_hash(str(i).encode() + b"gs") for i in range(64)]
+    ohs = [R.elliptic_hash(str(i).encode() + b"hs") for i in range(64)]
+    o_g, o_h, o_u = og(b"g"), og(b"h"), og(b"u")
+    v, gamma = R.Zq(0x1234567890ABCDEF, Qo), R.mod_hash(b"gamma0", Qo)
+    V = R.commitment(o_g, o_h, v, gamma)
+    proof = R.range_prove(v, 64, o_g, o_h, ogs, ohs, gamma, o_u, Qo, b"seed0", multiexp=cbind.msm)
+    t1 = time.perf_counter()
+    ok1 = bool(R.range_verify(V, o_g, o_h, ogs, ohs, o_u, proof))
+    dt1 = time.perf_counter() - t1
+    return {"value": total / dt, "unit": "verifies/s", "cores": thr, "kind": "port",
+            "sample": "the whole 2^14-proof batch, %d reps: bpmi_rp_batch_prepare (libbpmi's host preparation) + oracle/c decompression of %d points "
+                      "+ oracle/c bucket MSM, %d threads" % (reps, 19 * total, thr),
+            "seconds_per_batch": dt, "accepted": bool(ok),
+            "python_reference_verify": {"value": 1.0 / dt1, "unit": "verifies/s", "cores": 1, "seconds_per_verify": round(dt1, 4), "accepted": ok1,
+                                        "what": "oracle.bp_ref.range_verify: RangeVerifier.verify restated, the reference's subset-table multiexp, Python, one 64-bit proof"}}
+
+
+# ---- extra: config C2, Pippenger MSM n = 2^16 --------------------------------------------------------------
+def extra_c2(eng, world, rank, dev, d_pts, d_sc, n, dlog, G64):
+    """BASELINE config 2: one MSM of n = 2^16 pairs (the first 2^16 of the headline inputs), /root/reference/src/pippenger/
+    pippenger.py:22-61.  pairs/s one call at a time (a caller that needs the result before it goes on) and with two calls in
+    flight; per-stage times; the known-answer check."""
+    import torch
+    expect = eng.ec_mul_batch_bytes(G64, dlog.to_bytes(32, "little"), 1)
+    got = eng.msm_dev(d_pts, d_sc, n)
+    for _ in range(5):
+        eng.msm_dev(d_pts, d_sc, n)
+    torch.cuda.synchronize(dev)
+    reps = 200
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        eng.msm_dev(d_pts, d_sc, n)
+    sync_s = (time.perf_counter() - t0) / reps
+    eng.msm_dev_enqueue(0, d_pts, d_sc, n)
+    t0 = time.perf_counter()
+    for j in range(reps):
+        if j + 1 < reps:
+            eng.msm_dev_enqueue((j + 1) & 1, d_pts, d_sc, n)
+        eng.msm_finish(j & 1)
+    pipe_s = (time.perf_counter() - t0) / reps
+    eng.profile(1)
+    eng.profile_reset()
+    for _ in range(10):
+        eng.msm_dev(d_pts, d_sc, n)
+    prof = eng.profile_read()
+    eng.profile(False)
+    stage_ms = {k: round(v[0] / max(v[1], 1), 4) for k, v in prof.items() if v[1]}
+    acc_s = stage_ms.get("msm_accumulate", 0.0) / 1e3
+    return {"metric": "Pippenger MSM scalar-point pairs/sec at n=2^16 (config C2)", "value": n / pipe_s, "unit": "pairs/s", "n": n,
+            "ms_per_msm_two_in_flight": pipe_s * 1e3, "ms_per_msm_one_at_a_time": sync_s * 1e3, "pairs_per_s_one_at_a_time": n / sync_s,
+            "result_ok": bool(got == expect), "stage_ms_per_msm": stage_ms,
+            "roofline": {"bound": "hbm", "kernel": "k_accum_l0 (msm_accumulate)", "kernel_ms": acc_s * 1e3,
+                         "achieved": ALGO_BYTES_PER_PAIR * n / acc_s / 1e9 if acc_s > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ALGO_BYTES_PER_PAIR * n / acc_s / 1e9 / HBM_PEAK_GBS if acc_s > 0 else None, "traffic": None,
+                         "note": "at this size every stage is a short chain of dependent point additions: latency-bound, not throughput-bound"}}
 
 
 # ---- extra: config C3, inner-product-argument prover n = 2^20 ----------------------------------------
@@ -689,28 +795,69 @@ def cpu_quota():
 
 
 def cpu_baseline(logn, d_pts, d_sc, eng):
-    """The plain-C oracle MSM (bucket method, pthreads) on this host's cores over the
-    first 2^logn pairs of the same synthetic workload; its result is also compared with the GPU's."""
+    """The plain-C oracle MSM (bucket method, pthreads; "port") on this host's cores over the first 2^logn pairs of the same
+    synthetic workload (default: ALL 2^20 of them), its result compared with the GPU's; and `reference_algorithm`: the oracle's
+    restatement of src/pippenger's own subset-table schedule on ONE core (the reference is single-threaded)."""
     from oracle import cbind
     m = 1 << logn
     pts = bytes(d_pts[: 64 * m].cpu().numpy().tobytes())
     scs = bytes(d_sc[: 32 * m].cpu().numpy().tobytes())
-    # the C oracle parallelises over windows, so it cannot use more threads than windows
+    # the C oracle parallelises over windows, so it cannot use more threads than windows; and never more threads than the
+    # CPUs this process may actually use (cgroup quota / affinity)
     c = max(2, min(16, m.bit_length() - 1 - 2))
-    cores = min(os.cpu_count() or 1, (256 + c - 1) // c + 1)
+    cores = max(1, min(usable_cpus(), (256 + c - 1) // c + 1))
     cbind.msm_bytes(pts[: 64 * 256], scs[: 32 * 256], 256, cores)     # warm
     t0 = time.perf_counter()
     reps = 0
     while True:
         ref = cbind.msm_bytes(pts, scs, m, cores)
         reps += 1
-        if time.perf_counter() - t0 > 12.0:          # ~12 s of CPU work (bounded sample)
+        if time.perf_counter() - t0 > 10.0:          # ~10 s of CPU work (bounded sample)
             break
     dt = time.perf_counter() - t0
     gpu = eng.msm_dev(d_pts, d_sc, m)
-    return {"value": m * reps / dt, "unit": "pairs/s", "cores": cores, "host_cores": os.cpu_count(), "host_cpu_quota": cpu_quota(), "kind": "port",
-            "sample": "oracle/c bucket MSM, first 2^%d pairs of the same inputs, %d reps, %d threads" % (logn, reps, cores),
-            "sample_matches_gpu": bool(gpu == ref)}
+    out = {"value": m * reps / dt, "unit": "pairs/s", "cores": cores, "host_cores": os.cpu_count(), "host_cpu_quota": cpu_quota(), "kind": "port",
+           "sample": "oracle/c bucket MSM, %s 2^%d pairs of the same inputs, %d reps, %d threads" % ("all" if logn >= 20 else "first", logn, reps, cores),
+           "sample_matches_gpu": bool(gpu == ref)}
+    try:
+        out["reference_algorithm"] = cpu_reference_algorithm()
+    except Exception as e:
+        out["reference_algorithm"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    return out
+
+
+def cpu_reference_algorithm():
+    """src/pippenger/pippenger.py:22-94 as restated in oracle/bp_ref.py (same s / t / b, same subset tables), 1 core, on the
+    inputs of the reference-generated goldens at n = 2^10 and 2^12: the group-operation counts must EQUAL the ones the
+    reference itself performed on those inputs (tests/golden/multiexp.json; BASELINE.md quotes 53 815 / 259 068 for the survey's
+    own random draw of the same sizes), and the result must equal the golden point.  2^16 and 2^20 are op-count extrapolations."""
+    from oracle import bp_ref as R
+    from oracle.ec import secp256k1
+    with open(os.path.join(REPO, "tests", "golden", "multiexp.json")) as f:
+        g = json.load(f)
+    sg, ss = bytes.fromhex(g["seed_points"]), bytes.fromhex(g["seed_scalars"])
+    want = {c["n"]: c for c in g["cases"] if c["label"] == "random"}
+    pts_all = [R.elliptic_hash(str(i).encode() + sg) for i in range(4096)]
+    es_all = [R.mod_hash(str(i).encode() + ss, secp256k1.q) for i in range(4096)]
+    rows, sec_per_op = [], None
+    for n in (1024, 4096):
+        grp = R.EC()
+        t0 = time.perf_counter()
+        got = R.Pippenger(grp).multiexp(pts_all[:n], es_all[:n])
+        dt = time.perf_counter() - t0
+        same = ["%x" % got.x, "%x" % got.y] == want[n]["result"]
+        rows.append({"n": n, "seconds": round(dt, 3), "pairs_per_s": round(n / dt, 1), "group_ops": grp.ops,
+                     "group_ops_of_the_reference_on_these_inputs": want[n]["ops"], "ops_equal": grp.ops == want[n]["ops"],
+                     "result_equals_reference_golden": bool(same)})
+        sec_per_op = dt / grp.ops
+    extrap = []
+    for n, ops, src in ((1 << 16, 23703378, "measured op count of the reference at survey time (BASELINE.md)"),
+                        (1 << 20, 2.31e9, "closed form of SURVEY.md 3.1; 2.29e9 resident table entries: not runnable on any host")):
+        extrap.append({"n": n, "group_ops": ops, "seconds_extrapolated": round(ops * sec_per_op, 1), "pairs_per_s_extrapolated": round(n / (ops * sec_per_op), 2),
+                       "extrapolated": True, "op_count_source": src})
+    return {"what": "oracle.bp_ref.Pippenger(EC): the reference's subset-table schedule, Python, 1 core", "cores": 1, "kind": "port of the reference algorithm",
+            "measured": rows, "extrapolated": extrap,
+            "reference_at_survey_time": "BASELINE.md section 2: 761 / 483 / 225 / 84.1 pairs/s at n = 2^10 / 2^12 / 2^14 / 2^16 (reference code + pure-Python EC, 1 core)"}
 
 
 if __name__ == "__main__":

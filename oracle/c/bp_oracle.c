@@ -339,6 +339,56 @@ void orc_ec_lincomb2_batch(const uint8_t *p1, const uint8_t *p2, const uint8_t k
     batch_job J = {p1, p2, k1, k2, out, 0, 0, 0, 1};
     run_batch(J, n, threads);
 }
+
+/* ------------------------------------------------------- point decompression
+ * bytes_to_point (src/utils/utils.py:119-131) in bulk: tag 0x02 / 0x03 + 32-byte big-endian x,
+ * y = (x^3 + 7)^((p+1)/4), the root whose parity matches the tag.  33 zero bytes = the identity (the wire
+ * format's encoding of it, python-bulletproofs_amd/rangeproofs/codec.py).  ok[i] = 0 for an unknown tag,
+ * x >= p, or x^3 + 7 a non-residue (the reference would build an off-curve point there). */
+typedef struct { const uint8_t *comp; uint8_t *out, *ok; u64 i0, i1; } dec_job;
+static void *dec_worker(void *arg) {
+    dec_job *J = (dec_job *)arg;
+    /* (p + 1) / 4 */
+    const u64 e[4] = {0xFFFFFFFFBFFFFF0CULL, 0xFFFFFFFFFFFFFFFFULL, 0xFFFFFFFFFFFFFFFFULL, 0x3FFFFFFFFFFFFFFFULL};
+    for (u64 i = J->i0; i < J->i1; i++) {
+        const uint8_t *c = J->comp + 33 * i;
+        uint8_t *o = J->out + 64 * i;
+        int zero = 1;
+        for (int k = 0; k < 33; k++) zero &= c[k] == 0;
+        memset(o, 0, 64);
+        if (zero) { J->ok[i] = 1; continue; }
+        J->ok[i] = 0;
+        if (c[0] != 2 && c[0] != 3) continue;
+        fe x, t, y, chk;
+        for (int w = 0; w < 4; w++) {
+            u64 v = 0;
+            for (int b = 0; b < 8; b++) v = (v << 8) | c[1 + 8 * (3 - w) + b];
+            x.v[w] = v;
+        }
+        if (ge4(x.v, FE_P.v)) continue;
+        fe seven = {{7, 0, 0, 0}};
+        fe_sqr(&t, &x); fe_mul(&t, &t, &x); fe_add(&t, &t, &seven);
+        fe_pow(&y, &t, e);
+        fe_sqr(&chk, &y);
+        if (memcmp(&chk, &t, sizeof(fe)) != 0) continue;
+        if ((int)(y.v[0] & 1) != (c[0] == 3)) fe_neg(&y, &y);
+        memcpy(o, &x, 32); memcpy(o + 32, &y, 32);
+        J->ok[i] = 1;
+    }
+    return NULL;
+}
+void orc_ec_decompress_batch(const uint8_t *comp, u64 n, int threads, uint8_t *out, uint8_t *ok) {
+    if (threads < 1) threads = 1;
+    if (threads > 64) threads = 64;
+    if ((u64)threads > n) threads = n ? (int)n : 1;
+    pthread_t th[64]; dec_job jobs[64];
+    for (int t = 0; t < threads; t++) {
+        dec_job j = {comp, out, ok, n * t / threads, n * (t + 1) / threads};
+        jobs[t] = j;
+        pthread_create(&th[t], NULL, dec_worker, &jobs[t]);
+    }
+    for (int t = 0; t < threads; t++) pthread_join(th[t], NULL);
+}
 void orc_ec_add(const uint8_t a[64], const uint8_t b[64], uint8_t out[64]) {
     aff A, B, R; jac J;
     aff_load(&A, a); aff_load(&B, b);

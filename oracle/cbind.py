@@ -31,6 +31,8 @@ def lib():
         L.orc_ec_mul_batch.argtypes = [u8p, u8p, u64, i32, u8p]
         L.orc_ec_lincomb2_batch.argtypes = [u8p, u8p, u8p, u8p, u64, i32, u8p]
         L.orc_ec_add.argtypes = [u8p, u8p, u8p]
+        L.orc_ec_decompress_batch.argtypes = [u8p, u64, i32, u8p, u8p]
+        L.orc_ec_decompress_batch.restype = None
         L.orc_sc_dot.argtypes = [u8p, u8p, u64, u8p]
         L.orc_sc_fold.argtypes = [u8p, u8p, u8p, u8p, u64, u8p]
         L.orc_sc_mul.argtypes = [u8p, u8p, u8p]
@@ -80,6 +82,14 @@ def ec_lincomb2_batch(p1, p2, k1, k2, threads=None):
     lib().orc_ec_lincomb2_batch(pack_points(p1), pack_points(p2), pack_scalars([k1]), pack_scalars([k2]),
                                 n, threads or os.cpu_count() or 1, out)
     return unpack_points(out.raw, n)
+
+
+def ec_decompress_batch_bytes(comp, n, threads=None):
+    """n x 33-byte compressed points -> (n x 64-byte points, n validity bytes): bytes_to_point (src/utils/utils.py:119-131)
+    in bulk; 33 zero bytes decode to the identity."""
+    out, ok = ctypes.create_string_buffer(64 * n), ctypes.create_string_buffer(n)
+    lib().orc_ec_decompress_batch(bytes(comp), n, threads or os.cpu_count() or 1, out, ok)
+    return out.raw, ok.raw
 
 
 def ec_add(a, b):

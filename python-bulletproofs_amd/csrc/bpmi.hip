@@ -189,18 +189,21 @@ int bpmi_msm_dev(bpmi_ctx *ctx, const void *d_pts, const void *d_scalars, uint64
   if (rc) return rc;
   HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
   HIPCHK(ctx, hipStreamWaitEvent(ctx->stream1, ctx->ev_fork, 0));
+  // an error in the middle leaves the OTHER lane's slice queued: drain both lanes and release both slots, or every later MSM on
+  // this ctx would fail with "still pending"
+  auto abandon = [&](int code) { msm_abandon_pending(ctx); return code; };
   for (uint64_t k = 0; k < nsl; k++) {
     const int lane = (int)(k & 1);
-    if (k >= 2) { rc = msm_finish(ctx, lane, parts.data() + 64 * (k - 2)); if (rc) return rc; }
+    if (k >= 2) { rc = msm_finish(ctx, lane, parts.data() + 64 * (k - 2)); if (rc) return abandon(rc); }
     const uint64_t lo = k * SLICE, cnt = std::min<uint64_t>(SLICE, n - lo);
     Segs s = segs_init();
     s.pts[0] = (const u32 *)d_pts + 16 * lo; s.sc[0] = (const u32 *)d_scalars + 8 * lo; s.n[0] = (u32)cnt; s.total = (u32)cnt;
     rc = msm_enqueue(ctx, lane, lane, s);
-    if (rc) return rc;
+    if (rc) return abandon(rc);
   }
   for (uint64_t k = (nsl >= 2 ? nsl - 2 : 0); k < nsl; k++) {
     rc = msm_finish(ctx, (int)(k & 1), parts.data() + 64 * k);
-    if (rc) return rc;
+    if (rc) return abandon(rc);
   }
   return bpmi_ec_sum(ctx, parts.data(), nsl, out);
 }
@@ -1042,7 +1045,7 @@ int bpmi_mod_hash_range(const uint8_t *tail, uint64_t tail_len, uint64_t lo, uin
   if (threads < 1) threads = 1;
   if ((uint64_t)threads > count) threads = count ? (int)count : 1;
   auto work = [&](int t) {
-    std::vector<uint8_t> msg(20 + tail_len);
+    std::vector<uint8_t> msg(21 + tail_len);        // 20 digits of a 64-bit counter + snprintf's terminator
     for (uint64_t i = lo + count * t / threads, e = lo + count * (t + 1) / threads; i < e; i++) {
       const int dl = snprintf((char *)msg.data(), 21, "%llu", (unsigned long long)i);
       if (tail_len) memcpy(msg.data() + dl, tail, tail_len);

@@ -289,6 +289,12 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, int slot, const Segs &segs, u32 
   HIPCHK(ctx, hipGetLastError());
   return BPMI_OK;
 }
+// error path of a caller that has MSMs queued in the pending slots: wait for both lanes, release both slots
+static void msm_abandon_pending(bpmi_ctx *ctx) {
+  (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->stream1) (void)hipStreamSynchronize(ctx->stream1);
+  ctx->pend[0].active = ctx->pend[1].active = false;
+}
 // Wait for the slot's MSM (its completion event: work enqueued behind it keeps running) and run the
 // host part of the tail; out = the MSM result.
 static int msm_finish(bpmi_ctx *ctx, int slot, uint8_t out[64]) {
@@ -317,7 +323,7 @@ static int msm_run_split(bpmi_ctx *ctx, const Segs &segs, uint8_t out[64]) {
   rc = msm_enqueue(ctx, 0, 0, segs, 0, Wa);
   if (rc) return rc;
   rc = msm_enqueue(ctx, 1, 1, segs, Wa, W - Wa);
-  if (rc) { ctx->pend[0].active = false; return rc; }
+  if (rc) { msm_abandon_pending(ctx); return rc; }
   bpmi_ctx::PendingMsm &p0 = ctx->pend[0], &p1 = ctx->pend[1];
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream1));
@@ -349,7 +355,7 @@ static int msm_run_pair(bpmi_ctx *ctx, const Segs &s0, uint8_t out0[64], const S
   rc = msm_enqueue(ctx, 0, 0, s0);
   if (rc) return rc;
   rc = msm_enqueue(ctx, 1, 1, s1);
-  if (rc) { (void)hipStreamSynchronize(ctx->stream); ctx->pend[0].active = false; return rc; }
+  if (rc) { msm_abandon_pending(ctx); return rc; }
   rc = msm_finish(ctx, 0, out0);
   const int rc1 = msm_finish(ctx, 1, out1);
   return rc ? rc : rc1;

@@ -86,18 +86,20 @@ class Verifier2(_Checker):
         """u, L_j, R_j, P with the scalars a b, -x_j^2, -x_j^-2, -1 (reference :134-145, both sides in one sum)."""
         pr, q = self.proof, SUPERCURVE.q
         xv = [x.x % q for x in pr.xs]
+        self.assertThat(all(xv))                    # a challenge = 0 (mod q) cannot come out of mod_hash: "Proof invalid", not a ValueError from pow
         xi = [pow(v, -1, q) for v in xv]
         pts = [self.u] + list(pr.Ls) + list(pr.Rs) + [self.P]
         scs = [pr.a.x * pr.b.x] + [-v * v for v in xv] + [-v * v for v in xi] + [-1]
         return xv, xi, pts, scs
 
-    def verify_dev(self, d_g, d_h, n, d_hscale=None, engine=None):
+    def verify_dev(self, d_g, d_h, n, d_hscale=None, engine=None, _transcript_checked=False):
         """verify() for generators that already live in device memory (n points each; d_hscale: n scalars
         or None): transcript re-derivation on the host, everything of size n on the GPU."""
         q = SUPERCURVE.q
         pr = self.proof
         k = n.bit_length() - 1
-        self.verify_transcript(k)
+        if not _transcript_checked:                 # verify() has just re-hashed it
+            self.verify_transcript(k)
         xv, xi, pts, scs = self._extra_terms()
         eng = engine or _engine.default_engine()
         total = eng.ipa_verify_dev(d_g, d_h, n, pack_scalars(xv[:k], q), pack_scalars(xi[:k], q), pr.a.x, pr.b.x,
@@ -114,7 +116,7 @@ class Verifier2(_Checker):
             d_g, d_h = eng.upload(pack_points(self.g)), eng.upload(pack_points(self.h))
             d_s = None if self.h_scale is None else eng.upload(pack_scalars(self.h_scale, SUPERCURVE.q))
             try:
-                return self.verify_dev(d_g, d_h, n, d_s, eng)
+                return self.verify_dev(d_g, d_h, n, d_s, eng, _transcript_checked=True)
             finally:
                 for d in (d_g, d_h, d_s):
                     if d is not None:

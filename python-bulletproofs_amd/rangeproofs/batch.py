@@ -197,7 +197,18 @@ class BatchRangeVerifier:
 
     # ---- many proofs in wire format, host work spread over worker processes ---------------
     def state(self):
-        """Everything add() has accumulated, as plain picklable data (see merge)."""
+        """Everything add() / add_wire*() has accumulated, as plain picklable data (see merge).  Device-resident chunks of
+        add_wire_native (points and scalars of the proofs, which never came to the host) are downloaded for it."""
+        dev_pts, dev_scs, dev_n = [], [], 0
+        for d_p, d_s, cnt in self._dev_chunks:
+            dev_pts.append(d_p.download()[:64 * cnt])
+            dev_scs.append(d_s.download()[:32 * cnt])
+            dev_n += cnt
+        if dev_n:
+            return (self.c_g, self.c_h, self.c_u, self._gs_const, self._hs_const, list(self.c_gs), list(self.c_hs),
+                    b"".join(self._pts) + b"".join(self._raw_pts) + b"".join(dev_pts),
+                    b"".join(_le32(v) for v in self._scs) + b"".join(self._raw_scs) + b"".join(dev_scs),
+                    len(self._scs) + self._raw_count + dev_n, self.count)
         return (self.c_g, self.c_h, self.c_u, self._gs_const, self._hs_const, list(self.c_gs), list(self.c_hs),
                 b"".join(self._pts) + b"".join(self._raw_pts),
                 b"".join(_le32(v) for v in self._scs) + b"".join(self._raw_scs), len(self._scs) + self._raw_count, self.count)
@@ -301,6 +312,12 @@ class BatchRangeVerifier:
         else:
             count = len(offsets) - 1
             joined = blobs
+            # the table comes from the caller: it must stay inside the buffer it indexes (the native code checks it against the
+            # length it is TOLD, so that length must be the real one)
+            total = joined.nbytes if hasattr(joined, "ptr") else len(joined)
+            # (first / last here; the native code walks the whole table against the real size -- no Python loop over 2^14 proofs)
+            if count < 0 or offsets[0] < 0 or (count > 0 and not (0 <= offsets[count] <= total)):
+                raise ValueError("offsets must be non-decreasing positions inside the %d-byte proof buffer" % total)
         if not count:
             return
         k = self.n.bit_length() - 1
@@ -394,7 +411,7 @@ class BatchRangeVerifier:
                     src = ctypes.addressof((ctypes.c_char * len(joined)).from_buffer(joined))
                 except TypeError:                               # read-only buffer
                     src = bytes(joined)
-            nbytes = offs[count]
+            nbytes = joined.nbytes if hasattr(joined, "ptr") else len(joined)       # the buffer's REAL size: the native bounds check of the offset table is against it
             eng._ck(eng.lib.bpmi_rp_batch_prepare_dev(eng.ctx, self.n, m, count, src, nbytes, ctypes.cast(offs, ctypes.c_void_p), weights, seed,
                                                       d_scs.ptr, d_scs.ptr + 32 * nv, d_pts.ptr + 64 * nv, shared,
                                                       ctypes.cast(ctypes.pointer(bad), ctypes.c_void_p)))

@@ -234,7 +234,7 @@ def test_c5_batch_verify_2e14_from_wire(gp):
     from bulletproofs_amd.rangeproofs.codec import proof_to_bytes
     from bulletproofs_amd.utils import ModP, commitment, mod_hash
     eng = gp.engine()
-    n, total, distinct = 64, 1 << 14, 48
+    n, total, distinct = 64, 1 << 14, 1024        # 1024 DISTINCT proofs (values, blindings, seeds), each 16 times, positions interleaved
     gs, hs = gp.to_gpu_list(gens(n, b"c5gs")), gp.to_gpu_list(gens(n, b"c5hs"))
     g, h, u = (gp.to_gpu(R.elliptic_hash(s)) for s in (b"c5g", b"c5h", b"c5u"))
     Vd, wire = [], []
@@ -266,7 +266,7 @@ def test_c5_batch_verify_2e14_from_wire(gp):
             bv.verify()
     # a commitment that does not belong to its proof -> rejected (only the MSM can notice)
     Vs_bad = list(Vs)
-    Vs_bad[123] = Vd[(123 + 1) % distinct]
+    Vs_bad[1123] = Vd[(1123 + 1) % distinct]
     bv = BatchRangeVerifier(g, h, gs, hs, u)
     bv.add_wire_native(Vs_bad, blobs, threads=threads)
     with pytest.raises(Exception, match="Proof invalid"):
