@@ -266,7 +266,7 @@ int bpmi_debug_fe_op(bpmi_ctx *ctx, int op, const uint32_t *a, const uint32_t *b
  * stage (enable = 2: around the dominant stage, msm_accumulate, only -- every recorded event costs
  * a ~10 us bubble between two kernels, so a timed run should use 2); bpmi_profile_read returns accumulated milliseconds and launch counts
  * per stage since the last reset.  Stage names: bpmi_profile_stage_name(i). */
-#define BPMI_NSTAGES 14
+#define BPMI_NSTAGES 15
 int bpmi_profile(bpmi_ctx *ctx, int enable);
 int bpmi_profile_reset(bpmi_ctx *ctx);
 int bpmi_profile_read(bpmi_ctx *ctx, double ms[BPMI_NSTAGES], uint64_t calls[BPMI_NSTAGES]);

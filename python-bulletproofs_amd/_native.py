@@ -5,7 +5,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BPMI_LIB") or os.path.join(HERE, "libbpmi.so")      # BPMI_LIB: A/B experiments with two builds in one run
-NSTAGES = 14
+NSTAGES = 15
 
 # name -> (restype, argtypes); this table is checked against include/bpmi.h by tests
 _vp, _cp, _u64, _i, _sz = ctypes.c_void_p, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_size_t

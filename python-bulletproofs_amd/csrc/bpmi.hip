@@ -128,6 +128,7 @@ int bpmi_set_option(bpmi_ctx *ctx, const char *name, int64_t value) {
   if (!strcmp(name, "split")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "split must be 0 or 1"); ctx->opt_split = (int)value; return BPMI_OK; }
   if (!strcmp(name, "async_lanes")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "async_lanes must be 0 or 1"); ctx->opt_async_lanes = (int)value; return BPMI_OK; }
   if (!strcmp(name, "rp_only_role")) { if (value < -1 || value > 3) return fail(ctx, BPMI_E_ARG, "rp_only_role must be in [-1, 3]"); ctx->opt_rp_only_role = (int)value; return BPMI_OK; }
+  if (!strcmp(name, "rp_overlap")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "rp_overlap must be 0 or 1"); ctx->opt_rp_overlap = (int)value; return BPMI_OK; }
   if (!strcmp(name, "rp_rows")) { if (value < 0) return fail(ctx, BPMI_E_ARG, "rp_rows must be >= 0"); ctx->opt_rp_rows = (int)value; return BPMI_OK; }
   if (!strcmp(name, "rp_lanes")) {
     if (value != 0 && (value < 1 || value > 64 || (value & (value - 1)))) return fail(ctx, BPMI_E_ARG, "rp_lanes must be 0 or a power of two <= 64");
@@ -1098,78 +1099,103 @@ int bpmi_rp_batch_prepare_dev(bpmi_ctx *ctx, uint32_t n_gens, uint32_t values_pe
   const size_t o_w = o_off + align_up(8 * ((size_t)P + 1), 256), o_st = o_w + (weights ? align_up(128 * (size_t)P, 256) : 0);
   int rc = ensure_stage_in(ctx, o_st + align_up(RP_ROLES * (size_t)P, 256));
   if (rc) return rc;
+  rc = ensure_lane(ctx, 1);
+  if (rc) return rc;
+  rc = ensure_pin(ctx, 32 * (size_t)ncols + 64);
+  if (rc) return rc;
   char *din = (char *)ctx->stage_in;
-  HIPCHK(ctx, hipMemcpyAsync(din, blobs, blobs_len, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(ctx, hipMemcpyAsync(din + o_off, blob_off, 8 * ((size_t)P + 1), hipMemcpyHostToDevice, ctx->stream));
-  if (weights) HIPCHK(ctx, hipMemcpyAsync(din + o_w, weights, 128 * (size_t)P, hipMemcpyHostToDevice, ctx->stream));
-  // contributions: at most ~256 MB of cells per launch
-  const size_t cell_row = 36 * (size_t)ncols, out_row = 32 * (size_t)ncols;       // scratch cells are 9 limbs, the result 8 words
+  // contributions + contexts: at most ~256 MB of cells per launch
+  const u32 nslots = CTX_SLOTS(k, m);
+  const size_t cell_row = 36 * ((size_t)ncols + nslots), out_row = 32 * (size_t)ncols;       // scratch cells are 9 limbs, the result 8 words
   u32 rows = (u32)std::min<size_t>(P, std::max<size_t>(1, ((size_t)256 << 20) / cell_row));
   if (ctx->opt_rp_rows > 0) rows = std::min<u32>(rows, (u32)ctx->opt_rp_rows);
-  const size_t o_shared = align_up(cell_row * rows, 256), o_T = o_shared + align_up(out_row + 64, 256), T_bytes = 8 * (size_t)W * P;
+  const size_t o_ctx = align_up(36 * (size_t)ncols * rows, 256), o_shared = o_ctx + align_up(36 * (size_t)nslots * rows, 256),
+               o_T = o_shared + align_up(out_row + 64, 256), T_bytes = 8 * (size_t)W * P;
   const size_t need = o_T + T_bytes + 256;
   if (need > ctx->rp_buf_bytes) {
     if (ctx->rp_buf) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(ctx->rp_buf)); ctx->rp_buf = nullptr; ctx->rp_buf_bytes = 0; }
     HIPCHK(ctx, hipMalloc(&ctx->rp_buf, need));
     ctx->rp_buf_bytes = need;
   }
-  u32 *d_contrib = (u32 *)ctx->rp_buf, *d_shared = (u32 *)((char *)ctx->rp_buf + o_shared);
+  u32 *d_contrib = (u32 *)ctx->rp_buf, *d_ctx = (u32 *)((char *)ctx->rp_buf + o_ctx), *d_shared = (u32 *)((char *)ctx->rp_buf + o_shared);
   u64 *d_T = (u64 *)((char *)ctx->rp_buf + o_T);
   unsigned long long *d_bad = (unsigned long long *)(d_shared + 8 * (size_t)ncols);
-  HIPCHK(ctx, hipMemsetAsync(d_shared, 0, out_row, ctx->stream));
-  HIPCHK(ctx, hipMemsetAsync(d_bad, 0xFF, 8, ctx->stream));
-  // point decoding on the second lane: it reads only the wire bytes, so it runs beside the preparation kernels (which put one
-  // low-occupancy wave on every SIMD and leave room for it)
-  rc = ensure_lane(ctx, 1);
+  // Everything from here on is queued on the two lanes; an error in the middle must not return while the second lane is still
+  // writing into the caller's point array: `queue` reports, the code behind it waits for both lanes whatever happened.
+  auto queue = [&]() -> int {
+    HIPCHK(ctx, hipMemcpyAsync(din, blobs, blobs_len, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(din + o_off, blob_off, 8 * ((size_t)P + 1), hipMemcpyHostToDevice, ctx->stream));
+    if (weights) HIPCHK(ctx, hipMemcpyAsync(din + o_w, weights, 128 * (size_t)P, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(d_shared, 0, out_row, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(d_bad, 0xFF, 8, ctx->stream));
+    // point decoding on the second lane: it reads only the wire bytes, so it runs beside the preparation kernels (option
+    // rp_overlap = 0, measurements only: behind them on the same stream, so that every kernel's duration is its own)
+    auto decode = [&](hipStream_t st) -> int {
+      StageTimer t(ctx, ST_DECOMP, st);
+      const u64 npts = (u64)P * per;
+      hipLaunchKernelGGL(k_ec_decompress_wire, dim3((u32)((npts + 255) / 256)), dim3(256), 0, st, (const uint8_t *)din, (const u64 *)(din + o_off),
+                         k, P, (u64)0, (u32)RP_MAX_PROOF_BYTES, (u32 *)d_points, d_bad);
+      return BPMI_OK;
+    };
+    HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream1, ctx->ev_fork, 0));
+    if (ctx->opt_rp_overlap) decode(ctx->stream1);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->stream1));
+    {
+      StageTimer t(ctx, ST_RPPREP);
+      hipLaunchKernelGGL(rpd::k_rp_transpose, dim3((P + 63) / 64, (W + 63) / 64), dim3(256), 0, ctx->stream, (const uint8_t *)din, (const u64 *)(din + o_off), P, W, d_T);
+    }
+    rpd::Params q;
+    q.Tstride = P;
+    q.weights = weights ? (const uint8_t *)(din + o_w) : nullptr;
+    for (int i = 0; i < 8; i++) q.seed[i] = seed ? ((u32)seed[4 * i] << 24) | ((u32)seed[4 * i + 1] << 16) | ((u32)seed[4 * i + 2] << 8) | seed[4 * i + 3] : 0;
+    q.n = n_gens; q.k = k; q.m = m; q.Pall = P; q.only_role = ctx->opt_rp_only_role;
+    q.contrib = d_contrib;
+    q.ctx = d_ctx;
+    q.bad = d_bad;
+    const size_t lds_bytes = ((size_t)k + 1) * 9 * 64 * sizeof(u32);            // role 2: k + 1 prefix products of 9 limbs per lane
+    u32 lb = 0;
+    while ((1u << lb) < n_gens / m) lb++;
+    rpd::ElemGeom eg;
+    eg.el_log = std::min<u32>(3u, lb);
+    eg.ranges = n_gens >> eg.el_log;
+    for (u32 base = 0; base < P; base += rows) {
+      const u32 cnt = std::min(rows, P - base);
+      u32 lanes = (u32)ctx->opt_rp_lanes;
+      if (!lanes) lanes = 64;
+      q.off = (const u64 *)(din + o_off) + base;
+      q.T = d_T + base;
+      q.P = cnt; q.lanes = lanes; q.first = base;
+      q.v_scalars = (u32 *)d_v_scalars + 8 * (size_t)base * m;
+      q.pt_scalars = (u32 *)d_pt_scalars + 8 * (size_t)base * per;
+      q.status = (uint8_t *)(din + o_st) + base;
+      {
+        StageTimer t(ctx, ST_RPPREP);
+        hipLaunchKernelGGL(rpd::k_rp_roles, dim3(RP_ROLES * ((cnt + lanes - 1) / lanes)), dim3(64), lds_bytes, ctx->stream, q);
+      }
+      {
+        StageTimer t(ctx, ST_RPELEM);
+        hipLaunchKernelGGL(rpd::k_rp_elements, dim3(2 * eg.ranges * ((cnt + 63) / 64)), dim3(64), 0, ctx->stream, q, eg);
+        hipLaunchKernelGGL(rpd::k_rp_colsum, dim3(ncols), dim3(256), 0, ctx->stream, (const u32 *)d_contrib, cnt, d_shared);
+      }
+    }
+    if (!ctx->opt_rp_overlap) decode(ctx->stream);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->pin, d_shared, out_row + 8, hipMemcpyDeviceToHost, ctx->stream));
+    return BPMI_OK;
+  };
+  rc = queue();
+  const hipError_t e0 = hipStreamSynchronize(ctx->stream), e1 = hipStreamSynchronize(ctx->stream1);
   if (rc) return rc;
-  HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
-  HIPCHK(ctx, hipStreamWaitEvent(ctx->stream1, ctx->ev_fork, 0));
-  {
-    StageTimer t(ctx, ST_DECOMP, ctx->stream1);
-    const u64 npts = (u64)P * per;
-    hipLaunchKernelGGL(k_ec_decompress_wire, dim3((u32)((npts + 255) / 256)), dim3(256), 0, ctx->stream1, (const uint8_t *)din, (const u64 *)(din + o_off),
-                       k, P, (u64)0, (u32)RP_MAX_PROOF_BYTES, (u32 *)d_points, d_bad);
-  }
-  HIPCHK(ctx, hipGetLastError());
-  HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->stream1));
-  {
-    StageTimer t(ctx, ST_RPPREP);
-    hipLaunchKernelGGL(rpd::k_rp_transpose, dim3((P + 63) / 64, (W + 63) / 64), dim3(256), 0, ctx->stream, (const uint8_t *)din, (const u64 *)(din + o_off), P, W, d_T);
-  }
-  rpd::Params q;
-  q.Tstride = P;
-  q.weights = weights ? (const uint8_t *)(din + o_w) : nullptr;
-  for (int i = 0; i < 8; i++) q.seed[i] = seed ? ((u32)seed[4 * i] << 24) | ((u32)seed[4 * i + 1] << 16) | ((u32)seed[4 * i + 2] << 8) | seed[4 * i + 3] : 0;
-  q.n = n_gens; q.k = k; q.m = m; q.Pall = P; q.only_role = ctx->opt_rp_only_role;
-  q.contrib = d_contrib;
-  q.bad = d_bad;
-  const size_t lds_bytes = 2 * (size_t)k * 9 * 64 * sizeof(u32);            // 2k slots of 9 limbs per lane (the s-vector walk)
-  if (lds_bytes > 64 * 1024) HIPCHK(ctx, hipFuncSetAttribute((const void *)rpd::k_rp_prepare, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-  for (u32 base = 0; base < P; base += rows) {
-    const u32 cnt = std::min(rows, P - base);
-    u32 lanes = (u32)ctx->opt_rp_lanes;
-    if (!lanes) lanes = 64;
-    q.off = (const u64 *)(din + o_off) + base;
-    q.T = d_T + base;
-    q.P = cnt; q.lanes = lanes; q.first = base;
-    q.v_scalars = (u32 *)d_v_scalars + 8 * (size_t)base * m;
-    q.pt_scalars = (u32 *)d_pt_scalars + 8 * (size_t)base * per;
-    q.status = (uint8_t *)(din + o_st) + base;
-    StageTimer t(ctx, ST_RPPREP);
-    hipLaunchKernelGGL(rpd::k_rp_prepare, dim3(RP_ROLES * ((cnt + lanes - 1) / lanes)), dim3(64), lds_bytes, ctx->stream, q);
-    hipLaunchKernelGGL(rpd::k_rp_colsum, dim3(ncols), dim3(256), 0, ctx->stream, (const u32 *)d_contrib, cnt, d_shared);
-  }
-  HIPCHK(ctx, hipGetLastError());
-  HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
-  rc = ensure_pin(ctx, out_row + 64);
-  if (rc) return rc;
-  HIPCHK(ctx, hipMemcpyAsync(ctx->pin, d_shared, out_row + 8, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx, e0);
+  HIPCHK(ctx, e1);
   memcpy(shared, ctx->pin, out_row);
   unsigned long long bad;
   memcpy(&bad, (char *)ctx->pin + out_row, 8);
   *first_bad = bad == ~0ull ? -1 : (int64_t)bad;
-  if (ctx->opt_rp_only_role >= 0) *first_bad = 0;        // a profiling run checked half of every proof: it must never read as "all valid"
+  if (ctx->opt_rp_only_role >= 0) *first_bad = 0;        // a profiling run checked part of every proof: it must never read as "all valid"
   return BPMI_OK;
 }
 // page-locked host memory for buffers that are handed to the library again and again (e.g. the receive buffer of wire proofs:

@@ -7,11 +7,11 @@
 // ------------------------------------------------------------------------------------
 enum Stage {
   ST_DIGITS = 0, ST_SCAN, ST_SCATTER, ST_ACCUM, ST_SEGSCAN, ST_BREDUCE, ST_TAIL,
-  ST_MULBATCH, ST_LINCOMB2, ST_SCDOT, ST_SCFOLD, ST_MISC, ST_RPPREP, ST_DECOMP
+  ST_MULBATCH, ST_LINCOMB2, ST_SCDOT, ST_SCFOLD, ST_MISC, ST_RPPREP, ST_DECOMP, ST_RPELEM
 };
 static const char *STAGE_NAMES[BPMI_NSTAGES] = {
   "msm_digits_hist", "msm_scan", "msm_scatter", "msm_accumulate", "msm_segscan", "msm_bucket_reduce",
-  "msm_tail", "ec_mul_batch", "ec_lincomb2", "sc_dot", "sc_fold", "misc", "rp_prepare", "ec_decompress"
+  "msm_tail", "ec_mul_batch", "ec_lincomb2", "sc_dot", "sc_fold", "misc", "rp_prepare", "ec_decompress", "rp_elements"
 };
 
 struct EvPair { int stage; hipEvent_t a, b; };
@@ -51,6 +51,7 @@ struct bpmi_ctx {
   int opt_small = 0;    // largest n handled by the one-launch small-MSM kernel (0 = default, -1 = never)
   int opt_fold_wnaf = 1;     // the IPA's 16-way generator fold: width-4 NAF over affine tables of odd multiples (0: plain NAF ladder)
   int opt_rp_only_role = -1; // profiling only: run one role of the batch preparation kernel (the call then reports proof 0 as bad)
+  int opt_rp_overlap = 1;    // batch preparation: point decoding on the second lane beside the preparation kernels (0: behind them; measurements)
   int opt_rp_rows = 0;       // batch preparation: proofs per launch (0 = as many as fit ~256 MB of contribution cells)
   int opt_rp_lanes = 0;      // batch preparation kernel: proofs per wave (0 = chosen from the batch size)
   void *rp_buf = nullptr; size_t rp_buf_bytes = 0;   // batch preparation: per-proof contributions to the shared generators

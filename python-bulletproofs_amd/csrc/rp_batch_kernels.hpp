@@ -1,24 +1,34 @@
 // rp_batch_kernels.hpp -- part of libbpmi (included by bpmi.hip; one translation unit).  DEVICE code.
-// The per-proof preparation of the batch range-proof verifier on the GPU: a lane parses the wire blob of one proof,
-// re-hashes its Fiat-Shamir transcripts (SHA-256), runs the byte-level checks of the reference's verifiers
-// (rangeproof_verifier.py:42-53, inner_product_verifier.py:31-43 and :104-125) or produces the weighted scalars of the
-// batch's one MSM.  It is the device twin of rp_batch_host.hpp (same checks, same numbers: tests/test_gpu_batch_dev.py
-// compares the two byte for byte on the same weights); see that file for what each check means.
+// The per-proof preparation of the batch range-proof verifier on the GPU: the wire blob of every proof is parsed, its Fiat-Shamir
+// transcripts are re-hashed (SHA-256), the byte-level checks of the reference's verifiers run (rangeproof_verifier.py:42-53,
+// inner_product_verifier.py:31-43 and :104-125) and the weighted scalars of the batch's one MSM are produced.  It is the device
+// twin of rp_batch_host.hpp (same checks, same numbers: tests/test_gpu_batch_dev.py compares the two byte for byte on the same
+// weights); see that file for what each check means.
 //
-// Shape of the work.  A proof is ~230 000 instructions of serial integer work and a batch has ~2^14 proofs: a wave64
-// instruction costs its 4 issue cycles whatever its active-lane count, so waves must be FULL (64 proofs each), and 2^14
-// proofs are then only 256 waves for 1024 SIMDs.  Hence four ROLES per proof, each a wave of its own (k_rp_prepare): the hash
-// chain of the Protocol-2 transcript | the other transcript checks | the gs side of the algebra with the per-proof
-// scalars | the hs side.  They share nothing but the input -- the algebra only needs the challenges a proof CLAIMS, the
-// transcript roles verify the claims -- so a proof's critical path is its longest role and every SIMD has a wave.
-// Input: k_rp_transpose first re-lays the batch as 8-byte words, word-major over the proofs (see BPtr), so that lanes
-// walking their own proofs read neighbouring words.
+// Shape of the work (round 3).  A proof is a handful of SERIAL chains (a SHA-256 chain over the Protocol-2 transcript, the text
+// checks, one modular inversion with the tables that hang off it, the inverse-free scalars) plus 2n independent elements of the
+// s-vector.  A wave64 instruction costs its issue cycles whatever its active-lane count, so every chain runs with one lane per
+// proof in FULL waves (64 proofs), one wave per chain kind ("role"), and nothing is computed twice:
+//   k_rp_roles     role 0  hash chain of the Protocol-2 transcript (every x_i re-hashed from its prefix)
+//                  role 1  range-proof / Protocol-1 transcripts and the text half of Protocol 2 (L_i / R_i items vs the points)
+//                  role 2  the inversion of (x_1 .. x_k, y) and what needs it: the per-bit factor tables of the s-vector and of the
+//                          y^-i / 2^i progressions (the "context" of a proof, limb-major in global memory), the R_j scalars
+//                  role 3  everything that needs no inverse: the four weights, delta(y, z), the five scalar columns, the scalars of
+//                          V_j, T1, T2, A, S, u_new, P_new, L_j
+//   k_rp_elements  the 2n shared-generator contributions of every proof, EIGHT consecutive elements per lane: a lane multiplies
+//                  the proof's base value by the factors of the set high index bits (wave-uniform: a block is 64 proofs at ONE
+//                  element range), then walks its 8 elements with 7 multiplications (a binary tree over the three low bits, all
+//                  in registers) -- 2 * n/8 waves per 64 proofs instead of two, no LDS, no private arrays.
+// The roles share nothing but the input: the algebra needs only the challenges a proof CLAIMS, roles 0 / 1 verify the claims.
+// Nothing here lives in private memory: states and operands travel BY VALUE in registers (an object passed by reference to an
+// out-of-line routine lives in scratch, and a lone wave per SIMD has nothing to hide a scratch round trip behind); the one
+// indexed per-lane array (the prefix products of the batched inversion) lives in LDS.
+// Input: k_rp_transpose first re-lays the batch as 8-byte words, word-major over the proofs (see BPtr), so that lanes walking
+// their own proofs read neighbouring words.
 // Output: the (5 + 2n) shared-generator contributions of proof g go to cells (col, g) of nine 29-bit limbs, limb-major
-// (contrib[(col * 9 + limb) * P + g]: a wave stores coalesced dword rows), summed over g by k_rp_colsum.  The s-vector is
-// generated element by element -- ONE multiplication each, the level products in LDS -- so a lane needs no O(n) private
-// memory and the cells are write-only.  Per-proof scalars go straight to the MSM's scalar array.
-// Measurements: profiles/r02_C5_prepare_kernel.txt (host vs device, proofs per wave, each role alone),
-// profiles/r02_C5_prepare_kernel_pmc.txt (instruction counts, active / wait cycles, per role).
+// (contrib[(col * 9 + limb) * P + g]: a wave stores coalesced dword rows), summed over g by k_rp_colsum; per-proof scalars go
+// straight to the MSM's scalar array.
+// Measurements: profiles/r03_C5_prepare_kernel.txt; round 2's four-role kernel: profiles/r02_C5_prepare_kernel*.txt.
 #pragma once
 
 namespace rpd {
@@ -86,31 +96,12 @@ __device__ __forceinline__ void sha_init(Sha &s) {
   for (int i = 0; i < 16; i++) s.w[i] = 0;
   s.cur = 0; s.fill = 0; s.len = 0;
 }
-__device__ __forceinline__ void sha_byte_inl(Sha &s, u32 b) {
-  s.cur = (s.cur << 8) | b;
-  s.fill++;
-  s.len++;
-  if ((s.fill & 3u) == 0) {
-#pragma unroll
-    for (int i = 0; i < 15; i++) s.w[i] = s.w[i + 1];
-    s.w[15] = s.cur;
-    if (s.fill == 64u) { sha_compress(s); s.fill = 0; }
-  }
-}
-// The routines below work on a private COPY of the state and write it back once: the caller's object lives in memory (it
-// is passed by reference to out-of-line code), the copy in registers.
-__device__ __noinline__ void sha_byte(Sha &s, u32 b) {          // odd bytes (prefixes, the weight derivation)
-  Sha t = s;
-  sha_byte_inl(t, b);
-  s = t;
-}
 // Where the proof bytes are read from.  Every lane walks its own proof, so against the wire buffer a wave's load is 64
-// scattered cache lines (15 M L2 requests per 2^14 proofs; 5 M with the layout below).  k_rp_transpose therefore re-lays
-// the batch as 8-byte words, word-major over the proofs: T[w * stride + g] = bytes [8w, 8w + 8) of proof g, zero beyond the
-// proof's end.  Lanes that read the same word index of their proofs -- the normal case, the proofs have the same layout --
-// then touch neighbouring words: a load is a few coalesced 512-byte rows.  BPtr is a byte position inside one proof of that
-// array and stands in for `const uint8_t *` (p + n, p[i], ld8(p)); loads may run up to 80 bytes past the proof's end: the
-// array carries 16 zero rows of padding.
+// scattered cache lines.  k_rp_transpose therefore re-lays the batch as 8-byte words, word-major over the proofs:
+// T[w * stride + g] = bytes [8w, 8w + 8) of proof g, zero beyond the proof's end.  Lanes that read the same word index of their
+// proofs -- the normal case, the proofs have the same layout -- then touch neighbouring words: a load is a few coalesced
+// 512-byte rows.  BPtr is a byte position inside one proof of that array and stands in for `const uint8_t *` (p + n, p[i],
+// ld8(p)); loads may run up to 80 bytes past the proof's end: the array carries 16 zero rows of padding.
 struct BPtr {
   const u64 *base;      // T + g
   u32 stride;           // words between consecutive 8-byte words of one proof (= proofs in the array)
@@ -128,11 +119,11 @@ __device__ __forceinline__ u64 ld8(const BPtr p) {                       // the 
   return (a >> s) | ((b << (63 - s)) << 1);
 }
 __device__ __forceinline__ u64 ld8_raw(const uint8_t *p) { u64 w; __builtin_memcpy(&w, p, 8); return w; }      // plain memory (the weights)
-// Feeding WITHOUT compressing: the lanes of a wave hash prefixes of slightly different lengths, so their 64-byte blocks fill
-// at different steps; a compression call at every feeding step would run once per distinct phase in the wave.  sha_update
-// and sha_final_number therefore fill a lane's block completely (however many words that takes for the lane) and compress
-// at ONE point per block, where every lane of the wave that has a full block takes part (measured before: the hash-chain
-// role issued about twice the instructions one lane needs).
+
+// Feeding WITHOUT compressing at every step: the lanes of a wave hash prefixes of slightly different lengths, so their 64-byte
+// blocks fill at different steps; a compression call at every feeding step would run once per distinct phase in the wave.
+// sha_feed and sha_digest_number therefore fill a lane's block completely (however many words that takes for the lane) and
+// compress at ONE point per block, where every lane of the wave that has a full block takes part.
 __device__ __forceinline__ void sha_push_byte(Sha &s, u32 b) {           // the caller guarantees fill < 64
   s.cur = (s.cur << 8) | b;
   s.fill++;
@@ -150,15 +141,15 @@ __device__ __forceinline__ void sha_push_word(Sha &s, u32 w) {           // fill
   s.fill += 4;
   s.len += 4;
 }
-__device__ __noinline__ void sha_update(Sha &s, const BPtr p, u32 n) {
-  Sha t = s;
+// absorb p[0, n): inlined at its (few) call sites, so the state never leaves the registers
+__device__ __forceinline__ void sha_feed(Sha &t, const BPtr p, u32 n) {
   u32 i = 0;
   while (i < n) {
     while (i < n && (t.fill & 3u)) sha_push_byte(t, p[i++]);              // up to the next word boundary of the message (<= 3 bytes)
     if ((t.fill & 3u) == 0 && t.fill < 64u) {
       const u32 nw = min((64u - t.fill) >> 2, (n - i) >> 2);             // words that fit this block and exist
-      u64 x[8];                                                          // loads in flight together (a lone wave per SIMD has nothing
-#pragma unroll                                                           // else to overlap a memory round trip with)
+      u64 x[8];                                                          // loads in flight together
+#pragma unroll
       for (int j = 0; j < 8; j++) x[j] = ld8(p + i + 8 * j);
 #pragma unroll
       for (int j = 0; j < 16; j++)
@@ -169,11 +160,10 @@ __device__ __noinline__ void sha_update(Sha &s, const BPtr p, u32 n) {
     }
     if (t.fill == 64u) { sha_compress(t); t.fill = 0; }
   }
-  s = t;
 }
 // digest of a COPY of the state (the caller's state can go on absorbing), as the big-endian number it spells, and
 // whether that number is in [0, q)
-__device__ __noinline__ void sha_final_number(const Sha &s0, sc &r, bool &lt_q) {
+__device__ __forceinline__ void sha_digest_number(const Sha &s0, sc &r, bool &lt_q) {
   Sha s = s0;
   const u32 bits_hi = s.len >> 29, bits_lo = s.len << 3;
   // padding: 0x80, zeros up to 56 mod 64, the bit length as 8 big-endian bytes; one or two blocks, compressed at one point
@@ -196,17 +186,17 @@ __device__ __noinline__ void sha_final_number(const Sha &s0, sc &r, bool &lt_q) 
 }
 // mod_hash(msg, q): the first i >= 1 with SHA-256(str(i) || msg) in [1, q) (src/utils/utils.py:84-97); `one` has
 // absorbed "1" and msg already (the case i = 1); the retry (probability ~2^-128) re-hashes msg[0, n) from scratch
-__device__ __noinline__ void mod_hash_q(sc &r, const Sha &one, const BPtr msg, u32 n) {
+__device__ __forceinline__ void mod_hash_q(sc &r, const Sha &one, const BPtr msg, u32 n) {
   bool lt;
-  sha_final_number(one, r, lt);
+  sha_digest_number(one, r, lt);
   for (u32 i = 2; !lt || bpmi::sc_is_zero(r); i++) {
     Sha s;
     sha_init(s);
     u32 div = 1000000000u;
     while (div > i) div /= 10;
-    for (u32 v = i; div; div /= 10) { sha_byte(s, '0' + v / div); v %= div; }
-    sha_update(s, msg, n);
-    sha_final_number(s, r, lt);
+    for (u32 v = i; div; div /= 10) { sha_push_byte(s, '0' + v / div); v %= div; }       // <= 10 bytes: the block cannot fill
+    sha_feed(s, msg, n);
+    sha_digest_number(s, r, lt);
   }
 }
 
@@ -233,7 +223,7 @@ __device__ __noinline__ bool point_item_equals(const BPtr comp, const BPtr p, u3
   }
   return same;
 }
-// canonical decimal -> value mod q (false: not canonical decimal, or >= 2^256).  All (up to 80) bytes are loaded at once;
+// canonical decimal -> value mod q (ok = false: not canonical decimal, or >= 2^256).  All (up to 80) bytes are loaded at once;
 // eight digits become a number with three multiplications (first character in the lowest byte):
 //   pairs (x * 10 + (x >> 8)) & 0x00FF.., fours (* 100, >> 16), eight (* 10000, >> 32)
 __device__ __forceinline__ bool eight_digits(u64 x, u32 count, u32 &val) {          // the first `count` (1..8) bytes of x
@@ -249,8 +239,13 @@ __device__ __forceinline__ bool eight_digits(u64 x, u32 count, u32 &val) {      
   val = (u32)x;
   return ok;
 }
-__device__ __noinline__ bool parse_decimal(sc &r, const BPtr p, u32 n) {
-  if (n == 0 || n > 78 || (n > 1 && p[0] == '0')) return false;
+struct Dec { sc v; u32 ok; };            // returned BY VALUE: nine registers, no scratch
+__device__ __noinline__ Dec parse_decimal(const BPtr p, u32 n) {
+  Dec out;
+#pragma unroll
+  for (int k = 0; k < 8; k++) out.v.v[k] = 0;
+  out.ok = 0;
+  if (n == 0 || n > 78 || (n > 1 && p[0] == '0')) return out;
   u64 x[10];
 #pragma unroll
   for (int c = 0; c < 10; c++) x[c] = ld8(p + 8 * c);                  // 80 bytes; only the first n are looked at
@@ -272,11 +267,12 @@ __device__ __noinline__ bool parse_decimal(sc &r, const BPtr p, u32 n) {
       for (int k = 0; k < 9; k++) { cy += (u64)t[k] * scale; t[k] = (u32)cy; cy >>= 32; }
     }
   }
-  if (!digits || t[8]) return false;
+  if (!digits || t[8]) return out;
 #pragma unroll
-  for (int k = 0; k < 8; k++) r.v[k] = t[k];
-  bpmi::sc_reduce_once(r);
-  return true;
+  for (int k = 0; k < 8; k++) out.v.v[k] = t[k];
+  bpmi::sc_reduce_once(out.v);
+  out.ok = 1;
+  return out;
 }
 __device__ __forceinline__ bool sc_from_be(sc &r, const BPtr b) {          // 32 bytes big-endian; false when >= q
 #pragma unroll
@@ -301,14 +297,8 @@ __device__ __forceinline__ sc sc_small(u32 x) {
   for (int i = 0; i < 8; i++) r.v[i] = i ? 0 : x;
   return r;
 }
-// by value: two 8-word arguments and the 8-word result travel in registers (a by-reference version goes through scratch)
-__device__ __noinline__ sc mulq_v(const sc a, const sc b) { sc r; bpmi::sc_mul(r, a, b); return r; }
-__device__ __forceinline__ void mulq(sc &r, const sc &a, const sc &b) { r = mulq_v(a, b); }
-__device__ __forceinline__ void addq(sc &r, const sc &a, const sc &b) { bpmi::sc_add(r, a, b); }
-__device__ __forceinline__ void negq(sc &r, const sc &a) { bpmi::sc_neg(r, a); }
-__device__ __forceinline__ void subq(sc &r, const sc &a, const sc &b) { sc t; bpmi::sc_neg(t, b); bpmi::sc_add(r, a, t); }
-// mod-q arithmetic of the algebra role: 9 x 29-bit limbs (scalar.hpp "sq").  The multiplication is the one out-of-line routine
-// (~270 instructions, ~70 call sites); its operands travel in registers: one struct (9 words) plus nine scalars -- two
+// mod-q arithmetic of the algebra roles: 9 x 29-bit limbs (scalar.hpp "sq").  The multiplication is ONE out-of-line routine
+// (~270 instructions, dozens of call sites); its operands travel in registers: one struct (9 words) plus nine scalars -- two
 // structs would exceed the 16 registers the ABI gives to aggregate arguments and the second would go through scratch.
 __device__ __noinline__ sq mq_v(const sq a, u32 b0, u32 b1, u32 b2, u32 b3, u32 b4, u32 b5, u32 b6, u32 b7, u32 b8) {
   const sq b = {{b0, b1, b2, b3, b4, b5, b6, b7, b8}};
@@ -316,14 +306,12 @@ __device__ __noinline__ sq mq_v(const sq a, u32 b0, u32 b1, u32 b2, u32 b3, u32 
   bpmi::sq_mul(r, a, b);
   return r;
 }
-// inlined: for the per-element loops, whose cell stores would otherwise be waited for at every call boundary
 __device__ __forceinline__ void mq_inl(sq &r, const sq &a, const sq &b) { sq t; bpmi::sq_mul(t, a, b); r = t; }
 __device__ __forceinline__ void mq(sq &r, const sq &a, const sq &b) { r = mq_v(a, b.v[0], b.v[1], b.v[2], b.v[3], b.v[4], b.v[5], b.v[6], b.v[7], b.v[8]); }
 __device__ __forceinline__ sq to_sq(const sc &a) { sq r; bpmi::sq_from_sc(r, a); return r; }
 __device__ __noinline__ sc to_sc(const sq a) { sc r; bpmi::sq_to_sc(r, a); return r; }
 __device__ __forceinline__ void store_canon(u32 *p, const sq &a) { const sc c = to_sc(a); ::store_words8(p, c.v); }
 __device__ __noinline__ sc invq_v(const sc a) { sc r; bpmi::sc_inv(r, a); return r; }        // binary extended Euclid (scalar.hpp)
-__device__ __forceinline__ void invq(sc &r, const sc &a) { r = invq_v(a); }
 
 // ---- items of a '&'-separated transcript, walked front to back ---------------------------------------------------
 struct Walk {
@@ -360,21 +348,30 @@ struct Params {
   const u64 *off;            // P + 1 offsets into the wire buffer (only the lengths are used here)
   const uint8_t *weights;    // P x 4 x 32 bytes, or null: derived from `seed`
   u32 seed[8];               // the 32 seed bytes as big-endian words
-  u32 n, k, m, P, lanes;     // P: proofs of this launch
+  u32 n, k, m, P, lanes;     // P: proofs of this launch; lanes: proofs per wave of k_rp_roles
   int only_role;             // profiling: -1 all roles (product), 0..3 = run only that role (the others report success)
-  u32 Pall;                  // proofs of the whole call (the two status arrays are Pall bytes apart)
+  u32 Pall;                  // proofs of the whole call (the status arrays are Pall bytes apart)
   u64 first;                 // index of proof 0 of this launch inside the whole batch (seed weights depend on it)
   u32 *contrib;              // (5 + 2n) x P cells of 9 limbs, limb-major (see cell_load)
+  u32 *ctx;                  // (2 + 3k + m) x P context slots of 9 limbs, limb-major (role 2 -> k_rp_elements)
   u32 *v_scalars, *pt_scalars;
   uint8_t *status;           // [role * Pall + g] = verdict of a role (1 = passed); points at this launch's proof 0
   unsigned long long *bad;   // atomicMin of the failing proof indices (whole-batch numbering)
 };
+// context slots of one proof (9 loose limbs each)
+#define CTX_BASE_G 0u                          // w4 a prod x_d^-1
+#define CTX_BASE_H 1u                          // w4 b prod x_d
+#define CTX_FG(k_, b_) (2u + (b_))             // x_(k-1-b)^2: factor of index bit b on the gs side
+#define CTX_FH(k_, b_) (2u + (k_) + (b_))      // x_(k-1-b)^-2 y^-(2^b)
+#define CTX_GEO(k_, b_) (2u + 2u * (k_) + (b_))      // (2/y)^(2^b) inside a value block, y^-(2^b) for the block-index bits
+#define CTX_W2Z(k_, j_) (2u + 3u * (k_) + (j_))      // w2 z^(2+j)
+#define CTX_SLOTS(k_, m_) (2u + 3u * (k_) + (m_))
 
-// cell (col, g) = 9 limbs of a loose sq; limb w lives at contrib[(col * 9 + w) * P + g]: every access of a wave is one
+// cell (col, g) = 9 limbs of a loose sq; limb w lives at base[(col * 9 + w) * P + g]: every access of a wave is one
 // coalesced row of dwords
 typedef __attribute__((address_space(1))) u32 gu32;              // known-global pointer: global_load / global_store, not flat
-struct Cells { gu32 *base; size_t P; };                          // base = contrib + g
-__device__ __forceinline__ Cells cells_of(const Params &q, u32 g) { Cells c; c.base = (gu32 *)q.contrib + g; c.P = q.P; return c; }
+struct Cells { gu32 *base; size_t P; };                          // base = array + g
+__device__ __forceinline__ Cells cells_of(u32 *arr, u32 P, u32 g) { Cells c; c.base = (gu32 *)arr + g; c.P = P; return c; }
 __device__ __forceinline__ void cell_load(sq &r, const Cells &c, u32 col) {
   const gu32 *p = c.base + (size_t)col * 9 * c.P;
 #pragma unroll
@@ -388,66 +385,101 @@ __device__ __forceinline__ void cell_store(const Cells &c, u32 col, const sq &a)
 
 // SHA-256(seed || LE64(g) || t) with byte 31 cleared, read little-endian; 0 -> 1   (rp::derive_weight).  The 41-byte message
 // is one padded block, built in place: 8 seed words, g, t and the 0x80 marker, zeros, the bit length 328.
-__device__ __noinline__ void derive_weight(sc &w, const u32 seed[8], u64 g, u32 t) {
-  Sha s;
-  sha_init(s);
+__device__ __forceinline__ sc derive_weight(const u32 seed[8], u64 g, u32 t) {
+  const u32 H0[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+  const H8 d = sha_compress_v(H0[0], H0[1], H0[2], H0[3], H0[4], H0[5], H0[6], H0[7], seed[0], seed[1], seed[2], seed[3], seed[4], seed[5], seed[6], seed[7],
+                              __builtin_bswap32((u32)g), __builtin_bswap32((u32)(g >> 32)), (t << 24) | 0x00800000u, 0, 0, 0, 0, 41u * 8u);
+  sc w;
 #pragma unroll
-  for (int i = 0; i < 8; i++) s.w[i] = seed[i];
-  s.w[8] = __builtin_bswap32((u32)g);
-  s.w[9] = __builtin_bswap32((u32)(g >> 32));
-  s.w[10] = (t << 24) | 0x00800000u;
-#pragma unroll
-  for (int i = 11; i < 15; i++) s.w[i] = 0;
-  s.w[15] = 41u * 8u;
-  sha_compress(s);
-#pragma unroll
-  for (int i = 0; i < 8; i++) w.v[i] = __builtin_bswap32(s.h[i]);       // digest bytes read as a little-endian number
+  for (int i = 0; i < 8; i++) w.v[i] = __builtin_bswap32(d.v[i]);       // digest bytes read as a little-endian number
   w.v[7] &= 0x00FFFFFFu;
   if (bpmi::sc_is_zero(w)) w = sc_small(1);
+  return w;
 }
-
-// ---- one proof, structurally (rp::parse_blob): header, scalars < q, the three transcripts exactly fill the rest
-struct Parsed {
-  sc taux, mu, t_hat, a, b, xs[16];
-  BPtr comp;
-  BPtr ts[3];
-  u32 tl[3], start;
-};
-__device__ __forceinline__ bool parse_proof(Parsed &P, const BPtr blob, u32 blen, u32 k) {
-  const u32 fixed = 6 + 32 * (5 + k) + 33 * (6 + 2 * k) + 2;
-  if (!(blen >= fixed && blob[0] == 'B' && blob[1] == 'P' && blob[2] == 'R' && blob[3] == 'P' && blob[4] == '1' && blob[5] == k)) return false;
-  bool ok = true;
-  ok &= sc_from_be(P.taux, blob + 6);
-  ok &= sc_from_be(P.mu, blob + 38);
-  ok &= sc_from_be(P.t_hat, blob + 70);
-  ok &= sc_from_be(P.a, blob + 102);
-  ok &= sc_from_be(P.b, blob + 134);
-  for (u32 j = 0; j < k; j++) ok &= sc_from_be(P.xs[j], blob + 166 + 32 * j);
-  P.comp = blob + 6 + 32 * (5 + k);
-  u32 o = fixed - 2;
-  P.start = ((u32)blob[o] << 8) | blob[o + 1];
-  o += 2;
-  for (int t = 0; t < 3; t++) {
-    if (!ok || blen < o + 4) return false;
-    P.tl[t] = ((u32)blob[o] << 24) | ((u32)blob[o + 1] << 16) | ((u32)blob[o + 2] << 8) | blob[o + 3];
-    o += 4;
-    if (P.tl[t] > blen || blen - P.tl[t] < o) return false;
-    P.ts[t] = blob + o;
-    o += P.tl[t];
+__device__ __forceinline__ sq weight_of(const Params &q, u32 g, u32 t) {
+  sc ws;
+  if (q.weights) {
+    const uint8_t *src = q.weights + ((size_t)(q.first + g) * 4 + t) * 32;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { const u64 x = ld8_raw(src + 8 * i); ws.v[2 * i] = (u32)x; ws.v[2 * i + 1] = (u32)(x >> 32); }
+    bpmi::sc_reduce_once(ws);
+  } else {
+    ws = derive_weight(q.seed, q.first + g, t);
   }
-  return ok && o == blen;
+  return to_sq(ws);
 }
 
-// ---- roles 0 / 1: the byte-level transcript checks (rp::check_transcripts) --------------------------------------------------
-// part 0: the hash chain of the Protocol-2 transcript (every x_i re-hashed from its prefix); part 1: the range-proof and
-// Protocol-1 transcripts and the text half of Protocol 2 (the L_i / R_i items against the proof's points)
-__device__ __noinline__ bool check_transcripts(const Parsed &P, u32 k, u32 part) {
-  const BPtr comp = P.comp;
+// ---- one proof, structurally (rp::parse_blob): header, the three transcripts exactly fill the rest.  The scalars' ranges are
+// checked by the roles that read them (role 3: taux, mu, t_hat, a, b; role 0: the x_i).
+struct Layout {
+  BPtr blob;
+  u32 comp;            // byte offset of the (6 + 2k) x 33 compressed points
+  u32 ts[3], tl[3];    // byte offsets and lengths of the three transcripts
+  u32 start;
+};
+__device__ __forceinline__ bool parse_layout(Layout &L, const BPtr blob, u32 blen, u32 k) {
+  const u32 fixed = 6 + 32 * (5 + k) + 33 * (6 + 2 * k) + 2;
+  L.blob = blob;
+  if (!(blen >= fixed && blob[0] == 'B' && blob[1] == 'P' && blob[2] == 'R' && blob[3] == 'P' && blob[4] == '1' && blob[5] == k)) return false;
+  L.comp = 6 + 32 * (5 + k);
+  u32 o = fixed - 2;
+  L.start = ((u32)blob[o] << 8) | blob[o + 1];
+  o += 2;
+#pragma unroll
+  for (int t = 0; t < 3; t++) {
+    if (blen < o + 4) return false;
+    const u64 x = ld8(blob + o);
+    L.tl[t] = __builtin_bswap32((u32)x);
+    o += 4;
+    if (L.tl[t] > blen || blen - L.tl[t] < o) return false;
+    L.ts[t] = o;
+    o += L.tl[t];
+  }
+  return o == blen;
+}
+__device__ __forceinline__ BPtr xs_at(const Layout &L, u32 j) { return L.blob + (166 + 32 * j); }
+
+// ---- role 0: the hash chain of the Protocol-2 transcript: per round i the prefix that ends after R_i's '&' is re-hashed and
+// must spell x_i, which must also be the x_i of the proof's scalar section (inner_product_verifier.py:104-125, the hash half)
+__device__ __forceinline__ bool role_hash_chain(const Layout &L, u32 k) {
+  const BPtr ts2 = L.blob + L.ts[2];
+  Walk w;
+  walk_init(w, ts2, L.tl[2]);
+  for (u32 j = 0; j < L.start && w.have; j++) walk_next(w, walk_end(w));
+  Sha run;
+  sha_init(run);
+  sha_push_byte(run, '1');
+  u32 hashed = 0;
   bool ok = true;
-  if (part == 1) {
+  for (u32 i = 0; i < k; i++) {
+    if (!w.have) return false;
+    walk_next(w, walk_end(w));                                     // L_i and R_i: compared with the proof's points by role 1
+    if (!w.have) return false;
+    walk_next(w, walk_end(w));
+    if (!w.have) return false;
+    const u32 upto = w.pos;                                        // prefix incl. the '&' after R_i
+    sha_feed(run, ts2 + hashed, upto - hashed);
+    hashed = upto;
+    sc h, xi;
+    mod_hash_q(h, run, ts2, upto);
+    const u32 e = walk_end(w);
+    const Dec d = parse_decimal(w.p + w.pos, e - w.pos);
+    ok = sc_from_be(xi, xs_at(L, i));                              // the scalar section's x_i, < q
+    if (!(ok && d.ok && sc_eq(d.v, h) && sc_eq(d.v, xi))) return false;
+    walk_next(w, e);
+  }
+  return true;
+}
+
+// ---- role 1: the range-proof and Protocol-1 transcripts and the text half of Protocol 2 (rangeproof_verifier.py:42-53,
+// inner_product_verifier.py:31-43, :104-125)
+__device__ __forceinline__ bool role_text_checks(const Layout &L, u32 k) {
+  const BPtr comp = L.blob + L.comp;
+  bool ok = true;
+  {
     const BPtr T1 = comp, T2 = comp + 33, A = comp + 66, S = comp + 99;
     Walk w;
-    walk_init(w, P.ts[0], P.tl[0]);
+    walk_init(w, L.blob + L.ts[0], L.tl[0]);
     u32 e = walk_end(w);                                             // item 0: not checked
     walk_next(w, e);
     for (u32 j = 1; j < 8 && ok; j++) {
@@ -455,35 +487,36 @@ __device__ __noinline__ bool check_transcripts(const Parsed &P, u32 k, u32 part)
       e = walk_end(w);
       const BPtr ip = w.p + w.pos;
       const u32 il = e - w.pos;
-      sc num;
       if (j == 1) ok = point_item_equals(A, ip, il);
       else if (j == 2) ok = point_item_equals(S, ip, il);
       else if (j == 5) ok = point_item_equals(T1, ip, il);
       else if (j == 6) ok = point_item_equals(T2, ip, il);
-      else ok = parse_decimal(num, ip, il);                           // y, z, x: read by the algebra role
+      else ok = parse_decimal(ip, il).ok != 0;                       // y, z, x: read by the algebra roles
       walk_next(w, e);
     }
     if (!ok) return false;
   }
-  if (part == 1) {                                                   // Protocol 1: item 1 = str(mod_hash(item 0 + "&"))
+  {                                                                  // Protocol 1: item 1 = str(mod_hash(item 0 + "&"))
+    const BPtr ts1 = L.blob + L.ts[1];
     Walk w;
-    walk_init(w, P.ts[1], P.tl[1]);
+    walk_init(w, ts1, L.tl[1]);
     u32 e = walk_end(w);
     walk_next(w, e);
     if (!w.have) return false;
     Sha s;
     sha_init(s);
-    sha_byte(s, '1');
-    sha_update(s, P.ts[1], w.pos);
-    sc h, x_ip;
-    mod_hash_q(h, s, P.ts[1], w.pos);
+    sha_push_byte(s, '1');
+    sha_feed(s, ts1, w.pos);
+    sc h;
+    mod_hash_q(h, s, ts1, w.pos);
     e = walk_end(w);
-    if (!(parse_decimal(x_ip, w.p + w.pos, e - w.pos) && sc_eq(x_ip, h))) return false;
+    const Dec d = parse_decimal(w.p + w.pos, e - w.pos);
+    if (!(d.ok && sc_eq(d.v, h))) return false;
   }
-  if (part == 1) {                                                   // Protocol 2, the text half: items s+3i, s+3i+1 are base64(L_i), base64(R_i)
+  {                                                                  // Protocol 2, the text half: items s+3i, s+3i+1 are base64(L_i), base64(R_i)
     Walk w;
-    walk_init(w, P.ts[2], P.tl[2]);
-    for (u32 j = 0; j < P.start && w.have; j++) walk_next(w, walk_end(w));
+    walk_init(w, L.blob + L.ts[2], L.tl[2]);
+    for (u32 j = 0; j < L.start && w.have; j++) walk_next(w, walk_end(w));
     const BPtr Ls = comp + 33 * 6, Rs = Ls + 33 * k;
     for (u32 i = 0; i < k; i++) {
       if (!w.have) return false;
@@ -495,121 +528,42 @@ __device__ __noinline__ bool check_transcripts(const Parsed &P, u32 k, u32 part)
       ok = point_item_equals(Rs + 33 * i, w.p + w.pos, e - w.pos);
       walk_next(w, e);
       if (!ok || !w.have) return false;
-      walk_next(w, walk_end(w));                                     // x_i: part 0
-    }
-  }
-  if (part == 0) {                                                   // Protocol 2: L_i, R_i, x_i per round
-    Walk w;
-    walk_init(w, P.ts[2], P.tl[2]);
-    for (u32 j = 0; j < P.start && w.have; j++) walk_next(w, walk_end(w));
-    Sha run;
-    sha_init(run);
-    sha_byte(run, '1');
-    u32 hashed = 0;
-    for (u32 i = 0; i < k; i++) {
-      if (!w.have) return false;
-      walk_next(w, walk_end(w));                                     // L_i and R_i: compared with the proof's points by part 1
-      if (!w.have) return false;
-      walk_next(w, walk_end(w));
-      if (!w.have) return false;
-      const u32 upto = w.pos;                                        // prefix incl. the '&' after R_i
-      sha_update(run, P.ts[2] + hashed, upto - hashed);
-      hashed = upto;
-      sc h, xi;
-      mod_hash_q(h, run, P.ts[2], upto);
-      const u32 e = walk_end(w);
-      if (!(parse_decimal(xi, w.p + w.pos, e - w.pos) && sc_eq(xi, h) && sc_eq(xi, P.xs[i]))) return false;
-      walk_next(w, e);
+      walk_next(w, walk_end(w));                                     // x_i: role 0
     }
   }
   return true;
 }
 
-// ---- roles 2 / 3: the weighted scalars (rp::accumulate); the challenges are READ here, roles 0 / 1 check where they come from -----
-__device__ __forceinline__ bool read_challenges(const Parsed &P, sc &cx, sc &cy, sc &cz, sc &x_ip) {
+// items 3, 4 (and 7) of the range-proof transcript: y, z (, x); item 1 of the Protocol-1 transcript: x_ip
+__device__ __forceinline__ bool read_yz(const Layout &L, sc &cy, sc &cz, sc *cx) {
   Walk w;
-  walk_init(w, P.ts[0], P.tl[0]);
+  walk_init(w, L.blob + L.ts[0], L.tl[0]);
   for (u32 j = 0; j < 8; j++) {
     if (!w.have) return false;
     const u32 e = walk_end(w);
-    bool ok = true;
-    if (j == 3) ok = parse_decimal(cy, w.p + w.pos, e - w.pos);
-    else if (j == 4) ok = parse_decimal(cz, w.p + w.pos, e - w.pos);
-    else if (j == 7) ok = parse_decimal(cx, w.p + w.pos, e - w.pos);
-    if (!ok) return false;
+    if (j == 3 || j == 4 || (j == 7 && cx)) {
+      const Dec d = parse_decimal(w.p + w.pos, e - w.pos);
+      if (!d.ok) return false;
+      if (j == 3) cy = d.v; else if (j == 4) cz = d.v; else *cx = d.v;
+    }
+    if (j == 4 && !cx) return true;
     walk_next(w, e);
   }
-  walk_init(w, P.ts[1], P.tl[1]);
-  walk_next(w, walk_end(w));
-  if (!w.have) return false;
-  return parse_decimal(x_ip, w.p + w.pos, walk_end(w) - w.pos);
+  return true;
 }
-__device__ __forceinline__ void zero_outputs(const Params &q, u32 g, u32 side) {
-  const sc z = sc_small(0);
-  const sq zq = bpmi::sq_small(0);
-  const Cells C = cells_of(q, g);
-  if (side == 1) {
-    for (u32 c = 0; c < q.n; c++) cell_store(C, 5 + q.n + c, zq);
-    return;
-  }
-  for (u32 c = 0; c < 5 + q.n; c++) cell_store(C, c, zq);
-  for (u32 j = 0; j < q.m; j++) ::store_words8(q.v_scalars + ((size_t)g * q.m + j) * 8, z.v);
-  for (u32 j = 0; j < 6 + 2 * q.k; j++) ::store_words8(q.pt_scalars + ((size_t)g * (6 + 2 * q.k) + j) * 8, z.v);
-}
-// side 0: the gs columns, the five scalar columns and the per-proof point scalars; side 1: the hs columns.  Both sides start
-// from the same challenges, inverses and weights (recomputed: ~35 % of a side) and write disjoint outputs.
-__device__ __noinline__ bool weighted_scalars(const Params &q, u32 g, const Parsed &P, u32 side) {
+
+// ---- role 2: the inversion and what hangs off it.  Montgomery's trick inside the lane: prefix products of (x_1 .. x_k, y) (kept
+// in LDS: k + 1 slots of 9 limbs per lane, the one indexed array of this file), ONE inversion (binary Euclid stripping all
+// trailing zero bits per step, branch-free, ~195 steps), then the backward pass, which hands out x_t^-1 for t = k-1 .. 0, i.e.
+// for the index bits b = 0 .. k-1 in ascending order -- exactly the order in which the y^-(2^b) and (2/y)^(2^b) squaring
+// chains grow, so every table entry is produced in registers and stored once:
+//   FG[b]  = x_(k-1-b)^2                      gs side: s_i = base_g * prod over set bits b of i of FG[b]      (stored by role 3)
+//   FH[b]  = x_(k-1-b)^-2 y^-(2^b)            hs side: w4 b s_i^-1 y^-i = base_h * prod over set bits of FH[b]
+//   GEO[b] = (2/y)^(2^b) for b < log2(bits), y^-(2^b) above: w2 z^(2+j) 2^(i % bits) y^-i = W2Z[j] * prod over set bits of GEO[b]
+//            (W2Z[j] = w2 z^(2+j): role 3)
+// and the scalar of R_t: -w4 x_t^-2.
+__device__ __forceinline__ bool role_inverse_tables(const Params &q, u32 g, const Layout &L) {
   const u32 n = q.n, k = q.k, m = q.m;
-  const Cells C = cells_of(q, g);
-  sc cxs, cys, czs, xips;
-  if (!read_challenges(P, cxs, cys, czs, xips)) return false;
-  const sq cx = to_sq(cxs), cy = to_sq(cys), cz = to_sq(czs), x_ip = to_sq(xips);
-  // inverses of x_1 .. x_k and y: one inversion per proof (Montgomery's trick inside the lane)
-  sq xs[16], xinv[16], yinv;
-  {
-    sq pre[17], run = bpmi::sq_small(1);
-    bool nonzero = !bpmi::sc_is_zero(cys);                 // a zero challenge cannot come out of mod_hash
-    for (u32 t = 0; t < k; t++) { nonzero &= !bpmi::sc_is_zero(P.xs[t]); xs[t] = to_sq(P.xs[t]); }
-    if (!nonzero) return false;
-    for (u32 t = 0; t <= k; t++) {
-      pre[t] = run;
-      mq(run, run, t < k ? xs[t] : cy);
-    }
-    sc rinv_c;
-    invq(rinv_c, to_sc(run));
-    sq rinv = to_sq(rinv_c);
-    for (int t = (int)k; t >= 0; t--) {
-      sq iv;
-      mq(iv, rinv, pre[t]);
-      if (t == (int)k) { yinv = iv; mq(rinv, rinv, cy); }
-      else { xinv[t] = iv; mq(rinv, rinv, xs[t]); }
-    }
-  }
-  sq w[4];
-  for (u32 t = 0; t < 4; t++) {
-    if (side == 1 && !(t & 1u)) { w[t] = bpmi::sq_small(0); continue; }       // the hs side uses w2 and w4 only
-    sc ws;
-    if (q.weights) {
-      const uint8_t *src = q.weights + ((size_t)(q.first + g) * 4 + t) * 32;
-#pragma unroll
-      for (int i = 0; i < 4; i++) { const u64 x = ld8_raw(src + 8 * i); ws.v[2 * i] = (u32)x; ws.v[2 * i + 1] = (u32)(x >> 32); }
-      bpmi::sc_reduce_once(ws);
-    } else {
-      derive_weight(ws, q.seed, q.first + g, t);
-    }
-    w[t] = to_sq(ws);
-  }
-  sq t, u;
-  const u32 SG = 5, SH = 5 + n;
-  const u32 bits = n / m;
-  // The s-vector, element by element in index order.  With every inverse pulled into the starting value,
-  //   s_i = base * prod over the SET bits b of i of g1[k-1-b],
-  // clear bits cost nothing, and stepping from i - 1 to i is ONE multiplication: the carry of the increment sets bit
-  // p = ctz(i) and clears the bits below it, so s_i = lv[d0] * g1[d0] with d0 = k-1-p and lv[d] = the product over the
-  // top d index bits (the levels below d0 all become s_i).  n - 1 multiplications per vector instead of the 2n - 2 of
-  // doubling it in place, every element produced once, in registers, and nothing ever loaded back from the contribution
-  // cells.  lv and g1 live in LDS (2k slots of 9 limbs, limb-major over the 64 lanes: 27 KB per wave at k = 6, four waves
-  // per CU) -- LDS waits are counted apart from the global stores of the cells, so the loop never waits for a store.
   extern __shared__ u32 lds_slots[];
   const u32 lane = threadIdx.x;
   auto slot_store = [&](u32 slot, const sq &x) {
@@ -620,136 +574,161 @@ __device__ __noinline__ bool weighted_scalars(const Params &q, u32 g, const Pars
 #pragma unroll
     for (int wd = 0; wd < 9; wd++) x.v[wd] = lds_slots[(slot * 9 + wd) * 64 + lane];
   };
-  if (side == 1) {
-    // hs columns: sh_i = w4 b s_i^-1 y^-i = (w4 b prod_d x_d) * prod over set bits b of (x_(k-1-b)^-2 y^-(2^b)); then minus
-    // w2 z^(2+j) 2^(i % bits) y^-i
-    sq cur;
-    mq(cur, w[3], to_sq(P.b));
-    {
-      sq yp = yinv;
-      for (int d = (int)k - 1; d >= 0; d--) {
-        mq(cur, cur, xs[d]);
-        mq(t, xinv[d], xinv[d]);
-        mq(t, t, yp);
-        slot_store(k + d, t);
-        mq(yp, yp, yp);
-      }
-    }
-    for (u32 d = 0; d < k; d++) slot_store(d, cur);
-    sq z2, geo, r2;
-    mq(z2, cz, cz);
-    bpmi::sq_add(r2, yinv, yinv);                                     // 2 / y
-    sq yn_inv = bpmi::sq_small(1);                                    // y^-bits, square and multiply
-    for (int i = 31 - __clz(bits); i >= 0; i--) {
-      mq(yn_inv, yn_inv, yn_inv);
-      if ((bits >> i) & 1u) mq(yn_inv, yn_inv, yinv);
-    }
-    sq blk = bpmi::sq_small(1), zp = z2;                              // zp = z^(2 + j)
-    for (u32 i = 0, e = 0; i < n; i++) {
-      if (e == 0) {                                                   // a new value block: w2 z^(2+j) y^-(bits j)
-        mq(geo, w[1], zp);
-        mq(geo, geo, blk);
-        mq(blk, blk, yn_inv);
-        mq(zp, zp, cz);
-      }
-      if (i) {
-        const u32 d0 = k - 1 - (u32)__builtin_ctz(i);
-        sq f;
-        slot_load(cur, d0);
-        slot_load(f, k + d0);
-        mq_inl(cur, cur, f);
-        for (u32 d = d0 + 1; d < k; d++) slot_store(d, cur);
-      }
-      bpmi::sq_sub(t, cur, geo);
-      cell_store(C, SH + i, t);
-      mq_inl(geo, geo, r2);
-      if (++e == bits) e = 0;
-    }
-    return true;
+  auto load_x = [&](u32 t) { sc v; (void)sc_from_be(v, xs_at(L, t)); return v; };
+  sc cys, czs;
+  if (!read_yz(L, cys, czs, nullptr)) return false;
+  bool nonzero = !bpmi::sc_is_zero(cys);                   // a zero challenge cannot come out of mod_hash
+  const sq cy = to_sq(cys);
+  sq run = bpmi::sq_small(1);
+  for (u32 t = 0; t < k; t++) {
+    const sc xv = load_x(t);
+    nonzero &= !bpmi::sc_is_zero(xv);
+    slot_store(t, run);
+    mq(run, run, to_sq(xv));
   }
-  // side 0 -- gs columns: sg_i = w4 a s_i = (w4 a prod_d x_d^-1) * prod over set bits b of x_(k-1-b)^2
-  const sq pa = to_sq(P.a), pb = to_sq(P.b), t_hat = to_sq(P.t_hat);
-  {
-    sq cur;
-    mq(cur, w[3], pa);
-    for (u32 d = 0; d < k; d++) {
-      mq(cur, cur, xinv[d]);
-      mq(t, xs[d], xs[d]);
-      slot_store(k + d, t);
-    }
-    for (u32 d = 0; d < k; d++) slot_store(d, cur);
-    for (u32 i = 0; i < n; i++) {
-      if (i) {
-        const u32 d0 = k - 1 - (u32)__builtin_ctz(i);
-        sq f;
-        slot_load(cur, d0);
-        slot_load(f, k + d0);
-        mq_inl(cur, cur, f);
-        for (u32 d = d0 + 1; d < k; d++) slot_store(d, cur);
-      }
-      cell_store(C, SG + i, cur);
-    }
-  }
-  sq z2, w2z;
-  mq(z2, cz, cz);
-  mq(w2z, w[1], cz);
-  cell_store(C, 3, w2z);                                              // gs_const
-  bpmi::sq_neg(t, w2z); cell_store(C, 4, t);                          // hs_const
-  {
-    sq zp = z2;                                                       // V_j: -w1 z^(2+j)
-    for (u32 j = 0; j < m; j++) {
-      mq(t, w[0], zp); bpmi::sq_neg(t, t);
-      store_canon(q.v_scalars + ((size_t)g * m + j) * 8, t);
-      mq(zp, zp, cz);
-    }
-  }
-  // sum_{i<n} y^i by doubling; delta = (z - z^2) ysum - (2^bits - 1) sum_{j=1..m} z^(j+2)
-  sq ysum = bpmi::sq_small(1), ypw = cy;
-  const sq one = bpmi::sq_small(1);
-  for (u32 l2 = 1; l2 < n; l2 <<= 1) {
-    bpmi::sq_add(t, one, ypw);
-    mq(ysum, ysum, t);
-    mq(ypw, ypw, ypw);
-  }
-  sq two_n = bpmi::sq_small(1);
-  for (u32 i = 0; i < bits; i++) bpmi::sq_add(two_n, two_n, two_n);   // 2^bits mod q
-  bpmi::sq_sub(two_n, two_n, one);
-  sq delta, zsum = bpmi::sq_small(0), zp;
-  bpmi::sq_sub(t, cz, z2);
-  mq(delta, t, ysum);
-  mq(zp, z2, cz);                                                     // z^3
-  for (u32 j = 1; j <= m; j++) { bpmi::sq_add(zsum, zsum, zp); mq(zp, zp, cz); }
-  mq(t, zsum, two_n);
-  bpmi::sq_sub(delta, delta, t);
-  // c_g: w1 (t_hat - delta); c_h: w1 taux + w2 mu; c_u: -(w2 x_ip t_hat + w3 x_ip)
-  bpmi::sq_sub(t, t_hat, delta); mq(t, t, w[0]); cell_store(C, 0, t);
-  mq(t, w[0], to_sq(P.taux)); mq(u, w[1], to_sq(P.mu)); bpmi::sq_add(t, t, u); cell_store(C, 1, t);
-  mq(t, w[1], x_ip); mq(t, t, t_hat); mq(u, w[2], x_ip); bpmi::sq_add(t, t, u); bpmi::sq_neg(t, t); cell_store(C, 2, t);
-  // per-proof points in wire order: T1: -w1 x | T2: -w1 x^2 | A: -w2 | S: -w2 x | u_new: w3 + w4 a b | P_new: w2 - w4 | Ls | Rs
+  if (!nonzero) return false;
+  const sq prodx = run;                                    // prod x_d
+  slot_store(k, run);
+  mq(run, run, cy);
+  sq rinv = to_sq(invq_v(to_sc(run)));
+  sq yinv, pre;
+  slot_load(pre, k);
+  mq(yinv, rinv, pre);
+  mq(rinv, rinv, cy);                                      // (prod x_d)^-1
+  const sq w4 = weight_of(q, g, 3);
+  sc as, bs;
+  (void)sc_from_be(as, L.blob + 102);                      // a, b: range-checked by role 3
+  (void)sc_from_be(bs, L.blob + 134);
+  const Cells X = cells_of(q.ctx, q.P, g);
+  sq t, u;
+  mq(t, w4, to_sq(as)); mq(t, t, rinv); cell_store(X, CTX_BASE_G, t);
+  mq(t, w4, to_sq(bs)); mq(t, t, prodx); cell_store(X, CTX_BASE_H, t);
+  u32 lb = 0;
+  while ((1u << lb) < n / m) lb++;                         // log2(bits per value)
+  sq yp = yinv, rp;
+  bpmi::sq_add(rp, yinv, yinv);                            // 2 / y
   u32 *op = q.pt_scalars + (size_t)g * (6 + 2 * k) * 8;
-  mq(t, w[0], cx); bpmi::sq_neg(u, t); store_canon(op, u);
-  mq(t, t, cx); bpmi::sq_neg(u, t); store_canon(op + 8, u);
-  bpmi::sq_neg(u, w[1]); store_canon(op + 16, u);
-  mq(t, w[1], cx); bpmi::sq_neg(u, t); store_canon(op + 24, u);
-  mq(t, w[3], pa); mq(t, t, pb); bpmi::sq_add(u, w[2], t); store_canon(op + 32, u);
-  bpmi::sq_sub(u, w[1], w[3]); store_canon(op + 40, u);
-  for (u32 j = 0; j < k; j++) {
-    mq(t, w[3], xs[j]); mq(t, t, xs[j]); bpmi::sq_neg(u, t); store_canon(op + (6 + j) * 8, u);
-    mq(t, w[3], xinv[j]); mq(t, t, xinv[j]); bpmi::sq_neg(u, t); store_canon(op + (6 + k + j) * 8, u);
+  for (u32 b = 0; b < k; b++) {
+    const u32 d = k - 1 - b;
+    const sq xd = to_sq(load_x(d));
+    sq xi;
+    slot_load(pre, d);
+    mq(xi, rinv, pre);                                     // x_d^-1
+    if (d) mq(rinv, rinv, xd);
+    mq(t, xi, xi);                                         // x_d^-2        (FG[b] = x_d^2 needs no inverse: role 3)
+    mq(u, w4, t); bpmi::sq_neg(u, u); store_canon(op + (6 + k + d) * 8, u);
+    mq(t, t, yp); cell_store(X, CTX_FH(k, b), t);
+    cell_store(X, CTX_GEO(k, b), b < lb ? rp : yp);
+    if (b + 1 < k) {
+      mq(yp, yp, yp);
+      if (b + 1 < lb) mq(rp, rp, rp);
+    }
   }
   return true;
 }
 
-// Four waves per group of `lanes` proofs, one per ROLE: 0 the Protocol-2 transcript, 1 the range-proof and Protocol-1
-// transcripts (hashing and byte checks), 2 / 3 the two sides of the algebra.  The roles share nothing but the input -- the
-// challenges a proof CLAIMS are all the algebra needs, and roles 0 / 1 verify the claims -- so they run side by side, a
-// proof's critical path is its longest role instead of their sum, and 2^14 proofs put a full wave on every one of the 1024
-// SIMDs.  status[role * Pall + g] = verdict of a role; a proof whose algebra role fails gets all-zero outputs from it.
+// ---- role 3: everything that needs no inverse (rp::accumulate, the scalar half).  Cells 0..4 of the proof: c_g, c_h, c_u,
+// gs_const, hs_const; the scalars of V_j and of T1, T2, A, S, u_new, P_new, L_j in wire order.
+__device__ __forceinline__ bool role_scalars(const Params &q, u32 g, const Layout &L) {
+  const u32 n = q.n, k = q.k, m = q.m;
+  // operands are loaded (and range-checked) where they are used and weights derived when first needed: few values live at a time
+  sc cxs, cys, czs;
+  if (!read_yz(L, cys, czs, &cxs)) return false;
+  bool ok = true;
+  const Cells C = cells_of(q.contrib, q.P, g), X = cells_of(q.ctx, q.P, g);
+  const u32 bits = n / m;
+  u32 *op = q.pt_scalars + (size_t)g * (6 + 2 * k) * 8;
+  const sq w2 = weight_of(q, g, 1);
+  sq t, u;
+  {
+    const sq w1 = weight_of(q, g, 0), cz = to_sq(czs);
+    sq z2, delta;
+    mq(z2, cz, cz);
+    mq(t, w2, cz);
+    cell_store(C, 3, t);                                              // gs_const: w2 z
+    bpmi::sq_neg(t, t); cell_store(C, 4, t);                          // hs_const
+    {
+      sq zp = z2;                                                     // V_j: -w1 z^(2+j); context W2Z[j] = w2 z^(2+j)
+      for (u32 j = 0; j < m; j++) {
+        mq(t, w1, zp); bpmi::sq_neg(t, t);
+        store_canon(q.v_scalars + ((size_t)g * m + j) * 8, t);
+        mq(t, w2, zp); cell_store(X, CTX_W2Z(k, j), t);
+        mq(zp, zp, cz);
+      }
+    }
+    {
+      // sum_{i<n} y^i by doubling; delta = (z - z^2) ysum - (2^bits - 1) sum_{j=1..m} z^(j+2)
+      sq ysum = bpmi::sq_small(1), ypw = to_sq(cys);
+      const sq one = bpmi::sq_small(1);
+      for (u32 l2 = 1; l2 < n; l2 <<= 1) {
+        bpmi::sq_add(t, one, ypw);
+        mq(ysum, ysum, t);
+        mq(ypw, ypw, ypw);
+      }
+      bpmi::sq_sub(t, cz, z2);
+      mq(delta, t, ysum);
+      sq two_n = bpmi::sq_small(1);
+      for (u32 i = 0; i < bits; i++) bpmi::sq_add(two_n, two_n, two_n);   // 2^bits mod q
+      bpmi::sq_sub(two_n, two_n, one);
+      sq zsum = bpmi::sq_small(0), zp;
+      mq(zp, z2, cz);                                                 // z^3
+      for (u32 j = 1; j <= m; j++) { bpmi::sq_add(zsum, zsum, zp); mq(zp, zp, cz); }
+      mq(t, zsum, two_n);
+      bpmi::sq_sub(delta, delta, t);
+    }
+    sc v;
+    // c_g: w1 (t_hat - delta); c_h: w1 taux + w2 mu
+    ok &= sc_from_be(v, L.blob + 70);
+    bpmi::sq_sub(t, to_sq(v), delta); mq(t, t, w1); cell_store(C, 0, t);
+    ok &= sc_from_be(v, L.blob + 6);
+    mq(t, w1, to_sq(v));
+    ok &= sc_from_be(v, L.blob + 38);
+    mq(u, w2, to_sq(v)); bpmi::sq_add(t, t, u); cell_store(C, 1, t);
+    // per-proof points in wire order: T1: -w1 x | T2: -w1 x^2 | A: -w2 | S: -w2 x | u_new: w3 + w4 a b | P_new: w2 - w4 | Ls | (Rs: role 2)
+    const sq cx = to_sq(cxs);
+    mq(t, w1, cx); bpmi::sq_neg(u, t); store_canon(op, u);
+    mq(t, t, cx); bpmi::sq_neg(u, t); store_canon(op + 8, u);
+    bpmi::sq_neg(u, w2); store_canon(op + 16, u);
+    mq(t, w2, cx); bpmi::sq_neg(u, t); store_canon(op + 24, u);
+  }
+  const sq w3 = weight_of(q, g, 2);
+  {
+    // c_u: -(w2 x_ip t_hat + w3 x_ip) = -(w2 t_hat + w3) x_ip
+    Walk w;
+    walk_init(w, L.blob + L.ts[1], L.tl[1]);
+    walk_next(w, walk_end(w));
+    if (!w.have) return false;
+    const Dec d = parse_decimal(w.p + w.pos, walk_end(w) - w.pos);
+    if (!d.ok) return false;
+    sc v;
+    (void)sc_from_be(v, L.blob + 70);
+    mq(t, w2, to_sq(v)); bpmi::sq_add(t, t, w3); mq(t, t, to_sq(d.v)); bpmi::sq_neg(t, t); cell_store(C, 2, t);
+  }
+  const sq w4 = weight_of(q, g, 3);
+  {
+    sc v;
+    ok &= sc_from_be(v, L.blob + 102);                                // a
+    mq(t, w4, to_sq(v));
+    ok &= sc_from_be(v, L.blob + 134);                                // b
+    mq(t, t, to_sq(v)); bpmi::sq_add(u, w3, t); store_canon(op + 32, u);
+    bpmi::sq_sub(u, w2, w4); store_canon(op + 40, u);
+  }
+  for (u32 j = 0; j < k; j++) {
+    sc xv;
+    (void)sc_from_be(xv, xs_at(L, j));                                // range and origin: role 0
+    const sq xj = to_sq(xv);
+    mq(u, xj, xj); cell_store(X, CTX_FG(k, k - 1 - j), u);            // context: the factor of index bit k-1-j on the gs side
+    mq(t, w4, u); bpmi::sq_neg(u, t); store_canon(op + (6 + j) * 8, u);
+  }
+  return ok;
+}
+
+// Four waves per group of `lanes` proofs, one per ROLE (see the head of the file).  status[role * Pall + g] = verdict of a role.
 #define RP_ROLES 4
 // A wire proof longer than this is invalid (both here and in the host twin): it bounds the transposed array.  A 64-bit proof
 // is 2.6 KB, the largest shape the format allows (k = 16) under 8 KB.
 #define RP_MAX_PROOF_BYTES 32768u
-__global__ void __launch_bounds__(64) k_rp_prepare(Params q) {
+__global__ void __launch_bounds__(64) k_rp_roles(Params q) {
   if (threadIdx.x >= q.lanes) return;
   const u32 role = blockIdx.x & (RP_ROLES - 1);
   const u32 g = (blockIdx.x / RP_ROLES) * q.lanes + threadIdx.x;
@@ -758,17 +737,111 @@ __global__ void __launch_bounds__(64) k_rp_prepare(Params q) {
   BPtr blob;
   blob.base = q.T + g; blob.stride = q.Tstride; blob.off = 0;
   const u64 blen64 = q.off[g + 1] - q.off[g];
-  const u32 blen = (u32)blen64;
-  Parsed P;
-  bool ok = blen64 <= RP_MAX_PROOF_BYTES && parse_proof(P, blob, blen, q.k);
-  if (role < 2) {
-    ok = ok && check_transcripts(P, q.k, role);
-  } else {
-    ok = ok && weighted_scalars(q, g, P, role - 2);
-    if (!ok) zero_outputs(q, g, role - 2);
+  Layout L;
+  bool ok = blen64 <= RP_MAX_PROOF_BYTES && parse_layout(L, blob, (u32)blen64, q.k);
+  if (ok) {
+    if (role == 0) ok = role_hash_chain(L, q.k);
+    else if (role == 1) ok = role_text_checks(L, q.k);
+    else if (role == 2) ok = role_inverse_tables(q, g, L);
+    else ok = role_scalars(q, g, L);
   }
   q.status[(size_t)role * q.Pall + g] = ok ? 1 : 0;
   if (!ok) atomicMin(q.bad, (unsigned long long)(q.first + g));
+}
+
+
+#if defined(BPMI_ROLE_PROBE)
+template <int ROLE> __global__ void __launch_bounds__(64) k_rp_role_probe(Params q) {
+  const u32 g = blockIdx.x * 64 + threadIdx.x;
+  BPtr blob;
+  blob.base = q.T + g; blob.stride = q.Tstride; blob.off = 0;
+  Layout L;
+  bool ok = parse_layout(L, blob, (u32)(q.off[g + 1] - q.off[g]), q.k);
+  if (ok) {
+    if (ROLE == 0) ok = role_hash_chain(L, q.k);
+    else if (ROLE == 1) ok = role_text_checks(L, q.k);
+    else if (ROLE == 2) ok = role_inverse_tables(q, g, L);
+    else ok = role_scalars(q, g, L);
+  }
+  q.status[g] = ok;
+}
+template __global__ void k_rp_role_probe<0>(Params);
+template __global__ void k_rp_role_probe<1>(Params);
+template __global__ void k_rp_role_probe<2>(Params);
+template __global__ void k_rp_role_probe<3>(Params);
+#endif
+
+// ---- the 2n shared-generator contributions.  Block = 64 consecutive proofs at ONE (side, element range): lane = proof, the
+// range is wave-uniform.  value(i) = base * prod over the set bits b of i of F[b]; the range's high bits select factors once
+// (uniform branches), its EL = min(8, bits per value) elements are a binary tree over the low bits:
+//   v0 | v1 = v0 F0 | v2 = v0 F1 | v3 = v2 F0 | v4 = v0 F2 | v5 = v4 F0 | v6 = v4 F1 | v7 = v6 F0          (7 multiplications)
+// side 0 (gs): cell 5 + i = w4 a s_i.  side 1 (hs): cell 5 + n + i = w4 b s_i^-1 y^-i - w2 z^(2+j) 2^(i % bits) y^-i, both
+// progressions walk the same tree.  A proof whose role 2 failed gets zeros (its context is not valid).
+struct ElemGeom { u32 el_log, ranges; };       // elements per lane = 2^el_log; ranges per side = n >> el_log
+__global__ void __launch_bounds__(64) k_rp_elements(Params q, ElemGeom eg) {
+  const u32 n = q.n, k = q.k;
+  const u32 groups = (q.P + 63u) / 64u;
+  const u32 grp = blockIdx.x % groups, rs = blockIdx.x / groups;          // rs = side * ranges + range
+  const u32 side = rs / eg.ranges, range = rs % eg.ranges;
+  const u32 g = grp * 64u + threadIdx.x;
+  if (g >= q.P) return;
+  const u32 i0 = range << eg.el_log, EL = 1u << eg.el_log;
+  const Cells C = cells_of(q.contrib, q.P, g), X = cells_of(q.ctx, q.P, g);
+  const u32 col0 = 5u + side * n + i0;
+  if (!(q.status[(size_t)2 * q.Pall + g] & q.status[(size_t)3 * q.Pall + g])) {          // its context is not valid
+    const sq z = bpmi::sq_small(0);
+    for (u32 e = 0; e < EL; e++) cell_store(C, col0 + e, z);
+    return;
+  }
+  sq f;
+  if (side == 0) {
+    sq a0;
+    cell_load(a0, X, CTX_BASE_G);
+    for (u32 b = eg.el_log; b < k; b++)
+      if ((i0 >> b) & 1u) { cell_load(f, X, CTX_FG(k, b)); mq_inl(a0, a0, f); }
+    sq F0, F1, F2;
+    if (EL > 1) cell_load(F0, X, CTX_FG(k, 0));
+    if (EL > 2) cell_load(F1, X, CTX_FG(k, 1));
+    if (EL > 4) cell_load(F2, X, CTX_FG(k, 2));
+    sq v, a2, a4, a6;
+    cell_store(C, col0, a0);
+    if (EL > 1) { mq_inl(v, a0, F0); cell_store(C, col0 + 1, v); }
+    if (EL > 2) { mq_inl(a2, a0, F1); cell_store(C, col0 + 2, a2); mq_inl(v, a2, F0); cell_store(C, col0 + 3, v); }
+    if (EL > 4) {
+      mq_inl(a4, a0, F2); cell_store(C, col0 + 4, a4);
+      mq_inl(v, a4, F0); cell_store(C, col0 + 5, v);
+      mq_inl(a6, a4, F1); cell_store(C, col0 + 6, a6);
+      mq_inl(v, a6, F0); cell_store(C, col0 + 7, v);
+    }
+    return;
+  }
+  // hs side: two progressions on the same tree
+  const u32 bits = n / q.m;
+  sq a0, b0;
+  cell_load(a0, X, CTX_BASE_H);
+  cell_load(b0, X, CTX_W2Z(k, i0 / bits));
+  for (u32 b = eg.el_log; b < k; b++)
+    if ((i0 >> b) & 1u) {
+      cell_load(f, X, CTX_FH(k, b)); mq_inl(a0, a0, f);
+      cell_load(f, X, CTX_GEO(k, b)); mq_inl(b0, b0, f);
+    }
+  sq F0, F1, F2, G0, G1, G2;
+  if (EL > 1) { cell_load(F0, X, CTX_FH(k, 0)); cell_load(G0, X, CTX_GEO(k, 0)); }
+  if (EL > 2) { cell_load(F1, X, CTX_FH(k, 1)); cell_load(G1, X, CTX_GEO(k, 1)); }
+  if (EL > 4) { cell_load(F2, X, CTX_FH(k, 2)); cell_load(G2, X, CTX_GEO(k, 2)); }
+  sq v, w, d, a2, a4, a6, b2, b4, b6;
+  bpmi::sq_sub(d, a0, b0); cell_store(C, col0, d);
+  if (EL > 1) { mq_inl(v, a0, F0); mq_inl(w, b0, G0); bpmi::sq_sub(d, v, w); cell_store(C, col0 + 1, d); }
+  if (EL > 2) {
+    mq_inl(a2, a0, F1); mq_inl(b2, b0, G1); bpmi::sq_sub(d, a2, b2); cell_store(C, col0 + 2, d);
+    mq_inl(v, a2, F0); mq_inl(w, b2, G0); bpmi::sq_sub(d, v, w); cell_store(C, col0 + 3, d);
+  }
+  if (EL > 4) {
+    mq_inl(a4, a0, F2); mq_inl(b4, b0, G2); bpmi::sq_sub(d, a4, b4); cell_store(C, col0 + 4, d);
+    mq_inl(v, a4, F0); mq_inl(w, b4, G0); bpmi::sq_sub(d, v, w); cell_store(C, col0 + 5, d);
+    mq_inl(a6, a4, F1); mq_inl(b6, b4, G1); bpmi::sq_sub(d, a6, b6); cell_store(C, col0 + 6, d);
+    mq_inl(v, a6, F0); mq_inl(w, b6, G0); bpmi::sq_sub(d, v, w); cell_store(C, col0 + 7, d);
+  }
 }
 
 // T[w * P + g] = bytes [8w, 8w + 8) of proof g for w < W, zero beyond the proof's end (or beyond RP_MAX_PROOF_BYTES).  64 x 64
@@ -828,7 +901,7 @@ __global__ void __launch_bounds__(256) k_rp_colsum(const u32 *__restrict__ contr
     sc sum, cur;
     bpmi::sq_to_sc(sum, total);
     ::load_words8(cur.v, shared + 8ull * col);
-    addq(cur, cur, sum);
+    bpmi::sc_add(cur, cur, sum);
     ::store_words8(shared + 8ull * col, cur.v);
   }
 }

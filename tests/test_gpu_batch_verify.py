@@ -222,3 +222,43 @@ def test_batch_wire_path_native(gp, batch):
         with pytest.raises(Exception, match="Proof invalid"):
             bv.add_wire_native(b["Vs"], blobs[:4] + [bytes(bad)] + blobs[5:], threads=3)
             bv.verify()
+
+
+def test_state_and_merge_carry_device_resident_chunks(gp, batch):
+    """state() of a verifier whose proofs came in through add_wire_native(prepare="device") -- their points and scalars live only
+    in device memory -- exports them, and a second verifier that merges the state accepts / rejects like the first; the offset
+    table is checked against the REAL size of the proof buffer."""
+    from bulletproofs_amd.rangeproofs import BatchRangeVerifier
+    from bulletproofs_amd.rangeproofs.codec import proof_to_bytes
+    b = batch
+    blobs = [proof_to_bytes(pr) for pr in b["proofs"]]
+    bv = BatchRangeVerifier(b["g"], b["h"], b["gs"], b["hs"], b["u"])
+    bv.add_wire_native(b["Vs"], blobs, prepare="device")
+    assert bv._dev_chunks, "the device path must have been taken"
+    st = bv.state()
+    assert st[9] == sum(len(b["Vs"][:1]) + 6 + 2 * blobs[i][5] for i in range(len(blobs)))      # every V, T1, T2, A, S, P', u', L_j, R_j
+    other = BatchRangeVerifier(b["g"], b["h"], b["gs"], b["hs"], b["u"])
+    other.merge(st)
+    other.add(b["Vs"][1], b["proofs"][1])
+    assert other.count == len(blobs) + 1 and other.verify() is True
+    # a wrong commitment inside the exported state is still noticed after the merge
+    Vs_bad = list(b["Vs"])
+    Vs_bad[2] = b["Vs"][3]
+    bv2 = BatchRangeVerifier(b["g"], b["h"], b["gs"], b["hs"], b["u"])
+    bv2.add_wire_native(Vs_bad, blobs, prepare="device")
+    other = BatchRangeVerifier(b["g"], b["h"], b["gs"], b["hs"], b["u"])
+    other.merge(bv2.state())
+    with pytest.raises(Exception, match="Proof invalid"):
+        other.verify()
+    # offsets that end past the buffer: refused before anything is read
+    joined = b"".join(blobs)
+    from itertools import accumulate
+    offs = [0, *accumulate(map(len, blobs))]
+    offs[-1] += 64
+    bv3 = BatchRangeVerifier(b["g"], b["h"], b["gs"], b["hs"], b["u"])
+    with pytest.raises(ValueError):
+        bv3.add_wire_native(b["Vs"], joined, offsets=offs, prepare="device")
+    offs[-1] -= 64
+    offs[3], offs[4] = offs[4], offs[3]                    # not monotone: the native walk of the table refuses it
+    with pytest.raises(Exception):
+        bv3.add_wire_native(b["Vs"], joined, offsets=offs, prepare="device")

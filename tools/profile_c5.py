@@ -45,6 +45,8 @@ if os.environ.get("C5_PINNED"):                         # page-locked receive bu
     wire_off = (ctypes.c_uint64 * len(wire_off))(*wire_off)
 if os.environ.get("C5_LANES"):
     eng.set_option("rp_lanes", int(os.environ["C5_LANES"]))
+if os.environ.get("C5_SERIAL"):                         # point decoding behind the preparation kernels: every stage's time is its own
+    eng.set_option("rp_overlap", 0)
 if os.environ.get("C5_ONLY_ROLE"):
     eng.set_option("rp_only_role", int(os.environ["C5_ONLY_ROLE"]))
 if PREPARE != "host":
