@@ -234,6 +234,22 @@ int bpmi_rp_batch_prepare(uint32_t n_gens, uint32_t values_per_proof, uint64_t n
  * in bulk: the range-proof provers draw 2 n m blinding scalars this way (rangeproof_prover.py:57-60).  Host code. */
 int bpmi_mod_hash_range(const uint8_t *tail, uint64_t tail_len, uint64_t lo, uint64_t hi, int threads, uint8_t *out);
 
+/* The O(n m) scalar algebra of the range-proof provers and verifiers in native HOST code (csrc/rp_algebra_host.hpp; no elliptic-curve
+ * arithmetic, no GPU): vectors of scalars mod q in and out, 32 bytes little-endian each, `threads` host threads.  aL: one byte per
+ * bit (0 / 1); n bits per value, m values (m = 1 and aggregated = 0: the single proof's z^2 2^i terms).
+ *   bpmi_rp_poly_coeffs       t1, t2 of `_get_polynomial_coeffs` (src/rangeproofs/rangeproof_prover.py:93-101,
+ *                             rangeproof_aggreg_prover.py:117-130)
+ *   bpmi_rp_final_vectors     l, r, t_hat of `_final_compute` (:103-112 / :132-146), plus yscale_i = y^-i and
+ *                             hsc_i = (z y^i + zt_i) y^-i: the hs-scalars of P (:78-87 / :95-101) over the UNSCALED generators
+ *   bpmi_rp_verifier_vectors  yscale, hsc as above and ysum = sum_{i < n m} y^i for delta(y, z) (rangeproof_verifier.py:55-99,
+ *                             rangeproof_aggreg_verifier.py:55-108) */
+int bpmi_rp_poly_coeffs(uint32_t n, uint32_t m, int aggregated, const uint8_t *aL, const uint8_t *sL, const uint8_t *sR, const uint8_t y[32],
+                        const uint8_t z[32], int threads, uint8_t t1[32], uint8_t t2[32]);
+int bpmi_rp_final_vectors(uint32_t n, uint32_t m, int aggregated, const uint8_t *aL, const uint8_t *sL, const uint8_t *sR, const uint8_t y[32],
+                          const uint8_t z[32], const uint8_t x[32], int threads, uint8_t *ls, uint8_t *rs, uint8_t t_hat[32], uint8_t *hsc, uint8_t *yscale);
+int bpmi_rp_verifier_vectors(uint32_t n, uint32_t m, int aggregated, const uint8_t y[32], const uint8_t z[32], int threads, uint8_t *hsc, uint8_t *yscale,
+                             uint8_t ysum[32]);
+
 /* The same preparation on the GPU (csrc/rp_batch_kernels.hpp; one lane per proof parses, re-hashes the transcripts and computes
  * the weighted scalars).  `blobs` / `blob_off` / `weights` / `seed` / `shared` are HOST pointers with the meaning above (blobs may be
  * page-locked memory from bpmi_host_alloc: the upload then runs at link speed); the outputs that feed the MSM stay on the device:

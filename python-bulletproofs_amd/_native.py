@@ -53,6 +53,9 @@ SIGNATURES = {
     "bpmi_ipa_export": (_i, [_vp, _cp, _cp, _cp, _cp]),
     "bpmi_rp_batch_prepare": (_i, [ctypes.c_uint32, ctypes.c_uint32, _u64, _vp, _u64, ctypes.c_void_p, _cp, _cp, _i, _cp, _cp, _cp, _cp, ctypes.c_void_p]),
     "bpmi_mod_hash_range": (_i, [_cp, _u64, _u64, _u64, _i, _cp]),
+    "bpmi_rp_poly_coeffs": (_i, [ctypes.c_uint32, ctypes.c_uint32, _i, _cp, _cp, _cp, _cp, _cp, _i, _cp, _cp]),
+    "bpmi_rp_final_vectors": (_i, [ctypes.c_uint32, ctypes.c_uint32, _i, _cp, _cp, _cp, _cp, _cp, _cp, _i, _cp, _cp, _cp, _cp, _cp]),
+    "bpmi_rp_verifier_vectors": (_i, [ctypes.c_uint32, ctypes.c_uint32, _i, _cp, _cp, _i, _cp, _cp, _cp]),
     "bpmi_rp_batch_prepare_dev": (_i, [_vp, ctypes.c_uint32, ctypes.c_uint32, _u64, _vp, _u64, _vp, _cp, _cp, _vp, _vp, _vp, _cp, _vp]),
     "bpmi_host_alloc": (_i, [_vp, ctypes.c_size_t, ctypes.POINTER(_vp)]),
     "bpmi_host_free": (_i, [_vp, _vp]),

@@ -50,6 +50,7 @@ using namespace bpmi;
 #include "host_tail.hpp"
 #include "msm_host.hpp"
 #include "rp_batch_host.hpp"
+#include "rp_algebra_host.hpp"
 #include "rp_batch_kernels.hpp"
 
 // ------------------------------------------------------------------------------------

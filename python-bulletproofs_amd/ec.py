@@ -139,18 +139,68 @@ def pack_points(pts):
 
 class PackedScalars(list):
     """A list of scalars (ints in [0, q)) with its wire form (32 bytes little-endian each) attached -- for vectors that are both
-    computed with on the host and handed to an MSM (the provers' blinding vectors arrive from native code as bytes already)."""
+    computed with on the host and handed to an MSM (the provers' blinding vectors arrive from native code as bytes already).
+    Built `from_bytes`, the integers are only materialised when somebody looks at them (len() and the wire form need none)."""
 
     def __init__(self, es, packed=None):
         super().__init__(es)
         self.packed = packed if packed is not None else b"".join([e.to_bytes(32, "little") for e in self])
+        self._lazy = False
 
     @classmethod
     def from_bytes(cls, raw):
-        return cls([int.from_bytes(raw[i: i + 32], "little") for i in range(0, len(raw), 32)], bytes(raw))
+        self = cls((), bytes(raw))
+        self._lazy = len(self.packed) > 0
+        return self
+
+    def _fill(self):
+        if self._lazy:
+            self._lazy = False
+            raw = self.packed
+            list.extend(self, [int.from_bytes(raw[i: i + 32], "little") for i in range(0, len(raw), 32)])
+
+    def __len__(self):
+        return len(self.packed) // 32 if self._lazy else list.__len__(self)
+
+    def __iter__(self):
+        self._fill()
+        return list.__iter__(self)
+
+    def __getitem__(self, i):
+        self._fill()
+        return list.__getitem__(self, i)
+
+    def __eq__(self, other):
+        self._fill()
+        if isinstance(other, PackedScalars):
+            other._fill()
+        return list.__eq__(self, other)
+
+    def __ne__(self, other):
+        return not self.__eq__(other)
+
+    __hash__ = None
+
+    def __add__(self, other):
+        self._fill()
+        return list(self) + list(other)
+
+    def __radd__(self, other):
+        self._fill()
+        return list(other) + list(self)
+
+    def __contains__(self, v):
+        self._fill()
+        return list.__contains__(self, v)
+
+    def __repr__(self):
+        self._fill()
+        return list.__repr__(self)
 
     @classmethod
     def join(cls, *parts):
+        if any(isinstance(part, PackedScalars) and part._lazy for part in parts):
+            return cls.from_bytes(b"".join(pack_scalars(part) for part in parts))
         es = []
         for part in parts:
             es.extend(part)

@@ -80,6 +80,96 @@ def _mod_hash_ints(lo, hi, digest, q):
 
 
 _BIT_LE = ((0).to_bytes(32, "little"), (1).to_bytes(32, "little"))
+_MINUS1_LE = (secp256k1.q - 1).to_bytes(32, "little")
+_ASCII_BITS = bytes(range(256)).translate(bytes(c & 1 for c in range(256)))      # b"0" / b"1" -> 0 / 1
+
+
+def _threads(count):
+    import os
+    return max(1, min(8, len(os.sched_getaffinity(0)), count // 1024))
+
+
+def _le32(v, q):
+    return (int(v) % q).to_bytes(32, "little")
+
+
+def _native_prove(vs, n, g, h, gs, hs, gammas, u, group, seed, aggregated):
+    """prove() for the curve's own order with the O(n m) algebra in native host code (csrc/rp_algebra_host.hpp:
+    bpmi_rp_poly_coeffs / bpmi_rp_final_vectors) and every vector kept as the bytes the MSMs want -- no Python loop over the
+    n m elements is left.  Same transcript, same proof (tests/test_rp_algebra_cpu.py, the golden tests)."""
+    import ctypes
+    from .. import _native
+    lib = _native.load()
+    q = group.q
+    m = len(vs)
+    nm = n * m
+    thr = _threads(nm)
+    tr = Transcript(seed)
+    # aL: the n low bits of every value, least significant first (:40-47); one byte per bit for the native code
+    bits = b"".join(bin(v.x)[2:].zfill(n)[::-1][:n].encode() for v in vs).translate(_ASCII_BITS)
+    aL = PackedScalars.from_bytes(b"".join(map(_BIT_LE.__getitem__, bits)))
+    aR = PackedScalars.from_bytes(b"".join(map((_MINUS1_LE, _BIT_LE[0]).__getitem__, bits)))
+    alpha = mod_hash(b"alpha" + tr.digest, q).x
+    sL = _mod_hash_ints(0, nm, tr.digest, q)
+    sR = _mod_hash_ints(nm, 2 * nm, tr.digest, q)
+    rho = mod_hash(str(2 * n).encode() + tr.digest, q).x     # sic: 2*n also when aggregated (:61)
+    gs, hs = PackedPoints(gs) if not isinstance(gs, PackedPoints) else gs, PackedPoints(hs) if not isinstance(hs, PackedPoints) else hs
+    base = PackedPoints.join(gs, hs, [h])
+    A, S = PipSECP256k1.multiexp2(base, PackedScalars.join(aL, aR, [alpha]), base, PackedScalars.join(sL, sR, [rho]))
+    tr.add_list_points([A, S])
+    yM = tr.get_modp(q)
+    tr.add_number(yM)
+    zM = tr.get_modp(q)
+    tr.add_number(zM)
+    y, z = yM.x, zM.x
+    yb, zb = _le32(y, q), _le32(z, q)
+    t1b, t2b = ctypes.create_string_buffer(32), ctypes.create_string_buffer(32)
+    if lib.bpmi_rp_poly_coeffs(n, m, 1 if aggregated else 0, bits, sL.packed, sR.packed, yb, zb, thr, t1b, t2b) != 0:
+        raise RuntimeError("bpmi_rp_poly_coeffs failed")
+    t1, t2 = int.from_bytes(t1b.raw, "little"), int.from_bytes(t2b.raw, "little")
+    tau1 = mod_hash(b"tau1" + tr.digest, q).x
+    tau2 = mod_hash(b"tau2" + tr.digest, q).x
+    T1, T2 = PipSECP256k1.multiexp2([g, h], [t1, tau1], [g, h], [t2, tau2])
+    tr.add_list_points([T1, T2])
+    xM = tr.get_modp(q)
+    tr.add_number(xM)
+    x = xM.x
+    ls, rs = ctypes.create_string_buffer(32 * nm), ctypes.create_string_buffer(32 * nm)
+    hsc, ysc, thb = ctypes.create_string_buffer(32 * nm), ctypes.create_string_buffer(32 * nm), ctypes.create_string_buffer(32)
+    if lib.bpmi_rp_final_vectors(n, m, 1 if aggregated else 0, bits, sL.packed, sR.packed, yb, zb, _le32(x, q), thr, ls, rs, thb, hsc, ysc) != 0:
+        raise RuntimeError("bpmi_rp_final_vectors failed")
+    t_hat = int.from_bytes(thb.raw, "little")
+    if aggregated:
+        blind = sum(pow(z, 2 + j, q) * gammas[j].x for j in range(m))
+    else:
+        blind = z * z * gammas.x
+    taux = (tau2 * x * x + tau1 * x + blind) % q
+    mu = (alpha + rho * x) % q
+    yscale = PackedScalars.from_bytes(ysc.raw)
+    P_inner = PipSECP256k1.multiexp(
+        PackedPoints.join(gs, hs, [A, S, h]),
+        PackedScalars.join(PackedScalars.from_bytes(_le32(-z, q) * nm), PackedScalars.from_bytes(hsc.raw), [1, x, (-mu) % q]),
+    )
+    inner = NIProver(gs, hs, u, P_inner, ModP(t_hat, q), PackedScalars.from_bytes(ls.raw), PackedScalars.from_bytes(rs.raw), group,
+                     h_scale=yscale).prove()
+    return Proof(ModP(taux, q), ModP(mu, q), ModP(t_hat, q), T1, T2, A, S, inner, tr.digest)
+
+
+def verifier_vectors(y, z, n, m, aggregated):
+    """(hsc, yscale, ysum): hsc_i = (z y^i + zt_i) y^-i and yscale_i = y^-i as PackedScalars, ysum = sum_{i < n m} y^i -- the
+    O(n m) part of RangeVerifier.verify / AggregRangeVerifier.verify; native for the curve's own order."""
+    q = y.p
+    nm = n * m
+    if q == secp256k1.q and y.x % q:
+        import ctypes
+        from .. import _native
+        hsc, ysc, ysum = ctypes.create_string_buffer(32 * nm), ctypes.create_string_buffer(32 * nm), ctypes.create_string_buffer(32)
+        if _native.load().bpmi_rp_verifier_vectors(n, m, 1 if aggregated else 0, _le32(y.x, q), _le32(z.x, q), _threads(nm), hsc, ysc, ysum) != 0:
+            raise RuntimeError("bpmi_rp_verifier_vectors failed")
+        return PackedScalars.from_bytes(hsc.raw), PackedScalars.from_bytes(ysc.raw), int.from_bytes(ysum.raw, "little")
+    ypow, zt = _powers(y.x, nm, q), _z_terms(z.x, n, m, q, aggregated)
+    yscale = _powers(pow(y.x, -1, q), nm, q)
+    return [(z.x * ypow[i] + zt[i]) * yscale[i] % q for i in range(nm)], yscale, sum(ypow) % q
 
 
 def prove(vs, n, g, h, gs, hs, gammas, u, group, seed, aggregated):
@@ -89,6 +179,8 @@ def prove(vs, n, g, h, gs, hs, gammas, u, group, seed, aggregated):
     a, b -- is reduced there as well, so the results are identical); ModP objects appear
     only where the reference's surface shows them."""
     q = group.q
+    if q == secp256k1.q:
+        return _native_prove(vs, n, g, h, gs, hs, gammas, u, group, seed, aggregated)
     m = len(vs)
     nm = n * m
     tr = Transcript(seed)
@@ -169,17 +261,21 @@ class VerifierBase:
         self.assertThat(items[6] == point_to_b64(proof.T2))
         self.x = ModP(int(items[7]), p)
 
-    def _getP(self, x, y, z, A, S, gs, hsp, n, m=1, aggregated=False, extra_pts=(), extra_sc=(), h_scale=None, terms_only=False):
+    def _getP(self, x, y, z, A, S, gs, hsp, n, m=1, aggregated=False, extra_pts=(), extra_sc=(), h_scale=None, terms_only=False, hsc=None):
         """A + x*S + sum(-z)*gs_i + sum(z*y^i + zt_i)*hsp_i (+ extras) as one MSM.  With
         h_scale = [y^-i] the list `hsp` holds the UNSCALED hs and the factors ride in the
-        scalars."""
+        scalars (hsc: those scalars already computed, see verifier_vectors)."""
         q = y.p
         nm = n * m
-        zi, ypow, zt = z.x, _powers(y.x, nm, q), _z_terms(z.x, n, m, q, aggregated)
-        hsc = [zi * ypow[i] + zt[i] for i in range(nm)]
-        if h_scale is not None:
-            hsc = [v * c % q for v, c in zip(hsc, h_scale)]
-        pts, scs = gs + hsp + [A, S] + list(extra_pts), [-zi] * nm + hsc + [1, x] + list(extra_sc)
+        zi = z.x
+        if hsc is None:
+            ypow, zt = _powers(y.x, nm, q), _z_terms(z.x, n, m, q, aggregated)
+            hsc = [zi * ypow[i] + zt[i] for i in range(nm)]
+            if h_scale is not None:
+                hsc = [v * c % q for v, c in zip(hsc, h_scale)]
+        pts = PackedPoints.join(gs, hsp, [A, S], list(extra_pts))
+        scs = PackedScalars.join(PackedScalars.from_bytes(_le32(-zi, q) * nm) if q == secp256k1.q else [-zi] * nm, hsc,
+                                 [1, x] + list(extra_sc))
         if terms_only:
             return pts, scs
         return PipSECP256k1.multiexp(pts, scs)

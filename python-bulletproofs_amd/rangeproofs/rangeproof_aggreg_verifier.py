@@ -3,7 +3,7 @@ from ..ec import Point, secp256k1
 from ..innerproduct.inner_product_verifier import Verifier1
 from ..pippenger import PipSECP256k1
 from ..utils.utils import ModP
-from .common import Proof, VerifierBase, _powers
+from .common import Proof, VerifierBase, verifier_vectors
 
 CURVE = secp256k1
 
@@ -18,14 +18,14 @@ class AggregRangeVerifier(VerifierBase):
         nm = len(gs)
         m = len(self.Vs)
         n = nm // m
-        ysum = ModP(sum(_powers(y.x, nm, CURVE.q)) % CURVE.q, CURVE.q)
+        hsc, yscale, ysum = verifier_vectors(y, z, n, m, True)          # the O(n m) scalars: native host code
+        ysum = ModP(ysum, CURVE.q)
         delta_yz = (z - z ** 2) * ysum - sum([(z ** (j + 2)) * ModP(2 ** n - 1, CURVE.q) for j in range(1, m + 1)])
         # hsp[i] = y^-i * hs[i] is never materialised: y^-i goes into the MSM scalars
-        yscale = _powers(pow(y.x, -1, CURVE.q), nm, CURVE.q)
         # t_hat*g + taux*h == sum z^(j+2) V_j + delta*g + x*T1 + x^2*T2  (reference :82-89), one MSM == identity
         # ... overlapped with the independent MSM for P (:91-106) on the engine's second lane
         p_pts, p_scs = self._getP(x, y, z, proof.A, proof.S, gs, hs, n, m, aggregated=True,
-                                  extra_pts=[h], extra_sc=[-proof.mu], h_scale=yscale, terms_only=True)
+                                  extra_pts=[h], extra_sc=[-proof.mu], h_scale=yscale, terms_only=True, hsc=hsc)
         check, P_inner = PipSECP256k1.multiexp2(
             [g, h] + list(self.Vs) + [proof.T1, proof.T2],
             [proof.t_hat - delta_yz, proof.taux] + [-(z ** (j + 2)) for j in range(m)] + [-x, -(x ** 2)],

@@ -3,7 +3,7 @@ from ..ec import Point, secp256k1
 from ..innerproduct.inner_product_verifier import Verifier1
 from ..pippenger import PipSECP256k1
 from ..utils.utils import ModP
-from .common import Proof, VerifierBase, _powers
+from .common import Proof, VerifierBase, verifier_vectors
 
 CURVE = secp256k1
 
@@ -16,14 +16,14 @@ class RangeVerifier(VerifierBase):
         self.verify_transcript()
         g, h, gs, hs, x, y, z, proof = self.g, self.h, self.gs, self.hs, self.x, self.y, self.z, self.proof
         n = len(gs)
-        ysum = ModP(sum(_powers(y.x, n, CURVE.q)) % CURVE.q, CURVE.q)
+        hsc, yscale, ysum = verifier_vectors(y, z, n, 1, False)         # the O(n) scalars: native host code
+        ysum = ModP(ysum, CURVE.q)
         delta_yz = (z - z ** 2) * ysum - (z ** 3) * ModP(2 ** n - 1, CURVE.q)
         # hsp[i] = y^-i * hs[i] is never materialised: y^-i goes into the MSM scalars
-        yscale = _powers(pow(y.x, -1, CURVE.q), n, CURVE.q)
         # t_hat*g + taux*h == z^2*V + delta*g + x*T1 + x^2*T2  (reference :73-76) as one MSM == identity,
         # overlapped with the (independent) MSM for P (:78-95) on the engine's second lane
         p_pts, p_scs = self._getP(x, y, z, proof.A, proof.S, gs, hs, n, extra_pts=[h], extra_sc=[-proof.mu], h_scale=yscale,
-                                  terms_only=True)
+                                  terms_only=True, hsc=hsc)
         check, P_inner = PipSECP256k1.multiexp2([g, h, self.V, proof.T1, proof.T2],
                                                 [proof.t_hat - delta_yz, proof.taux, -(z ** 2), -x, -(x ** 2)], p_pts, p_scs)
         self.assertThat(check == Point.IDENTITY_ELEMENT)

@@ -47,6 +47,32 @@ def gpu_points(eng, n, seed):
     return eng.ec_mul_batch_bytes(G64 * n, rand_scalars(n, seed), n)
 
 
+def test_c2_msm_2e16_equals_the_reference_run(gp):
+    """BASELINE config C2, bit-exact against src/pippenger ITSELF: the inputs and the result of one run of the reference's
+    unmodified multiexp at n = 2^16 (tests/golden/multiexp_big.json, 740 s of the reference's subset-table schedule), through
+    the call surface (PipSECP256k1.multiexp) and through the C-ABI with the default window choice and with the small-window
+    path of the sort."""
+    from conftest import load_golden
+    from helpers import P, scal
+    g = load_golden("multiexp_big.json")
+    n = g["n"]
+    assert n == 1 << 16
+    pts, es = gens(n, bytes.fromhex(g["seed_points"])), [e.x for e in scal(n, bytes.fromhex(g["seed_scalars"]))]
+    want = P(g["result"])
+    pb, sb = cbind.pack_points(pts), cbind.pack_scalars(es)
+    eng = gp.engine()
+    out = eng.msm_bytes(pb, sb, n)
+    assert (int.from_bytes(out[:32], "little"), int.from_bytes(out[32:], "little")) == (want.x, want.y)
+    try:
+        eng.set_option("window_bits", 9)                      # the global-atomic sort path
+        assert eng.msm_bytes(pb, sb, n) == out
+    finally:
+        eng.set_option("window_bits", 0)
+    from bulletproofs_amd.pippenger import PipSECP256k1
+    got = PipSECP256k1.multiexp(gp.to_gpu_list(pts), es)
+    assert (got.x, got.y) == (want.x, want.y)
+
+
 def test_c2_headline_msm_2e20_equals_c_oracle(gp):
     eng = gp.engine()
     n = 1 << 20

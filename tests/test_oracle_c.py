@@ -61,3 +61,13 @@ def test_c_point_and_scalar_ops():
     xi = pow(x, -1, Q)
     assert cbind.sc_fold(a, b, x, xi) == [(x * u + xi * v) % Q for u, v in zip(a, b)]
     assert cbind.sc_dot([Q - 1] * 9, [Q - 1] * 9) == 9 % Q
+
+
+def test_c_msm_matches_the_reference_run_at_config_c2_size():
+    """ONE run of the reference's own multiexp at n = 2^16 (BASELINE config C2; 23.7 M group operations, 740 s and ~11 GB of subset
+    tables here: tests/golden/make_golden.py multiexp_big) pins the plain-C oracle at that size; the GPU suite compares the engine
+    with the same vector (tests/test_gpu_configs.py::test_c2_msm_2e16_equals_the_reference_run)."""
+    g = load_golden("multiexp_big.json")
+    n = g["n"]
+    gs, es = gens(n, bytes.fromhex(g["seed_points"])), scal(n, bytes.fromhex(g["seed_scalars"]))
+    assert cbind.msm(gs, es) == P(g["result"])
