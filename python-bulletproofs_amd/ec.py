@@ -144,8 +144,8 @@ class PackedScalars(list):
 
     def __init__(self, es, packed=None):
         super().__init__(es)
-        self.packed = packed if packed is not None else b"".join([e.to_bytes(32, "little") for e in self])
         self._lazy = False
+        self.packed = packed if packed is not None else b"".join([e.to_bytes(32, "little") for e in self])
 
     @classmethod
     def from_bytes(cls, raw):
