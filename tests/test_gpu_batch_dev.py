@@ -429,3 +429,63 @@ def test_c_program_verifies_a_batch_through_the_abi_only(eng, tmp_path):
     write(swapped, blobs, [b["Vs"][1], b["Vs"][0]] + b["Vs"][2:])
     r = subprocess.run([exe, swapped], capture_output=True, text=True, timeout=300)
     assert r.returncode == 1 and "INVALID" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("n", [8, 64])
+def test_device_scalars_equal_the_oracles_verifier_quantities(eng, n):
+    """The DIRECT link (no host twin in between): for fixed weights w1..w4 per proof, every per-proof scalar and every shared
+    coefficient the GPU preparation produces equals the combination of the quantities the reference's verifiers compute, taken
+    from the oracle's restatement of them -- delta(y, z) and the hs-scalars of P (rangeproof_verifier.py:55-99), the s-vector of
+    Verifier2.get_ss (inner_product_verifier.py:91-102), x_j^2 and x_j^-2 (:140-143), x_ip (:44-58):
+        V: -w1 z^2 | T1: -w1 x | T2: -w1 x^2 | A: -w2 | S: -w2 x | u': w3 + w4 a b | P': w2 - w4 | L_j: -w4 x_j^2 | R_j: -w4 x_j^-2
+        g: w1 (t_hat - delta) | h: w1 taux + w2 mu | u: -(w2 t_hat + w3) x_ip | gs_i: w2 z + w4 a s_i
+        hs_i: w4 b s_i^-1 y^-i - w2 (z y^i + z^2 2^i) y^-i"""
+    from oracle import bp_ref as R
+    from oracle import cbind
+    from helpers import gens
+    gs, hs = gens(n, b"dgs"), gens(n, b"dhs")
+    g, h, u = (R.elliptic_hash(s) for s in (b"dg", b"dh", b"du"))
+    rnd = random.Random(99 + n)
+    count = 5
+    proofs, blobs = [], []
+    from test_batch_verify_cpu import convert_proof
+    for k in range(count):
+        v = R.Zq(rnd.randrange(2 ** n), Q)
+        gamma = R.mod_hash(b"dg%d" % k, Q)
+        pr = R.range_prove(v, n, g, h, gs, hs, gamma, u, seed=b"ds%d" % k, multiexp=cbind.msm)
+        proofs.append(pr)
+        blobs.append(proof_to_bytes(convert_proof(pr)))
+    ws = [[rnd.randrange(1, Q) for _ in range(4)] for _ in range(count)]
+    weights = b"".join(w.to_bytes(32, "little") for row in ws for w in row)
+    rc, bad, v_sc, p_sc, shared, _ = dev_prepare(eng, n, 1, blobs, weights, None)
+    assert rc == 0 and bad == -1
+    k = n.bit_length() - 1
+    per = 6 + 2 * k
+    le = lambda raw, i: int.from_bytes(raw[32 * i: 32 * i + 32], "little")
+    want_shared = [0] * (5 + 2 * n)
+    for j, (pr, (w1, w2, w3, w4)) in enumerate(zip(proofs, ws)):
+        x, y, z = (c.x for c in R._range_transcript(pr))
+        ip = pr.innerProof
+        p2 = ip.proof2
+        x_ip = int(ip.transcript.split(b"&")[1])
+        a, b = p2.a.x, p2.b.x
+        xs = [c.x for c in p2.xs]
+        ss = [s.x for s in R.get_ss(p2.xs, n)]                                   # Verifier2.get_ss
+        ypow = [pow(y, i, Q) for i in range(n)]
+        delta = ((z - z * z) * sum(ypow) - pow(z, 3, Q) * (2 ** n - 1)) % Q      # as range_verify_generic computes it
+        yinv = pow(y, -1, Q)
+        want_p = [-w1 * x, -w1 * x * x, -w2, -w2 * x, w3 + w4 * a * b, w2 - w4] + [-w4 * c * c for c in xs] + \
+                 [-w4 * pow(c, -2, Q) for c in xs]
+        assert le(v_sc, j) == (-w1 * z * z) % Q, "V scalar"
+        assert [le(p_sc, j * per + t) for t in range(per)] == [v % Q for v in want_p], "point scalars of proof %d" % j
+        want_shared[0] += w1 * (pr.t_hat.x - delta)
+        want_shared[1] += w1 * pr.taux.x + w2 * pr.mu.x
+        want_shared[2] -= (w2 * pr.t_hat.x + w3) * x_ip
+        want_shared[3] += w2 * z
+        want_shared[4] -= w2 * z
+        for i in range(n):
+            want_shared[5 + i] += w4 * a * ss[i]
+            # the hs-scalar of P over hsp_i = y^-i hs_i is z y^i + z^2 2^i (R._zpow_term); E2 carries it with weight -w2 (the +w2 z
+            # part sits in the hs_const cell), E4 carries b s_i^-1 with weight w4, both over the unscaled hs_i
+            want_shared[5 + n + i] += (w4 * b * pow(ss[i], -1, Q) - w2 * R._zpow_term(R.Zq(z, Q), i, n).x) * pow(yinv, i, Q)
+    assert [le(shared, i) for i in range(5 + 2 * n)] == [v % Q for v in want_shared], "shared coefficients"

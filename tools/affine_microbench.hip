@@ -81,6 +81,11 @@ __global__ void __launch_bounds__(256) k_affine(const u32 *__restrict__ pts, u32
     load_pt(P1, pts, pidx(t, j, 0, npts));
     load_pt(P2, pts, pidx(t, j, 1, npts));
     fe dx; fe_sub(dx, P2.x, P1.x);                    // magnitude 3
+    // x1 == x2 (the same point drawn twice, or a point and its negative: the doubling / identity cases of the group law) must not
+    // enter the product -- one zero would wipe out the inverses of the whole batch.  A real kernel routes such a pair to the
+    // exceptional-case path; here it is left out of the batch (its output is not used; round 2's version of this file did not
+    // do this and 16 such pairs among the 16 M poisoned B results each: the "!! differ" lines of r02's output).
+    if (fe_is_zero(dx)) fe_set_one(dx);
 #pragma unroll
     for (int k = 0; k < 9; k++) scratch[((u64)j * nthreads + t) * 9 + k] = pref.v[k];      // prefix BEFORE element j
     fe_mul(pref, pref, dx);
@@ -96,6 +101,7 @@ __global__ void __launch_bounds__(256) k_affine(const u32 *__restrict__ pts, u32
     for (int k = 0; k < 9; k++) pj.v[k] = scratch[((u64)j * nthreads + t) * 9 + k];
     fe dx, dxinv, lam, ny, t1, x3, y3;
     fe_sub(dx, P2.x, P1.x);
+    if (fe_is_zero(dx)) fe_set_one(dx);               // as in the forward pass
     fe_mul(dxinv, inv, pj);                           // 1 / dx_j
     fe_mul(inv, inv, dx);                             // inverse of the shorter prefix
     fe_sub(t1, P2.y, P1.y);                           // magnitude 3
@@ -108,6 +114,51 @@ __global__ void __launch_bounds__(256) k_affine(const u32 *__restrict__ pts, u32
     fe_sub(t1, P1.x, x3);                             // x1 - x3 + 2p
     fe_neg(ny, P1.y);
     fe_mul_add(y3, lam, t1, ny);                      // y3 = lam (x1 - x3) - y1
+#pragma unroll
+    for (int k = 0; k < 9; k++) { out[((u64)j * nthreads + t) * 18 + k] = x3.v[k]; out[((u64)j * nthreads + t) * 18 + 9 + k] = y3.v[k]; }
+  }
+}
+
+// the same with the prefix products in LDS instead of a global scratch column: 64-thread blocks, B x 64 x 36 B of LDS per block
+// (B = 32: 73.7 KB, two blocks = two waves per CU -- the occupancy an LDS-resident batch of a useful size allows)
+__global__ void __launch_bounds__(64) k_affine_lds(const u32 *__restrict__ pts, u32 npts, u32 B, u32 nthreads, u32 *__restrict__ out) {
+  extern __shared__ u32 lds[];
+  const u32 t = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x;
+  if (t >= nthreads) return;
+  fe pref; fe_set_one(pref);
+  for (u32 j = 0; j < B; j++) {
+    affine P1, P2;
+    load_pt(P1, pts, pidx(t, j, 0, npts));
+    load_pt(P2, pts, pidx(t, j, 1, npts));
+    fe dx; fe_sub(dx, P2.x, P1.x);
+    if (fe_is_zero(dx)) fe_set_one(dx);
+#pragma unroll
+    for (int k = 0; k < 9; k++) lds[(j * 9 + k) * 64 + lane] = pref.v[k];
+    fe_mul(pref, pref, dx);
+  }
+  fe inv; fe_inv(inv, pref);
+  for (int j = (int)B - 1; j >= 0; j--) {
+    affine P1, P2;
+    load_pt(P1, pts, pidx(t, (u32)j, 0, npts));
+    load_pt(P2, pts, pidx(t, (u32)j, 1, npts));
+    fe pj;
+#pragma unroll
+    for (int k = 0; k < 9; k++) pj.v[k] = lds[(j * 9 + k) * 64 + lane];
+    fe dx, dxinv, lam, ny, t1, x3, y3;
+    fe_sub(dx, P2.x, P1.x);
+    if (fe_is_zero(dx)) fe_set_one(dx);
+    fe_mul(dxinv, inv, pj);
+    fe_mul(inv, inv, dx);
+    fe_sub(t1, P2.y, P1.y);
+    fe_mul(lam, t1, dxinv);
+    fe_add(t1, P1.x, P2.x);
+    { const u32 b4[9] = BPMI_FE_BIAS4;
+#pragma unroll
+      for (int k = 0; k < 9; k++) ny.v[k] = b4[k] - t1.v[k]; }
+    fe_sqr_add(x3, lam, ny);
+    fe_sub(t1, P1.x, x3);
+    fe_neg(ny, P1.y);
+    fe_mul_add(y3, lam, t1, ny);
 #pragma unroll
     for (int k = 0; k < 9; k++) { out[((u64)j * nthreads + t) * 18 + k] = x3.v[k]; out[((u64)j * nthreads + t) * 18 + 9 + k] = y3.v[k]; }
   }
@@ -218,6 +269,29 @@ int main() {
     printf("affine B=%3u threads=%7u scratch %6.1f MB out %6.1f MB  %8.3f ms  -> %6.2f G additions/s   (5M+1S + inversion/%u; 256 B read, 72 B scratch w+r, 72 B out)\n",
            B, threads, 36.0 * total / 1e6, 72.0 * total / 1e6, ms, total / ms / 1e6, B);
     CK(hipFree(d_out)); CK(hipFree(d_scratch));
+  }
+  // ---- batched affine with the prefix products in LDS
+  const u32 Bl[] = {8, 16, 32, 64};
+  for (u32 B : Bl) {
+    const u32 threads = (u32)(total / B);
+    const size_t lds_bytes = (size_t)B * 9 * 64 * 4;
+    if (lds_bytes > 160 * 1024) continue;
+    CK(hipFuncSetAttribute((const void *)k_affine_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    CK(hipMalloc(&d_out, 72ull * total));
+    double ms = 0;
+    for (int rep = 0; rep < 2; rep++) {
+      CK(hipEventRecord(e0));
+      hipLaunchKernelGGL(k_affine_lds, dim3((threads + 63) / 64), dim3(64), lds_bytes, 0, d_pts, N, B, threads, d_out);
+      CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+      ms = time_ms(e0, e1);
+    }
+    CK(hipMemset(d_sum, 0, 4));
+    hipLaunchKernelGGL(k_check_affine, dim3(8192 / 256), dim3(256), 0, 0, d_pts, N, B, threads, d_out, 8192u, d_sum);
+    CK(hipMemcpy(&bad, d_sum, 4, hipMemcpyDeviceToHost));
+    if (bad) printf("!! LDS B=%u: %u of 8192 sampled results differ from the XYZZ path\n", B, bad);
+    printf("affine-LDS B=%3u threads=%7u LDS %5.1f KB per 64-thread block (%u blocks per CU) %8.3f ms  -> %6.2f G additions/s\n",
+           B, threads, lds_bytes / 1024.0, (unsigned)(160 * 1024 / lds_bytes), ms, total / ms / 1e6);
+    CK(hipFree(d_out));
   }
   return 0;
 }
