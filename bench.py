@@ -448,15 +448,13 @@ def extra_c5(eng, world, rank, dev, log_batch=14, distinct=1024, per_gpu=False):
         return (not failed) and part == bytes(64)
 
     def one_batch(corrupt=False):
-        bv.reset()            # keeps the previous batch's device buffers for this one
         buf = wire_buf
         if corrupt:           # flip one bit inside one proof of this rank's shard: the batch must reject
             bad = bytearray(wire_joined)
             bad[(wire_off[len(blobs_in) // 2] + wire_off[len(blobs_in) // 2 + 1]) // 2] ^= 1
             buf = bytes(bad)
         try:
-            bv.add_wire_native(v_packed, buf, threads=threads, offsets=wire_off_c)
-            part = bv.partial()
+            part = bv.partial_wire(v_packed, buf, offsets=wire_off_c)      # ONE native call: upload, preparation, decoding, MSM
         except Exception as e:
             # "Proof invalid" is a verdict (the batch holds a bad proof); anything else is a defect and is reported as such
             if str(e) != "Proof invalid":
@@ -499,10 +497,8 @@ def extra_c5(eng, world, rank, dev, log_batch=14, distinct=1024, per_gpu=False):
 
     def local_partial(slot):
         bv, buf = slots[slot]
-        bv.reset()
         try:
-            bv.add_wire_native(v_packed, buf, threads=threads, offsets=wire_off_c)
-            return bv.partial()
+            return bv.partial_wire(v_packed, buf, offsets=wire_off_c)
         except Exception as e:
             if str(e) != "Proof invalid":
                 errors.append("%s: %s" % (type(e).__name__, e))
@@ -557,7 +553,7 @@ def extra_c5(eng, world, rank, dev, log_batch=14, distinct=1024, per_gpu=False):
         out_extra["errors"] = sorted(set(errors))[:4]
     return {**out_extra, **{"metric": "range-proof verifies/sec (batched, 64-bit proofs, wire bytes in)", "value": total / elapsed_pipe, "unit": "verifies/s",
             "batch": total, "scaling": "weak (2^%d proofs per GPU)" % log_batch if per_gpu else "strong (one batch of 2^%d split over the ranks)" % log_batch, "seconds_per_batch": elapsed_pipe, "batches_in_flight": inflight, "batch_latency_s": elapsed,
-            "verifies_per_s_one_batch_at_a_time": total / elapsed, "preparation": "device (bpmi_rp_batch_prepare_dev)",
+            "verifies_per_s_one_batch_at_a_time": total / elapsed, "preparation": "device, one native call per batch (bpmi_rp_batch_verify_dev)",
             "accepted": all(oks), "corrupted_batch_rejected": rejected,
             "host_threads_per_rank": threads, "host_cores_usable": usable, "msm_pairs_per_rank": msm_pairs,
             "proves_per_s_one_gpu": distinct / t_prove,

@@ -73,8 +73,12 @@ int bpmi_sync(bpmi_ctx *ctx);
  *                  before the first enqueue of a burst; default 0)
  *   "rp_lanes"     bpmi_rp_batch_prepare_dev: proofs per 64-lane wave (power of two; 0 = 64, the fastest measured)
  *   "rp_only_role" profiling only: 0..3 runs just that role of the preparation kernel (Protocol-2 hash chain | the other
- *                  transcript checks | gs side of the algebra | hs side); such a call reports proof 0 as bad
+ *                  transcript checks | inversion and factor tables | inverse-free scalars); such a call reports proof 0 as bad
  *                  whatever it saw, so it can never pass for a verification; -1 (default) all four
+ *   "rp_overlap"   0 (measurements only): the point decoding runs BEHIND the preparation kernels instead of beside them, and the
+ *                  upload is not sliced: every kernel's duration is then its own; 1 default
+ *   "glv"          1: the bucket pipeline runs on GLV-split scalars (2n pairs of 128-bit scalars, half the windows).  An
+ *                  experiment that lost (profiles/r03_glv_msm_on_off.txt); default 0 = off
  *   "rp_rows"      bpmi_rp_batch_prepare_dev: proofs per kernel launch (0 = as many as fit ~256 MB of scratch cells)
  *   "ipa_big_m"    base length from which the IPA prover folds its generators 16-way at
  *                  once instead of deferring the fold into the MSM scalars (default 2^18) */
@@ -262,6 +266,20 @@ int bpmi_rp_verifier_vectors(uint32_t n, uint32_t m, int aggregated, const uint8
 int bpmi_rp_batch_prepare_dev(bpmi_ctx *ctx, uint32_t n_gens, uint32_t values_per_proof, uint64_t n_proofs, const uint8_t *blobs, uint64_t blobs_len,
                               const uint64_t *blob_off, const uint8_t *weights, const uint8_t *seed, void *d_v_scalars, void *d_pt_scalars, void *d_points,
                               uint8_t *shared, int64_t *first_bad);
+/* The whole batch verification in ONE call (replaces a loop of RangeVerifier.verify, /root/reference/src/rangeproofs/
+ * rangeproof_verifier.py:55-99 with src/innerproduct/inner_product_verifier.py:44-58, :127-147, over proofs that share their
+ * generators): the preparation above (wire bytes uploaded in slices, the points of a slice decoded while the next slice is on the
+ * link), the shared coefficients folded into the scalars of g, h, u, gs, hs on the device, and the batch's one MSM over
+ * [g h u gs hs | commitments | proof points] -- no host round trip in between.
+ *   v_points  HOST   n_proofs x values_per_proof x 64 B: the commitments, in proof order
+ *   d_gens    DEVICE (3 + 2 n_gens) x 64 B: g, h, u, gs[0..n), hs[0..n)  (uploaded once per verifier)
+ *   d_points / d_scalars  DEVICE scratch for n_proofs (values_per_proof + 6 + 2k) points of 64 B / scalars of 32 B
+ * out = the 64-byte value of the random linear combination: the identity (64 zero bytes) exactly when every equation of every
+ * proof holds (up to the 1/q soundness error of the random weights); ranks that verified disjoint shards fold their values.
+ * *first_bad as for bpmi_rp_batch_prepare_dev; when it is >= 0 `out` means nothing.  At most 2^23 points in the MSM. */
+int bpmi_rp_batch_verify_dev(bpmi_ctx *ctx, uint32_t n_gens, uint32_t values_per_proof, uint64_t n_proofs, const uint8_t *blobs, uint64_t blobs_len,
+                             const uint64_t *blob_off, const uint8_t *weights, const uint8_t *seed, const uint8_t *v_points, const void *d_gens, void *d_points,
+                             void *d_scalars, uint8_t out[64], int64_t *first_bad);
 /* Page-locked host memory (hipHostMalloc) for buffers handed to the library repeatedly, e.g. the receive buffer of wire proofs. */
 int bpmi_host_alloc(bpmi_ctx *ctx, size_t bytes, void **out);
 int bpmi_host_free(bpmi_ctx *ctx, void *p);

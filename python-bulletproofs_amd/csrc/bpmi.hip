@@ -103,6 +103,7 @@ void bpmi_ctx_destroy(bpmi_ctx *ctx) {
   if (ctx->stream1) { (void)hipStreamSynchronize(ctx->stream1); (void)hipStreamDestroy(ctx->stream1); }
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+  for (auto e : ctx->ev_slice) if (e) (void)hipEventDestroy(e);
   for (auto e : ctx->ev_accum) if (e) (void)hipEventDestroy(e);
   if (ctx->ws1) (void)hipFree(ctx->ws1);
   for (auto &pd : ctx->pend) { if (pd.pin) (void)hipHostFree(pd.pin); if (pd.done) (void)hipEventDestroy(pd.done); }
@@ -129,6 +130,7 @@ int bpmi_set_option(bpmi_ctx *ctx, const char *name, int64_t value) {
   if (!strcmp(name, "split")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "split must be 0 or 1"); ctx->opt_split = (int)value; return BPMI_OK; }
   if (!strcmp(name, "async_lanes")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "async_lanes must be 0 or 1"); ctx->opt_async_lanes = (int)value; return BPMI_OK; }
   if (!strcmp(name, "rp_only_role")) { if (value < -1 || value > 3) return fail(ctx, BPMI_E_ARG, "rp_only_role must be in [-1, 3]"); ctx->opt_rp_only_role = (int)value; return BPMI_OK; }
+  if (!strcmp(name, "glv")) { if (value < -1 || value > 1) return fail(ctx, BPMI_E_ARG, "glv must be -1, 0 or 1"); ctx->opt_glv = (int)value; return BPMI_OK; }
   if (!strcmp(name, "rp_overlap")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "rp_overlap must be 0 or 1"); ctx->opt_rp_overlap = (int)value; return BPMI_OK; }
   if (!strcmp(name, "rp_rows")) { if (value < 0) return fail(ctx, BPMI_E_ARG, "rp_rows must be >= 0"); ctx->opt_rp_rows = (int)value; return BPMI_OK; }
   if (!strcmp(name, "rp_lanes")) {
@@ -1069,22 +1071,22 @@ int bpmi_mod_hash_range(const uint8_t *tail, uint64_t tail_len, uint64_t lo, uin
   return BPMI_OK;
 }
 
-// The same preparation on the GPU (rp_batch_kernels.hpp): the wire proofs are uploaded once, one lane per proof parses, hashes and
-// checks them, the weighted scalars are written straight into the caller's device scalar arrays, the proofs' points are decoded
-// where they lie in the blobs into d_points, and only the (5 + 2n) shared coefficients and the verdict come back.
-int bpmi_rp_batch_prepare_dev(bpmi_ctx *ctx, uint32_t n_gens, uint32_t values_per_proof, uint64_t n_proofs, const uint8_t *blobs, uint64_t blobs_len,
-                              const uint64_t *blob_off, const uint8_t *weights, const uint8_t *seed, void *d_v_scalars, void *d_pt_scalars, void *d_points,
-                              uint8_t *shared, int64_t *first_bad) {
-  if (!ctx) return BPMI_E_ARG;
-  if (!blobs || !blob_off || (!weights && !seed) || !d_v_scalars || !d_pt_scalars || !d_points || !shared || !first_bad) return fail(ctx, BPMI_E_ARG, "null argument");
+// The same preparation on the GPU (rp_batch_kernels.hpp): the wire proofs are uploaded (in a few slices, so that the decoding of
+// the points of slice c runs on the second lane while slice c + 1 is still on the link), one lane per proof and role parses,
+// hashes and checks them, the weighted scalars are written straight into the caller's device scalar arrays, the proofs' points
+// are decoded where they lie in the blobs into d_points, and only the (5 + 2n) shared coefficients and the verdict come back.
+struct RpQueued { u32 *d_shared; unsigned long long *d_bad; u32 ncols; };
+#define RP_UPLOAD_SLICES 4
+// queues everything on the ctx's two lanes and returns without waiting; the results stay on the device (d_shared: 5 + 2n
+// scalars of 8 words, *d_bad behind them).  The caller waits for both lanes whatever this returns.
+static int rp_prepare_enqueue(bpmi_ctx *ctx, uint32_t n_gens, uint32_t m, uint64_t n_proofs, const uint8_t *blobs, uint64_t blobs_len, const uint64_t *blob_off,
+                              const uint8_t *weights, const uint8_t *seed, void *d_v_scalars, void *d_pt_scalars, void *d_points, RpQueued &Q) {
   if (n_gens < 2 || (n_gens & (n_gens - 1)) || n_gens > 65536) return fail(ctx, BPMI_E_ARG, "n_gens must be a power of two in [2, 65536]");
-  const uint32_t m = values_per_proof;
   if (m < 1 || n_gens % m) return fail(ctx, BPMI_E_ARG, "values_per_proof must divide n_gens");
   if (n_proofs == 0 || n_proofs > (1ull << 22)) return fail(ctx, BPMI_E_ARG, "n_proofs must be in [1, 2^22]");
   if (blobs_len > (1ull << 32)) return fail(ctx, BPMI_E_ARG, "at most 4 GiB of proofs per call");
   uint32_t k = 0;
   while ((1u << k) < n_gens) k++;
-  *first_bad = -1;
   if (blob_off[0] > blobs_len) return fail(ctx, BPMI_E_ARG, "offset table leaves the buffer");
   uint64_t maxlen = 0;
   for (uint64_t g = 0; g < n_proofs; g++) {
@@ -1104,6 +1106,8 @@ int bpmi_rp_batch_prepare_dev(bpmi_ctx *ctx, uint32_t n_gens, uint32_t values_pe
   if (rc) return rc;
   rc = ensure_pin(ctx, 32 * (size_t)ncols + 64);
   if (rc) return rc;
+  for (int c = 0; c < RP_UPLOAD_SLICES; c++)
+    if (!ctx->ev_slice[c]) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_slice[c], hipEventDisableTiming));
   char *din = (char *)ctx->stage_in;
   // contributions + contexts: at most ~256 MB of cells per launch
   const u32 nslots = CTX_SLOTS(k, m);
@@ -1111,7 +1115,7 @@ int bpmi_rp_batch_prepare_dev(bpmi_ctx *ctx, uint32_t n_gens, uint32_t values_pe
   u32 rows = (u32)std::min<size_t>(P, std::max<size_t>(1, ((size_t)256 << 20) / cell_row));
   if (ctx->opt_rp_rows > 0) rows = std::min<u32>(rows, (u32)ctx->opt_rp_rows);
   const size_t o_ctx = align_up(36 * (size_t)ncols * rows, 256), o_shared = o_ctx + align_up(36 * (size_t)nslots * rows, 256),
-               o_T = o_shared + align_up(out_row + 64, 256), T_bytes = 8 * (size_t)W * P;
+               o_T = o_shared + align_up(2 * out_row + 256, 256), T_bytes = 8 * (size_t)W * P;      // summed columns | verdict | MSM scalars of the shared generators
   const size_t need = o_T + T_bytes + 256;
   if (need > ctx->rp_buf_bytes) {
     if (ctx->rp_buf) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(ctx->rp_buf)); ctx->rp_buf = nullptr; ctx->rp_buf_bytes = 0; }
@@ -1121,82 +1125,151 @@ int bpmi_rp_batch_prepare_dev(bpmi_ctx *ctx, uint32_t n_gens, uint32_t values_pe
   u32 *d_contrib = (u32 *)ctx->rp_buf, *d_ctx = (u32 *)((char *)ctx->rp_buf + o_ctx), *d_shared = (u32 *)((char *)ctx->rp_buf + o_shared);
   u64 *d_T = (u64 *)((char *)ctx->rp_buf + o_T);
   unsigned long long *d_bad = (unsigned long long *)(d_shared + 8 * (size_t)ncols);
-  // Everything from here on is queued on the two lanes; an error in the middle must not return while the second lane is still
-  // writing into the caller's point array: `queue` reports, the code behind it waits for both lanes whatever happened.
-  auto queue = [&]() -> int {
-    HIPCHK(ctx, hipMemcpyAsync(din, blobs, blobs_len, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(din + o_off, blob_off, 8 * ((size_t)P + 1), hipMemcpyHostToDevice, ctx->stream));
-    if (weights) HIPCHK(ctx, hipMemcpyAsync(din + o_w, weights, 128 * (size_t)P, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipMemsetAsync(d_shared, 0, out_row, ctx->stream));
-    HIPCHK(ctx, hipMemsetAsync(d_bad, 0xFF, 8, ctx->stream));
-    // point decoding on the second lane: it reads only the wire bytes, so it runs beside the preparation kernels (option
-    // rp_overlap = 0, measurements only: behind them on the same stream, so that every kernel's duration is its own)
-    auto decode = [&](hipStream_t st) -> int {
-      StageTimer t(ctx, ST_DECOMP, st);
-      const u64 npts = (u64)P * per;
-      hipLaunchKernelGGL(k_ec_decompress_wire, dim3((u32)((npts + 255) / 256)), dim3(256), 0, st, (const uint8_t *)din, (const u64 *)(din + o_off),
-                         k, P, (u64)0, (u32)RP_MAX_PROOF_BYTES, (u32 *)d_points, d_bad);
-      return BPMI_OK;
-    };
-    HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
-    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream1, ctx->ev_fork, 0));
-    if (ctx->opt_rp_overlap) decode(ctx->stream1);
-    HIPCHK(ctx, hipGetLastError());
-    HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->stream1));
+  Q.d_shared = d_shared; Q.d_bad = d_bad; Q.ncols = ncols;
+  HIPCHK(ctx, hipMemcpyAsync(din + o_off, blob_off, 8 * ((size_t)P + 1), hipMemcpyHostToDevice, ctx->stream));
+  if (weights) HIPCHK(ctx, hipMemcpyAsync(din + o_w, weights, 128 * (size_t)P, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(d_shared, 0, out_row, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(d_bad, 0xFF, 8, ctx->stream));
+  // Upload in slices of whole proofs; the point decoding of a slice (second lane; it reads only the wire bytes) starts as soon as the
+  // slice has arrived and runs beside the upload of the next one and, for the last slice, beside the preparation kernels.
+  // Option rp_overlap = 0 (measurements only): one decoding launch BEHIND the preparation kernels on the same stream, so that
+  // every kernel's duration is its own.
+  auto decode = [&](hipStream_t st, u32 g0, u32 g1) {
+    StageTimer t(ctx, ST_DECOMP, st);
+    const u64 npts = (u64)(g1 - g0) * per;
+    hipLaunchKernelGGL(k_ec_decompress_wire, dim3((u32)((npts + 255) / 256)), dim3(256), 0, st, (const uint8_t *)din, (const u64 *)(din + o_off) + g0,
+                       k, g1 - g0, (u64)g0, (u32)RP_MAX_PROOF_BYTES, (u32 *)d_points + 16ull * per * g0, d_bad);
+  };
+  const u32 nsl = (P >= 4096 && ctx->opt_rp_overlap) ? RP_UPLOAD_SLICES : 1;
+  for (u32 c = 0; c < nsl; c++) {
+    const u32 g0 = (u32)((uint64_t)P * c / nsl), g1 = (u32)((uint64_t)P * (c + 1) / nsl);
+    const uint64_t b0 = c == 0 ? 0 : blob_off[g0], b1 = c + 1 == nsl ? blobs_len : blob_off[g1];
+    if (b1 > b0) HIPCHK(ctx, hipMemcpyAsync(din + b0, blobs + b0, b1 - b0, hipMemcpyHostToDevice, ctx->stream));
+    if (ctx->opt_rp_overlap) {
+      HIPCHK(ctx, hipEventRecord(ctx->ev_slice[c], ctx->stream));
+      HIPCHK(ctx, hipStreamWaitEvent(ctx->stream1, ctx->ev_slice[c], 0));
+      decode(ctx->stream1, g0, g1);
+    }
+  }
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->stream1));
+  {
+    StageTimer t(ctx, ST_RPPREP);
+    hipLaunchKernelGGL(rpd::k_rp_transpose, dim3((P + 63) / 64, (W + 63) / 64), dim3(256), 0, ctx->stream, (const uint8_t *)din, (const u64 *)(din + o_off), P, W, d_T);
+  }
+  rpd::Params q;
+  q.Tstride = P;
+  q.weights = weights ? (const uint8_t *)(din + o_w) : nullptr;
+  for (int i = 0; i < 8; i++) q.seed[i] = seed ? ((u32)seed[4 * i] << 24) | ((u32)seed[4 * i + 1] << 16) | ((u32)seed[4 * i + 2] << 8) | seed[4 * i + 3] : 0;
+  q.n = n_gens; q.k = k; q.m = m; q.Pall = P; q.only_role = ctx->opt_rp_only_role;
+  q.contrib = d_contrib;
+  q.ctx = d_ctx;
+  q.bad = d_bad;
+  const size_t lds_bytes = ((size_t)k + 1) * 9 * 64 * sizeof(u32);            // role 2: k + 1 prefix products of 9 limbs per lane
+  u32 lb = 0;
+  while ((1u << lb) < n_gens / m) lb++;
+  rpd::ElemGeom eg;
+  eg.el_log = std::min<u32>(3u, lb);
+  eg.ranges = n_gens >> eg.el_log;
+  for (u32 base = 0; base < P; base += rows) {
+    const u32 cnt = std::min(rows, P - base);
+    u32 lanes = (u32)ctx->opt_rp_lanes;
+    if (!lanes) lanes = 64;
+    q.off = (const u64 *)(din + o_off) + base;
+    q.T = d_T + base;
+    q.P = cnt; q.lanes = lanes; q.first = base;
+    q.v_scalars = (u32 *)d_v_scalars + 8 * (size_t)base * m;
+    q.pt_scalars = (u32 *)d_pt_scalars + 8 * (size_t)base * per;
+    q.status = (uint8_t *)(din + o_st) + base;
     {
       StageTimer t(ctx, ST_RPPREP);
-      hipLaunchKernelGGL(rpd::k_rp_transpose, dim3((P + 63) / 64, (W + 63) / 64), dim3(256), 0, ctx->stream, (const uint8_t *)din, (const u64 *)(din + o_off), P, W, d_T);
+      hipLaunchKernelGGL(rpd::k_rp_roles, dim3(RP_ROLES * ((cnt + lanes - 1) / lanes)), dim3(64), lds_bytes, ctx->stream, q);
     }
-    rpd::Params q;
-    q.Tstride = P;
-    q.weights = weights ? (const uint8_t *)(din + o_w) : nullptr;
-    for (int i = 0; i < 8; i++) q.seed[i] = seed ? ((u32)seed[4 * i] << 24) | ((u32)seed[4 * i + 1] << 16) | ((u32)seed[4 * i + 2] << 8) | seed[4 * i + 3] : 0;
-    q.n = n_gens; q.k = k; q.m = m; q.Pall = P; q.only_role = ctx->opt_rp_only_role;
-    q.contrib = d_contrib;
-    q.ctx = d_ctx;
-    q.bad = d_bad;
-    const size_t lds_bytes = ((size_t)k + 1) * 9 * 64 * sizeof(u32);            // role 2: k + 1 prefix products of 9 limbs per lane
-    u32 lb = 0;
-    while ((1u << lb) < n_gens / m) lb++;
-    rpd::ElemGeom eg;
-    eg.el_log = std::min<u32>(3u, lb);
-    eg.ranges = n_gens >> eg.el_log;
-    for (u32 base = 0; base < P; base += rows) {
-      const u32 cnt = std::min(rows, P - base);
-      u32 lanes = (u32)ctx->opt_rp_lanes;
-      if (!lanes) lanes = 64;
-      q.off = (const u64 *)(din + o_off) + base;
-      q.T = d_T + base;
-      q.P = cnt; q.lanes = lanes; q.first = base;
-      q.v_scalars = (u32 *)d_v_scalars + 8 * (size_t)base * m;
-      q.pt_scalars = (u32 *)d_pt_scalars + 8 * (size_t)base * per;
-      q.status = (uint8_t *)(din + o_st) + base;
-      {
-        StageTimer t(ctx, ST_RPPREP);
-        hipLaunchKernelGGL(rpd::k_rp_roles, dim3(RP_ROLES * ((cnt + lanes - 1) / lanes)), dim3(64), lds_bytes, ctx->stream, q);
-      }
-      {
-        StageTimer t(ctx, ST_RPELEM);
-        hipLaunchKernelGGL(rpd::k_rp_elements, dim3(2 * eg.ranges * ((cnt + 63) / 64)), dim3(64), 0, ctx->stream, q, eg);
-        hipLaunchKernelGGL(rpd::k_rp_colsum, dim3(ncols), dim3(256), 0, ctx->stream, (const u32 *)d_contrib, cnt, d_shared);
-      }
+    {
+      StageTimer t(ctx, ST_RPELEM);
+      hipLaunchKernelGGL(rpd::k_rp_elements, dim3(2 * eg.ranges * ((cnt + 63) / 64)), dim3(64), 0, ctx->stream, q, eg);
+      hipLaunchKernelGGL(rpd::k_rp_colsum, dim3(ncols), dim3(256), 0, ctx->stream, (const u32 *)d_contrib, cnt, d_shared);
     }
-    if (!ctx->opt_rp_overlap) decode(ctx->stream);
-    HIPCHK(ctx, hipGetLastError());
-    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
-    HIPCHK(ctx, hipMemcpyAsync(ctx->pin, d_shared, out_row + 8, hipMemcpyDeviceToHost, ctx->stream));
-    return BPMI_OK;
-  };
-  rc = queue();
-  const hipError_t e0 = hipStreamSynchronize(ctx->stream), e1 = hipStreamSynchronize(ctx->stream1);
+  }
+  if (!ctx->opt_rp_overlap) decode(ctx->stream, 0, P);
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+  return BPMI_OK;
+}
+// both lanes idle again; the first error of (rc, the two waits)
+static int rp_wait_lanes(bpmi_ctx *ctx, int rc) {
+  const hipError_t e0 = hipStreamSynchronize(ctx->stream), e1 = ctx->stream1 ? hipStreamSynchronize(ctx->stream1) : hipSuccess;
   if (rc) return rc;
   HIPCHK(ctx, e0);
   HIPCHK(ctx, e1);
+  return BPMI_OK;
+}
+int bpmi_rp_batch_prepare_dev(bpmi_ctx *ctx, uint32_t n_gens, uint32_t values_per_proof, uint64_t n_proofs, const uint8_t *blobs, uint64_t blobs_len,
+                              const uint64_t *blob_off, const uint8_t *weights, const uint8_t *seed, void *d_v_scalars, void *d_pt_scalars, void *d_points,
+                              uint8_t *shared, int64_t *first_bad) {
+  if (!ctx) return BPMI_E_ARG;
+  if (!blobs || !blob_off || (!weights && !seed) || !d_v_scalars || !d_pt_scalars || !d_points || !shared || !first_bad) return fail(ctx, BPMI_E_ARG, "null argument");
+  *first_bad = -1;
+  RpQueued Q;
+  int rc = rp_prepare_enqueue(ctx, n_gens, values_per_proof, n_proofs, blobs, blobs_len, blob_off, weights, seed, d_v_scalars, d_pt_scalars, d_points, Q);
+  const size_t out_row = rc ? 0 : 32 * (size_t)Q.ncols;
+  if (!rc && hipMemcpyAsync(ctx->pin, Q.d_shared, out_row + 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = fail(ctx, BPMI_E_HIP, "copy of the shared coefficients failed");
+  // an error in the middle must not return while the second lane is still writing into the caller's point array
+  rc = rp_wait_lanes(ctx, rc);
+  if (rc) return rc;
   memcpy(shared, ctx->pin, out_row);
   unsigned long long bad;
   memcpy(&bad, (char *)ctx->pin + out_row, 8);
   *first_bad = bad == ~0ull ? -1 : (int64_t)bad;
   if (ctx->opt_rp_only_role >= 0) *first_bad = 0;        // a profiling run checked part of every proof: it must never read as "all valid"
+  return BPMI_OK;
+}
+
+// The whole batch verification in ONE call: preparation as above, the shared coefficients folded on the device into the scalars of
+// the 3 + 2n shared generators (k_rp_shared_scalars), and the batch's one MSM over [shared generators | commitments | proof
+// points] -- no host round trip between the preparation and the MSM.  out = the 64-byte value of the combination (the identity
+// for a valid batch; a sharded caller folds the ranks' values), *first_bad as above (then `out` means nothing).
+//   v_points  HOST, n_proofs x values_per_proof x 64 B: the commitments, in proof order
+//   d_gens    DEVICE, (3 + 2 n_gens) x 64 B: g, h, u, gs, hs (uploaded once per verifier)
+//   d_points  DEVICE scratch, (n_proofs (values_per_proof + 6 + 2k)) x 64 B;  d_scalars  DEVICE scratch, the same count x 32 B
+int bpmi_rp_batch_verify_dev(bpmi_ctx *ctx, uint32_t n_gens, uint32_t values_per_proof, uint64_t n_proofs, const uint8_t *blobs, uint64_t blobs_len,
+                             const uint64_t *blob_off, const uint8_t *weights, const uint8_t *seed, const uint8_t *v_points, const void *d_gens, void *d_points,
+                             void *d_scalars, uint8_t out[64], int64_t *first_bad) {
+  if (!ctx) return BPMI_E_ARG;
+  if (!blobs || !blob_off || (!weights && !seed) || !v_points || !d_gens || !d_points || !d_scalars || !out || !first_bad) return fail(ctx, BPMI_E_ARG, "null argument");
+  *first_bad = -1;
+  uint32_t k = 0;
+  while ((1u << k) < n_gens) k++;
+  const uint64_t nv = n_proofs * values_per_proof, npts = n_proofs * (6 + 2 * (uint64_t)k);
+  if (3 + 2 * (uint64_t)n_gens + nv + npts > (1ull << 23)) return fail(ctx, BPMI_E_ARG, "at most 2^23 points in the batch's MSM");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  // commitments: the first nv points / scalars of the per-proof arrays
+  HIPCHK(ctx, hipMemcpyAsync(d_points, v_points, 64 * nv, hipMemcpyHostToDevice, ctx->stream));
+  RpQueued Q;
+  int rc = rp_prepare_enqueue(ctx, n_gens, values_per_proof, n_proofs, blobs, blobs_len, blob_off, weights, seed, d_scalars, (char *)d_scalars + 32 * nv,
+                              (char *)d_points + 64 * nv, Q);
+  u32 *d_fin = nullptr;
+  if (!rc) {
+    // scalars of g, h, u, gs_i, hs_i: c_g, c_h, c_u, c_gs[i] + gs_const, c_hs[i] + hs_const -- in place behind the raw sums
+    d_fin = Q.d_shared + 8 * (size_t)Q.ncols + 32;
+    {
+      StageTimer t(ctx, ST_RPELEM);
+      hipLaunchKernelGGL(rpd::k_rp_shared_scalars, dim3((3 + 2 * n_gens + 255) / 256), dim3(256), 0, ctx->stream, (const u32 *)Q.d_shared, n_gens, d_fin);
+    }
+    if (hipMemcpyAsync(ctx->pin, Q.d_bad, 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = fail(ctx, BPMI_E_HIP, "copy of the verdict failed");
+  }
+  if (rc) return rp_wait_lanes(ctx, rc);
+  Segs s = segs_init();
+  s.pts[0] = (const u32 *)d_gens; s.sc[0] = d_fin; s.n[0] = 3 + 2 * n_gens;
+  s.pts[1] = (const u32 *)d_points; s.sc[1] = (const u32 *)d_scalars; s.n[1] = (u32)(nv + npts);
+  s.total = s.n[0] + s.n[1];
+  rc = msm_run(ctx, s, out);                      // waits for the MSM (ctx stream: behind everything queued above)
+  rc = rp_wait_lanes(ctx, rc);
+  if (rc) return rc;
+  unsigned long long bad;
+  memcpy(&bad, ctx->pin, 8);
+  *first_bad = bad == ~0ull ? -1 : (int64_t)bad;
+  if (ctx->opt_rp_only_role >= 0) *first_bad = 0;
   return BPMI_OK;
 }
 // page-locked host memory for buffers that are handed to the library again and again (e.g. the receive buffer of wire proofs:

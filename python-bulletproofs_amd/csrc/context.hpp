@@ -29,6 +29,7 @@ struct bpmi_ctx {
   // throughput-bound stages of the other
   hipStream_t stream1 = nullptr;
   void *ws1 = nullptr; size_t ws1_bytes = 0;
+  hipEvent_t ev_slice[4] = {nullptr, nullptr, nullptr, nullptr};      // batch preparation: upload slice c has arrived
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;      // fork: lane 1 may start; join: lane 1's work is in (batch preparation)
   // software pipeline of the asynchronous MSM pair on two lanes: the accumulate kernel of an MSM waits for the
   // accumulate kernel of the MSM enqueued before it (on the other lane), so the throughput-bound stage always has the
@@ -51,6 +52,7 @@ struct bpmi_ctx {
   int opt_small = 0;    // largest n handled by the one-launch small-MSM kernel (0 = default, -1 = never)
   int opt_fold_wnaf = 1;     // the IPA's 16-way generator fold: width-4 NAF over affine tables of odd multiples (0: plain NAF ladder)
   int opt_rp_only_role = -1; // profiling only: run one role of the batch preparation kernel (the call then reports proof 0 as bad)
+  int opt_glv = 0;           // MSM on GLV-split scalars (an experiment that lost, profiles/r03_glv_msm_on_off.txt): 0 / -1 = never (default), 1 = whenever the bucket pipeline runs
   int opt_rp_overlap = 1;    // batch preparation: point decoding on the second lane beside the preparation kernels (0: behind them; measurements)
   int opt_rp_rows = 0;       // batch preparation: proofs per launch (0 = as many as fit ~256 MB of contribution cells)
   int opt_rp_lanes = 0;      // batch preparation kernel: proofs per wave (0 = chosen from the batch size)

@@ -39,6 +39,13 @@ BPMI_HD void xyzz_from_affine(xyzz &r, const affine &a) {
 }
 
 // 64-byte wire form (x || y, 32-byte little-endian each = 16 u32 words) <-> affine
+// beta: the cube root of unity mod p with lambda (x, y) = (beta x, y) (scalar.hpp, GLV); limbs of
+// 0x7AE96A2B657C07106E64479EAC3434E99CF0497512F58995C1396C28719501EE
+#define BPMI_FE_BETA {0x119501EEu, 0x09CB6143u, 0x1D626570u, 0x0092EA25u, 0x034E99CFu, 0x03CF561Au, 0x1C41B991u, 0x056CAF80u, 0x007AE96Au}
+BPMI_HD void fe_mul_beta(fe &r, const fe &a) {
+  const fe beta = {BPMI_FE_BETA};
+  fe_mul(r, a, beta);
+}
 BPMI_HD void affine_from_words(affine &r, const u32 w[16]) {
   fe_from_words(r.x, w);
   fe_from_words(r.y, w + 8);

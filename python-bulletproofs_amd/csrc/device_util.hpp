@@ -23,6 +23,12 @@ struct Segs {
   // construction.  hlog[s] >= 32: dense (the default, set by segs_init).
   u32 hlog[3];
   u32 phase[3];
+  // GLV (scalar.hpp glv_split; prepared per MSM by k_glv_prepare, csrc/msm_kernels.hpp): when glv_sub is set the MSM runs over
+  // 2 * total VIRTUAL pairs -- virtual pair 2i is (P_i, |k1_i|), 2i + 1 is (lambda P_i, |k2_i|) -- with 128-bit magnitudes
+  // glv_sub[4 v ..] and signs glv_neg[v]; lambda P_i = (beta x_i, y_i), the x coordinates precomputed in glv_bx[8 i ..].
+  const u32 *glv_sub;
+  const unsigned char *glv_neg;
+  const u32 *glv_bx;
 };
 static inline Segs segs_init() {
   Segs s;
@@ -69,6 +75,17 @@ __device__ __forceinline__ const u32 *seg_scalar(const Segs &s, u32 i) {
   if (i < s.n[1]) return s.sc[1] + 8ull * seg_phys(s, 1, i);
   i -= s.n[1];
   return s.sc[2] + 8ull * seg_phys(s, 2, i);
+}
+// the 16 words (x, y) of the point an MSM entry refers to: a logical index, or with GLV a virtual one
+template <bool GLV> __device__ __forceinline__ void load_entry_point(u32 w[16], const Segs &s, u32 idx) {
+  if (GLV) {
+    const u32 i = idx >> 1;
+    const u32 *p = seg_point(s, i);
+    load_words8(w, (idx & 1u) ? s.glv_bx + 8ull * i : p);
+    load_words8(w + 8, p + 8);
+  } else {
+    load_words16(w, seg_point(s, idx));
+  }
 }
 __device__ __forceinline__ void load_affine(affine &P, const u32 *p) {
   u32 w[16];

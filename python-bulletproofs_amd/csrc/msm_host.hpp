@@ -24,6 +24,8 @@ static u32 pick_window_bits(const bpmi_ctx *ctx, uint64_t n) {
 #define SMALL_N_DEFAULT 4096     // tools/tune_msm.py: one-launch kernel against the bucket pipeline
 
 struct MsmWs {
+  u32 *glv_sub, *glv_bx;      // GLV: 2n x 16 B magnitudes, n x 32 B beta x
+  unsigned char *glv_neg;     // GLV: 2n sign bytes
   u32 *dig, *hist, *off, *cursor, *bsum, *sidx, *buckets, *chunk_key, *coarse_hist, *coarse_off, *coarse_cursor;
   unsigned short *dig16;      // path 2: recoded digits, window-major
   unsigned char *negs;        // path 2: 1 = the scalar was replaced by q - s
@@ -33,9 +35,12 @@ struct MsmWs {
   size_t total;
   u32 nscan_blocks, rec0_max;
 };
-static void msm_layout(const MsmGeom &g, MsmWs &w, char *base) {
+static void msm_layout(const MsmGeom &g, MsmWs &w, char *base, bool glv = false) {
   size_t o = 0;
   auto take = [&](size_t bytes) { char *p = base ? base + o : nullptr; o += align_up(bytes, 256); return (u32 *)p; };
+  w.glv_sub = take(glv ? 16ull * g.n : 0);               // g.n = virtual pairs
+  w.glv_bx = take(glv ? 16ull * g.n : 0);
+  w.glv_neg = (unsigned char *)take(glv ? g.n : 0);
   const size_t nW = (size_t)g.n * g.W;
   w.nscan_blocks = (u32)((g.G + SCAN_TILE - 1) / SCAN_TILE);
   w.rec0_max = (u32)(2 * ((nW + g.L - 1) / g.L));
@@ -106,7 +111,8 @@ static DigitJobs digit_jobs_concat(const DigitJobs &a, const DigitJobs &b) {
 // workspace), including the device->pinned-host copy the tail needs, into pending slot `slot`
 // (pinned buffer + completion event); returns without synchronising.
 //   [w0, w0 + wcount): the windows this call handles (wcount = 0: all of them)
-static int msm_enqueue(bpmi_ctx *ctx, int lane, int slot, const Segs &segs, u32 w0 = 0, u32 wcount = 0) {
+static int msm_enqueue(bpmi_ctx *ctx, int lane, int slot, const Segs &segs_in, u32 w0 = 0, u32 wcount = 0) {
+  Segs segs = segs_in;
   const uint64_t n = segs.total;
   bpmi_ctx::PendingMsm &pd = ctx->pend[slot];
   if (pd.active) return fail(ctx, BPMI_E_STATE, "an MSM is still pending in this slot (bpmi_msm_finish it first)");
@@ -117,8 +123,18 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, int slot, const Segs &segs, u32 
   g.n = (u32)n;
   const uint64_t small_max = ctx->opt_small < 0 ? 0 : (ctx->opt_small ? (uint64_t)ctx->opt_small : SMALL_N_DEFAULT);
   const bool small = n <= small_max && ctx->opt_c == 0 && wcount == 0;
+  // GLV (option "glv" = 1; OFF by default): 2n virtual pairs with 128-bit scalars (+ 1 bit of signed-digit carry) instead of n
+  // with 255-bit ones: as many bucket additions, half the windows.  Measured (profiles/r03_glv_msm_on_off.txt) it LOSES at every
+  // size from 2^15: the bucket reduction is bound by the depth of its addition chains, not by the number of windows (0.16 ms
+  // with 9 windows as with 16); a fifth of the 128-bit magnitudes exceed 2^127, so the signed recoding carries into a ninth
+  // window whose entries all land in ONE bucket (the sort's heavy-partition path: 0.09 -> 0.33 ms at 2^20, segmented scan
+  // 0.065 -> 0.14); and an entry's x and y come from two arrays (two 32-byte requests instead of one 64-byte one: accumulate
+  // 0.82 -> 1.02 ms).  Kept behind the option, with its tests, as the record of the experiment.  The sorted entry packs a
+  // 23-bit index, so 2n must fit it.
+  const bool glv = ctx->opt_glv > 0 && !small && wcount == 0 && n >= 2 && 2 * n <= (1ull << 23);
+  if (glv) g.n = (u32)(2 * n);
   g.c = small ? SMALL_C : pick_window_bits(ctx, n);
-  g.W = wcount ? wcount : 255u / g.c + 1u;
+  g.W = wcount ? wcount : (glv ? 128u / g.c + 1u : 255u / g.c + 1u);
   g.w0 = w0;
   g.B = 1u << (g.c - 1);
   g.G = g.W * g.B;
@@ -127,13 +143,18 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, int slot, const Segs &segs, u32 
   g.L = ctx->opt_chunk > 0 ? (u32)ctx->opt_chunk : (n >= (1u << 19) ? (ctx->chain_accum ? 86u : 64u) : (n >= (1u << 18) ? 32u : 16u));
   g.nv = (g.B <= 256u) ? 1u : 4u;                  // partial sums per window handed to the tail
   MsmWs w;
-  msm_layout(g, w, nullptr);
+  msm_layout(g, w, nullptr, glv);
   int rc = ensure_lane(ctx, lane);
   if (rc) return rc;
   rc = ensure_ws_lane(ctx, lane, w.total);
   if (rc) return rc;
-  msm_layout(g, w, (char *)(lane ? ctx->ws1 : ctx->ws));
+  msm_layout(g, w, (char *)(lane ? ctx->ws1 : ctx->ws), glv);
   hipStream_t st = lane_stream(ctx, lane);
+  if (glv) {
+    StageTimer t(ctx, ST_DIGITS, st);
+    hipLaunchKernelGGL(k_glv_prepare, dim3((u32)((n + 255) / 256)), dim3(256), 0, st, segs, (u32)n, w.glv_sub, w.glv_neg, w.glv_bx);
+    segs.glv_sub = w.glv_sub; segs.glv_neg = w.glv_neg; segs.glv_bx = w.glv_bx;
+  }
   TailOffs to;
   to.nv = 1; to.off[0] = to.off[1] = to.off[2] = to.off[3] = 0;
   if (small) {
@@ -155,7 +176,7 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, int slot, const Segs &segs, u32 
     HIPCHK(ctx, hipGetLastError());
     return BPMI_OK;
   }
-  const u32 nblk_n = (u32)std::min<uint64_t>((n + 255) / 256, 8192);
+  const u32 nblk_n = (u32)std::min<uint64_t>(((uint64_t)g.n + 255) / 256, 8192);
   {
     StageTimer t(ctx, ST_MISC, st);
     if (w.P) HIPCHK(ctx, hipMemsetAsync(w.coarse_hist, 0, 4ull * (PART_MAX + 1), st));
@@ -216,8 +237,10 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, int slot, const Segs &segs, u32 
   {
     StageTimer t(ctx, ST_ACCUM, st);
     const u32 nthreads = w.rec0_max / 2;
-    hipLaunchKernelGGL(k_accum_l0, dim3((nthreads + 255) / 256), dim3(256), 0, st, segs, g, w.off, w.chunk_key, w.sidx,
-                       w.buckets, w.rec_key[0], w.rec_pt[0]);
+    if (glv) hipLaunchKernelGGL(k_accum_l0<true>, dim3((nthreads + 255) / 256), dim3(256), 0, st, segs, g, w.off, w.chunk_key, w.sidx,
+                                w.buckets, w.rec_key[0], w.rec_pt[0]);
+    else hipLaunchKernelGGL(k_accum_l0<false>, dim3((nthreads + 255) / 256), dim3(256), 0, st, segs, g, w.off, w.chunk_key, w.sidx,
+                            w.buckets, w.rec_key[0], w.rec_pt[0]);
   }
   if (ctx->chain_accum) { HIPCHK(ctx, hipEventRecord(ctx->ev_accum[lane], st)); ctx->accum_chain_lane = lane; }
   debug_sync(ctx, "ST_ACCUM", st);

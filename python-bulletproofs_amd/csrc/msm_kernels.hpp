@@ -6,7 +6,7 @@
 // MSM kernels
 // ------------------------------------------------------------------------------------
 struct MsmGeom {
-  u32 n;       // pairs
+  u32 n;       // pairs (with GLV: virtual pairs = 2 x the caller's)
   u32 c;       // window bits
   u32 W;       // windows handled by this launch sequence: [w0, w0 + W) of the recoding
   u32 w0;      // first window (> 0 when one MSM is split into window groups on two lanes)
@@ -23,13 +23,25 @@ struct MsmGeom {
 //   (aR, rangeproof_prover.py:43-45) into the single digit -1.
 //   for_each_digit_raw reports the digit's own sign and returns whether the scalar was negated
 //   (final sign = digit sign ^ negated); a digit of magnitude B is never negative.
-template <typename F>
-__device__ __forceinline__ bool for_each_digit_raw(const Segs &segs, const MsmGeom &g, u32 i, F f) {
-  sc s;
+// magnitude (below 2^255) and sign of the scalar behind digit source i: scalar i reduced mod q and folded to s or q - s, or with
+// GLV the 128-bit magnitude and sign of virtual scalar i
+__device__ __forceinline__ bool load_digit_source(sc &s, const Segs &segs, u32 i) {
+  if (segs.glv_sub) {
+    const uint4 t = *reinterpret_cast<const uint4 *>(segs.glv_sub + 4ull * i);
+    s.v[0] = t.x; s.v[1] = t.y; s.v[2] = t.z; s.v[3] = t.w;
+    s.v[4] = s.v[5] = s.v[6] = s.v[7] = 0;
+    return segs.glv_neg[i] != 0;
+  }
   load_words8(s.v, seg_scalar(segs, i));
   sc_reduce_once(s);
   const bool neg = sc_is_high(s);
   if (neg) sc_neg(s, s);
+  return neg;
+}
+template <typename F>
+__device__ __forceinline__ bool for_each_digit_raw(const Segs &segs, const MsmGeom &g, u32 i, F f) {
+  sc s;
+  const bool neg = load_digit_source(s, segs, i);
   u32 carry = 0;
   const u32 mask = (1u << g.c) - 1u;
   const u32 wend = g.w0 + g.W;
@@ -48,10 +60,7 @@ __device__ __forceinline__ bool for_each_digit_raw(const Segs &segs, const MsmGe
 template <typename F>
 __device__ __forceinline__ void for_each_digit(const Segs &segs, const MsmGeom &g, u32 i, F f) {
   sc s;
-  load_words8(s.v, seg_scalar(segs, i));
-  sc_reduce_once(s);
-  const bool neg = sc_is_high(s);
-  if (neg) sc_neg(s, s);
+  const bool neg = load_digit_source(s, segs, i);
   u32 carry = 0;
   const u32 mask = (1u << g.c) - 1u;
   const u32 wend = g.w0 + g.W;
@@ -66,6 +75,31 @@ __device__ __forceinline__ void for_each_digit(const Segs &segs, const MsmGeom &
     else { b = t; sign = 0; carry = 0; }
     if (w >= g.w0) f(w - g.w0, b, b ? (sign ^ (u32)neg) : 0u);      // lower windows only feed the carry
   }
+}
+
+// GLV preparation, one thread per pair: scalar i (mod q) -> |k1|, |k2| and signs (virtual scalars 2i, 2i + 1); x_i -> beta x_i.
+__global__ void __launch_bounds__(256) k_glv_prepare(Segs segs, u32 n, u32 *__restrict__ sub, unsigned char *__restrict__ neg, u32 *__restrict__ bx) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  sc k;
+  load_words8(k.v, seg_scalar(segs, i));
+  sc_reduce_once(k);
+  u32 k1[4], k2[4];
+  bool n1, n2;
+  glv_split(k1, n1, k2, n2, k);
+  uint4 *o = reinterpret_cast<uint4 *>(sub + 8ull * i);
+  o[0] = make_uint4(k1[0], k1[1], k1[2], k1[3]);
+  o[1] = make_uint4(k2[0], k2[1], k2[2], k2[3]);
+  neg[2ull * i] = n1 ? 1 : 0;
+  neg[2ull * i + 1] = n2 ? 1 : 0;
+  u32 w[8];
+  load_words8(w, seg_point(segs, i));
+  fe x, r, c;
+  fe_from_words(x, w);
+  fe_mul_beta(r, x);
+  fe_canon(c, r);
+  fe_to_words(w, c);
+  store_words8(bx + 8ull * i, w);
 }
 
 // ================= sort path 1 (small n, c < 10): global-atomic counting sort ===========
@@ -454,7 +488,7 @@ __global__ void __launch_bounds__(256) k_scatter(MsmGeom g, const u32 *__restric
 }
 
 // ---- level 0: every thread adds exactly L sorted entries --------------------------------
-__global__ void __launch_bounds__(256) k_accum_l0(Segs segs, MsmGeom g, const u32 *__restrict__ off,
+template <bool GLV> __global__ void __launch_bounds__(256) k_accum_l0(Segs segs, MsmGeom g, const u32 *__restrict__ off,
                                                   const u32 *__restrict__ chunk_key, const u32 *__restrict__ sidx,
                                                   u32 *__restrict__ buckets, u32 *__restrict__ rec_key, u32 *__restrict__ rec_pt) {
   const u32 E = off[g.G];
@@ -470,14 +504,14 @@ __global__ void __launch_bounds__(256) k_accum_l0(Segs segs, MsmGeom g, const u3
   // software pipeline: the (index, point) of entry j+1 is in flight while entry j is added
   u32 e_next = sidx[start];
   u32 w_next[16];
-  load_words16(w_next, seg_point(segs, e_next & 0x7FFFFFFFu));
+  load_entry_point<GLV>(w_next, segs, e_next & 0x7FFFFFFFu);
   for (u32 j = (u32)start; j < end; j++) {
     const u32 e = e_next;
     affine P;
     affine_from_words(P, w_next);
     if (j + 1 < end) {
       e_next = sidx[j + 1];
-      load_words16(w_next, seg_point(segs, e_next & 0x7FFFFFFFu));
+      load_entry_point<GLV>(w_next, segs, e_next & 0x7FFFFFFFu);
     }
     if (j == boundary) {               // the run of `cur` ended: flush, move to the next non-empty bucket
       if (first) { rec_key[2 * t] = cur; xyzz_store_g(rec_pt + (2 * t) * XYZZ_WORDS, acc); first = false; }

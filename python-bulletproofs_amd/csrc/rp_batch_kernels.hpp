@@ -906,4 +906,22 @@ __global__ void __launch_bounds__(256) k_rp_colsum(const u32 *__restrict__ contr
   }
 }
 
+// out[0..3 + 2n): the scalars of g, h, u, gs_i, hs_i of the batch's MSM from the 5 + 2n summed columns:
+// c_g, c_h, c_u, c_gs[i] + gs_const, c_hs[i] + hs_const  (BatchRangeVerifier.partial does the same on Python integers)
+__global__ void __launch_bounds__(256) k_rp_shared_scalars(const u32 *__restrict__ shared, u32 n, u32 *__restrict__ out) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 3 + 2 * n) return;
+  sc v;
+  if (i < 3) {
+    ::load_words8(v.v, shared + 8ull * i);
+  } else {
+    const u32 j = i - 3, side = j >= n ? 1u : 0u;
+    sc a, b;
+    ::load_words8(a.v, shared + 8ull * (5 + j));
+    ::load_words8(b.v, shared + 8ull * (3 + side));
+    bpmi::sc_add(v, a, b);
+  }
+  ::store_words8(out + 8ull * i, v.v);
+}
+
 }  // namespace rpd

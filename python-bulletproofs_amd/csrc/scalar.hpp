@@ -229,6 +229,83 @@ BPMI_HD void sc_inv(sc &r, const sc &a) {
   for (int i = 0; i < 8; i++) r.v[i] = x2[i];
 }
 
+
+// ---- GLV decomposition on secp256k1: k = k1 + k2 lambda (mod q) with |k1|, |k2| < 2^128, where lambda (x, y) = (beta x, y) is the
+// curve's efficient endomorphism (lambda^3 = 1 mod q, beta^3 = 1 mod p).  An MSM over n pairs with 256-bit scalars becomes one over
+// 2n pairs with 128-bit scalars -- the same number of bucket additions, HALF the windows: half the buckets to reduce, half the
+// doublings in the tail (csrc/msm_host.hpp).  The result of the MSM is the same group element, so nothing visible changes.
+// Lattice basis (a1, b1), (a2, b2) with a_i + b_i lambda = 0 (mod q); c_i = round(k g_i / 2^384) with g1 = round(2^384 b2 / q),
+// g2 = round(2^384 (-b1) / q) (the constants of the well-known decomposition, e.g. libsecp256k1's scalar_split_lambda);
+//   k1 = k - c1 a1 - c2 a2,   k2 = c1 (-b1) - c2 b2     as INTEGERS: both are small, so 160-bit wrap-around arithmetic suffices.
+// tests/test_csrc_host.py checks k1 + k2 lambda == k (mod q) and the 128-bit bound on random and adversarial scalars.
+#define BPMI_GLV_G1  {0x45DBB031u, 0xE893209Au, 0x71E8CA7Fu, 0x3DAA8A14u, 0x9284EB15u, 0xE86C90E4u, 0xA7D46BCDu, 0x3086D221u}
+#define BPMI_GLV_G2  {0x8AC47F71u, 0x1571B4AEu, 0x9DF506C6u, 0x221208ACu, 0x0ABFE4C4u, 0x6F547FA9u, 0x010E8828u, 0xE4437ED6u}
+#define BPMI_GLV_A1  {0x9284EB15u, 0xE86C90E4u, 0xA7D46BCDu, 0x3086D221u, 0x00000000u}          /* = b2 */
+#define BPMI_GLV_MB1 {0x0ABFE4C3u, 0x6F547FA9u, 0x010E8828u, 0xE4437ED6u, 0x00000000u}          /* = -b1 */
+#define BPMI_GLV_A2  {0x9D44CFD8u, 0x57C1108Du, 0xA8E2F3F6u, 0x14CA50F7u, 0x00000001u}
+// c = round(k g / 2^384): the top 128 bits of the 512-bit product, plus its bit 383
+BPMI_HD void glv_mul_shift384(u32 c[4], const u32 k[8], const u32 g[8]) {
+  u32 t[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) t[i] = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    u64 cy = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) { cy += (u64)k[i] * g[j] + t[i + j]; t[i + j] = (u32)cy; cy >>= 32; }
+    t[i + 8] = (u32)cy;
+  }
+  u64 cy = t[11] >> 31;
+#pragma unroll
+  for (int i = 0; i < 4; i++) { cy += t[12 + i]; c[i] = (u32)cy; cy >>= 32; }
+}
+// r (5 words, mod 2^160) -= a (4 words) * b (5 words)
+BPMI_HD void glv_submul160(u32 r[5], const u32 a[4], const u32 b[5]) {
+  u32 prod[5];
+#pragma unroll
+  for (int i = 0; i < 5; i++) prod[i] = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    u64 cy = 0;
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+      if (i + j < 5) { cy += (u64)a[i] * b[j] + prod[i + j]; prod[i + j] = (u32)cy; cy >>= 32; }
+    }
+  }
+  u32 br = 0;
+#pragma unroll
+  for (int i = 0; i < 5; i++) r[i] = sc_sbb(r[i], prod[i], br);
+}
+// |v| of a 160-bit two's-complement value whose magnitude is known to fit 128 bits; returns the sign
+BPMI_HD bool glv_abs160(u32 m[4], const u32 v[5]) {
+  const bool neg = (v[4] >> 31) != 0;
+  const u32 x = neg ? 0xFFFFFFFFu : 0u;
+  u32 c = neg ? 1u : 0u;
+#pragma unroll
+  for (int i = 0; i < 4; i++) m[i] = sc_adc(v[i] ^ x, 0u, c);
+  return neg;
+}
+// k in [0, q) -> magnitudes (4 words each) and signs of k1, k2
+BPMI_HD void glv_split(u32 k1[4], bool &neg1, u32 k2[4], bool &neg2, const sc &k) {
+  const u32 G1[8] = BPMI_GLV_G1, G2[8] = BPMI_GLV_G2, A1[5] = BPMI_GLV_A1, MB1[5] = BPMI_GLV_MB1, A2[5] = BPMI_GLV_A2;
+  u32 c1[4], c2[4];
+  glv_mul_shift384(c1, k.v, G1);
+  glv_mul_shift384(c2, k.v, G2);
+  u32 v1[5], v2[5];
+#pragma unroll
+  for (int i = 0; i < 5; i++) { v1[i] = k.v[i]; v2[i] = 0; }       // k mod 2^160
+  glv_submul160(v1, c1, A1);
+  glv_submul160(v1, c2, A2);                                        // k1 = k - c1 a1 - c2 a2
+  glv_submul160(v2, c2, A1);                                        // - c2 b2   (b2 = a1)
+  u32 nv[5], z[5] = {0, 0, 0, 0, 0};
+  glv_submul160(z, c1, MB1);                                        // z = - c1 (-b1)
+  u32 br = 0;
+#pragma unroll
+  for (int i = 0; i < 5; i++) nv[i] = sc_sbb(v2[i], z[i], br);      // k2 = c1 (-b1) - c2 b2
+  neg1 = glv_abs160(k1, v1);
+  neg2 = glv_abs160(k2, nv);
+}
+
 // ---- the same field on 9 x 29-bit limbs ("sq"): for code whose time is modular MULTIPLICATIONS (the batch-preparation kernel:
 // ~400 per proof).  On 8 x 32-bit words every partial product needs its carry handled (sc_mul: ~720 instructions on the
 // device, 120 of them multiply-adds); with 29-bit limbs a column of nine 58-bit products fits a 64-bit accumulator, so a

@@ -96,6 +96,11 @@ class BatchRangeVerifier:
             if buf is not None:
                 buf.free()
                 setattr(self, name, None)
+        bufs = getattr(self, "_wire_bufs", None)
+        if bufs is not None:
+            bufs[1].free()
+            bufs[2].free()
+            self._wire_bufs = None
 
     def _chunk_buffers(self, eng, npairs):
         for i, (d_p, d_s) in enumerate(self._spare):
@@ -423,6 +428,91 @@ class BatchRangeVerifier:
             raise
         self._dev_chunks.append((d_pts, d_scs, nv + npts))
         self._absorb_shared(shared.raw, count)
+
+    def partial_wire(self, Vs, blobs, offsets=None):
+        """The 64-byte value of ONE batch of wire proofs, everything in one native call (bpmi_rp_batch_verify_dev): upload in
+        slices with the point decoding beside it, GPU preparation, the shared coefficients folded on the device, one MSM -- no
+        host round trip between the preparation and the MSM and no Python loop over anything.  Stand-alone: nothing is added to
+        this verifier's accumulators (a verifier that also holds proofs added otherwise folds the two values with ec_sum).
+        Vs / blobs / offsets as for add_wire_native (commitments packed, or Points / lists of Points).  Raises
+        Exception("Proof invalid") when a proof fails its byte-level checks or has an invalid point; the MSM's verdict is the
+        returned value (64 zero bytes = valid)."""
+        import ctypes
+        import os
+        from itertools import accumulate
+        if self._msm is not None:
+            raise ValueError("partial_wire needs the default engine (no custom msm)")
+        if offsets is None:
+            count = len(blobs)
+            offsets = [0, *accumulate(map(len, blobs))]
+            joined = b"".join(blobs)
+        else:
+            count = len(offsets) - 1
+            joined = blobs
+            total = joined.nbytes if hasattr(joined, "ptr") else len(joined)
+            if count < 0 or offsets[0] < 0 or (count > 0 and not (0 <= offsets[count] <= total)):
+                raise ValueError("offsets must be non-decreasing positions inside the %d-byte proof buffer" % total)
+        if not count:
+            return _ZERO64
+        k = self.n.bit_length() - 1
+        if isinstance(Vs, (bytes, bytearray, memoryview)):
+            vbytes = bytes(Vs)
+            m = len(vbytes) // (64 * count)
+            if m < 1 or len(vbytes) != 64 * count * m or self.n % m:
+                raise Exception("Proof invalid")
+        else:
+            assert len(Vs) == count
+            aggregated = isinstance(Vs[0], (list, tuple))
+            m = len(Vs[0]) if aggregated else 1
+            if aggregated:
+                if any(len(v) != m for v in Vs) or m < 1 or self.n % m:
+                    raise Exception("Proof invalid")
+                Vs = [V for group in Vs for V in group]
+            vbytes = b"".join([V.to_le64() for V in Vs])
+        weights = seed = None
+        if getattr(self, "_custom_rng", False):
+            weights = b"".join(self._weight().to_bytes(32, "little") for _ in range(4 * count))
+        else:
+            seed = os.urandom(32)
+        offs = offsets if isinstance(offsets, ctypes.Array) else (ctypes.c_uint64 * (count + 1))(*offsets)
+        eng = self._eng()
+        if getattr(self, "_d_shared_pts", None) is None or self._d_shared_pts.engine is not eng:
+            self._d_shared_pts, self._d_shared_scs = eng.upload(self._shared_pts), eng.alloc(max(32 * (3 + 2 * self.n), 16))
+        npairs = count * (m + 6 + 2 * k)
+        bufs = getattr(self, "_wire_bufs", None)
+        if bufs is None or bufs[0] != npairs or bufs[1].engine is not eng:
+            if bufs is not None:
+                bufs[1].free()
+                bufs[2].free()
+            bufs = (npairs, eng.alloc(64 * npairs), eng.alloc(32 * npairs))
+            self._wire_bufs = bufs
+        if isinstance(joined, bytes):
+            src, nbytes = joined, len(joined)
+        elif hasattr(joined, "ptr"):
+            src, nbytes = joined.ptr, joined.nbytes
+        else:
+            nbytes = len(joined)
+            try:
+                src = ctypes.addressof((ctypes.c_char * nbytes).from_buffer(joined))
+            except TypeError:
+                src = bytes(joined)
+        out = ctypes.create_string_buffer(64)
+        bad = ctypes.c_int64(-1)
+        eng._ck(eng.lib.bpmi_rp_batch_verify_dev(eng.ctx, self.n, m, count, src, nbytes, ctypes.cast(offs, ctypes.c_void_p), weights, seed, vbytes,
+                                                 self._d_shared_pts.ptr, bufs[1].ptr, bufs[2].ptr, out, ctypes.cast(ctypes.pointer(bad), ctypes.c_void_p)))
+        if bad.value >= 0:
+            raise Exception("Proof invalid")
+        return out.raw
+
+    def verify_wire(self, Vs, blobs, offsets=None, sharded=None):
+        """True if every proof of this batch of wire proofs is valid; raises Exception("Proof invalid") otherwise (partial_wire +
+        the comparison with the identity; `sharded`: a distributed.ShardedMSM that folds the ranks' values first)."""
+        part = self.partial_wire(Vs, blobs, offsets)
+        if sharded is not None:
+            part = sharded.combine(part)
+        if part != _ZERO64:
+            raise Exception("Proof invalid")
+        return True
 
     def _absorb_shared(self, sh, count):
         vals = [int.from_bytes(sh[32 * i: 32 * i + 32], "little") for i in range(5 + 2 * self.n)]

@@ -52,6 +52,22 @@ void t_fe_raw(int op, const u32 *a, const u32 *b, const u32 *c, const u32 *d, u3
   }
   for (int k = 0; k < 9; k++) out[k] = r.v[k];
 }
+// GLV: k (32 bytes LE, < q) -> |k1|, |k2| (16 bytes LE each) and their signs; beta * x for a field element
+void t_glv_split(const uint8_t *k, uint8_t *k1, uint8_t *k2, int *signs) {
+  sc s;
+  memcpy(s.v, k, 32);
+  u32 a[4], b[4];
+  bool n1, n2;
+  glv_split(a, n1, b, n2, s);
+  memcpy(k1, a, 16); memcpy(k2, b, 16);
+  signs[0] = n1; signs[1] = n2;
+}
+void t_fe_mul_beta(const uint8_t *x, uint8_t *out) {
+  fe a, r;
+  load_fe(a, x);
+  fe_mul_beta(r, a);
+  store_fe(out, r);
+}
 // arithmetic mod q (csrc/scalar.hpp) on canonical 32-byte little-endian values: op 0 mul, 1 add, 2 neg(a), 3 inv(a), 4 half(a),
 // 5 reduce_once(a)
 void t_sc_op(int op, const uint8_t *a, const uint8_t *b, uint8_t *out) {

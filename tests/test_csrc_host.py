@@ -329,3 +329,38 @@ def test_generated_device_bodies_are_current():
     import sys
     r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "gen_field_asm.py"), "--check"])
     assert r.returncode == 0, "run `python tools/gen_field_asm.py` and commit csrc/field_gen.hpp"
+
+
+def test_glv_split_and_beta(shim):
+    """csrc/scalar.hpp glv_split: k = k1 + k2 lambda (mod q) with |k1|, |k2| < 2^128 on random and adversarial scalars (every
+    single-bit value, values around multiples of the lattice constants, 0, 1, q - 1); fe_mul_beta: lambda (x, y) = (beta x, y)."""
+    q, p = secp256k1.q, secp256k1.p
+    lam = 0x5363AD4CC05C30E0A5261C028812645A122E22EA20816678DF02967C1B23BD72
+    beta = 0x7AE96A2B657C07106E64479EAC3434E99CF0497512F58995C1396C28719501EE
+    assert pow(lam, 3, q) == 1 and pow(beta, 3, p) == 1
+    shim.t_glv_split.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]
+    shim.t_fe_mul_beta.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
+    rnd = random.Random(31)
+    a1, mb1 = 0x3086D221A7D46BCDE86C90E49284EB15, 0xE4437ED6010E88286F547FA90ABFE4C3
+    cases = [0, 1, 2, q - 1, q - 2, q // 2, q // 2 + 1, lam, q - lam, (lam * lam) % q, a1, mb1, q - a1, q - mb1]
+    cases += [1 << b for b in range(256)] + [(1 << b) - 1 for b in range(1, 257) if (1 << b) - 1 < q]
+    cases += [(t * a1 + d) % q for t in (1, 7, 1 << 64, (1 << 127) + 3) for d in (-1, 0, 1)]
+    cases += [rnd.randrange(q) for _ in range(20000)]
+    worst = 0
+    for k in cases:
+        k %= q
+        k1b, k2b, sg = ctypes.create_string_buffer(16), ctypes.create_string_buffer(16), (ctypes.c_int * 2)()
+        shim.t_glv_split(k.to_bytes(32, "little"), k1b, k2b, sg)
+        k1, k2 = int.from_bytes(k1b.raw, "little"), int.from_bytes(k2b.raw, "little")
+        worst = max(worst, k1, k2)
+        v1, v2 = (-k1 if sg[0] else k1), (-k2 if sg[1] else k2)
+        assert (v1 + v2 * lam - k) % q == 0, hex(k)
+    assert worst < 1 << 128
+    G = secp256k1.G
+    for pt in [G] + gens(5, seed(3)):
+        out = ctypes.create_string_buffer(32)
+        shim.t_fe_mul_beta(pt.x.to_bytes(32, "little"), out)
+        bx = int.from_bytes(out.raw, "little")
+        assert bx == beta * pt.x % p
+        img = lam * pt
+        assert (img.x, img.y) == (bx, pt.y)

@@ -489,3 +489,55 @@ def test_device_scalars_equal_the_oracles_verifier_quantities(eng, n):
             # part sits in the hs_const cell), E4 carries b s_i^-1 with weight w4, both over the unscaled hs_i
             want_shared[5 + n + i] += (w4 * b * pow(ss[i], -1, Q) - w2 * R._zpow_term(R.Zq(z, Q), i, n).x) * pow(yinv, i, Q)
     assert [le(shared, i) for i in range(5 + 2 * n)] == [v % Q for v in want_shared], "shared coefficients"
+
+
+def test_one_call_batch_verification_equals_the_two_step_path(eng):
+    """bpmi_rp_batch_verify_dev (upload in slices, preparation, shared coefficients folded on the device, one MSM): accepts what
+    add_wire_native + verify accepts, gives the identity for valid batches (also aggregated ones, also below and above the
+    slicing threshold), a non-identity value for a wrong commitment, "Proof invalid" for corrupted bytes; with fixed weights
+    its 64-byte value equals the two-step path's partial()."""
+    b = make_batch(6, n=8)
+    blobs = [proof_to_bytes(pr) for pr in b["proofs"]]
+    bv = BatchRangeVerifier(b["g"], b["h"], b["gs"], b["hs"], b["u"])
+    assert bv.partial_wire(b["Vs"], blobs) == bytes(64)
+    assert bv.verify_wire(b["Vs"], blobs) is True
+    many = [blobs[i % 6] for i in range(5000)]                      # above the slicing threshold (4096 proofs)
+    manyV = [b["Vs"][i % 6] for i in range(5000)]
+    assert bv.partial_wire(manyV, many) == bytes(64)
+    wrong = list(manyV)
+    wrong[4321] = manyV[4322]
+    assert bv.partial_wire(wrong, many) != bytes(64)
+    with pytest.raises(Exception, match="Proof invalid"):
+        bv.verify_wire(wrong, many)
+    bad = bytearray(many[77])
+    bad[len(bad) - 3] ^= 4
+    with pytest.raises(Exception, match="Proof invalid"):
+        bv.partial_wire(manyV, many[:77] + [bytes(bad)] + many[78:])
+    # the same weights through both paths: the same 64 bytes (a non-zero value: one commitment is wrong)
+    rnd = random.Random(3)
+    ws = [rnd.randrange(1, Q) for _ in range(4 * 6)]
+    Vs_bad = [b["Vs"][1]] + b["Vs"][1:]
+    it1, it2 = iter(ws), iter(ws)
+    one = BatchRangeVerifier(b["g"], b["h"], b["gs"], b["hs"], b["u"], rng=lambda: next(it1))
+    two = BatchRangeVerifier(b["g"], b["h"], b["gs"], b["hs"], b["u"], rng=lambda: next(it2))
+    two.add_wire_native(Vs_bad, blobs, prepare="device")
+    assert one.partial_wire(Vs_bad, blobs) == two.partial() != bytes(64)
+    # aggregated proofs (m = 2 values each)
+    from oracle import bp_ref as R
+    from oracle import cbind
+    from helpers import gens
+    from test_batch_verify_cpu import convert_proof, gpt
+    m, bits = 2, 4
+    gs, hs = gens(m * bits, b"ags"), gens(m * bits, b"ahs")
+    g, h, u = (R.elliptic_hash(s) for s in (b"ag", b"ah", b"au"))
+    Vs_all, ab = [], []
+    for j in range(3):
+        vs = [R.Zq(rnd.randrange(2 ** bits), Q) for _ in range(m)]
+        gammas = [R.mod_hash(b"gb%d-%d" % (j, t), Q) for t in range(m)]
+        Vs_all.append([gpt(R.commitment(g, h, v, ga)) for v, ga in zip(vs, gammas)])
+        ab.append(proof_to_bytes(convert_proof(R.aggreg_range_prove(vs, bits, g, h, gs, hs, gammas, u, seed=b"bs%d" % j, multiexp=cbind.msm))))
+    av = BatchRangeVerifier(gpt(g), gpt(h), [gpt(p) for p in gs], [gpt(p) for p in hs], gpt(u))
+    assert av.verify_wire(Vs_all, ab) is True
+    Vs_all[1] = [Vs_all[1][1], Vs_all[1][0]]                        # two commitments of one proof exchanged
+    with pytest.raises(Exception, match="Proof invalid"):
+        av.verify_wire(Vs_all, ab)

@@ -29,7 +29,7 @@ def main():
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-DBPMI_ISA_PROBE", "-S", "--cuda-device-only",
                                "-Wno-unused-command-line-argument", "-o", asm, SRC], stderr=subprocess.DEVNULL)
         text = open(asm).read()
-    m = re.search(r"^_Z10k_accum_l0.*?; Occupancy: \d+", text, re.S | re.M)
+    m = re.search(r"^_Z10k_accum_l0ILb0E.*?; Occupancy: \d+", text, re.S | re.M)
     kernel = m.group(0)
     probe = re.search(r"^_Z16k_isa_probe_madd.*?; Occupancy: \d+", text, re.S | re.M).group(0)
     # the whole probe kernel is the main path plus the loads / stores of its operands and their address arithmetic;

@@ -25,6 +25,8 @@ def device_points(n, seed):
 
 CS = [int(v) for v in os.environ.get("TUNE_C", "0,8,9,10,11,12,13,14,15,16").split(",")]
 CHUNKS = [int(v) for v in os.environ.get("TUNE_CHUNK", "0,8,16,32,64").split(",")]
+if os.environ.get("TUNE_GLV"):
+    eng.set_option("glv", int(os.environ["TUNE_GLV"]))
 sizes = [int(a) for a in sys.argv[1:]] or [1 << 13, 1 << 14, 1 << 15, 1 << 16, 1 << 17, 1 << 18, 311427, 1 << 19]
 nmax = max(sizes)
 d_p, d_s = device_points(nmax, 1), eng.upload(sha_scalars(nmax, 2))
