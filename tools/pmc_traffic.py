@@ -27,7 +27,10 @@ def load(dirname, counter):
                 if row["Counter_Name"] != counter:
                     continue
                 per_dispatch[row["Dispatch_Id"]] += float(row["Counter_Value"])
-                names[row["Dispatch_Id"]] = row["Kernel_Name"].split("(")[0]
+                name = row["Kernel_Name"].split("(")[0]
+                if name.startswith("void "):                    # template instances: "void k_accum_l0<false>(...)"
+                    name = name[5:]
+                names[row["Dispatch_Id"]] = name.split("<")[0]
         for d, v in per_dispatch.items():
             acc[names[d]].append(v)
     return acc
@@ -37,7 +40,7 @@ def main():
     fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
     rows = []
     for k in sorted(set(fetch) | set(write)):
-        if not k.startswith("k_"):
+        if not (k.startswith("k_") or k.startswith("rpd::k_")):
             continue
         f = sum(fetch.get(k, [0])) / max(len(fetch.get(k, [0])), 1)
         w = sum(write.get(k, [0])) / max(len(write.get(k, [0])), 1)
