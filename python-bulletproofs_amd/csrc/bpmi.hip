@@ -16,7 +16,7 @@
 //                   bucket, the first/last run of a chunk become partial records
 //   k_segscan       block-wide segmented scan over partial records, 256 -> 2 per block,
 //                   repeated until one block is left
-//   k_digit_sums (x2) / k_weighted16   sum_b b*B[w][b]: the bucket index split in two digits
+//   k_digit_sums / k_digit_final       sum_b b*B[w][b]: the bucket index split in two digits, twice
 //                   twice (2 additions per element, sub-wave groups, shuffle butterflies),
 //                   then 16-term suffix scans; k_window_weighted_small for <= 256 buckets
 //   k_msm_small     n <= 4096: digit multiples per thread + butterfly sums (latency path)

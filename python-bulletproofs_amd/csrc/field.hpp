@@ -59,9 +59,16 @@ BPMI_HD void fe_from_words(fe &r, const u32 w[8]) {
 #pragma unroll
   for (int k = 0; k < 9; k++) {
     const int bit = 29 * k, i = bit >> 5, s = bit & 31;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // one v_alignbit_b32 per limb; the 64-bit form below made the vectoriser park the words in private memory and
+    // reload them at odd offsets (80-140 B of scratch in k_ec_sum, k_ec_lincomb2, k_tail)
+    const u32 hi = (i + 1 < 8) ? w[i + 1] : 0u;
+    r.v[k] = (s ? __builtin_amdgcn_alignbit(hi, w[i], (u32)s) : w[i]) & M29;
+#else
     u64 x = w[i];
     if (i + 1 < 8) x |= (u64)w[i + 1] << 32;
     r.v[k] = (u32)(x >> s) & M29;
+#endif
   }
 }
 // a must be canonical (fe_canon) -- limbs < 2^29, value < 2^256

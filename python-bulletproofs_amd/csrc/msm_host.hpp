@@ -31,7 +31,7 @@ struct MsmWs {
   unsigned char *negs;        // path 2: 1 = the scalar was replaced by q - s
   u32 P;          // partitions of sort path 2 (0 = path 1)
   u32 *rec_key[2], *rec_pt[2];
-  u32 *D, *D2, *E, *out;
+  u32 *D, *E, *out;
   size_t total;
   u32 nscan_blocks, rec0_max;
 };
@@ -66,7 +66,6 @@ static void msm_layout(const MsmGeom &g, MsmWs &w, char *base, bool glv = false)
   w.rec_key[1] = take(4ull * rec1_max);
   w.rec_pt[1] = take(4ull * XYZZ_WORDS * rec1_max);
   w.D = take(4ull * XYZZ_WORDS * g.W * (g.B > 256u ? (1u << ((g.c + 1u) / 2u)) + (1u << (g.c / 2u)) : 1u));   // stage-1 digit sums
-  w.D2 = take(4ull * XYZZ_WORDS * g.W * 64);                                                                  // stage-2 digit sums
   w.E = take(4ull * XYZZ_WORDS * g.W * 4);
   w.out = take(64);
   w.total = o;
@@ -271,23 +270,18 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, int slot, const Segs &segs_in, u
       const u32 s0 = g.c / 2u, N0 = (1u << s0) - 1u, N1 = g.B >> s0;          // stage-1 arrays: D0[1..N0], D1[1..N1]
       const u32 t0 = (s0 + 1u) / 2u, t1 = (msb_index(N1) + 1u) / 2u;          // stage-2 splits
       const u32 stride1 = N0 + N1;
-      // stage 1 is throughput-bound: 16 elements per lane (measured best of 4 / 8 / 12 / 16); stage 2 is pure
-      // latency: one element per lane, 16-lane butterflies
-      DigitJobs j1 = digit_jobs2(g.W, 0, g.B, g.B, s0, 0, stride1, ctx->opt_epl > 0 ? (u32)ctx->opt_epl : 16u);
+      // stage 1: as many elements per lane as keep about one wave on every SIMD (16 at c = 16 with all 16 windows: measured
+      // best of 4 / 8 / 12 / 16 there; fewer buckets -- smaller c, a window group of a split MSM -- get shorter chains
+      // instead of idle SIMDs); stage 2 + the finish are pure latency: one element per lane, 16-lane butterflies, one launch
+      u32 epl = ctx->opt_epl > 0 ? (u32)ctx->opt_epl : (u32)(((uint64_t)g.W * g.B) >> 15);
+      epl = epl < 2u ? 2u : (epl > 16u ? 16u : epl);
+      DigitJobs j1 = digit_jobs2(g.W, 0, g.B, g.B, s0, 0, stride1, epl);
       hipLaunchKernelGGL(k_digit_sums, dim3(j1.j[j1.njobs - 1].blk0 + digit_job_blocks(j1, j1.njobs - 1)), dim3(256), 0, st, w.buckets, w.D, j1);
-      // stage 2: D0 -> (D00, D01) at records [0, ..), D1 -> (D10, D11) behind them
+      // stage 2: D0 -> (D00, D01), D1 -> (D10, D11), each <= 16 sums of <= 16 elements, and E[a][r] = sum_d d * D..[d]
       DigitJobs ja = digit_jobs2(g.W, 0, stride1, N0, t0, 0, 64, 1);
-      const u32 used_a = ((1u << t0) - 1u) + (N0 >> t0);
-      DigitJobs jb = digit_jobs2(g.W, N0, stride1, N1, t1, used_a, 64, 1);
+      DigitJobs jb = digit_jobs2(g.W, N0, stride1, N1, t1, 0, 64, 1);
       DigitJobs j2 = digit_jobs_concat(ja, jb);
-      hipLaunchKernelGGL(k_digit_sums, dim3(j2.j[j2.njobs - 1].blk0 + digit_job_blocks(j2, j2.njobs - 1)), dim3(256), 0, st, w.D, w.D2, j2);
-      FinalJobs f;
-      f.nr = 4; f.in_stride = 64; f.cnt = g.W;
-      f.in_off[0] = 0;                       f.N[0] = (1u << t0) - 1u;
-      f.in_off[1] = f.N[0];                  f.N[1] = N0 >> t0;
-      f.in_off[2] = used_a;                  f.N[2] = (1u << t1) - 1u;
-      f.in_off[3] = used_a + f.N[2];         f.N[3] = N1 >> t1;
-      hipLaunchKernelGGL(k_weighted16, dim3((g.W * 4u * 16u + 255u) / 256u), dim3(256), 0, st, w.D2, w.E, f);
+      hipLaunchKernelGGL(k_digit_final, dim3(g.W * 4u), dim3(256), 0, st, w.D, w.E, j2);
       to.nv = 4; to.off[0] = 0; to.off[1] = t0; to.off[2] = s0; to.off[3] = s0 + t1;
     }
   }

@@ -243,8 +243,23 @@ __global__ void __launch_bounds__(1024) k_partition(MsmGeom g, u32 P, u32 TS, co
   }
 }
 // chunk_key[t] = bucket that contains sorted position t * L (for every chunk start inside [lo, hi))
+// Called by EVERY lane of a wave (lanes without a bucket pass lo == hi).  A bucket with few chunk starts is filled by its own
+// lane; a long one (skewed digits, the short top window of c = 12, 14, 15: thousands of chunk starts) by the whole wave,
+// instead of thousands of dependent stores from one lane (0.24 ms at n = 2^16, c = 15).
+#define CHUNK_FILL_OWN 16u
 __device__ __forceinline__ void fill_chunk_keys(u32 *__restrict__ chunk_key, u32 L, u32 key, u32 lo, u32 hi) {
-  for (u32 t = (lo + L - 1u) / L; (u64)t * L < hi; t++) chunk_key[t] = key;
+  const u32 t0 = (lo + L - 1u) / L;
+  const u32 t1 = hi > lo ? (u32)(((u64)hi + L - 1u) / L) : t0;         // chunk starts t0 .. t1 - 1 lie in [lo, hi)
+  const bool big = t1 - t0 > CHUNK_FILL_OWN;
+  if (!big) for (u32 t = t0; t < t1; t++) chunk_key[t] = key;
+  unsigned long long m = __ballot(big);
+  const u32 lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  while (m) {
+    const int src = __ffsll((long long)m) - 1;
+    m &= m - 1ull;
+    const u32 k = (u32)__shfl((int)key, src, 64), a = (u32)__shfl((int)t0, src, 64), b = (u32)__shfl((int)t1, src, 64);
+    for (u32 t = a + lane; t < b; t += 64u) chunk_key[t] = k;
+  }
 }
 // Level B, one block per partition: the partition's entries are counting-sorted by the low 8
 // key bits.  Its output range [base, base + m) is known from level A, so no global atomic and
@@ -393,8 +408,9 @@ __global__ void __launch_bounds__(256) k_fine_scatter_heavy(MsmGeom g, u32 P, co
 // path 1 equivalent of the chunk-key fill: one thread per bucket
 __global__ void __launch_bounds__(256) k_chunk_keys(MsmGeom g, const u32 *__restrict__ off, u32 *__restrict__ chunk_key) {
   const u32 key = blockIdx.x * blockDim.x + threadIdx.x;
-  if (key >= g.G) return;
-  fill_chunk_keys(chunk_key, g.L, key, off[key], off[key + 1]);
+  const bool valid = key < g.G;
+  const u32 lo = valid ? off[key] : 0u, hi = valid ? off[key + 1] : 0u;
+  fill_chunk_keys(chunk_key, g.L, key, lo, hi);
 }
 
 // ---- exclusive scan of hist[0..G) -> off[0..G], cursor[0..G) = off ------------------
@@ -618,7 +634,7 @@ __device__ __forceinline__ void block_tree_sum(xyzz &val, u32 *s_val) {
 //   D0[lo] = sum of X[hi 2^s + lo] over hi      (lo = 1 .. 2^s - 1)
 //   D1[hi] = sum of X[hi 2^s + lo] over lo      (hi = 1 .. N >> s)
 // i.e. TWO additions per element; applying it twice takes a window's 2^(c-1) buckets to four
-// arrays of <= 16 sums, which k_weighted16 finishes.  Every sum belongs to a group of
+// arrays of <= 16 sums, which k_digit_final (the second application and the finish in one launch) turns into E[a][0..3].  Every sum belongs to a group of
 // 2^gl_log lanes of one wave: each lane adds its share serially (about 8 elements), then a
 // butterfly of __shfl_xor exchanges folds the group -- no LDS, no block barrier.
 struct DigitJob {
@@ -684,17 +700,44 @@ __global__ void __launch_bounds__(256) k_digit_sums(const u32 *__restrict__ X, u
   }
   if (active && l == 0) xyzz_store_g(D + ((u64)a * J.out_stride + J.out_off + idx - 1u) * XYZZ_WORDS, acc);
 }
-// E[a][r] = sum_{d=1..N_r} d * X_r[d] for the (<= 4) arrays r of every a, N_r <= 16: one group of
-// 16 lanes per array -- inclusive suffix scan (4 steps), then the sum of all suffixes (4 steps)
-struct FinalJobs { u32 in_off[4], N[4]; u32 nr, in_stride, cnt; };
-__global__ void __launch_bounds__(256) k_weighted16(const u32 *__restrict__ X, u32 *__restrict__ Eout, FinalJobs f) {
-  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-  const u32 grp = t >> 4, l = t & 15u;
-  const bool active = grp < f.cnt * f.nr;
-  const u32 a = grp / f.nr, r = grp % f.nr;
+// Stage 2 and the finish in ONE launch: block (array r of window a) = 16 groups of 16 lanes; group j adds up the (<= 16)
+// elements of sum j + 1 of the array's digit job with a butterfly, parks it in LDS, and the first 16 lanes turn the (<= 16)
+// sums into sum_d d * X[d]: inclusive suffix scan (4 steps), then the sum of all suffixes (4 steps).  E[a][r] out.  Saves a launch and the trip of 64 records per window
+// through HBM on a path that is nothing but latency.
+__global__ void __launch_bounds__(256) k_digit_final(const u32 *__restrict__ X, u32 *__restrict__ Eout, DigitJobs jobs) {
+  __shared__ u32 s_val[16 * LDS_STRIDE];
+  const u32 a = blockIdx.x >> 2, r = blockIdx.x & 3u, tid = threadIdx.x;
+  const DigitJob J = jobs.j[r];
+  const u32 idx = (tid >> 4) + 1u, l = tid & 15u;
+  xyzz acc;
+  xyzz_set_inf(acc);
+  if (idx <= J.nsums) {
+    const u32 *base = X + ((u64)a * J.in_stride + J.in_off) * XYZZ_WORDS;
+    if (J.type == 0) {
+      for (u32 hi = l; ((hi << J.s) | idx) <= J.N; hi += 16u) {
+        xyzz x;
+        xyzz_load_g(x, base + (u64)(((hi << J.s) | idx) - 1u) * XYZZ_WORDS);
+        xyzz_add(acc, acc, x);
+      }
+    } else {
+      for (u32 lo = l; lo < (1u << J.s) && ((idx << J.s) | lo) <= J.N; lo += 16u) {
+        xyzz x;
+        xyzz_load_g(x, base + (u64)(((idx << J.s) | lo) - 1u) * XYZZ_WORDS);
+        xyzz_add(acc, acc, x);
+      }
+    }
+  }
+  for (u32 m = 1; m < 16u; m <<= 1) {
+    xyzz other;
+    xyzz_shfl_xor(other, acc, (int)m);
+    xyzz_add(acc, acc, other);
+  }
+  if (l == 0) xyzz_store(s_val + (idx - 1u) * LDS_STRIDE, acc);
+  __syncthreads();
+  if (tid >= 64u) return;
   xyzz val;
   xyzz_set_inf(val);
-  if (active && l < f.N[r]) xyzz_load_g(val, X + ((u64)a * f.in_stride + f.in_off[r] + l) * XYZZ_WORDS);
+  if (tid < J.nsums) xyzz_load(val, s_val + tid * LDS_STRIDE);            // lane d - 1 holds X[d]; lanes 16 .. 63 idle along
   for (u32 d = 1; d < 16; d <<= 1) {
     xyzz other;
     xyzz_shfl_down16(other, val, (int)d);
@@ -705,7 +748,7 @@ __global__ void __launch_bounds__(256) k_weighted16(const u32 *__restrict__ X, u
     xyzz_shfl_xor(other, val, (int)m);
     xyzz_add(val, val, other);
   }
-  if (active && l == 0) xyzz_store_g(Eout + (u64)grp * XYZZ_WORDS, val);
+  if (tid == 0) xyzz_store_g(Eout + (u64)blockIdx.x * XYZZ_WORDS, val);
 }
 
 // ---- bucket reduction for small windows (B <= 256): one block of B threads per window
@@ -800,25 +843,30 @@ __global__ void __launch_bounds__(64) k_small_combine(const u32 *__restrict__ pa
 
 // ---- tail: result = sum_w 2^(c w) sum_v 2^(off[v]) E[w][v], to canonical affine -------------
 BPMI_HD void msm_tail_combine(u32 out_words[16], const u32 *E, u32 W, u32 c, const TailOffs &to) {
-  // ONE Horner chain over bit positions: E[w][v] carries weight 2^(c*w + off[v]), so walking
-  // from the top bit down costs c*W doublings in total
+  // ONE Horner chain over bit positions: E[w][v] carries weight 2^(c*w + off[v]), so walking from the top bit down costs
+  // c*W doublings in total.  A flat loop over positions with the (<= 4) offsets in scalars: no indexed private array, the
+  // accumulator stays in registers.
+  const u32 o0 = to.off[0], o1 = to.nv > 1 ? to.off[1] : 0xFFFFFFFFu, o2 = to.nv > 2 ? to.off[2] : 0xFFFFFFFFu,
+            o3 = to.nv > 3 ? to.off[3] : 0xFFFFFFFFu;
   xyzz acc;
   xyzz_set_inf(acc);
-  for (int w = (int)W - 1; w >= 0; w--) {
-    int prev = (int)c;                              // bit offset (within the window) already reached
-    for (int v = (int)to.nv - 1; v >= 0; v--) {
-      for (int k = prev; k > (int)to.off[v]; k--) xyzz_dbl(acc, acc);
-      prev = (int)to.off[v];
+  u32 w = W, r = 0;                                   // position = w * c + r
+  for (u32 pos = W * c; pos-- > 0;) {
+    if (r == 0) { w--; r = c; }
+    r--;
+    xyzz_dbl(acc, acc);
+    const u32 v = r == o0 ? 0u : r == o1 ? 1u : r == o2 ? 2u : r == o3 ? 3u : 4u;
+    if (v < 4u) {
       xyzz e;
       xyzz_load(e, E + ((u64)w * to.nv + v) * XYZZ_WORDS);
       xyzz_add(acc, acc, e);
     }
   }
-  affine r;
-  xyzz_to_affine(r, acc);
-  affine_to_words(out_words, r);
+  affine r_aff;
+  xyzz_to_affine(r_aff, acc);
+  affine_to_words(out_words, r_aff);
 }
-__global__ void k_tail(const u32 *__restrict__ E, u32 W, u32 c, TailOffs to, u32 *__restrict__ out) {
+__global__ void __launch_bounds__(64) k_tail(const u32 *__restrict__ E, u32 W, u32 c, TailOffs to, u32 *__restrict__ out) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     u32 w16[16];
     msm_tail_combine(w16, E, W, c, to);

@@ -53,6 +53,11 @@ for n in sizes:
             eng.set_option("async_lanes", 0)
             print("n=%7d c=%2d chunk=%2d  sync %.3f ms  two-in-flight %.3f ms" % (n, c, chunk, dt * 1e3, dp * 1e3), flush=True)
             if best is None or dt < best[0]: best = (dt, c, chunk)
+            if os.environ.get("TUNE_STAGES"):           # the stage table of EVERY combination, not only of the best one
+                eng.profile(True); eng.profile_reset()
+                for _ in range(8): eng.msm_dev(d_p, d_s, n)
+                pr = eng.profile_read(); eng.profile(False)
+                print("   stages:", {k.replace("msm_", ""): round(v[0] / v[1], 4) for k, v in pr.items() if v[1]}, flush=True)
     print("## n=%d best sync: c=%d chunk=%d %.3f ms" % (n, best[1], best[2], best[0] * 1e3), flush=True)
     eng.set_option("window_bits", best[1]); eng.set_option("chunk", best[2])
     eng.profile(True); eng.profile_reset()
