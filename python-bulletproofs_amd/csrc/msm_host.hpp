@@ -13,7 +13,11 @@ static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; 
 // handful of buckets, so c in {8, 16} (top window 7, 15 bits) are preferred.
 static u32 pick_window_bits(const bpmi_ctx *ctx, uint64_t n) {
   if (ctx->opt_c >= 2 && ctx->opt_c <= 16) return (u32)ctx->opt_c;
-  if (n >= (1u << 15)) return 16;      // the LDS sort and the two-digit bucket reduction made 2^15 buckets per window cheap
+  // tools/tune_msm_mid.py (profiles/r03_tune_msm_mid_sizes.txt, ..._small_window_table.txt): c = 16 from 2^15 (the LDS sort and
+  // the two-digit bucket reduction made 2^15 buckets per window cheap; c = 12 .. 15 lose at every size above), c = 13 between
+  // 10 240 and 2^15 (0.30-0.33 ms against 0.33-0.46 with c = 8), c = 8 below
+  if (n >= (1u << 15)) return 16;
+  if (n >= 10240u) return 13;
   if (n >= (1u << 10)) return 8;
   u32 lg = 0;
   while ((1ull << (lg + 1)) <= n) lg++;

@@ -516,9 +516,12 @@ template <bool GLV> __global__ void __launch_bounds__(256) k_accum_l0(Segs segs,
   xyzz_set_inf(acc);
   u32 cur = chunk_key[t];              // bucket containing position `start`
   u32 boundary = off[cur + 1];         // first position after that bucket's run
+  u32 boundary2 = off[cur + 2 < g.G ? cur + 2 : g.G];       // ... and after the next bucket's: on its way before a flush needs it
   bool first = true;
-  // software pipeline: the (index, point) of entry j+1 is in flight while entry j is added
+  // software pipeline: the point of entry j+1 and the index of entry j+2 are in flight while entry j is added (the address of
+  // a point depends on its index: with the index only one entry ahead every iteration began with a full load latency)
   u32 e_next = sidx[start];
+  u32 e_next2 = (start + 1 < end) ? sidx[start + 1] : 0u;
   u32 w_next[16];
   load_entry_point<GLV>(w_next, segs, e_next & 0x7FFFFFFFu);
   for (u32 j = (u32)start; j < end; j++) {
@@ -526,14 +529,15 @@ template <bool GLV> __global__ void __launch_bounds__(256) k_accum_l0(Segs segs,
     affine P;
     affine_from_words(P, w_next);
     if (j + 1 < end) {
-      e_next = sidx[j + 1];
+      e_next = e_next2;
+      if (j + 2 < end) e_next2 = sidx[j + 2];
       load_entry_point<GLV>(w_next, segs, e_next & 0x7FFFFFFFu);
     }
     if (j == boundary) {               // the run of `cur` ended: flush, move to the next non-empty bucket
       if (first) { rec_key[2 * t] = cur; xyzz_store_g(rec_pt + (2 * t) * XYZZ_WORDS, acc); first = false; }
       else xyzz_store_g(buckets + (u64)cur * XYZZ_WORDS, acc);
       xyzz_set_inf(acc);
-      do { cur++; boundary = off[cur + 1]; } while (boundary == j);
+      do { cur++; boundary = boundary2; boundary2 = off[cur + 2 < g.G ? cur + 2 : g.G]; } while (boundary == j);
     }
     xyzz_madd_signed(acc, P, (e >> 31) != 0);
   }

@@ -60,6 +60,18 @@ def test_msm_vs_oracle_random(gp, n):
     assert gp.engine().msm_bytes(pb, sb, n) == cbind.msm_bytes(pb, sb, n)
 
 
+@pytest.mark.parametrize("n", [4096, 4097, 10239, 10240, 32767, 32768])
+def test_msm_at_the_window_table_boundaries(gp, n):
+    """Either side of every switch of the geometry: one-launch kernel / bucket pipeline (4096), window bits 8 / 13 (10 240) and
+    13 / 16 (2^15); scalars with the edge values mixed in (0, 1, q - 1, >= q, 2^255 and the half-order boundary)."""
+    pts, _ = gp.rand_points(n, 900 + n)
+    rnd = random.Random(n)
+    edge = [0, 1, Q - 1, Q, Q + 1, (1 << 256) - 1, 1 << 255, (Q - 1) // 2, (Q + 1) // 2, (1 << 13) - 1, 1 << 12, (1 << 16) - 1, 1 << 15]
+    es = [edge[rnd.randrange(len(edge))] if i % 5 == 0 else rnd.randrange(Q) for i in range(n)]
+    pb, sb = cbind.pack_points(pts), b"".join(e.to_bytes(32, "little") for e in es)       # unreduced: both sides reduce mod q
+    assert gp.engine().msm_bytes(pb, sb, n) == cbind.msm_bytes(pb, sb, n)
+
+
 @pytest.mark.parametrize("shape", ["acommit", "all_same", "same_point", "zeros", "cancel", "small", "with_inf", "top"])
 def test_msm_degenerate_shapes(gp, shape):
     n = 5000
@@ -258,13 +270,14 @@ def test_msm2_pairs(gp):
         PipSECP256k1.multiexp2(gp.to_gpu_list(pts[:2]), [1], [], [])
 
 
+@pytest.mark.parametrize("n", [40000, 30000])      # window bits 16, and 13 (the size range 10 240 .. 2^15: a short top window, always heavy)
 @pytest.mark.parametrize("shape", ["all_same", "two_values", "bits01", "small_range"])
-def test_msm_heavy_partitions(gp, shape):
+def test_msm_heavy_partitions(gp, shape, n):
     """Skewed digit distributions on the LDS-sort path: partitions with more than 12 288 entries
     are counted and scattered by the tile kernels (k_fine_hist_heavy / k_fine_scatter_heavy) instead of
-    one block's LDS; mixed with light partitions in the same MSM."""
+    one block's LDS; mixed with light partitions in the same MSM.  Buckets with thousands of entries also take the
+    wave-cooperative chunk-key fill."""
     eng = gp.engine()
-    n = 40000
     pts, _ = gp.rand_points(n, 23)
     rnd = random.Random(len(shape))
     if shape == "all_same":
