@@ -79,6 +79,9 @@ int bpmi_sync(bpmi_ctx *ctx);
  *                  upload is not sliced: every kernel's duration is then its own; 1 default
  *   "glv"          1: the bucket pipeline runs on GLV-split scalars (2n pairs of 128-bit scalars, half the windows).  An
  *                  experiment that lost (profiles/r03_glv_msm_on_off.txt); default 0 = off
+ *   "mul_batch_glv" bpmi_ec_mul_batch[_dev] from 32 768 points: 1 (default) GLV halves on fixed signed three-bit windows over affine
+ *                  3P, 5P, 7P (k_ec_odd_multiples + k_ec_mul_batch_glv; workspace 1 080 B per point of a 196 608-point slice);
+ *                  0 the bit-serial ladder at every size
  *   "rp_rows"      bpmi_rp_batch_prepare_dev: proofs per kernel launch (0 = as many as fit ~256 MB of scratch cells)
  *   "ipa_big_m"    base length from which the IPA prover folds its generators 16-way at
  *                  once instead of deferring the fold into the MSM scalars (default 2^18) */

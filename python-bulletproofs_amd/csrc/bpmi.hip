@@ -125,6 +125,7 @@ int bpmi_sync(bpmi_ctx *ctx) {
 int bpmi_set_option(bpmi_ctx *ctx, const char *name, int64_t value) {
   if (!ctx || !name) return BPMI_E_ARG;
   if (!strcmp(name, "window_bits")) { if (value != 0 && (value < 2 || value > 16)) return fail(ctx, BPMI_E_ARG, "window_bits must be 0 or 2..16"); ctx->opt_c = (int)value; return BPMI_OK; }
+  if (!strcmp(name, "mul_batch_glv")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "mul_batch_glv must be 0 or 1"); ctx->opt_mulb = (int)value; return BPMI_OK; }
   if (!strcmp(name, "tail")) { if (value < 0 || value > 2) return fail(ctx, BPMI_E_ARG, "tail must be 0, 1 or 2"); ctx->opt_tail = (int)value; return BPMI_OK; }
   if (!strcmp(name, "small_n")) { if (value < -1 || value > (1 << 16)) return fail(ctx, BPMI_E_ARG, "small_n must be -1 .. 65536"); ctx->opt_small = (int)value; return BPMI_OK; }
   if (!strcmp(name, "split")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "split must be 0 or 1"); ctx->opt_split = (int)value; return BPMI_OK; }
@@ -293,10 +294,28 @@ int bpmi_ec_mul_batch_dev(bpmi_ctx *ctx, const void *d_pts, const void *d_scalar
   if (n > BPMI_MAX_N) return fail(ctx, BPMI_E_ARG, "n exceeds BPMI_MAX_N");
   if (n == 0) return BPMI_OK;
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  {
+  if (n < (uint64_t)MULB_MIN_N || ctx->opt_mulb == 0) {            // few points: the table kernel's inversion chain is not worth its latency
     StageTimer t(ctx, ST_MULBATCH);
     hipLaunchKernelGGL(k_ec_mul_batch, dim3((u32)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const u32 *)d_pts,
                        (const u32 *)d_scalars, (u32)n, (u32 *)d_out);
+    HIPCHK(ctx, hipGetLastError());
+    return BPMI_OK;
+  }
+  // slices of 3 x 65 536 points: three waves on every SIMD (the kernels' occupancy) in ONE round, and a bounded workspace
+  // (affine 3P, 5P, 7P: 216 B per point; the table kernel's scratch columns: 864 B per point as it is laid out for two arrays)
+  const uint64_t slice = 3ull << 16;
+  const uint64_t m0 = std::min<uint64_t>(n, slice), nthr0 = (m0 + ODDMUL_PER_THREAD_MULB - 1) / ODDMUL_PER_THREAD_MULB;
+  const size_t tab_bytes = align_up(3 * 72 * (size_t)m0, 256), scr_bytes = 144 * 3 * (size_t)ODDMUL_PER_THREAD_MULB * 2 * nthr0;
+  int rc = ensure_ws(ctx, tab_bytes + scr_bytes);
+  if (rc) return rc;
+  u32 *tab = (u32 *)ctx->ws, *scr = (u32 *)((char *)ctx->ws + tab_bytes);
+  for (uint64_t base = 0; base < n; base += slice) {
+    const u32 m = (u32)std::min<uint64_t>(slice, n - base), nthr = (m + ODDMUL_PER_THREAD_MULB - 1) / ODDMUL_PER_THREAD_MULB;
+    const u32 *p = (const u32 *)d_pts + 16 * base, *k = (const u32 *)d_scalars + 8 * base;
+    StageTimer t(ctx, ST_MULBATCH);
+    hipLaunchKernelGGL(k_ec_odd_multiples<ODDMUL_PER_THREAD_MULB>, dim3((nthr + 255) / 256), dim3(256), 0, ctx->stream, p, (const u32 *)nullptr, m, tab,
+                       (u32 *)nullptr, scr);
+    hipLaunchKernelGGL(k_ec_mul_batch_glv, dim3((m + 255) / 256), dim3(256), 0, ctx->stream, p, k, m, (const u32 *)tab, (u32 *)d_out + 16 * base);
   }
   HIPCHK(ctx, hipGetLastError());
   return BPMI_OK;
@@ -899,7 +918,7 @@ int bpmi_ipa_fold(bpmi_ipa *st, const uint8_t x[32], const uint8_t xinv[32]) {
         HIPCHK(ctx, hipMemcpyAsync(dwb, &hwb, sizeof(WnafK), hipMemcpyHostToDevice, ctx->stream));
         {
           StageTimer t(ctx, ST_LINCOMB2);
-          hipLaunchKernelGGL(k_ec_odd_multiples, dim3((u32)((2 * nthr + 255) / 256)), dim3(256), 0, ctx->stream, st->g, st->h, (u32)npts, tab_a, tab_b, scr);
+          hipLaunchKernelGGL(k_ec_odd_multiples<ODDMUL_PER_THREAD>, dim3((u32)((2 * nthr + 255) / 256)), dim3(256), 0, ctx->stream, st->g, st->h, (u32)npts, tab_a, tab_b, scr);
           hipLaunchKernelGGL(k_ec_multifold_w4, dim3((u32)((2 * st->n + 255) / 256)), dim3(256), 0, ctx->stream, ja, jb, tab_a, tab_b, dwa, dwb,
                              (u32)st->n, K2);
         }

@@ -48,6 +48,7 @@ struct bpmi_ctx {
   // options
   int opt_c = 0;        // window bits, 0 = auto
   int opt_tail = 0;     // 0 auto, 1 device, 2 host
+  int opt_mulb = 1;     // bpmi_ec_mul_batch: 1 = GLV + fixed signed windows over affine odd multiples (n >= MULB_MIN_N), 0 = the bit-serial ladder
   int opt_chunk = 0;    // entries per thread in k_accum_l0, 0 = auto
   int opt_small = 0;    // largest n handled by the one-launch small-MSM kernel (0 = default, -1 = never)
   int opt_fold_wnaf = 1;     // the IPA's 16-way generator fold: width-4 NAF over affine tables of odd multiples (0: plain NAF ladder)

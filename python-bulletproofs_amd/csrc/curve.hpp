@@ -80,7 +80,7 @@ BPMI_HD void xyzz_dbl_affine(xyzz &r, const fe &x, const fe &y) {
 // r = 2 * a (dbl-2008-s-1, a = 0): 6M + 3S in eight reductions.  2-torsion does not exist on
 // secp256k1 (prime order), so Y == 0 only for the identity.
 BPMI_HD void xyzz_dbl(xyzz &r, const xyzz &a) {
-  if (xyzz_is_inf(a)) { xyzz_set_inf(r); return; }
+  if (xyzz_is_inf(a)) { r = a; return; }      // (every identity is the all-zero record of xyzz_set_inf; a copy, not 36 stores: with r == a nothing at all)
   fe U, V, W, S, M, t, nW, X3, Y3;
   fe_add(U, a.Y, a.Y);
   fe_sqr(V, U);

@@ -528,6 +528,11 @@ template <bool GLV> __global__ void __launch_bounds__(256) k_accum_l0(Segs segs,
     const u32 e = e_next;
     affine P;
     affine_from_words(P, w_next);
+    // the limbs exist HERE, before the next loads overwrite the words (otherwise the conversion sinks below them and the 16
+    // words are copied aside first)
+    asm volatile("" : "+v"(P.x.v[0]), "+v"(P.x.v[1]), "+v"(P.x.v[2]), "+v"(P.x.v[3]), "+v"(P.x.v[4]), "+v"(P.x.v[5]), "+v"(P.x.v[6]),
+                 "+v"(P.x.v[7]), "+v"(P.x.v[8]), "+v"(P.y.v[0]), "+v"(P.y.v[1]), "+v"(P.y.v[2]), "+v"(P.y.v[3]), "+v"(P.y.v[4]),
+                 "+v"(P.y.v[5]), "+v"(P.y.v[6]), "+v"(P.y.v[7]), "+v"(P.y.v[8]));
     if (j + 1 < end) {
       e_next = e_next2;
       if (j + 2 < end) e_next2 = sidx[j + 2];

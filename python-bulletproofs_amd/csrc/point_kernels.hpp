@@ -37,6 +37,97 @@ __global__ void __launch_bounds__(256, 3) k_ec_mul_batch(const u32 *__restrict__
   store_words16(out + 16ull * i, w16);
 }
 
+// The same product for many points at once, twice as fast (20 -> 10 ms per 2^20; the path of rangeproof_prover.py:77's
+// hsp and of every test / bench input):
+//  * GLV: k = k1 + k2 lambda with |k1|, |k2| < 2^128 (scalar.hpp glv_split) and lambda (x, y) = (beta x, y): 128 doublings
+//    instead of 256;
+//  * every lane of a wave executes every addition anyway (the scalars differ per lane), so sparse recodings buy nothing:
+//    FIXED windows with SIGNED ODD digits instead -- for an odd magnitude k < 2^129, E = (k - 1) / 2 + 2^128 and
+//    k = sum_i (2 e_i - 7) 8^i with e_i the 43 three-bit windows of E: every digit is one of +-1, +-3, +-5, +-7, none is
+//    zero, 43 additions per half-scalar.  An even magnitude uses k | 1 and takes the surplus point off at the end;
+//  * 3P, 5P, 7P of every point in AFFINE form from k_ec_odd_multiples (one inversion per 16 points), so every addition is
+//    a mixed one; the multiples of lambda P are the same entries with beta x.
+//   tab: entry j (0: 3P, 1: 5P, 2: 7P) of point i at tab + ((j * n) + i) * 18 limbs
+#define MULB_STEPS 43
+#define MULB_MIN_N 32768      // below: both forms are one latency-bound wave per SIMD or less, and the old one is a single launch
+__device__ __forceinline__ void mulb_window_register(u32 R[5], const u32 k[4]) {      // ((k & ~1) << 30) | 2^159: E, left-aligned
+  const u32 k0 = k[0] & ~1u;
+  R[0] = k0 << 30;
+  R[1] = (k[1] << 30) | (k0 >> 2);
+  R[2] = (k[2] << 30) | (k[1] >> 2);
+  R[3] = (k[3] << 30) | (k[2] >> 2);
+  R[4] = (k[3] >> 2) | 0x80000000u;
+}
+__device__ __forceinline__ u32 mulb_next_window(u32 R[5]) {                           // the top three bits, then R <<= 3
+  const u32 e = R[4] >> 29;
+#pragma unroll
+  for (int w = 4; w > 0; w--) R[w] = (R[w] << 3) | (R[w - 1] >> 29);
+  R[0] <<= 3;
+  return e;
+}
+// acc += +-(|d| P) or +-(|d| lambda P), d = 2e - 7
+__device__ __forceinline__ void mulb_add_digit(jac &acc, u32 e, bool neg_scalar, bool endo, const affine &P, const u32 *__restrict__ tab, u32 n, u32 i) {
+  const bool neg_digit = e < 4u;
+  const u32 idx = neg_digit ? 3u - e : e - 4u;                          // (|d| - 1) / 2
+  const uint2 *q = reinterpret_cast<const uint2 *>(tab + ((u64)(idx ? idx - 1u : 0u) * n + i) * 18u);
+  u32 w[18];
+#pragma unroll
+  for (int l = 0; l < 9; l++) { const uint2 t = q[l]; w[2 * l] = t.x; w[2 * l + 1] = t.y; }
+  fe x, y;
+#pragma unroll
+  for (int l = 0; l < 9; l++) { x.v[l] = idx ? w[l] : P.x.v[l]; y.v[l] = idx ? w[9 + l] : P.y.v[l]; }
+  if (endo) { fe bx; fe_mul_beta(bx, x); x = bx; }                      // wave-uniform
+  jac_madd_signed(acc, x, y, neg_digit != neg_scalar);
+}
+__global__ void __launch_bounds__(256, 3) k_ec_mul_batch_glv(const u32 *__restrict__ pts, const u32 *__restrict__ scs, u32 n, const u32 *__restrict__ tab,
+                                                            u32 *__restrict__ out) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  affine P;
+  load_affine(P, pts + 16ull * i);
+  u32 w16[16];
+  if (affine_is_inf(P)) {                                               // k * identity
+#pragma unroll
+    for (int k = 0; k < 16; k++) w16[k] = 0;
+    store_words16(out + 16ull * i, w16);
+    return;
+  }
+  sc s;
+  load_words8(s.v, scs + 8ull * i);
+  sc_reduce_once(s);
+  u32 k1[4], k2[4], R1[5], R2[5];
+  bool n1, n2;
+  glv_split(k1, n1, k2, n2, s);
+  const bool even1 = !(k1[0] & 1u), even2 = !(k2[0] & 1u);
+  mulb_window_register(R1, k1);
+  mulb_window_register(R2, k2);
+  jac acc;
+  jac_set_inf(acc);
+  for (int step = 0; step < MULB_STEPS; step++) {
+    if (step) { jac_dbl(acc, acc); jac_dbl(acc, acc); jac_dbl(acc, acc); }
+    mulb_add_digit(acc, mulb_next_window(R1), n1, false, P, tab, n, i);
+    mulb_add_digit(acc, mulb_next_window(R2), n2, true, P, tab, n, i);
+  }
+  // (k | 1) was used for an even magnitude: one sign(k) P (lambda P) too many
+  {
+    fe y;
+#pragma unroll
+    for (int l = 0; l < 9; l++) y.v[l] = P.y.v[l];
+    jac t = acc;
+    jac_madd_signed(t, P.x, y, !n1);
+    if (even1) acc = t;
+    fe bx;
+    fe_mul_beta(bx, P.x);
+    t = acc;
+    jac_madd_signed(t, bx, y, !n2);
+    if (even2) acc = t;
+  }
+  affine r;
+  jac_to_affine(r, acc);
+  affine_to_words(w16, r);
+  store_words16(out + 16ull * i, w16);
+}
+
 struct Sc2 { u32 k1[8]; u32 k2[8]; };
 
 // Non-adjacent forms of the two shared scalars, computed once on the host: bit i of nz*
@@ -245,14 +336,15 @@ __global__ void __launch_bounds__(256, 3) k_ec_multifold(MultifoldJob ja, Multif
 // 16 points -- Montgomery's trick, prefix products in a scratch column) and read by k_ec_multifold_w4.
 //   tab: entry j (0: 3P, 1: 5P, 2: 7P) of point k at tab + ((j * npts) + k) * 18 limbs (x, y; all zero = identity)
 //   scratch: 4 x 9 limbs (X, Y, Z, prefix) per (point, j), column-major per thread
-#define ODDMUL_PER_THREAD 16
-__global__ void __launch_bounds__(256, 3) k_ec_odd_multiples(const u32 *__restrict__ base_a, const u32 *__restrict__ base_b, u32 npts,
+#define ODDMUL_PER_THREAD 16        // the fold: 2^21 points, 131 072 threads
+#define ODDMUL_PER_THREAD_MULB 4    // k_ec_mul_batch_glv's slices of 196 608 points: 49 152 threads (16 per thread left most SIMDs idle)
+template <int PER> __global__ void __launch_bounds__(256, 3) k_ec_odd_multiples(const u32 *__restrict__ base_a, const u32 *__restrict__ base_b, u32 npts,
                                                             u32 *__restrict__ tab_a, u32 *__restrict__ tab_b, u32 *__restrict__ scratch) {
-  const u32 nthreads_per = (npts + ODDMUL_PER_THREAD - 1) / ODDMUL_PER_THREAD;
+  const u32 nthreads_per = (npts + PER - 1) / PER;
   u32 tid = blockIdx.x * blockDim.x + threadIdx.x;
   const bool second = tid >= nthreads_per;
   if (second) tid -= nthreads_per;
-  if (tid >= nthreads_per) return;
+  if (tid >= nthreads_per || (second && !base_b)) return;              // base_b == nullptr: one array only (k_ec_mul_batch_glv)
   const u32 *base = second ? base_b : base_a;
   u32 *tab = second ? tab_b : tab_a;
   const u32 col = (second ? nthreads_per : 0u) + tid;                 // scratch column of this thread
@@ -260,7 +352,7 @@ __global__ void __launch_bounds__(256, 3) k_ec_odd_multiples(const u32 *__restri
   auto rec = [&](u32 e) { return scratch + ((u64)e * ncols + col) * 36u; };      // e = r * 3 + j
   fe pref;
   fe_set_one(pref);
-  for (u32 r = 0; r < ODDMUL_PER_THREAD; r++) {
+  for (u32 r = 0; r < PER; r++) {
     const u32 k = tid + r * nthreads_per;                               // strided: consecutive threads read consecutive points
     affine P;
     if (k < npts) load_affine(P, base + 16ull * k); else { fe_set_zero(P.x); fe_set_zero(P.y); }
@@ -286,7 +378,7 @@ __global__ void __launch_bounds__(256, 3) k_ec_odd_multiples(const u32 *__restri
   }
   fe inv;
   fe_inv(inv, pref);                                                     // 1 / (product of all 48 Z)
-  for (int e = ODDMUL_PER_THREAD * 3 - 1; e >= 0; e--) {
+  for (int e = PER * 3 - 1; e >= 0; e--) {
     const u32 r = (u32)e / 3u, j = (u32)e % 3u, k = tid + r * nthreads_per;
     const u32 *q = rec((u32)e);
     fe X, Y, Z, pj, zi, zi2, zi3, x, y;

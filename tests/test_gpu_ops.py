@@ -27,6 +27,52 @@ def test_ec_mul_batch(gp):
     assert got == cbind.pack_points(cbind.ec_mul_batch(pts, es))
 
 
+def test_ec_mul_batch_glv_fixed_window_path(gp):
+    """n >= 32 768 takes k_ec_odd_multiples + k_ec_mul_batch_glv (GLV halves, 43 signed odd three-bit digits each, affine
+    3P / 5P / 7P): against the C oracle's ladder on scalars that make a half-scalar 0, 1, even, odd, negative or maximal
+    (0, 1, 2, q - 1, lambda, lambda^2, +-the lattice constants, single bits, 2^b - 1), unreduced ones, identity points, and
+    a size that is not a multiple of anything (slices of 196 608 points; 16 points per table thread)."""
+    lam = 0x5363AD4CC05C30E0A5261C028812645A122E22EA20816678DF02967C1B23BD72
+    a1, mb1 = 0x3086D221A7D46BCDE86C90E49284EB15, 0xE4437ED6010E88286F547FA90ABFE4C3
+    edge = [0, 1, 2, 3, Q - 1, Q - 2, Q // 2, Q // 2 + 1, lam, Q - lam, lam * lam % Q, (lam + 1) % Q, (lam - 1) % Q, 2 * lam % Q, a1, mb1, Q - a1,
+            Q - mb1, Q, Q + 1, (1 << 256) - 1, 1 << 255]
+    edge += [1 << b for b in range(256)] + [(1 << b) - 1 for b in range(2, 257)]
+    edge += [(t * a1 + d) % Q for t in (1, 7, 1 << 64, (1 << 127) + 3) for d in (-1, 0, 1)]
+    n = 32768 + 1111
+    pts, _ = gp.rand_points(n, 41)
+    rnd = random.Random(42)
+    es = [edge[i] if i < len(edge) else rnd.randrange(Q) for i in range(n)]
+    for i in (5, 700, n - 1):
+        pts[i] = INF
+    raw = b"".join(e.to_bytes(32, "little") for e in es)
+    eng = gp.engine()
+    want = cbind.pack_points(cbind.ec_mul_batch(pts, es))
+    got = eng.ec_mul_batch_bytes(cbind.pack_points(pts), raw, n)
+    assert got == want
+    eng.set_option("mul_batch_glv", 0)                   # the bit-serial ladder on the same inputs
+    try:
+        assert eng.ec_mul_batch_bytes(cbind.pack_points(pts), raw, n) == want
+    finally:
+        eng.set_option("mul_batch_glv", 1)
+
+
+@pytest.mark.parametrize("n", [3 * 65536, 3 * 65536 + 1, 400000])
+def test_ec_mul_batch_slices(gp, n):
+    """More than one slice: k_i * G for all i equals the C oracle's values at sampled positions (every slice seam) and the
+    sum of all products equals (sum k_i) * G (an MSM-free check of every element)."""
+    import hashlib
+    eng = gp.engine()
+    ks = b"".join(hashlib.sha256(b"mulb%d" % i).digest() for i in range(n))
+    G64 = cbind.pack_points([gp.G])
+    out = eng.ec_mul_batch_bytes(G64 * n, ks, n)
+    idx = sorted(set([0, 1, 15, 16, 17, 196607, 196608, 196609, n - 1] + [random.Random(n).randrange(n) for _ in range(40)]))
+    idx = [i for i in idx if i < n]
+    want = cbind.ec_mul_batch([gp.G] * len(idx), [int.from_bytes(ks[32 * i: 32 * i + 32], "little") for i in idx])
+    assert [out[64 * i: 64 * i + 64] for i in idx] == [cbind.pack_points([w]) for w in want]
+    total = sum(int.from_bytes(ks[32 * i: 32 * i + 32], "little") for i in range(n)) % Q
+    assert eng.ec_sum_bytes(out, n) == cbind.pack_points(cbind.ec_mul_batch([gp.G], [total]))
+
+
 def test_ec_lincomb2_batch(gp):
     n = 200
     pts, _ = gp.rand_points(2 * n, 5)
