@@ -500,12 +500,18 @@ int bpmi_msm_segs_dev(bpmi_ctx *ctx, uint32_t nseg, const void *const *d_pts, co
 }
 
 // ---- scalar ops -------------------------------------------------------------------------------
-static int sc_dot_dev_to(bpmi_ctx *ctx, const void *d_a, const void *d_b, uint64_t n, u32 *d_out, u32 *d_partial) {
-  const u32 nb = (u32)std::min<uint64_t>((n + 255) / 256, 1024);
+// njobs (1 or 2) inner products of length n in two launches; d_partial: njobs x SC_DOT_MAX_BLOCKS x 32 B
+static int sc_dot_jobs(bpmi_ctx *ctx, const DotJobs &jobs, u32 njobs, uint64_t n, u32 *d_partial) {
+  const u32 nb = (u32)std::min<uint64_t>((n + 255) / 256, SC_DOT_MAX_BLOCKS);
   StageTimer t(ctx, ST_SCDOT);
-  hipLaunchKernelGGL(k_sc_dot, dim3(nb), dim3(256), 0, ctx->stream, (const u32 *)d_a, (const u32 *)d_b, (u32)n, d_partial);
-  hipLaunchKernelGGL(k_sc_sum, dim3(1), dim3(256), 0, ctx->stream, d_partial, nb, d_out);
+  hipLaunchKernelGGL(k_sc_dot, dim3(nb, njobs), dim3(256), 0, ctx->stream, jobs, (u32)n, d_partial);
+  hipLaunchKernelGGL(k_sc_sum, dim3(njobs), dim3(256), 0, ctx->stream, (const u32 *)d_partial, nb, jobs);
   return BPMI_OK;
+}
+static int sc_dot_dev_to(bpmi_ctx *ctx, const void *d_a, const void *d_b, uint64_t n, u32 *d_out, u32 *d_partial) {
+  DotJobs j;
+  j.a[0] = j.a[1] = (const u32 *)d_a; j.b[0] = j.b[1] = (const u32 *)d_b; j.out[0] = j.out[1] = d_out;
+  return sc_dot_jobs(ctx, j, 1, n, d_partial);
 }
 int bpmi_sc_dot_dev(bpmi_ctx *ctx, const void *d_a, const void *d_b, uint64_t n, uint8_t out[32]) {
   if (!ctx || !out || (n && (!d_a || !d_b))) return ctx ? fail(ctx, BPMI_E_ARG, "null argument") : BPMI_E_ARG;
@@ -540,11 +546,13 @@ int bpmi_sc_fold_dev(bpmi_ctx *ctx, const void *d_lo, const void *d_hi, const ui
   if (n > BPMI_MAX_N) return fail(ctx, BPMI_E_ARG, "n exceeds BPMI_MAX_N");
   if (n == 0) return BPMI_OK;
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  Sc2 xy;
-  memcpy(xy.k1, x, 32); memcpy(xy.k2, y, 32);
+  FoldJobs fj;
+  fj.lo[0] = fj.lo[1] = (const u32 *)d_lo; fj.hi[0] = fj.hi[1] = (const u32 *)d_hi; fj.out[0] = fj.out[1] = (u32 *)d_out;
+  memcpy(fj.xy[0].k1, x, 32); memcpy(fj.xy[0].k2, y, 32);
+  fj.xy[1] = fj.xy[0];
   {
     StageTimer t(ctx, ST_SCFOLD);
-    hipLaunchKernelGGL(k_sc_fold, dim3((u32)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const u32 *)d_lo, (const u32 *)d_hi, xy, (u32)n, (u32 *)d_out);
+    hipLaunchKernelGGL(k_sc_fold, dim3((u32)((n + 255) / 256), 1), dim3(256), 0, ctx->stream, fj, (u32)n);
   }
   HIPCHK(ctx, hipGetLastError());
   return BPMI_OK;
@@ -692,7 +700,7 @@ static int ipa_alloc(bpmi_ctx *ctx, uint64_t n, bpmi_ipa **out) {
   if (st->big_m < 32) st->big_m = 32;
   const size_t pts = align_up(64 * n, 256), scs = align_up(32 * n, 256);
   const size_t pts2 = align_up(64 * (n / 16 + 1), 256), coef = align_up(32 * n, 256);
-  const size_t bytes = pts * 2 + pts2 * 2 + scs * 7 + coef * 4 + 256 * 3 + 32 * 1024 + 2 * align_up(sizeof(NafK), 256);
+  const size_t bytes = pts * 2 + pts2 * 2 + scs * 7 + coef * 4 + 256 * 3 + 2 * 32 * SC_DOT_MAX_BLOCKS + 2 * align_up(sizeof(NafK), 256);
   hipError_t e = hipMalloc(&st->block, bytes);
   if (e != hipSuccess) { delete st; return fail(ctx, BPMI_E_NOMEM, std::string("hipMalloc(ipa state): ") + hipGetErrorString(e)); }
   char *p = (char *)st->block;
@@ -712,7 +720,7 @@ static int ipa_alloc(bpmi_ctx *ctx, uint64_t n, bpmi_ipa **out) {
   st->u = (u32 *)p; p += 256;
   st->cl = (u32 *)p; p += 256;
   st->cr = (u32 *)p; p += 256;
-  st->partial = (u32 *)p; p += 32 * 1024;
+  st->partial = (u32 *)p; p += 2 * 32 * SC_DOT_MAX_BLOCKS;
   for (int k = 0; k < 2; k++) { st->nafk[k] = (NafK *)p; p += align_up(sizeof(NafK), 256); }
   // coefficient tables start as [1]
   uint8_t one[32] = {1};
@@ -804,8 +812,12 @@ int bpmi_ipa_round_LR(bpmi_ipa *st, uint8_t L[64], uint8_t R[64]) {
   const uint64_t np = st->n / 2;
   u32 *a_lo = st->a, *a_hi = st->a + 8 * np, *b_lo = st->b, *b_hi = st->b + 8 * np;
   // cl = <a_lo, b_hi>, cr = <a_hi, b_lo>  (inner_product_prover.py:96-97), kept on the device
-  sc_dot_dev_to(ctx, a_lo, b_hi, np, st->cl, st->partial);
-  sc_dot_dev_to(ctx, a_hi, b_lo, np, st->cr, st->partial);
+  {
+    DotJobs dj;
+    dj.a[0] = a_lo; dj.b[0] = b_hi; dj.out[0] = st->cl;
+    dj.a[1] = a_hi; dj.b[1] = b_lo; dj.out[1] = st->cr;
+    sc_dot_jobs(ctx, dj, 2, np, st->partial);                 // both in one pair of launches
+  }
   int rc;
   if (st->d == 0 && !st->hscale) {
     // bases are the current generators: L = <a_lo, g_hi> + <b_hi, h_lo> + cl*u  (:98) as ONE
@@ -829,13 +841,15 @@ int bpmi_ipa_round_LR(bpmi_ipa *st, uint8_t L[64], uint8_t R[64]) {
     u32 logm = 0;
     while ((1ull << logm) < st->n) logm++;
     Segs sg[2];
+    {
+      StageTimer t(ctx, ST_SCFOLD);
+      ExpandOut eo;
+      eo.eg[0] = st->eg; eo.eh[0] = st->eh; eo.eg[1] = st->eg2; eo.eh[1] = st->eh2;
+      hipLaunchKernelGGL(k_ipa_expand, dim3((u32)((st->M + 255) / 256), 2), dim3(256), 0, ctx->stream, st->a, st->b, st->cg[st->cur], st->ch[st->cur],
+                         st->hscale, (u32)st->M, logm, eo);           // the scalars of L and of R in one launch
+    }
     for (int right = 0; right < 2; right++) {
       u32 *eg = right ? st->eg2 : st->eg, *eh = right ? st->eh2 : st->eh;
-      {
-        StageTimer t(ctx, ST_SCFOLD);
-        hipLaunchKernelGGL(k_ipa_expand, dim3((u32)((st->M + 255) / 256)), dim3(256), 0, ctx->stream, st->a, st->b,
-                           st->cg[st->cur], st->ch[st->cur], st->hscale, (u32)st->M, logm, right, eg, eh);
-      }
       // only the non-zero half of every block of m logical positions takes part: for L the
       // upper g-halves and lower h-halves (g_hi with a_lo, h_lo with b_hi), for R the opposite
       sg[right] = segs_init();
@@ -864,10 +878,16 @@ int bpmi_ipa_fold(bpmi_ipa *st, const uint8_t x[32], const uint8_t xinv[32]) {
   const uint64_t np = st->n / 2;
   int rc;
   // a' = x a_lo + x^-1 a_hi ; b' = x^-1 b_lo + x b_hi  (:109-110)
-  rc = bpmi_sc_fold_dev(ctx, st->a, st->a + 8 * np, x, xinv, np, st->a);
-  if (rc) return rc;
-  rc = bpmi_sc_fold_dev(ctx, st->b, st->b + 8 * np, xinv, x, np, st->b);
-  if (rc) return rc;
+  {
+    FoldJobs fj;
+    fj.lo[0] = st->a; fj.hi[0] = st->a + 8 * np; fj.out[0] = st->a;
+    fj.lo[1] = st->b; fj.hi[1] = st->b + 8 * np; fj.out[1] = st->b;
+    memcpy(fj.xy[0].k1, x, 32); memcpy(fj.xy[0].k2, xinv, 32);
+    memcpy(fj.xy[1].k1, xinv, 32); memcpy(fj.xy[1].k2, x, 32);
+    StageTimer t(ctx, ST_SCFOLD);
+    hipLaunchKernelGGL(k_sc_fold, dim3((u32)((np + 255) / 256), 2), dim3(256), 0, ctx->stream, fj, (u32)np);       // a and b in one launch
+  }
+  (void)rc;
   // g' = x^-1 g_lo + x g_hi ; h' = x h_lo + x^-1 h_hi  (:107-108): deferred -- only the
   // coefficient tables double
   const u32 K = 1u << st->d;

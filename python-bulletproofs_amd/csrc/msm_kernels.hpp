@@ -542,7 +542,16 @@ template <bool GLV> __global__ void __launch_bounds__(256) k_accum_l0(Segs segs,
       if (first) { rec_key[2 * t] = cur; xyzz_store_g(rec_pt + (2 * t) * XYZZ_WORDS, acc); first = false; }
       else xyzz_store_g(buckets + (u64)cur * XYZZ_WORDS, acc);
       xyzz_set_inf(acc);
-      do { cur++; boundary = boundary2; boundary2 = off[cur + 2 < g.G ? cur + 2 : g.G]; } while (boundary == j);
+      cur++; boundary = boundary2;
+      if (boundary == j) {
+        // the next bucket is empty: the bucket of sorted position j by bisection over off[] -- the scalars of a range proof
+        // (bits, and one blinding factor per window) leave thousands of empty buckets between two entries, and a walk over
+        // them is one dependent load each (2 ms per MSM at n = 16 385, c = 13)
+        u32 lo = cur + 1u, hi = g.G - 1u;                     // smallest key > cur - 1 with off[key + 1] > j
+        while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (off[mid + 1] > j) hi = mid; else lo = mid + 1u; }
+        cur = lo; boundary = off[cur + 1];
+      }
+      boundary2 = off[cur + 2 < g.G ? cur + 2 : g.G];
     }
     xyzz_madd_signed(acc, P, (e >> 31) != 0);
   }

@@ -236,11 +236,14 @@ __global__ void __launch_bounds__(256) k_ipa_coef_update(const u32 *cg, const u3
 }
 // scalars of the L (right = 0) or R (right = 1) MSM over the unfolded bases:
 //   L = <a_lo, g_hi> + <b_hi, h_lo>,  R = <a_hi, g_lo> + <b_lo, h_hi>   (:98-99)
+// both in one launch: blockIdx.y = right
+struct ExpandOut { u32 *eg[2], *eh[2]; };
 __global__ void __launch_bounds__(256) k_ipa_expand(const u32 *__restrict__ a, const u32 *__restrict__ b, const u32 *__restrict__ cg,
-                                                    const u32 *__restrict__ ch, const u32 *__restrict__ hscale, u32 M, u32 logm, int right,
-                                                    u32 *__restrict__ eg, u32 *__restrict__ eh) {
+                                                    const u32 *__restrict__ ch, const u32 *__restrict__ hscale, u32 M, u32 logm, ExpandOut o) {
   const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= M) return;
+  const int right = (int)blockIdx.y;
+  u32 *__restrict__ eg = o.eg[blockIdx.y], *__restrict__ eh = o.eh[blockIdx.y];
   const u32 m = 1u << logm, half = m >> 1;
   const u32 i = k & (m - 1u), t = k >> logm;
   const bool hi = i >= half;

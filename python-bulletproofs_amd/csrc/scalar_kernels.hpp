@@ -5,9 +5,14 @@
 // ------------------------------------------------------------------------------------
 // scalar kernels
 // ------------------------------------------------------------------------------------
-// partial[b] = sum over the block's stride of a_i * b_i ; then k_sc_dot_final sums partials
-__global__ void __launch_bounds__(256) k_sc_dot(const u32 *__restrict__ a, const u32 *__restrict__ b, u32 n, u32 *__restrict__ partial) {
+// One or two inner products per launch (blockIdx.y = job: the IPA's cl and cr of a round): partial[job][b] = sum over the
+// block's stride of a_i * b_i ; then k_sc_sum adds the partials of every job.
+#define SC_DOT_MAX_BLOCKS 1024
+struct DotJobs { const u32 *a[2], *b[2]; u32 *out[2]; };
+__global__ void __launch_bounds__(256) k_sc_dot(DotJobs jobs, u32 n, u32 *__restrict__ partial_all) {
   __shared__ u32 sh[256 * 8];
+  const u32 *__restrict__ a = jobs.a[blockIdx.y], *__restrict__ b = jobs.b[blockIdx.y];
+  u32 *partial = partial_all + 8u * SC_DOT_MAX_BLOCKS * blockIdx.y;
   sc acc;
 #pragma unroll
   for (int k = 0; k < 8; k++) acc.v[k] = 0;
@@ -33,8 +38,10 @@ __global__ void __launch_bounds__(256) k_sc_dot(const u32 *__restrict__ a, const
   }
   if (threadIdx.x == 0) store_words8(partial + 8ull * blockIdx.x, acc.v);
 }
-__global__ void __launch_bounds__(256) k_sc_sum(const u32 *__restrict__ partial, u32 n, u32 *__restrict__ out) {
+__global__ void __launch_bounds__(256) k_sc_sum(const u32 *__restrict__ partial_all, u32 n, DotJobs jobs) {
   __shared__ u32 sh[256 * 8];
+  const u32 *partial = partial_all + 8u * SC_DOT_MAX_BLOCKS * blockIdx.x;
+  u32 *out = jobs.out[blockIdx.x];
   sc acc;
 #pragma unroll
   for (int k = 0; k < 8; k++) acc.v[k] = 0;
@@ -53,13 +60,16 @@ __global__ void __launch_bounds__(256) k_sc_sum(const u32 *__restrict__ partial,
   }
   if (threadIdx.x == 0) store_words8(out, acc.v);
 }
-// out[i] = x * lo[i] + y * hi[i]
-__global__ void __launch_bounds__(256) k_sc_fold(const u32 *lo, const u32 *hi, Sc2 xy, u32 n, u32 *out) {
+// out[i] = x * lo[i] + y * hi[i]; one or two folds per launch (blockIdx.y = job: the IPA's a and b vectors)
+struct FoldJobs { const u32 *lo[2], *hi[2]; u32 *out[2]; Sc2 xy[2]; };
+__global__ void __launch_bounds__(256) k_sc_fold(FoldJobs jobs, u32 n) {
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  const u32 *lo = jobs.lo[blockIdx.y], *hi = jobs.hi[blockIdx.y];
+  u32 *out = jobs.out[blockIdx.y];
   sc X, Y, a, b, t, s;
 #pragma unroll
-  for (int k = 0; k < 8; k++) { X.v[k] = xy.k1[k]; Y.v[k] = xy.k2[k]; }
+  for (int k = 0; k < 8; k++) { X.v[k] = blockIdx.y ? jobs.xy[1].k1[k] : jobs.xy[0].k1[k]; Y.v[k] = blockIdx.y ? jobs.xy[1].k2[k] : jobs.xy[0].k2[k]; }
   load_words8(a.v, lo + 8ull * i);
   load_words8(b.v, hi + 8ull * i);
   sc_mul(t, X, a);

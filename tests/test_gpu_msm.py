@@ -271,7 +271,7 @@ def test_msm2_pairs(gp):
 
 
 @pytest.mark.parametrize("n", [40000, 30000])      # window bits 16, and 13 (the size range 10 240 .. 2^15: a short top window, always heavy)
-@pytest.mark.parametrize("shape", ["all_same", "two_values", "bits01", "small_range"])
+@pytest.mark.parametrize("shape", ["all_same", "two_values", "bits01", "bits_and_blinding", "small_range"])
 def test_msm_heavy_partitions(gp, shape, n):
     """Skewed digit distributions on the LDS-sort path: partitions with more than 12 288 entries
     are counted and scattered by the tile kernels (k_fine_hist_heavy / k_fine_scatter_heavy) instead of
@@ -287,6 +287,10 @@ def test_msm_heavy_partitions(gp, shape, n):
         es = [vals[rnd.randrange(2)] for _ in range(n)]
     elif shape == "bits01":                       # the aL / aR vectors of a range proof
         es = [rnd.randrange(2) for _ in range(n // 2)] + [(rnd.randrange(2) - 1) % Q for _ in range(n - n // 2)]
+    elif shape == "bits_and_blinding":            # ... with a few full-size scalars: long runs of EMPTY buckets between entries (bisection in k_accum_l0)
+        es = [rnd.randrange(2) for _ in range(n // 2)] + [(rnd.randrange(2) - 1) % Q for _ in range(n - n // 2)]
+        for i in range(0, n, 4099):
+            es[i] = rnd.randrange(Q)
     else:
         es = [rnd.randrange(1 << 20) if i % 3 else rnd.randrange(Q) for i in range(n)]
     pb, sb = cbind.pack_points(pts), cbind.pack_scalars(es)

@@ -73,6 +73,19 @@ while time.time() - t0 < budget:
         k1, k2 = special_scalar(), special_scalar()
         got = eng.ec_lincomb2_batch_bytes(cbind.pack_points(p1), cbind.pack_points(p2), le(k1), le(k2), n)
         check(got == cbind.pack_points(cbind.ec_lincomb2_batch(p1, p2, k1, k2)), "lincomb2 n=%d" % n)
+    elif op == 2 and rnd.random() < 0.04:    # mul batch, the GLV fixed-window path (n >= 32 768): against the bit-serial ladder + oracle samples
+        lam = 0x5363AD4CC05C30E0A5261C028812645A122E22EA20816678DF02967C1B23BD72
+        n = rnd.randrange(32768, 70000)
+        ps = [rnd.choice(pool) if rnd.random() > 0.01 else INF for _ in range(n)]
+        ks = [rnd.choice((special_scalar(), (special_scalar() * lam + special_scalar()) % Q, rnd.randrange(Q), (1 << rnd.randrange(256)) % Q)) for _ in range(n)]
+        pb, kb = cbind.pack_points(ps), cbind.pack_scalars(ks)
+        got = eng.ec_mul_batch_bytes(pb, kb, n)
+        eng.set_option("mul_batch_glv", 0)
+        ref = eng.ec_mul_batch_bytes(pb, kb, n)
+        eng.set_option("mul_batch_glv", 1)
+        idx = [rnd.randrange(n) for _ in range(64)]
+        want = cbind.pack_points(cbind.ec_mul_batch([ps[i] for i in idx], [ks[i] for i in idx]))
+        check(got == ref and b"".join(got[64 * i: 64 * i + 64] for i in idx) == want, "mul_batch glv n=%d" % n)
     elif op == 2:    # mul batch
         n = rnd.randrange(1, 400)
         ps = [rnd.choice(pool) if rnd.random() > 0.05 else INF for _ in range(n)]
