@@ -104,9 +104,13 @@ def launch_ranks(args, argv):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)       # 0.2 s of timed MSMs: the fill and the drain of the two-deep pipeline are 1 % of it
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--logn", type=int, default=20)
+    ap.add_argument("--preheat-ms", type=float, default=120.0,
+                    help="untimed MSM steps for this long BEFORE the warm-up steps (and before every extra's timed region): after the "
+                         "host-side input setup the GPU sits at idle clocks and needs ~40 steps (45 ms) to reach its steady ones "
+                         "(tools/step_ramp.py, profiles/r03_clock_ramp_after_idle.txt); 0 = none")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the C5 / C3 extra measurements")
@@ -237,9 +241,21 @@ def main():
             res = sharded.combine_wait(pending)
         return res
 
+    def preheat():
+        """Untimed: the same pipelined steps for --preheat-ms (the clocks ramp over ~45 ms of work after an idle second)."""
+        if args.preheat_ms <= 0:
+            return
+        t_h = time.perf_counter()
+        while (time.perf_counter() - t_h) * 1e3 < args.preheat_ms:
+            eng.msm_dev_enqueue(0, d_pts, d_sc, n)
+            eng.msm_dev_enqueue(1, d_pts, d_sc, n)
+            eng.msm_finish(0)
+            eng.msm_finish(1)
+    preheat()
     result = run_steps(args.warmup)
     host_t[:] = [0.0, 0.0, 0.0, 0.0, 0]
-    eng.profile(2)              # HIP events around the dominant kernel only: each recorded event is a ~10 us bubble
+    if not os.environ.get("BENCH_NO_KERNEL_EVENTS"):       # (experiments only: what the two events per step cost)
+        eng.profile(2)          # HIP events around the dominant kernel only: each recorded event is a ~10 us bubble
     eng.profile_reset()
     barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -328,6 +344,7 @@ def main():
                          "peak_source": "profiles/r01_fe_microbench.txt (V8: the product's own fe_mul in isolation; NOT a hardware peak)"},
         "stage_ms_per_msm": stages,
         "hip_event_ms_per_step": ev_ms / args.steps,
+        "preheat_ms": args.preheat_ms,
         "host_ms_per_step": host_ms,
         "input_setup_s": round(t_in, 2),
         "result_x_lo": result[:8].hex(),
@@ -468,7 +485,8 @@ def extra_c5(eng, world, rank, dev, log_batch=14, distinct=1024, per_gpu=False):
             return part == bytes(64)
         return finish(part)
 
-    one_batch()                                        # warm (workspaces, pinned buffers)
+    for _ in range(4):                                 # warm: workspaces, pinned buffers, and the clocks (a batch is ~2 ms of GPU work)
+        one_batch()
     if dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize(dev)
@@ -511,8 +529,9 @@ def extra_c5(eng, world, rank, dev, log_batch=14, distinct=1024, per_gpu=False):
     pipe_batches = 16 * inflight
     lanes = [ThreadPoolExecutor(1) for _ in range(inflight)]                         # one thread per slot: a slot never runs two batches at once
     try:
-        for f in [lanes[i].submit(local_partial, i) for i in range(inflight)]:       # warm every slot
-            finish(f.result())
+        for _ in range(4):                                                            # warm every slot, and ~40 ms of this very load for the clocks
+            for f in [lanes[i].submit(local_partial, i) for i in range(inflight)]:
+                finish(f.result())
         if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize(dev)
@@ -622,21 +641,24 @@ def extra_c2(eng, world, rank, dev, d_pts, d_sc, n, dlog, G64):
     import torch
     expect = eng.ec_mul_batch_bytes(G64, dlog.to_bytes(32, "little"), 1)
     got = eng.msm_dev(d_pts, d_sc, n)
-    for _ in range(5):
-        eng.msm_dev(d_pts, d_sc, n)
-    torch.cuda.synchronize(dev)
-    reps = 200
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        eng.msm_dev(d_pts, d_sc, n)
-    sync_s = (time.perf_counter() - t0) / reps
-    eng.msm_dev_enqueue(0, d_pts, d_sc, n)
-    t0 = time.perf_counter()
-    for j in range(reps):
-        if j + 1 < reps:
-            eng.msm_dev_enqueue((j + 1) & 1, d_pts, d_sc, n)
-        eng.msm_finish(j & 1)
-    pipe_s = (time.perf_counter() - t0) / reps
+    def measure():
+        for _ in range(150):             # warm: ~60 ms of this very load (clocks; tools/step_ramp.py)
+            eng.msm_dev(d_pts, d_sc, n)
+        torch.cuda.synchronize(dev)
+        reps = 200
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            eng.msm_dev(d_pts, d_sc, n)
+        sync = (time.perf_counter() - t0) / reps
+        eng.msm_dev_enqueue(0, d_pts, d_sc, n)
+        t0 = time.perf_counter()
+        for j in range(reps):
+            if j + 1 < reps:
+                eng.msm_dev_enqueue((j + 1) & 1, d_pts, d_sc, n)
+            eng.msm_finish(j & 1)
+        return sync, (time.perf_counter() - t0) / reps
+
+    sync_s, pipe_s = measure()
     eng.profile(1)
     eng.profile_reset()
     for _ in range(10):
@@ -695,7 +717,8 @@ def extra_c3(eng, world, rank, dev, logn=20):
         dt = time.perf_counter() - t0
         return dt, pr
 
-    prove(False)                         # warm
+    prove(False)                         # warm: workspaces
+    prove(False)                         # ... and clocks
     if dist.is_initialized():
         dist.barrier()
     times = []

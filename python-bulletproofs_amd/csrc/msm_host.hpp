@@ -145,6 +145,7 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, int slot, const Segs &segs_in, u
   // (profiles/r02_chunk_sweep_two_lanes.txt)
   g.L = ctx->opt_chunk > 0 ? (u32)ctx->opt_chunk : (n >= (1u << 19) ? (ctx->chain_accum ? 86u : 64u) : (n >= (1u << 18) ? 32u : 16u));
   g.nv = (g.B <= 256u) ? 1u : 4u;                  // partial sums per window handed to the tail
+  g.prio = ctx->opt_prio ? 1u : 0u;
   MsmWs w;
   msm_layout(g, w, nullptr, glv);
   int rc = ensure_lane(ctx, lane);
@@ -280,11 +281,13 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, int slot, const Segs &segs_in, u
       u32 epl = ctx->opt_epl > 0 ? (u32)ctx->opt_epl : (u32)(((uint64_t)g.W * g.B) >> 15);
       epl = epl < 2u ? 2u : (epl > 16u ? 16u : epl);
       DigitJobs j1 = digit_jobs2(g.W, 0, g.B, g.B, s0, 0, stride1, epl);
+      j1.prio = g.prio;
       hipLaunchKernelGGL(k_digit_sums, dim3(j1.j[j1.njobs - 1].blk0 + digit_job_blocks(j1, j1.njobs - 1)), dim3(256), 0, st, w.buckets, w.D, j1);
       // stage 2: D0 -> (D00, D01), D1 -> (D10, D11), each <= 16 sums of <= 16 elements, and E[a][r] = sum_d d * D..[d]
       DigitJobs ja = digit_jobs2(g.W, 0, stride1, N0, t0, 0, 64, 1);
       DigitJobs jb = digit_jobs2(g.W, N0, stride1, N1, t1, 0, 64, 1);
       DigitJobs j2 = digit_jobs_concat(ja, jb);
+      j2.prio = g.prio;
       hipLaunchKernelGGL(k_digit_final, dim3(g.W * 4u), dim3(256), 0, st, w.D, w.E, j2);
       to.nv = 4; to.off[0] = 0; to.off[1] = t0; to.off[2] = s0; to.off[3] = s0 + t1;
     }

@@ -14,7 +14,14 @@ struct MsmGeom {
   u32 G;       // W * B
   u32 L;       // entries per thread in k_accum_l0
   u32 nv;      // partial sums per window that the bucket reduction hands to the tail (1 or 4)
+  u32 prio;    // 1: every kernel but the accumulation raises its waves' issue priority (see raise_priority)
 };
+// Experiment (option "priority", default off; profiles/r03_wave_priority_ab.txt).  The stages around the accumulation are chains
+// of dependent work with few waves; beside the OTHER lane's accumulation (three busy waves on every SIMD) they stretch three- to
+// five-fold (k_digit_final: 66 us alone, 320 us beside k_accum_l0).  Raising their waves' issue priority with s_setprio was
+// expected to bring the lane behind them to its own accumulation sooner; measured, two MSMs in flight get 2.6 % (2^20) to
+// 6 % (2^16) SLOWER -- the accumulation's waves lose more than the chains gain.
+__device__ __forceinline__ void raise_priority(u32 on) { if (on) __builtin_amdgcn_s_setprio(3); }
 
 // Signed-digit recoding of scalar i: calls f(w, b, sign) for every window, b = |digit|
 // in [0, B] (0 = nothing to add), sign = 1 when the NEGATED point is added.
@@ -106,6 +113,7 @@ __global__ void __launch_bounds__(256) k_glv_prepare(Segs segs, u32 n, u32 *__re
 // dig[w * n + i] = |d| | (sign << 31); histogram with one atomic per lane, or one per wave
 // when the whole wave agrees (degenerate inputs)
 __global__ void __launch_bounds__(256) k_digits_hist(Segs segs, MsmGeom g, u32 *__restrict__ dig, u32 *__restrict__ hist) {
+  raise_priority(g.prio);
   const u32 stride = gridDim.x * blockDim.x;
   for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < g.n; i += stride) {
     for_each_digit(segs, g, i, [&](u32 w, u32 b, u32 sign) {
@@ -140,6 +148,7 @@ __global__ void __launch_bounds__(256) k_digits_hist(Segs segs, MsmGeom g, u32 *
 #define DIG_NONE 0xFFFFu
 __global__ void __launch_bounds__(256) k_coarse_hist(Segs segs, MsmGeom g, u32 P, u32 *__restrict__ coarse_hist, unsigned short *__restrict__ dig16,
                                                      unsigned char *__restrict__ negs) {
+  raise_priority(g.prio);
   __shared__ u32 lh[PART_MAX];
   for (u32 p = threadIdx.x; p < P; p += 256u) lh[p] = 0;
   __syncthreads();
@@ -189,6 +198,7 @@ __global__ void __launch_bounds__(1024) k_coarse_scan(const u32 *__restrict__ co
 __global__ void __launch_bounds__(1024) k_partition(MsmGeom g, u32 P, u32 TS, const u32 *__restrict__ coarse_off, u32 *__restrict__ coarse_cursor,
                                                     const unsigned short *__restrict__ dig16, const unsigned char *__restrict__ negs,
                                                     u32 *__restrict__ part, u32 *__restrict__ fine_hist, u32 *__restrict__ any_heavy) {
+  raise_priority(g.prio);
   __shared__ u32 cnt[128], excl[128], delta[128];
   __shared__ u32 s_out[PT_MAX];
   const u32 Bc = g.B >> 8, w = blockIdx.y, tid = threadIdx.x;
@@ -272,6 +282,7 @@ __device__ __forceinline__ void fill_chunk_keys(u32 *__restrict__ chunk_key, u32
 __global__ void __launch_bounds__(FINE_THREADS) k_fine_sort_part(MsmGeom g, const u32 *__restrict__ coarse_off, const u32 *__restrict__ part,
                                                                   const u32 *__restrict__ fine_hist, u32 *__restrict__ off, u32 *__restrict__ cursor,
                                                                   u32 *__restrict__ chunk_key, u32 *__restrict__ sidx, u32 *__restrict__ buckets) {
+  raise_priority(g.prio);
   __shared__ u32 bins[256];
   __shared__ u32 s_out[FINE_CAP];
   const u32 p = blockIdx.x, tid = threadIdx.x;
@@ -345,6 +356,7 @@ __device__ __forceinline__ FineTile fine_tile_setup(const u32 *__restrict__ coar
 }
 __global__ void __launch_bounds__(256) k_fine_hist_heavy(MsmGeom g, u32 P, const u32 *__restrict__ coarse_off, const u32 *__restrict__ part,
                                                          const u32 *__restrict__ offE, const u32 *__restrict__ any_heavy, u32 *__restrict__ fine_hist) {
+  raise_priority(g.prio);
   __shared__ u32 s_off[PART_MAX + 1];
   __shared__ u32 bins[FINE_BINS];
   if (!*any_heavy) return;
@@ -370,6 +382,7 @@ __global__ void __launch_bounds__(256) k_fine_hist_heavy(MsmGeom g, u32 P, const
 __global__ void __launch_bounds__(256) k_fine_scatter_heavy(MsmGeom g, u32 P, const u32 *__restrict__ coarse_off, const u32 *__restrict__ part,
                                                             const u32 *__restrict__ offE, const u32 *__restrict__ any_heavy, u32 *__restrict__ cursor,
                                                             u32 *__restrict__ sidx) {
+  raise_priority(g.prio);
   __shared__ u32 s_off[PART_MAX + 1];
   __shared__ u32 bins[FINE_BINS];
   if (!*any_heavy) return;
@@ -407,6 +420,7 @@ __global__ void __launch_bounds__(256) k_fine_scatter_heavy(MsmGeom g, u32 P, co
 }
 // path 1 equivalent of the chunk-key fill: one thread per bucket
 __global__ void __launch_bounds__(256) k_chunk_keys(MsmGeom g, const u32 *__restrict__ off, u32 *__restrict__ chunk_key) {
+  raise_priority(g.prio);
   const u32 key = blockIdx.x * blockDim.x + threadIdx.x;
   const bool valid = key < g.G;
   const u32 lo = valid ? off[key] : 0u, hi = valid ? off[key + 1] : 0u;
@@ -477,6 +491,7 @@ __global__ void __launch_bounds__(256) k_scan_final(const u32 *__restrict__ hist
 // ---- counting-sort scatter (path 1) ---------------------------------------------------
 __global__ void __launch_bounds__(256) k_scatter(MsmGeom g, const u32 *__restrict__ dig, u32 *__restrict__ cursor,
                                                  u32 *__restrict__ sidx) {
+  raise_priority(g.prio);
   const u32 stride = gridDim.x * blockDim.x;
   for (u32 w = 0; w < g.W; w++) {
     for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < g.n; i += stride) {
@@ -544,12 +559,17 @@ template <bool GLV> __global__ void __launch_bounds__(256) k_accum_l0(Segs segs,
       xyzz_set_inf(acc);
       cur++; boundary = boundary2;
       if (boundary == j) {
-        // the next bucket is empty: the bucket of sorted position j by bisection over off[] -- the scalars of a range proof
-        // (bits, and one blinding factor per window) leave thousands of empty buckets between two entries, and a walk over
-        // them is one dependent load each (2 ms per MSM at n = 16 385, c = 13)
-        u32 lo = cur + 1u, hi = g.G - 1u;                     // smallest key > cur - 1 with off[key + 1] > j
-        while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (off[mid + 1] > j) hi = mid; else lo = mid + 1u; }
-        cur = lo; boundary = off[cur + 1];
+        // empty buckets ahead.  Uniform digits leave one or two (2 entries per bucket on average at n = 2^16: a walk of a load
+        // or two); the scalars of a range proof (bits, and one blinding factor per window) leave THOUSANDS between two entries,
+        // and a walk over those is one dependent load each (2 ms per MSM at n = 16 385, c = 13): after eight steps, bisect
+        // off[] for the bucket of sorted position j.  (Bisecting at once costs the common case 19 loads: 0.09 -> 0.14 ms at 2^16.)
+        u32 steps = 0;
+        do { cur++; boundary = off[cur + 1]; steps++; } while (boundary == j && steps < 8u);
+        if (boundary == j) {
+          u32 lo = cur + 1u, hi = g.G - 1u;                   // smallest key > cur with off[key + 1] > j
+          while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (off[mid + 1] > j) hi = mid; else lo = mid + 1u; }
+          cur = lo; boundary = off[cur + 1];
+        }
       }
       boundary2 = off[cur + 2 < g.G ? cur + 2 : g.G];
     }
@@ -581,6 +601,7 @@ __device__ __forceinline__ u32 records_at_level(u32 E, u32 L, int level, bool &i
 __global__ void __launch_bounds__(256) k_segscan(MsmGeom g, const u32 *__restrict__ off, int level,
                                                  const u32 *__restrict__ in_key, const u32 *__restrict__ in_pt,
                                                  u32 *__restrict__ out_key, u32 *__restrict__ out_pt, u32 *__restrict__ buckets) {
+  raise_priority(g.prio);
   __shared__ u32 s_key[256];
   __shared__ u32 s_val[256 * LDS_STRIDE];
   bool is_final;
@@ -663,7 +684,7 @@ struct DigitJob {
   u32 out_off, out_stride;   // sum idx (1-based) of array a -> record a * out_stride + out_off + idx - 1 of D
   u32 blk0;                  // first block of this job
 };
-struct DigitJobs { DigitJob j[4]; u32 njobs, cnt; };
+struct DigitJobs { DigitJob j[4]; u32 njobs, cnt, prio; };
 
 __device__ __forceinline__ void xyzz_shfl_xor(xyzz &r, const xyzz &a, int mask) {
 #pragma unroll
@@ -685,6 +706,7 @@ __device__ __forceinline__ void xyzz_shfl_down16(xyzz &r, const xyzz &a, int d) 
 }
 
 __global__ void __launch_bounds__(256) k_digit_sums(const u32 *__restrict__ X, u32 *__restrict__ D, DigitJobs jobs) {
+  raise_priority(jobs.prio);
   u32 ji = 0;
   for (u32 k = 1; k < jobs.njobs; k++) if (blockIdx.x >= jobs.j[k].blk0) ji = k;
   const DigitJob J = jobs.j[ji];
@@ -723,6 +745,7 @@ __global__ void __launch_bounds__(256) k_digit_sums(const u32 *__restrict__ X, u
 // sums into sum_d d * X[d]: inclusive suffix scan (4 steps), then the sum of all suffixes (4 steps).  E[a][r] out.  Saves a launch and the trip of 64 records per window
 // through HBM on a path that is nothing but latency.
 __global__ void __launch_bounds__(256) k_digit_final(const u32 *__restrict__ X, u32 *__restrict__ Eout, DigitJobs jobs) {
+  raise_priority(jobs.prio);
   __shared__ u32 s_val[16 * LDS_STRIDE];
   const u32 a = blockIdx.x >> 2, r = blockIdx.x & 3u, tid = threadIdx.x;
   const DigitJob J = jobs.j[r];
@@ -774,6 +797,7 @@ __global__ void __launch_bounds__(256) k_digit_final(const u32 *__restrict__ X, 
 // 2 log2(B) dependent additions) -- shorter than the digit-sum stages when B is small.
 // Eout[w] then has nv = 1.
 __global__ void __launch_bounds__(256) k_window_weighted_small(MsmGeom g, const u32 *__restrict__ buckets, u32 *__restrict__ Eout) {
+  raise_priority(g.prio);
   __shared__ u32 s_val[256 * LDS_STRIDE];
   const u32 tid = threadIdx.x, w = blockIdx.x;
   xyzz val;

@@ -12,9 +12,9 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocm-smi --showclocks --showpower > $OUT/rocm_smi_before.txt 2>&1
 B="python3 $R/bench.py --no-cpu-baseline --no-extra --soak-seconds 0"
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_bench -- $B --steps 10 --warmup 2 > $OUT/bench_under_rocprofv3.json 2> $OUT/stats_bench.err
-timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_FETCH_SIZE -- $B --steps 3 --warmup 1 > $OUT/pmc_fetch.log 2>&1
-timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_WRITE_SIZE -- $B --steps 3 --warmup 1 > $OUT/pmc_write.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_bench -- $B --steps 20 --warmup 3 --preheat-ms 60 > $OUT/bench_under_rocprofv3.json 2> $OUT/stats_bench.err
+timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_FETCH_SIZE -- $B --steps 3 --warmup 1 --preheat-ms 0 > $OUT/pmc_fetch.log 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_WRITE_SIZE -- $B --steps 3 --warmup 1 --preheat-ms 0 > $OUT/pmc_write.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c3 -- python3 $R/tools/bench_ipa_sharded.py 20 > $OUT/c3.json 2> $OUT/stats_c3.err
 export C5_PINNED=1 C5_PREPARE=device C5_ONECALL=1          # the batch verifier's one-call path on a page-locked receive buffer
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c5 -- python3 $R/tools/profile_c5.py > $OUT/c5.txt 2> $OUT/stats_c5.err
