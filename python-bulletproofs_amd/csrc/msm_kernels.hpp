@@ -354,6 +354,14 @@ __device__ __forceinline__ FineTile fine_tile_setup(const u32 *__restrict__ coar
   t.p_first = lo;
   return t;
 }
+// the partition that holds position j (> the current one's range): bisection over the offsets in LDS -- a walk costs one
+// step per EMPTY partition, and a range proof's commitment scalars (one giant partition, then 2000 nearly empty ones) made
+// every thread of every tile walk them all (0.2 ms of the sort at n = 2^16)
+__device__ __forceinline__ u32 fine_partition_of(const u32 *s_off, u32 P, u32 pcur, u32 j) {
+  u32 lo = pcur + 1u, hi = P - 1u;                  // smallest p > pcur with s_off[p + 1] > j   (j < s_off[P])
+  while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (s_off[mid + 1] > j) hi = mid; else lo = mid + 1u; }
+  return lo;
+}
 __global__ void __launch_bounds__(256) k_fine_hist_heavy(MsmGeom g, u32 P, const u32 *__restrict__ coarse_off, const u32 *__restrict__ part,
                                                          const u32 *__restrict__ offE, const u32 *__restrict__ any_heavy, u32 *__restrict__ fine_hist) {
   raise_priority(g.prio);
@@ -369,7 +377,7 @@ __global__ void __launch_bounds__(256) k_fine_hist_heavy(MsmGeom g, u32 P, const
   u32 pcur = t.p_first, bound = s_off[pcur + 1];
   bool heavy = bound - s_off[pcur] > FINE_CAP;
   for (u32 j = t.j0 + threadIdx.x; j < t.j1; j += 256u) {
-    while (j >= bound) { pcur++; bound = s_off[pcur + 1]; heavy = bound - s_off[pcur] > FINE_CAP; }
+    if (j >= bound) { pcur = fine_partition_of(s_off, P, pcur, j); bound = s_off[pcur + 1]; heavy = bound - s_off[pcur] > FINE_CAP; }
     if (heavy) {
       const u32 key = pcur * 256u + (part[j] >> 24);
       const u32 rel = key - g_first;
@@ -395,7 +403,7 @@ __global__ void __launch_bounds__(256) k_fine_scatter_heavy(MsmGeom g, u32 P, co
   u32 pcur = t.p_first, bound = s_off[pcur + 1];
   bool heavy = bound - s_off[pcur] > FINE_CAP;
   for (u32 j = t.j0 + threadIdx.x; j < t.j1; j += 256u) {
-    while (j >= bound) { pcur++; bound = s_off[pcur + 1]; heavy = bound - s_off[pcur] > FINE_CAP; }
+    if (j >= bound) { pcur = fine_partition_of(s_off, P, pcur, j); bound = s_off[pcur + 1]; heavy = bound - s_off[pcur] > FINE_CAP; }
     if (heavy) {
       const u32 rel = pcur * 256u + (part[j] >> 24) - g_first;
       if (rel < FINE_BINS) atomicAdd(&bins[rel], 1u);
@@ -408,7 +416,7 @@ __global__ void __launch_bounds__(256) k_fine_scatter_heavy(MsmGeom g, u32 P, co
   pcur = t.p_first; bound = s_off[pcur + 1];
   heavy = bound - s_off[pcur] > FINE_CAP;
   for (u32 j = t.j0 + threadIdx.x; j < t.j1; j += 256u) {
-    while (j >= bound) { pcur++; bound = s_off[pcur + 1]; heavy = bound - s_off[pcur] > FINE_CAP; }
+    if (j >= bound) { pcur = fine_partition_of(s_off, P, pcur, j); bound = s_off[pcur + 1]; heavy = bound - s_off[pcur] > FINE_CAP; }
     if (heavy) {
       const u32 e = part[j];
       const u32 key = pcur * 256u + (e >> 24);
