@@ -141,9 +141,18 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, int slot, const Segs &segs_in, u
   g.w0 = w0;
   g.B = 1u << (g.c - 1);
   g.G = g.W * g.B;
-  // tools/tune_msm.py sweeps; on the two-lane pipeline 86 entries per thread fill the 3 waves per SIMD exactly once at n = 2^20
-  // (profiles/r02_chunk_sweep_two_lanes.txt)
-  g.L = ctx->opt_chunk > 0 ? (u32)ctx->opt_chunk : (n >= (1u << 19) ? (ctx->chain_accum ? 86u : 64u) : (n >= (1u << 18) ? 32u : 16u));
+  // tools/tune_msm.py sweeps.  On the two-lane pipeline the accumulation is sized in whole rounds of TWO waves per SIMD (2048 waves):
+  // it could hold three (151 VGPRs), and alone it is 4 % faster with three (L = 86 at n = 2^20), but two leave the register file
+  // one 144-VGPR wave of the OTHER lane's segmented scan / bucket reduction needs, which otherwise wait for the accumulation to
+  // drain: 1.008 against 1.024-1.038 ms per step at steady clocks; anything between the quantisation points is far worse (L = 120:
+  // 1.21) -- profiles/r03_chunk_sweep_steady_clocks.txt (round 2, in the clock ramp, had 86: profiles/r02_chunk_sweep_two_lanes.txt)
+  u32 L_lanes = 86u;
+  {
+    const uint64_t per_round = 64ull * 2048ull, e_max = (uint64_t)g.W * n;
+    const uint64_t m = std::max<uint64_t>(1, (e_max + per_round * 56) / (per_round * 112));      // rounds: chunks of about 112 entries
+    L_lanes = (u32)std::max<uint64_t>(64, (e_max + per_round * m - 1) / (per_round * m));
+  }
+  g.L = ctx->opt_chunk > 0 ? (u32)ctx->opt_chunk : (n >= (1u << 19) ? (ctx->chain_accum ? L_lanes : 64u) : (n >= (1u << 18) ? 32u : 16u));
   g.nv = (g.B <= 256u) ? 1u : 4u;                  // partial sums per window handed to the tail
   g.prio = ctx->opt_prio ? 1u : 0u;
   MsmWs w;
