@@ -141,18 +141,27 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, int slot, const Segs &segs_in, u
   g.w0 = w0;
   g.B = 1u << (g.c - 1);
   g.G = g.W * g.B;
-  // tools/tune_msm.py sweeps.  On the two-lane pipeline the accumulation is sized in whole rounds of TWO waves per SIMD (2048 waves):
-  // it could hold three (151 VGPRs), and alone it is 4 % faster with three (L = 86 at n = 2^20), but two leave the register file
-  // one 144-VGPR wave of the OTHER lane's segmented scan / bucket reduction needs, which otherwise wait for the accumulation to
-  // drain: 1.008 against 1.024-1.038 ms per step at steady clocks; anything between the quantisation points is far worse (L = 120:
-  // 1.21) -- profiles/r03_chunk_sweep_steady_clocks.txt (round 2, in the clock ramp, had 86: profiles/r02_chunk_sweep_two_lanes.txt)
-  u32 L_lanes = 86u;
+  // tools/tune_msm.py sweeps; on the two-lane pipeline 86 entries per thread fill the 3 waves per SIMD exactly once at n = 2^20
+  // (profiles/r02_chunk_sweep_two_lanes.txt).  Round 3, at steady clocks (profiles/r03_chunk_sweep_steady_clocks.txt,
+  // r03_chunk_length_vs_kernel_events.txt): L = 128 -- one round of TWO waves per SIMD, room for a 144-VGPR wave of the other lane's
+  // segmented scan / bucket reduction -- measures 0.99-1.01 ms per step against 1.04 under bench.py, but ONLY there: the HIP events
+  // bench.py records around this kernel change the interleaving of the two lanes, and without them (every other caller) L = 128
+  // costs 1.19 ms against 1.04.  86 stays; anything between the quantisation points is far worse (L = 120: 1.21).
+  const u32 L_lanes = 86u;
+  // One MSM at a time (and the pairs of the IPA): the accumulation as ONE round of three waves per SIMD (3072 waves) from the size
+  // where that leaves chunks of 20 entries, one round of two below (a chunk is a chain of dependent additions and every chunk
+  // costs a pair of partial records), never fewer than 8 entries, at most 64.  Powers of two missed the quantisation points:
+  // 311 427 pairs at L = 32 are 2 433 waves -- a third round for a fifth of the chip, 0.635 ms against 0.590 at L = 26
+  // (profiles/r03_chunk_sweep_wave_quantisation.txt).
+  u32 L_one = 64u;
   {
-    const uint64_t per_round = 64ull * 2048ull, e_max = (uint64_t)g.W * n;
-    const uint64_t m = std::max<uint64_t>(1, (e_max + per_round * 56) / (per_round * 112));      // rounds: chunks of about 112 entries
-    L_lanes = (u32)std::max<uint64_t>(64, (e_max + per_round * m - 1) / (per_round * m));
+    const uint64_t e_max = (uint64_t)g.W * n;
+    auto chunks_for = [&](uint64_t waves) { return (u32)((e_max * 1000 + 64 * waves * 1005 - 1) / (64 * waves * 1005)); };   // 0.5 % over is no extra round
+    const u32 l3 = chunks_for(3072), l2 = chunks_for(2048);
+    L_one = l3 >= 20u ? l3 : (l2 < 8u ? 8u : l2);
+    if (L_one > 64u) L_one = 64u;
   }
-  g.L = ctx->opt_chunk > 0 ? (u32)ctx->opt_chunk : (n >= (1u << 19) ? (ctx->chain_accum ? L_lanes : 64u) : (n >= (1u << 18) ? 32u : 16u));
+  g.L = ctx->opt_chunk > 0 ? (u32)ctx->opt_chunk : ((n >= (1u << 19) && ctx->chain_accum) ? L_lanes : L_one);
   g.nv = (g.B <= 256u) ? 1u : 4u;                  // partial sums per window handed to the tail
   g.prio = ctx->opt_prio ? 1u : 0u;
   MsmWs w;

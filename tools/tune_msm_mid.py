@@ -38,12 +38,18 @@ for n in sizes:
             r = eng.msm_dev(d_p, d_s, n)
             ref = ref or r
             assert r == ref, (n, c, chunk)
-            reps = 40
-            for _ in range(3): eng.msm_dev(d_p, d_s, n)
+            reps = int(os.environ.get("TUNE_REPS", "40"))
+            t_h = time.perf_counter()
+            while time.perf_counter() - t_h < float(os.environ.get("TUNE_PREHEAT_S", "0.06")):      # steady clocks (tools/step_ramp.py)
+                eng.msm_dev(d_p, d_s, n)
             t = time.perf_counter()
             for _ in range(reps): eng.msm_dev(d_p, d_s, n)
             dt = (time.perf_counter() - t) / reps
             eng.set_option("async_lanes", 1)
+            for j in range(10):
+                eng.msm_dev_enqueue(j & 1, d_p, d_s, n)
+                if j: eng.msm_finish((j - 1) & 1)
+            eng.msm_finish(1)
             eng.msm_dev_enqueue(0, d_p, d_s, n)
             t = time.perf_counter()
             for j in range(reps):
