@@ -526,7 +526,7 @@ def extra_c5(eng, world, rank, dev, log_batch=14, distinct=1024, per_gpu=False):
                 errors.append("%s: %s" % (type(e).__name__, e))
             return None
 
-    pipe_batches = 16 * inflight
+    pipe_batches = 32 * inflight                                                     # ~0.3 s of batches: run to run the figure moves by +-5 % (tools/c5_inflight_sweep.sh)
     lanes = [ThreadPoolExecutor(1) for _ in range(inflight)]                         # one thread per slot: a slot never runs two batches at once
     try:
         for _ in range(4):                                                            # warm every slot, and ~40 ms of this very load for the clocks
