@@ -234,12 +234,14 @@ int bpmi_msm_dev_enqueue(bpmi_ctx *ctx, int slot, const void *d_pts, const void 
     rc = ensure_lane(ctx, 1);
     if (rc) return rc;
   }
-  if (lane == 1) {
-    if (!ctx->async_lane1_ordered) {       // order lane 1 after whatever produced the inputs on the ctx stream, once per idle period
-      HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
-      HIPCHK(ctx, hipStreamWaitEvent(ctx->stream1, ctx->ev_fork, 0));
-      ctx->async_lane1_ordered = true;
-    }
+  if (ctx->opt_async_lanes && !ctx->async_lane1_ordered) {
+    // order lane 1 after whatever produced the inputs on the ctx stream, once per burst and BEFORE this burst's first MSM is
+    // queued (the option's contract: inputs complete before the first enqueue of a burst).  Recorded at the first use of
+    // slot 1 instead, the event sat behind slot 0's whole MSM and a caller that queues a pair and then waits for both got
+    // them one after the other (profiles/r03_pair_modes.txt).
+    HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream1, ctx->ev_fork, 0));
+    ctx->async_lane1_ordered = true;
   }
   ctx->chain_accum = ctx->opt_async_lanes != 0;
   rc = msm_enqueue(ctx, lane, slot, s);
