@@ -8,8 +8,10 @@ for r in rows:
     name = r.get("Kernel_Name") or r.get("Name")
     ks.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Queue_Id", "?"), name.split("(")[0].replace("void ", "")))
 ks.sort()
-accs = [i for i, k in enumerate(ks) if k[3].startswith("k_accum_l0")]
-first = accs[-7] if len(accs) >= 7 else accs[0]
+min_us = float(sys.argv[2]) if len(sys.argv) > 2 else 0.0          # only accumulations at least this long (the large MSMs of a mixed trace)
+back = int(sys.argv[3]) if len(sys.argv) > 3 else 7
+accs = [i for i, k in enumerate(ks) if k[3].startswith("k_accum_l0") and (k[1] - k[0]) / 1e3 >= min_us]
+first = accs[-back] if len(accs) >= back else accs[0]
 t0 = ks[first][0]
 sel = [k for k in ks[first:] if k[0] - t0 < 4.5e6]
 for s, e, q, n in sel:
