@@ -211,7 +211,12 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, int slot, const Segs &segs_in, u
   if (w.P) {
     {
       StageTimer t(ctx, ST_DIGITS, st);
-      hipLaunchKernelGGL(k_coarse_hist, dim3(std::min<u32>(nblk_n, 512)), dim3(256), 0, st, segs, g, w.P, w.coarse_hist, w.dig16, w.negs);
+      // few blocks (every block ends with a flush of its 2048-bin LDS histogram), many threads: a thread recodes its scalars one after
+      // the other and every one starts with a load, so the waves per SIMD are what hides that latency (512 blocks of 256 threads: 38 us at
+      // n = 2^20, 256 blocks of 1024: 28.5; options "hist_threads" / "hist_blocks", tools/hist_sweep.py)
+      const u32 ht = ctx->opt_hist_threads > 0 ? (u32)ctx->opt_hist_threads : 1024u;
+      const u32 hb = (u32)std::min<uint64_t>(((uint64_t)g.n + ht - 1) / ht, ctx->opt_hist_blocks > 0 ? (u32)ctx->opt_hist_blocks : 256u);
+      hipLaunchKernelGGL(k_coarse_hist, dim3(hb), dim3(ht), 0, st, segs, g, w.P, w.coarse_hist, w.dig16, w.negs);
     }
     debug_sync(ctx, "ST_DIGITS", st);
     {

@@ -146,11 +146,11 @@ __global__ void __launch_bounds__(256) k_digits_hist(Segs segs, MsmGeom g, u32 *
 // per scalar says whether it was negated.  Level A then reads one window of one tile as a
 // contiguous 2-byte stream instead of recoding the scalars.
 #define DIG_NONE 0xFFFFu
-__global__ void __launch_bounds__(256) k_coarse_hist(Segs segs, MsmGeom g, u32 P, u32 *__restrict__ coarse_hist, unsigned short *__restrict__ dig16,
+__global__ void __launch_bounds__(1024) k_coarse_hist(Segs segs, MsmGeom g, u32 P, u32 *__restrict__ coarse_hist, unsigned short *__restrict__ dig16,
                                                      unsigned char *__restrict__ negs) {
   raise_priority(g.prio);
   __shared__ u32 lh[PART_MAX];
-  for (u32 p = threadIdx.x; p < P; p += 256u) lh[p] = 0;
+  for (u32 p = threadIdx.x; p < P; p += blockDim.x) lh[p] = 0;
   __syncthreads();
   const u32 Bc = g.B >> 8;
   const u32 stride = gridDim.x * blockDim.x;
@@ -162,7 +162,7 @@ __global__ void __launch_bounds__(256) k_coarse_hist(Segs segs, MsmGeom g, u32 P
     negs[i] = neg ? 1 : 0;
   }
   __syncthreads();
-  for (u32 p = threadIdx.x; p < P; p += 256u) { const u32 v = lh[p]; if (v) atomicAdd(&coarse_hist[p], v); }
+  for (u32 p = threadIdx.x; p < P; p += blockDim.x) { const u32 v = lh[p]; if (v) atomicAdd(&coarse_hist[p], v); }
 }
 // exclusive scan of the <= PART_MAX partition counts in one block:
 // coarse_off[0..P] (coarse_off[P] = total), coarse_cursor = copy, off[G] = total
