@@ -299,6 +299,9 @@ int bpmi_host_free(bpmi_ctx *ctx, void *p);
  * 13 -a (raw limbs out); 14 canonical 8 words of a; 15 inverse of a's canonical value (8 words, binary Euclid). */
 int bpmi_debug_fe_op(bpmi_ctx *ctx, int op, const uint32_t *a, const uint32_t *b, const uint32_t *c, const uint32_t *d, uint64_t n,
                      uint32_t *out);
+/* self-test hook: out[i] = a[i] + b[i] on 144-byte XYZZ records (4 x 9 limbs of 29 bits: X, Y, ZZ, ZZZ; all zero = identity) with the
+ * four-lane point addition of the bucket reduction (csrc/msm_kernels.hpp quad_add) */
+int bpmi_debug_quad_add(bpmi_ctx *ctx, const uint32_t *a, const uint32_t *b, uint64_t n, uint32_t *out);
 
 /* ---- per-stage device timing (HIP events on the ctx's stream) --------------------------
  * After bpmi_profile(ctx, 1) every MSM records HIP events around each kernel

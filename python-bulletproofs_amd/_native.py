@@ -62,6 +62,7 @@ SIGNATURES = {
     "bpmi_host_free": (_i, [_vp, _vp]),
     "bpmi_ipa_destroy": (None, [_vp]),
     "bpmi_debug_fe_op": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _u64, _vp]),
+    "bpmi_debug_quad_add": (_i, [_vp, _vp, _vp, _u64, _vp]),
     "bpmi_profile": (_i, [_vp, _i]),
     "bpmi_profile_reset": (_i, [_vp]),
     "bpmi_profile_read": (_i, [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_u64)]),

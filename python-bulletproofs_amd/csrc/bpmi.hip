@@ -128,6 +128,7 @@ int bpmi_set_option(bpmi_ctx *ctx, const char *name, int64_t value) {
   if (!strcmp(name, "priority")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "priority must be 0 or 1"); ctx->opt_prio = (int)value; return BPMI_OK; }
   if (!strcmp(name, "hist_threads")) { if (value != 0 && value != 256 && value != 512 && value != 1024) return fail(ctx, BPMI_E_ARG, "hist_threads must be 0, 256, 512 or 1024"); ctx->opt_hist_threads = (int)value; return BPMI_OK; }
   if (!strcmp(name, "hist_blocks")) { if (value < 0 || value > 8192) return fail(ctx, BPMI_E_ARG, "hist_blocks must be in [0, 8192]"); ctx->opt_hist_blocks = (int)value; return BPMI_OK; }
+  if (!strcmp(name, "quad_final")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "quad_final must be 0 or 1"); ctx->opt_quad = (int)value; return BPMI_OK; }
   if (!strcmp(name, "mul_batch_glv")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "mul_batch_glv must be 0 or 1"); ctx->opt_mulb = (int)value; return BPMI_OK; }
   if (!strcmp(name, "tail")) { if (value < 0 || value > 2) return fail(ctx, BPMI_E_ARG, "tail must be 0, 1 or 2"); ctx->opt_tail = (int)value; return BPMI_OK; }
   if (!strcmp(name, "small_n")) { if (value < -1 || value > (1 << 16)) return fail(ctx, BPMI_E_ARG, "small_n must be -1 .. 65536"); ctx->opt_small = (int)value; return BPMI_OK; }
@@ -1348,6 +1349,26 @@ int bpmi_debug_fe_op(bpmi_ctx *ctx, int op, const uint32_t *a, const uint32_t *b
                      (const u32 *)(base + 2 * stride), (const u32 *)(base + 3 * stride), (u32)n, (u32 *)(base + 4 * stride));
   HIPCHK(ctx, hipGetLastError());
   HIPCHK(ctx, hipMemcpyAsync(out, base + 4 * stride, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return BPMI_OK;
+}
+
+// the four-lane point addition of the bucket reduction (quad_add, msm_kernels.hpp) on n pairs of 144-byte XYZZ records
+int bpmi_debug_quad_add(bpmi_ctx *ctx, const uint32_t *a, const uint32_t *b, uint64_t n, uint32_t *out) {
+  if (!ctx || !a || !b || !out) return ctx ? fail(ctx, BPMI_E_ARG, "null argument") : BPMI_E_ARG;
+  if (n == 0) return BPMI_OK;
+  if (n > (1u << 20)) return fail(ctx, BPMI_E_ARG, "n too large");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const size_t bytes = 4 * XYZZ_WORDS * n, stride = align_up(bytes, 256);
+  int rc = ensure_stage_in(ctx, 3 * stride + 512);
+  if (rc) return rc;
+  char *base = (char *)ctx->stage_in;
+  HIPCHK(ctx, hipMemcpyAsync(base, a, bytes, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(base + stride, b, bytes, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_debug_quad_add, dim3((u32)((4 * n + 255) / 256)), dim3(256), 0, ctx->stream, (const u32 *)base, (const u32 *)(base + stride), (u32)n,
+                     (u32 *)(base + 2 * stride));
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipMemcpyAsync(out, base + 2 * stride, bytes, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return BPMI_OK;
 }

@@ -50,6 +50,7 @@ struct bpmi_ctx {
   int opt_tail = 0;     // 0 auto, 1 device, 2 host
   int opt_prio = 0;     // MSM: 1 = the latency-bound stages raise their waves' priority (s_setprio); measured 2-6 % SLOWER with two MSMs in flight (profiles/r03_wave_priority_ab.txt): off
   int opt_hist_threads = 0, opt_hist_blocks = 0;     // k_coarse_hist launch shape (0 = default)
+  int opt_quad = 1;     // bucket reduction's finish with four-lane point additions (k_digit_final_quad); 0 = one lane per point
   int opt_mulb = 1;     // bpmi_ec_mul_batch: 1 = GLV + fixed signed windows over affine odd multiples (n >= MULB_MIN_N), 0 = the bit-serial ladder
   int opt_chunk = 0;    // entries per thread in k_accum_l0, 0 = auto
   int opt_small = 0;    // largest n handled by the one-launch small-MSM kernel (0 = default, -1 = never)

@@ -311,7 +311,8 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, int slot, const Segs &segs_in, u
       DigitJobs jb = digit_jobs2(g.W, N0, stride1, N1, t1, 0, 64, 1);
       DigitJobs j2 = digit_jobs_concat(ja, jb);
       j2.prio = g.prio;
-      hipLaunchKernelGGL(k_digit_final, dim3(g.W * 4u), dim3(256), 0, st, w.D, w.E, j2);
+      if (ctx->opt_quad) hipLaunchKernelGGL(k_digit_final_quad, dim3(g.W * 4u), dim3(1024), 0, st, w.D, w.E, j2);
+      else hipLaunchKernelGGL(k_digit_final, dim3(g.W * 4u), dim3(256), 0, st, w.D, w.E, j2);
       to.nv = 4; to.off[0] = 0; to.off[1] = t0; to.off[2] = s0; to.off[3] = s0 + t1;
     }
   }

@@ -800,6 +800,182 @@ __global__ void __launch_bounds__(256) k_digit_final(const u32 *__restrict__ X, 
   if (tid == 0) xyzz_store_g(Eout + (u64)blockIdx.x * XYZZ_WORDS, val);
 }
 
+// ---- a point addition on FOUR lanes -------------------------------------------------------------------------------
+// The scan / reduction stages are chains of dependent general additions run by a handful of waves: what they cost is the
+// LENGTH of one addition (14 multiplications one after the other, ~1 950 instructions, 5.5 us), not its work.  Here a point
+// lives in a quad of lanes, lane q holding coordinate q (0: X, 1: Y, 2: ZZ, 3: ZZZ) -- exactly the four 9-word groups of the
+// 144-byte record -- and the 14 multiplications run as FOUR levels of four (operands exchanged inside the quad with DPP):
+//   level 1   U1 = X1 ZZ2 | S1 = Y1 ZZZ2 | U2 = X2 ZZ1 | S2 = Y2 ZZZ1        (own a times the b of lane q ^ 2)
+//             P = U2 - U1 (lanes 0, 2), R = S2 - S1 (lanes 1, 3), carried: the zero tests of the exceptional cases
+//   level 2   PP = P^2 | RR = R^2 | zz = ZZ1 ZZ2 | zzz = ZZZ1 ZZZ2
+//   level 3   PPP = P PP | Q = U1 PP | ZZ3 = zz PP | -
+//             X3 = RR - PPP - 2Q (lane 1)
+//   level 4   S1 PPP | R (Q - X3) | - | ZZZ3 = zzz PPP ;   Y3 = R (Q - X3) - S1 PPP (lane 1)
+// ~950 instructions per lane instead of ~1 950.  Same formulas, same field routines, the same projective result as xyzz_add.
+// Identity operands and P = -Q are selects; P = Q (a doubling) gathers the point into every lane and runs xyzz_dbl there.
+#define QP_SWAP2 0x4E        // quad_perm [2, 3, 0, 1]
+#define QP_B0 0x00           // every lane reads lane 0 of its quad
+#define QP_B1 0x55
+#define QP_B2 0xAA
+#define QP_B3 0xFF
+// (The exchanged value is pinned in its own register: left to itself the compiler folds the DPP move into the instruction that
+// uses it, and for a subtraction with the DPP operand on the right it emitted the operands REVERSED -- r4[0] - r4[q] instead of
+// r4[q] - r4[0] in the last line of quad_add; tests/test_gpu_field.py::test_four_lane_point_addition... caught it.)
+template <int CTRL> __device__ __forceinline__ void fe_quad(fe &r, const fe &s) {
+#pragma unroll
+  for (int k = 0; k < 9; k++) {
+    u32 v = (u32)__builtin_amdgcn_update_dpp(0, (int)s.v[k], CTRL, 0xF, 0xF, false);
+    asm volatile("" : "+v"(v));
+    r.v[k] = v;
+  }
+}
+template <int CTRL> __device__ __forceinline__ u32 u32_quad(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false); }
+__device__ __forceinline__ void fe_select(fe &r, bool c, const fe &x, const fe &y) {      // c ? x : y
+#pragma unroll
+  for (int k = 0; k < 9; k++) r.v[k] = c ? x.v[k] : y.v[k];
+}
+// a <- a + b; a, b: this lane's coordinate of the two points, q = lane & 3.  Every lane of the quad must call it.
+__device__ __forceinline__ void quad_add(fe &a, const fe &b, u32 q) {
+  const bool lo = q < 2u;
+  const u32 infA = u32_quad<QP_B2>(fe_is_zero_tight(a) ? 1u : 0u), infB = u32_quad<QP_B2>(fe_is_zero_tight(b) ? 1u : 0u);
+  fe bx, r1, o1, t, u;
+  fe_quad<QP_SWAP2>(bx, b);
+  fe_mul(r1, a, bx);                                   // U1 | S1 | U2 | S2
+  fe_quad<QP_SWAP2>(o1, r1);
+  fe_select(u, lo, o1, r1);                            // U2 | S2 | U2 | S2
+  fe_select(t, lo, r1, o1);                            // U1 | S1 | U1 | S1
+  fe_sub(t, u, t);
+  fe_carry(t, t);                                      // P | R | P | R, tight
+  const u32 z = fe_is_zero_tight(t) ? 1u : 0u;
+  const u32 pz = u32_quad<QP_B0>(z), rz = u32_quad<QP_B1>(z);
+  fe opa, opb, r2, r3, r4, ppb, tmp;
+  fe_select(opa, lo, t, a);
+  fe_select(opb, lo, t, b);
+  fe_mul(r2, opa, opb);                                // PP | RR | zz | zzz
+  fe_quad<QP_B0>(ppb, r2);
+  fe_quad<QP_B0>(tmp, r1);                             // U1
+  fe_select(opa, q == 0u, t, r2);
+  fe_select(opa, q == 1u, tmp, opa);                   // P | U1 | zz | zzz
+  fe_mul(r3, opa, ppb);                                // PPP | Q | ZZ3 | (unused)
+  fe pppb, x3, qx;
+  fe_quad<QP_B0>(pppb, r3);
+  fe_sub(x3, r2, pppb);                                // lane 1: RR - PPP + 2p
+  fe_add(tmp, r3, r3);
+  fe_sub_m2(x3, x3, tmp);                              // - 2Q + 4p          (limbs < 2^32: 1 + 2 + 3 magnitudes)
+  fe_carry(x3, x3);                                    // lane 1: X3, tight
+  fe_sub(qx, r3, x3);                                  // lane 1: Q - X3 + 2p, magnitude 3
+  fe_quad<QP_B1>(tmp, r1);                             // S1
+  fe_select(opa, q == 0u, tmp, r2);                    // S1 | . | . | zzz
+  fe_select(opa, q == 1u, t, opa);                     // S1 | R | zz | zzz
+  fe_select(opb, q == 1u, qx, pppb);                   // PPP | Q - X3 | PPP | PPP      (lane 0's own r3 IS pppb)
+  fe_mul(r4, opa, opb);                                // S1 PPP | R (Q - X3) | (unused) | ZZZ3
+  fe y3;
+  fe_quad<QP_B0>(tmp, r4);
+  fe_sub(y3, r4, tmp);
+  fe_carry(y3, y3);                                    // lane 1: Y3, tight
+  fe x3b, res;
+  fe_quad<QP_B1>(x3b, x3);
+  fe_select(res, q == 0u, x3b, y3);
+  fe_select(res, q == 2u, r3, res);
+  fe_select(res, q == 3u, r4, res);
+  // exceptional cases (uniform inside the quad)
+  const bool dbl = !infA && !infB && pz && rz;
+  if (__ballot(dbl)) {                                 // some quad of the wave doubles: every lane gathers its point and doubles it
+    xyzz A;
+    fe_quad<QP_B0>(A.X, a); fe_quad<QP_B1>(A.Y, a); fe_quad<QP_B2>(A.ZZ, a); fe_quad<QP_B3>(A.ZZZ, a);
+    if (dbl) {
+      xyzz D;
+      xyzz_dbl(D, A);
+      fe_select(res, q == 0u, D.X, D.Y);
+      fe_select(res, q == 2u, D.ZZ, res);
+      fe_select(res, q == 3u, D.ZZZ, res);
+    }
+  }
+  fe zero;
+  fe_set_zero(zero);
+  fe_select(res, pz && !rz, zero, res);                // P = -Q: the identity (the all-zero record)
+  fe_select(res, infB != 0u, a, res);
+  fe_select(res, infA != 0u, b, res);
+  a = res;
+}
+
+// k_digit_final on quads: block (array r of window a) = 16 waves; wave j adds up the (<= 16) elements of sum j + 1, one element
+// per QUAD of lanes, with a butterfly of quad additions, parks it in LDS, and the first wave turns the (<= 16) sums into
+// sum_d d * X[d] (suffix scan over quads, then the sum of all suffixes).  The same 12 dependent additions, each 4 levels deep.
+__global__ void __launch_bounds__(1024) k_digit_final_quad(const u32 *__restrict__ X, u32 *__restrict__ Eout, DigitJobs jobs) {
+  __shared__ u32 s_val[16 * XYZZ_WORDS];
+  const u32 a_idx = blockIdx.x >> 2, r = blockIdx.x & 3u, tid = threadIdx.x;
+  const DigitJob J = jobs.j[r];
+  const u32 wave = tid >> 6, lane = tid & 63u, e = lane >> 2, q = lane & 3u;
+  const u32 idx = wave + 1u;
+  fe a;
+  fe_set_zero(a);
+  if (idx <= J.nsums) {
+    const u32 *base = X + ((u64)a_idx * J.in_stride + J.in_off) * XYZZ_WORDS;
+    u32 rec = 0;                                            // 1-based record of this quad's element, 0 = none
+    if (J.type == 0) { const u32 b = (e << J.s) | idx; if (b <= J.N) rec = b; }
+    else { const u32 b = (idx << J.s) | e; if (e < (1u << J.s) && b <= J.N) rec = b; }
+    if (rec) {
+      const u32 *p = base + (u64)(rec - 1u) * XYZZ_WORDS + q * 9u;
+#pragma unroll
+      for (int k = 0; k < 9; k++) a.v[k] = p[k];
+    }
+  }
+#pragma unroll 1
+  for (u32 m = 4; m < 64u; m <<= 1) {
+    fe b;
+#pragma unroll
+    for (int k = 0; k < 9; k++) b.v[k] = (u32)__shfl_xor((int)a.v[k], (int)m, 64);
+    quad_add(a, b, q);
+  }
+  if (e == 0) {
+#pragma unroll
+    for (int k = 0; k < 9; k++) s_val[wave * XYZZ_WORDS + q * 9u + k] = a.v[k];
+  }
+  __syncthreads();
+  if (wave) return;
+  fe_set_zero(a);
+  if (e < J.nsums) {                                        // quad d holds X[d + 1]
+#pragma unroll
+    for (int k = 0; k < 9; k++) a.v[k] = s_val[e * XYZZ_WORDS + q * 9u + k];
+  }
+#pragma unroll 1
+  for (u32 d = 1; d < 16u; d <<= 1) {                       // inclusive suffix scan over the 16 quads
+    fe b;
+#pragma unroll
+    for (int k = 0; k < 9; k++) { const u32 v = (u32)__shfl_down((int)a.v[k], (int)(4u * d), 64); b.v[k] = (e + d < 16u) ? v : 0u; }
+    quad_add(a, b, q);
+  }
+#pragma unroll 1
+  for (u32 m = 4; m < 64u; m <<= 1) {                       // the sum of all suffixes
+    fe b;
+#pragma unroll
+    for (int k = 0; k < 9; k++) b.v[k] = (u32)__shfl_xor((int)a.v[k], (int)m, 64);
+    quad_add(a, b, q);
+  }
+  if (e == 0) {
+#pragma unroll
+    for (int k = 0; k < 9; k++) Eout[(u64)blockIdx.x * XYZZ_WORDS + q * 9u + k] = a.v[k];
+  }
+}
+
+// self-test hook (bpmi_debug_quad_add): out[i] = a[i] + b[i] for XYZZ records, one quad per pair
+__global__ void __launch_bounds__(256) k_debug_quad_add(const u32 *__restrict__ ra, const u32 *__restrict__ rb, u32 n, u32 *__restrict__ out) {
+  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  u32 i = t >> 2;
+  const u32 q = t & 3u;
+  const bool live = i < n;
+  if (!live) i = n - 1u;                        // whole quads stay active for the lane exchanges
+  fe a, b;
+#pragma unroll
+  for (int k = 0; k < 9; k++) { a.v[k] = ra[(u64)i * XYZZ_WORDS + q * 9u + k]; b.v[k] = rb[(u64)i * XYZZ_WORDS + q * 9u + k]; }
+  quad_add(a, b, q);
+  if (live) {
+#pragma unroll
+    for (int k = 0; k < 9; k++) out[(u64)i * XYZZ_WORDS + q * 9u + k] = a.v[k];
+  }
+}
+
 // ---- bucket reduction for small windows (B <= 256): one block of B threads per window
 // computes sum_b b * B[w][b] directly as sum_j Suffix_j (inclusive suffix scan + tree sum,
 // 2 log2(B) dependent additions) -- shorter than the digit-sum stages when B is small.

@@ -105,3 +105,55 @@ def test_device_mod_q_limb_arithmetic_equals_host(shim):  # noqa: F811
     for i in range(m):
         inv = sum(v << (32 * k) for k, v in enumerate(got[9 * i: 9 * i + 8]))
         assert inv == (pow(canon[i], -1, q) if canon[i] else 0)
+
+
+def test_four_lane_point_addition_equals_the_affine_group_law():
+    """csrc/msm_kernels.hpp quad_add (a general XYZZ addition spread over four lanes, the step of the bucket reduction's latency-
+    bound stages) against the oracle's affine group law on 6 000 pairs: random points under random projective scalings, the
+    identity on either side and on both, P + P (the doubling path), P + (-P), equal points under DIFFERENT scalings, and
+    neighbours of every special case inside the same wave."""
+    import gpu_common
+    from oracle.ec import INF, secp256k1
+    from oracle import cbind
+    eng = gpu_common.engine()
+    rnd = random.Random(77)
+    M29 = (1 << 29) - 1
+
+    def limbs(v):
+        return [(v >> (29 * k)) & M29 for k in range(9)]
+
+    def record(pt, z):
+        if pt == INF:
+            return [0] * 36
+        zz, zzz = z * z % P, z * z * z % P
+        return limbs(pt.x * zz % P) + limbs(pt.y * zzz % P) + limbs(zz) + limbs(zzz)
+
+    pool = cbind.ec_mul_batch([secp256k1.G] * 300, [rnd.randrange(1, secp256k1.q) for _ in range(300)])
+    pairs = []
+    for i in range(6000):
+        a, b = rnd.choice(pool), rnd.choice(pool)
+        kind = i % 12
+        if kind == 1: a = INF
+        elif kind == 2: b = INF
+        elif kind == 3: a = b = INF
+        elif kind == 4: b = a
+        elif kind == 5: b = -a
+        pairs.append((a, b))
+    n = len(pairs)
+    za = [rnd.choice((1, rnd.randrange(1, P))) for _ in range(n)]
+    zb = [rnd.choice((1, rnd.randrange(1, P))) for _ in range(n)]
+    ra = (ctypes.c_uint32 * (36 * n))(*[v for (a, _), z in zip(pairs, za) for v in record(a, z)])
+    rb = (ctypes.c_uint32 * (36 * n))(*[v for (_, b), z in zip(pairs, zb) for v in record(b, z)])
+    out = (ctypes.c_uint32 * (36 * n))()
+    eng._ck(eng.lib.bpmi_debug_quad_add(eng.ctx, ra, rb, n, out))
+    got = list(out)
+    for i, (a, b) in enumerate(pairs):
+        rec = got[36 * i: 36 * i + 36]
+        X, Y, ZZ, ZZZ = (limbs_value(rec[9 * k: 9 * k + 9]) % P for k in range(4))
+        want = a + b
+        if want == INF:
+            assert ZZ == 0, (i, "expected the identity")
+        else:
+            assert ZZ != 0 and ZZZ != 0, i
+            assert (X * pow(ZZ, -1, P) % P, Y * pow(ZZZ, -1, P) % P) == (want.x, want.y), (i, i % 12)
+            assert pow(ZZ, 3, P) == ZZZ * ZZZ % P                      # a consistent (Z^2, Z^3) pair
