@@ -100,6 +100,8 @@ void bpmi_ctx_destroy(bpmi_ctx *ctx) {
   if (ctx->stage_in) (void)hipFree(ctx->stage_in);
   if (ctx->rp_buf) (void)hipFree(ctx->rp_buf);
   if (ctx->pin) (void)hipHostFree(ctx->pin);
+  if (ctx->up_ring) (void)hipHostFree(ctx->up_ring);
+  if (ctx->up_ev) (void)hipEventDestroy(ctx->up_ev);
   if (ctx->stream1) { (void)hipStreamSynchronize(ctx->stream1); (void)hipStreamDestroy(ctx->stream1); }
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
@@ -166,7 +168,7 @@ int bpmi_free(bpmi_ctx *ctx, void *dptr) {
 int bpmi_upload(bpmi_ctx *ctx, void *dptr, const void *host, size_t bytes) {
   if (!ctx || (bytes && (!dptr || !host))) return BPMI_E_ARG;
   if (!bytes) return BPMI_OK;
-  HIPCHK(ctx, hipMemcpyAsync(dptr, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, h2d(ctx, dptr, host, bytes, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return BPMI_OK;
 }
@@ -270,8 +272,8 @@ int bpmi_msm(bpmi_ctx *ctx, const uint8_t *pts, const uint8_t *scalars, uint64_t
   if (rc) return rc;
   char *dp = (char *)ctx->stage_in;
   char *ds = dp + align_up(64 * n, 256);
-  HIPCHK(ctx, hipMemcpyAsync(dp, pts, 64 * n, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(ctx, hipMemcpyAsync(ds, scalars, 32 * n, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, h2d(ctx, dp, pts, 64 * n, ctx->stream));
+  HIPCHK(ctx, h2d(ctx, ds, scalars, 32 * n, ctx->stream));
   return bpmi_msm_dev(ctx, dp, ds, n, out);
 }
 
@@ -286,8 +288,8 @@ int bpmi_msm2(bpmi_ctx *ctx, const uint8_t *pts0, const uint8_t *sc0, uint64_t n
   int rc = ensure_stage_in(ctx, o_s1 + 32 * n1 + 512);
   if (rc) return rc;
   char *d = (char *)ctx->stage_in;
-  if (n0) { HIPCHK(ctx, hipMemcpyAsync(d, pts0, 64 * n0, hipMemcpyHostToDevice, ctx->stream)); HIPCHK(ctx, hipMemcpyAsync(d + o_s0, sc0, 32 * n0, hipMemcpyHostToDevice, ctx->stream)); }
-  if (n1) { HIPCHK(ctx, hipMemcpyAsync(d + o_p1, pts1, 64 * n1, hipMemcpyHostToDevice, ctx->stream)); HIPCHK(ctx, hipMemcpyAsync(d + o_s1, sc1, 32 * n1, hipMemcpyHostToDevice, ctx->stream)); }
+  if (n0) { HIPCHK(ctx, h2d(ctx, d, pts0, 64 * n0, ctx->stream)); HIPCHK(ctx, h2d(ctx, d + o_s0, sc0, 32 * n0, ctx->stream)); }
+  if (n1) { HIPCHK(ctx, h2d(ctx, d + o_p1, pts1, 64 * n1, ctx->stream)); HIPCHK(ctx, h2d(ctx, d + o_s1, sc1, 32 * n1, ctx->stream)); }
   Segs a = segs_init(), b = segs_init();
   a.pts[0] = (const u32 *)d; a.sc[0] = (const u32 *)(d + o_s0); a.n[0] = (u32)n0; a.total = (u32)n0;
   b.pts[0] = (const u32 *)(d + o_p1); b.sc[0] = (const u32 *)(d + o_s1); b.n[0] = (u32)n1; b.total = (u32)n1;
@@ -334,8 +336,8 @@ int bpmi_ec_mul_batch(bpmi_ctx *ctx, const uint8_t *pts, const uint8_t *scalars,
   int rc = ensure_stage_in(ctx, 160 * n + 1024);
   if (rc) return rc;
   char *dp = (char *)ctx->stage_in, *ds = dp + align_up(64 * n, 256), *dout = ds + align_up(32 * n, 256);
-  HIPCHK(ctx, hipMemcpyAsync(dp, pts, 64 * n, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(ctx, hipMemcpyAsync(ds, scalars, 32 * n, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, h2d(ctx, dp, pts, 64 * n, ctx->stream));
+  HIPCHK(ctx, h2d(ctx, ds, scalars, 32 * n, ctx->stream));
   rc = bpmi_ec_mul_batch_dev(ctx, dp, ds, n, dout);
   if (rc) return rc;
   HIPCHK(ctx, hipMemcpyAsync(out, dout, 64 * n, hipMemcpyDeviceToHost, ctx->stream));
@@ -380,8 +382,8 @@ int bpmi_ec_lincomb2_batch(bpmi_ctx *ctx, const uint8_t *p1, const uint8_t *p2, 
   int rc = ensure_stage_in(ctx, 192 * n + 1024);
   if (rc) return rc;
   char *d1 = (char *)ctx->stage_in, *d2 = d1 + align_up(64 * n, 256), *dout = d2 + align_up(64 * n, 256);
-  HIPCHK(ctx, hipMemcpyAsync(d1, p1, 64 * n, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(ctx, hipMemcpyAsync(d2, p2, 64 * n, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, h2d(ctx, d1, p1, 64 * n, ctx->stream));
+  HIPCHK(ctx, h2d(ctx, d2, p2, 64 * n, ctx->stream));
   rc = bpmi_ec_lincomb2_batch_dev(ctx, d1, d2, k1, k2, n, dout);
   if (rc) return rc;
   HIPCHK(ctx, hipMemcpyAsync(out, dout, 64 * n, hipMemcpyDeviceToHost, ctx->stream));
@@ -396,7 +398,7 @@ int bpmi_ec_sum(bpmi_ctx *ctx, const uint8_t *pts, uint64_t n, uint8_t out[64]) 
   int rc = ensure_stage_in(ctx, 64 * n + 512);
   if (rc) return rc;
   char *dp = (char *)ctx->stage_in, *dout = dp + align_up(64 * n, 256);
-  HIPCHK(ctx, hipMemcpyAsync(dp, pts, 64 * n, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, h2d(ctx, dp, pts, 64 * n, ctx->stream));
   {
     StageTimer t(ctx, ST_MISC);
     hipLaunchKernelGGL(k_ec_sum, dim3(1), dim3(256), 0, ctx->stream, (const u32 *)dp, (u32)n, (u32 *)dout);
@@ -445,7 +447,7 @@ int bpmi_ec_decompress_batch(bpmi_ctx *ctx, const uint8_t *comp, uint64_t n, uin
   int rc = ensure_stage_in(ctx, 98 * n + 1024);
   if (rc) return rc;
   char *din = (char *)ctx->stage_in, *dout = din + align_up(33 * n, 256), *dok = dout + align_up(64 * n, 256);
-  HIPCHK(ctx, hipMemcpyAsync(din, comp, 33 * n, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, h2d(ctx, din, comp, 33 * n, ctx->stream));
   {
     StageTimer t(ctx, ST_DECOMP);
     hipLaunchKernelGGL(k_ec_decompress, dim3((u32)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const uint8_t *)din, (u32)n,
@@ -468,7 +470,7 @@ int bpmi_ec_decompress_batch_dev(bpmi_ctx *ctx, const uint8_t *comp, uint64_t n,
   int rc = ensure_stage_in(ctx, 34 * n + 1024);
   if (rc) return rc;
   char *din = (char *)ctx->stage_in, *dok = din + align_up(33 * n, 256);
-  HIPCHK(ctx, hipMemcpyAsync(din, comp, 33 * n, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, h2d(ctx, din, comp, 33 * n, ctx->stream));
   {
     StageTimer t(ctx, ST_DECOMP);
     hipLaunchKernelGGL(k_ec_decompress, dim3((u32)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const uint8_t *)din, (u32)n, (u32 *)d_out, (uint8_t *)dok);
@@ -543,8 +545,8 @@ int bpmi_sc_dot(bpmi_ctx *ctx, const uint8_t *a, const uint8_t *b, uint64_t n, u
   int rc = ensure_stage_in(ctx, 64 * n + 512);
   if (rc) return rc;
   char *da = (char *)ctx->stage_in, *db = da + align_up(32 * n, 256);
-  HIPCHK(ctx, hipMemcpyAsync(da, a, 32 * n, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(ctx, hipMemcpyAsync(db, b, 32 * n, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, h2d(ctx, da, a, 32 * n, ctx->stream));
+  HIPCHK(ctx, h2d(ctx, db, b, 32 * n, ctx->stream));
   return bpmi_sc_dot_dev(ctx, da, db, n, out);
 }
 int bpmi_sc_fold_dev(bpmi_ctx *ctx, const void *d_lo, const void *d_hi, const uint8_t x[32], const uint8_t y[32], uint64_t n, void *d_out) {
@@ -571,8 +573,8 @@ int bpmi_sc_fold(bpmi_ctx *ctx, const uint8_t *lo, const uint8_t *hi, const uint
   int rc = ensure_stage_in(ctx, 96 * n + 1024);
   if (rc) return rc;
   char *dl = (char *)ctx->stage_in, *dh = dl + align_up(32 * n, 256), *dout = dh + align_up(32 * n, 256);
-  HIPCHK(ctx, hipMemcpyAsync(dl, lo, 32 * n, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(ctx, hipMemcpyAsync(dh, hi, 32 * n, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, h2d(ctx, dl, lo, 32 * n, ctx->stream));
+  HIPCHK(ctx, h2d(ctx, dh, hi, 32 * n, ctx->stream));
   rc = bpmi_sc_fold_dev(ctx, dl, dh, x, y, n, dout);
   if (rc) return rc;
   HIPCHK(ctx, hipMemcpyAsync(out, dout, 32 * n, hipMemcpyDeviceToHost, ctx->stream));
@@ -601,7 +603,7 @@ static int svector_launch(bpmi_ctx *ctx, const SvecLayout &L, const void *d_scal
   const size_t ntab = ((size_t)1 << L.kl) + ((size_t)1 << (k - L.kl));
   std::vector<uint8_t> xt(64 * (size_t)(k ? k : 1));
   for (u32 j = 0; j < k; j++) { memcpy(&xt[64 * j], xs + 32 * j, 32); memcpy(&xt[64 * j + 32], xinvs + 32 * j, 32); }
-  HIPCHK(ctx, hipMemcpyAsync(L.xt, xt.data(), xt.size(), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, h2d(ctx, L.xt, xt.data(), xt.size(), ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));          // xt is owned by this frame
   Sc2 ab;
   memcpy(ab.k1, a, 32); memcpy(ab.k2, b, 32);
@@ -624,7 +626,7 @@ int bpmi_sc_svector(bpmi_ctx *ctx, const uint8_t *xs, const uint8_t *xinvs, uint
   SvecLayout L;
   int rc = svector_layout(ctx, n, k, scale ? 32 * n : 0, L);
   if (rc) return rc;
-  if (scale) HIPCHK(ctx, hipMemcpyAsync(L.extra, scale, 32 * n, hipMemcpyHostToDevice, ctx->stream));
+  if (scale) HIPCHK(ctx, h2d(ctx, L.extra, scale, 32 * n, ctx->stream));
   rc = svector_launch(ctx, L, scale ? L.extra : nullptr, n, xs, xinvs, a, b);
   if (rc) return rc;
   HIPCHK(ctx, hipMemcpyAsync(sa, L.sa, 32 * n, hipMemcpyDeviceToHost, ctx->stream));
@@ -651,8 +653,8 @@ int bpmi_ipa_verify_dev(bpmi_ctx *ctx, const void *d_g, const void *d_h, const v
   u32 *d_sa = L.sa, *d_sb = L.sb;
   char *d_ex = L.extra;
   if (n_extra) {
-    HIPCHK(ctx, hipMemcpyAsync(d_ex, extra_pts, 64 * n_extra, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(d_ex + o_es, extra_scalars, 32 * n_extra, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, h2d(ctx, d_ex, extra_pts, 64 * n_extra, ctx->stream));
+    HIPCHK(ctx, h2d(ctx, d_ex + o_es, extra_scalars, 32 * n_extra, ctx->stream));
   }
   Segs s = segs_init();
   s.pts[0] = (const u32 *)d_g; s.sc[0] = d_sa; s.n[0] = (u32)n;
@@ -730,8 +732,8 @@ static int ipa_alloc(bpmi_ctx *ctx, uint64_t n, bpmi_ipa **out) {
   for (int k = 0; k < 2; k++) { st->nafk[k] = (NafK *)p; p += align_up(sizeof(NafK), 256); }
   // coefficient tables start as [1]
   uint8_t one[32] = {1};
-  e = hipMemcpyAsync(st->cg[0], one, 32, hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(st->ch[0], one, 32, hipMemcpyHostToDevice, ctx->stream);
+  e = h2d(ctx, st->cg[0], one, 32, ctx->stream);
+  if (e == hipSuccess) e = h2d(ctx, st->ch[0], one, 32, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
   if (e != hipSuccess) { (void)hipFree(st->block); delete st; return fail(ctx, BPMI_E_HIP, std::string("ipa_alloc: ") + hipGetErrorString(e)); }
   sc o; memset(&o, 0, sizeof(o)); o.v[0] = 1;
@@ -763,7 +765,7 @@ int bpmi_ipa_create_dev(bpmi_ctx *ctx, const void *d_g, const void *d_h, const v
   if (e == hipSuccess) e = hipMemcpyAsync(st->h, d_h, 64 * n, hipMemcpyDeviceToDevice, s);
   if (e == hipSuccess) e = hipMemcpyAsync(st->a, d_a, 32 * n, hipMemcpyDeviceToDevice, s);
   if (e == hipSuccess) e = hipMemcpyAsync(st->b, d_b, 32 * n, hipMemcpyDeviceToDevice, s);
-  if (e == hipSuccess) e = hipMemcpyAsync(st->u, u, 64, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) e = h2d(ctx, st->u, u, 64, s);
   if (e == hipSuccess) e = hipStreamSynchronize(s);
   if (e != hipSuccess) { (void)hipFree(st->block); if (st->wtab) (void)hipFree(st->wtab); delete st; return fail(ctx, BPMI_E_HIP, std::string("ipa_create copy: ") + hipGetErrorString(e)); }
   *out = st;
@@ -778,11 +780,11 @@ int bpmi_ipa_create(bpmi_ctx *ctx, const uint8_t *g, const uint8_t *h, const uin
   int rc = ipa_alloc(ctx, n, &st);
   if (rc) return rc;
   hipStream_t s = ctx->stream;
-  hipError_t e = hipMemcpyAsync(st->g, g, 64 * n, hipMemcpyHostToDevice, s);
-  if (e == hipSuccess) e = hipMemcpyAsync(st->h, h, 64 * n, hipMemcpyHostToDevice, s);
-  if (e == hipSuccess) e = hipMemcpyAsync(st->a, a, 32 * n, hipMemcpyHostToDevice, s);
-  if (e == hipSuccess) e = hipMemcpyAsync(st->b, b, 32 * n, hipMemcpyHostToDevice, s);
-  if (e == hipSuccess) e = hipMemcpyAsync(st->u, u, 64, hipMemcpyHostToDevice, s);
+  hipError_t e = h2d(ctx, st->g, g, 64 * n, s);
+  if (e == hipSuccess) e = h2d(ctx, st->h, h, 64 * n, s);
+  if (e == hipSuccess) e = h2d(ctx, st->a, a, 32 * n, s);
+  if (e == hipSuccess) e = h2d(ctx, st->b, b, 32 * n, s);
+  if (e == hipSuccess) e = h2d(ctx, st->u, u, 64, s);
   if (e == hipSuccess) e = hipStreamSynchronize(s);
   if (e != hipSuccess) { (void)hipFree(st->block); if (st->wtab) (void)hipFree(st->wtab); delete st; return fail(ctx, BPMI_E_HIP, std::string("ipa_create copy: ") + hipGetErrorString(e)); }
   *out = st;
@@ -795,12 +797,12 @@ int bpmi_ipa_create_scaled(bpmi_ctx *ctx, const uint8_t *g, const uint8_t *h, co
   bpmi_ipa *st = *out;
   if (n >= st->big_m) {
     // large bases get folded by the shared-scalar ladder, which needs real points: scale them once
-    HIPCHK(ctx, hipMemcpyAsync(st->hscale_buf, h_scale, 32 * n, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, h2d(ctx, st->hscale_buf, h_scale, 32 * n, ctx->stream));
     rc = bpmi_ec_mul_batch_dev(ctx, st->h, st->hscale_buf, n, st->h);
     if (rc == BPMI_OK) { hipError_t e = hipStreamSynchronize(ctx->stream); if (e != hipSuccess) rc = fail(ctx, BPMI_E_HIP, hipGetErrorString(e)); }
   } else {
     // never folded: the factors ride in the scalars of every L / R MSM
-    hipError_t e = hipMemcpyAsync(st->hscale_buf, h_scale, 32 * n, hipMemcpyHostToDevice, ctx->stream);
+    hipError_t e = h2d(ctx, st->hscale_buf, h_scale, 32 * n, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) rc = fail(ctx, BPMI_E_HIP, std::string("ipa_create_scaled: ") + hipGetErrorString(e));
     else st->hscale = st->hscale_buf;
@@ -940,8 +942,8 @@ int bpmi_ipa_fold(bpmi_ipa *st, const uint8_t x[32], const uint8_t xinv[32]) {
           host_wnaf4((const uint8_t *)st->hcg[t].v, hwa.dg[t], hwa.top);
           host_wnaf4((const uint8_t *)st->hch[t].v, hwb.dg[t], hwb.top);
         }
-        HIPCHK(ctx, hipMemcpyAsync(dwa, &hwa, sizeof(WnafK), hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(ctx, hipMemcpyAsync(dwb, &hwb, sizeof(WnafK), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, h2d(ctx, dwa, &hwa, sizeof(WnafK), ctx->stream));
+        HIPCHK(ctx, h2d(ctx, dwb, &hwb, sizeof(WnafK), ctx->stream));
         {
           StageTimer t(ctx, ST_LINCOMB2);
           hipLaunchKernelGGL(k_ec_odd_multiples<ODDMUL_PER_THREAD>, dim3((u32)((2 * nthr + 255) / 256)), dim3(256), 0, ctx->stream, st->g, st->h, (u32)npts, tab_a, tab_b, scr);
@@ -960,8 +962,8 @@ int bpmi_ipa_fold(bpmi_ipa *st, const uint8_t x[32], const uint8_t xinv[32]) {
         host_naf((const uint8_t *)st->hcg[t].v, ha.nz[t], ha.sg[t], ha.top);
         host_naf((const uint8_t *)st->hch[t].v, hb.nz[t], hb.sg[t], hb.top);
       }
-      HIPCHK(ctx, hipMemcpyAsync(st->nafk[0], &ha, sizeof(NafK), hipMemcpyHostToDevice, ctx->stream));
-      HIPCHK(ctx, hipMemcpyAsync(st->nafk[1], &hb, sizeof(NafK), hipMemcpyHostToDevice, ctx->stream));
+      HIPCHK(ctx, h2d(ctx, st->nafk[0], &ha, sizeof(NafK), ctx->stream));
+      HIPCHK(ctx, h2d(ctx, st->nafk[1], &hb, sizeof(NafK), ctx->stream));
       HIPCHK(ctx, hipStreamSynchronize(ctx->stream));     // ha / hb are stack objects
       {
         StageTimer t(ctx, ST_LINCOMB2);
@@ -976,8 +978,8 @@ int bpmi_ipa_fold(bpmi_ipa *st, const uint8_t x[32], const uint8_t xinv[32]) {
     st->M = st->n;
     st->d = 0;
     uint8_t one[32] = {1};
-    HIPCHK(ctx, hipMemcpyAsync(st->cg[st->cur], one, 32, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(st->ch[st->cur], one, 32, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, h2d(ctx, st->cg[st->cur], one, 32, ctx->stream));
+    HIPCHK(ctx, h2d(ctx, st->ch[st->cur], one, 32, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     sc o; memset(&o, 0, sizeof(o)); o.v[0] = 1;
     st->hcg.assign(1, o); st->hch.assign(1, o);
@@ -1171,8 +1173,8 @@ static int rp_prepare_enqueue(bpmi_ctx *ctx, uint32_t n_gens, uint32_t m, uint64
   u64 *d_T = (u64 *)((char *)ctx->rp_buf + o_T);
   unsigned long long *d_bad = (unsigned long long *)(d_shared + 8 * (size_t)ncols);
   Q.d_shared = d_shared; Q.d_bad = d_bad; Q.ncols = ncols;
-  HIPCHK(ctx, hipMemcpyAsync(din + o_off, blob_off, 8 * ((size_t)P + 1), hipMemcpyHostToDevice, ctx->stream));
-  if (weights) HIPCHK(ctx, hipMemcpyAsync(din + o_w, weights, 128 * (size_t)P, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, h2d(ctx, din + o_off, blob_off, 8 * ((size_t)P + 1), ctx->stream));
+  if (weights) HIPCHK(ctx, h2d(ctx, din + o_w, weights, 128 * (size_t)P, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(d_shared, 0, out_row, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(d_bad, 0xFF, 8, ctx->stream));
   // Upload in slices of whole proofs; the point decoding of a slice (second lane; it reads only the wire bytes) starts as soon as the
@@ -1189,7 +1191,7 @@ static int rp_prepare_enqueue(bpmi_ctx *ctx, uint32_t n_gens, uint32_t m, uint64
   for (u32 c = 0; c < nsl; c++) {
     const u32 g0 = (u32)((uint64_t)P * c / nsl), g1 = (u32)((uint64_t)P * (c + 1) / nsl);
     const uint64_t b0 = c == 0 ? 0 : blob_off[g0], b1 = c + 1 == nsl ? blobs_len : blob_off[g1];
-    if (b1 > b0) HIPCHK(ctx, hipMemcpyAsync(din + b0, blobs + b0, b1 - b0, hipMemcpyHostToDevice, ctx->stream));
+    if (b1 > b0) HIPCHK(ctx, h2d(ctx, din + b0, blobs + b0, b1 - b0, ctx->stream));
     if (ctx->opt_rp_overlap) {
       HIPCHK(ctx, hipEventRecord(ctx->ev_slice[c], ctx->stream));
       HIPCHK(ctx, hipStreamWaitEvent(ctx->stream1, ctx->ev_slice[c], 0));
@@ -1243,7 +1245,7 @@ static int rp_prepare_enqueue(bpmi_ctx *ctx, uint32_t n_gens, uint32_t m, uint64
 }
 // both lanes idle again; the first error of (rc, the two waits)
 static int rp_wait_lanes(bpmi_ctx *ctx, int rc) {
-  const hipError_t e0 = hipStreamSynchronize(ctx->stream), e1 = ctx->stream1 ? hipStreamSynchronize(ctx->stream1) : hipSuccess;
+  const hipError_t e0 = wait_stream(ctx->stream), e1 = ctx->stream1 ? wait_stream(ctx->stream1) : hipSuccess;
   if (rc) return rc;
   HIPCHK(ctx, e0);
   HIPCHK(ctx, e1);
@@ -1289,7 +1291,7 @@ int bpmi_rp_batch_verify_dev(bpmi_ctx *ctx, uint32_t n_gens, uint32_t values_per
   if (3 + 2 * (uint64_t)n_gens + nv + npts > (1ull << 23)) return fail(ctx, BPMI_E_ARG, "at most 2^23 points in the batch's MSM");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   // commitments: the first nv points / scalars of the per-proof arrays
-  HIPCHK(ctx, hipMemcpyAsync(d_points, v_points, 64 * nv, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, h2d(ctx, d_points, v_points, 64 * nv, ctx->stream));
   RpQueued Q;
   int rc = rp_prepare_enqueue(ctx, n_gens, values_per_proof, n_proofs, blobs, blobs_len, blob_off, weights, seed, d_scalars, (char *)d_scalars + 32 * nv,
                               (char *)d_points + 64 * nv, Q);
@@ -1344,7 +1346,7 @@ int bpmi_debug_fe_op(bpmi_ctx *ctx, int op, const uint32_t *a, const uint32_t *b
   if (rc) return rc;
   char *base = (char *)ctx->stage_in;
   const uint32_t *src[4] = {a, b, c, d};
-  for (int k = 0; k < 4; k++) HIPCHK(ctx, hipMemcpyAsync(base + k * stride, src[k], bytes, hipMemcpyHostToDevice, ctx->stream));
+  for (int k = 0; k < 4; k++) HIPCHK(ctx, h2d(ctx, base + k * stride, src[k], bytes, ctx->stream));
   hipLaunchKernelGGL(k_debug_fe_op, dim3((u32)((n + 255) / 256)), dim3(256), 0, ctx->stream, op, (const u32 *)base, (const u32 *)(base + stride),
                      (const u32 *)(base + 2 * stride), (const u32 *)(base + 3 * stride), (u32)n, (u32 *)(base + 4 * stride));
   HIPCHK(ctx, hipGetLastError());
@@ -1363,8 +1365,8 @@ int bpmi_debug_quad_add(bpmi_ctx *ctx, const uint32_t *a, const uint32_t *b, uin
   int rc = ensure_stage_in(ctx, 3 * stride + 512);
   if (rc) return rc;
   char *base = (char *)ctx->stage_in;
-  HIPCHK(ctx, hipMemcpyAsync(base, a, bytes, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(ctx, hipMemcpyAsync(base + stride, b, bytes, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, h2d(ctx, base, a, bytes, ctx->stream));
+  HIPCHK(ctx, h2d(ctx, base + stride, b, bytes, ctx->stream));
   hipLaunchKernelGGL(k_debug_quad_add, dim3((u32)((4 * n + 255) / 256)), dim3(256), 0, ctx->stream, (const u32 *)base, (const u32 *)(base + stride), (u32)n,
                      (u32 *)(base + 2 * stride));
   HIPCHK(ctx, hipGetLastError());

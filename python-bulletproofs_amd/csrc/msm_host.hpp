@@ -292,7 +292,8 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, int slot, const Segs &segs_in, u
   {
     StageTimer t(ctx, ST_BREDUCE, st);
     if (g.B <= 256u) {
-      hipLaunchKernelGGL(k_window_weighted_small, dim3(g.W), dim3(g.B < 64u ? 64u : g.B), 0, st, g, w.buckets, w.E);
+      if (ctx->opt_quad) hipLaunchKernelGGL(k_window_weighted_small_quad, dim3(g.W), dim3(g.B < 16u ? 64u : 4u * g.B), 0, st, g, w.buckets, w.E);
+      else hipLaunchKernelGGL(k_window_weighted_small, dim3(g.W), dim3(g.B < 64u ? 64u : g.B), 0, st, g, w.buckets, w.E);
     } else {
       // bucket index b in [1, B], B = 2^(c-1):  b = hi 2^s0 + lo, then each digit again in two
       const u32 s0 = g.c / 2u, N0 = (1u << s0) - 1u, N1 = g.B >> s0;          // stage-1 arrays: D0[1..N0], D1[1..N1]
@@ -349,7 +350,7 @@ static int msm_finish(bpmi_ctx *ctx, int slot, uint8_t out[64]) {
   bpmi_ctx::PendingMsm &pd = ctx->pend[slot];
   if (!pd.active) { memset(out, 0, 64); return BPMI_OK; }      // n == 0
   pd.active = false;
-  HIPCHK(ctx, hipEventSynchronize(pd.done));
+  HIPCHK(ctx, wait_event(pd.done));
   const void *pin = pd.pin;
   if (pd.tail == 1) {
     memcpy(out, pin, 64);

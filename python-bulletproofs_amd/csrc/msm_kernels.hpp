@@ -1001,6 +1001,46 @@ __global__ void __launch_bounds__(256) k_window_weighted_small(MsmGeom g, const 
   if (tid == 0) xyzz_store_g(Eout + (u64)w * XYZZ_WORDS, val);
 }
 
+// the same on quads of lanes (quad_add): 4 B threads, bucket b = (tid >> 2) + 1, lane tid & 3 holds one coordinate
+__global__ void __launch_bounds__(1024) k_window_weighted_small_quad(MsmGeom g, const u32 *__restrict__ buckets, u32 *__restrict__ Eout) {
+  __shared__ u32 s_val[256 * XYZZ_WORDS];
+  const u32 tid = threadIdx.x, w = blockIdx.x, rec = tid >> 2, q = tid & 3u;
+  fe a;
+  fe_set_zero(a);
+  if (rec < g.B) {
+    const u32 *p = buckets + ((u64)w * g.B + rec) * XYZZ_WORDS + q * 9u;
+#pragma unroll
+    for (int k = 0; k < 9; k++) a.v[k] = p[k];
+  }
+  u32 *mine = s_val + rec * XYZZ_WORDS + q * 9u;
+#pragma unroll 1
+  for (u32 d = 1; d < g.B; d <<= 1) {                       // inclusive suffix scan
+#pragma unroll
+    for (int k = 0; k < 9; k++) mine[k] = a.v[k];
+    __syncthreads();
+    fe b;
+#pragma unroll
+    for (int k = 0; k < 9; k++) b.v[k] = (rec + d < g.B) ? mine[d * XYZZ_WORDS + k] : 0u;
+    __syncthreads();
+    quad_add(a, b, q);
+  }
+#pragma unroll 1
+  for (u32 d = (blockDim.x >> 3); d > 0; d >>= 1) {         // sum of all suffixes: records [0, 2d) -> [0, d)
+#pragma unroll
+    for (int k = 0; k < 9; k++) mine[k] = a.v[k];
+    __syncthreads();
+    fe b;
+#pragma unroll
+    for (int k = 0; k < 9; k++) b.v[k] = (rec < d) ? mine[d * XYZZ_WORDS + k] : 0u;
+    __syncthreads();
+    quad_add(a, b, q);
+  }
+  if (rec == 0) {
+#pragma unroll
+    for (int k = 0; k < 9; k++) Eout[(u64)w * XYZZ_WORDS + q * 9u + k] = a.v[k];
+  }
+}
+
 // ---- small MSMs (n <= a few thousand): latency, not throughput, is what counts ------------
 // One dependent point addition costs 5-8 us when a wave issues alone, so the bucket pipeline
 // (sort, L sequential additions per thread, segmented scan, bucket reduction: >= 60
