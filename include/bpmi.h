@@ -208,6 +208,11 @@ int bpmi_ipa_create_scaled(bpmi_ctx *ctx, const uint8_t *g, const uint8_t *h, co
 uint64_t bpmi_ipa_len(const bpmi_ipa *st);
 int bpmi_ipa_round_LR(bpmi_ipa *st, uint8_t L[64], uint8_t R[64]);
 int bpmi_ipa_fold(bpmi_ipa *st, const uint8_t x[32], const uint8_t xinv[32]);
+/* the whole halving loop in one call, Fiat-Shamir included: rounds of (L, R) -> transcript items -> x = mod_hash(transcript, q) -> fold
+ * until the state has length 1 (inner_product_prover.py:94-110, utils.py:84-97).  digest: the transcript so far; digest_out
+ * (capacity cap): the transcript after the last round; xs / Ls / Rs: 32 / 64 / 64 bytes per round, max_rounds entries each. */
+int bpmi_ipa_prove_rounds(bpmi_ipa *st, const uint8_t *digest, uint64_t digest_len, uint8_t *digest_out, uint64_t cap, uint64_t *out_len, uint8_t *xs,
+                          uint8_t *Ls, uint8_t *Rs, uint32_t max_rounds, uint32_t *rounds);
 int bpmi_ipa_finish(bpmi_ipa *st, uint8_t a[32], uint8_t b[32]);
 /* The CURRENT (folded) g, h (len points each) and a, b (len scalars each), len = bpmi_ipa_len:
  * what the reference holds in gp, hp, ap, bp at the top of its loop (:84).  With folds

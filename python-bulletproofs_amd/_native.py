@@ -61,6 +61,7 @@ SIGNATURES = {
     "bpmi_host_alloc": (_i, [_vp, ctypes.c_size_t, ctypes.POINTER(_vp)]),
     "bpmi_host_free": (_i, [_vp, _vp]),
     "bpmi_ipa_destroy": (None, [_vp]),
+    "bpmi_ipa_prove_rounds": (_i, [_vp, _cp, _u64, _vp, _u64, _vp, _vp, _vp, _vp, ctypes.c_uint32, _vp]),
     "bpmi_debug_fe_op": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _u64, _vp]),
     "bpmi_debug_quad_add": (_i, [_vp, _vp, _vp, _u64, _vp]),
     "bpmi_profile": (_i, [_vp, _i]),

@@ -987,6 +987,74 @@ int bpmi_ipa_fold(bpmi_ipa *st, const uint8_t x[32], const uint8_t xinv[32]) {
   return BPMI_OK;
 }
 
+// The whole halving loop of FastNIProver2.prove (/root/reference/src/innerproduct/inner_product_prover.py:94-110) in ONE call, the
+// Fiat-Shamir edge included: per round L, R (bpmi_ipa_round_LR), the transcript items of the two points (base64 of the compressed
+// point, '&'), the challenge x = mod_hash(transcript, q) (src/utils/utils.py:84-97), its decimal item, the fold (bpmi_ipa_fold with
+// x and 1/x).  Byte for byte what utils/transcript.py builds -- the golden proofs pin it -- without a trip through the interpreter
+// per round (20 rounds x ~40 us at n = 2^20).  The sharded prover keeps the round-by-round entry points (it exchanges L and R).
+//   digest / digest_len   the transcript so far;  digest_out (capacity cap) receives the transcript after the last round
+//   xs, Ls, Rs            32 / 64 / 64 bytes per round (little-endian scalars, 64-byte points), max_rounds entries each
+int bpmi_ipa_prove_rounds(bpmi_ipa *st, const uint8_t *digest, uint64_t digest_len, uint8_t *digest_out, uint64_t cap, uint64_t *out_len, uint8_t *xs,
+                          uint8_t *Ls, uint8_t *Rs, uint32_t max_rounds, uint32_t *rounds) {
+  if (!st || (!digest && digest_len) || !digest_out || !out_len || !xs || !Ls || !Rs || !rounds) return BPMI_E_ARG;
+  bpmi_ctx *ctx = st->ctx;
+  std::vector<uint8_t> dg(digest, digest + digest_len);
+  dg.reserve(digest_len + 256 * 24);
+  uint32_t r = 0;
+  while (st->n > 1) {
+    if (r >= max_rounds) return fail(ctx, BPMI_E_ARG, "more rounds than max_rounds");
+    uint8_t *L = Ls + 64 * (size_t)r, *R = Rs + 64 * (size_t)r;
+    int rc = bpmi_ipa_round_LR(st, L, R);
+    if (rc) return rc;
+    for (const uint8_t *pt : {(const uint8_t *)L, (const uint8_t *)R}) {
+      uint8_t comp[33] = {0}, item[48];
+      bool zero = true;
+      for (int k = 0; k < 64; k++) zero &= pt[k] == 0;
+      if (!zero) {
+        comp[0] = (pt[32] & 1) ? 3 : 2;                              // y is little-endian: its parity is in byte 0
+        for (int k = 0; k < 32; k++) comp[1 + k] = pt[31 - k];        // x big-endian
+      }
+      const size_t il = rp::point_item(item, comp);
+      dg.insert(dg.end(), item, item + il);
+      dg.push_back('&');
+    }
+    rp::Sha one;
+    rp::sha_init(one);
+    rp::sha_update(one, (const uint8_t *)"1", 1);
+    rp::sha_update(one, dg.data(), dg.size());
+    rp::Sq x, xi;
+    rp::mod_hash_q(x, one, dg.data(), dg.size());
+    {                                                                // decimal item of x
+      uint64_t v[4] = {x.v[0], x.v[1], x.v[2], x.v[3]};
+      char buf[80];
+      int pos = 80;
+      for (;;) {
+        unsigned __int128 rem = 0;                                   // v /= 10^19
+        const uint64_t D = 10000000000000000000ULL;
+        for (int k = 3; k >= 0; k--) { const unsigned __int128 cur = (rem << 64) | v[k]; v[k] = (uint64_t)(cur / D); rem = cur % D; }
+        uint64_t chunk = (uint64_t)rem;
+        const bool more = (v[0] | v[1] | v[2] | v[3]) != 0;
+        for (int k = 0; k < 19 && (more || chunk || k == 0); k++) { buf[--pos] = (char)('0' + chunk % 10); chunk /= 10; }
+        if (!more) break;
+      }
+      dg.insert(dg.end(), buf + pos, buf + 80);
+      dg.push_back('&');
+    }
+    rp::q_inv(xi, x);
+    uint8_t xb[32], xib[32];
+    rp::q_to_le(xb, x); rp::q_to_le(xib, xi);
+    memcpy(xs + 32 * (size_t)r, xb, 32);
+    rc = bpmi_ipa_fold(st, xb, xib);
+    if (rc) return rc;
+    r++;
+  }
+  if (dg.size() > cap) return fail(ctx, BPMI_E_ARG, "digest_out too small");
+  memcpy(digest_out, dg.data(), dg.size());
+  *out_len = dg.size();
+  *rounds = r;
+  return BPMI_OK;
+}
+
 int bpmi_ipa_finish(bpmi_ipa *st, uint8_t a[32], uint8_t b[32]) {
   if (!st || !a || !b) return BPMI_E_ARG;
   bpmi_ctx *ctx = st->ctx;

@@ -241,6 +241,19 @@ class IpaState:
     def fold(self, x, xinv):
         self.engine._ck(self.engine.lib.bpmi_ipa_fold(self.handle, sc_bytes(x), sc_bytes(xinv)))
 
+    def prove_rounds(self, digest):
+        """Every remaining round in one native call (bpmi_ipa_prove_rounds): the transcript `digest` so far ->
+        (transcript after the last round, [x as int], [L as 64 bytes], [R as 64 bytes])."""
+        k = max(1, len(self).bit_length())
+        cap = len(digest) + 256 * k
+        out, out_len, rounds = ctypes.create_string_buffer(cap), ctypes.c_uint64(0), ctypes.c_uint32(0)
+        xs, Ls, Rs = ctypes.create_string_buffer(32 * k), ctypes.create_string_buffer(64 * k), ctypes.create_string_buffer(64 * k)
+        self.engine._ck(self.engine.lib.bpmi_ipa_prove_rounds(self.handle, digest, len(digest), out, cap, ctypes.byref(out_len), xs, Ls, Rs, k,
+                                                              ctypes.byref(rounds)))
+        r = rounds.value
+        return (out.raw[:out_len.value], [int.from_bytes(xs.raw[32 * i: 32 * i + 32], "little") for i in range(r)],
+                [Ls.raw[64 * i: 64 * i + 64] for i in range(r)], [Rs.raw[64 * i: 64 * i + 64] for i in range(r)])
+
     def finish(self):
         a = ctypes.create_string_buffer(32)
         b = ctypes.create_string_buffer(32)
