@@ -57,7 +57,7 @@ IPA_ALGO_BYTES_PER_ELEMENT = 960   # whole proof, per el
 MADS_PER_MADD = None           # filled from profiles/r02_isa_counts.json when present
 RAW_MAD_TOPS = 28.85           # T lane-ops/s, tools/fe_microbench.hip (profiles/r01_fe_microbench.txt)
 MULS_PER_MADD = 10.5           # 8M + 2S plus carries/subtractions in multiplication-equivalents
-FE_MUL_PEAK_G = 196.0          # the product's own fe_mul in isolation, G multiplications/s (r01_fe_microbench.txt, V8)
+FE_MUL_PEAK_G = 221.4          # the product's own fe_mul in isolation, G multiplications/s (profiles/r03_fe_microbench.txt, V8; round 1's fe_mul: 196)
 
 
 def synth_scalars(n, seed):
@@ -341,7 +341,7 @@ def main():
                          "achieved": madds_per_launch * MULS_PER_MADD / acc_avg_s / 1e9 if acc_avg_s > 0 else 0.0,
                          "peak": FE_MUL_PEAK_G, "frac": (madds_per_launch * MULS_PER_MADD / acc_avg_s / 1e9 / FE_MUL_PEAK_G) if acc_avg_s > 0 else 0.0,
                          "work": "%d windows x n mixed additions x %.1f multiplication-equivalents (8M + 2S)" % (windows, MULS_PER_MADD),
-                         "peak_source": "profiles/r01_fe_microbench.txt (V8: the product's own fe_mul in isolation; NOT a hardware peak)"},
+                         "peak_source": "profiles/r03_fe_microbench.txt (V8: the product's own fe_mul in isolation; NOT a hardware peak)"},
         "stage_ms_per_msm": stages,
         "hip_event_ms_per_step": ev_ms / args.steps,
         "preheat_ms": args.preheat_ms,
