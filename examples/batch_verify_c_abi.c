@@ -18,6 +18,7 @@
  *      5 + 2 n_gens shared coefficients and the index of the first bad proof (-1: none);
  *   3. the shared coefficients become the scalars of g, h, u, gs_i, hs_i (two constants are added to every gs_i / hs_i);
  *   4. ONE MSM over [g h u gs hs | V .. | proof points ..] (bpmi_msm_segs_dev) -- the identity iff every proof is valid.
+ *   (and steps 2-4 again as one call, bpmi_rp_batch_verify_dev, which must give the same verdict)
  * Exit code 0: the batch verifies; 1: it does not; 2: usage / I/O / library error. */
 #define _POSIX_C_SOURCE 200809L
 #include <stdio.h>
@@ -109,6 +110,16 @@ int main(int argc, char **argv) {
     verdict = zero ? 0 : 1;
     printf("batch of %u proofs (%llu MSM pairs): %s in %.3f ms\n", P, (unsigned long long)(n_shared + nv + npts), zero ? "VALID" : "INVALID",
            (now() - t0) * 1e3);
+    /* The same in ONE call (bpmi_rp_batch_verify_dev): the upload in slices with the point decoding beside it, the preparation, the
+     * shared coefficients folded on the device, the MSM -- nothing comes back to the host in between. */
+    const double t1 = now();
+    uint8_t out1[64];
+    int64_t bad1 = -1;
+    CK(bpmi_rp_batch_verify_dev(ctx, n, m, P, recv, blobs_len, off, NULL, seed, vpts, d_shared_pts, d_pts, d_sc, out1, &bad1));
+    int zero1 = bad1 < 0;
+    for (int i = 0; i < 64 && zero1; i++) zero1 &= out1[i] == 0;
+    printf("one call: %s in %.3f ms\n", zero1 ? "VALID" : "INVALID", (now() - t1) * 1e3);
+    if (zero1 != zero) { fprintf(stderr, "the two paths disagree\n"); return 3; }
   }
   bpmi_free(ctx, d_shared_pts); bpmi_free(ctx, d_shared_sc); bpmi_free(ctx, d_pts); bpmi_free(ctx, d_sc);
   bpmi_host_free(ctx, recv);

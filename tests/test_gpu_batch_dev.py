@@ -391,7 +391,8 @@ def test_large_aggregated_proofs_device_equals_host(eng, m, bits):
 
 def test_c_program_verifies_a_batch_through_the_abi_only(eng, tmp_path):
     """examples/batch_verify_c_abi.c: a C99 program over include/bpmi.h and libbpmi.so alone verifies a batch of wire proofs
-    (page-locked receive buffer -> bpmi_rp_batch_prepare_dev -> shared coefficients -> bpmi_msm_segs_dev): a valid batch, one
+    (page-locked receive buffer -> bpmi_rp_batch_prepare_dev -> shared coefficients -> bpmi_msm_segs_dev, and the same as ONE call,
+    bpmi_rp_batch_verify_dev, with the same verdict): a valid batch, one
     with a flipped transcript bit (rejected before the MSM, with the proof's index) and one with exchanged commitments (the
     MSM is not the identity)."""
     import os
@@ -418,7 +419,7 @@ def test_c_program_verifies_a_batch_through_the_abi_only(eng, tmp_path):
     good = str(tmp_path / "good.bin")
     write(good, blobs, b["Vs"])
     r = subprocess.run([exe, good, "3"], capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0 and r.stdout.count("VALID in") == 3 and "INVALID" not in r.stdout, r.stdout + r.stderr
+    assert r.returncode == 0 and r.stdout.count("VALID in") == 6 and r.stdout.count("one call: VALID") == 3 and "INVALID" not in r.stdout, r.stdout + r.stderr
     flipped = bytearray(blobs[4])
     flipped[-9] ^= 4
     bad = str(tmp_path / "bad.bin")
