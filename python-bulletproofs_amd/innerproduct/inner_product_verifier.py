@@ -8,6 +8,23 @@ from ..utils.utils import ModP, mod_hash, point_to_b64
 SUPERCURVE = secp256k1
 
 
+
+def _batch_inv(vals, q):
+    """[v^-1 mod q for v in vals] with ONE inversion (Montgomery's trick); every v is non-zero mod q."""
+    if not vals:
+        return []
+    pref, acc = [], 1
+    for v in vals:
+        pref.append(acc)
+        acc = acc * v % q
+    inv = pow(acc, -1, q)
+    out = [0] * len(vals)
+    for i in range(len(vals) - 1, -1, -1):
+        out[i] = inv * pref[i] % q
+        inv = inv * vals[i] % q
+    return out
+
+
 class Proof1:
     """Protocol 1 proof (reference :10-17)."""
 
@@ -87,7 +104,7 @@ class Verifier2(_Checker):
         pr, q = self.proof, SUPERCURVE.q
         xv = [x.x % q for x in pr.xs]
         self.assertThat(all(xv))                    # a challenge = 0 (mod q) cannot come out of mod_hash: "Proof invalid", not a ValueError from pow
-        xi = [pow(v, -1, q) for v in xv]
+        xi = _batch_inv(xv, q)                       # one modular inversion for all the challenges (the reference: one egcd each, utils.py:66-72)
         pts = [self.u] + list(pr.Ls) + list(pr.Rs) + [self.P]
         scs = [pr.a.x * pr.b.x] + [-v * v for v in xv] + [-v * v for v in xi] + [-1]
         return xv, xi, pts, scs
@@ -129,7 +146,7 @@ class Verifier2(_Checker):
         #   sum a s_i g_i + sum b s_i^-1 h_i + (a b) u - P - sum (x_j^2 L_j + x_j^-2 R_j) = 0
         q = SUPERCURVE.q
         xsq = [x.x * x.x % q for x in pr.xs]
-        xisq = [pow(v, -1, q) for v in xsq]
+        xisq = _batch_inv(xsq, q)
         total = PipSECP256k1.multiexp(
             self.g + self.h + [self.u] + pr.Ls + pr.Rs + [self.P],
             sa + sb + [pr.a * pr.b] + [-v for v in xsq] + [-v for v in xisq] + [-1],
