@@ -122,6 +122,23 @@ class PackedPoints(list):
     def __init__(self, pts, packed=None):
         super().__init__(pts)
         self.packed = packed if packed is not None else b"".join(map(Point.to_le64, self))
+        self._dev = None                # (engine, DeviceBuffer): the same bytes in device memory, uploaded at first use
+
+    def device(self, engine):
+        """The list in `engine`'s device memory, uploaded once (generator lists are deployment constants: the verifiers
+        read them from there instead of uploading them per proof).  Freed with the object."""
+        if self._dev is None or self._dev[0] is not engine:
+            if self._dev is not None:
+                self._dev[1].free()
+            self._dev = (engine, engine.upload(self.packed))
+        return self._dev[1]
+
+    def __del__(self):
+        try:
+            if self._dev is not None:
+                self._dev[1].free()
+        except Exception:
+            pass
 
     @classmethod
     def join(cls, *parts):

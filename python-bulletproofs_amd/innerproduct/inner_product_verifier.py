@@ -1,7 +1,7 @@
 """Inner-product argument: proof containers and verifiers
 (reference: src/innerproduct/inner_product_verifier.py)."""
 from .. import engine as _engine
-from ..ec import Point, pack_points, pack_scalars, secp256k1
+from ..ec import PackedPoints, Point, pack_points, pack_scalars, secp256k1
 from ..pippenger import PipSECP256k1
 from ..utils.utils import ModP, mod_hash, point_to_b64
 
@@ -130,14 +130,22 @@ class Verifier2(_Checker):
         n = len(self.g)
         if n >= self.DEVICE_SVECTOR_MIN_N and n & (n - 1) == 0:
             eng = _engine.default_engine()
-            d_g, d_h = eng.upload(pack_points(self.g)), eng.upload(pack_points(self.h))
+            own = []                                 # PackedPoints keep their device copy; anything else is uploaded for this call
+            d_gh = []
+            for lst in (self.g, self.h):
+                if isinstance(lst, PackedPoints):
+                    d_gh.append(lst.device(eng))
+                else:
+                    d_gh.append(eng.upload(pack_points(lst)))
+                    own.append(d_gh[-1])
             d_s = None if self.h_scale is None else eng.upload(pack_scalars(self.h_scale, SUPERCURVE.q))
+            if d_s is not None:
+                own.append(d_s)
             try:
-                return self.verify_dev(d_g, d_h, n, d_s, eng, _transcript_checked=True)
+                return self.verify_dev(d_gh[0], d_gh[1], n, d_s, eng, _transcript_checked=True)
             finally:
-                for d in (d_g, d_h, d_s):
-                    if d is not None:
-                        d.free()
+                for d in own:
+                    d.free()
         sa, sb = self._scaled_ss(pr.xs, pr.a.x, pr.b.x)
         if self.h_scale is not None:
             q = SUPERCURVE.q
