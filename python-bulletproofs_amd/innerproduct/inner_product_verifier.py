@@ -154,6 +154,7 @@ class Verifier2(_Checker):
         #   sum a s_i g_i + sum b s_i^-1 h_i + (a b) u - P - sum (x_j^2 L_j + x_j^-2 R_j) = 0
         q = SUPERCURVE.q
         xsq = [x.x * x.x % q for x in pr.xs]
+        self.assertThat(all(xsq))                   # as in _extra_terms: a zero challenge is "Proof invalid", not a ValueError
         xisq = _batch_inv(xsq, q)
         total = PipSECP256k1.multiexp(
             self.g + self.h + [self.u] + pr.Ls + pr.Rs + [self.P],
