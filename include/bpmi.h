@@ -81,6 +81,7 @@ int bpmi_sync(bpmi_ctx *ctx);
  *                  experiment that lost (profiles/r03_glv_msm_on_off.txt); default 0 = off
  *   "priority"     1: the MSM's latency-bound stages raise their waves' issue priority (s_setprio).  An experiment that lost
  *                  (profiles/r03_wave_priority_ab.txt); default 0
+ *   "spin_wait"    polls of a completion event before the calling thread sleeps in the runtime (process-wide; default 0)
  *   "mul_batch_glv" bpmi_ec_mul_batch[_dev] from 32 768 points: 1 (default) GLV halves on fixed signed three-bit windows over affine
  *                  3P, 5P, 7P (k_ec_odd_multiples + k_ec_mul_batch_glv; workspace 1 080 B per point of a 196 608-point slice);
  *                  0 the bit-serial ladder at every size

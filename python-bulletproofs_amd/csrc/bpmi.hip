@@ -131,6 +131,7 @@ int bpmi_set_option(bpmi_ctx *ctx, const char *name, int64_t value) {
   if (!strcmp(name, "hist_threads")) { if (value != 0 && value != 256 && value != 512 && value != 1024) return fail(ctx, BPMI_E_ARG, "hist_threads must be 0, 256, 512 or 1024"); ctx->opt_hist_threads = (int)value; return BPMI_OK; }
   if (!strcmp(name, "hist_blocks")) { if (value < 0 || value > 8192) return fail(ctx, BPMI_E_ARG, "hist_blocks must be in [0, 8192]"); ctx->opt_hist_blocks = (int)value; return BPMI_OK; }
   if (!strcmp(name, "quad_final")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "quad_final must be 0 or 1"); ctx->opt_quad = (int)value; return BPMI_OK; }
+  if (!strcmp(name, "spin_wait")) { if (value < 0 || value > 10000000) return fail(ctx, BPMI_E_ARG, "spin_wait must be in [0, 10^7]"); g_spin_wait = (int)value; return BPMI_OK; }
   if (!strcmp(name, "mul_batch_glv")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "mul_batch_glv must be 0 or 1"); ctx->opt_mulb = (int)value; return BPMI_OK; }
   if (!strcmp(name, "tail")) { if (value < 0 || value > 2) return fail(ctx, BPMI_E_ARG, "tail must be 0, 1 or 2"); ctx->opt_tail = (int)value; return BPMI_OK; }
   if (!strcmp(name, "small_n")) { if (value < -1 || value > (1 << 16)) return fail(ctx, BPMI_E_ARG, "small_n must be -1 .. 65536"); ctx->opt_small = (int)value; return BPMI_OK; }
