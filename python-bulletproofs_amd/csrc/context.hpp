@@ -121,6 +121,37 @@ struct StageTimer {
   }
 };
 
+// Host -> device copies of 4 KB .. 8 MB from PAGEABLE memory go through a page-locked ring of the ctx.  Left to the runtime such
+// a copy pins the caller's pages on the fly, and on a busy host that took 9 ms for the 1.5 MB of a bpmi_msm2 call (0.1 ms on a
+// quiet one: config C4's prover 31-39 ms instead of 10.5 on one box in four).  Sources that are already page-locked
+// (bpmi_host_alloc: the batch verifier's receive buffers) and very large or tiny copies go straight to the runtime.
+#define UP_RING_BYTES (32u << 20)
+static hipError_t h2d(bpmi_ctx *ctx, void *dst, const void *src, size_t bytes, hipStream_t st) {
+  if (bytes < 4096 || bytes > (8u << 20)) return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st);
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, src) == hipSuccess && attr.type == hipMemoryTypeHost) return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st);
+  (void)hipGetLastError();                                  // an ordinary host pointer is "invalid value" to the query
+  if (!ctx->up_ring) {
+    if (hipHostMalloc(&ctx->up_ring, UP_RING_BYTES, hipHostMallocDefault) != hipSuccess) { ctx->up_ring = nullptr; (void)hipGetLastError(); return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st); }
+    if (hipEventCreateWithFlags(&ctx->up_ev, hipEventDisableTiming) != hipSuccess) return hipErrorOutOfMemory;
+  }
+  const size_t need = (bytes + 255) & ~(size_t)255;
+  if (ctx->up_cursor + need > UP_RING_BYTES) {              // wrap: everything queued from the ring so far must have left it
+    if (ctx->up_pending) {                                  // (the event covers the stream of the last copy; the ctx's streams are few)
+      hipError_t e = hipEventSynchronize(ctx->up_ev);
+      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+      if (e == hipSuccess && ctx->stream1) e = hipStreamSynchronize(ctx->stream1);
+      if (e != hipSuccess) return e;
+    }
+    ctx->up_cursor = 0;
+  }
+  char *stage = (char *)ctx->up_ring + ctx->up_cursor;
+  ctx->up_cursor += need;
+  memcpy(stage, src, bytes);
+  hipError_t e = hipMemcpyAsync(dst, stage, bytes, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) { e = hipEventRecord(ctx->up_ev, st); ctx->up_pending = true; }
+  return e;
+}
 // Waits of the latency-critical paths.  Polling the event before sleeping in the runtime (option "spin_wait" = number of polls) was
 // tried against the slow boxes of the pool and is OFF: the slowness was the pageable uploads (h2d above), the polls change nothing
 // for one caller (C2 0.36 ms, C4 10.3 ms either way) and cost the batch verifier's eight threads 4.5 % of their throughput
