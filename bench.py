@@ -115,7 +115,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the C5 / C3 extra measurements")
     ap.add_argument("--no-pipeline", action="store_true", help="synchronous bpmi_msm_dev per step instead of the two-deep pipeline")
-    ap.add_argument("--async-lanes", type=int, default=1, help="1: the two in-flight MSMs run on the engine's two lanes (streams)")
+    ap.add_argument("--async-lanes", type=int, default=1, help="1: the in-flight MSMs run on the engine's lanes (one stream + workspace per slot)")
+    ap.add_argument("--depth", type=int, default=2, choices=(2, 3), help="MSMs in flight in the timed loop (slots rotate)")
     ap.add_argument("--soak-seconds", type=float, default=6.0,
                     help="untimed MSMs after the timed region, so that an external sampler (rocm-smi every few seconds) sees the GPU busy")
     ap.add_argument("--cpu-logn", type=int, default=0, help="CPU baseline on the first 2^k pairs; 0 = the bench size itself (--logn)")
@@ -221,15 +222,16 @@ def main():
         # (N > 1: ONE all_gather of the 64-byte partials + bpmi_ec_sum fold on every rank)
         # the exchange of step j is started (queued on its own stream) and collected one iteration later, so the host
         # never waits for the fold kernel before it has fed the GPU its next MSM
-        if k:
-            eng.msm_dev_enqueue(0, d_pts, d_sc, n)
+        D = args.depth
+        for j in range(min(k, D - 1)):
+            eng.msm_dev_enqueue(j % D, d_pts, d_sc, n)
         pending = None
         for j in range(k):
             ta = time.perf_counter()
-            if j + 1 < k:
-                eng.msm_dev_enqueue((j + 1) & 1, d_pts, d_sc, n)
+            if j + D - 1 < k:
+                eng.msm_dev_enqueue((j + D - 1) % D, d_pts, d_sc, n)
             tb = time.perf_counter()
-            part = eng.msm_finish(j & 1)
+            part = eng.msm_finish(j % D)
             tc = time.perf_counter()
             if pending is not None:
                 res = sharded.combine_wait(pending)
@@ -247,10 +249,10 @@ def main():
             return
         t_h = time.perf_counter()
         while (time.perf_counter() - t_h) * 1e3 < args.preheat_ms:
-            eng.msm_dev_enqueue(0, d_pts, d_sc, n)
-            eng.msm_dev_enqueue(1, d_pts, d_sc, n)
-            eng.msm_finish(0)
-            eng.msm_finish(1)
+            for sl in range(args.depth):
+                eng.msm_dev_enqueue(sl, d_pts, d_sc, n)
+            for sl in range(args.depth):
+                eng.msm_finish(sl)
     preheat()
     result = run_steps(args.warmup)
     host_t[:] = [0.0, 0.0, 0.0, 0.0, 0]
@@ -326,7 +328,7 @@ def main():
                                " over secp256k1, uniform 256-bit scalars (SHA-256), points k_i*G, inputs resident in HBM, "
                                "64-byte result to host every step",
                    "pairs_per_gpu": n, "sharding": "pairs across ranks, one all_gather of 64 B partials per step",
-                   "pipeline": "synchronous" if args.no_pipeline else "two MSMs in flight (bpmi_msm_dev_enqueue / bpmi_msm_finish)"},
+                   "pipeline": "synchronous" if args.no_pipeline else "%d MSMs in flight (bpmi_msm_dev_enqueue / bpmi_msm_finish)" % args.depth},
         "n_ranks_seen": n_ranks_seen,
         "dist_backend": backend,
         "result_ok": result_ok,

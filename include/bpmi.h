@@ -55,7 +55,14 @@ int bpmi_version(void);
 /* number of visible HIP devices (0 if none); does not initialise a device */
 int bpmi_device_count(void);
 /* `stream`: a hipStream_t to enqueue on (e.g. torch.cuda.current_stream().cuda_stream),
- * or NULL for a stream owned by the ctx.  Returns NULL on failure. */
+ * or NULL for a stream owned by the ctx.  Returns NULL on failure.
+ * One ctx drives ONE device.  A multi-GPU caller creates one ctx per device (one process per GPU is
+ * what the Python side and bench.py do; a single C process may equally hold several ctxs, one thread
+ * each) and folds the 64-byte partial results itself (bpmi_ec_sum): the library has no multi-device
+ * entry point and no collective of its own.
+ * Host memory a ctx allocates lazily: a 32 MB page-locked staging ring at the first upload of 4 KB .. 8 MB
+ * from pageable memory (uploads from bpmi_host_alloc memory bypass it), 16 KB of page-locked result
+ * buffer per pending-MSM slot. */
 bpmi_ctx *bpmi_ctx_create(int device, void *stream);
 void bpmi_ctx_destroy(bpmi_ctx *ctx);
 const char *bpmi_last_error(const bpmi_ctx *ctx);
@@ -68,9 +75,11 @@ int bpmi_sync(bpmi_ctx *ctx);
  *                  2 host thread (default; the result is consumed on the host anyway)
  *   "small_n"      largest n that runs on the one-launch small-MSM kernel (-1: never; default 4096)
  *   "split"        1: run one MSM as two window groups on the ctx's two lanes (default 0)
- *   "async_lanes"  1: slot 1 of bpmi_msm_dev_enqueue runs on the ctx's second lane (own stream and workspace), so
+ *   "async_lanes"  1: slot s of bpmi_msm_dev_enqueue runs on the ctx's lane s (own stream and workspace; three lanes), so
  *                  the tail stages of one MSM overlap the sort / accumulate of the next (inputs must be complete
  *                  before the first enqueue of a burst; default 0)
+ *   "fused_scan"   1 (default): the accumulate kernel folds the partial results of the 64 threads of a wave itself (two
+ *                  records per wave go to the segmented scan); 0: two records per thread (round 3; kept for A/B runs and tests)
  *   "rp_lanes"     bpmi_rp_batch_prepare_dev: proofs per 64-lane wave (power of two; 0 = 64, the fastest measured)
  *   "rp_only_role" profiling only: 0..3 runs just that role of the preparation kernel (Protocol-2 hash chain | the other
  *                  transcript checks | inversion and factor tables | inverse-free scalars); such a call reports proof 0 as bad
@@ -81,7 +90,7 @@ int bpmi_sync(bpmi_ctx *ctx);
  *                  experiment that lost (profiles/r03_glv_msm_on_off.txt); default 0 = off
  *   "priority"     1: the MSM's latency-bound stages raise their waves' issue priority (s_setprio).  An experiment that lost
  *                  (profiles/r03_wave_priority_ab.txt); default 0
- *   "spin_wait"    polls of a completion event before the calling thread sleeps in the runtime (process-wide; default 0)
+ *   "spin_wait"    polls of a completion event before the calling thread sleeps in the runtime (per ctx; default 0)
  *   "mul_batch_glv" bpmi_ec_mul_batch[_dev] from 32 768 points: 1 (default) GLV halves on fixed signed three-bit windows over affine
  *                  3P, 5P, 7P (k_ec_odd_multiples + k_ec_mul_batch_glv; workspace 1 080 B per point of a 196 608-point slice);
  *                  0 the bit-serial ladder at every size
@@ -110,9 +119,10 @@ int bpmi_msm(bpmi_ctx *ctx, const uint8_t *pts, const uint8_t *scalars, uint64_t
 int bpmi_msm_dev(bpmi_ctx *ctx, const void *d_pts, const void *d_scalars, uint64_t n, uint8_t out[64]);
 /* The same MSM (n <= 2^23, device pointers) split into an asynchronous pair: `enqueue` queues every kernel
  * and the device->host copy of the window sums on the ctx stream and returns; `finish` waits for that
- * MSM only (its own completion event), runs the host part of the tail and writes the result.  Two slots
- * (0, 1) may be in flight: a caller that alternates them overlaps the host tail -- and its own work between
- * two MSMs, e.g. the exchange of per-GPU partial results -- of MSM k with the kernels of MSM k + 1.  The
+ * MSM only (its own completion event), runs the host part of the tail and writes the result.  Three slots
+ * (0, 1, 2) may be in flight: a caller that rotates them overlaps the host tail -- and its own work between
+ * two MSMs, e.g. the exchange of per-GPU partial results -- of MSM k with the kernels of MSM k + 1 (and, three
+ * deep with "async_lanes", the sort of MSM k + 2).  The
  * inputs must stay valid and unmodified until `finish`; while a slot is pending, a synchronous call that
  * needs it fails with BPMI_E_STATE. */
 int bpmi_msm_dev_enqueue(bpmi_ctx *ctx, int slot, const void *d_pts, const void *d_scalars, uint64_t n);

@@ -51,6 +51,7 @@ using namespace bpmi;
 #include "msm_host.hpp"
 #include "rp_batch_host.hpp"
 #include "rp_algebra_host.hpp"
+#include "transcript_host.hpp"
 #include "rp_batch_kernels.hpp"
 
 // ------------------------------------------------------------------------------------
@@ -103,6 +104,8 @@ void bpmi_ctx_destroy(bpmi_ctx *ctx) {
   if (ctx->up_ring) (void)hipHostFree(ctx->up_ring);
   if (ctx->up_ev) (void)hipEventDestroy(ctx->up_ev);
   if (ctx->stream1) { (void)hipStreamSynchronize(ctx->stream1); (void)hipStreamDestroy(ctx->stream1); }
+  if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamDestroy(ctx->stream2); }
+  if (ctx->ws2) (void)hipFree(ctx->ws2);
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   for (auto e : ctx->ev_slice) if (e) (void)hipEventDestroy(e);
@@ -130,8 +133,9 @@ int bpmi_set_option(bpmi_ctx *ctx, const char *name, int64_t value) {
   if (!strcmp(name, "priority")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "priority must be 0 or 1"); ctx->opt_prio = (int)value; return BPMI_OK; }
   if (!strcmp(name, "hist_threads")) { if (value != 0 && value != 256 && value != 512 && value != 1024) return fail(ctx, BPMI_E_ARG, "hist_threads must be 0, 256, 512 or 1024"); ctx->opt_hist_threads = (int)value; return BPMI_OK; }
   if (!strcmp(name, "hist_blocks")) { if (value < 0 || value > 8192) return fail(ctx, BPMI_E_ARG, "hist_blocks must be in [0, 8192]"); ctx->opt_hist_blocks = (int)value; return BPMI_OK; }
+  if (!strcmp(name, "fused_scan")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "fused_scan must be 0 or 1"); ctx->opt_fuse = (int)value; return BPMI_OK; }
   if (!strcmp(name, "quad_final")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "quad_final must be 0 or 1"); ctx->opt_quad = (int)value; return BPMI_OK; }
-  if (!strcmp(name, "spin_wait")) { if (value < 0 || value > 10000000) return fail(ctx, BPMI_E_ARG, "spin_wait must be in [0, 10^7]"); g_spin_wait = (int)value; return BPMI_OK; }
+  if (!strcmp(name, "spin_wait")) { if (value < 0 || value > 10000000) return fail(ctx, BPMI_E_ARG, "spin_wait must be in [0, 10^7]"); ctx->opt_spin_wait = (int)value; return BPMI_OK; }
   if (!strcmp(name, "mul_batch_glv")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "mul_batch_glv must be 0 or 1"); ctx->opt_mulb = (int)value; return BPMI_OK; }
   if (!strcmp(name, "tail")) { if (value < 0 || value > 2) return fail(ctx, BPMI_E_ARG, "tail must be 0, 1 or 2"); ctx->opt_tail = (int)value; return BPMI_OK; }
   if (!strcmp(name, "small_n")) { if (value < -1 || value > (1 << 16)) return fail(ctx, BPMI_E_ARG, "small_n must be -1 .. 65536"); ctx->opt_small = (int)value; return BPMI_OK; }
@@ -203,17 +207,20 @@ int bpmi_msm_dev(bpmi_ctx *ctx, const void *d_pts, const void *d_scalars, uint64
   HIPCHK(ctx, hipStreamWaitEvent(ctx->stream1, ctx->ev_fork, 0));
   // an error in the middle leaves the OTHER lane's slice queued: drain both lanes and release both slots, or every later MSM on
   // this ctx would fail with "still pending"
-  auto abandon = [&](int code) { msm_abandon_pending(ctx); return code; };
+  unsigned mine = 0;                                       // slots that hold a slice of THIS call
+  auto abandon = [&](int code) { msm_abandon_pending(ctx, mine); return code; };
   for (uint64_t k = 0; k < nsl; k++) {
     const int lane = (int)(k & 1);
-    if (k >= 2) { rc = msm_finish(ctx, lane, parts.data() + 64 * (k - 2)); if (rc) return abandon(rc); }
+    if (k >= 2) { mine &= ~(1u << lane); rc = msm_finish(ctx, lane, parts.data() + 64 * (k - 2)); if (rc) return abandon(rc); }
     const uint64_t lo = k * SLICE, cnt = std::min<uint64_t>(SLICE, n - lo);
     Segs s = segs_init();
     s.pts[0] = (const u32 *)d_pts + 16 * lo; s.sc[0] = (const u32 *)d_scalars + 8 * lo; s.n[0] = (u32)cnt; s.total = (u32)cnt;
     rc = msm_enqueue(ctx, lane, lane, s);
     if (rc) return abandon(rc);
+    mine |= 1u << lane;
   }
   for (uint64_t k = (nsl >= 2 ? nsl - 2 : 0); k < nsl; k++) {
+    mine &= ~(1u << (k & 1));
     rc = msm_finish(ctx, (int)(k & 1), parts.data() + 64 * k);
     if (rc) return abandon(rc);
   }
@@ -225,7 +232,7 @@ int bpmi_msm_dev(bpmi_ctx *ctx, const void *d_pts, const void *d_scalars, uint64
 // kernels of MSM k + 1.
 int bpmi_msm_dev_enqueue(bpmi_ctx *ctx, int slot, const void *d_pts, const void *d_scalars, uint64_t n) {
   if (!ctx || (n && (!d_pts || !d_scalars))) return ctx ? fail(ctx, BPMI_E_ARG, "null argument") : BPMI_E_ARG;
-  if (slot < 0 || slot > 1) return fail(ctx, BPMI_E_ARG, "slot must be 0 or 1");
+  if (slot < 0 || slot >= BPMI_LANES) return fail(ctx, BPMI_E_ARG, "slot must be 0, 1 or 2");
   if (n > (1ull << 23)) return fail(ctx, BPMI_E_ARG, "bpmi_msm_dev_enqueue takes at most 2^23 pairs (use bpmi_msm_dev)");
   if (ctx->opt_split) return fail(ctx, BPMI_E_STATE, "option split is not available with the asynchronous entry points");
   if (ctx->pend[slot].async) return fail(ctx, BPMI_E_STATE, "an MSM is still pending in this slot (bpmi_msm_finish it first)");
@@ -234,11 +241,17 @@ int bpmi_msm_dev_enqueue(bpmi_ctx *ctx, int slot, const void *d_pts, const void 
   s.pts[0] = (const u32 *)d_pts; s.sc[0] = (const u32 *)d_scalars; s.n[0] = (u32)n; s.total = (u32)n;
   // option async_lanes: slot 1 runs on the second lane (own stream + workspace), so the latency-bound tail stages of
   // one MSM (segmented scan, bucket reduction: few waves) overlap the throughput stages of the next one
-  const int lane = (ctx->opt_async_lanes && slot == 1) ? 1 : 0;
+  const int lane = ctx->opt_async_lanes ? slot : 0;
   int rc;
   if (ctx->opt_async_lanes) {
     rc = ensure_lane(ctx, 1);
+    if (rc == BPMI_OK && slot == 2) rc = ensure_lane(ctx, 2);
     if (rc) return rc;
+  }
+  if (lane == 2 && !ctx->async_lane2_ordered) {               // as below for lane 1: once per burst, before this lane's first MSM
+    HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->stream));
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_join, 0));
+    ctx->async_lane2_ordered = true;
   }
   if (ctx->opt_async_lanes && !ctx->async_lane1_ordered) {
     // order lane 1 after whatever produced the inputs on the ctx stream, once per burst and BEFORE this burst's first MSM is
@@ -252,16 +265,19 @@ int bpmi_msm_dev_enqueue(bpmi_ctx *ctx, int slot, const void *d_pts, const void 
   ctx->chain_accum = ctx->opt_async_lanes != 0;
   rc = msm_enqueue(ctx, lane, slot, s);
   ctx->chain_accum = false;
-  if (rc == BPMI_OK) ctx->pend[slot].async = true;
+  if (rc == BPMI_OK) { ctx->pend[slot].async = true; ctx->pend[slot].async_empty = (n == 0); }
   return rc;
 }
 int bpmi_msm_finish(bpmi_ctx *ctx, int slot, uint8_t out[64]) {
   if (!ctx || !out) return ctx ? fail(ctx, BPMI_E_ARG, "null argument") : BPMI_E_ARG;
-  if (slot < 0 || slot > 1) return fail(ctx, BPMI_E_ARG, "slot must be 0 or 1");
+  if (slot < 0 || slot >= BPMI_LANES) return fail(ctx, BPMI_E_ARG, "slot must be 0, 1 or 2");
   if (!ctx->pend[slot].async) return fail(ctx, BPMI_E_STATE, "no MSM was enqueued in this slot");
   ctx->pend[slot].async = false;
-  if (!ctx->pend[0].async && !ctx->pend[1].async) { ctx->async_lane1_ordered = false; ctx->accum_chain_lane = -1; }
+  if (!ctx->pend[0].async && !ctx->pend[1].async && !ctx->pend[2].async) { ctx->async_lane1_ordered = ctx->async_lane2_ordered = false; ctx->accum_chain_lane = -1; }
   HIPCHK(ctx, hipSetDevice(ctx->device));
+  // msm_finish reads an inactive slot as "n was 0" (the identity, which a verifier reads as VALID): only a slot that was enqueued
+  // with n = 0 may be inactive here
+  if (!ctx->pend[slot].active && !ctx->pend[slot].async_empty) return fail(ctx, BPMI_E_STATE, "the MSM of this slot was abandoned");
   return msm_finish(ctx, slot, out);
 }
 int bpmi_msm(bpmi_ctx *ctx, const uint8_t *pts, const uint8_t *scalars, uint64_t n, uint8_t out[64]) {
@@ -1007,40 +1023,10 @@ int bpmi_ipa_prove_rounds(bpmi_ipa *st, const uint8_t *digest, uint64_t digest_l
     uint8_t *L = Ls + 64 * (size_t)r, *R = Rs + 64 * (size_t)r;
     int rc = bpmi_ipa_round_LR(st, L, R);
     if (rc) return rc;
-    for (const uint8_t *pt : {(const uint8_t *)L, (const uint8_t *)R}) {
-      uint8_t comp[33] = {0}, item[48];
-      bool zero = true;
-      for (int k = 0; k < 64; k++) zero &= pt[k] == 0;
-      if (!zero) {
-        comp[0] = (pt[32] & 1) ? 3 : 2;                              // y is little-endian: its parity is in byte 0
-        for (int k = 0; k < 32; k++) comp[1 + k] = pt[31 - k];        // x big-endian
-      }
-      const size_t il = rp::point_item(item, comp);
-      dg.insert(dg.end(), item, item + il);
-      dg.push_back('&');
-    }
-    rp::Sha one;
-    rp::sha_init(one);
-    rp::sha_update(one, (const uint8_t *)"1", 1);
-    rp::sha_update(one, dg.data(), dg.size());
+    rpt::append_point(dg, L);
+    rpt::append_point(dg, R);
     rp::Sq x, xi;
-    rp::mod_hash_q(x, one, dg.data(), dg.size());
-    {                                                                // decimal item of x
-      uint64_t v[4] = {x.v[0], x.v[1], x.v[2], x.v[3]};
-      char buf[80];
-      int pos = 80;
-      for (;;) {
-        unsigned __int128 rem = 0;                                   // v /= 10^19
-        const uint64_t D = 10000000000000000000ULL;
-        for (int k = 3; k >= 0; k--) { const unsigned __int128 cur = (rem << 64) | v[k]; v[k] = (uint64_t)(cur / D); rem = cur % D; }
-        uint64_t chunk = (uint64_t)rem;
-        const bool more = (v[0] | v[1] | v[2] | v[3]) != 0;
-        for (int k = 0; k < 19 && (more || chunk || k == 0); k++) { buf[--pos] = (char)('0' + chunk % 10); chunk /= 10; }
-        if (!more) break;
-      }
-      dg.insert(dg.end(), buf + pos, buf + 80);
-      dg.push_back('&');
-    }
+    rpt::challenge(x, dg);
     rp::q_inv(xi, x);
     uint8_t xb[32], xib[32];
     rp::q_to_le(xb, x); rp::q_to_le(xib, xi);
@@ -1049,9 +1035,7 @@ int bpmi_ipa_prove_rounds(bpmi_ipa *st, const uint8_t *digest, uint64_t digest_l
     if (rc) return rc;
     r++;
   }
-  if (dg.size() > cap) return fail(ctx, BPMI_E_ARG, "digest_out too small");
-  memcpy(digest_out, dg.data(), dg.size());
-  *out_len = dg.size();
+  if (!rpt::export_digest(dg, digest_out, cap, out_len)) return fail(ctx, BPMI_E_ARG, "digest_out too small");
   *rounds = r;
   return BPMI_OK;
 }
@@ -1152,37 +1136,6 @@ int bpmi_rp_batch_prepare(uint32_t n_gens, uint32_t values_per_proof, uint64_t n
     rp::Sq sum = rp::q_small(0);
     for (int t = 0; t < threads; t++) rp::q_add(sum, sum, acc[t][i]);
     rp::q_to_le(shared + 32 * i, sum);
-  }
-  return BPMI_OK;
-}
-
-// out[i - lo] = mod_hash(str(i) || tail, q) for i in [lo, hi), 32 bytes little-endian each: the reference's seeded "randomness"
-// (src/utils/utils.py:84-97; the provers draw their blinding vectors sL, sR this way, rangeproof_prover.py:57-60, one hash per
-// element) in native code.  Host code, no GPU involved; `threads` host threads share the range.
-int bpmi_mod_hash_range(const uint8_t *tail, uint64_t tail_len, uint64_t lo, uint64_t hi, int threads, uint8_t *out) {
-  if ((!tail && tail_len) || !out || hi < lo) return BPMI_E_ARG;
-  const uint64_t count = hi - lo;
-  if (threads < 1) threads = 1;
-  if ((uint64_t)threads > count) threads = count ? (int)count : 1;
-  auto work = [&](int t) {
-    std::vector<uint8_t> msg(21 + tail_len);        // 20 digits of a 64-bit counter + snprintf's terminator
-    for (uint64_t i = lo + count * t / threads, e = lo + count * (t + 1) / threads; i < e; i++) {
-      const int dl = snprintf((char *)msg.data(), 21, "%llu", (unsigned long long)i);
-      if (tail_len) memcpy(msg.data() + dl, tail, tail_len);
-      rp::Sha one;
-      rp::sha_init(one);
-      rp::sha_update(one, (const uint8_t *)"1", 1);
-      rp::sha_update(one, msg.data(), dl + tail_len);
-      rp::Sq v;
-      rp::mod_hash_q(v, one, msg.data(), dl + tail_len);
-      rp::q_to_le(out + 32 * (i - lo), v);
-    }
-  };
-  if (threads == 1) work(0);
-  else {
-    std::vector<std::thread> th;
-    for (int t = 0; t < threads; t++) th.emplace_back(work, t);
-    for (auto &x : th) x.join();
   }
   return BPMI_OK;
 }
@@ -1314,7 +1267,7 @@ static int rp_prepare_enqueue(bpmi_ctx *ctx, uint32_t n_gens, uint32_t m, uint64
 }
 // both lanes idle again; the first error of (rc, the two waits)
 static int rp_wait_lanes(bpmi_ctx *ctx, int rc) {
-  const hipError_t e0 = wait_stream(ctx->stream), e1 = ctx->stream1 ? wait_stream(ctx->stream1) : hipSuccess;
+  const hipError_t e0 = wait_stream(ctx, ctx->stream), e1 = ctx->stream1 ? wait_stream(ctx, ctx->stream1) : hipSuccess;      // (lane 2 never takes part in a batch)
   if (rc) return rc;
   HIPCHK(ctx, e0);
   HIPCHK(ctx, e1);

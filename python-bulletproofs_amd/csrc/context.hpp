@@ -15,6 +15,7 @@ static const char *STAGE_NAMES[BPMI_NSTAGES] = {
 };
 
 struct EvPair { int stage; hipEvent_t a, b; };
+#define BPMI_LANES 3          // streams / workspaces / pending-MSM slots of a ctx
 
 struct bpmi_ctx {
   int device = 0;
@@ -29,12 +30,16 @@ struct bpmi_ctx {
   // throughput-bound stages of the other
   hipStream_t stream1 = nullptr;
   void *ws1 = nullptr; size_t ws1_bytes = 0;
+  // third lane: only the asynchronous MSM pipeline uses it (slot 2 of bpmi_msm_dev_enqueue with option async_lanes): with
+  // three MSMs in flight the sort of MSM k + 1 is on the GPU while MSM k accumulates and MSM k - 1 is being reduced
+  hipStream_t stream2 = nullptr;
+  void *ws2 = nullptr; size_t ws2_bytes = 0;
   hipEvent_t ev_slice[4] = {nullptr, nullptr, nullptr, nullptr};      // batch preparation: upload slice c has arrived
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;      // fork: lane 1 may start; join: lane 1's work is in (batch preparation)
   // software pipeline of the asynchronous MSM pair on two lanes: the accumulate kernel of an MSM waits for the
   // accumulate kernel of the MSM enqueued before it (on the other lane), so the throughput-bound stage always has the
   // whole GPU while the other lane's latency-bound tail (segmented scan, bucket reduction) and next sort run beside it
-  hipEvent_t ev_accum[2] = {nullptr, nullptr};
+  hipEvent_t ev_accum[BPMI_LANES] = {nullptr, nullptr, nullptr};
   int accum_chain_lane = -1;     // lane whose ev_accum is the newest, -1: none pending
   bool chain_accum = false;      // set by bpmi_msm_dev_enqueue around msm_enqueue
   void *up_ring = nullptr;       // page-locked staging ring of h2d()
@@ -46,8 +51,8 @@ struct bpmi_ctx {
   // keep two MSMs in flight on ONE stream: the host tail of MSM k overlaps the kernels of MSM k + 1).
   struct PendingMsm {
     bool active = false; u32 W = 0, nv = 0, c = 0; int tail = 2; TailOffs to;
-    void *pin = nullptr; size_t pin_bytes = 0; hipEvent_t done = nullptr; bool async = false;
-  } pend[2];
+    void *pin = nullptr; size_t pin_bytes = 0; hipEvent_t done = nullptr; bool async = false, async_empty = false;
+  } pend[BPMI_LANES];
   void *stage_in = nullptr; size_t stage_in_bytes = 0;  // device staging for host-pointer entry points
   // options
   int opt_c = 0;        // window bits, 0 = auto
@@ -66,8 +71,10 @@ struct bpmi_ctx {
   int opt_rp_lanes = 0;      // batch preparation kernel: proofs per wave (0 = chosen from the batch size)
   void *rp_buf = nullptr; size_t rp_buf_bytes = 0;   // batch preparation: per-proof contributions to the shared generators
   int opt_epl = 0;           // bucket reduction stage 1: elements per lane (0 = default 16)
+  int opt_fuse = 1;          // k_accum_l0 folds a wave's partial records itself (0: two records per thread, the round-3 path; A/B and tests)
+  int opt_spin_wait = 0;     // polls of an event / stream before sleeping in the runtime (see wait_event; measured: no gain, off)
   int opt_async_lanes = 0;   // 1: slot 1 of the asynchronous MSM pair runs on the second lane
-  bool async_lane1_ordered = false;
+  bool async_lane1_ordered = false, async_lane2_ordered = false;
   int opt_split = 0;    // 1: one MSM as two window groups, one per lane (measured: +5 % at 2^20, -8 % at 2^19; off)
   int64_t opt_ipa_big = 0;   // base length from which the IPA folds generators 16-way (0 = default 2^18)
   // profiling
@@ -133,7 +140,12 @@ static hipError_t h2d(bpmi_ctx *ctx, void *dst, const void *src, size_t bytes, h
   (void)hipGetLastError();                                  // an ordinary host pointer is "invalid value" to the query
   if (!ctx->up_ring) {
     if (hipHostMalloc(&ctx->up_ring, UP_RING_BYTES, hipHostMallocDefault) != hipSuccess) { ctx->up_ring = nullptr; (void)hipGetLastError(); return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st); }
-    if (hipEventCreateWithFlags(&ctx->up_ev, hipEventDisableTiming) != hipSuccess) return hipErrorOutOfMemory;
+    if (hipEventCreateWithFlags(&ctx->up_ev, hipEventDisableTiming) != hipSuccess) {       // no ring without its event: the runtime's own copy
+      (void)hipGetLastError();
+      (void)hipHostFree(ctx->up_ring);
+      ctx->up_ring = nullptr; ctx->up_ev = nullptr;
+      return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st);
+    }
   }
   const size_t need = (bytes + 255) & ~(size_t)255;
   if (ctx->up_cursor + need > UP_RING_BYTES) {              // wrap: everything queued from the ring so far must have left it
@@ -141,6 +153,7 @@ static hipError_t h2d(bpmi_ctx *ctx, void *dst, const void *src, size_t bytes, h
       hipError_t e = hipEventSynchronize(ctx->up_ev);
       if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
       if (e == hipSuccess && ctx->stream1) e = hipStreamSynchronize(ctx->stream1);
+      if (e == hipSuccess && ctx->stream2) e = hipStreamSynchronize(ctx->stream2);
       if (e != hipSuccess) return e;
     }
     ctx->up_cursor = 0;
@@ -156,9 +169,8 @@ static hipError_t h2d(bpmi_ctx *ctx, void *dst, const void *src, size_t bytes, h
 // tried against the slow boxes of the pool and is OFF: the slowness was the pageable uploads (h2d above), the polls change nothing
 // for one caller (C2 0.36 ms, C4 10.3 ms either way) and cost the batch verifier's eight threads 4.5 % of their throughput
 // (profiles/r03_spin_wait_ab.txt).
-static int g_spin_wait = 0;              // polls of the event before sleeping in the runtime (option "spin_wait"; process-wide; see wait_event)
-static hipError_t wait_event(hipEvent_t ev) {
-  for (int spin = 0; spin < g_spin_wait; spin++) {                  // some tens of milliseconds at most
+static hipError_t wait_event(const bpmi_ctx *ctx, hipEvent_t ev) {
+  for (int spin = 0; spin < ctx->opt_spin_wait; spin++) {           // some tens of milliseconds at most (option "spin_wait", per ctx)
     const hipError_t e = hipEventQuery(ev);
     if (e != hipErrorNotReady) return e;
 #if defined(__x86_64__)
@@ -167,8 +179,8 @@ static hipError_t wait_event(hipEvent_t ev) {
   }
   return hipEventSynchronize(ev);
 }
-static hipError_t wait_stream(hipStream_t st) {
-  for (int spin = 0; spin < g_spin_wait; spin++) {
+static hipError_t wait_stream(const bpmi_ctx *ctx, hipStream_t st) {
+  for (int spin = 0; spin < ctx->opt_spin_wait; spin++) {
     const hipError_t e = hipStreamQuery(st);
     if (e != hipErrorNotReady) return e;
 #if defined(__x86_64__)
@@ -186,21 +198,27 @@ static int ensure_ws(bpmi_ctx *ctx, size_t bytes) {
   return BPMI_OK;
 }
 static int ensure_lane(bpmi_ctx *ctx, int lane) {
-  if (lane == 0 || ctx->stream1) return BPMI_OK;
-  HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream1, hipStreamNonBlocking));
-  HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-  HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
-  for (int k = 0; k < 2; k++) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_accum[k], hipEventDisableTiming));
+  if (lane == 0) return BPMI_OK;
+  if (!ctx->stream1) {
+    HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream1, hipStreamNonBlocking));
+    HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+    HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+    for (int k = 0; k < BPMI_LANES; k++) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_accum[k], hipEventDisableTiming));
+  }
+  if (lane == 2 && !ctx->stream2) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
   return BPMI_OK;
 }
-static hipStream_t lane_stream(bpmi_ctx *ctx, int lane) { return lane ? ctx->stream1 : ctx->stream; }
+static hipStream_t lane_stream(bpmi_ctx *ctx, int lane) { return lane == 0 ? ctx->stream : (lane == 1 ? ctx->stream1 : ctx->stream2); }
+static void *lane_ws(bpmi_ctx *ctx, int lane) { return lane == 0 ? ctx->ws : (lane == 1 ? ctx->ws1 : ctx->ws2); }
 static int ensure_ws_lane(bpmi_ctx *ctx, int lane, size_t bytes) {
   if (lane == 0) return ensure_ws(ctx, bytes);
-  if (bytes <= ctx->ws1_bytes) return BPMI_OK;
-  if (ctx->ws1) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream1)); HIPCHK(ctx, hipFree(ctx->ws1)); ctx->ws1 = nullptr; ctx->ws1_bytes = 0; }
+  void *&ws = lane == 1 ? ctx->ws1 : ctx->ws2;
+  size_t &have = lane == 1 ? ctx->ws1_bytes : ctx->ws2_bytes;
+  if (bytes <= have) return BPMI_OK;
+  if (ws) { HIPCHK(ctx, hipStreamSynchronize(lane_stream(ctx, lane))); HIPCHK(ctx, hipFree(ws)); ws = nullptr; have = 0; }
   const size_t want = bytes + bytes / 8;
-  HIPCHK(ctx, hipMalloc(&ctx->ws1, want));
-  ctx->ws1_bytes = want;
+  HIPCHK(ctx, hipMalloc(&ws, want));
+  have = want;
   return BPMI_OK;
 }
 static int ensure_pin_slot(bpmi_ctx *ctx, int slot, size_t bytes);

@@ -37,7 +37,7 @@ struct MsmWs {
   u32 *rec_key[2], *rec_pt[2];
   u32 *D, *E, *out;
   size_t total;
-  u32 nscan_blocks, rec0_max;
+  u32 nscan_blocks, rec0_max, nchunks;
 };
 static void msm_layout(const MsmGeom &g, MsmWs &w, char *base, bool glv = false) {
   size_t o = 0;
@@ -47,7 +47,8 @@ static void msm_layout(const MsmGeom &g, MsmWs &w, char *base, bool glv = false)
   w.glv_neg = (unsigned char *)take(glv ? g.n : 0);
   const size_t nW = (size_t)g.n * g.W;
   w.nscan_blocks = (u32)((g.G + SCAN_TILE - 1) / SCAN_TILE);
-  w.rec0_max = (u32)(2 * ((nW + g.L - 1) / g.L));
+  w.nchunks = (u32)((nW + g.L - 1) / g.L);                  // threads of k_accum_l0
+  w.rec0_max = 2u * (g.fuse ? (w.nchunks + 63u) / 64u : w.nchunks);
   const u32 rec1_max = 2 * ((w.rec0_max + 255) / 256);
   // sort path 2 (LDS partition sort) when the bucket key has more than 8 bits and the
   // packed entry (8-bit lo | sign | 23-bit index) fits; path 1 (global atomics) otherwise
@@ -63,7 +64,7 @@ static void msm_layout(const MsmGeom &g, MsmWs &w, char *base, bool glv = false)
   w.sidx = take(4ull * nW);
   w.dig16 = (unsigned short *)take(w.P ? 2ull * nW : 0);
   w.negs = (unsigned char *)take(w.P ? g.n : 0);
-  w.chunk_key = take(4ull * (w.rec0_max / 2 + 1));
+  w.chunk_key = take(4ull * (w.nchunks + 1));
   w.buckets = take(4ull * XYZZ_WORDS * g.G);
   w.rec_key[0] = take(4ull * w.rec0_max);
   w.rec_pt[0] = take(4ull * XYZZ_WORDS * w.rec0_max);
@@ -164,13 +165,14 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, int slot, const Segs &segs_in, u
   g.L = ctx->opt_chunk > 0 ? (u32)ctx->opt_chunk : ((n >= (1u << 19) && ctx->chain_accum) ? L_lanes : L_one);
   g.nv = (g.B <= 256u) ? 1u : 4u;                  // partial sums per window handed to the tail
   g.prio = ctx->opt_prio ? 1u : 0u;
+  g.fuse = ctx->opt_fuse ? 1u : 0u;
   MsmWs w;
   msm_layout(g, w, nullptr, glv);
   int rc = ensure_lane(ctx, lane);
   if (rc) return rc;
   rc = ensure_ws_lane(ctx, lane, w.total);
   if (rc) return rc;
-  msm_layout(g, w, (char *)(lane ? ctx->ws1 : ctx->ws), glv);
+  msm_layout(g, w, (char *)lane_ws(ctx, lane), glv);
   hipStream_t st = lane_stream(ctx, lane);
   if (glv) {
     StageTimer t(ctx, ST_DIGITS, st);
@@ -263,11 +265,9 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, int slot, const Segs &segs_in, u
     HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_accum[ctx->accum_chain_lane], 0));
   {
     StageTimer t(ctx, ST_ACCUM, st);
-    const u32 nthreads = w.rec0_max / 2;
-    if (glv) hipLaunchKernelGGL(k_accum_l0<true>, dim3((nthreads + 255) / 256), dim3(256), 0, st, segs, g, w.off, w.chunk_key, w.sidx,
-                                w.buckets, w.rec_key[0], w.rec_pt[0]);
-    else hipLaunchKernelGGL(k_accum_l0<false>, dim3((nthreads + 255) / 256), dim3(256), 0, st, segs, g, w.off, w.chunk_key, w.sidx,
-                            w.buckets, w.rec_key[0], w.rec_pt[0]);
+    const u32 nthreads = w.nchunks;
+    auto kern = glv ? (g.fuse ? k_accum_l0<true, true> : k_accum_l0<true, false>) : (g.fuse ? k_accum_l0<false, true> : k_accum_l0<false, false>);
+    hipLaunchKernelGGL(kern, dim3((nthreads + 255) / 256), dim3(256), 0, st, segs, g, w.off, w.chunk_key, w.sidx, w.buckets, w.rec_key[0], w.rec_pt[0]);
   }
   if (ctx->chain_accum) { HIPCHK(ctx, hipEventRecord(ctx->ev_accum[lane], st)); ctx->accum_chain_lane = lane; }
   debug_sync(ctx, "ST_ACCUM", st);
@@ -338,11 +338,14 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, int slot, const Segs &segs_in, u
   HIPCHK(ctx, hipGetLastError());
   return BPMI_OK;
 }
-// error path of a caller that has MSMs queued in the pending slots: wait for both lanes, release both slots
-static void msm_abandon_pending(bpmi_ctx *ctx) {
+// error path of a caller that has MSMs of ITS OWN queued in pending slots (bit s of `mine` = slot s was enqueued by this call):
+// wait for both lanes, release those slots and no others -- a slot that holds a caller's asynchronous MSM (bpmi_msm_dev_enqueue)
+// keeps it, so a later bpmi_msm_finish still returns that MSM's result and never the identity of an emptied slot
+static void msm_abandon_pending(bpmi_ctx *ctx, unsigned mine) {
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->stream1) (void)hipStreamSynchronize(ctx->stream1);
-  ctx->pend[0].active = ctx->pend[1].active = false;
+  if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
+  for (int s = 0; s < BPMI_LANES; s++) if ((mine >> s) & 1u) ctx->pend[s].active = false;
 }
 // Wait for the slot's MSM (its completion event: work enqueued behind it keeps running) and run the
 // host part of the tail; out = the MSM result.
@@ -350,7 +353,7 @@ static int msm_finish(bpmi_ctx *ctx, int slot, uint8_t out[64]) {
   bpmi_ctx::PendingMsm &pd = ctx->pend[slot];
   if (!pd.active) { memset(out, 0, 64); return BPMI_OK; }      // n == 0
   pd.active = false;
-  HIPCHK(ctx, wait_event(pd.done));
+  HIPCHK(ctx, wait_event(ctx, pd.done));
   const void *pin = pd.pin;
   if (pd.tail == 1) {
     memcpy(out, pin, 64);
@@ -372,7 +375,7 @@ static int msm_run_split(bpmi_ctx *ctx, const Segs &segs, uint8_t out[64]) {
   rc = msm_enqueue(ctx, 0, 0, segs, 0, Wa);
   if (rc) return rc;
   rc = msm_enqueue(ctx, 1, 1, segs, Wa, W - Wa);
-  if (rc) { msm_abandon_pending(ctx); return rc; }
+  if (rc) { msm_abandon_pending(ctx, 1u); return rc; }
   bpmi_ctx::PendingMsm &p0 = ctx->pend[0], &p1 = ctx->pend[1];
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream1));
@@ -404,7 +407,7 @@ static int msm_run_pair(bpmi_ctx *ctx, const Segs &s0, uint8_t out0[64], const S
   rc = msm_enqueue(ctx, 0, 0, s0);
   if (rc) return rc;
   rc = msm_enqueue(ctx, 1, 1, s1);
-  if (rc) { msm_abandon_pending(ctx); return rc; }
+  if (rc) { msm_abandon_pending(ctx, 1u); return rc; }
   rc = msm_finish(ctx, 0, out0);
   const int rc1 = msm_finish(ctx, 1, out1);
   return rc ? rc : rc1;

@@ -15,6 +15,7 @@ struct MsmGeom {
   u32 L;       // entries per thread in k_accum_l0
   u32 nv;      // partial sums per window that the bucket reduction hands to the tail (1 or 4)
   u32 prio;    // 1: every kernel but the accumulation raises its waves' issue priority (see raise_priority)
+  u32 fuse;    // 1: k_accum_l0 folds the partial records of a wave's 64 chunks itself (two records per WAVE go to k_segscan, not two per thread)
 };
 // Experiment (option "priority", default off; profiles/r03_wave_priority_ab.txt).  The stages around the accumulation are chains
 // of dependent work with few waves; beside the OTHER lane's accumulation (three busy waves on every SIMD) they stretch three- to
@@ -527,20 +528,43 @@ __global__ void __launch_bounds__(256) k_scatter(MsmGeom g, const u32 *__restric
 }
 
 // ---- level 0: every thread adds exactly L sorted entries --------------------------------
-template <bool GLV> __global__ void __launch_bounds__(256) k_accum_l0(Segs segs, MsmGeom g, const u32 *__restrict__ off,
+__device__ __forceinline__ void xyzz_shfl_up(xyzz &r, const xyzz &a, int d) {
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    r.X.v[i] = (u32)__shfl_up((int)a.X.v[i], d, 64);
+    r.Y.v[i] = (u32)__shfl_up((int)a.Y.v[i], d, 64);
+    r.ZZ.v[i] = (u32)__shfl_up((int)a.ZZ.v[i], d, 64);
+    r.ZZZ.v[i] = (u32)__shfl_up((int)a.ZZZ.v[i], d, 64);
+  }
+}
+// FUSE (round 4): the first level of the segmented scan happens HERE, inside the wave.  A chunk leaves a head run (the part of
+// its first bucket that lies in the chunk) and a tail run (of its last bucket); the tail of lane i and the head of lane i + 1
+// are almost always the same bucket.  Without FUSE both go to memory as 148-byte records -- 2 per thread, 390 000 at n = 2^20 --
+// and k_segscan's first level (1 525 blocks, every wave paying a general addition) adds them up: 52 us of a 1.04 ms step, and at
+// n = 2^16 0.035 of 0.36 ms.  With FUSE the head waits in LDS, and after the loop the wave runs a segmented scan over its 64
+// lanes with shuffles: tails that cover a whole chunk ("single": the chunk is one run) chain through log-many steps (none for
+// uniform digits), then every head takes the tail in front of it -- ONE general addition per thread --, completed runs go
+// straight to their buckets and only the wave's first and last run become records: 2 per WAVE (6 100 at 2^20; k_segscan is two
+// tiny launches).  Heavy buckets keep their log depth: 6 steps in the wave, then k_segscan over waves.
+template <bool GLV, bool FUSE> __global__ void __launch_bounds__(256) k_accum_l0(Segs segs, MsmGeom g, const u32 *__restrict__ off,
                                                   const u32 *__restrict__ chunk_key, const u32 *__restrict__ sidx,
                                                   u32 *__restrict__ buckets, u32 *__restrict__ rec_key, u32 *__restrict__ rec_pt) {
+  __shared__ u32 s_head[FUSE ? 256 * LDS_STRIDE : 1];
   const u32 E = off[g.G];
   const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   const u64 start = t * g.L;
-  if (start >= E) return;
+  const bool valid = start < E;
+  if (!FUSE) { if (!valid) return; }
+  else if (__ballot(valid) == 0ull) return;          // (valid lanes are a prefix of the wave)
   const u32 end = (u32)((start + g.L < E) ? start + g.L : E);
   xyzz acc;
   xyzz_set_inf(acc);
-  u32 cur = chunk_key[t];              // bucket containing position `start`
+  u32 cur = valid ? chunk_key[t] : 0u;              // bucket containing position `start`
+  const u32 hk = cur;                  // ... = the key of the chunk's head run
+  bool first = true;
+  if (valid) {
   u32 boundary = off[cur + 1];         // first position after that bucket's run
   u32 boundary2 = off[cur + 2 < g.G ? cur + 2 : g.G];       // ... and after the next bucket's: on its way before a flush needs it
-  bool first = true;
   // software pipeline: the point of entry j+1 and the index of entry j+2 are in flight while entry j is added (the address of
   // a point depends on its index: with the index only one entry ahead every iteration began with a full load latency)
   u32 e_next = sidx[start];
@@ -562,7 +586,11 @@ template <bool GLV> __global__ void __launch_bounds__(256) k_accum_l0(Segs segs,
       load_entry_point<GLV>(w_next, segs, e_next & 0x7FFFFFFFu);
     }
     if (j == boundary) {               // the run of `cur` ended: flush, move to the next non-empty bucket
-      if (first) { rec_key[2 * t] = cur; xyzz_store_g(rec_pt + (2 * t) * XYZZ_WORDS, acc); first = false; }
+      if (first) {
+        if (FUSE) xyzz_store(s_head + threadIdx.x * LDS_STRIDE, acc);
+        else { rec_key[2 * t] = cur; xyzz_store_g(rec_pt + (2 * t) * XYZZ_WORDS, acc); }
+        first = false;
+      }
       else xyzz_store_g(buckets + (u64)cur * XYZZ_WORDS, acc);
       xyzz_set_inf(acc);
       cur++; boundary = boundary2;
@@ -583,19 +611,71 @@ template <bool GLV> __global__ void __launch_bounds__(256) k_accum_l0(Segs segs,
     }
     xyzz_madd_signed(acc, P, (e >> 31) != 0);
   }
-  if (first) {
-    rec_key[2 * t] = cur; xyzz_store_g(rec_pt + (2 * t) * XYZZ_WORDS, acc);
-    xyzz_set_inf(acc);
   }
-  rec_key[2 * t + 1] = cur;
-  xyzz_store_g(rec_pt + (2 * t + 1) * XYZZ_WORDS, acc);
+  if (!FUSE) {
+    if (first) {
+      rec_key[2 * t] = cur; xyzz_store_g(rec_pt + (2 * t) * XYZZ_WORDS, acc);
+      xyzz_set_inf(acc);
+    }
+    rec_key[2 * t + 1] = cur;
+    xyzz_store_g(rec_pt + (2 * t + 1) * XYZZ_WORDS, acc);
+    return;
+  }
+  // ---- the wave's segmented scan.  Lane i holds: tail run S = acc with key tk = cur; head run (key hk) in LDS unless the chunk
+  // is one single run (`single`: then S IS the chunk and hk == tk).  link: the run in front of this chunk continues into it.
+  const u32 lane = threadIdx.x & 63u;
+  const u32 gw = (u32)(t >> 6);                                  // global wave index: records 2 gw (head run of the wave), 2 gw + 1 (tail run)
+  const bool single = first;
+  const u32 tk = cur;
+  const u32 prev_tk = (u32)__shfl_up((int)tk, 1, 64);
+  const bool link = valid && lane > 0u && prev_tk == hk;
+  bool F = !(valid && single && link);                          // true: this lane's S starts a segment
+  for (u32 d = 1; d < 64u; d <<= 1) {
+    const bool take = !F;                                        // (implies lane >= d: lane 0 always starts a segment)
+    if (__ballot(take) == 0ull) break;
+    xyzz o;
+    xyzz_shfl_up(o, acc, (int)d);
+    const bool oF = __shfl_up((int)F, (int)d, 64) != 0;
+    if (take) { xyzz_add(acc, o, acc); F = oF; }
+  }
+  const u32 first_key = (u32)__shfl((int)hk, 0, 64);
+  const bool next_valid = __shfl_down((int)valid, 1, 64) != 0, next_link = __shfl_down((int)link, 1, 64) != 0;
+  const bool last = valid && (lane == 63u || !next_valid);
+  // tails first (then S is dead and the heads have the registers): S_i is complete when the next chunk does not continue it (or
+  // there is no next chunk in the wave); the copy for the lane behind is taken before
+  xyzz Sp;
+  xyzz_shfl_up(Sp, acc, 1);
+  const bool s_done = valid && (last || !next_link);
+  const bool s_is_head = tk == first_key;                         // the wave's first run reaches to here (every chunk so far single)
+  {
+    // one store site, per-lane destination (see k_segscan about merged stores in divergent flow)
+    u32 *dst = s_is_head ? rec_pt + (u64)(2u * gw) * XYZZ_WORDS : (last ? rec_pt + (u64)(2u * gw + 1u) * XYZZ_WORDS : buckets + (u64)tk * XYZZ_WORDS);
+    if (s_done) xyzz_store_g(dst, acc);
+  }
+  if (last) {
+    rec_key[2u * gw + 1u] = tk;
+    if (s_is_head) {                                             // the whole wave is one run: empty tail record
+      xyzz_set_inf(acc);
+      xyzz_store_g(rec_pt + (u64)(2u * gw + 1u) * XYZZ_WORDS, acc);
+    }
+  }
+  // heads: H_i += S_(i-1) where the run continues and ends inside chunk i; a head with the wave's first key is the wave's head record
+  const bool has_head = valid && !single;
+  if (__ballot(has_head) != 0ull) {
+    if (has_head) xyzz_load(acc, s_head + threadIdx.x * LDS_STRIDE); else xyzz_set_inf(acc);
+    if (__ballot(has_head && link) != 0ull) { if (has_head && link) xyzz_add(acc, Sp, acc); }
+    u32 *dst = (hk == first_key) ? rec_pt + (u64)(2u * gw) * XYZZ_WORDS : buckets + (u64)hk * XYZZ_WORDS;
+    if (has_head) xyzz_store_g(dst, acc);
+  }
+  if (lane == 0u) rec_key[2u * gw] = first_key;
 }
 
 // number of records entering segscan level `level` (1-based); 0 when that level has nothing to do
-__device__ __forceinline__ u32 records_at_level(u32 E, u32 L, int level, bool &is_final) {
+__device__ __forceinline__ u32 records_at_level(u32 E, u32 L, u32 fuse, int level, bool &is_final) {
   is_final = false;
   if (E == 0) return 0;
-  u32 R = 2u * ((E + L - 1) / L);
+  const u32 chunks = (E + L - 1) / L;
+  u32 R = 2u * (fuse ? (chunks + 63u) / 64u : chunks);           // two records per wave of k_accum_l0<.., true>, per thread otherwise
   for (int l = 1; l < level; l++) {
     const u32 nb = (R + 255u) / 256u;
     if (nb <= 1) return 0;          // the previous level was already final
@@ -613,7 +693,7 @@ __global__ void __launch_bounds__(256) k_segscan(MsmGeom g, const u32 *__restric
   __shared__ u32 s_key[256];
   __shared__ u32 s_val[256 * LDS_STRIDE];
   bool is_final;
-  const u32 R = records_at_level(off[g.G], g.L, level, is_final);
+  const u32 R = records_at_level(off[g.G], g.L, g.fuse, level, is_final);
   const u32 nb = (R + 255u) / 256u;
   if (blockIdx.x >= nb) return;
   const u32 tid = threadIdx.x;

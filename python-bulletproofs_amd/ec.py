@@ -7,6 +7,8 @@ Group operations are NOT computed here: `+` and `*` go to the HIP engine
 (bpmi_ec_sum / bpmi_ec_mul_batch).  Only representation-level work (equality, negation
 of y, the on-curve check of the constructor, byte packing) is done with Python ints.
 """
+import threading
+
 from . import engine as _engine
 
 
@@ -122,21 +124,34 @@ class PackedPoints(list):
     def __init__(self, pts, packed=None):
         super().__init__(pts)
         self.packed = packed if packed is not None else b"".join(map(Point.to_le64, self))
-        self._dev = None                # (engine, DeviceBuffer): the same bytes in device memory, uploaded at first use
+        self._dev = {}                  # id(engine) -> (engine, DeviceBuffer): the same bytes in that engine's device memory
+        self._dev_lock = threading.Lock()
 
     def device(self, engine):
-        """The list in `engine`'s device memory, uploaded once (generator lists are deployment constants: the verifiers
-        read them from there instead of uploading them per proof).  Freed with the object."""
-        if self._dev is None or self._dev[0] is not engine:
-            if self._dev is not None:
-                self._dev[1].free()
-            self._dev = (engine, engine.upload(self.packed))
-        return self._dev[1]
+        """The list in `engine`'s device memory, uploaded once PER ENGINE (generator lists are deployment constants shared by
+        every engine and thread of a process: the verifiers read them from there instead of uploading them per proof).  A
+        buffer is never freed on behalf of another engine -- its queued MSMs may still read it; `release()` or the
+        collection of the list frees them (a DeviceBuffer whose engine is already closed frees nothing)."""
+        with self._dev_lock:
+            hit = self._dev.get(id(engine))
+            if hit is None or hit[0] is not engine or hit[1].ptr is None:
+                hit = self._dev[id(engine)] = (engine, engine.upload(self.packed))
+            return hit[1]
+
+    def release(self, engine=None):
+        """Free the device copy held for `engine` (all engines when None)."""
+        with self._dev_lock:
+            keys = [k for k, (e, _) in self._dev.items() if engine is None or e is engine]
+            for k in keys:
+                e, buf = self._dev.pop(k)
+                if getattr(e, "ctx", None):
+                    buf.free()
+                else:
+                    buf.ptr = None        # the ctx is gone, and with it the right to call into it
 
     def __del__(self):
         try:
-            if self._dev is not None:
-                self._dev[1].free()
+            self.release()
         except Exception:
             pass
 
@@ -213,6 +228,36 @@ class PackedScalars(list):
     def __repr__(self):
         self._fill()
         return list.__repr__(self)
+
+    # every other read of the list sees the materialised integers ...
+    def copy(self):
+        self._fill()
+        return list.copy(self)
+
+    def __reversed__(self):
+        self._fill()
+        return list.__reversed__(self)
+
+    def index(self, *args):
+        self._fill()
+        return list.index(self, *args)
+
+    def count(self, v):
+        self._fill()
+        return list.count(self, v)
+
+    def __mul__(self, k):
+        self._fill()
+        return list.__mul__(self, k)
+
+    __rmul__ = __mul__
+
+    # ... and a write would leave `packed` behind: the class is read-only (build a new one)
+    def _read_only(self, *args, **kwargs):
+        raise TypeError("PackedScalars is read-only: its wire form is attached (build a new one)")
+
+    __setitem__ = __delitem__ = __iadd__ = __imul__ = _read_only
+    append = extend = insert = pop = remove = clear = sort = reverse = _read_only
 
     @classmethod
     def join(cls, *parts):

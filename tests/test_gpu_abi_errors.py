@@ -114,6 +114,18 @@ def test_async_pair_state_machine(gp):
     assert lib.bpmi_msm_finish(ctx, 1, out) == 0 and out.raw == bytes(64)
     assert lib.bpmi_msm_finish(ctx, 1, out) == -5
     assert lib.bpmi_msm_dev(ctx, d_p.ptr, d_s.ptr, 6000, out) == 0 and out.raw == want
+    # a synchronous PAIR that is refused because slot 1 holds the caller's asynchronous MSM must leave that MSM alone: its
+    # finish returns ITS result (an emptied slot would read as the identity -- "valid" to a verifier) -- ADVICE r03
+    o0, o1 = ctypes.create_string_buffer(64), ctypes.create_string_buffer(64)
+    assert lib.bpmi_msm_dev_enqueue(ctx, 1, d_p.ptr, d_s.ptr, 6000) == 0
+    assert lib.bpmi_msm2(ctx, pb, sb, 6000, o0, pb, sb, 6000, o1) == -5
+    assert b"pending" in lib.bpmi_last_error(ctx)
+    assert lib.bpmi_msm_finish(ctx, 1, out) == 0 and out.raw == want
+    assert lib.bpmi_msm2(ctx, pb, sb, 6000, o0, pb, sb, 6000, o1) == 0 and o0.raw == want and o1.raw == want
+    # ... and the same with slot 0 taken: the pair is refused before anything of it is queued
+    assert lib.bpmi_msm_dev_enqueue(ctx, 0, d_p.ptr, d_s.ptr, 6000) == 0
+    assert lib.bpmi_msm2(ctx, pb, sb, 6000, o0, pb, sb, 6000, o1) == -5
+    assert lib.bpmi_msm_finish(ctx, 0, out) == 0 and out.raw == want
     # three device segments in one MSM; argument errors
     P = (ctypes.c_void_p * 3)(d_p.ptr, d_p.ptr + 64 * 1000, d_p.ptr + 64 * 2500)
     S = (ctypes.c_void_p * 3)(d_s.ptr, d_s.ptr + 32 * 1000, d_s.ptr + 32 * 2500)

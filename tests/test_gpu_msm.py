@@ -113,16 +113,64 @@ def test_msm_multiblock_segscan(gp, n, chunk, c):
     try:
         eng.set_option("chunk", chunk)
         eng.set_option("window_bits", c)
-        for tail in (1, 2):
-            eng.set_option("tail", tail)
+        for fused in (1, 0):                 # the wave-level scan inside k_accum_l0 (two records per wave) / two records per thread
+            eng.set_option("fused_scan", fused)
+            eng.set_option("split", 0)
+            for tail in (1, 2):
+                eng.set_option("tail", tail)
+                assert eng.msm_bytes(pb, sb, n) == cbind.msm_bytes(pb, sb, n)
+            eng.set_option("split", 1)           # two window groups on two lanes (carry crosses the groups)
             assert eng.msm_bytes(pb, sb, n) == cbind.msm_bytes(pb, sb, n)
-        eng.set_option("split", 1)           # two window groups on two lanes (carry crosses the groups)
-        assert eng.msm_bytes(pb, sb, n) == cbind.msm_bytes(pb, sb, n)
     finally:
         eng.set_option("chunk", 0)
         eng.set_option("window_bits", 0)
         eng.set_option("tail", 0)
         eng.set_option("split", 0)
+        eng.set_option("fused_scan", 1)
+
+
+@pytest.mark.parametrize("shape", ["one_scalar", "two_scalars", "runs_of_chunk_multiples", "runs_of_odd_lengths", "sparse_then_dense", "uniform"])
+@pytest.mark.parametrize("n,chunk,c", [(2500, 1, 4), (2500, 2, 8), (6000, 4, 10), (6000, 7, 10), (20000, 3, 8), (70, 1, 4), (130, 2, 4), (40000, 0, 0)])
+def test_msm_fused_wave_scan_shapes(gp, shape, n, chunk, c):
+    """The segmented scan k_accum_l0 runs over the 64 chunks of a wave (round 4): chunks that are one single run chained through
+    many lanes and through whole waves, runs that end exactly at chunk and at wave boundaries, a last wave with idle lanes, every
+    bucket written exactly once -- against the C oracle, and identical to the unfused path."""
+    eng = gp.engine()
+    pts, _ = gp.rand_points(n, 11)
+    rnd = random.Random(n * 7 + chunk * 13 + c)
+    L = chunk if chunk else 8
+    if shape == "one_scalar":
+        es = [rnd.randrange(Q)] * n
+    elif shape == "two_scalars":
+        a, b = rnd.randrange(Q), rnd.randrange(1 << 40)
+        es = [a if rnd.random() < 0.7 else b for _ in range(n)]
+    elif shape == "runs_of_chunk_multiples":       # every distinct scalar exactly 64 L k times: runs end at chunk AND wave boundaries
+        es = []
+        while len(es) < n:
+            es += [rnd.randrange(Q)] * (64 * L * rnd.randrange(1, 3))
+        es = es[:n]
+    elif shape == "runs_of_odd_lengths":
+        es = []
+        while len(es) < n:
+            es += [rnd.randrange(Q)] * rnd.choice((1, 2, 3, L, L + 1, 2 * L - 1, 5 * L, 63 * L, 64 * L + 1, 200))
+        es = es[:n]
+    elif shape == "sparse_then_dense":             # a handful of full-size scalars, then small ones: empty-bucket runs and heavy buckets in one MSM
+        es = [rnd.randrange(Q) if i % 97 == 0 else rnd.randrange(4) for i in range(n)]
+    else:
+        es = [rnd.randrange(Q) for _ in range(n)]
+    pb, sb = cbind.pack_points(pts), cbind.pack_scalars(es)
+    want = cbind.msm_bytes(pb, sb, n, 4)
+    try:
+        eng.set_option("chunk", chunk)
+        eng.set_option("window_bits", c)
+        eng.set_option("fused_scan", 1)
+        assert eng.msm_bytes(pb, sb, n) == want
+        eng.set_option("fused_scan", 0)
+        assert eng.msm_bytes(pb, sb, n) == want
+    finally:
+        eng.set_option("chunk", 0)
+        eng.set_option("window_bits", 0)
+        eng.set_option("fused_scan", 1)
 
 
 @pytest.mark.parametrize("logn", [16, 20])

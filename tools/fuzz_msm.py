@@ -2,7 +2,7 @@
 """Randomised differential test of the HIP MSM against the C oracle: random sizes, scalar
 shapes (uniform, tiny, near q/2 and q, repeated, zero), point shapes (duplicates, negated
 pairs, identities) and engine options (window bits, chunk length, tail placement, window-group
-split, small-MSM threshold, GLV split on / off); a few percent of the cases are large enough for the LDS sort path.
+split, small-MSM threshold, GLV split on / off, fused / unfused wave scan); a few percent of the cases are large enough for the LDS sort path.
   python tools/fuzz_msm.py [seconds]"""
 import os
 import random
@@ -63,7 +63,8 @@ while time.time() - t0 < budget:
     opts = {"window_bits": rnd.choice((0, 0, 0, 2, 4, 5, 7, 8, 9, 10, 11, 13, 16)),
             "chunk": rnd.choice((0, 0, 1, 2, 5, 16, 33, 64, 200)), "tail": rnd.choice((0, 1, 2)),
             "split": rnd.choice((0, 0, 0, 1)), "small_n": rnd.choice((0, 0, -1, 100, 65536)),
-            "glv": rnd.choice((0, 0, 1, 1, -1))}          # 1: the GLV split at every size the bucket pipeline takes, -1: never
+            "glv": rnd.choice((0, 0, 1, 1, -1)),          # 1: the GLV split at every size the bucket pipeline takes, -1: never
+            "fused_scan": rnd.choice((1, 1, 1, 0))}       # 0: two partial records per thread and k_segscan's first level (round 3)
     if n > 20000:
         opts["window_bits"] = rnd.choice((0, 0, 13, 16))
         opts["chunk"] = rnd.choice((0, 0, 16, 64))
@@ -78,5 +79,6 @@ while time.time() - t0 < budget:
         print("MISMATCH n=%d shape=%d kind=%d opts=%s seed=%d case=%d" % (n, shape, kind, opts, seed, cases), flush=True)
 for k in ("window_bits", "chunk", "tail", "split", "small_n", "glv"):
     eng.set_option(k, 0)
+eng.set_option("fused_scan", 1)
 print("fuzz: %d cases, %d mismatches, %.0f s, seed %d" % (cases, fails, time.time() - t0, seed))
 sys.exit(1 if fails else 0)
