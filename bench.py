@@ -101,6 +101,90 @@ def launch_ranks(args, argv):
     return proc.returncode if (proc.returncode or line is not None) else 1
 
 
+class PeerFailure(Exception):
+    """Some rank failed in the local phase of an extra; .bad = {rank: text}."""
+
+    def __init__(self, bad):
+        super().__init__("; ".join("rank %d: %s" % kv for kv in sorted(bad.items())))
+        self.bad = bad
+
+
+class Ready:
+    """Every extra calls ready() ONCE, after its local setup (inputs, allocations, warm-up: where a rank can fail on its own)
+    and before its first collective: the ranks exchange `None` or an error text over the control group, and if any rank
+    failed, ALL of them leave the extra with PeerFailure -- nobody waits in a collective for a rank that is gone."""
+
+    def __init__(self, gather):
+        self.gather, self.called = gather, False
+
+    def __call__(self, err=None):
+        self.called = True
+        bad = {r: t for r, t in enumerate(self.gather(err)) if t}
+        if bad:
+            raise PeerFailure(bad)
+
+
+def run_extras(extras, call_args, gather, rank, sync=lambda: None):
+    """Run [(name, fn)] one after the other on every rank; fn(*call_args, ready) -> dict.  Returns {name: dict}.
+    The contract that keeps one failing rank from costing the others (or the headline line):
+      * every rank makes exactly TWO exchanges per extra over the control group (`gather`): ready() -- inside fn, after its local
+        setup and before its first collective, or by this wrapper when fn has none or failed before it -- and the report at the end;
+      * a rank that raises in its local phase tells the others through ready(text): they all leave the extra with PeerFailure
+        before any collective, and every rank's entry carries `errors_by_rank`;
+      * a failure of the control group itself (a rank that vanished: the exchange times out) marks the group broken: the
+        remaining extras are skipped, not waited for.
+    BENCH_INJECT_FAILURE="<extra>:<rank>" makes that rank raise at the start of that extra (tests)."""
+    inject = os.environ.get("BENCH_INJECT_FAILURE", "")
+    results, dist_broken = {}, False
+    for name, fn in extras:
+        if dist_broken:
+            results[name] = {"error": "skipped: the control group failed in an earlier extra"}
+            continue
+        ready = Ready(gather)
+        res = None
+        try:
+            if inject.split(":")[:2] == [name, str(rank)]:
+                raise RuntimeError("injected failure in %s on rank %d" % (name, rank))
+            res = fn(*call_args, ready)
+            if not ready.called:     # an extra without collectives: the exchange still happens once per rank and extra,
+                try:                 # and this rank keeps its own (complete) result beside the others' errors
+                    ready()
+                except PeerFailure as pf:
+                    if isinstance(res, dict):
+                        res["errors_by_rank"] = {str(k_): v for k_, v in pf.bad.items()}
+        except PeerFailure as pf:        # another rank failed before the extra's collectives: every rank leaves it here
+            res = {"error": "skipped: " + str(pf), "errors_by_rank": {str(k_): v for k_, v in pf.bad.items()}}
+        except Exception as e:      # an extra must never cost the headline line
+            res = {"error": "%s: %s" % (type(e).__name__, e)}
+            if not ready.called:    # the others wait in ready(): tell them
+                try:
+                    ready(res["error"])
+                except PeerFailure as pf:
+                    res["errors_by_rank"] = {str(k_): v for k_, v in pf.bad.items()}
+                except Exception as e2:
+                    dist_broken = True
+                    res["control_plane"] = "%s: %s" % (type(e2).__name__, e2)
+        # end of the extra: every rank reports (this is also the barrier between two extras)
+        if not dist_broken:
+            try:
+                sync()
+                sts = gather(res.get("error") if isinstance(res, dict) else None)
+                bad = {str(r_): t_ for r_, t_ in enumerate(sts) if t_}
+                if bad and isinstance(res, dict):
+                    res.setdefault("errors_by_rank", bad)
+            except Exception as e2:
+                dist_broken = True
+                if isinstance(res, dict):
+                    res["control_plane"] = "%s: %s" % (type(e2).__name__, e2)
+        results[name] = res
+    return results
+
+
+def c5_inflight(usable, world):
+    """Batches in flight of the C5 extra: every slot is a host thread of its rank (BENCH_C5_INFLIGHT overrides)."""
+    return max(1, int(os.environ.get("BENCH_C5_INFLIGHT", "0")) or min(8, max(2, usable // world)))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -121,6 +205,9 @@ def main():
                     help="untimed MSMs after the timed region, so that an external sampler (rocm-smi every few seconds) sees the GPU busy")
     ap.add_argument("--cpu-logn", type=int, default=0, help="CPU baseline on the first 2^k pairs; 0 = the bench size itself (--logn)")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="bpmi_set_option passthrough (tuning experiments)")
+    ap.add_argument("--extra-scale", choices=("full", "small"), default="full",
+                    help="small: the extras at test sizes (C5 2^8 proofs, C3 n = 2^12, C4 4 x 16 bits, the strong MSM at --logn): the N-rank "
+                         "control flow with every extra in a minute (tests/test_gpu_dist.py)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -149,11 +236,27 @@ def main():
         # RCCL ("nccl") is the backend of record; BENCH_DIST_BACKEND=gloo exists only to dry-run the N > 1
         # control flow with several ranks sharing ONE GPU (RCCL refuses duplicate devices)
         backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+        import datetime
+        # a rank that dies must cost its peers minutes, not the runtime's default half hour
+        pg_timeout = datetime.timedelta(seconds=int(os.environ.get("BENCH_PG_TIMEOUT_S", "300")))
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=pg_timeout)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=pg_timeout)
         assert dist.get_world_size() == args.gpus, "rendezvous gave %d ranks, --gpus says %d" % (dist.get_world_size(), args.gpus)
+    # control plane of the extras (who is ready, who failed, with what text): host objects over gloo, whatever the data-path
+    # backend is -- a timeout there is a Python exception on the waiting ranks, not a watchdog abort
+    ctl = None
+    if use_dist:
+        ctl = dist.new_group(backend="gloo", timeout=pg_timeout) if backend == "nccl" else dist.group.WORLD
+
+    def gather_objs(obj):
+        """[obj of rank 0, ..., obj of rank N-1] on every rank (control group)."""
+        if not use_dist:
+            return [obj]
+        got = [None] * world
+        dist.all_gather_object(got, obj, group=ctl)
+        return got
 
     import bulletproofs_amd  # noqa: F401
     from bulletproofs_amd.engine import Engine
@@ -198,6 +301,8 @@ def main():
     local_dlog = sum(e * k for e, k in zip(ev, kv)) % Q
     c2_n = min(n, 1 << 16)
     c2_dlog = sum(e * k for e, k in zip(ev[:c2_n], kv[:c2_n])) % Q
+    ns_strong = n // world                 # extra MSM_strong: this rank's share (its first n / N pairs) of ONE n-pair MSM
+    strong_dlog = sum(e * k for e, k in zip(ev[:ns_strong], kv[:ns_strong])) % Q
     del kb, kv, eb, ev
     t_in = time.time() - t_in
 
@@ -338,12 +443,17 @@ def main():
                      "traffic_measured_in_run": False,
                      "traffic_source": traffic_src,
                      "kernel": "k_accum_l0 (msm_accumulate)", "kernel_avg_ms": acc_avg_s * 1e3,
-                     "note": "integer-ALU bound path: 96 algorithmic B/pair vs ~1.5e4 multiply-adds/pair"},
-        "alu_roofline": {"kernel": "k_accum_l0", "unit": "G field-mul/s",
-                         "achieved": madds_per_launch * MULS_PER_MADD / acc_avg_s / 1e9 if acc_avg_s > 0 else 0.0,
-                         "peak": FE_MUL_PEAK_G, "frac": (madds_per_launch * MULS_PER_MADD / acc_avg_s / 1e9 / FE_MUL_PEAK_G) if acc_avg_s > 0 else 0.0,
-                         "work": "%d windows x n mixed additions x %.1f multiplication-equivalents (8M + 2S)" % (windows, MULS_PER_MADD),
-                         "peak_source": "profiles/r03_fe_microbench.txt (V8: the product's own fe_mul in isolation; NOT a hardware peak)"},
+                     "duration_used": "kernel_avg_ms = the kernel's average over the timed steps from HIP events on its launch streams, i.e. IN the "
+                                      "pipeline, beside the other lane's sort / reduction (alone, in synchronous steps, it is stage_ms_per_msm.msm_accumulate)",
+                     "frac_step": ALGO_BYTES_PER_PAIR * n / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
+                     "frac_kernel_alone": (ALGO_BYTES_PER_PAIR * n / (stages["msm_accumulate"] / 1e3) / 1e9 / HBM_PEAK_GBS) if stages.get("msm_accumulate") else None,
+                     "note": "integer-ALU bound path: 96 algorithmic B/pair vs ~1.5e4 multiply-adds/pair; frac_step = the same bytes over the whole step (ms_per_step)"},
+        "alu_roofline": {"kernel": "k_accum_l0", "unit": "T lane multiply-adds/s (v_mad_u64_u32)",
+                         "frac_vs_own_fe_mul": (madds_per_launch * MULS_PER_MADD / acc_avg_s / 1e9 / FE_MUL_PEAK_G) if acc_avg_s > 0 else 0.0,
+                         "own_fe_mul": {"achieved_G_mul_s": madds_per_launch * MULS_PER_MADD / acc_avg_s / 1e9 if acc_avg_s > 0 else 0.0, "peak_G_mul_s": FE_MUL_PEAK_G,
+                                        "note": "against the product's own fe_mul in isolation (profiles/r03_fe_microbench.txt, V8): NOT a hardware peak, kept for "
+                                                "continuity with rounds 1-3 where it was `frac`"},
+                         "work": "%d windows x n mixed additions x %.1f multiplication-equivalents (8M + 2S)" % (windows, MULS_PER_MADD)},
         "stage_ms_per_msm": stages,
         "hip_event_ms_per_step": ev_ms / args.steps,
         "preheat_ms": args.preheat_ms,
@@ -354,24 +464,67 @@ def main():
     if isa and acc_avg_s > 0:
         mads = isa["v_mad_u64_u32_per_madd"]
         lane_mads = madds_per_launch * mads / acc_avg_s / 1e12
-        out["alu_roofline"]["frac_vs_raw_mad"] = lane_mads / RAW_MAD_TOPS
+        step_mads = madds_per_launch * mads / (elapsed / args.steps) / 1e12
+        alone_s = stages.get("msm_accumulate", 0.0) / 1e3
+        out["alu_roofline"].update({
+            "achieved": lane_mads, "peak": RAW_MAD_TOPS, "frac": lane_mads / RAW_MAD_TOPS,      # = frac_vs_raw_mad: the hardware figure IS the headline one (round 4)
+            "frac_vs_raw_mad": lane_mads / RAW_MAD_TOPS,                   # on kernel_avg_ms (the kernel in the pipeline)
+            "frac_vs_raw_mad_step": step_mads / RAW_MAD_TOPS,               # the same multiply-adds over the WHOLE step (ms_per_step): what the chip delivers per MSM
+            "frac_vs_raw_mad_kernel_alone": (madds_per_launch * mads / alone_s / 1e12 / RAW_MAD_TOPS) if alone_s > 0 else None})
         out["alu_roofline"]["raw_mad"] = {"achieved_T_lane_ops": lane_mads, "peak_T_lane_ops": RAW_MAD_TOPS,
                                           "mads_per_madd": mads, "instructions_per_madd": isa["instructions_per_madd"],
                                           "source": "profiles/r03_isa_counts.json (ISA of k_accum_l0's main path), "
                                                     "profiles/r01_fe_microbench.txt (raw v_mad_u64_u32 rate)"}
 
+    usable = usable_cpus()
+    out["host_budget"] = {"usable_cpus": usable, "ranks_on_this_host": world, "cpus_per_rank": max(1, usable // world),
+                          "c5_batches_in_flight": c5_inflight(usable, world), "c5_host_threads_per_rank": max(1, min(32, usable // world)),
+                          "cpu_baseline_threads": usable if world == 1 else 0,
+                          "note": "every batch slot of C5 is a host thread of its rank; the C oracle (cpu_baseline) runs on rank 0 at N = 1 only"}
+
     if not args.no_extra:
         out["extra"] = {}
-        extras = [("C2_msm_2e16", lambda e_, w_, r_, d_: extra_c2(e_, w_, r_, d_, d_pts, d_sc, c2_n, c2_dlog, G64)),
-                  ("C5_batch_verify", extra_c5), ("C3_ipa_prover", extra_c3), ("C4_aggregated_range_proof", extra_c4)]
-        if world > 1:         # the same verifier with 2^14 proofs per GPU: a rank's 2048-proof share of the fixed batch is mostly fixed latencies
-            extras.insert(1, ("C5_batch_verify_per_gpu_batches", lambda *a: extra_c5(*a, per_gpu=True)))
-        for name, fn in extras:
-            try:
-                out["extra"][name] = fn(eng, world, rank, dev)
-            except Exception as e:      # an extra must never cost the headline line
-                out["extra"][name] = {"error": "%s: %s" % (type(e).__name__, e)}
+        small = args.extra_scale == "small"
+
+        def msm_strong(e_, w_, r_, d_, ready):
+            """ONE MSM of n pairs split over the N ranks (n / N each, the exchange of 64-byte partials every step): the strong-scaling
+            line of the MSM in the same run as the weak headline."""
+            ready()
+            steps = min(args.steps, 50)
+            for _ in range(3):
+                sharded.multiexp_local_dev(d_pts, d_sc, ns_strong)
             barrier()
+            t_s = time.perf_counter()
+            e_.msm_dev_enqueue(0, d_pts, d_sc, ns_strong)
+            res_s, pend = None, None
+            for j in range(steps):
+                if j + 1 < steps:
+                    e_.msm_dev_enqueue((j + 1) & 1, d_pts, d_sc, ns_strong)
+                part = e_.msm_finish(j & 1)
+                if pend is not None:
+                    res_s = sharded.combine_wait(pend)
+                pend = sharded.combine_begin(part)
+            res_s = sharded.combine_wait(pend)
+            barrier()
+            dt = time.perf_counter() - t_s
+            dts = gather_objs(dt)
+            dl_ = gather_objs(strong_dlog)
+            want = e_.ec_mul_batch_bytes(G64, (sum(dl_) % Q).to_bytes(32, "little"), 1)
+            return {"metric": "Pippenger MSM scalar-point pairs/sec, ONE MSM of n = %d pairs split over %d GPUs" % (ns_strong * w_, w_),
+                    "value": ns_strong * w_ * steps / max(dts), "unit": "pairs/s", "scaling": "strong", "steps": steps,
+                    "ms_per_step": max(dts) / steps * 1e3, "ms_per_step_by_rank": [round(v / steps * 1e3, 4) for v in dts],
+                    "pairs_per_gpu": ns_strong, "result_ok": bool(res_s == want)}
+
+        extras = [("C2_msm_2e16", lambda e_, w_, r_, d_, ready: extra_c2(e_, w_, r_, d_, d_pts, d_sc, c2_n, c2_dlog, G64)),
+                  ("C5_batch_verify", (lambda *a: extra_c5(*a, log_batch=8, distinct=32)) if small else extra_c5),
+                  ("C3_ipa_prover", (lambda *a: extra_c3(*a, logn=12)) if small else extra_c3),
+                  ("C4_aggregated_range_proof", (lambda *a: extra_c4(*a, m=4, nbits=16)) if small else extra_c4)]
+        if world > 1:         # the same verifier with 2^14 proofs per GPU: a rank's 2048-proof share of the fixed batch is mostly fixed latencies
+            extras.insert(1, ("C5_batch_verify_per_gpu_batches", (lambda *a: extra_c5(*a, log_batch=8, distinct=32, per_gpu=True)) if small
+                              else (lambda *a: extra_c5(*a, per_gpu=True))))
+            if args.scaling == "weak":
+                extras.insert(0, ("MSM_strong", msm_strong))
+        out["extra"] = run_extras(extras, (eng, world, rank, dev), gather_objs, rank, lambda: torch.cuda.synchronize(dev))
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(min(args.cpu_logn or args.logn, args.logn), d_pts, d_sc, eng)
@@ -413,7 +566,7 @@ def committed_traffic(logn):
 
 
 # ---- extra: config C5, batch verification of 2^14 64-bit range proofs -----------------------------
-def extra_c5(eng, world, rank, dev, log_batch=14, distinct=1024, per_gpu=False):
+def extra_c5(eng, world, rank, dev, ready, log_batch=14, distinct=1024, per_gpu=False):
     """verifies/s of the random-linear-combination batch verifier on wire-format proofs: bytes in a page-locked receive
     buffer -> one upload -> GPU preparation (parse, SHA-256 transcript re-hashes, weighted scalars; one lane per proof) ->
     GPU decoding of 19 points per proof -> ONE MSM over 3 + 2*64 + 19*batch points; sharded by proof over the ranks.
@@ -487,6 +640,7 @@ def extra_c5(eng, world, rank, dev, log_batch=14, distinct=1024, per_gpu=False):
             return part == bytes(64)
         return finish(part)
 
+    ready()                                            # inputs, buffers and verifiers exist on every rank: the collectives start here
     for _ in range(4):                                 # warm: workspaces, pinned buffers, and the clocks (a batch is ~2 ms of GPU work)
         one_batch()
     if dist.is_initialized():
@@ -502,7 +656,16 @@ def extra_c5(eng, world, rank, dev, log_batch=14, distinct=1024, per_gpu=False):
     torch.cuda.synchronize(dev)
     elapsed = (time.perf_counter() - t0) / reps
     prof = eng.profile_read()
+    # every stage's OWN duration: one more batch with the point decoding behind the preparation kernels instead of beside them
+    # (option rp_overlap = 0): beside each other the two stretch (0.63 ms for a decoding that takes 0.32), and a roofline fraction
+    # computed on a stretched duration understates the kernel
+    eng.set_option("rp_overlap", 0)
+    eng.profile_reset()
+    ok_serial = one_batch()
+    prof_serial = eng.profile_read()
+    eng.set_option("rp_overlap", 1)
     eng.profile(False)
+    oks.append(ok_serial)
     rejected = not one_batch(corrupt=True)
     # Throughput: several batches in flight.  Verifiers with an engine (stream, workspaces) and a receive buffer of their own
     # work from their own threads (the library calls release the GIL): the upload of one batch overlaps the kernels of the other.  The
@@ -510,7 +673,7 @@ def extra_c5(eng, world, rank, dev, log_batch=14, distinct=1024, per_gpu=False):
     from concurrent.futures import ThreadPoolExecutor
     # batches in flight: throughput keeps growing with the depth (one GPU: 2: 7.9-9.2e6 verifies/s, 3: 9.1-9.4e6, 4: 9.5-10.4e6,
     # 6: 10.4-11.4e6, 8: 10.9-11.0e6, 10: 11.8-12.1e6); every slot is a host thread, so the default follows the CPUs this rank may use
-    inflight = max(1, int(os.environ.get("BENCH_C5_INFLIGHT", "0")) or min(8, max(2, usable // world)))
+    inflight = c5_inflight(usable, world)
     slots, extra_engines = [(bv, wire_buf)], []
     for _ in range(inflight - 1):
         e2 = Engine(device=eng.device)
@@ -559,8 +722,9 @@ def extra_c5(eng, world, rank, dev, log_batch=14, distinct=1024, per_gpu=False):
         elapsed, elapsed_pipe = float(tt[0].item()), float(tt[1].item())
     msm_pairs = 3 + 2 * nbits + 19 * (hi - lo)
     stage_ms = {k: v[0] / reps for k, v in prof.items() if v[1]}
-    dom = max(stage_ms, key=stage_ms.get) if stage_ms else None
-    dom_s = stage_ms.get(dom, 0.0) / 1e3 if dom else 0.0
+    serial_ms = {k: v[0] for k, v in prof_serial.items() if v[1]}
+    dom = max(serial_ms, key=serial_ms.get) if serial_ms else None
+    dom_s = serial_ms.get(dom, 0.0) / 1e3 if dom else 0.0
     wire_bytes = len(wire_joined)
     gpu_ms = sum(stage_ms.values())
     # algorithmic bytes of the dominant stage per batch: the preparation and the point decoding read the wire bytes once
@@ -583,7 +747,9 @@ def extra_c5(eng, world, rank, dev, log_batch=14, distinct=1024, per_gpu=False):
             "host_threads_per_rank": threads, "host_cores_usable": usable, "msm_pairs_per_rank": msm_pairs,
             "proves_per_s_one_gpu": distinct / t_prove,
             "gpu_stage_ms_per_batch": {k: round(v, 4) for k, v in stage_ms.items()},
-            "roofline": {"bound": "hbm", "kernel": "stage %s (the dominant GPU stage of a batch)" % dom, "kernel_ms": dom_s * 1e3,
+            "gpu_stage_ms_per_batch_serial": {k: round(v, 4) for k, v in serial_ms.items()},
+            "roofline": {"bound": "hbm", "kernel": "stage %s (the dominant GPU stage of a batch; duration from a batch whose stages run one after the other: gpu_stage_ms_per_batch_serial)" % dom,
+                         "kernel_ms": dom_s * 1e3,
                          "achieved": (dom_bytes / dom_s / 1e9) if dom_s > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (dom_bytes / dom_s / 1e9 / HBM_PEAK_GBS) if dom_s > 0 else None,
                          "algorithmic_bytes": dom_bytes, "dominant_gpu_stage": dom, "traffic": None,
@@ -679,7 +845,7 @@ def extra_c2(eng, world, rank, dev, d_pts, d_sc, n, dlog, G64):
 
 
 # ---- extra: config C3, inner-product-argument prover n = 2^20 ----------------------------------------
-def extra_c3(eng, world, rank, dev, logn=20):
+def extra_c3(eng, world, rank, dev, ready, logn=20):
     """Seconds per FastNIProver2.prove at n = 2^20 (/root/reference/src/innerproduct/inner_product_prover.py:70-110):
     g, h, a, b resident in HBM, 20 rounds of (c_L, c_R, L, R) -> host Fiat-Shamir -> fold.  With N > 1 the
     vectors are sharded cyclically (ShardedFastNIProver2) and the proof is the same one."""
@@ -719,6 +885,7 @@ def extra_c3(eng, world, rank, dev, logn=20):
         dt = time.perf_counter() - t0
         return dt, pr
 
+    ready()                              # the shards are resident on every rank: the sharded prover's collectives start here
     prove(False)                         # warm: workspaces
     prove(False)                         # ... and clocks
     if dist.is_initialized():
@@ -754,7 +921,7 @@ def extra_c3(eng, world, rank, dev, logn=20):
 
 
 # ---- extra: config C4, aggregated range proof m = 128 x 64-bit ------------------------------------------
-def extra_c4(eng, world, rank, dev, m=128, nbits=64):
+def extra_c4(eng, world, rank, dev, ready, m=128, nbits=64):
     """Seconds to prove and to verify ONE aggregated range proof over m = 128 values of 64 bits
     (/root/reference/src/rangeproofs/rangeproof_aggreg_prover.py:36-115, rangeproof_aggreg_verifier.py:55-108): vectors of
     n m = 8192 generators, one large Pedersen MSM per commitment, a 13-round inner-product argument.  Not sharded: with N > 1

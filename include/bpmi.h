@@ -96,7 +96,9 @@ int bpmi_sync(bpmi_ctx *ctx);
  *                  0 the bit-serial ladder at every size
  *   "rp_rows"      bpmi_rp_batch_prepare_dev: proofs per kernel launch (0 = as many as fit ~256 MB of scratch cells)
  *   "ipa_big_m"    base length from which the IPA prover folds its generators 16-way at
- *                  once instead of deferring the fold into the MSM scalars (default 2^18) */
+ *                  once instead of deferring the fold into the MSM scalars (default 2^18)
+ *   "ipa_small_m"  logical length at which bases below "ipa_big_m" are folded once more, through per-term products
+ *                  (0 = default 4096, 1 = never, else a power of two; the later rounds then run on the one-launch small-MSM kernel) */
 int bpmi_set_option(bpmi_ctx *ctx, const char *name, int64_t value);
 
 /* ---- device buffers (so callers need no other GPU runtime) ------------------- */

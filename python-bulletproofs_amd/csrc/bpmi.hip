@@ -29,7 +29,10 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <condition_variable>
+#include <functional>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -106,6 +109,7 @@ void bpmi_ctx_destroy(bpmi_ctx *ctx) {
   if (ctx->stream1) { (void)hipStreamSynchronize(ctx->stream1); (void)hipStreamDestroy(ctx->stream1); }
   if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamDestroy(ctx->stream2); }
   if (ctx->ws2) (void)hipFree(ctx->ws2);
+  if (ctx->fold_tab) (void)hipFree(ctx->fold_tab);
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   for (auto e : ctx->ev_slice) if (e) (void)hipEventDestroy(e);
@@ -113,6 +117,7 @@ void bpmi_ctx_destroy(bpmi_ctx *ctx) {
   if (ctx->ws1) (void)hipFree(ctx->ws1);
   for (auto &pd : ctx->pend) { if (pd.pin) (void)hipHostFree(pd.pin); if (pd.done) (void)hipEventDestroy(pd.done); }
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx->helper;
   delete ctx;
 }
 
@@ -133,6 +138,9 @@ int bpmi_set_option(bpmi_ctx *ctx, const char *name, int64_t value) {
   if (!strcmp(name, "priority")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "priority must be 0 or 1"); ctx->opt_prio = (int)value; return BPMI_OK; }
   if (!strcmp(name, "hist_threads")) { if (value != 0 && value != 256 && value != 512 && value != 1024) return fail(ctx, BPMI_E_ARG, "hist_threads must be 0, 256, 512 or 1024"); ctx->opt_hist_threads = (int)value; return BPMI_OK; }
   if (!strcmp(name, "hist_blocks")) { if (value < 0 || value > 8192) return fail(ctx, BPMI_E_ARG, "hist_blocks must be in [0, 8192]"); ctx->opt_hist_blocks = (int)value; return BPMI_OK; }
+  if (!strcmp(name, "tail_thread")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "tail_thread must be 0 or 1"); ctx->opt_tail_thread = (int)value; return BPMI_OK; }
+  if (!strcmp(name, "pair_chain")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "pair_chain must be 0 or 1"); ctx->opt_pair_chain = (int)value; return BPMI_OK; }
+  if (!strcmp(name, "small_pair")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "small_pair must be 0 or 1"); ctx->opt_pair1 = (int)value; return BPMI_OK; }
   if (!strcmp(name, "fused_scan")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "fused_scan must be 0 or 1"); ctx->opt_fuse = (int)value; return BPMI_OK; }
   if (!strcmp(name, "quad_final")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "quad_final must be 0 or 1"); ctx->opt_quad = (int)value; return BPMI_OK; }
   if (!strcmp(name, "spin_wait")) { if (value < 0 || value > 10000000) return fail(ctx, BPMI_E_ARG, "spin_wait must be in [0, 10^7]"); ctx->opt_spin_wait = (int)value; return BPMI_OK; }
@@ -153,6 +161,7 @@ int bpmi_set_option(bpmi_ctx *ctx, const char *name, int64_t value) {
   if (!strcmp(name, "fold_wnaf")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "fold_wnaf must be 0 or 1"); ctx->opt_fold_wnaf = (int)value; return BPMI_OK; }
   if (!strcmp(name, "reduce_epl")) { if (value < 0 || value > 64) return fail(ctx, BPMI_E_ARG, "reduce_epl must be 0..64"); ctx->opt_epl = (int)value; return BPMI_OK; }
   if (!strcmp(name, "chunk")) { if (value < 0 || value > 4096) return fail(ctx, BPMI_E_ARG, "chunk must be 0..4096"); ctx->opt_chunk = (int)value; return BPMI_OK; }
+  if (!strcmp(name, "ipa_small_m")) { if (value < 0 || (value & (value - 1))) return fail(ctx, BPMI_E_ARG, "ipa_small_m must be 0 (default), 1 (never) or a power of two"); ctx->opt_ipa_small = value; return BPMI_OK; }
   if (!strcmp(name, "ipa_big_m")) { if (value < 0 || (value & (value - 1))) return fail(ctx, BPMI_E_ARG, "ipa_big_m must be 0 or a power of two"); ctx->opt_ipa_big = value; return BPMI_OK; }
   return fail(ctx, BPMI_E_ARG, std::string("unknown option ") + name);
 }
@@ -527,10 +536,10 @@ int bpmi_msm_segs_dev(bpmi_ctx *ctx, uint32_t nseg, const void *const *d_pts, co
 // ---- scalar ops -------------------------------------------------------------------------------
 // njobs (1 or 2) inner products of length n in two launches; d_partial: njobs x SC_DOT_MAX_BLOCKS x 32 B
 static int sc_dot_jobs(bpmi_ctx *ctx, const DotJobs &jobs, u32 njobs, uint64_t n, u32 *d_partial) {
-  const u32 nb = (u32)std::min<uint64_t>((n + 255) / 256, SC_DOT_MAX_BLOCKS);
+  const u32 nb = n <= 4096 ? 1u : (u32)std::min<uint64_t>((n + 255) / 256, SC_DOT_MAX_BLOCKS);
   StageTimer t(ctx, ST_SCDOT);
   hipLaunchKernelGGL(k_sc_dot, dim3(nb, njobs), dim3(256), 0, ctx->stream, jobs, (u32)n, d_partial);
-  hipLaunchKernelGGL(k_sc_sum, dim3(njobs), dim3(256), 0, ctx->stream, (const u32 *)d_partial, nb, jobs);
+  if (nb > 1) hipLaunchKernelGGL(k_sc_sum, dim3(njobs), dim3(256), 0, ctx->stream, (const u32 *)d_partial, nb, jobs);
   return BPMI_OK;
 }
 static int sc_dot_dev_to(bpmi_ctx *ctx, const void *d_a, const void *d_b, uint64_t n, u32 *d_out, u32 *d_partial) {
@@ -702,7 +711,7 @@ struct bpmi_ipa {
   NafK *nafk[2];        // device, NAF tables for the multifold kernel
   u32 *hscale_buf;      // device, room for n0 scalars
   u32 *hscale;          // device, optional per-base scale of the h generators (n0 scalars) or nullptr
-  void *wtab;           // tables + scratch of the width-4 NAF generator fold (allocated with the state when it will fold), or nullptr
+  uint64_t small_m;     // logical length at which bases below big_m are folded through products (0: never)
   void *block;          // one allocation
   std::vector<sc> hcg, hch;   // host copies of the coefficient tables while 2^d <= 16
   bool lr_done;
@@ -715,6 +724,11 @@ struct bpmi_ipa {
 // is ~2 ms of pure latency.
 #define IPA_BIG_M_DEFAULT (1u << 18)
 #define IPA_BIG_D 4
+// Round 4: bases BELOW that threshold (the 2^16 points per side a 2^20-element proof is left with after its 16-way fold; the 2^14
+// generators of an aggregated 128 x 64-bit range proof) are folded ONCE more, when the logical length reaches 4 096, through
+// per-term products (k_ipa_fold_scalars, bpmi_ec_mul_batch, k_ec_sum_strided: point_kernels.hpp) -- from there on L and R are MSMs
+// over <= 4 097 pairs on the one-launch small-MSM kernel, both in one launch.  Option "ipa_small_m": 0 default, 1 never, else the length.
+#define IPA_SMALL_M_DEFAULT 4096u
 
 extern "C" {
 
@@ -723,8 +737,10 @@ static int ipa_alloc(bpmi_ctx *ctx, uint64_t n, bpmi_ipa **out) {
   st->ctx = ctx; st->n0 = st->n = st->M = n; st->d = 0; st->cur = 0; st->lr_done = false;
   st->big_m = ctx->opt_ipa_big > 0 ? (uint64_t)ctx->opt_ipa_big : IPA_BIG_M_DEFAULT;
   if (st->big_m < 32) st->big_m = 32;
+  st->small_m = ctx->opt_ipa_small == 1 ? 0 : (ctx->opt_ipa_small > 1 ? (uint64_t)ctx->opt_ipa_small : IPA_SMALL_M_DEFAULT);
   const size_t pts = align_up(64 * n, 256), scs = align_up(32 * n, 256);
-  const size_t pts2 = align_up(64 * (n / 16 + 1), 256), coef = align_up(32 * n, 256);
+  // the targets of a fold: n / 16 points (the ladder's 16-way fold) or small_m points (the product fold of bases that were never folded)
+  const size_t pts2 = align_up(64 * std::max<uint64_t>(n / 16 + 1, std::min<uint64_t>(n, st->small_m)), 256), coef = align_up(32 * n, 256);
   const size_t bytes = pts * 2 + pts2 * 2 + scs * 7 + coef * 4 + 256 * 3 + 2 * 32 * SC_DOT_MAX_BLOCKS + 2 * align_up(sizeof(NafK), 256);
   hipError_t e = hipMalloc(&st->block, bytes);
   if (e != hipSuccess) { delete st; return fail(ctx, BPMI_E_NOMEM, std::string("hipMalloc(ipa state): ") + hipGetErrorString(e)); }
@@ -756,14 +772,6 @@ static int ipa_alloc(bpmi_ctx *ctx, uint64_t n, bpmi_ipa **out) {
   sc o; memset(&o, 0, sizeof(o)); o.v[0] = 1;
   st->hcg.assign(1, o); st->hch.assign(1, o);
   st->hscale_buf = hscale_buf;
-  st->wtab = nullptr;
-  if (ctx->opt_fold_wnaf && n >= st->big_m && n >= 256) {
-    // 3 affine multiples (216 B) per base point and 432 B of scratch per point, for g and h, plus the two digit tables;
-    // if it does not fit the fold uses the plain NAF ladder
-    const uint64_t nthr = (n + ODDMUL_PER_THREAD - 1) / ODDMUL_PER_THREAD;
-    const size_t tab_bytes = align_up(3ull * n * 72, 256), scr_bytes = align_up(2ull * nthr * ODDMUL_PER_THREAD * 3 * 144, 256);
-    if (hipMalloc(&st->wtab, 2 * tab_bytes + scr_bytes + 2 * align_up(sizeof(WnafK), 256)) != hipSuccess) { (void)hipGetLastError(); st->wtab = nullptr; }
-  }
   *out = st;
   return BPMI_OK;
 }
@@ -784,7 +792,7 @@ int bpmi_ipa_create_dev(bpmi_ctx *ctx, const void *d_g, const void *d_h, const v
   if (e == hipSuccess) e = hipMemcpyAsync(st->b, d_b, 32 * n, hipMemcpyDeviceToDevice, s);
   if (e == hipSuccess) e = h2d(ctx, st->u, u, 64, s);
   if (e == hipSuccess) e = hipStreamSynchronize(s);
-  if (e != hipSuccess) { (void)hipFree(st->block); if (st->wtab) (void)hipFree(st->wtab); delete st; return fail(ctx, BPMI_E_HIP, std::string("ipa_create copy: ") + hipGetErrorString(e)); }
+  if (e != hipSuccess) { (void)hipFree(st->block); delete st; return fail(ctx, BPMI_E_HIP, std::string("ipa_create copy: ") + hipGetErrorString(e)); }
   *out = st;
   return BPMI_OK;
 }
@@ -803,7 +811,7 @@ int bpmi_ipa_create(bpmi_ctx *ctx, const uint8_t *g, const uint8_t *h, const uin
   if (e == hipSuccess) e = h2d(ctx, st->b, b, 32 * n, s);
   if (e == hipSuccess) e = h2d(ctx, st->u, u, 64, s);
   if (e == hipSuccess) e = hipStreamSynchronize(s);
-  if (e != hipSuccess) { (void)hipFree(st->block); if (st->wtab) (void)hipFree(st->wtab); delete st; return fail(ctx, BPMI_E_HIP, std::string("ipa_create copy: ") + hipGetErrorString(e)); }
+  if (e != hipSuccess) { (void)hipFree(st->block); delete st; return fail(ctx, BPMI_E_HIP, std::string("ipa_create copy: ") + hipGetErrorString(e)); }
   *out = st;
   return BPMI_OK;
 }
@@ -943,12 +951,22 @@ int bpmi_ipa_fold(bpmi_ipa *st, const uint8_t x[32], const uint8_t xinv[32]) {
     const u32 K2 = 1u << st->d;
     MultifoldJob ja = {st->g, st->g2}, jb = {st->h, st->h2};
     const uint64_t npts = st->M;
-    void *wtab = (ctx->opt_fold_wnaf && npts == st->n0) ? st->wtab : nullptr;      // sized for the first fold of the state
+    // width-4 NAF over affine tables of 3P, 5P, 7P: 2 x 216 B + 2 x 432 B of scratch per base point (1.4 GB at 2^20), allocated
+    // HERE, when a fold is actually reached, and kept by the ctx for the next proof (round 3 allocated them with every state,
+    // folded or not); if they do not fit the fold uses the plain NAF ladder
+    void *wtab = nullptr;
+    const uint64_t nthr = (npts + ODDMUL_PER_THREAD - 1) / ODDMUL_PER_THREAD;
+    const size_t tab_bytes = align_up(3ull * npts * 72, 256), scr_bytes = align_up(2ull * nthr * ODDMUL_PER_THREAD * 3 * 144, 256),
+                 wn_bytes = align_up(sizeof(WnafK), 256);
+    if (ctx->opt_fold_wnaf && npts >= 256) {
+      const size_t need = 2 * tab_bytes + scr_bytes + 2 * wn_bytes;
+      if (need > ctx->fold_tab_bytes) {
+        if (ctx->fold_tab) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->fold_tab); ctx->fold_tab = nullptr; ctx->fold_tab_bytes = 0; }
+        if (hipMalloc(&ctx->fold_tab, need) == hipSuccess) ctx->fold_tab_bytes = need; else { (void)hipGetLastError(); ctx->fold_tab = nullptr; }
+      }
+      wtab = ctx->fold_tab;
+    }
     if (wtab) {
-      // width-4 NAF over affine tables of 3P, 5P, 7P (transient: 2 x 216 B + 2 x 432 B of scratch per base point)
-      const uint64_t nthr = (npts + ODDMUL_PER_THREAD - 1) / ODDMUL_PER_THREAD;
-      const size_t tab_bytes = align_up(3ull * npts * 72, 256), scr_bytes = align_up(2ull * nthr * ODDMUL_PER_THREAD * 3 * 144, 256),
-                   wn_bytes = align_up(sizeof(WnafK), 256);
       {
         u32 *tab_a = (u32 *)wtab, *tab_b = (u32 *)((char *)wtab + tab_bytes), *scr = (u32 *)((char *)wtab + 2 * tab_bytes);
         WnafK *dwa = (WnafK *)((char *)wtab + 2 * tab_bytes + scr_bytes), *dwb = (WnafK *)((char *)dwa + wn_bytes);
@@ -998,6 +1016,42 @@ int bpmi_ipa_fold(bpmi_ipa *st, const uint8_t x[32], const uint8_t xinv[32]) {
     HIPCHK(ctx, h2d(ctx, st->cg[st->cur], one, 32, ctx->stream));
     HIPCHK(ctx, h2d(ctx, st->ch[st->cur], one, 32, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    sc o; memset(&o, 0, sizeof(o)); o.v[0] = 1;
+    st->hcg.assign(1, o); st->hch.assign(1, o);
+  } else if (st->small_m && st->M < st->big_m && st->n == st->small_m && st->M > st->n && st->n > 1 &&
+             (2 * st->M >= (uint64_t)MULB_MIN_N || ctx->opt_ipa_small > 1)) {
+    // the product fold (point_kernels.hpp): out[i] = sum_t coef[t] (hscale) base[i + t m] with one thread per TERM
+    const uint64_t M = st->M, m = st->n;
+    const u32 K = (u32)(M / m);
+    u32 logm = 0;
+    while ((1ull << logm) < m) logm++;
+    const size_t o_sc = align_up(128 * M, 256), o_pr = o_sc + align_up(64 * M, 256);
+    rc = ensure_stage_in(ctx, o_pr + 128 * M + 512);
+    if (rc) return rc;
+    char *buf = (char *)ctx->stage_in;
+    u32 *d_pts = (u32 *)buf, *d_sc = (u32 *)(buf + o_sc), *d_prod = (u32 *)(buf + o_pr);
+    HIPCHK(ctx, hipMemcpyAsync(d_pts, st->g, 64 * M, hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(d_pts + 16 * M, st->h, 64 * M, hipMemcpyDeviceToDevice, ctx->stream));
+    {
+      StageTimer t(ctx, ST_SCFOLD);
+      hipLaunchKernelGGL(k_ipa_fold_scalars, dim3((u32)((M + 255) / 256)), dim3(256), 0, ctx->stream, st->cg[st->cur], st->ch[st->cur], st->hscale, (u32)M, logm,
+                         d_sc, d_sc + 8 * M);
+    }
+    rc = bpmi_ec_mul_batch_dev(ctx, d_pts, d_sc, 2 * M, d_prod);
+    if (rc) return rc;
+    {
+      StageTimer t(ctx, ST_LINCOMB2);
+      hipLaunchKernelGGL(k_ec_sum_strided, dim3((u32)((2 * m + 255) / 256)), dim3(256), 0, ctx->stream, d_prod, (u32)m, K, st->g2, st->h2);
+    }
+    HIPCHK(ctx, hipGetLastError());
+    std::swap(st->g, st->g2);
+    std::swap(st->h, st->h2);
+    st->M = m;
+    st->d = 0;
+    st->hscale = nullptr;                  // the factors are in the folded generators now
+    static const uint8_t one[32] = {1};
+    HIPCHK(ctx, h2d(ctx, st->cg[st->cur], one, 32, ctx->stream));
+    HIPCHK(ctx, h2d(ctx, st->ch[st->cur], one, 32, ctx->stream));
     sc o; memset(&o, 0, sizeof(o)); o.v[0] = 1;
     st->hcg.assign(1, o); st->hch.assign(1, o);
   }
@@ -1091,7 +1145,6 @@ void bpmi_ipa_destroy(bpmi_ipa *st) {
   (void)hipSetDevice(st->ctx->device);
   (void)hipStreamSynchronize(st->ctx->stream);
   (void)hipFree(st->block);
-  if (st->wtab) (void)hipFree(st->wtab);
   delete st;
 }
 

@@ -17,6 +17,7 @@ static const char *STAGE_NAMES[BPMI_NSTAGES] = {
 struct EvPair { int stage; hipEvent_t a, b; };
 #define BPMI_LANES 3          // streams / workspaces / pending-MSM slots of a ctx
 
+struct HostHelper;
 struct bpmi_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -71,19 +72,67 @@ struct bpmi_ctx {
   int opt_rp_lanes = 0;      // batch preparation kernel: proofs per wave (0 = chosen from the batch size)
   void *rp_buf = nullptr; size_t rp_buf_bytes = 0;   // batch preparation: per-proof contributions to the shared generators
   int opt_epl = 0;           // bucket reduction stage 1: elements per lane (0 = default 16)
+  int opt_tail_thread = 1;   // a synchronous PAIR of MSMs: the host tail of the second one runs on the ctx's helper thread beside the first one's (0: one after the other)
+  int opt_pair_chain = 0;    // a synchronous pair of LARGE MSMs: 1 = their accumulate kernels chained as in the asynchronous pipeline (A/B; round 3 measured it slower)
+  int opt_pair1 = 1;         // a pair of SMALL MSMs (bpmi_msm2, the L / R of an inner-product round) as one launch sequence on one stream (0: two lanes)
   int opt_fuse = 1;          // k_accum_l0 folds a wave's partial records itself (0: two records per thread, the round-3 path; A/B and tests)
   int opt_spin_wait = 0;     // polls of an event / stream before sleeping in the runtime (see wait_event; measured: no gain, off)
   int opt_async_lanes = 0;   // 1: slot 1 of the asynchronous MSM pair runs on the second lane
   bool async_lane1_ordered = false, async_lane2_ordered = false;
   int opt_split = 0;    // 1: one MSM as two window groups, one per lane (measured: +5 % at 2^20, -8 % at 2^19; off)
   int64_t opt_ipa_big = 0;   // base length from which the IPA folds generators 16-way (0 = default 2^18)
+  int64_t opt_ipa_small = 0; // logical length at which smaller bases are folded through products (0 = default 4096, 1 = never)
+  void *fold_tab = nullptr; size_t fold_tab_bytes = 0;     // tables + scratch of the width-4 NAF generator fold, allocated at the first fold, kept
   // profiling
   bool prof = false;
   int prof_only = -1;      // >= 0: time only this stage (every event record costs a ~10 us bubble between kernels)
   std::vector<EvPair> evs;
   std::vector<hipEvent_t> ev_pool;      // recycled timing events (creating one costs more than recording it)
+  HostHelper *helper = nullptr;
   double prof_ms[BPMI_NSTAGES] = {0};
   uint64_t prof_calls[BPMI_NSTAGES] = {0};
+};
+
+// One helper thread per ctx (started at first use) for host work that can run beside the calling thread's: the host tail of the
+// second MSM of a synchronous pair (40 us of field arithmetic per MSM; 20 rounds of an inner-product argument pay it twice each).
+struct HostHelper {
+  std::thread th;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::function<void()> job;
+  bool has_job = false, done = true, quit = false;
+  void start() {
+    if (th.joinable()) return;
+    th = std::thread([this] {
+      std::unique_lock<std::mutex> lk(mu);
+      for (;;) {
+        cv.wait(lk, [this] { return has_job || quit; });
+        if (quit) return;
+        std::function<void()> j = std::move(job);
+        has_job = false;
+        lk.unlock();
+        j();
+        lk.lock();
+        done = true;
+        cv.notify_all();
+      }
+    });
+  }
+  void submit(std::function<void()> j) {
+    start();
+    std::lock_guard<std::mutex> lk(mu);
+    job = std::move(j); has_job = true; done = false;
+    cv.notify_all();
+  }
+  void wait() {
+    std::unique_lock<std::mutex> lk(mu);
+    cv.wait(lk, [this] { return done; });
+  }
+  ~HostHelper() {
+    if (!th.joinable()) return;
+    { std::lock_guard<std::mutex> lk(mu); quit = true; cv.notify_all(); }
+    th.join();
+  }
 };
 
 static std::string g_create_err;

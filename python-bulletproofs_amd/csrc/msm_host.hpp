@@ -25,7 +25,10 @@ static u32 pick_window_bits(const bpmi_ctx *ctx, uint64_t n) {
   return (u32)(c < 4 ? 4 : c);
 }
 
-#define SMALL_N_DEFAULT 4096     // tools/tune_msm.py: one-launch kernel against the bucket pipeline
+// tools/try_small.py (profiles/r04_small_msm_vs_bucket_pipeline.txt): the one-launch kernel wins up to 2^12 pairs (0.21 ms against
+// 0.26) and loses at 2^13 (0.33 against 0.29); the threshold sits just above 4 097 = the L / R of an inner-product round over
+// 4 096 generators (a 64-bit x 32 aggregated range proof; every late round of a larger proof after its product fold)
+#define SMALL_N_DEFAULT 4608
 
 struct MsmWs {
   u32 *glv_sub, *glv_bx;      // GLV: 2n x 16 B magnitudes, n x 32 B beta x
@@ -57,7 +60,7 @@ static void msm_layout(const MsmGeom &g, MsmWs &w, char *base, bool glv = false)
   w.off = take(4ull * (g.G + 1));
   w.cursor = take(4ull * g.G);               // path 1 only
   w.bsum = take(4ull * (w.nscan_blocks + 1));
-  w.coarse_hist = take(4ull * (PART_MAX + 1));
+  w.coarse_hist = take(4ull * COARSE_HIST_WORDS);
   w.coarse_off = take(4ull * (PART_MAX + 1));
   w.coarse_cursor = take(4ull * (PART_MAX + 1));
   w.dig = take(4ull * nW);                   // path 1: digits; path 2: partitioned entries
@@ -203,7 +206,7 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, int slot, const Segs &segs_in, u
   const u32 nblk_n = (u32)std::min<uint64_t>(((uint64_t)g.n + 255) / 256, 8192);
   {
     StageTimer t(ctx, ST_MISC, st);
-    if (w.P) HIPCHK(ctx, hipMemsetAsync(w.coarse_hist, 0, 4ull * (PART_MAX + 1), st));
+    if (w.P) HIPCHK(ctx, hipMemsetAsync(w.coarse_hist, 0, 4ull * COARSE_HIST_WORDS, st));      // (a multiple of 256 bytes: ONE fill kernel, not an aligned part and a tail)
     else {
       HIPCHK(ctx, hipMemsetAsync(w.hist, 0, 4ull * g.G, st));
       HIPCHK(ctx, hipMemsetAsync(w.buckets, 0, 4ull * XYZZ_WORDS * g.G, st));      // path 2: k_fine_sort_part clears the empty buckets
@@ -394,23 +397,109 @@ static int msm_run(bpmi_ctx *ctx, const Segs &segs, uint8_t out[64]) {
   if (rc) return rc;
   return msm_finish(ctx, 0, out);
 }
+// finish both slots of a synchronous pair; the second tail on the helper thread (it waits for its own event there)
+static int msm_finish_pair(bpmi_ctx *ctx, uint8_t out0[64], uint8_t out1[64]) {
+  if (!ctx->opt_tail_thread || !ctx->pend[0].active || !ctx->pend[1].active) {
+    const int rc = msm_finish(ctx, 0, out0), rc1 = msm_finish(ctx, 1, out1);
+    return rc ? rc : rc1;
+  }
+  if (!ctx->helper) ctx->helper = new HostHelper();
+  bpmi_ctx::PendingMsm &pd = ctx->pend[1];
+  hipError_t e1 = hipSuccess;
+  const int dev = ctx->device;
+  ctx->helper->submit([&pd, &e1, out1, dev, ctx] {           // (no ctx->err from this thread: the code travels back in e1)
+    (void)hipSetDevice(dev);
+    e1 = wait_event(ctx, pd.done);
+    if (e1 != hipSuccess) return;
+    if (pd.tail == 1) memcpy(out1, pd.pin, 64);
+    else bpmi_host::tail_combine(out1, (const u32 *)pd.pin, pd.W, pd.c, pd.to);
+  });
+  const int rc = msm_finish(ctx, 0, out0);
+  ctx->helper->wait();
+  pd.active = false;
+  if (rc) return rc;
+  HIPCHK(ctx, e1);
+  return BPMI_OK;
+}
+// Two SMALL MSMs (both on the one-launch kernel's path) as one launch sequence on the ctx stream: one k_msm_small_pair, one
+// combine, the two copies; pending slots 0 and 1 as for a pair on two lanes.  (Two lanes cost a fork event, a second queue's
+// doorbell and a second wait: ~40 us of a 0.3 ms round of the inner-product argument.)
+static int msm_enqueue_small_pair(bpmi_ctx *ctx, const Segs &s0, const Segs &s1) {
+  bpmi_ctx::PendingMsm &p0 = ctx->pend[0], &p1 = ctx->pend[1];
+  if (p0.active || p1.active) return fail(ctx, BPMI_E_STATE, "an MSM is still pending in this slot (bpmi_msm_finish it first)");
+  SmallPair sp;
+  CombinePair cp;
+  const Segs *ss[2] = {&s0, &s1};
+  size_t off[2], total = 0;
+  MsmWs w[2];
+  for (int j = 0; j < 2; j++) {
+    MsmGeom &g = sp.g[j];
+    memset(&g, 0, sizeof(g));
+    g.n = ss[j]->total; g.c = SMALL_C; g.W = 255u / g.c + 1u; g.w0 = 0; g.B = 1u << (g.c - 1); g.G = g.W * g.B; g.L = 8; g.nv = 1;
+    msm_layout(g, w[j], nullptr);
+    off[j] = total;
+    total += align_up(w[j].total, 256);
+  }
+  int rc = ensure_ws(ctx, total);
+  if (rc) return rc;
+  const size_t eb = 4ull * XYZZ_WORDS * sp.g[0].W;
+  for (int j = 0; j < 2; j++) { rc = ensure_pin_slot(ctx, j, eb); if (rc) return rc; }
+  u32 Smax = 1, threads = 64;
+  for (int j = 0; j < 2; j++) {
+    msm_layout(sp.g[j], w[j], (char *)ctx->ws + off[j]);
+    const uint64_t n = ss[j]->total;
+    const u32 S = (u32)std::min<uint64_t>(64, (n + 255) / 256);
+    sp.segs[j] = *ss[j]; sp.S[j] = S; sp.out[j] = S > 1 ? w[j].buckets : w[j].E;
+    cp.part[j] = w[j].buckets; cp.S[j] = S; cp.E[j] = w[j].E;
+    Smax = std::max(Smax, S);
+    threads = std::max(threads, (u32)std::min<uint64_t>(256, (n + 63) / 64 * 64));
+  }
+  hipStream_t st = ctx->stream;
+  {
+    StageTimer t(ctx, ST_ACCUM, st);
+    hipLaunchKernelGGL(k_msm_small_pair, dim3(sp.g[0].W, Smax, 2), dim3(threads), 0, st, sp);
+    if (Smax > 1) hipLaunchKernelGGL(k_small_combine_pair, dim3(sp.g[0].W, 2), dim3(64), 0, st, cp);
+  }
+  debug_sync(ctx, "k_msm_small_pair", st);
+  TailOffs to;
+  to.nv = 1; to.off[0] = to.off[1] = to.off[2] = to.off[3] = 0;
+  for (int j = 0; j < 2; j++) {
+    bpmi_ctx::PendingMsm &pd = ctx->pend[j];
+    HIPCHK(ctx, hipMemcpyAsync(pd.pin, w[j].E, eb, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipEventRecord(pd.done, st));
+    pd.active = true; pd.W = sp.g[j].W; pd.nv = 1; pd.c = SMALL_C; pd.tail = 2; pd.to = to;
+  }
+  HIPCHK(ctx, hipGetLastError());
+  return BPMI_OK;
+}
 // two independent MSMs, overlapped on the two lanes; everything already enqueued on the
 // ctx stream (the producers of the scalars) is ordered before both
 static int msm_run_pair(bpmi_ctx *ctx, const Segs &s0, uint8_t out0[64], const Segs &s1, uint8_t out1[64]) {
   if (s0.total > BPMI_MAX_N || s1.total > BPMI_MAX_N) return fail(ctx, BPMI_E_ARG, "n exceeds BPMI_MAX_N");
+  {
+    const uint64_t small_max = ctx->opt_small < 0 ? 0 : (ctx->opt_small ? (uint64_t)ctx->opt_small : SMALL_N_DEFAULT);
+    if (ctx->opt_pair1 && ctx->opt_c == 0 && s0.total && s1.total && s0.total <= small_max && s1.total <= small_max) {
+      int rc = msm_enqueue_small_pair(ctx, s0, s1);
+      if (rc) { if (ctx->pend[0].active && ctx->pend[1].active) msm_abandon_pending(ctx, 3u); return rc; }
+      return msm_finish_pair(ctx, out0, out1);
+    }
+  }
   int rc = ensure_lane(ctx, 1);
   if (rc) return rc;
   HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
   HIPCHK(ctx, hipStreamWaitEvent(ctx->stream1, ctx->ev_fork, 0));
   // (chaining the pair's accumulate kernels with the event of the asynchronous pipeline was measured on the IPA's 2^20-sized
   // rounds: 2.43 ms per round against 2.35 -- with only two MSMs there is no steady state to pipeline)
+  const bool chain = ctx->opt_pair_chain && s0.total >= (1u << 19) && s1.total >= (1u << 19);
+  if (chain) { ctx->chain_accum = true; ctx->accum_chain_lane = -1; }
   rc = msm_enqueue(ctx, 0, 0, s0);
+  if (rc == BPMI_OK) {
+    rc = msm_enqueue(ctx, 1, 1, s1);
+    if (rc) msm_abandon_pending(ctx, 1u);
+  }
+  if (chain) { ctx->chain_accum = false; ctx->accum_chain_lane = -1; }
   if (rc) return rc;
-  rc = msm_enqueue(ctx, 1, 1, s1);
-  if (rc) { msm_abandon_pending(ctx, 1u); return rc; }
-  rc = msm_finish(ctx, 0, out0);
-  const int rc1 = msm_finish(ctx, 1, out1);
-  return rc ? rc : rc1;
+  return msm_finish_pair(ctx, out0, out1);
 }
 
 // second-level segscan buffer sizing relies on this: every level after the first has

@@ -141,6 +141,7 @@ __global__ void __launch_bounds__(256) k_digits_hist(Segs segs, MsmGeom g, u32 *
 // (tile, partition); level B gives every partition to one block, which counting-sorts it
 // by lo entirely in LDS.  No per-element global atomic anywhere.
 #define PART_MAX 2048          // W * (B / 256) <= 2048 for every c in [10, 16]
+#define COARSE_HIST_WORDS (PART_MAX + 64)      // the partition counts + the any_heavy flag, padded to whole 256-byte lines
 #define FINE_CAP 12288          // entries of a partition that level B sorts in one block's LDS
 // The recoded digits are kept, 16 bits each, window-major: dig16[w * n + i] = (b - 1) | digit sign << 15,
 // DIG_NONE for b = 0 (a negative digit has b <= 2^(c-1) - 1, so that code is free), and one byte
@@ -1131,12 +1132,11 @@ __global__ void __launch_bounds__(1024) k_window_weighted_small_quad(MsmGeom g, 
 #define SMALL_C 8
 // grid = (W, S): block (w, s) covers the points i = s * blockDim + tid (+ k * S * blockDim) and
 // writes its partial sum to out[w * S + s]; k_small_combine adds the S partials of a window.
-__global__ void __launch_bounds__(256) k_msm_small(Segs segs, MsmGeom g, u32 *__restrict__ out) {
-  __shared__ u32 s_val[4 * LDS_STRIDE];
+__device__ __forceinline__ void msm_small_block(const Segs &segs, const MsmGeom &g, u32 *__restrict__ out, u32 *s_val, u32 S) {
   const u32 w = blockIdx.x, tid = threadIdx.x;
   xyzz acc;
   xyzz_set_inf(acc);
-  for (u32 i = blockIdx.y * blockDim.x + tid; i < g.n; i += gridDim.y * blockDim.x) {
+  for (u32 i = blockIdx.y * blockDim.x + tid; i < g.n; i += S * blockDim.x) {
     u32 b = 0, sign = 0;
     for_each_digit(segs, g, i, [&](u32 ww, u32 bb, u32 sg) { if (ww == w) { b = bb; sign = sg; } });
     affine P;
@@ -1171,8 +1171,21 @@ __global__ void __launch_bounds__(256) k_msm_small(Segs segs, MsmGeom g, u32 *__
       xyzz_shfl_xor(other, acc, (int)m);
       xyzz_add(acc, acc, other);
     }
-    if (tid == 0) xyzz_store_g(out + ((u64)w * gridDim.y + blockIdx.y) * XYZZ_WORDS, acc);
+    if (tid == 0) xyzz_store_g(out + ((u64)w * S + blockIdx.y) * XYZZ_WORDS, acc);
   }
+}
+__global__ void __launch_bounds__(256) k_msm_small(Segs segs, MsmGeom g, u32 *__restrict__ out) {
+  __shared__ u32 s_val[4 * LDS_STRIDE];
+  msm_small_block(segs, g, out, s_val, gridDim.y);
+}
+// two independent small MSMs in ONE launch (blockIdx.z = job): the L and R of a late inner-product round, the A / S and T1 / T2
+// pairs of a 64-bit range proof -- on this path a launch and a stream hand-over are a tenth of the MSM
+struct SmallPair { Segs segs[2]; MsmGeom g[2]; u32 *out[2]; u32 S[2]; };
+__global__ void __launch_bounds__(256) k_msm_small_pair(SmallPair p) {
+  __shared__ u32 s_val[4 * LDS_STRIDE];
+  const u32 job = blockIdx.z;
+  if (blockIdx.y >= p.S[job]) return;                     // (the grid is sized for the larger job)
+  msm_small_block(p.segs[job], p.g[job], p.out[job], s_val, p.S[job]);
 }
 // E[w] = sum of the S (<= 64) partials of window w: one wave per window
 __global__ void __launch_bounds__(64) k_small_combine(const u32 *__restrict__ part, u32 S, u32 *__restrict__ E) {
@@ -1185,6 +1198,20 @@ __global__ void __launch_bounds__(64) k_small_combine(const u32 *__restrict__ pa
     xyzz_add(acc, acc, other);
   }
   if (l == 0) xyzz_store_g(E + (u64)w * XYZZ_WORDS, acc);
+}
+
+struct CombinePair { const u32 *part[2]; u32 S[2]; u32 *E[2]; };
+__global__ void __launch_bounds__(64) k_small_combine_pair(CombinePair c) {
+  const u32 w = blockIdx.x, l = threadIdx.x, job = blockIdx.y, S = c.S[job];
+  if (S <= 1) return;                                      // that job's k_msm_small blocks wrote E themselves
+  xyzz acc;
+  if (l < S) xyzz_load_g(acc, c.part[job] + ((u64)w * S + l) * XYZZ_WORDS); else xyzz_set_inf(acc);
+  for (u32 m = 1; m < S; m <<= 1) {
+    xyzz other;
+    xyzz_shfl_xor(other, acc, (int)m);
+    xyzz_add(acc, acc, other);
+  }
+  if (l == 0) xyzz_store_g(c.E[job] + (u64)w * XYZZ_WORDS, acc);
 }
 
 // ---- tail: result = sum_w 2^(c w) sum_v 2^(off[v]) E[w][v], to canonical affine -------------

@@ -294,6 +294,52 @@ __global__ void __launch_bounds__(256) k_ipa_export_scalars(const u32 *__restric
   store_words8(eg + 8ull * k, rg.v);
   store_words8(eh + 8ull * k, rh.v);
 }
+// ---- the second fold: through PRODUCTS (round 4) ---------------------------------------------------------------------------
+// The shared-scalar ladder above is one thread per OUTPUT running 256 doublings + K x 51 additions in a row: for the 2 x 4 096
+// outputs of a fold of 2^16 bases that is 128 waves and ~2 ms of pure latency -- why bases below 2^18 points were never folded and
+// rounds 5 .. 20 of a 2^20-element proof all ran pairs of 65 537-pair MSMs (0.56 ms each).  Here every TERM is a thread:
+//   k_ipa_fold_scalars   e[k] = coef[k >> log m] (x hscale[k]): the scalar of base point k in its output
+//   bpmi_ec_mul_batch    prod[k] = e[k] * base[k]  (GLV + fixed signed windows: 126 doublings + 88 additions deep, 2 M threads)
+//   k_ec_sum_strided     out[i] = sum_t prod[i + t m]: K mixed additions and one inversion per output
+// ~0.5 ms for 2 x 2^16 bases; afterwards the argument runs on 4 096 generators per side and its MSMs on the one-launch kernel.
+__global__ void __launch_bounds__(256) k_ipa_fold_scalars(const u32 *__restrict__ cg, const u32 *__restrict__ ch, const u32 *__restrict__ hscale, u32 M, u32 logm,
+                                                          u32 *__restrict__ eg, u32 *__restrict__ eh) {
+  const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= M) return;
+  const u32 t = k >> logm;
+  sc rg, rh;
+  load_words8(rg.v, cg + 8ull * t);
+  load_words8(rh.v, ch + 8ull * t);
+  if (hscale) {
+    sc c;
+    load_words8(c.v, hscale + 8ull * k);
+    sc_mul(rh, rh, c);
+  }
+  store_words8(eg + 8ull * k, rg.v);
+  store_words8(eh + 8ull * k, rh.v);
+}
+// prod: [side 0: M points | side 1: M points] (affine, wire form); out_a[i] / out_b[i] = sum over t < K of prod[side M + i + t m]
+__global__ void __launch_bounds__(256) k_ec_sum_strided(const u32 *__restrict__ prod, u32 m, u32 K, u32 *__restrict__ out_a, u32 *__restrict__ out_b) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool second = i >= m;
+  if (second) i -= m;
+  if (i >= m) return;
+  const u32 *base = prod + (second ? 16ull * m * K : 0ull);
+  xyzz acc;
+  xyzz_set_inf(acc);
+#pragma unroll 1
+  for (u32 t = 0; t < K; t++) {
+    affine P;
+    load_affine(P, base + 16ull * ((u64)i + (u64)t * m));
+    xyzz_madd_signed(acc, P, false);
+  }
+  affine r;
+  xyzz_to_affine(r, acc);
+  u32 w16[16];
+  affine_to_words(w16, r);
+  store_words16((second ? out_b : out_a) + 16ull * i, w16);
+}
+
 // materialise 2^d-way folded generators: out[i] = sum_t coef[t] * G[i + t*m], i < m, as an
 // interleaved NAF ladder (shared scalars -> wave-uniform branches); two jobs (g and h) per launch
 #define MULTIFOLD_MAXK 16

@@ -36,7 +36,8 @@ __global__ void __launch_bounds__(256) k_sc_dot(DotJobs jobs, u32 n, u32 *__rest
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) store_words8(partial + 8ull * blockIdx.x, acc.v);
+  // a single block per job IS the sum (short vectors: the late rounds of the inner-product argument save a launch each)
+  if (threadIdx.x == 0) store_words8(gridDim.x == 1 ? jobs.out[blockIdx.y] : partial + 8ull * blockIdx.x, acc.v);
 }
 __global__ void __launch_bounds__(256) k_sc_sum(const u32 *__restrict__ partial_all, u32 n, DotJobs jobs) {
   __shared__ u32 sh[256 * 8];

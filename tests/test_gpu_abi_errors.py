@@ -103,7 +103,7 @@ def test_async_pair_state_machine(gp):
     out = ctypes.create_string_buffer(64)
     want = cbind.msm_bytes(pb, sb, 6000)
     assert lib.bpmi_msm_finish(ctx, 0, out) == -5                       # nothing enqueued
-    assert lib.bpmi_msm_dev_enqueue(ctx, 2, d_p.ptr, d_s.ptr, 10) == -3   # no such slot
+    assert lib.bpmi_msm_dev_enqueue(ctx, 3, d_p.ptr, d_s.ptr, 10) == -3   # no such slot (0, 1, 2 exist)
     assert lib.bpmi_msm_dev_enqueue(ctx, 0, d_p.ptr, d_s.ptr, (1 << 23) + 1) == -3
     assert lib.bpmi_msm_dev_enqueue(ctx, 0, d_p.ptr, d_s.ptr, 6000) == 0
     assert lib.bpmi_msm_dev_enqueue(ctx, 0, d_p.ptr, d_s.ptr, 6000) == -5      # slot still pending
@@ -126,6 +126,19 @@ def test_async_pair_state_machine(gp):
     assert lib.bpmi_msm_dev_enqueue(ctx, 0, d_p.ptr, d_s.ptr, 6000) == 0
     assert lib.bpmi_msm2(ctx, pb, sb, 6000, o0, pb, sb, 6000, o1) == -5
     assert lib.bpmi_msm_finish(ctx, 0, out) == 0 and out.raw == want
+    # the third slot; three MSMs in flight, finished out of order
+    for sl in (0, 1, 2):
+        assert lib.bpmi_msm_dev_enqueue(ctx, sl, d_p.ptr, d_s.ptr, 6000 - sl) == 0
+    for sl in (2, 0, 1):
+        assert lib.bpmi_msm_finish(ctx, sl, out) == 0 and out.raw == cbind.msm_bytes(pb[:64 * (6000 - sl)], sb[:32 * (6000 - sl)], 6000 - sl)
+    eng.set_option("async_lanes", 1)                    # ... and on three lanes
+    try:
+        for sl in (0, 1, 2):
+            assert lib.bpmi_msm_dev_enqueue(ctx, sl, d_p.ptr, d_s.ptr, 6000 - sl) == 0
+        for sl in (1, 2, 0):
+            assert lib.bpmi_msm_finish(ctx, sl, out) == 0 and out.raw == cbind.msm_bytes(pb[:64 * (6000 - sl)], sb[:32 * (6000 - sl)], 6000 - sl)
+    finally:
+        eng.set_option("async_lanes", 0)
     # three device segments in one MSM; argument errors
     P = (ctypes.c_void_p * 3)(d_p.ptr, d_p.ptr + 64 * 1000, d_p.ptr + 64 * 2500)
     S = (ctypes.c_void_p * 3)(d_s.ptr, d_s.ptr + 32 * 1000, d_s.ptr + 32 * 2500)

@@ -52,6 +52,57 @@ def test_bench_self_launches_its_ranks():
     assert out["scaling"] == "strong" and out["result_ok"] is True and out["config"]["pairs_per_gpu"] == 1 << 15
 
 
+def _bench_line(cmd, env, timeout):
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    return json.loads(lines[0])
+
+
+def test_bench_eight_ranks_time_sharing_this_gpu_with_every_extra():
+    """What the driver's 8-GPU node will run, rehearsed on ONE GPU: `bench.py --gpus 8` with eight gloo ranks time-sharing the device,
+    EVERY extra (at test sizes: --extra-scale small), weak and strong.  The line must say eight ranks were seen, carry eight per-rank
+    step times, the host budget, the strong-scaling MSM beside the weak headline, and both C5 variants."""
+    env = dict(os.environ, BENCH_DIST_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "8", "--steps", "4", "--warmup", "1", "--logn", "14", "--preheat-ms", "0",
+           "--soak-seconds", "0", "--no-cpu-baseline", "--extra-scale", "small"]
+    out = _bench_line(cmd, env, 1500)
+    assert out["n_gpus"] == 8 and out["n_ranks_seen"] == 8 and out["result_ok"] is True and out["scaling"] == "weak"
+    assert len(out["ms_per_step_by_rank"]) == 8 and all(v > 0 for v in out["ms_per_step_by_rank"])
+    hb = out["host_budget"]
+    assert hb["ranks_on_this_host"] == 8 and hb["c5_batches_in_flight"] >= 1 and hb["cpus_per_rank"] >= 1
+    ex = out["extra"]
+    assert set(ex) >= {"MSM_strong", "C2_msm_2e16", "C5_batch_verify", "C5_batch_verify_per_gpu_batches", "C3_ipa_prover", "C4_aggregated_range_proof"}
+    for name, v in ex.items():
+        assert "error" not in v and "errors_by_rank" not in v, (name, v)
+    st = ex["MSM_strong"]
+    assert st["scaling"] == "strong" and st["result_ok"] is True and st["pairs_per_gpu"] == (1 << 14) // 8 and len(st["ms_per_step_by_rank"]) == 8
+    assert ex["C5_batch_verify"]["accepted"] is True and ex["C5_batch_verify"]["corrupted_batch_rejected"] is True and ex["C5_batch_verify"]["batch"] == 256
+    assert ex["C5_batch_verify"]["scaling"].startswith("strong") and ex["C5_batch_verify_per_gpu_batches"]["scaling"].startswith("weak")
+    assert ex["C5_batch_verify_per_gpu_batches"]["batch"] == 8 * 256 and ex["C5_batch_verify_per_gpu_batches"]["accepted"] is True
+    assert ex["C3_ipa_prover"]["rounds"] == 12 and ex["C3_ipa_prover"]["deterministic"] is True
+    assert ex["C4_aggregated_range_proof"]["verified"] is True
+    # strong scaling as the headline of its own run
+    out = _bench_line(cmd + ["--scaling", "strong", "--no-extra"], env, 900)
+    assert out["scaling"] == "strong" and out["n_ranks_seen"] == 8 and out["result_ok"] is True and out["config"]["pairs_per_gpu"] == (1 << 14) // 8
+
+
+def test_an_extra_failing_on_one_rank_costs_neither_the_line_nor_the_other_extras():
+    """Rank 5 of eight raises in the C3 extra (BENCH_INJECT_FAILURE): the headline is intact, every rank left C3 before its
+    collectives, the text of the exception is in rank 0's line, and the extras behind it ran."""
+    env = dict(os.environ, BENCH_DIST_BACKEND="gloo", BENCH_INJECT_FAILURE="C3_ipa_prover:5")
+    env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "8", "--steps", "4", "--warmup", "1", "--logn", "14", "--preheat-ms", "0",
+           "--soak-seconds", "0", "--no-cpu-baseline", "--extra-scale", "small"]
+    out = _bench_line(cmd, env, 1500)
+    assert out["n_ranks_seen"] == 8 and out["result_ok"] is True and out["value"] > 0
+    c3 = out["extra"]["C3_ipa_prover"]
+    assert c3["errors_by_rank"] == {"5": "RuntimeError: injected failure in C3_ipa_prover on rank 5"} and c3["error"].startswith("skipped: rank 5")
+    assert out["extra"]["C4_aggregated_range_proof"].get("verified") is True and "error" not in out["extra"]["C5_batch_verify"]
+
+
 def test_bench_collectives_on_rccl_with_one_rank():
     """bench.py under torch.distributed.run with ONE rank and BENCH_FORCE_DIST=1: every collective of the N > 1 path (the
     all_gather of partials on the exchange stream + device fold, the MAX all_reduce of the elapsed time, the gather of the

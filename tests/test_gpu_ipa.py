@@ -102,14 +102,19 @@ def test_ipa_cheating_cases(gp):
         Verifier1(g, h, u, P1, ip, p1).verify()
 
 
-@pytest.mark.parametrize("n,big_m", [(2, 0), (64, 0), (1024, 0), (8192, 0), (4096, 256), (1 << 14, 1 << 10), (1 << 12, 1 << 12)])
-def test_ipa_rounds_vs_oracle(gp, n, big_m):
+@pytest.mark.parametrize("n,big_m,small_m", [(2, 0, 0), (64, 0, 0), (1024, 0, 0), (8192, 0, 0), (4096, 256, 0), (1 << 14, 1 << 10, 0), (1 << 12, 1 << 12, 0),
+                                             (64, 0, 4), (1024, 0, 64), (1024, 0, 512), (8192, 1024, 32), (1 << 15, 0, 0), (1 << 14, 0, 1)])
+def test_ipa_rounds_vs_oracle(gp, n, big_m, small_m):
     """Every round's L, R and the folded vectors against the C oracle, through the raw
     C-ABI state object (bpmi_ipa_*), with arbitrary challenges.  `big_m` lowers the base
     length from which generators are folded 16-way at once, so the deferred-MSM path, the
-    materialisation kernel and the rounds after it are all exercised at test sizes."""
+    materialisation kernel and the rounds after it are all exercised at test sizes; `small_m` is the
+    logical length at which smaller bases are folded through per-term products (round 4: 0 = the
+    default 4096 -- reached by the 2^15 case, K = 8, on the GLV product kernel --, 1 = never, else the
+    length: K = 16, 2 and 16 behind a ladder fold), after which L and R run as ONE small-MSM launch."""
     eng = gp.engine()
     eng.set_option("ipa_big_m", big_m)
+    eng.set_option("ipa_small_m", small_m)
     pts, _ = gp.rand_points(2 * n + 1, 40 + n)
     g, h, u = pts[:n], pts[n:2 * n], pts[2 * n]
     rnd = random.Random(n)
@@ -136,6 +141,7 @@ def test_ipa_rounds_vs_oracle(gp, n, big_m):
     assert st.finish() == (a[0], b[0])
     st.close()
     eng.set_option("ipa_big_m", 0)
+    eng.set_option("ipa_small_m", 0)
 
 
 def test_ipa_full_size_round_trip(gp):
@@ -169,13 +175,16 @@ def test_ipa_full_size_round_trip(gp):
         Verifier2(g, h, u, P + u, proof).verify()
 
 
-@pytest.mark.parametrize("n,big_m", [(1, 0), (2, 0), (256, 0), (1024, 256), (2048, 2048)])
-def test_ipa_scaled_generators(gp, n, big_m):
+@pytest.mark.parametrize("n,big_m,small_m", [(1, 0, 0), (2, 0, 0), (256, 0, 0), (1024, 256, 0), (2048, 2048, 0), (256, 0, 16), (1 << 14, 0, 0)])
+def test_ipa_scaled_generators(gp, n, big_m, small_m):
     """bpmi_ipa_create_scaled: the argument over c_i * h[i] must equal the plain argument over
     the materialised points, in both regimes (factors in the MSM scalars / one batched
-    multiplication for bases that get folded)."""
+    multiplication for bases that get folded), and through the product fold, which multiplies the
+    factors into the folded generators (small_m = 16; and the default at the 2^14 generators of an
+    aggregated 128 x 64-bit range proof: K = 4 at length 4096)."""
     eng = gp.engine()
     eng.set_option("ipa_big_m", big_m)
+    eng.set_option("ipa_small_m", small_m)
     pts, _ = gp.rand_points(2 * n + 1, 70 + n)
     g, h, u = pts[:n], pts[n:2 * n], pts[2 * n]
     rnd = random.Random(n + 1)
@@ -202,6 +211,7 @@ def test_ipa_scaled_generators(gp, n, big_m):
     st.close()
     ref.close()
     eng.set_option("ipa_big_m", 0)
+    eng.set_option("ipa_small_m", 0)
 
 
 def test_ipa_export_too_long_is_a_state_error(gp):
