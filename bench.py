@@ -945,7 +945,7 @@ def extra_c4(eng, world, rank, dev, ready, m=128, nbits=64):
     # lists of Points that carry their wire form (64 bytes per point): the generators of a deployment are fixed, they are packed once
     gs, hs = PackedPoints(gen_points(7000)), PackedPoints(gen_points(7001))
     g, h, u = elliptic_hash(b"g"), elliptic_hash(b"h"), elliptic_hash(b"u")
-    vs = [ModP(int.from_bytes(hashlib.sha256(b"v%d" % j).digest()[:8], "big"), Q) for j in range(m)]
+    vs = [ModP(int.from_bytes(hashlib.sha256(b"v%d" % j).digest()[:8], "big") % (1 << nbits), Q) for j in range(m)]      # values of nbits bits
     gammas = [mod_hash(b"gamma%d" % j, Q) for j in range(m)]
     Vs = [commitment(g, h, vs[j], gammas[j]) for j in range(m)]
     prove_s, verify_s = [], []

@@ -118,6 +118,8 @@ void bpmi_ctx_destroy(bpmi_ctx *ctx) {
   for (auto &pd : ctx->pend) { if (pd.pin) (void)hipHostFree(pd.pin); if (pd.done) (void)hipEventDestroy(pd.done); }
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx->helper;
+  msm_graphs_clear(ctx);
+  delete ctx->graphs;
   delete ctx;
 }
 
@@ -138,8 +140,12 @@ int bpmi_set_option(bpmi_ctx *ctx, const char *name, int64_t value) {
   if (!strcmp(name, "priority")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "priority must be 0 or 1"); ctx->opt_prio = (int)value; return BPMI_OK; }
   if (!strcmp(name, "hist_threads")) { if (value != 0 && value != 256 && value != 512 && value != 1024) return fail(ctx, BPMI_E_ARG, "hist_threads must be 0, 256, 512 or 1024"); ctx->opt_hist_threads = (int)value; return BPMI_OK; }
   if (!strcmp(name, "hist_blocks")) { if (value < 0 || value > 8192) return fail(ctx, BPMI_E_ARG, "hist_blocks must be in [0, 8192]"); ctx->opt_hist_blocks = (int)value; return BPMI_OK; }
+  if (!strcmp(name, "direct_result")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "direct_result must be 0 or 1"); ctx->opt_direct = (int)value; msm_graphs_clear(ctx); return BPMI_OK; }
+  if (!strcmp(name, "graphs")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "graphs must be 0 or 1"); ctx->opt_graph = (int)value; if (!value) msm_graphs_clear(ctx); return BPMI_OK; }
   if (!strcmp(name, "tail_thread")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "tail_thread must be 0 or 1"); ctx->opt_tail_thread = (int)value; return BPMI_OK; }
   if (!strcmp(name, "pair_chain")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "pair_chain must be 0 or 1"); ctx->opt_pair_chain = (int)value; return BPMI_OK; }
+  if (!strcmp(name, "mid_min")) { if (value < -1 || value > MID_NMAX) return fail(ctx, BPMI_E_ARG, "mid_min must be -1 .. 8448"); ctx->opt_mid_min = (int)value; msm_graphs_clear(ctx); return BPMI_OK; }
+  if (!strcmp(name, "mid_single_min")) { if (value < -1 || value > MID_NMAX) return fail(ctx, BPMI_E_ARG, "mid_single_min must be -1 .. 8448"); ctx->opt_mid_single = (int)value; msm_graphs_clear(ctx); return BPMI_OK; }
   if (!strcmp(name, "small_pair")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "small_pair must be 0 or 1"); ctx->opt_pair1 = (int)value; return BPMI_OK; }
   if (!strcmp(name, "fused_scan")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "fused_scan must be 0 or 1"); ctx->opt_fuse = (int)value; return BPMI_OK; }
   if (!strcmp(name, "quad_final")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "quad_final must be 0 or 1"); ctx->opt_quad = (int)value; return BPMI_OK; }

@@ -18,6 +18,7 @@ struct EvPair { int stage; hipEvent_t a, b; };
 #define BPMI_LANES 3          // streams / workspaces / pending-MSM slots of a ctx
 
 struct HostHelper;
+struct MsmGraphCache;
 struct bpmi_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -74,6 +75,8 @@ struct bpmi_ctx {
   int opt_epl = 0;           // bucket reduction stage 1: elements per lane (0 = default 16)
   int opt_tail_thread = 1;   // a synchronous PAIR of MSMs: the host tail of the second one runs on the ctx's helper thread beside the first one's (0: one after the other)
   int opt_pair_chain = 0;    // a synchronous pair of LARGE MSMs: 1 = their accumulate kernels chained as in the asynchronous pipeline (A/B; round 3 measured it slower)
+  int opt_mid_min = 0;       // a pair of MSMs runs as one launch of k_msm_mid from this many pairs in the larger one (0 = default 1536, -1 = never)
+  int opt_mid_single = 0;    // a single MSM runs on k_msm_mid from this many pairs (0 = default 2560, -1 = never)
   int opt_pair1 = 1;         // a pair of SMALL MSMs (bpmi_msm2, the L / R of an inner-product round) as one launch sequence on one stream (0: two lanes)
   int opt_fuse = 1;          // k_accum_l0 folds a wave's partial records itself (0: two records per thread, the round-3 path; A/B and tests)
   int opt_spin_wait = 0;     // polls of an event / stream before sleeping in the runtime (see wait_event; measured: no gain, off)
@@ -89,6 +92,9 @@ struct bpmi_ctx {
   std::vector<EvPair> evs;
   std::vector<hipEvent_t> ev_pool;      // recycled timing events (creating one costs more than recording it)
   HostHelper *helper = nullptr;
+  MsmGraphCache *graphs = nullptr;      // captured launch sequences of repeated MSMs (msm_host.hpp)
+  int opt_direct = 1;                   // the last kernel of an MSM writes its result into the slot's page-locked host buffer (0: workspace + copy)
+  int opt_graph = 0;                    // 1: replay an MSM's launch sequence as a HIP graph when the same call comes again
   double prof_ms[BPMI_NSTAGES] = {0};
   uint64_t prof_calls[BPMI_NSTAGES] = {0};
 };
@@ -238,8 +244,10 @@ static hipError_t wait_stream(const bpmi_ctx *ctx, hipStream_t st) {
   }
   return hipStreamSynchronize(st);
 }
+static void msm_graphs_clear(bpmi_ctx *ctx);
 static int ensure_ws(bpmi_ctx *ctx, size_t bytes) {
   if (bytes <= ctx->ws_bytes) return BPMI_OK;
+  msm_graphs_clear(ctx);                 // captured sequences hold pointers into the workspace
   if (ctx->ws) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(ctx->ws)); ctx->ws = nullptr; ctx->ws_bytes = 0; }
   size_t want = bytes + bytes / 8;
   HIPCHK(ctx, hipMalloc(&ctx->ws, want));
@@ -264,6 +272,7 @@ static int ensure_ws_lane(bpmi_ctx *ctx, int lane, size_t bytes) {
   void *&ws = lane == 1 ? ctx->ws1 : ctx->ws2;
   size_t &have = lane == 1 ? ctx->ws1_bytes : ctx->ws2_bytes;
   if (bytes <= have) return BPMI_OK;
+  msm_graphs_clear(ctx);
   if (ws) { HIPCHK(ctx, hipStreamSynchronize(lane_stream(ctx, lane))); HIPCHK(ctx, hipFree(ws)); ws = nullptr; have = 0; }
   const size_t want = bytes + bytes / 8;
   HIPCHK(ctx, hipMalloc(&ws, want));
@@ -291,6 +300,7 @@ static int ensure_pin_slot(bpmi_ctx *ctx, int slot, size_t bytes) {
   bpmi_ctx::PendingMsm &pd = ctx->pend[slot];
   if (!pd.done) HIPCHK(ctx, hipEventCreateWithFlags(&pd.done, hipEventDisableTiming));
   if (bytes <= pd.pin_bytes) return BPMI_OK;
+  msm_graphs_clear(ctx);
   if (bytes < 16384) bytes = 16384;
   if (pd.pin) { HIPCHK(ctx, hipEventSynchronize(pd.done)); HIPCHK(ctx, hipHostFree(pd.pin)); pd.pin = nullptr; pd.pin_bytes = 0; }
   HIPCHK(ctx, hipHostMalloc(&pd.pin, bytes, hipHostMallocDefault));

@@ -29,6 +29,10 @@ static u32 pick_window_bits(const bpmi_ctx *ctx, uint64_t n) {
 // 0.26) and loses at 2^13 (0.33 against 0.29); the threshold sits just above 4 097 = the L / R of an inner-product round over
 // 4 096 generators (a 64-bit x 32 aggregated range proof; every late round of a larger proof after its product fold)
 #define SMALL_N_DEFAULT 4608
+// a PAIR of MSMs (bpmi_msm2, the L / R of an inner-product round) whose larger one has this many pairs or more, up to MID_NMAX, is ONE
+// launch of k_msm_mid (option "mid_min": 0 default, -1 never)
+#define MID_MIN_DEFAULT 1536
+#define MID_SINGLE_MIN_DEFAULT 2560      // one MSM at a time (option "mid_single_min": 0 default, -1 never)
 
 struct MsmWs {
   u32 *glv_sub, *glv_bx;      // GLV: 2n x 16 B magnitudes, n x 32 B beta x
@@ -114,6 +118,40 @@ static DigitJobs digit_jobs_concat(const DigitJobs &a, const DigitJobs &b) {
   return J;
 }
 
+// ---- replay of an MSM's launch sequence as a HIP graph (option "graphs") -------------------------------------------------------
+// An MSM is a dozen to 17 launches; the host pays ~9 us for each, and for every MSM below ~2^18 pairs the GPU finishes the sort's
+// short kernels faster than the host can queue the next one (round 4, profiles/r04_C3_kernel_timeline_mid_round.txt: 160 us between
+// the first kernels of the two lanes of one inner-product round).  Callers repeat the SAME sequence -- same input arrays, same
+// size, same workspace: the rounds of an inner-product argument, a verifier's batches, a benchmark loop -- so the sequence is
+// captured once per (lane, slot, inputs, geometry, options) and launched as one graph afterwards.  Only launches are captured: the
+// slot's completion event is recorded behind the graph, allocation happens before the capture, a reallocation of the workspace or
+// of the slot's pinned buffer drops the cache.  Not used with stage timers, debug syncs or the chained asynchronous pipeline.
+struct MsmGraphKey {
+  int lane, slot, glv, small, opt_quad, opt_tail, opt_epl, opt_hist_threads, opt_hist_blocks;
+  u32 w0, wcount;
+  Segs segs;
+  MsmGeom g;
+  const void *ws, *pin;
+};
+struct MsmGraphEntry {
+  MsmGraphKey key;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  u32 W = 0, nv = 0, c = 0; int tail = 2; TailOffs to;
+};
+struct MsmGraphCache { std::vector<MsmGraphEntry> entries; };
+static void msm_graphs_clear(bpmi_ctx *ctx) {
+  if (!ctx->graphs) return;
+  for (auto &e : ctx->graphs->entries) { if (e.exec) (void)hipGraphExecDestroy(e.exec); if (e.graph) (void)hipGraphDestroy(e.graph); }
+  ctx->graphs->entries.clear();
+}
+// ends a capture that an error path would otherwise leave open on the stream
+struct CaptureGuard {
+  hipStream_t st; bool open = false;
+  explicit CaptureGuard(hipStream_t s) : st(s) {}
+  ~CaptureGuard() { if (open) { hipGraph_t g = nullptr; (void)hipStreamEndCapture(st, &g); if (g) (void)hipGraphDestroy(g); (void)hipGetLastError(); } }
+};
+
 // Enqueue every GPU stage of one MSM on `lane` (0 = the ctx stream, 1 = the second lane: stream +
 // workspace), including the device->pinned-host copy the tail needs, into pending slot `slot`
 // (pinned buffer + completion event); returns without synchronising.
@@ -129,7 +167,12 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, int slot, const Segs &segs_in, u
   MsmGeom g;
   g.n = (u32)n;
   const uint64_t small_max = ctx->opt_small < 0 ? 0 : (ctx->opt_small ? (uint64_t)ctx->opt_small : SMALL_N_DEFAULT);
-  const bool small = n <= small_max && ctx->opt_c == 0 && wcount == 0;
+  // the one-block-per-window bucket kernel (k_msm_mid) between the small-MSM kernel and the pipeline
+  // (measured, profiles/r04_mid_kernel_latency.txt: one MSM at a time it wins from ~2 500 pairs -- 0.18 ms against 0.21 at 3 000, 0.25
+  // against 0.29 at 8 193 --, a PAIR in one launch from ~1 500 pairs each: 0.29 ms against 0.44 for two lanes of the pipeline at 4 097)
+  const uint64_t mid_single = ctx->opt_mid_single > 0 ? (uint64_t)ctx->opt_mid_single : MID_SINGLE_MIN_DEFAULT;
+  const bool mid = ctx->opt_mid_single >= 0 && n >= mid_single && n <= MID_NMAX && ctx->opt_c == 0 && wcount == 0 && ctx->opt_glv <= 0;
+  const bool small = !mid && n <= small_max && ctx->opt_c == 0 && wcount == 0;
   // GLV (option "glv" = 1; OFF by default): 2n virtual pairs with 128-bit scalars (+ 1 bit of signed-digit carry) instead of n
   // with 255-bit ones: as many bucket additions, half the windows.  Measured (profiles/r03_glv_msm_on_off.txt) it LOSES at every
   // size from 2^15: the bucket reduction is bound by the depth of its addition chains, not by the number of windows (0.16 ms
@@ -140,7 +183,7 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, int slot, const Segs &segs_in, u
   // 23-bit index, so 2n must fit it.
   const bool glv = ctx->opt_glv > 0 && !small && wcount == 0 && n >= 2 && 2 * n <= (1ull << 23);
   if (glv) g.n = (u32)(2 * n);
-  g.c = small ? SMALL_C : pick_window_bits(ctx, n);
+  g.c = mid ? MID_C : (small ? SMALL_C : pick_window_bits(ctx, n));
   g.W = wcount ? wcount : (glv ? 128u / g.c + 1u : 255u / g.c + 1u);
   g.w0 = w0;
   g.B = 1u << (g.c - 1);
@@ -177,6 +220,50 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, int slot, const Segs &segs_in, u
   if (rc) return rc;
   msm_layout(g, w, (char *)lane_ws(ctx, lane), glv);
   hipStream_t st = lane_stream(ctx, lane);
+  // the slot's pinned buffer before anything is queued (a capture must not allocate)
+  rc = ensure_pin_slot(ctx, slot, std::max<size_t>(4096, 4ull * XYZZ_WORDS * g.W * 4));
+  if (rc) return rc;
+  // Round 4: the kernels that produce an MSM's last device-side values (the window sums, or the point of the device tail) write
+  // them straight into the slot's page-locked host buffer -- it is mapped into the device's address space -- instead of into the
+  // workspace with a copy behind: one kernel boundary less on a path where every boundary is ~8 us (option "direct_result" = 0: the copy)
+  u32 *const E_dst = ctx->opt_direct ? (u32 *)pd.pin : w.E;
+  CaptureGuard cap(st);
+  MsmGraphKey key;
+  const bool use_graph = ctx->opt_graph && !ctx->prof && !g_debug_sync && !ctx->chain_accum;
+  // queued behind the graph or behind the launches: the completion event, the slot's bookkeeping
+  auto commit = [&](u32 W_, u32 nv_, u32 c_, int tail_, const TailOffs &to_) -> int {
+    if (cap.open) {
+      MsmGraphEntry e;
+      memcpy(&e.key, &key, sizeof(key)); e.W = W_; e.nv = nv_; e.c = c_; e.tail = tail_; e.to = to_;
+      cap.open = false;
+      HIPCHK(ctx, hipStreamEndCapture(st, &e.graph));
+      hipError_t ie = hipGraphInstantiate(&e.exec, e.graph, nullptr, nullptr, 0);
+      if (ie != hipSuccess) { (void)hipGraphDestroy(e.graph); return fail(ctx, BPMI_E_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ie)); }
+      if (!ctx->graphs) ctx->graphs = new MsmGraphCache();
+      if (ctx->graphs->entries.size() >= 48) msm_graphs_clear(ctx);
+      ctx->graphs->entries.push_back(e);
+      HIPCHK(ctx, hipGraphLaunch(e.exec, st));
+    }
+    HIPCHK(ctx, hipEventRecord(pd.done, st));
+    pd.active = true; pd.W = W_; pd.nv = nv_; pd.c = c_; pd.tail = tail_; pd.to = to_;
+    HIPCHK(ctx, hipGetLastError());
+    return BPMI_OK;
+  };
+  if (use_graph) {
+    memset(&key, 0, sizeof(key));
+    key.lane = lane; key.slot = slot; key.glv = glv; key.small = small ? 1 : (mid ? 2 : 0); key.opt_quad = ctx->opt_quad; key.opt_tail = ctx->opt_tail; key.opt_epl = ctx->opt_epl;
+    key.opt_hist_threads = ctx->opt_hist_threads; key.opt_hist_blocks = ctx->opt_hist_blocks; key.w0 = w0; key.wcount = wcount;
+    memcpy(&key.segs, &segs_in, sizeof(Segs)); memcpy(&key.g, &g, sizeof(MsmGeom));
+    key.ws = lane_ws(ctx, lane); key.pin = pd.pin;
+    if (ctx->graphs)
+      for (auto &e : ctx->graphs->entries)
+        if (!memcmp(&e.key, &key, sizeof(key))) {
+          HIPCHK(ctx, hipGraphLaunch(e.exec, st));
+          return commit(e.W, e.nv, e.c, e.tail, e.to);
+        }
+    HIPCHK(ctx, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    cap.open = true;
+  }
   if (glv) {
     StageTimer t(ctx, ST_DIGITS, st);
     hipLaunchKernelGGL(k_glv_prepare, dim3((u32)((n + 255) / 256)), dim3(256), 0, st, segs, (u32)n, w.glv_sub, w.glv_neg, w.glv_bx);
@@ -184,24 +271,32 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, int slot, const Segs &segs_in, u
   }
   TailOffs to;
   to.nv = 1; to.off[0] = to.off[1] = to.off[2] = to.off[3] = 0;
+  if (mid) {
+    g.nv = 1;
+    {
+      StageTimer t(ctx, ST_ACCUM, st);
+      MidPair mp;
+      memset(&mp, 0, sizeof(mp));
+      mp.segs[0] = segs; mp.g[0] = g; mp.E[0] = E_dst;
+      hipLaunchKernelGGL(k_msm_mid, dim3(g.W, 1), dim3(MID_THREADS), 0, st, mp);
+    }
+    debug_sync(ctx, "k_msm_mid", st);
+    if (!ctx->opt_direct) HIPCHK(ctx, hipMemcpyAsync(pd.pin, w.E, 4ull * XYZZ_WORDS * g.W, hipMemcpyDeviceToHost, st));
+    return commit(g.W, 1, g.c, 2, to);
+  }
   if (small) {
     g.nv = 1;
     {
       StageTimer t(ctx, ST_ACCUM, st);
       const u32 threads = (u32)std::min<uint64_t>(256, (n + 63) / 64 * 64);
       const u32 S = (u32)std::min<uint64_t>(64, (n + 255) / 256);
-      hipLaunchKernelGGL(k_msm_small, dim3(g.W, S), dim3(threads), 0, st, segs, g, S > 1 ? w.buckets : w.E);
-      if (S > 1) hipLaunchKernelGGL(k_small_combine, dim3(g.W), dim3(64), 0, st, w.buckets, S, w.E);
+      hipLaunchKernelGGL(k_msm_small, dim3(g.W, S), dim3(threads), 0, st, segs, g, S > 1 ? w.buckets : E_dst);
+      if (S > 1) hipLaunchKernelGGL(k_small_combine, dim3(g.W), dim3(64), 0, st, w.buckets, S, E_dst);
     }
     debug_sync(ctx, "k_msm_small", st);
     const size_t eb = 4ull * XYZZ_WORDS * g.W;
-    rc = ensure_pin_slot(ctx, slot, eb);
-    if (rc) return rc;
-    HIPCHK(ctx, hipMemcpyAsync(pd.pin, w.E, eb, hipMemcpyDeviceToHost, st));
-    HIPCHK(ctx, hipEventRecord(pd.done, st));
-    pd.active = true; pd.W = g.W; pd.nv = 1; pd.c = g.c; pd.tail = 2; pd.to = to;
-    HIPCHK(ctx, hipGetLastError());
-    return BPMI_OK;
+    if (!ctx->opt_direct) HIPCHK(ctx, hipMemcpyAsync(pd.pin, w.E, eb, hipMemcpyDeviceToHost, st));
+    return commit(g.W, 1, g.c, 2, to);
   }
   const u32 nblk_n = (u32)std::min<uint64_t>(((uint64_t)g.n + 255) / 256, 8192);
   {
@@ -292,11 +387,13 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, int slot, const Segs &segs_in, u
     }
   }
   debug_sync(ctx, "ST_SEGSCAN", st);
+  const int tail_pre = wcount ? 2 : (ctx->opt_tail ? ctx->opt_tail : 2);
+  u32 *const E_red = (tail_pre == 1) ? w.E : E_dst;             // the device tail reads the window sums where they are
   {
     StageTimer t(ctx, ST_BREDUCE, st);
     if (g.B <= 256u) {
-      if (ctx->opt_quad) hipLaunchKernelGGL(k_window_weighted_small_quad, dim3(g.W), dim3(g.B < 16u ? 64u : 4u * g.B), 0, st, g, w.buckets, w.E);
-      else hipLaunchKernelGGL(k_window_weighted_small, dim3(g.W), dim3(g.B < 64u ? 64u : g.B), 0, st, g, w.buckets, w.E);
+      if (ctx->opt_quad) hipLaunchKernelGGL(k_window_weighted_small_quad, dim3(g.W), dim3(g.B < 16u ? 64u : 4u * g.B), 0, st, g, w.buckets, E_red);
+      else hipLaunchKernelGGL(k_window_weighted_small, dim3(g.W), dim3(g.B < 64u ? 64u : g.B), 0, st, g, w.buckets, E_red);
     } else {
       // bucket index b in [1, B], B = 2^(c-1):  b = hi 2^s0 + lo, then each digit again in two
       const u32 s0 = g.c / 2u, N0 = (1u << s0) - 1u, N1 = g.B >> s0;          // stage-1 arrays: D0[1..N0], D1[1..N1]
@@ -315,31 +412,25 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, int slot, const Segs &segs_in, u
       DigitJobs jb = digit_jobs2(g.W, N0, stride1, N1, t1, 0, 64, 1);
       DigitJobs j2 = digit_jobs_concat(ja, jb);
       j2.prio = g.prio;
-      if (ctx->opt_quad) hipLaunchKernelGGL(k_digit_final_quad, dim3(g.W * 4u), dim3(1024), 0, st, w.D, w.E, j2);
-      else hipLaunchKernelGGL(k_digit_final, dim3(g.W * 4u), dim3(256), 0, st, w.D, w.E, j2);
+      if (ctx->opt_quad) hipLaunchKernelGGL(k_digit_final_quad, dim3(g.W * 4u), dim3(1024), 0, st, w.D, E_red, j2);
+      else hipLaunchKernelGGL(k_digit_final, dim3(g.W * 4u), dim3(256), 0, st, w.D, E_red, j2);
       to.nv = 4; to.off[0] = 0; to.off[1] = t0; to.off[2] = s0; to.off[3] = s0 + t1;
     }
   }
   debug_sync(ctx, "ST_BREDUCE", st);
+  int tail_mode = 2;
   {
     StageTimer t(ctx, ST_TAIL, st);
-    const int tail = wcount ? 2 : (ctx->opt_tail ? ctx->opt_tail : 2);      // window groups are combined on the host
-    if (tail == 1) {
-      hipLaunchKernelGGL(k_tail, dim3(1), dim3(64), 0, st, w.E, g.W, g.c, to, w.out);
-      rc = ensure_pin_slot(ctx, slot, 4096);
-      if (rc) return rc;
-      HIPCHK(ctx, hipMemcpyAsync(pd.pin, w.out, 64, hipMemcpyDeviceToHost, st));
-    } else {
+    tail_mode = wcount ? 2 : (ctx->opt_tail ? ctx->opt_tail : 2);      // window groups are combined on the host
+    if (tail_mode == 1) {
+      hipLaunchKernelGGL(k_tail, dim3(1), dim3(64), 0, st, w.E, g.W, g.c, to, ctx->opt_direct ? (u32 *)pd.pin : w.out);
+      if (!ctx->opt_direct) HIPCHK(ctx, hipMemcpyAsync(pd.pin, w.out, 64, hipMemcpyDeviceToHost, st));
+    } else if (!ctx->opt_direct) {
       const size_t eb = 4ull * XYZZ_WORDS * g.W * g.nv;
-      rc = ensure_pin_slot(ctx, slot, eb);
-      if (rc) return rc;
       HIPCHK(ctx, hipMemcpyAsync(pd.pin, w.E, eb, hipMemcpyDeviceToHost, st));
     }
-    HIPCHK(ctx, hipEventRecord(pd.done, st));
-    pd.active = true; pd.W = g.W; pd.nv = g.nv; pd.c = g.c; pd.tail = tail; pd.to = to;
   }
-  HIPCHK(ctx, hipGetLastError());
-  return BPMI_OK;
+  return commit(g.W, g.nv, g.c, tail_mode, to);
 }
 // error path of a caller that has MSMs of ITS OWN queued in pending slots (bit s of `mine` = slot s was enqueued by this call):
 // wait for both lanes, release those slots and no others -- a slot that holds a caller's asynchronous MSM (bpmi_msm_dev_enqueue)
@@ -424,50 +515,59 @@ static int msm_finish_pair(bpmi_ctx *ctx, uint8_t out0[64], uint8_t out1[64]) {
 // Two SMALL MSMs (both on the one-launch kernel's path) as one launch sequence on the ctx stream: one k_msm_small_pair, one
 // combine, the two copies; pending slots 0 and 1 as for a pair on two lanes.  (Two lanes cost a fork event, a second queue's
 // doorbell and a second wait: ~40 us of a 0.3 ms round of the inner-product argument.)
-static int msm_enqueue_small_pair(bpmi_ctx *ctx, const Segs &s0, const Segs &s1) {
+static int msm_enqueue_small_pair(bpmi_ctx *ctx, const Segs &s0, const Segs &s1, bool mid) {
   bpmi_ctx::PendingMsm &p0 = ctx->pend[0], &p1 = ctx->pend[1];
   if (p0.active || p1.active) return fail(ctx, BPMI_E_STATE, "an MSM is still pending in this slot (bpmi_msm_finish it first)");
   SmallPair sp;
   CombinePair cp;
+  MidPair mp;
+  memset(&mp, 0, sizeof(mp));
   const Segs *ss[2] = {&s0, &s1};
   size_t off[2], total = 0;
   MsmWs w[2];
+  MsmGeom gg[2];
+  const u32 c = mid ? MID_C : SMALL_C;
   for (int j = 0; j < 2; j++) {
-    MsmGeom &g = sp.g[j];
+    MsmGeom &g = gg[j];
     memset(&g, 0, sizeof(g));
-    g.n = ss[j]->total; g.c = SMALL_C; g.W = 255u / g.c + 1u; g.w0 = 0; g.B = 1u << (g.c - 1); g.G = g.W * g.B; g.L = 8; g.nv = 1;
+    g.n = ss[j]->total; g.c = c; g.W = 255u / g.c + 1u; g.w0 = 0; g.B = 1u << (g.c - 1); g.G = g.W * g.B; g.L = 8; g.nv = 1;
     msm_layout(g, w[j], nullptr);
     off[j] = total;
     total += align_up(w[j].total, 256);
   }
   int rc = ensure_ws(ctx, total);
   if (rc) return rc;
-  const size_t eb = 4ull * XYZZ_WORDS * sp.g[0].W;
+  const size_t eb = 4ull * XYZZ_WORDS * gg[0].W;
   for (int j = 0; j < 2; j++) { rc = ensure_pin_slot(ctx, j, eb); if (rc) return rc; }
   u32 Smax = 1, threads = 64;
   for (int j = 0; j < 2; j++) {
-    msm_layout(sp.g[j], w[j], (char *)ctx->ws + off[j]);
+    msm_layout(gg[j], w[j], (char *)ctx->ws + off[j]);
     const uint64_t n = ss[j]->total;
     const u32 S = (u32)std::min<uint64_t>(64, (n + 255) / 256);
-    sp.segs[j] = *ss[j]; sp.S[j] = S; sp.out[j] = S > 1 ? w[j].buckets : w[j].E;
-    cp.part[j] = w[j].buckets; cp.S[j] = S; cp.E[j] = w[j].E;
+    u32 *const E_dst = ctx->opt_direct ? (u32 *)ctx->pend[j].pin : w[j].E;        // (see msm_enqueue: straight into the slot's host buffer)
+    sp.segs[j] = *ss[j]; sp.g[j] = gg[j]; sp.S[j] = S; sp.out[j] = S > 1 ? w[j].buckets : E_dst;
+    cp.part[j] = w[j].buckets; cp.S[j] = S; cp.E[j] = E_dst;
+    mp.segs[j] = *ss[j]; mp.g[j] = gg[j]; mp.E[j] = E_dst;
     Smax = std::max(Smax, S);
     threads = std::max(threads, (u32)std::min<uint64_t>(256, (n + 63) / 64 * 64));
   }
   hipStream_t st = ctx->stream;
   {
     StageTimer t(ctx, ST_ACCUM, st);
-    hipLaunchKernelGGL(k_msm_small_pair, dim3(sp.g[0].W, Smax, 2), dim3(threads), 0, st, sp);
-    if (Smax > 1) hipLaunchKernelGGL(k_small_combine_pair, dim3(sp.g[0].W, 2), dim3(64), 0, st, cp);
+    if (mid) hipLaunchKernelGGL(k_msm_mid, dim3(gg[0].W, 2), dim3(MID_THREADS), 0, st, mp);
+    else {
+      hipLaunchKernelGGL(k_msm_small_pair, dim3(gg[0].W, Smax, 2), dim3(threads), 0, st, sp);
+      if (Smax > 1) hipLaunchKernelGGL(k_small_combine_pair, dim3(gg[0].W, 2), dim3(64), 0, st, cp);
+    }
   }
-  debug_sync(ctx, "k_msm_small_pair", st);
+  debug_sync(ctx, "k_msm_small_pair / k_msm_mid", st);
   TailOffs to;
   to.nv = 1; to.off[0] = to.off[1] = to.off[2] = to.off[3] = 0;
   for (int j = 0; j < 2; j++) {
     bpmi_ctx::PendingMsm &pd = ctx->pend[j];
-    HIPCHK(ctx, hipMemcpyAsync(pd.pin, w[j].E, eb, hipMemcpyDeviceToHost, st));
+    if (!ctx->opt_direct) HIPCHK(ctx, hipMemcpyAsync(pd.pin, w[j].E, eb, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipEventRecord(pd.done, st));
-    pd.active = true; pd.W = sp.g[j].W; pd.nv = 1; pd.c = SMALL_C; pd.tail = 2; pd.to = to;
+    pd.active = true; pd.W = gg[j].W; pd.nv = 1; pd.c = c; pd.tail = 2; pd.to = to;
   }
   HIPCHK(ctx, hipGetLastError());
   return BPMI_OK;
@@ -478,8 +578,11 @@ static int msm_run_pair(bpmi_ctx *ctx, const Segs &s0, uint8_t out0[64], const S
   if (s0.total > BPMI_MAX_N || s1.total > BPMI_MAX_N) return fail(ctx, BPMI_E_ARG, "n exceeds BPMI_MAX_N");
   {
     const uint64_t small_max = ctx->opt_small < 0 ? 0 : (ctx->opt_small ? (uint64_t)ctx->opt_small : SMALL_N_DEFAULT);
-    if (ctx->opt_pair1 && ctx->opt_c == 0 && s0.total && s1.total && s0.total <= small_max && s1.total <= small_max) {
-      int rc = msm_enqueue_small_pair(ctx, s0, s1);
+    const uint64_t mid_min = ctx->opt_mid_min > 0 ? (uint64_t)ctx->opt_mid_min : MID_MIN_DEFAULT;
+    const uint64_t big = std::max<uint64_t>(s0.total, s1.total);
+    const bool mid = ctx->opt_mid_min >= 0 && big >= mid_min && big <= MID_NMAX && ctx->opt_glv <= 0;
+    if (ctx->opt_pair1 && ctx->opt_c == 0 && s0.total && s1.total && (mid || big <= small_max)) {
+      int rc = msm_enqueue_small_pair(ctx, s0, s1, mid);
       if (rc) { if (ctx->pend[0].active && ctx->pend[1].active) msm_abandon_pending(ctx, 3u); return rc; }
       return msm_finish_pair(ctx, out0, out1);
     }

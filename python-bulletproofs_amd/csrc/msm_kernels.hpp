@@ -1214,6 +1214,165 @@ __global__ void __launch_bounds__(64) k_small_combine_pair(CombinePair c) {
   if (l == 0) xyzz_store_g(c.E[job] + (u64)w * XYZZ_WORDS, acc);
 }
 
+// ---- mid-size MSMs in ONE launch: a whole window's bucket method in one block (round 4) -----------------------------------------
+// Between the one-launch kernel above (work ~300 point operations per pair: every window multiplies every point by its digit
+// from scratch -- fine for hundreds of pairs, 275 us for the two 4 097-pair MSMs of a late inner-product round) and the bucket
+// pipeline (34 operations per pair, but a dozen dependent launches: 0.26-0.3 ms however small the input) sits this kernel: block
+// (w, job) runs the bucket method for window w of one MSM ENTIRELY in LDS --
+//   1. every thread recodes its scalars and keeps window w's signed 7-bit digit (u16 per pair in LDS), counting the 64 buckets;
+//   2. the bucket offsets, and lanes handed out in proportion to the bucket sizes (q entries per lane, q = E / (512 - 64): a
+//      bucket of ANY size is shared evenly -- all pairs in one bucket, the bit vectors of a range proof, cost what uniform digits cost);
+//   3. a counting sort of the (pair, sign) entries by bucket; every lane adds its share of one bucket (strided within the
+//      bucket, the next point in flight while one is added);
+//   4. a block-wide segmented scan over the lanes (keys = buckets, already in order; stops when no lane finds its key at the
+//      current distance: two or three steps for uniform digits) leaves the bucket sums in LDS;
+//   5. sum_b b X[b] on quads of lanes (suffix scan + tree, 12 dependent four-lane additions), one XYZZ record out.
+// 37 windows of 7 bits; the two MSMs of a pair are blockIdx.y.  ~0.1 ms for a pair of 4 097-pair MSMs.
+#define MID_C 7
+#define MID_B 64                 // 2^(MID_C - 1)
+#define MID_THREADS 512
+#define MID_NMAX 8448            // pairs per MSM: the digit and entry arrays live in LDS
+struct MidPair { Segs segs[2]; MsmGeom g[2]; u32 *E[2]; };
+__global__ void __launch_bounds__(MID_THREADS) k_msm_mid(MidPair p) {
+  __shared__ u32 s_cnt[MID_B + 2], s_off[MID_B + 2], s_cur[MID_B + 2], s_lane0[MID_B + 2];
+  __shared__ unsigned short s_dig[MID_NMAX];
+  __shared__ u32 s_ent[MID_NMAX];
+  __shared__ u32 s_key[MID_THREADS];
+  __shared__ u32 s_val[MID_THREADS * LDS_STRIDE];
+  __shared__ u32 s_bkt[MID_B * XYZZ_WORDS];
+  const u32 job = blockIdx.y, w = blockIdx.x, tid = threadIdx.x;
+  const MsmGeom g = p.g[job];
+  const u32 n = g.n;
+  if (tid < MID_B + 2) s_cnt[tid] = 0;
+  for (u32 i = tid; i < MID_B * XYZZ_WORDS; i += MID_THREADS) s_bkt[i] = 0;          // empty buckets are the identity
+  __syncthreads();
+  // 1. digits of window w.  The carry chain of the signed recoding (for_each_digit: 37 dependent steps per scalar, and every one
+  // of the 37 blocks of an MSM would walk it for every scalar) is replaced by its closed form: with K = 64 sum_{j < 36} 2^(7 j),
+  // the 7-bit field j of s + K is d_j + 64 for digits d_j in [-64, 63] that represent the same s (the top field, bits 252 .. 255,
+  // stays as it is: s < 2^255 and K < 2^252, so it is at most 9) -- one 256-bit addition and a bit-field extraction per scalar.
+  for (u32 i = tid; i < n; i += MID_THREADS) {
+    sc v;
+    const bool neg = load_digit_source(v, p.segs[job], i);       // s or q - s (< 2^255), and whether the point is negated
+    {
+      // K = 0x0408102040810204081020408102040810204081020408102040810204081020 40 (bit 6 + 7 j set, j < 36)
+      u64 cy = 0;
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        u32 kw = 0;
+#pragma unroll
+        for (int j = 0; j < 36; j++) { const int bit = 6 + 7 * j; if ((bit >> 5) == k) kw |= 1u << (bit & 31); }
+        cy += (u64)v.v[k] + kw;
+        v.v[k] = (u32)cy;
+        cy >>= 32;
+      }
+    }
+    const u32 pos = MID_C * w, wi = pos >> 5, sh = pos & 31u;
+    u32 lo_w = 0, hi_w = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) { if ((u32)k == wi) lo_w = v.v[k]; if ((u32)k == wi + 1u) hi_w = v.v[k]; }
+    const u32 field = (u32)((((u64)hi_w << 32) | lo_w) >> sh) & ((1u << MID_C) - 1u);
+    int d = (int)field - (w + 1u < g.W ? (int)MID_B : 0);
+    const u32 b = (u32)(d < 0 ? -d : d);
+    const u32 sign = (d < 0 ? 1u : 0u) ^ (neg ? 1u : 0u);
+    s_dig[i] = (unsigned short)(b | ((b ? sign : 0u) << 15));
+    if (b) atomicAdd(&s_cnt[b], 1u);
+  }
+  __syncthreads();
+  // 2. offsets and lanes (65 values: one thread)
+  if (tid == 0) {
+    u32 E = 0;
+    for (u32 b = 1; b <= MID_B; b++) { s_off[b] = E; s_cur[b] = E; E += s_cnt[b]; }
+    s_off[MID_B + 1] = E;
+    const u32 q = (E + (MID_THREADS - MID_B) - 1) / (MID_THREADS - MID_B);                 // entries per lane (0 when E = 0)
+    u32 L = 0;
+    for (u32 b = 1; b <= MID_B; b++) { s_lane0[b] = L; L += q ? (s_cnt[b] + q - 1) / q : 0u; }
+    s_lane0[MID_B + 1] = L;                                                            // <= E / q + 64 <= 512
+  }
+  __syncthreads();
+  // 3. counting sort, then every lane adds its share of its bucket
+  for (u32 i = tid; i < n; i += MID_THREADS) {
+    const u32 d = s_dig[i], b = d & 0x7FFFu;
+    if (b) s_ent[atomicAdd(&s_cur[b], 1u)] = i | ((d >> 15) << 31);
+  }
+  __syncthreads();
+  const u32 TL = s_lane0[MID_B + 1];
+  u32 key = 0xFFFFFFFFu;
+  xyzz acc;
+  xyzz_set_inf(acc);
+  if (tid < TL) {
+    u32 lo = 1, hi = MID_B;                                     // largest b with s_lane0[b] <= tid (buckets without lanes share their successor's start)
+    while (lo < hi) { const u32 mid = (lo + hi + 1) >> 1; if (s_lane0[mid] <= tid) lo = mid; else hi = mid - 1; }
+    // several empty buckets may start at the same lane: the one that owns it is the last of them (the only one with lanes)
+    const u32 b = lo;
+    key = b;
+    const u32 lanes = s_lane0[b + 1] - s_lane0[b], j = tid - s_lane0[b];
+    const u32 beg = s_off[b], end = s_off[b + 1];
+    u32 pos = beg + j;
+    u32 w_next[16];
+    u32 e_next = 0;
+    if (pos < end) { e_next = s_ent[pos]; load_entry_point<false>(w_next, p.segs[job], e_next & 0x7FFFFFFFu); }
+    while (pos < end) {
+      const u32 e = e_next;
+      affine P;
+      affine_from_words(P, w_next);
+      pos += lanes;
+      if (pos < end) { e_next = s_ent[pos]; load_entry_point<false>(w_next, p.segs[job], e_next & 0x7FFFFFFFu); }
+      xyzz_madd_signed(acc, P, (e >> 31) != 0);
+    }
+  }
+  // 4. segmented scan over the lanes (keys ascending); the last lane of a bucket leaves its sum in LDS
+  s_key[tid] = key;
+  __syncthreads();
+  for (u32 d = 1; d < MID_THREADS; d <<= 1) {
+    const bool act = tid >= d && key != 0xFFFFFFFFu && s_key[tid - d] == key;
+    if (!__syncthreads_or(act)) break;
+    xyzz_store(s_val + tid * LDS_STRIDE, acc);
+    __syncthreads();
+    if (act) {
+      xyzz other;
+      xyzz_load(other, s_val + (tid - d) * LDS_STRIDE);
+      xyzz_add(acc, other, acc);
+    }
+    __syncthreads();
+  }
+  if (key != 0xFFFFFFFFu && (tid + 1 == MID_THREADS || s_key[tid + 1] != key)) xyzz_store(s_bkt + (key - 1u) * XYZZ_WORDS, acc);
+  __syncthreads();
+  // 5. sum_b b X[b] over the 64 buckets: bucket b = rec + 1 on the quad of lanes 4 rec .. 4 rec + 3 -- the first four waves; the
+  // other four are done (a wave that has ended no longer counts at the block's barriers)
+  if (tid >= 4 * MID_B) return;
+  const u32 rec = tid >> 2, q4 = tid & 3u;
+  fe a;
+#pragma unroll
+  for (int k = 0; k < 9; k++) a.v[k] = s_bkt[rec * XYZZ_WORDS + q4 * 9u + k];
+  u32 *mine = s_val + rec * XYZZ_WORDS + q4 * 9u;                // (s_val is free again)
+#pragma unroll 1
+  for (u32 d = 1; d < MID_B; d <<= 1) {                           // inclusive suffix scan
+#pragma unroll
+    for (int k = 0; k < 9; k++) mine[k] = a.v[k];
+    __syncthreads();
+    fe b;
+#pragma unroll
+    for (int k = 0; k < 9; k++) b.v[k] = (rec + d < MID_B) ? mine[d * XYZZ_WORDS + k] : 0u;
+    __syncthreads();
+    quad_add(a, b, q4);
+  }
+#pragma unroll 1
+  for (u32 d = MID_B >> 1; d > 0; d >>= 1) {                      // sum of all suffixes: records [0, 2d) -> [0, d)
+#pragma unroll
+    for (int k = 0; k < 9; k++) mine[k] = a.v[k];
+    __syncthreads();
+    fe b;
+#pragma unroll
+    for (int k = 0; k < 9; k++) b.v[k] = (rec < d) ? mine[d * XYZZ_WORDS + k] : 0u;
+    __syncthreads();
+    quad_add(a, b, q4);
+  }
+  if (rec == 0) {
+#pragma unroll
+    for (int k = 0; k < 9; k++) p.E[job][(u64)w * XYZZ_WORDS + q4 * 9u + k] = a.v[k];
+  }
+}
+
 // ---- tail: result = sum_w 2^(c w) sum_v 2^(off[v]) E[w][v], to canonical affine -------------
 BPMI_HD void msm_tail_combine(u32 out_words[16], const u32 *E, u32 W, u32 c, const TailOffs &to) {
   // ONE Horner chain over bit positions: E[w][v] carries weight 2^(c*w + off[v]), so walking from the top bit down costs

@@ -343,3 +343,91 @@ def test_msm_heavy_partitions(gp, shape, n):
         es = [rnd.randrange(1 << 20) if i % 3 else rnd.randrange(Q) for i in range(n)]
     pb, sb = cbind.pack_points(pts), cbind.pack_scalars(es)
     assert eng.msm_bytes(pb, sb, n) == cbind.msm_bytes(pb, sb, n)
+
+
+@pytest.mark.parametrize("n", [300, 5000, 40000])
+def test_msm_graph_replay_and_result_placement(gp, n):
+    """Options "graphs" (the launch sequence of a repeated MSM replayed as a HIP graph: first call captures, later calls replay,
+    another input misses the cache) and "direct_result" (the last kernel writes into the slot's page-locked buffer / into the
+    workspace with a copy behind) must not change a byte; synchronous, paired and asynchronous entry points."""
+    eng = gp.engine()
+    pts, _ = gp.rand_points(n, 77)
+    rnd = random.Random(n)
+    sets = [[rnd.randrange(Q) for _ in range(n)] for _ in range(2)]
+    pb = cbind.pack_points(pts)
+    sbs = [cbind.pack_scalars(es) for es in sets]
+    wants = [cbind.msm_bytes(pb, sb, n, 4) for sb in sbs]
+    d_p = eng.upload(pb)
+    d_s = [eng.upload(sb) for sb in sbs]
+    try:
+        for direct in (1, 0):
+            for graphs in (1, 0):
+                eng.set_option("direct_result", direct)
+                eng.set_option("graphs", graphs)
+                for rep in range(3):                      # capture, replay, replay
+                    for k in (0, 1):
+                        assert eng.msm_dev(d_p, d_s[k], n) == wants[k]
+                o0, o1 = eng.msm2_bytes(pb, sbs[0], n, pb, sbs[1], n)
+                assert (o0, o1) == (wants[0], wants[1])
+                for rep in range(2):
+                    eng.msm_dev_enqueue(0, d_p, d_s[0], n)
+                    eng.msm_dev_enqueue(1, d_p, d_s[1], n)
+                    assert eng.msm_finish(1) == wants[1] and eng.msm_finish(0) == wants[0]
+                for tail in (1, 2):
+                    eng.set_option("tail", tail)
+                    eng.set_option("small_n", -1)
+                    assert eng.msm_dev(d_p, d_s[0], n) == wants[0]
+                    eng.set_option("small_n", 0)
+                eng.set_option("tail", 0)
+    finally:
+        eng.set_option("graphs", 0)
+        eng.set_option("direct_result", 1)
+        eng.set_option("tail", 0)
+        eng.set_option("small_n", 0)
+        d_p.free()
+        for d in d_s:
+            d.free()
+
+
+@pytest.mark.parametrize("shape", ["uniform", "one_scalar", "bits", "bits_and_blinding", "small_values", "identities_and_negatives", "near_q"])
+@pytest.mark.parametrize("n", [1536, 2049, 4097, 8193, 8448])
+def test_msm_mid_kernel_one_block_per_window(gp, shape, n):
+    """k_msm_mid (round 4): a whole window's bucket method in one block -- digits, counting sort and lane shares in LDS, the
+    segmented scan over the lanes, the weighted bucket sum on quads.  Every size class it takes, digit distributions that put
+    everything in one bucket or leave almost all buckets empty, identity points, scalars around q / 2 and q; single MSMs and the
+    pair in one launch; against the C oracle and against the pipeline (mid_min = -1) and the small kernel."""
+    eng = gp.engine()
+    pts, _ = gp.rand_points(n, 91)
+    rnd = random.Random(n * 3 + len(shape))
+    half = (Q - 1) // 2
+    if shape == "uniform":
+        es = [rnd.randrange(Q) for _ in range(n)]
+    elif shape == "one_scalar":
+        es = [rnd.randrange(Q)] * n
+    elif shape == "bits":
+        es = [rnd.randrange(2) for _ in range(n)]
+    elif shape == "bits_and_blinding":
+        es = [rnd.randrange(Q) if i % 1024 == 0 else (Q - 1 if rnd.random() < 0.5 else 0) for i in range(n)]
+    elif shape == "small_values":
+        es = [rnd.randrange(1 << rnd.choice((3, 7, 8, 14, 64))) for _ in range(n)]
+    elif shape == "identities_and_negatives":
+        es = [rnd.randrange(Q) for _ in range(n)]
+        pts = [INF if i % 5 == 0 else (-pts[i - 1] if i % 5 == 1 else p) for i, p in enumerate(pts)]
+    else:
+        es = [[half, half + 1, half - 1, Q - 1, Q - 2, 1, (1 << 255) - 19, Q + 5][i % 8] for i in range(n)]
+    pb, sb = cbind.pack_points(pts), cbind.pack_scalars([e % (1 << 256) for e in es])
+    want = cbind.msm_bytes(pb, sb, n, 4)
+    try:
+        eng.set_option("mid_min", 1)
+        eng.set_option("mid_single_min", 1)
+        assert eng.msm_bytes(pb, sb, n) == want
+        o0, o1 = eng.msm2_bytes(pb, sb, n, pb[:64 * (n - 7)], sb[:32 * (n - 7)], n - 7)      # the pair in ONE launch, unequal sizes
+        assert o0 == want and o1 == cbind.msm_bytes(pb[:64 * (n - 7)], sb[:32 * (n - 7)], n - 7, 4)
+        eng.set_option("mid_min", -1)
+        eng.set_option("mid_single_min", -1)
+        assert eng.msm_bytes(pb, sb, n) == want
+        o0, o1 = eng.msm2_bytes(pb, sb, n, pb[:64 * (n - 7)], sb[:32 * (n - 7)], n - 7)
+        assert o0 == want
+    finally:
+        eng.set_option("mid_min", 0)
+        eng.set_option("mid_single_min", 0)

@@ -64,7 +64,9 @@ while time.time() - t0 < budget:
             "chunk": rnd.choice((0, 0, 1, 2, 5, 16, 33, 64, 200)), "tail": rnd.choice((0, 1, 2)),
             "split": rnd.choice((0, 0, 0, 1)), "small_n": rnd.choice((0, 0, -1, 100, 65536)),
             "glv": rnd.choice((0, 0, 1, 1, -1)),          # 1: the GLV split at every size the bucket pipeline takes, -1: never
-            "fused_scan": rnd.choice((1, 1, 1, 0))}       # 0: two partial records per thread and k_segscan's first level (round 3)
+            "fused_scan": rnd.choice((1, 1, 1, 0)),       # 0: two partial records per thread and k_segscan's first level (round 3)
+            "direct_result": rnd.choice((1, 1, 0)), "graphs": rnd.choice((0, 0, 1)),
+            "mid_single_min": rnd.choice((0, 0, 1, 300, -1))}   # k_msm_mid for single MSMs from that many pairs (0: default 2560, -1: never)
     if n > 20000:
         opts["window_bits"] = rnd.choice((0, 0, 13, 16))
         opts["chunk"] = rnd.choice((0, 0, 16, 64))
@@ -77,8 +79,10 @@ while time.time() - t0 < budget:
     if got != want:
         fails += 1
         print("MISMATCH n=%d shape=%d kind=%d opts=%s seed=%d case=%d" % (n, shape, kind, opts, seed, cases), flush=True)
-for k in ("window_bits", "chunk", "tail", "split", "small_n", "glv"):
+for k in ("window_bits", "chunk", "tail", "split", "small_n", "glv", "mid_single_min"):
     eng.set_option(k, 0)
 eng.set_option("fused_scan", 1)
+eng.set_option("direct_result", 1)
+eng.set_option("graphs", 0)
 print("fuzz: %d cases, %d mismatches, %.0f s, seed %d" % (cases, fails, time.time() - t0, seed))
 sys.exit(1 if fails else 0)
