@@ -594,169 +594,188 @@ def extra_c5(eng, world, rank, dev, ready, log_batch=14, distinct=1024, per_gpu=
         proofs.append((commitment(g, h, v, gamma), NIRangeProver(v, nbits, g, h, gs, hs, gamma, u, secp256k1, b"seed%d" % j).prove()))
     t_prove = time.perf_counter() - t0
     wire = [proof_to_bytes(pr) for _, pr in proofs]
-    total = (1 << log_batch) * (world if per_gpu else 1)
-    lo, hi = shard_bounds(total, world, rank)
-    Vs_in = [proofs[k % distinct][0] for k in range(lo, hi)]
-    blobs_in = [wire[k % distinct] for k in range(lo, hi)]
-    # the proofs arrive as ONE receive buffer with an offset table (what a socket reader produces), not as 2^14 Python objects
-    from itertools import accumulate
-    wire_off = [0, *accumulate(map(len, blobs_in))]
-    wire_joined = b"".join(blobs_in)
-    wire_buf = eng.host_alloc(len(wire_joined))       # page-locked, as a receive buffer registered with the GPU would be
-    wire_buf.view[:] = wire_joined
-    v_packed = b"".join(V.to_le64() for V in Vs_in)   # commitments in the library's 64-byte point format
-    import ctypes
-    wire_off_c = (ctypes.c_uint64 * len(wire_off))(*wire_off)
-    usable = usable_cpus()
-    threads = max(1, min(32, usable // world))
-    from bulletproofs_amd.engine import Engine
-    eng_x = Engine(device=eng.device)                 # the exchange folds the ranks' partials on an engine of its own: the batch slots' engines
-    sharded = ShardedMSM(engine=eng_x)                # are busy on other threads while this thread combines (one thread per engine at a time)
+    wire2 = [proof_to_bytes(pr, version=2) for _, pr in proofs]       # format 2: no transcripts, the device rebuilds them (1.09 KB instead of 2.56 KB per proof)
 
-    bv = BatchRangeVerifier(g, h, gs, hs, u, engine=eng)
+    def run_format(wire, first):
+        """Everything measured on one wire format: one batch at a time, several in flight, the checks."""
+        total = (1 << log_batch) * (world if per_gpu else 1)
+        lo, hi = shard_bounds(total, world, rank)
+        Vs_in = [proofs[k % distinct][0] for k in range(lo, hi)]
+        blobs_in = [wire[k % distinct] for k in range(lo, hi)]
+        # the proofs arrive as ONE receive buffer with an offset table (what a socket reader produces), not as 2^14 Python objects
+        from itertools import accumulate
+        wire_off = [0, *accumulate(map(len, blobs_in))]
+        wire_joined = b"".join(blobs_in)
+        wire_buf = eng.host_alloc(len(wire_joined))       # page-locked, as a receive buffer registered with the GPU would be
+        wire_buf.view[:] = wire_joined
+        v_packed = b"".join(V.to_le64() for V in Vs_in)   # commitments in the library's 64-byte point format
+        import ctypes
+        wire_off_c = (ctypes.c_uint64 * len(wire_off))(*wire_off)
+        usable = usable_cpus()
+        threads = max(1, min(32, usable // world))
+        from bulletproofs_amd.engine import Engine
+        eng_x = Engine(device=eng.device)                 # the exchange folds the ranks' partials on an engine of its own: the batch slots' engines
+        sharded = ShardedMSM(engine=eng_x)                # are busy on other threads while this thread combines (one thread per engine at a time)
 
-    errors = []
+        bv = BatchRangeVerifier(g, h, gs, hs, u, engine=eng)
 
-    def finish(part):
-        failed = part is None
-        if dist.is_initialized():        # a rank whose batch failed still takes part in the exchange (with a point that cannot sum to the identity by accident): no rank is left waiting
-            part = sharded.combine(secp256k1.G.to_le64() if failed else part)
-        return (not failed) and part == bytes(64)
+        errors = []
 
-    def one_batch(corrupt=False):
-        buf = wire_buf
-        if corrupt:           # flip one bit inside one proof of this rank's shard: the batch must reject
-            bad = bytearray(wire_joined)
-            bad[(wire_off[len(blobs_in) // 2] + wire_off[len(blobs_in) // 2 + 1]) // 2] ^= 1
-            buf = bytes(bad)
-        try:
-            part = bv.partial_wire(v_packed, buf, offsets=wire_off_c)      # ONE native call: upload, preparation, decoding, MSM
-        except Exception as e:
-            # "Proof invalid" is a verdict (the batch holds a bad proof); anything else is a defect and is reported as such
-            if str(e) != "Proof invalid":
-                errors.append("%s: %s" % (type(e).__name__, e))
-            part = None
-        if corrupt:           # verified locally: the verdict on this rank's own shard is what is being checked
-            return part == bytes(64)
-        return finish(part)
+        def finish(part):
+            failed = part is None
+            if dist.is_initialized():        # a rank whose batch failed still takes part in the exchange (with a point that cannot sum to the identity by accident): no rank is left waiting
+                part = sharded.combine(secp256k1.G.to_le64() if failed else part)
+            return (not failed) and part == bytes(64)
 
-    ready()                                            # inputs, buffers and verifiers exist on every rank: the collectives start here
-    for _ in range(4):                                 # warm: workspaces, pinned buffers, and the clocks (a batch is ~2 ms of GPU work)
-        one_batch()
-    if dist.is_initialized():
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    eng.profile(1)
-    eng.profile_reset()
-    reps = 3
-    t0 = time.perf_counter()
-    oks = [one_batch() for _ in range(reps)]
-    if dist.is_initialized():
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    elapsed = (time.perf_counter() - t0) / reps
-    prof = eng.profile_read()
-    # every stage's OWN duration: one more batch with the point decoding behind the preparation kernels instead of beside them
-    # (option rp_overlap = 0): beside each other the two stretch (0.63 ms for a decoding that takes 0.32), and a roofline fraction
-    # computed on a stretched duration understates the kernel
-    eng.set_option("rp_overlap", 0)
-    eng.profile_reset()
-    ok_serial = one_batch()
-    prof_serial = eng.profile_read()
-    eng.set_option("rp_overlap", 1)
-    eng.profile(False)
-    oks.append(ok_serial)
-    rejected = not one_batch(corrupt=True)
-    # Throughput: several batches in flight.  Verifiers with an engine (stream, workspaces) and a receive buffer of their own
-    # work from their own threads (the library calls release the GIL): the upload of one batch overlaps the kernels of the other.  The
-    # exchange of the partials stays on this thread, in batch order, so every rank issues its collectives in the same order.
-    from concurrent.futures import ThreadPoolExecutor
-    # batches in flight: throughput keeps growing with the depth (one GPU: 2: 7.9-9.2e6 verifies/s, 3: 9.1-9.4e6, 4: 9.5-10.4e6,
-    # 6: 10.4-11.4e6, 8: 10.9-11.0e6, 10: 11.8-12.1e6); every slot is a host thread, so the default follows the CPUs this rank may use
-    inflight = c5_inflight(usable, world)
-    slots, extra_engines = [(bv, wire_buf)], []
-    for _ in range(inflight - 1):
-        e2 = Engine(device=eng.device)
-        b2 = e2.host_alloc(len(wire_joined))
-        b2.view[:] = wire_joined
-        extra_engines.append((e2, b2))
-        slots.append((BatchRangeVerifier(g, h, gs, hs, u, engine=e2), b2))
+        def one_batch(corrupt=False):
+            buf = wire_buf
+            if corrupt:           # flip one bit inside one proof of this rank's shard: the batch must reject
+                bad = bytearray(wire_joined)
+                bad[(wire_off[len(blobs_in) // 2] + wire_off[len(blobs_in) // 2 + 1]) // 2] ^= 1
+                buf = bytes(bad)
+            try:
+                part = bv.partial_wire(v_packed, buf, offsets=wire_off_c)      # ONE native call: upload, preparation, decoding, MSM
+            except Exception as e:
+                # "Proof invalid" is a verdict (the batch holds a bad proof); anything else is a defect and is reported as such
+                if str(e) != "Proof invalid":
+                    errors.append("%s: %s" % (type(e).__name__, e))
+                part = None
+            if corrupt:           # verified locally: the verdict on this rank's own shard is what is being checked
+                return part == bytes(64)
+            return finish(part)
 
-    def local_partial(slot):
-        bv, buf = slots[slot]
-        try:
-            return bv.partial_wire(v_packed, buf, offsets=wire_off_c)
-        except Exception as e:
-            if str(e) != "Proof invalid":
-                errors.append("%s: %s" % (type(e).__name__, e))
-            return None
-
-    pipe_batches = 32 * inflight                                                     # ~0.3 s of batches: run to run the figure moves by +-5 % (tools/c5_inflight_sweep.sh)
-    lanes = [ThreadPoolExecutor(1) for _ in range(inflight)]                         # one thread per slot: a slot never runs two batches at once
-    try:
-        for _ in range(4):                                                            # warm every slot, and ~40 ms of this very load for the clocks
-            for f in [lanes[i].submit(local_partial, i) for i in range(inflight)]:
-                finish(f.result())
+        if first:
+            ready()                                        # inputs, buffers and verifiers exist on every rank: the collectives start here
+        for _ in range(4):                                 # warm: workspaces, pinned buffers, and the clocks (a batch is ~2 ms of GPU work)
+            one_batch()
         if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize(dev)
+        eng.profile(1)
+        eng.profile_reset()
+        reps = 3
         t0 = time.perf_counter()
-        futs = [lanes[i % inflight].submit(local_partial, i % inflight) for i in range(pipe_batches)]
-        oks += [finish(f.result()) for f in futs]
+        oks = [one_batch() for _ in range(reps)]
         if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize(dev)
-        elapsed_pipe = (time.perf_counter() - t0) / pipe_batches
-    finally:
-        for ex in lanes:
-            ex.shutdown()
-    for bv, _ in slots:
-        bv.release()
-    for e2, b2 in extra_engines:
-        b2.free()
-        e2.close()
-    wire_buf.free()
-    if dist.is_initialized():
-        tt = torch.tensor([elapsed, elapsed_pipe], dtype=torch.float64, device="cpu" if dist.get_backend() != "nccl" else dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed, elapsed_pipe = float(tt[0].item()), float(tt[1].item())
-    msm_pairs = 3 + 2 * nbits + 19 * (hi - lo)
-    stage_ms = {k: v[0] / reps for k, v in prof.items() if v[1]}
-    serial_ms = {k: v[0] for k, v in prof_serial.items() if v[1]}
-    dom = max(serial_ms, key=serial_ms.get) if serial_ms else None
-    dom_s = serial_ms.get(dom, 0.0) / 1e3 if dom else 0.0
-    wire_bytes = len(wire_joined)
-    gpu_ms = sum(stage_ms.values())
-    # algorithmic bytes of the dominant stage per batch: the preparation and the point decoding read the wire bytes once
-    # (and write 32 B per scalar / 64 B per point); the MSM stages read 96 B per pair
-    stage_bytes = {"rp_prepare": wire_bytes + 32 * msm_pairs, "ec_decompress": 33 * 19 * (hi - lo) + 64 * 19 * (hi - lo)}
-    dom_bytes = stage_bytes.get(dom, ALGO_BYTES_PER_PAIR * msm_pairs)
-    cpu = None
-    if rank == 0 and world == 1 and not per_gpu and os.environ.get("BENCH_NO_CPU_BASELINE") != "1":
-        try:
-            cpu = c5_cpu_baseline(g, h, gs, hs, u, v_packed, wire_joined, wire_off_c, total, usable)
-        except Exception as e:
-            cpu = {"error": "%s: %s" % (type(e).__name__, e)}
-    out_extra = {"cpu_baseline": cpu} if cpu is not None else {}
-    if errors:
-        out_extra["errors"] = sorted(set(errors))[:4]
-    return {**out_extra, **{"metric": "range-proof verifies/sec (batched, 64-bit proofs, wire bytes in)", "value": total / elapsed_pipe, "unit": "verifies/s",
-            "batch": total, "scaling": "weak (2^%d proofs per GPU)" % log_batch if per_gpu else "strong (one batch of 2^%d split over the ranks)" % log_batch, "seconds_per_batch": elapsed_pipe, "batches_in_flight": inflight, "batch_latency_s": elapsed,
-            "verifies_per_s_one_batch_at_a_time": total / elapsed, "preparation": "device, one native call per batch (bpmi_rp_batch_verify_dev)",
-            "accepted": all(oks), "corrupted_batch_rejected": rejected,
-            "host_threads_per_rank": threads, "host_cores_usable": usable, "msm_pairs_per_rank": msm_pairs,
-            "proves_per_s_one_gpu": distinct / t_prove,
-            "gpu_stage_ms_per_batch": {k: round(v, 4) for k, v in stage_ms.items()},
-            "gpu_stage_ms_per_batch_serial": {k: round(v, 4) for k, v in serial_ms.items()},
-            "roofline": {"bound": "hbm", "kernel": "stage %s (the dominant GPU stage of a batch; duration from a batch whose stages run one after the other: gpu_stage_ms_per_batch_serial)" % dom,
-                         "kernel_ms": dom_s * 1e3,
-                         "achieved": (dom_bytes / dom_s / 1e9) if dom_s > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (dom_bytes / dom_s / 1e9 / HBM_PEAK_GBS) if dom_s > 0 else None,
-                         "algorithmic_bytes": dom_bytes, "dominant_gpu_stage": dom, "traffic": None,
-                         "note": "GPU stages %.2f ms per batch (preparation kernels, point decoding, one MSM); one batch at a time takes %.2f ms "
-                                 "(+ the %.1f MB upload from the page-locked receive buffer and the syncs), %d in flight %.2f ms per batch; integer-ALU bound like the MSM"
-                                 % (gpu_ms, elapsed * 1e3, wire_bytes / 1e6, inflight, elapsed_pipe * 1e3)}}}
+        elapsed = (time.perf_counter() - t0) / reps
+        prof = eng.profile_read()
+        # every stage's OWN duration: one more batch with the point decoding behind the preparation kernels instead of beside them
+        # (option rp_overlap = 0): beside each other the two stretch (0.63 ms for a decoding that takes 0.32), and a roofline fraction
+        # computed on a stretched duration understates the kernel
+        eng.set_option("rp_overlap", 0)
+        eng.profile_reset()
+        ok_serial = one_batch()
+        prof_serial = eng.profile_read()
+        eng.set_option("rp_overlap", 1)
+        eng.profile(False)
+        oks.append(ok_serial)
+        rejected = not one_batch(corrupt=True)
+        # Throughput: several batches in flight.  Verifiers with an engine (stream, workspaces) and a receive buffer of their own
+        # work from their own threads (the library calls release the GIL): the upload of one batch overlaps the kernels of the other.  The
+        # exchange of the partials stays on this thread, in batch order, so every rank issues its collectives in the same order.
+        from concurrent.futures import ThreadPoolExecutor
+        # batches in flight: throughput keeps growing with the depth (one GPU: 2: 7.9-9.2e6 verifies/s, 3: 9.1-9.4e6, 4: 9.5-10.4e6,
+        # 6: 10.4-11.4e6, 8: 10.9-11.0e6, 10: 11.8-12.1e6); every slot is a host thread, so the default follows the CPUs this rank may use
+        inflight = c5_inflight(usable, world)
+        slots, extra_engines = [(bv, wire_buf)], []
+        for _ in range(inflight - 1):
+            e2 = Engine(device=eng.device)
+            b2 = e2.host_alloc(len(wire_joined))
+            b2.view[:] = wire_joined
+            extra_engines.append((e2, b2))
+            slots.append((BatchRangeVerifier(g, h, gs, hs, u, engine=e2), b2))
 
+        def local_partial(slot):
+            bv, buf = slots[slot]
+            try:
+                return bv.partial_wire(v_packed, buf, offsets=wire_off_c)
+            except Exception as e:
+                if str(e) != "Proof invalid":
+                    errors.append("%s: %s" % (type(e).__name__, e))
+                return None
+
+        pipe_batches = 32 * inflight                                                     # ~0.3 s of batches: run to run the figure moves by +-5 % (tools/c5_inflight_sweep.sh)
+        lanes = [ThreadPoolExecutor(1) for _ in range(inflight)]                         # one thread per slot: a slot never runs two batches at once
+        try:
+            for _ in range(4):                                                            # warm every slot, and ~40 ms of this very load for the clocks
+                for f in [lanes[i].submit(local_partial, i) for i in range(inflight)]:
+                    finish(f.result())
+            if dist.is_initialized():
+                dist.barrier()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            futs = [lanes[i % inflight].submit(local_partial, i % inflight) for i in range(pipe_batches)]
+            oks += [finish(f.result()) for f in futs]
+            if dist.is_initialized():
+                dist.barrier()
+            torch.cuda.synchronize(dev)
+            elapsed_pipe = (time.perf_counter() - t0) / pipe_batches
+        finally:
+            for ex in lanes:
+                ex.shutdown()
+        for bv, _ in slots:
+            bv.release()
+        for e2, b2 in extra_engines:
+            b2.free()
+            e2.close()
+        wire_buf.free()
+        eng_x.close()
+        if dist.is_initialized():
+            tt = torch.tensor([elapsed, elapsed_pipe], dtype=torch.float64, device="cpu" if dist.get_backend() != "nccl" else dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed, elapsed_pipe = float(tt[0].item()), float(tt[1].item())
+        msm_pairs = 3 + 2 * nbits + 19 * (hi - lo)
+        stage_ms = {k: v[0] / reps for k, v in prof.items() if v[1]}
+        serial_ms = {k: v[0] for k, v in prof_serial.items() if v[1]}
+        dom = max(serial_ms, key=serial_ms.get) if serial_ms else None
+        dom_s = serial_ms.get(dom, 0.0) / 1e3 if dom else 0.0
+        wire_bytes = len(wire_joined)
+        gpu_ms = sum(stage_ms.values())
+        # algorithmic bytes of the dominant stage per batch: the preparation and the point decoding read the wire bytes once
+        # (and write 32 B per scalar / 64 B per point); the MSM stages read 96 B per pair (SURVEY 8d)
+        stage_bytes = {"rp_prepare": wire_bytes + 32 * msm_pairs, "ec_decompress": 33 * 19 * (hi - lo) + 64 * 19 * (hi - lo)}
+        dom_bytes = stage_bytes.get(dom, ALGO_BYTES_PER_PAIR * msm_pairs)
+        cpu = None
+        if first and rank == 0 and world == 1 and not per_gpu and os.environ.get("BENCH_NO_CPU_BASELINE") != "1":
+            try:
+                cpu = c5_cpu_baseline(g, h, gs, hs, u, v_packed, wire_joined, wire_off_c, total, usable)
+            except Exception as e:
+                cpu = {"error": "%s: %s" % (type(e).__name__, e)}
+        out_extra = {"cpu_baseline": cpu} if cpu is not None else {}
+        if errors:
+            out_extra["errors"] = sorted(set(errors))[:4]
+        return {**out_extra, **{"metric": "range-proof verifies/sec (batched, 64-bit proofs, wire bytes in)", "value": total / elapsed_pipe, "unit": "verifies/s",
+                "batch": total, "scaling": "weak (2^%d proofs per GPU)" % log_batch if per_gpu else "strong (one batch of 2^%d split over the ranks)" % log_batch, "seconds_per_batch": elapsed_pipe, "batches_in_flight": inflight, "batch_latency_s": elapsed,
+                "verifies_per_s_one_batch_at_a_time": total / elapsed, "preparation": "device, one native call per batch (bpmi_rp_batch_verify_dev)",
+                "accepted": all(oks), "corrupted_batch_rejected": rejected,
+                "host_threads_per_rank": threads, "host_cores_usable": usable, "msm_pairs_per_rank": msm_pairs,
+                "proves_per_s_one_gpu": distinct / t_prove, "wire_bytes_per_batch": wire_bytes, "wire_bytes_per_proof": round(wire_bytes / max(hi - lo, 1), 1),
+                "gpu_stage_ms_per_batch": {k: round(v, 4) for k, v in stage_ms.items()},
+                "gpu_stage_ms_per_batch_serial": {k: round(v, 4) for k, v in serial_ms.items()},
+                "roofline": {"bound": "hbm", "kernel": "stage %s (the dominant GPU stage of a batch; duration from a batch whose stages run one after the other: gpu_stage_ms_per_batch_serial)" % dom,
+                             "kernel_ms": dom_s * 1e3,
+                             "achieved": (dom_bytes / dom_s / 1e9) if dom_s > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": (dom_bytes / dom_s / 1e9 / HBM_PEAK_GBS) if dom_s > 0 else None,
+                             "algorithmic_bytes": dom_bytes, "dominant_gpu_stage": dom, "traffic": None,
+                             "note": "GPU stages %.2f ms per batch (preparation kernels, point decoding, one MSM); one batch at a time takes %.2f ms "
+                                     "(+ the %.1f MB upload from the page-locked receive buffer and the syncs), %d in flight %.2f ms per batch; integer-ALU bound like the MSM"
+                                     % (gpu_ms, elapsed * 1e3, wire_bytes / 1e6, inflight, elapsed_pipe * 1e3)}}}
+
+    res = run_format(wire, True)
+    res["wire_format"] = "1 (the reference Proof object's fields, transcripts included: rangeproofs/codec.py)"
+    try:
+        r2 = run_format(wire2, False)
+        res["wire_format_2"] = {k_: r2[k_] for k_ in ("value", "seconds_per_batch", "batch_latency_s", "verifies_per_s_one_batch_at_a_time", "accepted", "corrupted_batch_rejected",
+                                                      "wire_bytes_per_batch", "wire_bytes_per_proof", "gpu_stage_ms_per_batch", "gpu_stage_ms_per_batch_serial") if k_ in r2}
+        res["wire_format_2"]["note"] = ("the same proofs without their three transcripts (csrc/rp_wire_v2_host.hpp): the device rebuilds them (k_rp_expand_v2) and runs "
+                                        "the format-1 checks on the expansion; same verdicts (tests/test_gpu_configs.py::test_c5_wire_format_2_same_verdicts_as_format_1)")
+        if "errors" in r2:
+            res["wire_format_2"]["errors"] = r2["errors"]
+    except Exception as e:
+        res["wire_format_2"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    return res
 
 
 def c5_cpu_baseline(g, h, gs, hs, u, v_packed, wire_joined, wire_off_c, total, usable):

@@ -277,6 +277,16 @@ int bpmi_rp_final_vectors(uint32_t n, uint32_t m, int aggregated, const uint8_t 
 int bpmi_rp_verifier_vectors(uint32_t n, uint32_t m, int aggregated, const uint8_t y[32], const uint8_t z[32], int threads, uint8_t *hsc, uint8_t *yscale,
                              uint8_t ysum[32]);
 
+/* Wire format 2 of a range proof (csrc/rp_wire_v2_host.hpp, rangeproofs/codec.py): format 1 without the three transcripts -- they
+ * are functions of the other fields (/root/reference/src/utils/transcript.py:13-33, rangeproof_verifier.py:42-53) -- plus the four
+ * challenges y, z, x, x_ip in binary and the two transcript seeds: 1.09 KB instead of 2.56 KB for a 64-bit proof.  This entry point
+ * expands n_proofs format-2 proofs (proof g = blobs[off[g], off[g + 1])) into format-1 proofs packed in out[0, cap), out_off[0 ..
+ * n_proofs]; HOST code.  *first_bad = first proof that is not a well-formed format-2 proof, or -1.  bpmi_rp_batch_prepare_dev and
+ * bpmi_rp_batch_verify_dev take EITHER format (all proofs of a call in the same one, told by the magic of the first): format 2 is
+ * uploaded as it is and expanded on the device.  A format-2 proof is valid exactly when its expansion is. */
+int bpmi_rp_wire_v2_to_v1(const uint8_t *blobs, uint64_t blobs_len, const uint64_t *off, uint64_t n_proofs, uint8_t *out, uint64_t cap,
+                          uint64_t *out_off, int64_t *first_bad);
+
 /* The same preparation on the GPU (csrc/rp_batch_kernels.hpp; one lane per proof parses, re-hashes the transcripts and computes
  * the weighted scalars).  `blobs` / `blob_off` / `weights` / `seed` / `shared` are HOST pointers with the meaning above (blobs may be
  * page-locked memory from bpmi_host_alloc: the upload then runs at link speed); the outputs that feed the MSM stay on the device:

@@ -56,6 +56,7 @@ SIGNATURES = {
     "bpmi_rp_poly_coeffs": (_i, [ctypes.c_uint32, ctypes.c_uint32, _i, _cp, _cp, _cp, _cp, _cp, _i, _cp, _cp]),
     "bpmi_rp_final_vectors": (_i, [ctypes.c_uint32, ctypes.c_uint32, _i, _cp, _cp, _cp, _cp, _cp, _cp, _i, _cp, _cp, _cp, _cp, _cp]),
     "bpmi_rp_verifier_vectors": (_i, [ctypes.c_uint32, ctypes.c_uint32, _i, _cp, _cp, _i, _cp, _cp, _cp]),
+    "bpmi_rp_wire_v2_to_v1": (_i, [_vp, _u64, _vp, _u64, _vp, _u64, _vp, _vp]),
     "bpmi_rp_batch_prepare_dev": (_i, [_vp, ctypes.c_uint32, ctypes.c_uint32, _u64, _vp, _u64, _vp, _cp, _cp, _vp, _vp, _vp, _cp, _vp]),
     "bpmi_rp_batch_verify_dev": (_i, [_vp, ctypes.c_uint32, ctypes.c_uint32, _u64, _vp, _u64, _vp, _cp, _cp, _cp, _vp, _vp, _vp, _cp, _vp]),
     "bpmi_host_alloc": (_i, [_vp, ctypes.c_size_t, ctypes.POINTER(_vp)]),

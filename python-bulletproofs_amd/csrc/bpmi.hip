@@ -55,6 +55,7 @@ using namespace bpmi;
 #include "rp_batch_host.hpp"
 #include "rp_algebra_host.hpp"
 #include "transcript_host.hpp"
+#include "rp_wire_v2_host.hpp"
 #include "rp_batch_kernels.hpp"
 
 // ------------------------------------------------------------------------------------
@@ -167,6 +168,7 @@ int bpmi_set_option(bpmi_ctx *ctx, const char *name, int64_t value) {
   if (!strcmp(name, "fold_wnaf")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "fold_wnaf must be 0 or 1"); ctx->opt_fold_wnaf = (int)value; return BPMI_OK; }
   if (!strcmp(name, "reduce_epl")) { if (value < 0 || value > 64) return fail(ctx, BPMI_E_ARG, "reduce_epl must be 0..64"); ctx->opt_epl = (int)value; return BPMI_OK; }
   if (!strcmp(name, "chunk")) { if (value < 0 || value > 4096) return fail(ctx, BPMI_E_ARG, "chunk must be 0..4096"); ctx->opt_chunk = (int)value; return BPMI_OK; }
+  if (!strcmp(name, "fold_shared")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "fold_shared must be 0 or 1"); ctx->opt_fold_shared = (int)value; return BPMI_OK; }
   if (!strcmp(name, "ipa_small_m")) { if (value < 0 || (value & (value - 1))) return fail(ctx, BPMI_E_ARG, "ipa_small_m must be 0 (default), 1 (never) or a power of two"); ctx->opt_ipa_small = value; return BPMI_OK; }
   if (!strcmp(name, "ipa_big_m")) { if (value < 0 || (value & (value - 1))) return fail(ctx, BPMI_E_ARG, "ipa_big_m must be 0 or a power of two"); ctx->opt_ipa_big = value; return BPMI_OK; }
   return fail(ctx, BPMI_E_ARG, std::string("unknown option ") + name);
@@ -938,7 +940,8 @@ int bpmi_ipa_fold(bpmi_ipa *st, const uint8_t x[32], const uint8_t xinv[32]) {
                        xs, K, st->cg[st->cur ^ 1], st->ch[st->cur ^ 1]);
   }
   st->cur ^= 1;
-  const bool track_host = (2 * K <= MULTIFOLD_MAXK) && st->M >= st->big_m;
+  const bool track_host = ((2 * K <= MULTIFOLD_MAXK) && st->M >= st->big_m) ||
+                          (2 * K <= GLVF_MAXK && st->small_m && st->M < st->big_m && st->M > st->small_m && !st->hscale && st->hcg.size() == K);
   if (track_host) {
     sc X, XI;
     host_sc_from(X, x); host_sc_from(XI, xinv);
@@ -1031,6 +1034,41 @@ int bpmi_ipa_fold(bpmi_ipa *st, const uint8_t x[32], const uint8_t xinv[32]) {
     const u32 K = (u32)(M / m);
     u32 logm = 0;
     while ((1ull << logm) < m) logm++;
+    if (!st->hscale && st->hcg.size() == K && K % GLVF_TERMS == 0 && K <= GLVF_MAXK && m % 64 == 0 && ctx->opt_fold_shared) {
+      // shared coefficients: GLV halves in non-adjacent form from the host, two terms per thread (k_ec_fold_glv)
+      static thread_local GlvFoldK hk;
+      memset(&hk, 0, sizeof(hk));
+      hk.top = -1;
+      for (int side = 0; side < 2; side++)
+        for (u32 t = 0; t < K; t++) {
+          const sc &cf = side ? st->hch[t] : st->hcg[t];
+          u32 k1[4], k2[4];
+          bool n1, n2;
+          glv_split(k1, n1, k2, n2, cf);
+          for (int hf = 0; hf < 2; hf++) {
+            uint8_t k32[32] = {0};
+            memcpy(k32, hf ? k2 : k1, 16);
+            u32 nz[9], sg[9];
+            host_naf(k32, nz, sg, hk.top);
+            const bool neg = hf ? n2 : n1;
+            for (int wd = 0; wd < 5; wd++) { hk.nz[side][2 * t + hf][wd] = nz[wd]; hk.sg[side][2 * t + hf][wd] = neg ? (nz[wd] & ~sg[wd]) : sg[wd]; }
+          }
+        }
+      const u32 G = K / GLVF_TERMS;
+      const size_t o_part = align_up(sizeof(GlvFoldK), 256);
+      rc = ensure_stage_in(ctx, o_part + 4ull * XYZZ_WORDS * 2 * G * m + 512);
+      if (rc) return rc;
+      char *buf = (char *)ctx->stage_in;
+      HIPCHK(ctx, h2d(ctx, buf, &hk, sizeof(hk), ctx->stream));
+      {
+        StageTimer t(ctx, ST_LINCOMB2);
+        hipLaunchKernelGGL(k_ec_fold_glv, dim3((u32)((2ull * G * m + 255) / 256)), dim3(256), 0, ctx->stream, st->g, st->h, (u32)m, K, (const GlvFoldK *)buf,
+                           (u32 *)(buf + o_part));
+        hipLaunchKernelGGL(k_ec_sum_partials, dim3((u32)((2 * m + 255) / 256)), dim3(256), 0, ctx->stream, (const u32 *)(buf + o_part), (u32)m, G, st->g2, st->h2);
+      }
+      HIPCHK(ctx, hipGetLastError());
+      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));          // the digit table is a thread-local static
+    } else {
     const size_t o_sc = align_up(128 * M, 256), o_pr = o_sc + align_up(64 * M, 256);
     rc = ensure_stage_in(ctx, o_pr + 128 * M + 512);
     if (rc) return rc;
@@ -1050,6 +1088,7 @@ int bpmi_ipa_fold(bpmi_ipa *st, const uint8_t x[32], const uint8_t xinv[32]) {
       hipLaunchKernelGGL(k_ec_sum_strided, dim3((u32)((2 * m + 255) / 256)), dim3(256), 0, ctx->stream, d_prod, (u32)m, K, st->g2, st->h2);
     }
     HIPCHK(ctx, hipGetLastError());
+    }
     std::swap(st->g, st->g2);
     std::swap(st->h, st->h2);
     st->M = m;
@@ -1168,6 +1207,19 @@ int bpmi_rp_batch_prepare(uint32_t n_gens, uint32_t values_per_proof, uint64_t n
   // the offset table comes from the caller, the proofs from the network: never read outside blobs[0, blobs_len)
   if (blob_off[0] > blobs_len) return BPMI_E_ARG;
   for (uint64_t g = 0; g < n_proofs; g++) if (blob_off[g] > blob_off[g + 1] || blob_off[g + 1] > blobs_len) return BPMI_E_ARG;
+  // wire format 2 (rp_wire_v2_host.hpp): expanded to format 1 here, then everything below runs as before
+  std::vector<uint8_t> expanded;
+  std::vector<uint64_t> expanded_off;
+  if (n_proofs && blob_off[1] - blob_off[0] >= 5 && blobs[blob_off[0] + 4] == '2') {
+    expanded_off.assign(n_proofs + 1, 0);
+    std::vector<uint8_t> one;
+    for (uint64_t g = 0; g < n_proofs; g++) {
+      if (!rpw::expand_v2(blobs + blob_off[g], (size_t)(blob_off[g + 1] - blob_off[g]), one)) { *first_bad = (int64_t)g; return BPMI_OK; }
+      expanded.insert(expanded.end(), one.begin(), one.end());
+      expanded_off[g + 1] = expanded.size();
+    }
+    blobs = expanded.data(); blobs_len = expanded.size(); blob_off = expanded_off.data();
+  }
   const size_t nacc = 5 + 2 * (size_t)n_gens;
   if (threads < 1) threads = 1;
   if ((uint64_t)threads > n_proofs) threads = n_proofs ? (int)n_proofs : 1;
@@ -1216,10 +1268,25 @@ static int rp_prepare_enqueue(bpmi_ctx *ctx, uint32_t n_gens, uint32_t m, uint64
   uint32_t k = 0;
   while ((1u << k) < n_gens) k++;
   if (blob_off[0] > blobs_len) return fail(ctx, BPMI_E_ARG, "offset table leaves the buffer");
+  // wire format 2 (rp_wire_v2_host.hpp): told by the first proof's magic; every proof of the call must then be format 2 (the device
+  // expander refuses the others).  The array the roles read holds the EXPANDED proofs: its rows are sized by the longest expansion
+  const bool v2 = blob_off[1] - blob_off[0] >= 5 && blobs[blob_off[0] + 4] == '2';
   uint64_t maxlen = 0;
   for (uint64_t g = 0; g < n_proofs; g++) {
     if (blob_off[g] > blob_off[g + 1] || blob_off[g + 1] > blobs_len) return fail(ctx, BPMI_E_ARG, "offset table leaves the buffer");
-    maxlen = std::max(maxlen, blob_off[g + 1] - blob_off[g]);
+    uint64_t len = blob_off[g + 1] - blob_off[g];
+    if (v2) {
+      const uint8_t *b = blobs + blob_off[g];
+      const uint64_t body = 6 + 32ull * (5 + k) + 33ull * (6 + 2 * k);
+      uint64_t sl = 0, sl1 = 0;
+      if (len >= body + 132) {
+        sl = ((uint64_t)b[body + 128] << 8) | b[body + 129];
+        if (len >= body + 132 + sl) sl1 = ((uint64_t)b[body + 130 + sl] << 8) | b[body + 131 + sl];
+      }
+      const uint64_t b64s = 4 * ((sl + 2) / 3), b64s1 = 4 * ((sl1 + 2) / 3);
+      len = body + 2 + 12 + (b64s + 1 + 4 * 45 + 3 * 79) + (b64s1 + 1 + 79) + (1 + b64s1 + 1 + 79 + (uint64_t)k * (45 + 45 + 79));
+    }
+    maxlen = std::max(maxlen, len);
   }
   HIPCHK(ctx, hipSetDevice(ctx->device));
   const u32 P = (u32)n_proofs, ncols = 5 + 2 * n_gens, per = 6 + 2 * k;
@@ -1243,8 +1310,9 @@ static int rp_prepare_enqueue(bpmi_ctx *ctx, uint32_t n_gens, uint32_t m, uint64
   u32 rows = (u32)std::min<size_t>(P, std::max<size_t>(1, ((size_t)256 << 20) / cell_row));
   if (ctx->opt_rp_rows > 0) rows = std::min<u32>(rows, (u32)ctx->opt_rp_rows);
   const size_t o_ctx = align_up(36 * (size_t)ncols * rows, 256), o_shared = o_ctx + align_up(36 * (size_t)nslots * rows, 256),
-               o_T = o_shared + align_up(2 * out_row + 256, 256), T_bytes = 8 * (size_t)W * P;      // summed columns | verdict | MSM scalars of the shared generators
-  const size_t need = o_T + T_bytes + 256;
+               o_T = o_shared + align_up(2 * out_row + 256, 256), T_bytes = 8 * (size_t)W * P,      // summed columns | verdict | MSM scalars of the shared generators
+               o_lens = o_T + align_up(T_bytes, 256);                                               // format 2: lengths of the expanded proofs
+  const size_t need = o_lens + 4 * (size_t)P + 256;
   if (need > ctx->rp_buf_bytes) {
     if (ctx->rp_buf) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(ctx->rp_buf)); ctx->rp_buf = nullptr; ctx->rp_buf_bytes = 0; }
     HIPCHK(ctx, hipMalloc(&ctx->rp_buf, need));
@@ -1281,7 +1349,13 @@ static int rp_prepare_enqueue(bpmi_ctx *ctx, uint32_t n_gens, uint32_t m, uint64
   }
   HIPCHK(ctx, hipGetLastError());
   HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->stream1));
-  {
+  u32 *d_lens = v2 ? (u32 *)((char *)ctx->rp_buf + o_lens) : nullptr;
+  if (v2) {
+    // the expander writes the format-1 proofs word-major itself; what it does not write must read as zero
+    HIPCHK(ctx, hipMemsetAsync(d_T, 0, T_bytes, ctx->stream));
+    StageTimer t(ctx, ST_RPPREP);
+    hipLaunchKernelGGL(rpd::k_rp_expand_v2, dim3((P + 63) / 64), dim3(64), 0, ctx->stream, (const uint8_t *)din, (const u64 *)(din + o_off), P, k, W, d_T, d_lens);
+  } else {
     StageTimer t(ctx, ST_RPPREP);
     hipLaunchKernelGGL(rpd::k_rp_transpose, dim3((P + 63) / 64, (W + 63) / 64), dim3(256), 0, ctx->stream, (const uint8_t *)din, (const u64 *)(din + o_off), P, W, d_T);
   }
@@ -1304,6 +1378,7 @@ static int rp_prepare_enqueue(bpmi_ctx *ctx, uint32_t n_gens, uint32_t m, uint64
     u32 lanes = (u32)ctx->opt_rp_lanes;
     if (!lanes) lanes = 64;
     q.off = (const u64 *)(din + o_off) + base;
+    q.lens = v2 ? d_lens + base : nullptr;
     q.T = d_T + base;
     q.P = cnt; q.lanes = lanes; q.first = base;
     q.v_scalars = (u32 *)d_v_scalars + 8 * (size_t)base * m;

@@ -84,6 +84,7 @@ struct bpmi_ctx {
   bool async_lane1_ordered = false, async_lane2_ordered = false;
   int opt_split = 0;    // 1: one MSM as two window groups, one per lane (measured: +5 % at 2^20, -8 % at 2^19; off)
   int64_t opt_ipa_big = 0;   // base length from which the IPA folds generators 16-way (0 = default 2^18)
+  int opt_fold_shared = 1;   // the product fold of a state without per-generator scales: shared GLV halves, two terms per thread (0: per-lane products)
   int64_t opt_ipa_small = 0; // logical length at which smaller bases are folded through products (0 = default 4096, 1 = never)
   void *fold_tab = nullptr; size_t fold_tab_bytes = 0;     // tables + scratch of the width-4 NAF generator fold, allocated at the first fold, kept
   // profiling

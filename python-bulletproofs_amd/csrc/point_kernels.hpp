@@ -340,6 +340,74 @@ __global__ void __launch_bounds__(256) k_ec_sum_strided(const u32 *__restrict__ 
   store_words16((second ? out_b : out_a) + 16ull * i, w16);
 }
 
+// ---- the product fold with SHARED scalars: GLV halves, two terms per thread (round 4) ------------------------------------------
+// When the K coefficients of a fold are the same for every output (no per-generator scale rides along), the products need no
+// per-lane recoding: every coefficient is split on the host into two 128-bit halves (k = k1 + k2 lambda, scalar.hpp glv_split),
+// their non-adjacent forms go to the device as bit masks, and every branch is wave-uniform.  Thread (side, group, i) adds up TWO
+// terms of output i -- four half-scalars over P, lambda P (= (beta x, y)) of two base points held in registers: 128 doublings
+// + ~172 mixed additions, against 126 + 88 PER TERM on the per-lane product path (k_ec_mul_batch_glv) -- and leaves an XYZZ
+// partial; k_ec_sum_partials adds the K / 2 partials of an output and makes it affine.
+//   2 x 2^16 bases -> 2 x 4 096 generators: 0.9 ms against 1.5 (profiles/r04_C3_product_fold_shared_scalars.txt)
+#define GLVF_MAXK 32
+#define GLVF_TERMS 2
+struct GlvFoldK { u32 nz[2][2 * GLVF_MAXK][5]; u32 sg[2][2 * GLVF_MAXK][5]; int top; };      // [side][2 t + half][160 bits]
+__global__ void __launch_bounds__(256, 2) k_ec_fold_glv(const u32 *__restrict__ base_a, const u32 *__restrict__ base_b, u32 m, u32 K,
+                                                        const GlvFoldK *__restrict__ dk, u32 *__restrict__ partial) {
+  const u32 G = K / GLVF_TERMS;
+  const u32 tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= 2u * G * m) return;
+  const u32 i = tid % m, grp = (tid / m) % G, side = tid / (m * G);          // m is a multiple of 64: side and group are wave-uniform
+  const u32 *base = side ? base_b : base_a;
+  // (two terms, written out: arrays of points indexed in an unrolled loop went to scratch)
+  affine P0, P1;
+  fe bx0, bx1;
+  load_affine(P0, base + 16ull * ((u64)i + (u64)(grp * GLVF_TERMS) * m));
+  load_affine(P1, base + 16ull * ((u64)i + (u64)(grp * GLVF_TERMS + 1u) * m));
+  const bool inf0 = affine_is_inf(P0), inf1 = affine_is_inf(P1);
+  fe_mul_beta(bx0, P0.x); fe_carry(bx0, bx0);
+  fe_mul_beta(bx1, P1.x); fe_carry(bx1, bx1);
+  const u32 row0 = 2u * (grp * GLVF_TERMS);
+  xyzz acc;
+  xyzz_set_inf(acc);
+  for (int pos = dk->top; pos >= 0; pos--) {
+    xyzz_dbl(acc, acc);
+    const u32 msk = 1u << (pos & 31);
+    const int wd = pos >> 5;
+#pragma unroll 1
+    for (u32 r = 0; r < 4u; r++) {                       // ONE inlined copy of the addition; r is wave-uniform
+      if (!(dk->nz[side][row0 + r][wd] & msk) || (r < 2u ? inf0 : inf1)) continue;
+      affine Q;
+#pragma unroll
+      for (int l = 0; l < 9; l++) {
+        Q.x.v[l] = r == 0u ? P0.x.v[l] : (r == 1u ? bx0.v[l] : (r == 2u ? P1.x.v[l] : bx1.v[l]));
+        Q.y.v[l] = r < 2u ? P0.y.v[l] : P1.y.v[l];
+      }
+      xyzz_madd_signed(acc, Q, (dk->sg[side][row0 + r][wd] & msk) != 0);
+    }
+  }
+  xyzz_store_g(partial + (u64)tid * XYZZ_WORDS, acc);
+}
+// out_a[i] / out_b[i] = sum over the G partials of output i (partial index = (side G + grp) m + i), canonical affine
+__global__ void __launch_bounds__(256) k_ec_sum_partials(const u32 *__restrict__ partial, u32 m, u32 G, u32 *__restrict__ out_a, u32 *__restrict__ out_b) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool second = i >= m;
+  if (second) i -= m;
+  if (i >= m) return;
+  xyzz acc;
+  xyzz_load_g(acc, partial + ((u64)(second ? G : 0u) * m + i) * XYZZ_WORDS);
+#pragma unroll 1
+  for (u32 grp = 1; grp < G; grp++) {
+    xyzz x;
+    xyzz_load_g(x, partial + ((u64)((second ? G : 0u) + grp) * m + i) * XYZZ_WORDS);
+    xyzz_add(acc, acc, x);
+  }
+  affine r;
+  xyzz_to_affine(r, acc);
+  u32 w16[16];
+  affine_to_words(w16, r);
+  store_words16((second ? out_b : out_a) + 16ull * i, w16);
+}
+
 // materialise 2^d-way folded generators: out[i] = sum_t coef[t] * G[i + t*m], i < m, as an
 // interleaved NAF ladder (shared scalars -> wave-uniform branches); two jobs (g and h) per launch
 #define MULTIFOLD_MAXK 16
@@ -578,8 +646,10 @@ __global__ void __launch_bounds__(256, 3) k_ec_decompress_wire(const uint8_t *__
   const uint8_t *blob = blobs + off[g];
   const u64 len = off[g + 1] - off[g];
   const u32 pts_at = 6 + 32 * (5 + k);
-  if (len >= pts_at + 33ull * per + 2 && len <= max_len && blob[0] == 'B' && blob[1] == 'P' && blob[2] == 'R' && blob[3] == 'P' && blob[4] == '1' &&
-      blob[5] == k) {
+  // (both wire formats hold the encodings at the same offset; which one a batch is in, and that every proof is in it, is the
+  // preparation's business)
+  if (len >= pts_at + 33ull * per + 2 && len <= max_len && blob[0] == 'B' && blob[1] == 'P' && blob[2] == 'R' && blob[3] == 'P' &&
+      (blob[4] == '1' || blob[4] == '2') && blob[5] == k) {
     const bool valid = ec_decompress_one(blob + pts_at + 33 * t, w16);
     if (!valid) atomicMin(bad, (unsigned long long)(first + g));
   }

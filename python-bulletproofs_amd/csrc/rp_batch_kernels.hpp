@@ -346,6 +346,7 @@ struct Params {
   const u64 *T;              // the proofs of this launch as 8-byte words, word-major (k_rp_transpose); T points at proof 0 of the launch
   u32 Tstride;               // proofs in the array (= Pall)
   const u64 *off;            // P + 1 offsets into the wire buffer (only the lengths are used here)
+  const u32 *lens;           // format 2: the lengths of the EXPANDED proofs (k_rp_expand_v2), or null: the lengths are the offsets' differences
   const uint8_t *weights;    // P x 4 x 32 bytes, or null: derived from `seed`
   u32 seed[8];               // the 32 seed bytes as big-endian words
   u32 n, k, m, P, lanes;     // P: proofs of this launch; lanes: proofs per wave of k_rp_roles
@@ -736,7 +737,7 @@ __global__ void __launch_bounds__(64) k_rp_roles(Params q) {
   if (q.only_role >= 0 && (u32)q.only_role != role) { q.status[(size_t)role * q.Pall + g] = 1; return; }
   BPtr blob;
   blob.base = q.T + g; blob.stride = q.Tstride; blob.off = 0;
-  const u64 blen64 = q.off[g + 1] - q.off[g];
+  const u64 blen64 = q.lens ? (u64)q.lens[g] : q.off[g + 1] - q.off[g];
   Layout L;
   bool ok = blen64 <= RP_MAX_PROOF_BYTES && parse_layout(L, blob, (u32)blen64, q.k);
   if (ok) {
@@ -870,6 +871,148 @@ __global__ void __launch_bounds__(256) k_rp_transpose(const uint8_t *__restrict_
     const u32 w = w0 + c, g = g0 + lane;
     if (w < W && g < P) T[(size_t)w * P + g] = tile[lane][c];
   }
+}
+
+// ---- wire format 2 -> the transposed format-1 array (round 4; host twin and the format: rp_wire_v2_host.hpp) -------------------------
+// One lane per proof rebuilds what format 2 leaves out -- the three transcripts: base64 of the seeds and of the points, the
+// challenges in decimal -- and writes the format-1 proof straight into the word-major array the roles read (T[w * P + g]: lanes
+// that are at the same byte of their proofs store one 512-byte row), so a batch of format-2 proofs needs no k_rp_transpose.
+// lens[g] = length of the expansion, 0 for a proof that is not a well-formed format-2 proof (the roles then report it).
+struct TWriter {
+  u64 *base;        // T + g
+  u32 stride;       // P
+  u32 rows;         // W: never written beyond
+  u32 pos;          // bytes so far
+  u64 cur;          // the word being assembled
+};
+__device__ __forceinline__ void tw_put(TWriter &t, u32 b) {
+  t.cur |= (u64)(b & 0xFFu) << (8 * (t.pos & 7u));
+  t.pos++;
+  if ((t.pos & 7u) == 0) {
+    const u32 w = (t.pos >> 3) - 1u;
+    if (w < t.rows) t.base[(size_t)w * t.stride] = t.cur;
+    t.cur = 0;
+  }
+}
+__device__ __forceinline__ void tw_flush(TWriter &t) {
+  if (t.pos & 7u) { const u32 w = t.pos >> 3; if (w < t.rows) t.base[(size_t)w * t.stride] = t.cur; }
+}
+// overwrite the four bytes at `at` (a length field left open) with v, big-endian; they may be in memory already or still in `cur`
+__device__ __forceinline__ void tw_patch_be32(TWriter &t, u32 at, u32 v) {
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const u32 o = at + i, w = o >> 3, sh = 8 * (o & 7u);
+    const u64 byte = (u64)((v >> (24 - 8 * i)) & 0xFFu) << sh, mask = ~((u64)0xFFu << sh);
+    if (w == (t.pos >> 3)) t.cur = (t.cur & mask) | byte;
+    else if (w < t.rows) { u64 *p = t.base + (size_t)w * t.stride; *p = (*p & mask) | byte; }
+  }
+}
+// base64 of n raw bytes at p, then '&'
+__device__ __forceinline__ void tw_b64(TWriter &t, const uint8_t *p, u32 n) {
+  for (u32 i = 0; i < n; i += 3) {
+    const u32 b0 = p[i], b1 = i + 1 < n ? p[i + 1] : 0u, b2 = i + 2 < n ? p[i + 2] : 0u;
+    const u32 v = (b0 << 16) | (b1 << 8) | b2;
+    tw_put(t, b64_char((v >> 18) & 63u));
+    tw_put(t, b64_char((v >> 12) & 63u));
+    tw_put(t, i + 1 < n ? b64_char((v >> 6) & 63u) : '=');
+    tw_put(t, i + 2 < n ? b64_char(v & 63u) : '=');
+  }
+  tw_put(t, '&');
+}
+// the transcript item of a point (33 zero bytes = the identity = base64(b"\x00")), then '&'
+__device__ __forceinline__ void tw_point(TWriter &t, const uint8_t *comp) {
+  u32 any = 0;
+  for (int i = 0; i < 33; i++) any |= comp[i];
+  const uint8_t zero = 0;
+  if (any) tw_b64(t, comp, 33); else tw_b64(t, &zero, 1);
+}
+// a 256-bit big-endian value at p: false when it is >= q; its decimal digits (no leading zeros), then '&'
+__device__ __forceinline__ bool tw_decimal(TWriter &t, const uint8_t *p) {
+  u32 w[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) { const uint8_t *s = p + 28 - 4 * k; w[k] = ((u32)s[0] << 24) | ((u32)s[1] << 16) | ((u32)s[2] << 8) | s[3]; }
+  const u32 Qw[8] = BPMI_SC_Q;
+  bool lt = false, decided = false;
+#pragma unroll
+  for (int k = 7; k >= 0; k--) { if (!decided && w[k] != Qw[k]) { lt = w[k] < Qw[k]; decided = true; } }
+  if (!lt) return false;
+  u32 c[9];                                            // base 10^9, least significant first
+#pragma unroll
+  for (int j = 0; j < 9; j++) {
+    u64 rem = 0;
+#pragma unroll
+    for (int k = 7; k >= 0; k--) { const u64 cur = (rem << 32) | w[k]; w[k] = (u32)(cur / 1000000000ull); rem = cur % 1000000000ull; }
+    c[j] = (u32)rem;
+  }
+  bool started = false;
+#pragma unroll
+  for (int j = 8; j >= 0; j--) {
+    u32 div = 100000000u;
+#pragma unroll
+    for (int d = 0; d < 9; d++) {
+      const u32 digit = (c[j] / div) % 10u;
+      div /= 10u;
+      if (digit || started || (j == 0 && d == 8)) { tw_put(t, '0' + digit); started = true; }
+    }
+  }
+  tw_put(t, '&');
+  return true;
+}
+__global__ void __launch_bounds__(64) k_rp_expand_v2(const uint8_t *__restrict__ blobs, const u64 *__restrict__ off, u32 P, u32 k, u32 W, u64 *__restrict__ T,
+                                                     u32 *__restrict__ lens) {
+  const u32 g = blockIdx.x * 64 + threadIdx.x;
+  if (g >= P) return;
+  const uint8_t *b = blobs + off[g];
+  const u64 n = off[g + 1] - off[g];
+  const u32 body = 6 + 32 * (5 + k) + 33 * (6 + 2 * k);
+  u32 out_len = 0;
+  bool ok = n >= body + 132ull && n <= RP_MAX_PROOF_BYTES && b[0] == 'B' && b[1] == 'P' && b[2] == 'R' && b[3] == 'P' && b[4] == '2' && b[5] == k;
+  u32 sl = 0, sl1 = 0;
+  if (ok) {
+    sl = ((u32)b[body + 128] << 8) | b[body + 129];
+    ok = n >= (u64)body + 132 + sl;
+    if (ok) { sl1 = ((u32)b[body + 130 + sl] << 8) | b[body + 131 + sl]; ok = n == (u64)body + 132 + sl + sl1; }
+  }
+  if (ok) {
+    TWriter t;
+    t.base = T + g; t.stride = P; t.rows = W; t.pos = 0; t.cur = 0;
+    // the header and the scalar / point sections are the same bytes in both formats (but for the '1')
+    for (u32 i = 0; i < body; i++) tw_put(t, i == 4 ? (u32)'1' : (u32)b[i]);
+    const uint8_t *sc = b + 6, *pts = sc + 32 * (5 + k), *ch = b + body, *seed = b + body + 130, *seed1 = seed + sl + 2;
+    tw_put(t, 0); tw_put(t, 3);                                  // start_transcript
+    // range-proof transcript
+    u32 at = t.pos;
+    for (int i = 0; i < 4; i++) tw_put(t, 0);
+    tw_b64(t, seed, sl);
+    tw_point(t, pts + 66); tw_point(t, pts + 99);                // A, S
+    ok = tw_decimal(t, ch) && ok;                                // y
+    ok = tw_decimal(t, ch + 32) && ok;                           // z
+    tw_point(t, pts); tw_point(t, pts + 33);                     // T1, T2
+    ok = tw_decimal(t, ch + 64) && ok;                           // x
+    tw_patch_be32(t, at, t.pos - at - 4);
+    // Protocol 1
+    at = t.pos;
+    for (int i = 0; i < 4; i++) tw_put(t, 0);
+    tw_b64(t, seed1, sl1);
+    ok = tw_decimal(t, ch + 96) && ok;                           // x_ip
+    tw_patch_be32(t, at, t.pos - at - 4);
+    // Protocol 2: "&" + the Protocol-1 transcript, then L_i, R_i, x_i per round
+    at = t.pos;
+    for (int i = 0; i < 4; i++) tw_put(t, 0);
+    tw_put(t, '&');
+    tw_b64(t, seed1, sl1);
+    (void)tw_decimal(t, ch + 96);
+    for (u32 j = 0; j < k; j++) {
+      tw_point(t, pts + 33 * (6 + j));
+      tw_point(t, pts + 33 * (6 + k + j));
+      ok = tw_decimal(t, sc + 32 * (5 + j)) && ok;
+    }
+    tw_patch_be32(t, at, t.pos - at - 4);
+    tw_flush(t);
+    out_len = t.pos;
+    if (out_len > RP_MAX_PROOF_BYTES || (out_len + 7u) / 8u > W) ok = false;
+  }
+  lens[g] = ok ? out_len : 0u;
 }
 
 // shared[col] += sum over the P proofs of cell (col, .): the nine limb rows are summed as plain 64-bit integers (P < 2^22 loose

@@ -12,6 +12,13 @@ Layout (integers big-endian):
   len (4 B) | range-proof transcript ; len | Protocol-1 transcript ; len | Protocol-2 transcript
 A serialised proof is at most 32 KiB (a 64-bit proof is 2.6 KB): the native batch preparation, host and device, calls a longer
 one invalid.
+
+Format 2 (round 4; csrc/rp_wire_v2_host.hpp) is format 1 without the three transcripts -- they spell out, in base64 and decimal,
+what the other fields already say (src/utils/transcript.py:13-33) -- plus what they held that is NOT elsewhere:
+  "BPRP2" | k | the same scalar and point sections | y z x x_ip (4 x 32 B) | len (2 B) seed | len (2 B) Protocol-1 seed
+1.09 KB for a 64-bit proof.  `wire_v2_to_v1` rebuilds the format-1 bytes; a format-2 proof is valid exactly when they are, and
+every parser here takes either format.  Only proofs whose transcripts ARE the canonical ones can be written as format 2
+(`proof_to_bytes(proof, version=2)` checks it and raises otherwise).
 """
 import struct
 
@@ -22,6 +29,7 @@ from ..utils.utils import ModP, point_to_bytes
 from .common import Proof
 
 MAGIC = b"BPRP1"
+MAGIC2 = b"BPRP2"
 Q = secp256k1.q
 
 
@@ -30,7 +38,57 @@ def _pt33(P):
     return b if len(b) == 33 else bytes(33)
 
 
-def proof_to_bytes(proof) -> bytes:
+def _body_len(k):
+    return 6 + 32 * (5 + k) + 33 * (6 + 2 * k)
+
+
+def wire_v2_to_v1(blob) -> bytes:
+    """The format-1 proof a format-2 proof stands for (pure Python; the bulk paths use bpmi_rp_wire_v2_to_v1 or the device)."""
+    from base64 import b64encode
+    if len(blob) < 6 or blob[:5] != MAGIC2:
+        raise Exception("Proof invalid")
+    k = blob[5]
+    body = _body_len(k)
+    o = body + 128
+    if k > 16 or len(blob) < o + 4:
+        raise Exception("Proof invalid")
+    y, z, x, x_ip = (int.from_bytes(blob[body + 32 * j: body + 32 * j + 32], "big") for j in range(4))
+    xs = [int.from_bytes(blob[6 + 32 * (5 + j): 6 + 32 * (6 + j)], "big") for j in range(k)]
+    if any(v >= Q for v in (y, z, x, x_ip, *xs)):
+        raise Exception("Proof invalid")
+    seeds = []
+    for _ in range(2):
+        if len(blob) < o + 2:
+            raise Exception("Proof invalid")
+        (ln,) = struct.unpack(">H", blob[o: o + 2])
+        if len(blob) < o + 2 + ln:
+            raise Exception("Proof invalid")
+        seeds.append(bytes(blob[o + 2: o + 2 + ln]))
+        o += 2 + ln
+    if o != len(blob):
+        raise Exception("Proof invalid")
+    pts = blob[6 + 32 * (5 + k): body]
+    pt = [pts[33 * j: 33 * j + 33] for j in range(6 + 2 * k)]
+
+    def item(c):
+        return b64encode(b"\x00" if c == bytes(33) else c) + b"&"
+
+    def num(v):
+        return str(v).encode() + b"&"
+
+    T1, T2, A, S = pt[0], pt[1], pt[2], pt[3]
+    t_rp = b64encode(seeds[0]) + b"&" + item(A) + item(S) + num(y) + num(z) + item(T1) + item(T2) + num(x)
+    t_1 = b64encode(seeds[1]) + b"&" + num(x_ip)
+    t_2 = b"&" + t_1 + b"".join(item(pt[6 + j]) + item(pt[6 + k + j]) + num(xs[j]) for j in range(k))
+    out = [MAGIC, blob[5:body], struct.pack(">H", 3)]
+    for t in (t_rp, t_1, t_2):
+        out += [struct.pack(">I", len(t)), t]
+    return b"".join(out)
+
+
+def proof_to_bytes(proof, version=1) -> bytes:
+    if version == 2:
+        return _proof_to_bytes_v2(proof)
     ip, p2 = proof.innerProof, proof.innerProof.proof2
     k = len(p2.xs)
     assert len(p2.Ls) == k and len(p2.Rs) == k and k < 256
@@ -44,9 +102,32 @@ def proof_to_bytes(proof) -> bytes:
     return b"".join(out)
 
 
+def _proof_to_bytes_v2(proof) -> bytes:
+    from base64 import b64decode
+    v1 = proof_to_bytes(proof, 1)
+    k = v1[5]
+    body = _body_len(k)
+    try:
+        it_rp = proof.transcript.split(b"&")
+        it_1 = proof.innerProof.transcript.split(b"&")
+        y, z, x, x_ip = int(it_rp[3]), int(it_rp[4]), int(it_rp[7]), int(it_1[1])
+        seed, seed1 = b64decode(it_rp[0], validate=True), b64decode(it_1[0], validate=True)
+    except Exception:
+        raise ValueError("the proof's transcripts are not canonical: it has no format-2 form")
+    if max(y, z, x, x_ip) >= Q or min(y, z, x, x_ip) < 0 or max(len(seed), len(seed1)) > 0xFFFF:
+        raise ValueError("the proof's transcripts are not canonical: it has no format-2 form")
+    v2 = b"".join([MAGIC2, v1[5:body]] + [v.to_bytes(32, "big") for v in (y, z, x, x_ip)] +
+                  [struct.pack(">H", len(seed)), seed, struct.pack(">H", len(seed1)), seed1])
+    if wire_v2_to_v1(v2) != v1:
+        raise ValueError("the proof's transcripts are not canonical: it has no format-2 form")
+    return v2
+
+
 def parse_blob(blob):
-    """Structural checks and the scalar part of one serialised proof ->
+    """Structural checks and the scalar part of one serialised proof (either format) ->
     (k, ints, compressed_points, start_transcript, [3 transcripts]); no point is decoded."""
+    if blob[:5] == MAGIC2:
+        blob = wire_v2_to_v1(blob)
     if len(blob) < 6 or blob[:5] != MAGIC:
         raise Exception("Proof invalid")
     k = blob[5]
@@ -79,8 +160,8 @@ def parse_blob(blob):
 
 
 def compressed_points(blob):
-    """The 33-byte point encodings of a serialised proof (cheap: no integer is parsed)."""
-    if len(blob) < 6 or blob[:5] != MAGIC:
+    """The 33-byte point encodings of a serialised proof of either format (cheap: no integer is parsed)."""
+    if len(blob) < 6 or blob[:5] not in (MAGIC, MAGIC2):
         raise Exception("Proof invalid")
     k = blob[5]
     o = 6 + 32 * (5 + k)

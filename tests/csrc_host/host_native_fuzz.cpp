@@ -4,6 +4,7 @@
 //   transcript_host.hpp   the transcript builder of bpmi_ipa_prove_rounds (/root/reference/src/utils/transcript.py:13-33) with its
 //                         bounded export, bpmi_mod_hash_range (src/utils/utils.py:84-97)
 //   host_tail.hpp         the MSM's window combine on the host
+//   rp_wire_v2_host.hpp   wire format 2 -> format 1 (untrusted bytes in: every malformed shape must be refused, never overrun)
 // Built by tests/test_host_native_sanitizers.py with -fsanitize=address,undefined (every output buffer is a heap block of
 // EXACTLY the documented size, so an overrun of one byte is a report) and again with -fsanitize=thread (the threaded entry
 // points with 1..8 threads).  Besides "no report" it checks what can be checked without an oracle: results do not depend on the
@@ -16,6 +17,7 @@
 #include "rp_batch_host.hpp"
 #include "rp_algebra_host.hpp"
 #include "transcript_host.hpp"
+#include "rp_wire_v2_host.hpp"
 #include "host_tail.hpp"
 
 static uint64_t rng_state = 0x9E3779B97F4A7C15ULL;
@@ -190,6 +192,66 @@ static void test_host_tail() {
   if (kind == 0) { uint8_t z[64] = {0}; CHECK(!memcmp(out.p, z, 64)); }
 }
 
+// a structurally valid format-2 proof with random content (the expander never decodes a point: any 33 bytes will do)
+static std::vector<uint8_t> random_v2(uint32_t k) {
+  std::vector<uint8_t> b = {'B', 'P', 'R', 'P', '2', (uint8_t)k};
+  uint8_t sc32[32];
+  auto put_scalar = [&] { rand_scalar(sc32, (int)(rnd() % 3)); for (int i = 31; i >= 0; i--) b.push_back(sc32[i]); };      // big-endian, < q
+  for (uint32_t j = 0; j < 5 + k; j++) put_scalar();
+  for (uint32_t j = 0; j < 6 + 2 * k; j++) { const bool inf = rnd() % 9 == 0; for (int i = 0; i < 33; i++) b.push_back(inf ? 0 : (uint8_t)rnd()); }
+  for (int j = 0; j < 4; j++) put_scalar();
+  for (int s = 0; s < 2; s++) {
+    const size_t sl = rnd() % 3 == 0 ? 0 : rnd() % 40;
+    b.push_back((uint8_t)(sl >> 8)); b.push_back((uint8_t)sl);
+    for (size_t i = 0; i < sl; i++) b.push_back((uint8_t)rnd());
+  }
+  return b;
+}
+static void test_wire_v2() {
+  const uint32_t k = (uint32_t)(rnd() % 17);
+  std::vector<std::vector<uint8_t>> proofs;
+  const int count = 1 + (int)(rnd() % 4);
+  for (int i = 0; i < count; i++) proofs.push_back(random_v2(k));
+  const int victim = (int)(rnd() % count), kind = (int)(rnd() % 7);
+  std::vector<uint8_t> &v = proofs[victim];
+  const size_t body = 6 + 32 * (size_t)(5 + k) + 33 * (size_t)(6 + 2 * k);
+  if (kind == 1) v[rnd() % v.size()] ^= (uint8_t)(1u << (rnd() % 8));
+  else if (kind == 2) v.resize(rnd() % (v.size() + 1));
+  else if (kind == 3) { const size_t extra = 1 + rnd() % 9; for (size_t i = 0; i < extra; i++) v.push_back((uint8_t)rnd()); }
+  else if (kind == 4) { v[body + 128] = (uint8_t)rnd(); v[body + 129] = (uint8_t)rnd(); }                       // a seed length that lies
+  else if (kind == 5) { for (int i = 0; i < 32; i++) v[body + 32 * (rnd() % 4) + i] = 0xFF; }                    // a challenge >= q
+  else if (kind == 6) v[5] = (uint8_t)rnd();
+  // one exact-size heap block for the batch, offsets
+  size_t total = 0;
+  std::vector<uint64_t> off = {0};
+  for (auto &p : proofs) { total += p.size(); off.push_back(total); }
+  Buf in(total);
+  { size_t o = 0; for (auto &p : proofs) { if (!p.empty()) memcpy(in.p + o, p.data(), p.size()); o += p.size(); } }
+  std::vector<uint64_t> out_off(count + 1, 777);
+  int64_t bad = 5;
+  Buf big(4 * total + 4096);
+  const int rc = bpmi_rp_wire_v2_to_v1(in.p, total, off.data(), (uint64_t)count, big.p, big.n, out_off.data(), &bad);
+  CHECK(rc == BPMI_OK);
+  std::vector<uint8_t> one;
+  bool all = true;
+  for (int i = 0; i < count; i++) {
+    const bool ok = rpw::expand_v2(in.p + off[i], (size_t)(off[i + 1] - off[i]), one);
+    if (!ok && all) { CHECK(bad == i); all = false; }
+    if (ok && all) { CHECK(out_off[i + 1] - out_off[i] == one.size() && !memcmp(big.p + out_off[i], one.data(), one.size())); CHECK(one[4] == '1' && one.size() > body); }
+  }
+  if (all) {
+    CHECK(bad == -1);
+    const size_t need = (size_t)out_off[count];
+    Buf exact(need), shorter(need - 1);
+    CHECK(bpmi_rp_wire_v2_to_v1(in.p, total, off.data(), (uint64_t)count, exact.p, need, out_off.data(), &bad) == BPMI_OK && bad == -1 && !memcmp(exact.p, big.p, need));
+    CHECK(bpmi_rp_wire_v2_to_v1(in.p, total, off.data(), (uint64_t)count, shorter.p, need - 1, out_off.data(), &bad) == BPMI_E_ARG);
+  }
+  if (kind == 0) CHECK(all);
+  // an offset table that leaves the buffer is refused before anything is read
+  off[count] = total + 1;
+  CHECK(bpmi_rp_wire_v2_to_v1(in.p, total, off.data(), (uint64_t)count, big.p, big.n, out_off.data(), &bad) == BPMI_E_ARG);
+}
+
 int main(int argc, char **argv) {
   const long iters = argc > 1 ? atol(argv[1]) : 200;
   if (argc > 2) rng_state ^= (uint64_t)atoll(argv[2]) * 0x9E3779B97F4A7C15ULL;
@@ -198,6 +260,7 @@ int main(int argc, char **argv) {
     test_transcript();
     test_mod_hash_range();
     test_host_tail();
+    for (int r = 0; r < 8; r++) test_wire_v2();
   }
   printf("host_native_fuzz: %ld iterations, %d failed checks\n", iters, fails);
   return fails ? 1 : 0;

@@ -542,3 +542,112 @@ def test_one_call_batch_verification_equals_the_two_step_path(eng):
     Vs_all[1] = [Vs_all[1][1], Vs_all[1][0]]                        # two commitments of one proof exchanged
     with pytest.raises(Exception, match="Proof invalid"):
         av.verify_wire(Vs_all, ab)
+
+
+# ---- wire format 2 (round 4): format 1 without the transcripts; the device expands it (k_rp_expand_v2) -----------------------------
+def _v2(blobs_v1_proofs):
+    return [proof_to_bytes(pr, version=2) for pr in blobs_v1_proofs]
+
+
+@pytest.mark.parametrize("n", [2, 8, 64])
+def test_format_2_gives_the_same_scalars_points_and_coefficients_as_format_1(eng, n):
+    """The same proofs in both wire formats through the device preparation: identical V scalars, per-proof point scalars, shared
+    coefficients and decoded points, byte for byte -- and identical to the host twin (which expands format 2 with
+    rp_wire_v2_host.hpp before it parses)."""
+    b = make_batch(7, n=n)
+    v1 = [proof_to_bytes(pr) for pr in b["proofs"]]
+    v2 = _v2(b["proofs"])
+    assert all(len(y) < 0.62 * len(x) for x, y in zip(v1, v2))
+    rnd = random.Random(n + 5)
+    weights = b"".join(rnd.randrange(1, Q).to_bytes(32, "little") for _ in range(4 * 7))
+    for w, seed in ((weights, None), (None, bytes(range(32)))):
+        d1 = dev_prepare(eng, n, 1, v1, w, seed)
+        d2 = dev_prepare(eng, n, 1, v2, w, seed)
+        assert d1[0] == 0 and d1[1] == -1 and d2 == d1
+        assert_same(eng, n, 1, v2, w, seed)
+
+
+def test_format_2_aggregated_and_many_proofs(eng):
+    from oracle import bp_ref as R
+    from oracle import cbind
+    from helpers import gens
+    from test_batch_verify_cpu import convert_proof
+    m, bits = 4, 8
+    nm = m * bits
+    gs, hs = gens(nm, b"ags"), gens(nm, b"ahs")
+    g, h, u = (R.elliptic_hash(s) for s in (b"ag", b"ah", b"au"))
+    rnd = random.Random(77)
+    proofs = []
+    for k in range(3):
+        vs = [R.Zq(rnd.randrange(2 ** bits), Q) for _ in range(m)]
+        gammas = [R.mod_hash(b"ga%d-%d" % (k, j), Q) for j in range(m)]
+        proofs.append(convert_proof(R.aggreg_range_prove(vs, bits, g, h, gs, hs, gammas, u, seed=b"a seed of some length %d" % k, multiexp=cbind.msm)))
+    v1, v2 = [proof_to_bytes(pr) for pr in proofs], _v2(proofs)
+    assert dev_prepare(eng, nm, m, v2, None, b"\x07" * 32) == dev_prepare(eng, nm, m, v1, None, b"\x07" * 32)
+    # 300 proofs, several launch shapes
+    b = make_batch(7, n=8)
+    base1, base2 = [proof_to_bytes(pr) for pr in b["proofs"]], _v2(b["proofs"])
+    want = dev_prepare(eng, 8, 1, [base1[i % 7] for i in range(300)], None, b"\x21" * 32)
+    try:
+        for lanes, rows in ((0, 0), (16, 37), (0, 128)):
+            eng.set_option("rp_lanes", lanes)
+            eng.set_option("rp_rows", rows)
+            assert dev_prepare(eng, 8, 1, [base2[i % 7] for i in range(300)], None, b"\x21" * 32) == want
+    finally:
+        eng.set_option("rp_lanes", 0)
+        eng.set_option("rp_rows", 0)
+
+
+def test_format_2_corrupted_proofs_same_verdict_as_their_expansion(eng):
+    """160 corruptions of format-2 proofs (bit flips in every section, truncation, trailing bytes, a seed length that lies, another
+    proof's magic): the device reports the same first failing proof as the host twin, i.e. as the format-1 checks on the host
+    expansion -- and a mix of the two formats in one call is refused at the first proof of the other format."""
+    b = make_batch(4, n=8)
+    v1s, blobs = [proof_to_bytes(pr) for pr in b["proofs"]], _v2(b["proofs"])
+    k = 3
+    body = 6 + 32 * (5 + k) + 33 * (6 + 2 * k)
+    rnd = random.Random(12)
+    w = b"".join(rnd.randrange(1, Q).to_bytes(32, "little") for _ in range(16))
+    rejected = 0
+    for trial in range(160):
+        j = rnd.randrange(4)
+        bad = bytearray(blobs[j])
+        kind = rnd.choice(("scalar", "point", "challenge", "seed", "header", "truncate", "extend", "seedlen", "two"))
+        if kind == "scalar":
+            bad[rnd.randrange(6, 6 + 32 * (5 + k))] ^= 1 << rnd.randrange(8)
+        elif kind == "point":
+            bad[rnd.randrange(6 + 32 * (5 + k), body)] ^= 1 << rnd.randrange(8)
+        elif kind == "challenge":
+            bad[rnd.randrange(body, body + 128)] ^= 1 << rnd.randrange(8)
+        elif kind == "seed":
+            bad[rnd.randrange(body + 130, len(bad))] ^= 1 << rnd.randrange(8)
+        elif kind == "header":
+            bad[rnd.randrange(0, 6)] ^= 1 << rnd.randrange(8)
+        elif kind == "truncate":
+            del bad[rnd.randrange(0, len(bad)):]
+        elif kind == "extend":
+            bad += bytes(rnd.randrange(256) for _ in range(rnd.randrange(1, 9)))
+        elif kind == "seedlen":
+            bad[body + 128 + rnd.randrange(2)] ^= 1 << rnd.randrange(8)
+        mutated = blobs[:j] + [bytes(bad)] + blobs[j + 1:]
+        if kind == "two":
+            j2 = rnd.randrange(4)
+            b2 = bytearray(mutated[j2])
+            b2[rnd.randrange(6, 6 + 32 * (5 + k))] ^= 0x10
+            mutated[j2] = bytes(b2)
+        if mutated[0][:5] != b"BPRP2":           # the first proof tells the format of the call: keep it format 2 (the mix is tested below)
+            continue
+        h = host_prepare(8, 1, mutated, w, None)
+        d = dev_prepare(eng, 8, 1, mutated, w, None)
+        assert h[0] == 0 and d[0] == 0
+        host_bad = h[1]
+        upto = 4 if host_bad < 0 else host_bad
+        if upto:
+            _, ok = eng.ec_decompress_batch_bytes(h[5][:33 * upto * (6 + 2 * k)], upto * (6 + 2 * k))
+            if 0 in ok:
+                host_bad = ok.index(0) // (6 + 2 * k)
+        assert d[1] == host_bad, (trial, kind, d[1], host_bad)
+        rejected += d[1] >= 0
+    assert rejected >= 90           # (flips in taux, mu, t_hat, a, b pass the byte-level checks: those proofs fail in the MSM)
+    assert dev_prepare(eng, 8, 1, [blobs[0], v1s[1], blobs[2]], w, None)[1] == 1
+    assert dev_prepare(eng, 8, 1, [v1s[0], blobs[1], v1s[2]], w, None)[1] == 1

@@ -305,3 +305,59 @@ def test_c5_batch_verify_2e14_from_wire(gp):
         parts.append(half.partial())
     assert parts[0] == bytes(64) and parts[1] == bytes(64)      # each shard is itself a valid batch
     assert eng.ec_sum_bytes(parts[0] + parts[1], 2) == bytes(64)
+
+
+def test_c5_wire_format_2_same_verdicts_as_format_1(gp):
+    """Config C5's verifier on the SAME 1 024 distinct 64-bit proofs in both wire formats (VERDICT r03 "next" #8): the one-call
+    batch verification accepts both with the identity; over 160 corruptions of one proof of the batch (any byte of the format-2
+    proof, truncation, extension) the format-2 batch and the batch holding the host expansion of the corrupted proof get the same
+    verdict -- rejected where the expansion does not exist; and the format-2 batch is 2.3 x smaller on the wire."""
+    import random
+    from bulletproofs_amd.ec import secp256k1
+    from bulletproofs_amd.rangeproofs import BatchRangeVerifier, NIRangeProver
+    from bulletproofs_amd.rangeproofs.codec import proof_to_bytes, wire_v2_to_v1
+    from bulletproofs_amd.utils import ModP, commitment, mod_hash
+    n, distinct = 64, 1024
+    gs, hs = gp.to_gpu_list(gens(n, b"c5gs")), gp.to_gpu_list(gens(n, b"c5hs"))
+    g, h, u = (gp.to_gpu(R.elliptic_hash(s)) for s in (b"c5g", b"c5h", b"c5u"))
+    Vs, w1, w2 = [], [], []
+    for j in range(distinct):
+        v = ModP(int.from_bytes(hashlib.sha256(b"c5v%d" % j).digest()[:8], "big"), Q)
+        gamma = mod_hash(b"c5gamma%d" % j, Q)
+        Vs.append(commitment(g, h, v, gamma))
+        pr = NIRangeProver(v, n, g, h, gs, hs, gamma, u, secp256k1, b"c5seed%d" % j).prove()
+        w1.append(proof_to_bytes(pr))
+        w2.append(proof_to_bytes(pr, version=2))
+        assert wire_v2_to_v1(w2[-1]) == w1[-1]
+    assert sum(map(len, w2)) < 0.45 * sum(map(len, w1))
+    bv = BatchRangeVerifier(g, h, gs, hs, u)
+
+    def verdict(blobs):
+        try:
+            return bv.partial_wire(Vs, blobs) == bytes(64)
+        except Exception as e:
+            assert str(e) == "Proof invalid"
+            return False
+
+    assert verdict(w1) is True and verdict(w2) is True
+    rnd = random.Random(2024)
+    rejected = 0
+    for trial in range(160):
+        j = rnd.randrange(1, distinct)
+        bad = bytearray(w2[j])
+        kind = trial % 8
+        if kind == 6:
+            del bad[rnd.randrange(6, len(bad)):]
+        elif kind == 7:
+            bad += bytes([rnd.randrange(256)])
+        else:
+            bad[rnd.randrange(len(bad))] ^= 1 << rnd.randrange(8)
+        try:
+            expansion = wire_v2_to_v1(bytes(bad))
+        except Exception:
+            expansion = None
+        got = verdict(w2[:j] + [bytes(bad)] + w2[j + 1:])
+        want = False if expansion is None else verdict(w1[:j] + [expansion] + w1[j + 1:])
+        assert got == want, (trial, kind, j)
+        rejected += not got
+    assert rejected >= 150

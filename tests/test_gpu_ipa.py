@@ -144,6 +144,44 @@ def test_ipa_rounds_vs_oracle(gp, n, big_m, small_m):
     eng.set_option("ipa_small_m", 0)
 
 
+@pytest.mark.parametrize("n,small_m", [(1024, 64), (1 << 14, 1024), (1 << 16, 0)])
+def test_product_fold_shared_scalars_equals_per_lane_products(gp, n, small_m):
+    """The two forms of the product fold -- shared GLV halves in non-adjacent form with two terms per thread (k_ec_fold_glv, the
+    default when no per-generator scale rides along) and per-lane products (bpmi_ec_mul_batch + k_ec_sum_strided) -- must leave
+    the same generators: identical L, R in every round after the fold, identical final scalars, for K = 16 (twice) and at the
+    default length."""
+    eng = gp.engine()
+    pts, _ = gp.rand_points(2 * n + 1 if n <= (1 << 14) else 4097, 333)
+    if n > (1 << 14):                       # many points from few: products of the pool on the GPU
+        ks = b"".join(random.Random(5).randrange(1, Q).to_bytes(32, "little") for _ in range(2 * n + 1))
+        raw = eng.ec_mul_batch_bytes(b"".join(cbind.pack_points([pts[i % 4097]]) for i in range(2 * n + 1)), ks, 2 * n + 1)
+        gb, hb, ub = raw[:64 * n], raw[64 * n: 128 * n], raw[128 * n:]
+    else:
+        gb, hb, ub = cbind.pack_points(pts[:n]), cbind.pack_points(pts[n:2 * n]), cbind.pack_points([pts[2 * n]])
+    rnd = random.Random(n)
+    ab = cbind.pack_scalars([rnd.randrange(Q) for _ in range(n)]), cbind.pack_scalars([rnd.randrange(Q) for _ in range(n)])
+    xs = [rnd.randrange(1, Q) for _ in range(n.bit_length())]
+    runs = []
+    try:
+        eng.set_option("ipa_small_m", small_m)
+        for shared in (1, 0):
+            eng.set_option("fold_shared", shared)
+            st = eng.ipa_create(gb, hb, ab[0], ab[1], n, ub)
+            trace = []
+            for x in xs:
+                if len(st) <= 1:
+                    break
+                trace.append(st.round_LR())
+                st.fold(x, pow(x, -1, Q))
+            trace.append(st.finish())
+            st.close()
+            runs.append(trace)
+    finally:
+        eng.set_option("ipa_small_m", 0)
+        eng.set_option("fold_shared", 1)
+    assert runs[0] == runs[1]
+
+
 def test_ipa_full_size_round_trip(gp):
     """Size-independent property at a size the oracle cannot reach in seconds: a proof
     produced by FastNIProver2 at n = 2^16 (deferred folding, 32 MSMs) must be accepted by
