@@ -1210,7 +1210,7 @@ int bpmi_rp_batch_prepare(uint32_t n_gens, uint32_t values_per_proof, uint64_t n
   // wire format 2 (rp_wire_v2_host.hpp): expanded to format 1 here, then everything below runs as before
   std::vector<uint8_t> expanded;
   std::vector<uint64_t> expanded_off;
-  if (n_proofs && blob_off[1] - blob_off[0] >= 5 && blobs[blob_off[0] + 4] == '2') {
+  if (n_proofs && blob_off[1] >= blob_off[0] + 5 && blobs[blob_off[0] + 4] == '2') {
     expanded_off.assign(n_proofs + 1, 0);
     std::vector<uint8_t> one;
     for (uint64_t g = 0; g < n_proofs; g++) {
@@ -1270,21 +1270,18 @@ static int rp_prepare_enqueue(bpmi_ctx *ctx, uint32_t n_gens, uint32_t m, uint64
   if (blob_off[0] > blobs_len) return fail(ctx, BPMI_E_ARG, "offset table leaves the buffer");
   // wire format 2 (rp_wire_v2_host.hpp): told by the first proof's magic; every proof of the call must then be format 2 (the device
   // expander refuses the others).  The array the roles read holds the EXPANDED proofs: its rows are sized by the longest expansion
-  const bool v2 = blob_off[1] - blob_off[0] >= 5 && blobs[blob_off[0] + 4] == '2';
+  const bool v2 = blob_off[1] >= blob_off[0] + 5 && blob_off[0] + 5 <= blobs_len && blobs[blob_off[0] + 4] == '2';
   uint64_t maxlen = 0;
   for (uint64_t g = 0; g < n_proofs; g++) {
     if (blob_off[g] > blob_off[g + 1] || blob_off[g + 1] > blobs_len) return fail(ctx, BPMI_E_ARG, "offset table leaves the buffer");
     uint64_t len = blob_off[g + 1] - blob_off[g];
     if (v2) {
-      const uint8_t *b = blobs + blob_off[g];
+      // longest expansion a format-2 proof of this length can have (its seeds' lengths are NOT read here: 2^14 scattered reads of
+      // the receive buffer cost more than the upload saves): S seed bytes in all, base64 of them at most three times (the
+      // Protocol-1 seed appears in two transcripts), every point item 45 bytes, every decimal item 79
       const uint64_t body = 6 + 32ull * (5 + k) + 33ull * (6 + 2 * k);
-      uint64_t sl = 0, sl1 = 0;
-      if (len >= body + 132) {
-        sl = ((uint64_t)b[body + 128] << 8) | b[body + 129];
-        if (len >= body + 132 + sl) sl1 = ((uint64_t)b[body + 130 + sl] << 8) | b[body + 131 + sl];
-      }
-      const uint64_t b64s = 4 * ((sl + 2) / 3), b64s1 = 4 * ((sl1 + 2) / 3);
-      len = body + 2 + 12 + (b64s + 1 + 4 * 45 + 3 * 79) + (b64s1 + 1 + 79) + (1 + b64s1 + 1 + 79 + (uint64_t)k * (45 + 45 + 79));
+      const uint64_t S = len > body + 132 ? len - body - 132 : 0;
+      len = body + 2 + 12 + 3 * (4 * ((S + 2) / 3) + 1) + 4 * 45 + 3 * 79 + 2 * 79 + 1 + (uint64_t)k * (45 + 45 + 79);
     }
     maxlen = std::max(maxlen, len);
   }
@@ -1354,7 +1351,7 @@ static int rp_prepare_enqueue(bpmi_ctx *ctx, uint32_t n_gens, uint32_t m, uint64
     // the expander writes the format-1 proofs word-major itself; what it does not write must read as zero
     HIPCHK(ctx, hipMemsetAsync(d_T, 0, T_bytes, ctx->stream));
     StageTimer t(ctx, ST_RPPREP);
-    hipLaunchKernelGGL(rpd::k_rp_expand_v2, dim3((P + 63) / 64), dim3(64), 0, ctx->stream, (const uint8_t *)din, (const u64 *)(din + o_off), P, k, W, d_T, d_lens);
+    hipLaunchKernelGGL(rpd::k_rp_expand_v2, dim3((P + 3) / 4), dim3(64), 0, ctx->stream, (const uint8_t *)din, (const u64 *)(din + o_off), P, k, W, d_T, d_lens);
   } else {
     StageTimer t(ctx, ST_RPPREP);
     hipLaunchKernelGGL(rpd::k_rp_transpose, dim3((P + 63) / 64, (W + 63) / 64), dim3(256), 0, ctx->stream, (const uint8_t *)din, (const u64 *)(din + o_off), P, W, d_T);

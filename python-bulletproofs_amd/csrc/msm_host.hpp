@@ -17,7 +17,8 @@ static u32 pick_window_bits(const bpmi_ctx *ctx, uint64_t n) {
   // the two-digit bucket reduction made 2^15 buckets per window cheap; c = 12 .. 15 lose at every size above), c = 13 between
   // 10 240 and 2^15 (0.30-0.33 ms against 0.33-0.46 with c = 8), c = 8 below
   if (n >= (1u << 15)) return 16;
-  if (n >= 10240u) return 13;
+  if (n >= 20480u) return 13;
+  if (n >= 10240u) return 12;          // round 4, with the wave-level scan in the accumulation: 0.303 ms against 0.312 at 2^14 (profiles/r04_tune_msm_mid_sizes_fused_scan.txt)
   if (n >= (1u << 10)) return 8;
   u32 lg = 0;
   while ((1ull << (lg + 1)) <= n) lg++;

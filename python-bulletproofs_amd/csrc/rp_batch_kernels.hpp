@@ -874,39 +874,46 @@ __global__ void __launch_bounds__(256) k_rp_transpose(const uint8_t *__restrict_
 }
 
 // ---- wire format 2 -> the transposed format-1 array (round 4; host twin and the format: rp_wire_v2_host.hpp) -------------------------
-// One lane per proof rebuilds what format 2 leaves out -- the three transcripts: base64 of the seeds and of the points, the
-// challenges in decimal -- and writes the format-1 proof straight into the word-major array the roles read (T[w * P + g]: lanes
-// that are at the same byte of their proofs store one 512-byte row), so a batch of format-2 proofs needs no k_rp_transpose.
+// SIXTEEN lanes per proof rebuild what format 2 leaves out -- the three transcripts: base64 of the seeds and of the points, the
+// challenges in decimal -- and write the format-1 proof straight into the word-major array the roles read (T[w * P + g]), so a
+// batch of format-2 proofs needs no k_rp_transpose.  The expansion is a list of ITEMS (64-byte pieces of the unchanged head, the
+// length fields, base64 items, decimal items); a first pass has the lanes of a proof measure the items whose length depends on
+// the data (the digits of a challenge, "AA==" for the identity point) into LDS, then every lane walks the list, adding up
+// lengths, and writes the items it owns (item i: lane i mod 16) at their byte offsets -- whole words with plain stores, the
+// partial first / last word of an item with atomicOr into the zeroed array.  (One lane per proof took 0.27 ms of a batch's
+// latency: 256 waves, ~100 000 dependent instructions each; this form is 4 096 waves of ~5 000.)
 // lens[g] = length of the expansion, 0 for a proof that is not a well-formed format-2 proof (the roles then report it).
 struct TWriter {
   u64 *base;        // T + g
   u32 stride;       // P
   u32 rows;         // W: never written beyond
-  u32 pos;          // bytes so far
+  u32 pos;          // byte position of the next byte
+  u32 first;        // word index of the item's first (possibly shared) word
   u64 cur;          // the word being assembled
 };
+__device__ __forceinline__ TWriter tw_at(u64 *base, u32 stride, u32 rows, u32 at) {
+  TWriter t;
+  t.base = base; t.stride = stride; t.rows = rows; t.pos = at; t.first = at >> 3; t.cur = 0;
+  return t;
+}
+__device__ __forceinline__ void tw_store(TWriter &t, u32 w, bool shared) {
+  if (w >= t.rows) return;
+  u64 *p = t.base + (size_t)w * t.stride;
+  if (shared) atomicOr((unsigned long long *)p, (unsigned long long)t.cur); else *p = t.cur;
+}
 __device__ __forceinline__ void tw_put(TWriter &t, u32 b) {
   t.cur |= (u64)(b & 0xFFu) << (8 * (t.pos & 7u));
   t.pos++;
   if ((t.pos & 7u) == 0) {
     const u32 w = (t.pos >> 3) - 1u;
-    if (w < t.rows) t.base[(size_t)w * t.stride] = t.cur;
+    tw_store(t, w, w == t.first);           // the item's first word may hold the tail of the item before it
     t.cur = 0;
   }
 }
 __device__ __forceinline__ void tw_flush(TWriter &t) {
-  if (t.pos & 7u) { const u32 w = t.pos >> 3; if (w < t.rows) t.base[(size_t)w * t.stride] = t.cur; }
+  if (t.pos & 7u) tw_store(t, t.pos >> 3, true);
 }
-// overwrite the four bytes at `at` (a length field left open) with v, big-endian; they may be in memory already or still in `cur`
-__device__ __forceinline__ void tw_patch_be32(TWriter &t, u32 at, u32 v) {
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const u32 o = at + i, w = o >> 3, sh = 8 * (o & 7u);
-    const u64 byte = (u64)((v >> (24 - 8 * i)) & 0xFFu) << sh, mask = ~((u64)0xFFu << sh);
-    if (w == (t.pos >> 3)) t.cur = (t.cur & mask) | byte;
-    else if (w < t.rows) { u64 *p = t.base + (size_t)w * t.stride; *p = (*p & mask) | byte; }
-  }
-}
+__device__ __forceinline__ void tw_be32(TWriter &t, u32 v) { tw_put(t, v >> 24); tw_put(t, v >> 16); tw_put(t, v >> 8); tw_put(t, v); }
 // base64 of n raw bytes at p, then '&'
 __device__ __forceinline__ void tw_b64(TWriter &t, const uint8_t *p, u32 n) {
   for (u32 i = 0; i < n; i += 3) {
@@ -919,15 +926,18 @@ __device__ __forceinline__ void tw_b64(TWriter &t, const uint8_t *p, u32 n) {
   }
   tw_put(t, '&');
 }
-// the transcript item of a point (33 zero bytes = the identity = base64(b"\x00")), then '&'
-__device__ __forceinline__ void tw_point(TWriter &t, const uint8_t *comp) {
+__device__ __forceinline__ bool comp_is_identity(const uint8_t *comp) {
   u32 any = 0;
   for (int i = 0; i < 33; i++) any |= comp[i];
-  const uint8_t zero = 0;
-  if (any) tw_b64(t, comp, 33); else tw_b64(t, &zero, 1);
+  return any == 0;
 }
-// a 256-bit big-endian value at p: false when it is >= q; its decimal digits (no leading zeros), then '&'
-__device__ __forceinline__ bool tw_decimal(TWriter &t, const uint8_t *p) {
+// the transcript item of a point (33 zero bytes = the identity = base64(b"\x00")), then '&'
+__device__ __forceinline__ void tw_point(TWriter &t, const uint8_t *comp) {
+  const uint8_t zero = 0;
+  if (comp_is_identity(comp)) tw_b64(t, &zero, 1); else tw_b64(t, comp, 33);
+}
+// a 256-bit big-endian value at p -> base 10^9, least significant first; false when the value is >= q
+__device__ __forceinline__ bool dec_chunks(u32 c[9], const uint8_t *p) {
   u32 w[8];
 #pragma unroll
   for (int k = 0; k < 8; k++) { const uint8_t *s = p + 28 - 4 * k; w[k] = ((u32)s[0] << 24) | ((u32)s[1] << 16) | ((u32)s[2] << 8) | s[3]; }
@@ -935,8 +945,6 @@ __device__ __forceinline__ bool tw_decimal(TWriter &t, const uint8_t *p) {
   bool lt = false, decided = false;
 #pragma unroll
   for (int k = 7; k >= 0; k--) { if (!decided && w[k] != Qw[k]) { lt = w[k] < Qw[k]; decided = true; } }
-  if (!lt) return false;
-  u32 c[9];                                            // base 10^9, least significant first
 #pragma unroll
   for (int j = 0; j < 9; j++) {
     u64 rem = 0;
@@ -944,6 +952,22 @@ __device__ __forceinline__ bool tw_decimal(TWriter &t, const uint8_t *p) {
     for (int k = 7; k >= 0; k--) { const u64 cur = (rem << 32) | w[k]; w[k] = (u32)(cur / 1000000000ull); rem = cur % 1000000000ull; }
     c[j] = (u32)rem;
   }
+  return lt;
+}
+// digits of the value (no leading zeros; "0" for zero) + 1 for the '&'; 0 when the value is >= q
+__device__ __forceinline__ u32 dec_item_len(const uint8_t *p) {
+  u32 c[9];
+  if (!dec_chunks(c, p)) return 0;
+  u32 top = 0, tv = c[0];
+#pragma unroll
+  for (int j = 1; j < 9; j++) if (c[j]) { top = (u32)j; tv = c[j]; }
+  u32 d = 1;
+  for (u32 lim = 10u; d < 9u && tv >= lim; lim *= 10u) d++;
+  return 9u * top + d + 1u;
+}
+__device__ __forceinline__ void tw_decimal(TWriter &t, const uint8_t *p) {
+  u32 c[9];
+  (void)dec_chunks(c, p);
   bool started = false;
 #pragma unroll
   for (int j = 8; j >= 0; j--) {
@@ -956,63 +980,109 @@ __device__ __forceinline__ bool tw_decimal(TWriter &t, const uint8_t *p) {
     }
   }
   tw_put(t, '&');
-  return true;
 }
+#define V2_LPP 16u                 // lanes per proof
+#define V2_MAXLEN 64u              // measured items per proof: 4 + k challenges, 4 + 2 k points  (k <= 16)
 __global__ void __launch_bounds__(64) k_rp_expand_v2(const uint8_t *__restrict__ blobs, const u64 *__restrict__ off, u32 P, u32 k, u32 W, u64 *__restrict__ T,
                                                      u32 *__restrict__ lens) {
-  const u32 g = blockIdx.x * 64 + threadIdx.x;
-  if (g >= P) return;
-  const uint8_t *b = blobs + off[g];
-  const u64 n = off[g + 1] - off[g];
+  // Lanes of a wave only run side by side when they run the SAME code: the items are therefore written kind by kind -- all decimal
+  // items of a proof at once (one per lane), then all point items, then the pieces of the unchanged head -- each at the byte
+  // offset the group's first lane has worked out from the measured lengths.  (A first parallel version gave every lane "its"
+  // items of the mixed list: at any item only one lane in sixteen was active, every wave ran the whole list serially, and the
+  // kernel was slower than one lane per proof.)
+  __shared__ u32 s_len[4][V2_MAXLEN];       // measured lengths: challenges y z x x_ip x_0 .., then points A S T1 T2 L_0 .. R_0 ..
+  __shared__ u32 s_dec[4][24];              // byte offsets of the decimal items in layout order: y z x x_ip x_ip(again) x_0 ..
+  __shared__ u32 s_pt[4][40];               // byte offsets of the point items: A S T1 T2 L_0 R_0 L_1 R_1 ..
+  __shared__ u32 s_fix[4][8];               // offsets of: start, len_rp, seed, len_1, seed1, len_2, '&', seed1 (again)
+  const u32 pw = threadIdx.x >> 4, lane = threadIdx.x & (V2_LPP - 1u);
+  const u32 g = blockIdx.x * 4u + pw;
+  const bool live = g < P;
+  const uint8_t *b = blobs + (live ? off[g] : 0ull);
+  const u64 n = live ? off[g + 1] - off[g] : 0ull;
   const u32 body = 6 + 32 * (5 + k) + 33 * (6 + 2 * k);
-  u32 out_len = 0;
-  bool ok = n >= body + 132ull && n <= RP_MAX_PROOF_BYTES && b[0] == 'B' && b[1] == 'P' && b[2] == 'R' && b[3] == 'P' && b[4] == '2' && b[5] == k;
+  bool ok = live && n >= body + 132ull && n <= RP_MAX_PROOF_BYTES && b[0] == 'B' && b[1] == 'P' && b[2] == 'R' && b[3] == 'P' && b[4] == '2' && b[5] == k;
   u32 sl = 0, sl1 = 0;
   if (ok) {
     sl = ((u32)b[body + 128] << 8) | b[body + 129];
     ok = n >= (u64)body + 132 + sl;
     if (ok) { sl1 = ((u32)b[body + 130 + sl] << 8) | b[body + 131 + sl]; ok = n == (u64)body + 132 + sl + sl1; }
   }
+  const uint8_t *sc = b + 6, *pts = sc + 32 * (5 + k), *ch = b + body, *seed = b + body + 130, *seed1 = seed + sl + 2;
+  const u32 nch = 4 + k, npt = 4 + 2 * k, nmeas = nch + npt;
+  auto chal = [&](u32 j) { return j < 4 ? ch + 32 * j : sc + 32 * (5 + (j - 4)); };                     // y z x x_ip x_0 ..
+  auto point = [&](u32 j) { return j == 0 ? pts + 66 : (j == 1 ? pts + 99 : (j == 2 ? pts : (j == 3 ? pts + 33 : pts + 33 * (6 + (j - 4))))); };      // A S T1 T2 L.. R..
+  if (ok)
+    for (u32 j = lane; j < nmeas; j += V2_LPP) s_len[pw][j] = j < nch ? dec_item_len(chal(j)) : (comp_is_identity(point(j - nch)) ? 5u : 45u);
+  __syncthreads();
+  const u32 *L = s_len[pw];
+  if (ok) for (u32 j = 0; j < nch; j++) ok = ok && L[j] != 0;                   // a challenge >= q
+  u32 out_len = 0, len_rp = 0, len_1 = 0, len_2 = 0;
+  const u32 b64s = 4 * ((sl + 2) / 3) + 1, b64s1 = 4 * ((sl1 + 2) / 3) + 1;
   if (ok) {
-    TWriter t;
-    t.base = T + g; t.stride = P; t.rows = W; t.pos = 0; t.cur = 0;
-    // the header and the scalar / point sections are the same bytes in both formats (but for the '1')
-    for (u32 i = 0; i < body; i++) tw_put(t, i == 4 ? (u32)'1' : (u32)b[i]);
-    const uint8_t *sc = b + 6, *pts = sc + 32 * (5 + k), *ch = b + body, *seed = b + body + 130, *seed1 = seed + sl + 2;
-    tw_put(t, 0); tw_put(t, 3);                                  // start_transcript
-    // range-proof transcript
-    u32 at = t.pos;
-    for (int i = 0; i < 4; i++) tw_put(t, 0);
-    tw_b64(t, seed, sl);
-    tw_point(t, pts + 66); tw_point(t, pts + 99);                // A, S
-    ok = tw_decimal(t, ch) && ok;                                // y
-    ok = tw_decimal(t, ch + 32) && ok;                           // z
-    tw_point(t, pts); tw_point(t, pts + 33);                     // T1, T2
-    ok = tw_decimal(t, ch + 64) && ok;                           // x
-    tw_patch_be32(t, at, t.pos - at - 4);
-    // Protocol 1
-    at = t.pos;
-    for (int i = 0; i < 4; i++) tw_put(t, 0);
-    tw_b64(t, seed1, sl1);
-    ok = tw_decimal(t, ch + 96) && ok;                           // x_ip
-    tw_patch_be32(t, at, t.pos - at - 4);
-    // Protocol 2: "&" + the Protocol-1 transcript, then L_i, R_i, x_i per round
-    at = t.pos;
-    for (int i = 0; i < 4; i++) tw_put(t, 0);
-    tw_put(t, '&');
-    tw_b64(t, seed1, sl1);
-    (void)tw_decimal(t, ch + 96);
-    for (u32 j = 0; j < k; j++) {
-      tw_point(t, pts + 33 * (6 + j));
-      tw_point(t, pts + 33 * (6 + k + j));
-      ok = tw_decimal(t, sc + 32 * (5 + j)) && ok;
-    }
-    tw_patch_be32(t, at, t.pos - at - 4);
-    tw_flush(t);
-    out_len = t.pos;
-    if (out_len > RP_MAX_PROOF_BYTES || (out_len + 7u) / 8u > W) ok = false;
+    len_rp = b64s + L[nch] + L[nch + 1] + L[0] + L[1] + L[nch + 2] + L[nch + 3] + L[2];
+    len_1 = b64s1 + L[3];
+    len_2 = 1 + len_1;
+    for (u32 j = 0; j < k; j++) len_2 += L[nch + 4 + j] + L[nch + 4 + k + j] + L[4 + j];
+    out_len = body + 2 + 12 + len_rp + len_1 + len_2;
+    ok = out_len <= RP_MAX_PROOF_BYTES && (out_len + 7u) / 8u <= W;
   }
-  lens[g] = ok ? out_len : 0u;
+  if (ok && lane == 0) {                                        // the layout, once per proof
+    u32 pos = body;
+    s_fix[pw][0] = pos; pos += 2;                               // start_transcript
+    s_fix[pw][1] = pos; pos += 4;                               // length of the range-proof transcript
+    s_fix[pw][2] = pos; pos += b64s;                            // seed
+    s_pt[pw][0] = pos; pos += L[nch];                           // A
+    s_pt[pw][1] = pos; pos += L[nch + 1];                       // S
+    s_dec[pw][0] = pos; pos += L[0];                            // y
+    s_dec[pw][1] = pos; pos += L[1];                            // z
+    s_pt[pw][2] = pos; pos += L[nch + 2];                       // T1
+    s_pt[pw][3] = pos; pos += L[nch + 3];                       // T2
+    s_dec[pw][2] = pos; pos += L[2];                            // x
+    s_fix[pw][3] = pos; pos += 4;
+    s_fix[pw][4] = pos; pos += b64s1;
+    s_dec[pw][3] = pos; pos += L[3];                            // x_ip
+    s_fix[pw][5] = pos; pos += 4;
+    s_fix[pw][6] = pos; pos += 1;
+    s_fix[pw][7] = pos; pos += b64s1;
+    s_dec[pw][4] = pos; pos += L[3];                            // x_ip again (Protocol 2 starts with the Protocol-1 transcript)
+    for (u32 j = 0; j < k; j++) {
+      s_pt[pw][4 + 2 * j] = pos; pos += L[nch + 4 + j];         // L_j
+      s_pt[pw][5 + 2 * j] = pos; pos += L[nch + 4 + k + j];     // R_j
+      s_dec[pw][5 + j] = pos; pos += L[4 + j];                  // x_j
+    }
+  }
+  __syncthreads();
+  if (ok) {
+    u64 *base = T + g;
+    // decimal items: y z x x_ip x_ip x_0 .. (5 + k of them), one per lane
+    for (u32 j = lane; j < 5 + k; j += V2_LPP) {
+      TWriter t = tw_at(base, P, W, s_dec[pw][j]);
+      tw_decimal(t, j < 4 ? chal(j) : (j == 4 ? chal(3) : chal(j - 1)));
+      tw_flush(t);
+    }
+    // point items: A S T1 T2 L_0 R_0 L_1 R_1 ..
+    for (u32 j = lane; j < npt; j += V2_LPP) {
+      const uint8_t *c = j < 4 ? point(j) : pts + 33 * (6 + ((j - 4) >> 1) + ((j - 4) & 1u) * k);
+      TWriter t = tw_at(base, P, W, s_pt[pw][j]);
+      tw_point(t, c);
+      tw_flush(t);
+    }
+    // the head (the same bytes in both formats but for the '1') in pieces of 64 bytes
+    for (u32 o = 64u * lane; o < body; o += 64u * V2_LPP) {
+      const u32 cnt = body - o < 64u ? body - o : 64u;
+      TWriter t = tw_at(base, P, W, o);
+      for (u32 i = 0; i < cnt; i++) tw_put(t, (o + i) == 4u ? (u32)'1' : (u32)b[o + i]);
+      tw_flush(t);
+    }
+    // the few fixed items, one lane each
+    if (lane == 1) { TWriter t = tw_at(base, P, W, s_fix[pw][0]); tw_put(t, 0); tw_put(t, 3); tw_be32(t, len_rp); tw_flush(t); }      // start | len_rp: adjacent
+    if (lane == 2) { TWriter t = tw_at(base, P, W, s_fix[pw][2]); tw_b64(t, seed, sl); tw_flush(t); }
+    if (lane == 3) { TWriter t = tw_at(base, P, W, s_fix[pw][3]); tw_be32(t, len_1); tw_flush(t); }
+    if (lane == 4) { TWriter t = tw_at(base, P, W, s_fix[pw][4]); tw_b64(t, seed1, sl1); tw_flush(t); }
+    if (lane == 5) { TWriter t = tw_at(base, P, W, s_fix[pw][5]); tw_be32(t, len_2); tw_put(t, '&'); tw_flush(t); }                   // len_2 | '&': adjacent
+    if (lane == 6) { TWriter t = tw_at(base, P, W, s_fix[pw][7]); tw_b64(t, seed1, sl1); tw_flush(t); }
+  }
+  if (live && lane == 0) lens[g] = ok ? out_len : 0u;
 }
 
 // shared[col] += sum over the P proofs of cell (col, .): the nine limb rows are summed as plain 64-bit integers (P < 2^22 loose
