@@ -168,6 +168,7 @@ int bpmi_set_option(bpmi_ctx *ctx, const char *name, int64_t value) {
   if (!strcmp(name, "fold_wnaf")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "fold_wnaf must be 0 or 1"); ctx->opt_fold_wnaf = (int)value; return BPMI_OK; }
   if (!strcmp(name, "reduce_epl")) { if (value < 0 || value > 64) return fail(ctx, BPMI_E_ARG, "reduce_epl must be 0..64"); ctx->opt_epl = (int)value; return BPMI_OK; }
   if (!strcmp(name, "chunk")) { if (value < 0 || value > 4096) return fail(ctx, BPMI_E_ARG, "chunk must be 0..4096"); ctx->opt_chunk = (int)value; return BPMI_OK; }
+  if (!strcmp(name, "ipa_small_step")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "ipa_small_step must be 0 or 1"); ctx->opt_ipa_step = (int)value; return BPMI_OK; }
   if (!strcmp(name, "fold_shared")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "fold_shared must be 0 or 1"); ctx->opt_fold_shared = (int)value; return BPMI_OK; }
   if (!strcmp(name, "ipa_small_m")) { if (value < 0 || (value & (value - 1))) return fail(ctx, BPMI_E_ARG, "ipa_small_m must be 0 (default), 1 (never) or a power of two"); ctx->opt_ipa_small = value; return BPMI_OK; }
   if (!strcmp(name, "ipa_big_m")) { if (value < 0 || (value & (value - 1))) return fail(ctx, BPMI_E_ARG, "ipa_big_m must be 0 or a power of two"); ctx->opt_ipa_big = value; return BPMI_OK; }
@@ -723,6 +724,7 @@ struct bpmi_ipa {
   void *block;          // one allocation
   std::vector<sc> hcg, hch;   // host copies of the coefficient tables while 2^d <= 16
   bool lr_done;
+  bool prep_ready;      // the scalars of the next L / R and c_L, c_R are on the device already (k_ipa_small_step did the next round's preparation)
 };
 
 // deferral policy: bases of 2^18 points or more are folded 16-way at once (an MSM over the
@@ -742,7 +744,7 @@ extern "C" {
 
 static int ipa_alloc(bpmi_ctx *ctx, uint64_t n, bpmi_ipa **out) {
   bpmi_ipa *st = new bpmi_ipa();
-  st->ctx = ctx; st->n0 = st->n = st->M = n; st->d = 0; st->cur = 0; st->lr_done = false;
+  st->ctx = ctx; st->n0 = st->n = st->M = n; st->d = 0; st->cur = 0; st->lr_done = false; st->prep_ready = false;
   st->big_m = ctx->opt_ipa_big > 0 ? (uint64_t)ctx->opt_ipa_big : IPA_BIG_M_DEFAULT;
   if (st->big_m < 32) st->big_m = 32;
   st->small_m = ctx->opt_ipa_small == 1 ? 0 : (ctx->opt_ipa_small > 1 ? (uint64_t)ctx->opt_ipa_small : IPA_SMALL_M_DEFAULT);
@@ -852,8 +854,10 @@ int bpmi_ipa_round_LR(bpmi_ipa *st, uint8_t L[64], uint8_t R[64]) {
   HIPCHK(ctx, hipSetDevice(ctx->device));
   const uint64_t np = st->n / 2;
   u32 *a_lo = st->a, *a_hi = st->a + 8 * np, *b_lo = st->b, *b_hi = st->b + 8 * np;
+  const bool prepared = st->prep_ready;          // k_ipa_small_step left c_L, c_R and the expanded scalars of this round on the device
+  st->prep_ready = false;
   // cl = <a_lo, b_hi>, cr = <a_hi, b_lo>  (inner_product_prover.py:96-97), kept on the device
-  {
+  if (!prepared) {
     DotJobs dj;
     dj.a[0] = a_lo; dj.b[0] = b_hi; dj.out[0] = st->cl;
     dj.a[1] = a_hi; dj.b[1] = b_lo; dj.out[1] = st->cr;
@@ -882,7 +886,7 @@ int bpmi_ipa_round_LR(bpmi_ipa *st, uint8_t L[64], uint8_t R[64]) {
     u32 logm = 0;
     while ((1ull << logm) < st->n) logm++;
     Segs sg[2];
-    {
+    if (!prepared) {
       StageTimer t(ctx, ST_SCFOLD);
       ExpandOut eo;
       eo.eg[0] = st->eg; eo.eh[0] = st->eh; eo.eg[1] = st->eg2; eo.eh[1] = st->eh2;
@@ -918,6 +922,32 @@ int bpmi_ipa_fold(bpmi_ipa *st, const uint8_t x[32], const uint8_t xinv[32]) {
   HIPCHK(ctx, hipSetDevice(ctx->device));
   const uint64_t np = st->n / 2;
   int rc;
+  st->prep_ready = false;
+  // short vectors: the fold of a and b, the coefficient tables AND the next round's c_L, c_R and expanded scalars in one launch
+  // (only where no generator fold can come any more: not above the ladder's threshold, not above the product fold's length)
+  const bool small_step = ctx->opt_ipa_step && st->M <= 4096 && st->M == st->n << st->d && st->M < st->big_m && !(st->small_m && st->M > st->small_m);
+  if (small_step) {
+    const u32 K = 1u << st->d;
+    IpaStep ps;
+    ps.a = st->a; ps.b = st->b;
+    ps.cg = st->cg[st->cur]; ps.ch = st->ch[st->cur]; ps.cg2 = st->cg[st->cur ^ 1]; ps.ch2 = st->ch[st->cur ^ 1];
+    memcpy(ps.x_xinv.k1, x, 32); memcpy(ps.x_xinv.k2, xinv, 32);
+    ps.np = (u32)np; ps.K = K; ps.M = (u32)st->M;
+    ps.hscale = st->hscale;
+    ps.cl = st->cl; ps.cr = st->cr;
+    ps.eg[0] = st->eg; ps.eh[0] = st->eh; ps.eg[1] = st->eg2; ps.eh[1] = st->eh2;
+    {
+      StageTimer t(ctx, ST_SCFOLD);
+      hipLaunchKernelGGL(k_ipa_small_step, dim3(1), dim3(1024), 0, ctx->stream, ps);
+    }
+    HIPCHK(ctx, hipGetLastError());
+    st->cur ^= 1;
+    st->d += 1;
+    st->n = np;
+    st->lr_done = false;
+    st->prep_ready = np >= 2;
+    return BPMI_OK;
+  }
   // a' = x a_lo + x^-1 a_hi ; b' = x^-1 b_lo + x b_hi  (:109-110)
   {
     FoldJobs fj;
@@ -1167,6 +1197,7 @@ int bpmi_ipa_export(bpmi_ipa *st, uint8_t *g, uint8_t *h, uint8_t *a, uint8_t *b
   }
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   if (m > IPA_EXPORT_MAX) return fail(ctx, BPMI_E_STATE, "ipa export with deferred folds needs a current length <= 64");
+  st->prep_ready = false;                 // the export's scalars go through the buffers a prepared round would read
   // deferred folds: every current generator is one MSM over the unfolded bases
   u32 logm = 0;
   while ((1ull << logm) < m) logm++;

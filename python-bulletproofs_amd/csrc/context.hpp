@@ -84,6 +84,9 @@ struct bpmi_ctx {
   bool async_lane1_ordered = false, async_lane2_ordered = false;
   int opt_split = 0;    // 1: one MSM as two window groups, one per lane (measured: +5 % at 2^20, -8 % at 2^19; off)
   int64_t opt_ipa_big = 0;   // base length from which the IPA folds generators 16-way (0 = default 2^18)
+  int opt_ipa_step = 0;      // short inner-product vectors: fold + coefficient tables + the next round's dots and scalars in ONE launch (k_ipa_small_step).
+                             // Measured (profiles/r04_C3_small_step_ab.txt): the one block takes 60 us where the four launches it replaces take 25 + gaps:
+                             // 25.1-25.3 ms per proof against 24.5.  OFF; kept with its tests (tools/fuzz_ops.py draws it)
   int opt_fold_shared = 1;   // the product fold of a state without per-generator scales: shared GLV halves, two terms per thread (0: per-lane products)
   int64_t opt_ipa_small = 0; // logical length at which smaller bases are folded through products (0 = default 4096, 1 = never)
   void *fold_tab = nullptr; size_t fold_tab_bytes = 0;     // tables + scratch of the width-4 NAF generator fold, allocated at the first fold, kept

@@ -79,6 +79,115 @@ __global__ void __launch_bounds__(256) k_sc_fold(FoldJobs jobs, u32 n) {
   store_words8(out + 8ull * i, t.v);
 }
 
+// ---- a late round of the inner-product argument between two challenges, ONE launch (round 4) ---------------------------------
+// For short vectors (the rounds behind the product fold, or a short argument from the start: M <= 4096 base points per side) the
+// four launches between a challenge and the next pair of MSMs -- a' / b' (k_sc_fold), the coefficient tables (k_ipa_coef_update),
+// c_L / c_R of the NEXT round (k_sc_dot), the expanded scalars of its L and R (k_ipa_expand) -- are one block of 1 024 threads
+// with three block barriers.  Same arithmetic, statement for statement, as the four kernels.  MEASURED AND OFF (option
+// "ipa_small_step"): the launches it saves cost ~10 us of a round, the single block's 8 192 expansions on ONE CU cost 60 us more
+// than the four kernels spread over the chip (profiles/r04_C3_small_step_ab.txt: 25.1-25.3 ms per 2^20 proof against 24.5).
+struct IpaStep {
+  u32 *a, *b;                       // n = 2 np elements each, folded in place to np
+  const u32 *cg, *ch;               // coefficient tables in (K entries) ...
+  u32 *cg2, *ch2;                   // ... and out (2 K)
+  Sc2 x_xinv;
+  u32 np, K, M;                     // M = np * 2 K: the unfolded bases per side
+  const u32 *hscale;                // or null
+  u32 *cl, *cr;                     // out: <a'_lo, b'_hi>, <a'_hi, b'_lo>   (np >= 2)
+  u32 *eg[2], *eh[2];               // out: the scalars of the next L (0) and R (1) over the M bases
+};
+__global__ void __launch_bounds__(1024) k_ipa_small_step(IpaStep p) {
+  __shared__ u32 sh[1024 * 8];
+  const u32 tid = threadIdx.x;
+  sc X, XI;
+#pragma unroll
+  for (int k = 0; k < 8; k++) { X.v[k] = p.x_xinv.k1[k]; XI.v[k] = p.x_xinv.k2[k]; }
+  // a' = x a_lo + x^-1 a_hi ; b' = x^-1 b_lo + x b_hi          (inner_product_prover.py:109-110)
+  for (u32 i = tid; i < 2u * p.np; i += 1024u) {
+    const bool isb = i >= p.np;
+    const u32 j = isb ? i - p.np : i;
+    u32 *v = isb ? p.b : p.a;
+    sc lo, hi, t, s2;
+    load_words8(lo.v, v + 8ull * j);
+    load_words8(hi.v, v + 8ull * (j + p.np));
+    sc_mul(t, isb ? XI : X, lo);
+    sc_mul(s2, isb ? X : XI, hi);
+    sc_add(t, t, s2);
+    store_words8(v + 8ull * j, t.v);
+  }
+  // g' = x^-1 g_lo + x g_hi ; h' = x h_lo + x^-1 h_hi  (:107-108), deferred: the coefficient tables double
+  for (u32 j = tid; j < 2u * p.K; j += 1024u) {
+    sc c, r;
+    load_words8(c.v, p.cg + 8ull * (j >> 1));
+    sc_mul(r, c, (j & 1u) ? X : XI);
+    store_words8(p.cg2 + 8ull * j, r.v);
+    load_words8(c.v, p.ch + 8ull * (j >> 1));
+    sc_mul(r, c, (j & 1u) ? XI : X);
+    store_words8(p.ch2 + 8ull * j, r.v);
+  }
+  __syncthreads();
+  if (p.np < 2u) return;                                  // the argument is down to one element: no next round
+  const u32 half = p.np >> 1;
+  // c_L = <a'_lo, b'_hi>, c_R = <a'_hi, b'_lo>  (:96-97): threads [0, 512) the first, [512, 1024) the second
+  {
+    const u32 job = tid >> 9, l = tid & 511u;
+    sc acc;
+#pragma unroll
+    for (int k = 0; k < 8; k++) acc.v[k] = 0;
+    for (u32 i = l; i < half; i += 512u) {
+      sc x, y, t;
+      load_words8(x.v, p.a + 8ull * (job ? half + i : i));
+      load_words8(y.v, p.b + 8ull * (job ? i : half + i));
+      sc_mul(t, x, y);
+      sc_add(acc, acc, t);
+    }
+    for (u32 d = 256; d > 0; d >>= 1) {
+#pragma unroll
+      for (int k = 0; k < 8; k++) sh[tid * 8 + k] = acc.v[k];
+      __syncthreads();
+      if (l < d) {
+        sc o;
+#pragma unroll
+        for (int k = 0; k < 8; k++) o.v[k] = sh[(tid + d) * 8 + k];
+        sc_add(acc, acc, o);
+      }
+      __syncthreads();
+    }
+    if (l == 0) store_words8(job ? p.cr : p.cl, acc.v);
+  }
+  // the scalars of the next L and R over the unfolded bases (k_ipa_expand with the new tables and the new length)
+  u32 logm = 0;
+  while ((1u << logm) < p.np) logm++;
+  const u32 m = p.np;
+  for (u32 idx = tid; idx < 2u * p.M; idx += 1024u) {
+    const u32 right = idx >= p.M ? 1u : 0u, k = right ? idx - p.M : idx;
+    const u32 i = k & (m - 1u), t = k >> logm;
+    const bool hi = i >= half;
+    sc z;
+#pragma unroll
+    for (int q = 0; q < 8; q++) z.v[q] = 0;
+    sc rg = z, rh = z;
+    if (hi != (right != 0u)) {
+      sc av, c;
+      load_words8(av.v, p.a + 8ull * (right ? half + i : i - half));
+      load_words8(c.v, p.cg2 + 8ull * t);
+      sc_mul(rg, av, c);
+    }
+    if (hi == (right != 0u)) {
+      sc bv, c;
+      load_words8(bv.v, p.b + 8ull * (right ? i - half : half + i));
+      load_words8(c.v, p.ch2 + 8ull * t);
+      sc_mul(rh, bv, c);
+      if (p.hscale) {
+        load_words8(c.v, p.hscale + 8ull * k);
+        sc_mul(rh, rh, c);
+      }
+    }
+    store_words8(p.eg[right] + 8ull * k, rg.v);
+    store_words8(p.eh[right] + 8ull * k, rh.v);
+  }
+}
+
 // The verifier's s-vector with the proof's final scalars folded in (Verifier2.get_ss,
 // /root/reference/src/innerproduct/inner_product_verifier.py:91-102, and the `a * s_i`, `b / s_i` lists of :131-133):
 //   s_i = prod_j x_j^(+1 if bit (k-1-j) of i is set else -1),  sa[i] = a s_i,  sb[i] = b s_i^-1 (c_i)

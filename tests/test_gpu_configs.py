@@ -172,9 +172,35 @@ def test_c3_ipa_prover_2e20(gp):
         pack([v * xi1 for v in ahi]) + pack([v * x1 for v in ahi]) + pack([v * x1 for v in blo]) + pack([v * xi1 for v in blo]) + cr2,
         4 * q4 + 1)
     assert L2 == wantL and R2 == wantR
-    # ---- middle rounds with the real transcript; the last two rounds against the oracle on the exported state
+    # ---- middle rounds with the real transcript.  a and b are folded alongside by the C oracle, and the rounds AROUND THE SECOND
+    # (product) FOLD -- length 8192 just before it, 4096 right behind it, 2048 (the first round whose c_L, c_R and scalars come from
+    # the one-launch step) -- are checked like round 2: the logical generators are linear in the ORIGINAL ones, g'[j] = sum_t cg[t]
+    # G[j + t m] with the coefficient tables doubled per round (newest fold = lowest bit of t), so L and R are MSMs over all 2^20
+    # original points with Python-integer scalars
+    ak, bk = a2, b2                                          # the vectors entering round 2
+    cg, ch = [xi1, x1], [x1, xi1]                            # g' = xi g_lo + x g_hi ; h' = x h_lo + xi h_hi   (t = 0: lo, 1: hi)
+    xk, xik = x2, xi2
+    G_pts, H_pts = g, h
     while len(st) > 4:
-        one_round()
+        m = len(st)                                          # ak, bk have 2 m elements and are folded with (xk, xik) to m
+        ak = cbind.sc_fold_bytes(sc(ak, 0, m), sc(ak, m, 2 * m), xk, xik, m)
+        bk = cbind.sc_fold_bytes(sc(bk, 0, m), sc(bk, m, 2 * m), xik, xk, m)
+        cg = [c * f % Q for c in cg for f in (xik, xk)]
+        ch = [c * f % Q for c in ch for f in (xk, xik)]
+        Lb, Rb, xk, xik = one_round()
+        if m in (8192, 4096, 2048):
+            hm = m // 2
+            alo, ahi, blo, bhi = ints(sc(ak, 0, hm)), ints(sc(ak, hm, m)), ints(sc(bk, 0, hm)), ints(sc(bk, hm, m))
+            clm = cbind.sc_dot_bytes(sc(ak, 0, hm), sc(bk, hm, m), hm)
+            crm = cbind.sc_dot_bytes(sc(ak, hm, m), sc(bk, 0, hm), hm)
+            T = len(cg)
+            assert T * m == n
+            ptsL = b"".join(pt(G_pts, t * m + hm, t * m + m) for t in range(T)) + b"".join(pt(H_pts, t * m, t * m + hm) for t in range(T)) + u
+            scL = b"".join(pack([v * cg[t] for v in alo]) for t in range(T)) + b"".join(pack([v * ch[t] for v in bhi]) for t in range(T)) + clm
+            ptsR = b"".join(pt(G_pts, t * m, t * m + hm) for t in range(T)) + b"".join(pt(H_pts, t * m + hm, t * m + m) for t in range(T)) + u
+            scR = b"".join(pack([v * cg[t] for v in ahi]) for t in range(T)) + b"".join(pack([v * ch[t] for v in blo]) for t in range(T)) + crm
+            assert Lb == cbind.msm_bytes(ptsL, scL, n + 1), "L at length %d" % m
+            assert Rb == cbind.msm_bytes(ptsR, scR, n + 1), "R at length %d" % m
     for m in (4, 2):
         ge, he, ae, be = st.export()
         assert len(st) == m

@@ -182,6 +182,39 @@ def test_product_fold_shared_scalars_equals_per_lane_products(gp, n, small_m):
     assert runs[0] == runs[1]
 
 
+@pytest.mark.parametrize("n,scaled", [(4096, False), (512, False), (2048, True), (2, False)])
+def test_one_launch_step_for_short_vectors_equals_the_four_kernels(gp, n, scaled):
+    """Option ipa_small_step (off by default: measured slower): fold of a and b, the coefficient tables and the NEXT round's c_L,
+    c_R and expanded scalars in one launch must give the rounds the four separate kernels give, with and without a per-generator
+    scale, and an export in between must not disturb it."""
+    eng = gp.engine()
+    pts, _ = gp.rand_points(2 * n + 1, 444)
+    rnd = random.Random(n + 9)
+    gb, hb, ub = cbind.pack_points(pts[:n]), cbind.pack_points(pts[n:2 * n]), cbind.pack_points([pts[2 * n]])
+    ab = cbind.pack_scalars([rnd.randrange(Q) for _ in range(n)]), cbind.pack_scalars([rnd.randrange(Q) for _ in range(n)])
+    hsc = cbind.pack_scalars([rnd.randrange(1, Q) for _ in range(n)]) if scaled else None
+    xs = [rnd.randrange(1, Q) for _ in range(n.bit_length())]
+    runs = []
+    try:
+        for step in (1, 0):
+            eng.set_option("ipa_small_step", step)
+            st = eng.ipa_create(gb, hb, ab[0], ab[1], n, ub, hsc)
+            trace = []
+            for x in xs:
+                if len(st) <= 1:
+                    break
+                trace.append(st.round_LR())
+                st.fold(x, pow(x, -1, Q))
+                if len(st) in (8, 2):
+                    trace.append(st.export())
+            trace.append(st.finish())
+            st.close()
+            runs.append(trace)
+    finally:
+        eng.set_option("ipa_small_step", 0)
+    assert runs[0] == runs[1]
+
+
 def test_ipa_full_size_round_trip(gp):
     """Size-independent property at a size the oracle cannot reach in seconds: a proof
     produced by FastNIProver2 at n = 2^16 (deferred folding, 32 MSMs) must be accepted by
