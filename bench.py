@@ -53,8 +53,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 ALGO_BYTES_PER_PAIR = 96       # 32-B scalar + 64-B affine point
 IPA_ALGO_BYTES_PER_ELEMENT = 960   # whole proof, per element of the n-vector
 # multiply-add content of one bucket update (xyzz_madd, csrc/curve.hpp): v_mad_u64_u32 per wave-lane, counted in
-# the ISA of k_accum_l0 (profiles/r03_isa_counts.json); and the chip's raw rate for that instruction
-MADS_PER_MADD = None           # filled from profiles/r02_isa_counts.json when present
+# the ISA of k_accum_l0 (profiles/r04_isa_counts.json); and the chip's raw rate for that instruction
+MADS_PER_MADD = None           # filled from profiles/r04_isa_counts.json when present
 RAW_MAD_TOPS = 28.85           # T lane-ops/s, tools/fe_microbench.hip (profiles/r01_fe_microbench.txt)
 MULS_PER_MADD = 10.5           # 8M + 2S plus carries/subtractions in multiplication-equivalents
 FE_MUL_PEAK_G = 221.4          # the product's own fe_mul in isolation, G multiplications/s (profiles/r03_fe_microbench.txt, V8; round 1's fe_mul: 196)
@@ -473,7 +473,7 @@ def main():
             "frac_vs_raw_mad_kernel_alone": (madds_per_launch * mads / alone_s / 1e12 / RAW_MAD_TOPS) if alone_s > 0 else None})
         out["alu_roofline"]["raw_mad"] = {"achieved_T_lane_ops": lane_mads, "peak_T_lane_ops": RAW_MAD_TOPS,
                                           "mads_per_madd": mads, "instructions_per_madd": isa["instructions_per_madd"],
-                                          "source": "profiles/r03_isa_counts.json (ISA of k_accum_l0's main path), "
+                                          "source": "profiles/r04_isa_counts.json (ISA of k_accum_l0's main path), "
                                                     "profiles/r01_fe_microbench.txt (raw v_mad_u64_u32 rate)"}
 
     usable = usable_cpus()
@@ -542,7 +542,7 @@ def main():
 
 def isa_counts():
     try:
-        for name in ("r03_isa_counts.json", "r02_isa_counts.json"):
+        for name in ("r04_isa_counts.json", "r03_isa_counts.json", "r02_isa_counts.json"):
             path = os.path.join(REPO, "profiles", name)
             if os.path.exists(path):
                 with open(path) as f:
@@ -554,7 +554,7 @@ def isa_counts():
 
 def committed_traffic(logn):
     """Per-launch HBM bytes of the dominant kernel from the committed rocprofv3 --pmc passes (NOT measured in this run)."""
-    for name in ("r03_pmc_traffic_msm_n2e20.json", "r02_pmc_traffic_msm_n2e20.json", "r01_pmc_traffic_msm_n2e20.json"):
+    for name in ("r04_pmc_traffic_msm_n2e20.json", "r03_pmc_traffic_msm_n2e20.json", "r02_pmc_traffic_msm_n2e20.json", "r01_pmc_traffic_msm_n2e20.json"):
         try:
             with open(os.path.join(REPO, "profiles", name)) as f:
                 for row in json.load(f)["kernels"]:

@@ -6,9 +6,9 @@ on operands it loads from memory; every instruction of that kernel is tallied by
 separately).
 
     python tools/isa_counts.py                       # prints the JSON object
-    python tools/isa_counts.py --write               # also writes profiles/r03_isa_counts.json and the ISA excerpt
+    python tools/isa_counts.py --write               # also writes profiles/r04_isa_counts.json and the ISA excerpt
 
-bench.py reads profiles/r03_isa_counts.json for `alu_roofline.frac_vs_raw_mad` (multiply-adds actually issued per
+bench.py reads profiles/r04_isa_counts.json for `alu_roofline.frac_vs_raw_mad` (multiply-adds actually issued per
 second against the chip's raw v_mad_u64_u32 rate)."""
 import collections
 import json
@@ -59,9 +59,9 @@ def main():
         "round_1_for_comparison": {"instructions_per_madd": 1953, "v_mad_u64_u32_per_madd": 942, "note": "same span measured on the round-1 code (commit c7275e6)"}}}
     print(json.dumps(out, indent=1))
     if "--write" in sys.argv:
-        with open(os.path.join(REPO, "profiles", "r03_isa_counts.json"), "w") as f:
+        with open(os.path.join(REPO, "profiles", "r04_isa_counts.json"), "w") as f:
             json.dump(out, f, indent=1)
-        with open(os.path.join(REPO, "profiles", "r03_isa_k_isa_probe_madd.s"), "w") as f:
+        with open(os.path.join(REPO, "profiles", "r04_isa_k_isa_probe_madd.s"), "w") as f:
             f.write(probe + "\n")
 
 
