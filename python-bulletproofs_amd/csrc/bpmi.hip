@@ -165,7 +165,7 @@ int bpmi_set_option(bpmi_ctx *ctx, const char *name, int64_t value) {
     ctx->opt_rp_lanes = (int)value;
     return BPMI_OK;
   }
-  if (!strcmp(name, "fold_wnaf")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "fold_wnaf must be 0 or 1"); ctx->opt_fold_wnaf = (int)value; return BPMI_OK; }
+  if (!strcmp(name, "fold_wnaf")) { if (value < 0 || value > 2) return fail(ctx, BPMI_E_ARG, "fold_wnaf must be 0, 1 or 2"); ctx->opt_fold_wnaf = (int)value; return BPMI_OK; }
   if (!strcmp(name, "reduce_epl")) { if (value < 0 || value > 64) return fail(ctx, BPMI_E_ARG, "reduce_epl must be 0..64"); ctx->opt_epl = (int)value; return BPMI_OK; }
   if (!strcmp(name, "chunk")) { if (value < 0 || value > 4096) return fail(ctx, BPMI_E_ARG, "chunk must be 0..4096"); ctx->opt_chunk = (int)value; return BPMI_OK; }
   if (!strcmp(name, "ipa_small_step")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "ipa_small_step must be 0 or 1"); ctx->opt_ipa_step = (int)value; return BPMI_OK; }
@@ -995,10 +995,11 @@ int bpmi_ipa_fold(bpmi_ipa *st, const uint8_t x[32], const uint8_t xinv[32]) {
     // folded or not); if they do not fit the fold uses the plain NAF ladder
     void *wtab = nullptr;
     const uint64_t nthr = (npts + ODDMUL_PER_THREAD - 1) / ODDMUL_PER_THREAD;
+    const bool glv = ctx->opt_fold_wnaf >= 2 && st->n % 64 == 0;          // k_ec_multifold_w4g reads its digits per WAVE: a wave must not straddle g and h
     const size_t tab_bytes = align_up(3ull * npts * 72, 256), scr_bytes = align_up(2ull * nthr * ODDMUL_PER_THREAD * 3 * 144, 256),
-                 wn_bytes = align_up(sizeof(WnafK), 256);
+                 wn_bytes = align_up(glv ? sizeof(WnafG) : sizeof(WnafK), 256), tabx_bytes = glv ? align_up(4ull * npts * 36, 256) : 0;
     if (ctx->opt_fold_wnaf && npts >= 256) {
-      const size_t need = 2 * tab_bytes + scr_bytes + 2 * wn_bytes;
+      const size_t need = 2 * tab_bytes + scr_bytes + 2 * wn_bytes + 2 * tabx_bytes;
       if (need > ctx->fold_tab_bytes) {
         if (ctx->fold_tab) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->fold_tab); ctx->fold_tab = nullptr; ctx->fold_tab_bytes = 0; }
         if (hipMalloc(&ctx->fold_tab, need) == hipSuccess) ctx->fold_tab_bytes = need; else { (void)hipGetLastError(); ctx->fold_tab = nullptr; }
@@ -1006,9 +1007,54 @@ int bpmi_ipa_fold(bpmi_ipa *st, const uint8_t x[32], const uint8_t xinv[32]) {
       wtab = ctx->fold_tab;
     }
     if (wtab) {
-      {
-        u32 *tab_a = (u32 *)wtab, *tab_b = (u32 *)((char *)wtab + tab_bytes), *scr = (u32 *)((char *)wtab + 2 * tab_bytes);
-        WnafK *dwa = (WnafK *)((char *)wtab + 2 * tab_bytes + scr_bytes), *dwb = (WnafK *)((char *)dwa + wn_bytes);
+      u32 *tab_a = (u32 *)wtab, *tab_b = (u32 *)((char *)wtab + tab_bytes), *scr = (u32 *)((char *)wtab + 2 * tab_bytes);
+      char *dw = (char *)wtab + 2 * tab_bytes + scr_bytes;
+      u32 *tabx_a = (u32 *)(dw + 2 * wn_bytes), *tabx_b = (u32 *)(dw + 2 * wn_bytes + tabx_bytes);
+      if (glv) {
+        // the coefficients in two 128-bit halves each (k = k1 + k2 lambda): row 2 t + half, a negative half with its digits negated
+        static thread_local WnafG hga, hgb;
+        for (int side = 0; side < 2; side++) {
+          WnafG &hw = side ? hgb : hga;
+          static thread_local signed char dg[2 * MULTIFOLD_MAXK][136];
+          int top = -1;
+          for (u32 t = 0; t < K2; t++) {
+            u32 k1[4], k2[4];
+            bool n1, n2;
+            glv_split(k1, n1, k2, n2, side ? st->hch[t] : st->hcg[t]);
+            for (int hf = 0; hf < 2; hf++) {
+              uint8_t k32[32] = {0};
+              memcpy(k32, hf ? k2 : k1, 16);
+              signed char *row = dg[2 * t + hf];
+              host_wnaf4(k32, row, top, 136);
+              if (hf ? n2 : n1) for (int q = 0; q < 136; q++) row[q] = (signed char)-row[q];
+            }
+          }
+          hw.nops = 0;
+          u32 ndbl = 0;                                        // nothing to double before the first addition
+          for (int pos = top; pos >= 0; pos--) {
+            for (u32 r = 0; r < 2 * K2; r++) {
+              const int d = dg[r][pos];
+              if (!d) continue;
+              if (hw.nops >= WNAFG_MAXOPS) return fail(ctx, BPMI_E_STATE, "fold: operation list overflow");   // (cannot happen: at most one digit in four positions, 32 x 34 < 2048)
+              const u32 mag = (u32)(d < 0 ? -d : d);
+              hw.op[hw.nops++] = ndbl | (r << 8) | ((mag >> 1) << 13) | ((d < 0 ? 1u : 0u) << 16);
+              ndbl = 0;
+            }
+            if (hw.nops) ndbl++;                               // the doubling that moves on to position pos - 1
+          }
+          hw.tail = hw.nops ? ndbl - 1u : 0u;                  // (the last position has no doubling after it)
+        }
+        HIPCHK(ctx, h2d(ctx, dw, &hga, sizeof(WnafG), ctx->stream));
+        HIPCHK(ctx, h2d(ctx, dw + wn_bytes, &hgb, sizeof(WnafG), ctx->stream));
+        {
+          StageTimer t(ctx, ST_LINCOMB2);
+          hipLaunchKernelGGL(k_ec_odd_multiples<ODDMUL_PER_THREAD>, dim3((u32)((2 * nthr + 255) / 256)), dim3(256), 0, ctx->stream, st->g, st->h, (u32)npts, tab_a, tab_b, scr,
+                             tabx_a, tabx_b);
+          hipLaunchKernelGGL(k_ec_multifold_w4g, dim3((u32)((2 * st->n + 255) / 256)), dim3(256), 0, ctx->stream, ja, jb, tab_a, tab_b, tabx_a, tabx_b,
+                             (const WnafG *)dw, (const WnafG *)(dw + wn_bytes), (u32)st->n, K2);
+        }
+      } else {
+        WnafK *dwa = (WnafK *)dw, *dwb = (WnafK *)(dw + wn_bytes);
         static thread_local WnafK hwa, hwb;
         memset(&hwa, 0, sizeof(hwa)); memset(&hwb, 0, sizeof(hwb));
         hwa.top = hwb.top = -1;
@@ -1020,13 +1066,14 @@ int bpmi_ipa_fold(bpmi_ipa *st, const uint8_t x[32], const uint8_t xinv[32]) {
         HIPCHK(ctx, h2d(ctx, dwb, &hwb, sizeof(WnafK), ctx->stream));
         {
           StageTimer t(ctx, ST_LINCOMB2);
-          hipLaunchKernelGGL(k_ec_odd_multiples<ODDMUL_PER_THREAD>, dim3((u32)((2 * nthr + 255) / 256)), dim3(256), 0, ctx->stream, st->g, st->h, (u32)npts, tab_a, tab_b, scr);
+          hipLaunchKernelGGL(k_ec_odd_multiples<ODDMUL_PER_THREAD>, dim3((u32)((2 * nthr + 255) / 256)), dim3(256), 0, ctx->stream, st->g, st->h, (u32)npts, tab_a, tab_b, scr,
+                             (u32 *)nullptr, (u32 *)nullptr);
           hipLaunchKernelGGL(k_ec_multifold_w4, dim3((u32)((2 * st->n + 255) / 256)), dim3(256), 0, ctx->stream, ja, jb, tab_a, tab_b, dwa, dwb,
                              (u32)st->n, K2);
         }
-        HIPCHK(ctx, hipGetLastError());
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));     // the host digit tables are thread-local statics
       }
+      HIPCHK(ctx, hipGetLastError());
+      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));     // the host digit tables are thread-local statics
     }
     if (!wtab) {
       NafK ha, hb;

@@ -65,7 +65,7 @@ struct bpmi_ctx {
   int opt_mulb = 1;     // bpmi_ec_mul_batch: 1 = GLV + fixed signed windows over affine odd multiples (n >= MULB_MIN_N), 0 = the bit-serial ladder
   int opt_chunk = 0;    // entries per thread in k_accum_l0, 0 = auto
   int opt_small = 0;    // largest n handled by the one-launch small-MSM kernel (0 = default, -1 = never)
-  int opt_fold_wnaf = 1;     // the IPA's 16-way generator fold: width-4 NAF over affine tables of odd multiples (0: plain NAF ladder)
+  int opt_fold_wnaf = 2;     // the IPA's 16-way generator fold: 2 = width-4 NAF of the coefficients' GLV halves over affine tables of odd multiples, 1 = of the whole coefficients, 0 = plain NAF ladder
   int opt_rp_only_role = -1; // profiling only: run one role of the batch preparation kernel (the call then reports proof 0 as bad)
   int opt_glv = 0;           // MSM on GLV-split scalars (an experiment that lost, profiles/r03_glv_msm_on_off.txt): 0 / -1 = never (default), 1 = whenever the bucket pipeline runs
   int opt_rp_overlap = 1;    // batch preparation: point decoding on the second lane beside the preparation kernels (0: behind them; measurements)

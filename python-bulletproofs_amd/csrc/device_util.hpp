@@ -92,6 +92,12 @@ __device__ __forceinline__ void load_affine(affine &P, const u32 *p) {
   load_words16(w, p);
   affine_from_words(P, w);
 }
+__device__ __forceinline__ void load_affine_y(fe &y, const u32 *p) {    // the y half of a 64-byte wire point
+  const uint4 *q = reinterpret_cast<const uint4 *>(p);
+  const uint4 a = q[2], b = q[3];
+  const u32 w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  fe_from_words(y, w);
+}
 __device__ __forceinline__ void xyzz_load_g(xyzz &a, const u32 *p) {   // 144 B, 16-B aligned
   u32 w[XYZZ_WORDS];
   const uint4 *q = reinterpret_cast<const uint4 *>(p);

@@ -455,8 +455,11 @@ __global__ void __launch_bounds__(256, 3) k_ec_multifold(MultifoldJob ja, Multif
 //   scratch: 4 x 9 limbs (X, Y, Z, prefix) per (point, j), column-major per thread
 #define ODDMUL_PER_THREAD 16        // the fold: 2^21 points, 131 072 threads
 #define ODDMUL_PER_THREAD_MULB 4    // k_ec_mul_batch_glv's slices of 196 608 points: 49 152 threads (16 per thread left most SIMDs idle)
+//   tabx (optional, the GLV ladder k_ec_multifold_w4g): beta x of P, 3P, 5P, 7P -- the x of lambda (jP) = (beta x, y) -- entry j
+//   (0: P .. 3: 7P) of point k at tabx + ((j * npts) + k) * 9 limbs
 template <int PER> __global__ void __launch_bounds__(256, 3) k_ec_odd_multiples(const u32 *__restrict__ base_a, const u32 *__restrict__ base_b, u32 npts,
-                                                            u32 *__restrict__ tab_a, u32 *__restrict__ tab_b, u32 *__restrict__ scratch) {
+                                                            u32 *__restrict__ tab_a, u32 *__restrict__ tab_b, u32 *__restrict__ scratch,
+                                                            u32 *__restrict__ tabx_a = nullptr, u32 *__restrict__ tabx_b = nullptr) {
   const u32 nthreads_per = (npts + PER - 1) / PER;
   u32 tid = blockIdx.x * blockDim.x + threadIdx.x;
   const bool second = tid >= nthreads_per;
@@ -464,6 +467,7 @@ template <int PER> __global__ void __launch_bounds__(256, 3) k_ec_odd_multiples(
   if (tid >= nthreads_per || (second && !base_b)) return;              // base_b == nullptr: one array only (k_ec_mul_batch_glv)
   const u32 *base = second ? base_b : base_a;
   u32 *tab = second ? tab_b : tab_a;
+  u32 *tabx = second ? tabx_b : tabx_a;
   const u32 col = (second ? nthreads_per : 0u) + tid;                 // scratch column of this thread
   const u32 ncols = 2u * nthreads_per;
   auto rec = [&](u32 e) { return scratch + ((u64)e * ncols + col) * 36u; };      // e = r * 3 + j
@@ -474,6 +478,12 @@ template <int PER> __global__ void __launch_bounds__(256, 3) k_ec_odd_multiples(
     affine P;
     if (k < npts) load_affine(P, base + 16ull * k); else { fe_set_zero(P.x); fe_set_zero(P.y); }
     const bool inf = affine_is_inf(P);
+    if (tabx && k < npts) {
+      fe bx;
+      fe_mul_beta(bx, P.x); fe_carry(bx, bx);
+#pragma unroll
+      for (int l = 0; l < 9; l++) tabx[(u64)k * 9u + l] = bx.v[l];
+    }
     jac two, m[3];
     if (!inf) {
       jac one; one.X = P.x; one.Y = P.y; fe_set_one(one.Z);
@@ -512,17 +522,24 @@ template <int PER> __global__ void __launch_bounds__(256, 3) k_ec_odd_multiples(
       u32 *o = tab + ((u64)j * npts + k) * 18u;
 #pragma unroll
       for (int l = 0; l < 9; l++) { o[l] = x.v[l]; o[9 + l] = y.v[l]; }   // the identity gives X = Y = 0 -> (0, 0)
+      if (tabx) {
+        fe bx;
+        fe_mul_beta(bx, x); fe_carry(bx, bx);
+        u32 *ox = tabx + ((u64)(j + 1u) * npts + k) * 9u;
+#pragma unroll
+        for (int l = 0; l < 9; l++) ox[l] = bx.v[l];
+      }
     }
   }
 }
 // digits of the K (<= 16) shared scalars, width-4 NAF: dg[t][pos] in {0, +-1, +-3, +-5, +-7}, pos <= top
 struct WnafK { signed char dg[MULTIFOLD_MAXK][264]; int top; };
-static void host_wnaf4(const uint8_t k32[32], signed char dg[264], int &top) {
+static void host_wnaf4(const uint8_t k32[32], signed char *dg, int &top, int len = 264) {
   u32 w[9];
   memcpy(w, k32, 32);
   w[8] = 0;
-  memset(dg, 0, 264);
-  for (int pos = 0; pos < 260; pos++) {
+  memset(dg, 0, (size_t)len);
+  for (int pos = 0; pos < len - 4; pos++) {
     if (w[0] & 1u) {
       int d = (int)(w[0] & 15u);                     // k mod 16
       if (d > 8) d -= 16;                            // odd digit in [-7, 7]
@@ -569,6 +586,74 @@ __global__ void __launch_bounds__(256, 3) k_ec_multifold_w4(MultifoldJob ja, Mul
       xyzz_madd_signed(acc, P, d < 0);
     }
   }
+  affine r;
+  xyzz_to_affine(r, acc);
+  u32 w16[16];
+  affine_to_words(w16, r);
+  store_words16(out + 16ull * i, w16);
+}
+
+// ---- ... and with the coefficients split in two (round 4) -------------------------------------------------------------------
+// k = k1 + k2 lambda (scalar.hpp glv_split), lambda (x, y) = (beta x, y): the 16 coefficients become 32 half-scalars of 128 bits,
+// the ladder 129 doublings instead of 257 with the same ~816 additions -- 8 370 reductions per output instead of 9 392.  The x of
+// lambda (jP) comes from k_ec_odd_multiples' beta-x table (a multiplication per addition would give half of the saving back);
+// a negative half has its digits' signs flipped on the host.
+// The ladder as a flat list of operations, built on the host (the digits are the same for every output): "double n times, then
+// add (-)(j-th odd multiple) of (lambda?) point row / 2".  The kernel fetches the point of operation q + 1 before it computes
+// operation q: 2^17 outputs are 2 048 waves -- two per SIMD, too few to hide a load behind the other waves' arithmetic.
+//   op = n_dbl | row << 8 | j << 13 | neg << 16          tail = doublings after the last addition
+#define WNAFG_MAXOPS 2048
+struct WnafG { u32 nops, tail; u32 op[WNAFG_MAXOPS]; };
+__device__ __forceinline__ void multifold_fetch(affine &P, u32 op, u32 i, u32 m, u32 npts, const u32 *base, const u32 *tab, const u32 *tabx) {
+  const u32 r = (op >> 8) & 31u, j = (op >> 13) & 7u, k = i + (r >> 1) * m;      // j = 0: P, 1: 3P, 2: 5P, 3: 7P
+  const bool lam = (r & 1u) != 0u;                                               // wave-uniform: the half that multiplies lambda (jP)
+  if (j == 0u) {
+    if (lam) load_affine_y(P.y, base + 16ull * k); else load_affine(P, base + 16ull * k);
+  } else {
+    const u32 *q = tab + ((u64)(j - 1u) * npts + k) * 18u;
+#pragma unroll
+    for (int l = 0; l < 9; l++) P.y.v[l] = q[9 + l];
+    if (!lam) {
+#pragma unroll
+      for (int l = 0; l < 9; l++) P.x.v[l] = q[l];
+    }
+  }
+  if (lam) {
+    const u32 *qx = tabx + ((u64)j * npts + k) * 9u;
+#pragma unroll
+    for (int l = 0; l < 9; l++) P.x.v[l] = qx[l];
+  }
+}
+__global__ void __launch_bounds__(256, 2) k_ec_multifold_w4g(MultifoldJob ja, MultifoldJob jb, const u32 *__restrict__ tab_a, const u32 *__restrict__ tab_b,
+                                                             const u32 *__restrict__ tabx_a, const u32 *__restrict__ tabx_b,
+                                                             const WnafG *__restrict__ wa, const WnafG *__restrict__ wb, u32 m, u32 K) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool second = i >= m;
+  if (second) i -= m;
+  if (i >= m) return;
+  const u32 *base = second ? jb.base : ja.base;
+  const u32 *tab = second ? tab_b : tab_a;
+  const u32 *tabx = second ? tabx_b : tabx_a;
+  u32 *out = second ? jb.out : ja.out;
+  const WnafG *nf = second ? wb : wa;
+  const u32 npts = m * K;
+  const u32 nops = __builtin_amdgcn_readfirstlane(nf->nops);
+  xyzz acc;
+  xyzz_set_inf(acc);
+  affine Pn;
+  u32 opn = 0;
+  if (nops) { opn = __builtin_amdgcn_readfirstlane(nf->op[0]); multifold_fetch(Pn, opn, i, m, npts, base, tab, tabx); }
+#pragma unroll 1
+  for (u32 q = 0; q < nops; q++) {
+    const affine P = Pn;
+    const u32 op = opn;
+    if (q + 1u < nops) { opn = __builtin_amdgcn_readfirstlane(nf->op[q + 1u]); multifold_fetch(Pn, opn, i, m, npts, base, tab, tabx); }
+#pragma unroll 1
+    for (u32 t = op & 255u; t; t--) xyzz_dbl(acc, acc);
+    xyzz_madd_signed(acc, P, ((op >> 16) & 1u) != 0u);
+  }
+#pragma unroll 1
+  for (u32 t = __builtin_amdgcn_readfirstlane(nf->tail); t; t--) xyzz_dbl(acc, acc);
   affine r;
   xyzz_to_affine(r, acc);
   u32 w16[16];

@@ -144,6 +144,43 @@ def test_ipa_rounds_vs_oracle(gp, n, big_m, small_m):
     eng.set_option("ipa_small_m", 0)
 
 
+@pytest.mark.parametrize("n,big_m", [(512, 256), (4096, 256), (1 << 13, 1 << 13)])
+def test_sixteen_way_generator_fold_three_ladders_one_result(gp, n, big_m):
+    """The 16-way fold of the generators behind four deferred rounds, three ways (ctx option fold_wnaf): 2 = width-4 NAF of the
+    coefficients' GLV halves over the tables of odd multiples and their beta-x twins (k_ec_multifold_w4g, the default), 1 = width-4
+    NAF of the whole coefficients (k_ec_multifold_w4), 0 = the plain NAF ladder (k_ec_multifold).  Same L, R in every round, same
+    exported generators, and test_ipa_rounds_vs_oracle pins the default against the oracle."""
+    eng = gp.engine()
+    eng.set_option("ipa_big_m", big_m)
+    eng.set_option("ipa_small_m", 1)
+    pts, _ = gp.rand_points(2 * n + 1, 77 + n)
+    # identities among the generators: a table entry (0, 0) and its beta-x twin must both read as the identity
+    pts[3] = cbind.INF
+    pts[n + 5] = cbind.INF
+    rnd = random.Random(5 * n)
+    a = [rnd.randrange(Q) for _ in range(n)]
+    b = [rnd.randrange(Q) for _ in range(n)]
+    xs = [rnd.randrange(1, Q) for _ in range(n.bit_length() - 1)]
+    seen = []
+    for mode in (2, 1, 0):
+        eng.set_option("fold_wnaf", mode)
+        st = eng.ipa_create(cbind.pack_points(pts[:n]), cbind.pack_points(pts[n:2 * n]), cbind.pack_scalars(a), cbind.pack_scalars(b),
+                            n, cbind.pack_points([pts[2 * n]]))
+        trace = []
+        for x in xs:
+            trace.append(st.round_LR())
+            st.fold(x, pow(x, -1, Q))
+            if len(st) == 8:
+                trace.append(st.export())
+        trace.append(st.finish())
+        st.close()
+        seen.append(trace)
+    eng.set_option("fold_wnaf", 2)
+    eng.set_option("ipa_big_m", 0)
+    eng.set_option("ipa_small_m", 0)
+    assert seen[0] == seen[1] == seen[2]
+
+
 @pytest.mark.parametrize("n,small_m", [(1024, 64), (1 << 14, 1024), (1 << 16, 0)])
 def test_product_fold_shared_scalars_equals_per_lane_products(gp, n, small_m):
     """The two forms of the product fold -- shared GLV halves in non-adjacent form with two terms per thread (k_ec_fold_glv, the
