@@ -31,22 +31,25 @@ template <int OP> __global__ void __launch_bounds__(64) k_rate(u32 *io, int K) {
     if (OP == 5) { REP8(ADD32) REP8(ADD32) }
     if (OP == 6) { REP8(ADD64) REP8(ADD64) }
     if (OP == 7) { REP8(MAD) REP8(AND32) }          // the mix of a product column
+#define MADNOP(j) asm volatile("v_mad_u64_u32 %0, s[10:11], %1, %2, %0\n\ts_nop 0" : "+v"(a[j]) : "v"(b[j]), "v"(b[(j + 1) & 7]) : "s10", "s11");
+    if (OP == 8) { REP8(MADNOP) REP8(MADNOP) }      // round 4: what the compiler's s_nop 0 behind an asm statement costs (instruction count: 16 of 32 are nops)
   }
   u32 r = 0;
   for (int k = 0; k < 8; k++) r ^= (u32)a[k] ^ (u32)(a[k] >> 32) ^ b[k];
   io[t * 16] = r;
 }
-int main() {
+int main(int argc, char **argv) {
   u32 *d;
-  const int blocks = 4 * 1024;
+  const int blocks = (argc > 1 ? atoi(argv[1]) : 4) * 1024;          // waves per SIMD
   CK(hipMalloc(&d, 64ull * 64 * blocks));
   CK(hipMemset(d, 0x5A, 64ull * 64 * blocks));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   hipDeviceProp_t pr; CK(hipGetDeviceProperties(&pr, 0));
   const double ghz = pr.clockRate / 1e6;
   const int K = 4000;
-  const char *names[8] = {"v_mad_u64_u32", "v_lshrrev_b64", "v_alignbit_b32", "v_lshrrev_b32", "v_and_b32", "v_add_u32", "v_lshl_add_u64", "8 mad + 8 and"};
-  for (int op = 0; op < 8; op++) {
+  const char *names[9] = {"v_mad_u64_u32", "v_lshrrev_b64", "v_alignbit_b32", "v_lshrrev_b32", "v_and_b32", "v_add_u32", "v_lshl_add_u64", "8 mad + 8 and", "16 mad + 16 s_nop"};
+  printf("%d wave(s) per SIMD\n", blocks / 1024);
+  for (int op = 0; op < 9; op++) {
     float ms = 0;
     for (int rep = 0; rep < 3; rep++) {
       CK(hipEventRecord(e0));
@@ -58,14 +61,15 @@ int main() {
         case 4: hipLaunchKernelGGL(k_rate<4>, dim3(blocks), dim3(64), 0, 0, d, K); break;
         case 5: hipLaunchKernelGGL(k_rate<5>, dim3(blocks), dim3(64), 0, 0, d, K); break;
         case 6: hipLaunchKernelGGL(k_rate<6>, dim3(blocks), dim3(64), 0, 0, d, K); break;
-        default: hipLaunchKernelGGL(k_rate<7>, dim3(blocks), dim3(64), 0, 0, d, K); break;
+        case 7: hipLaunchKernelGGL(k_rate<7>, dim3(blocks), dim3(64), 0, 0, d, K); break;
+        default: hipLaunchKernelGGL(k_rate<8>, dim3(blocks), dim3(64), 0, 0, d, K); break;
       }
       CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
       CK(hipEventElapsedTime(&ms, e0, e1));
     }
     const double instr_per_wave = 16.0 * K, waves_per_simd = blocks / 1024.0;
     const double cycles = ms * 1e-3 * ghz * 1e9 / (instr_per_wave * waves_per_simd);
-    printf("%-16s %8.3f ms  -> %5.2f SIMD cycles per wave-instruction at %.2f GHz (4 = full rate)\n", names[op], ms, cycles, ghz);
+    printf("%-16s %8.3f ms  -> %5.2f SIMD cycles per wave-instruction at %.2f GHz (4 = full rate; the s_nop row counts its 16 multiply-adds only)\n", names[op], ms, cycles, ghz);
   }
   return 0;
 }
