@@ -564,14 +564,22 @@ static int msm_enqueue_small_pair(bpmi_ctx *ctx, const Segs &s0, const Segs &s1,
   debug_sync(ctx, "k_msm_small_pair / k_msm_mid", st);
   TailOffs to;
   to.nv = 1; to.off[0] = to.off[1] = to.off[2] = to.off[3] = 0;
-  for (int j = 0; j < 2; j++) {
-    bpmi_ctx::PendingMsm &pd = ctx->pend[j];
-    if (!ctx->opt_direct) HIPCHK(ctx, hipMemcpyAsync(pd.pin, w[j].E, eb, hipMemcpyDeviceToHost, st));
-    HIPCHK(ctx, hipEventRecord(pd.done, st));
-    pd.active = true; pd.W = gg[j].W; pd.nv = 1; pd.c = c; pd.tail = 2; pd.to = to;
-  }
-  HIPCHK(ctx, hipGetLastError());
-  return BPMI_OK;
+  // a failure from here on leaves none of THIS call's slots pending (both were free on entry: nobody else's is touched)
+  unsigned mine = 0;
+  auto queue_results = [&]() -> int {
+    for (int j = 0; j < 2; j++) {
+      bpmi_ctx::PendingMsm &pd = ctx->pend[j];
+      if (!ctx->opt_direct) HIPCHK(ctx, hipMemcpyAsync(pd.pin, w[j].E, eb, hipMemcpyDeviceToHost, st));
+      HIPCHK(ctx, hipEventRecord(pd.done, st));
+      pd.active = true; pd.W = gg[j].W; pd.nv = 1; pd.c = c; pd.tail = 2; pd.to = to;
+      mine |= 1u << j;
+    }
+    HIPCHK(ctx, hipGetLastError());
+    return BPMI_OK;
+  };
+  rc = queue_results();
+  if (rc && mine) msm_abandon_pending(ctx, mine);
+  return rc;
 }
 // two independent MSMs, overlapped on the two lanes; everything already enqueued on the
 // ctx stream (the producers of the scalars) is ordered before both
@@ -583,8 +591,8 @@ static int msm_run_pair(bpmi_ctx *ctx, const Segs &s0, uint8_t out0[64], const S
     const uint64_t big = std::max<uint64_t>(s0.total, s1.total);
     const bool mid = ctx->opt_mid_min >= 0 && big >= mid_min && big <= MID_NMAX && ctx->opt_glv <= 0;
     if (ctx->opt_pair1 && ctx->opt_c == 0 && s0.total && s1.total && (mid || big <= small_max)) {
-      int rc = msm_enqueue_small_pair(ctx, s0, s1, mid);
-      if (rc) { if (ctx->pend[0].active && ctx->pend[1].active) msm_abandon_pending(ctx, 3u); return rc; }
+      int rc = msm_enqueue_small_pair(ctx, s0, s1, mid);           // (cleans up after itself)
+      if (rc) return rc;
       return msm_finish_pair(ctx, out0, out1);
     }
   }
