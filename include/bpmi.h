@@ -99,6 +99,8 @@ int bpmi_sync(bpmi_ctx *ctx);
  *                  once instead of deferring the fold into the MSM scalars (default 2^18)
  *   "ipa_small_m"  logical length at which bases below "ipa_big_m" are folded once more, through per-term products
  *                  (0 = default 4096, 1 = never, else a power of two; the later rounds then run on the one-launch small-MSM kernel)
+ *   "pair_phases"  1: bpmi_msm2 on the bucket pipeline queues both MSMs' sorts before either accumulation.  An experiment that came out
+ *                  neutral (profiles/r04_C3_pair_phases_ab.txt); default 0
  *   "fold_wnaf"    the ladder of that 16-way fold: 2 (default) width-4 non-adjacent forms of the coefficients' GLV halves over affine
  *                  tables of 3P, 5P, 7P and of beta x (k_ec_multifold_w4g; 792 B of workspace per generator, kept by the ctx after the first fold),
  *                  1 of the whole coefficients (k_ec_multifold_w4), 0 the plain NAF ladder without tables (k_ec_multifold) */

@@ -165,6 +165,7 @@ int bpmi_set_option(bpmi_ctx *ctx, const char *name, int64_t value) {
     ctx->opt_rp_lanes = (int)value;
     return BPMI_OK;
   }
+  if (!strcmp(name, "pair_phases")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "pair_phases must be 0 or 1"); ctx->opt_pair_phases = (int)value; return BPMI_OK; }
   if (!strcmp(name, "fold_wnaf")) { if (value < 0 || value > 2) return fail(ctx, BPMI_E_ARG, "fold_wnaf must be 0, 1 or 2"); ctx->opt_fold_wnaf = (int)value; return BPMI_OK; }
   if (!strcmp(name, "reduce_epl")) { if (value < 0 || value > 64) return fail(ctx, BPMI_E_ARG, "reduce_epl must be 0..64"); ctx->opt_epl = (int)value; return BPMI_OK; }
   if (!strcmp(name, "chunk")) { if (value < 0 || value > 4096) return fail(ctx, BPMI_E_ARG, "chunk must be 0..4096"); ctx->opt_chunk = (int)value; return BPMI_OK; }

@@ -98,6 +98,7 @@ struct bpmi_ctx {
   HostHelper *helper = nullptr;
   MsmGraphCache *graphs = nullptr;      // captured launch sequences of repeated MSMs (msm_host.hpp)
   int opt_direct = 1;                   // the last kernel of an MSM writes its result into the slot's page-locked host buffer (0: workspace + copy)
+  int opt_pair_phases = 0;              // 1: a synchronous pair of MSMs queues both sorts before either accumulation (measured neutral: profiles/r04_C3_pair_phases_ab.txt)
   int opt_graph = 0;                    // 1: replay an MSM's launch sequence as a HIP graph when the same call comes again
   double prof_ms[BPMI_NSTAGES] = {0};
   uint64_t prof_calls[BPMI_NSTAGES] = {0};

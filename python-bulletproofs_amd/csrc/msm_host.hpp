@@ -157,7 +157,11 @@ struct CaptureGuard {
 // workspace), including the device->pinned-host copy the tail needs, into pending slot `slot`
 // (pinned buffer + completion event); returns without synchronising.
 //   [w0, w0 + wcount): the windows this call handles (wcount = 0: all of them)
-static int msm_enqueue(bpmi_ctx *ctx, int lane, int slot, const Segs &segs_in, u32 w0 = 0, u32 wcount = 0) {
+//   phase: 0 = everything; 1 = the sort only (recoding .. sorted entries), nothing becomes pending; 2 = the rest of an MSM whose
+//   sort a phase-1 call with the SAME arguments queued on this lane (the geometry is a function of the arguments: it is simply
+//   computed again).  A synchronous pair queues both sorts before either accumulation (msm_run_pair).  MSMs on the one-launch
+//   kernels or on GLV scalars have no separate sort: phase 1 does nothing for them and phase 2 everything.
+static int msm_enqueue(bpmi_ctx *ctx, int lane, int slot, const Segs &segs_in, u32 w0 = 0, u32 wcount = 0, int phase = 0) {
   Segs segs = segs_in;
   const uint64_t n = segs.total;
   bpmi_ctx::PendingMsm &pd = ctx->pend[slot];
@@ -230,7 +234,10 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, int slot, const Segs &segs_in, u
   u32 *const E_dst = ctx->opt_direct ? (u32 *)pd.pin : w.E;
   CaptureGuard cap(st);
   MsmGraphKey key;
-  const bool use_graph = ctx->opt_graph && !ctx->prof && !g_debug_sync && !ctx->chain_accum;
+  const bool use_graph = phase == 0 && ctx->opt_graph && !ctx->prof && !g_debug_sync && !ctx->chain_accum;
+  const bool has_sort_phase = !mid && !small && !glv;
+  if (phase == 1 && !has_sort_phase) return BPMI_OK;
+  const bool skip_sort = phase == 2 && has_sort_phase;
   // queued behind the graph or behind the launches: the completion event, the slot's bookkeeping
   auto commit = [&](u32 W_, u32 nv_, u32 c_, int tail_, const TailOffs &to_) -> int {
     if (cap.open) {
@@ -300,6 +307,7 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, int slot, const Segs &segs_in, u
     return commit(g.W, 1, g.c, 2, to);
   }
   const u32 nblk_n = (u32)std::min<uint64_t>(((uint64_t)g.n + 255) / 256, 8192);
+  if (!skip_sort) {
   {
     StageTimer t(ctx, ST_MISC, st);
     if (w.P) HIPCHK(ctx, hipMemsetAsync(w.coarse_hist, 0, 4ull * COARSE_HIST_WORDS, st));      // (a multiple of 256 bytes: ONE fill kernel, not an aligned part and a tail)
@@ -360,6 +368,8 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, int slot, const Segs &segs_in, u
     }
     debug_sync(ctx, "ST_SCATTER", st);
   }
+  }      // !skip_sort
+  if (phase == 1) { HIPCHK(ctx, hipGetLastError()); return BPMI_OK; }
   if (ctx->chain_accum && ctx->accum_chain_lane >= 0 && ctx->accum_chain_lane != lane)
     HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_accum[ctx->accum_chain_lane], 0));
   {
@@ -604,9 +614,21 @@ static int msm_run_pair(bpmi_ctx *ctx, const Segs &s0, uint8_t out0[64], const S
   // rounds: 2.43 ms per round against 2.35 -- with only two MSMs there is no steady state to pipeline)
   const bool chain = ctx->opt_pair_chain && s0.total >= (1u << 19) && s1.total >= (1u << 19);
   if (chain) { ctx->chain_accum = true; ctx->accum_chain_lane = -1; }
-  rc = msm_enqueue(ctx, 0, 0, s0);
+  // Round 4 experiment (option "pair_phases", off): both sorts first, then both accumulations.  Queued one MSM after the other, the
+  // second MSM's sort meets the first one's accumulation -- a one-round kernel that holds every wave slot of the chip -- and crawls
+  // (k_fine_sort_part 463 us instead of 100, profiles/r04_C3_big_round_timeline.txt); with the sorts up front the two accumulations
+  // share the chip from the start and both reductions run at the end.  Measured: NO difference (2.336 / 2.330 against 2.343 / 2.319 ms
+  // for a round of the 2^20-element prover, profiles/r04_C3_pair_phases_ab.txt) -- the round is the sum of its stages' work whichever
+  // way they are interleaved, which also settles what ONE pass over both MSMs (32 windows) could have gained.
+  const bool phases = ctx->opt_pair_phases && !chain && !ctx->opt_graph && s0.total >= (1u << 15) && s1.total >= (1u << 15);
+  if (phases) {
+    rc = msm_enqueue(ctx, 0, 0, s0, 0, 0, 1);
+    if (rc == BPMI_OK) rc = msm_enqueue(ctx, 1, 1, s1, 0, 0, 1);
+    if (rc) { msm_abandon_pending(ctx, 0u); return rc; }        // (nothing pending yet: only drains the lanes)
+  }
+  rc = msm_enqueue(ctx, 0, 0, s0, 0, 0, phases ? 2 : 0);
   if (rc == BPMI_OK) {
-    rc = msm_enqueue(ctx, 1, 1, s1);
+    rc = msm_enqueue(ctx, 1, 1, s1, 0, 0, phases ? 2 : 0);
     if (rc) msm_abandon_pending(ctx, 1u);
   }
   if (chain) { ctx->chain_accum = false; ctx->accum_chain_lane = -1; }

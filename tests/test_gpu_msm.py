@@ -318,6 +318,31 @@ def test_msm2_pairs(gp):
         PipSECP256k1.multiexp2(gp.to_gpu_list(pts[:2]), [1], [], [])
 
 
+def test_msm2_both_sorts_before_either_accumulation(gp):
+    """Option pair_phases (an experiment that came out neutral, off by default): a synchronous pair on the bucket pipeline queues both
+    MSMs' sorts first and the rest of each afterwards (msm_enqueue phase 1 / phase 2).  Same results as one MSM after the other, for
+    unequal sizes, for a pair whose second MSM is on a one-launch kernel (no separate sort: phase 2 does everything), and twice in a
+    row (the lanes' workspaces are reused)."""
+    eng = gp.engine()
+    rnd = random.Random(88)
+    n = 40000
+    pts, _ = gp.rand_points(n, 23)
+    pb = cbind.pack_points(pts)
+    a = cbind.pack_scalars([rnd.randrange(Q) for _ in range(n)])
+    b = cbind.pack_scalars([rnd.randrange(Q) for _ in range(n)])
+    want = {}
+    try:
+        for mode in (0, 1, 1):
+            eng.set_option("pair_phases", mode)
+            for n0, n1 in ((n, n), (n, 33000), (36000, 5)):
+                got = eng.msm2_bytes(pb, a, n0, pb, b, n1)
+                if (n0, n1) not in want:
+                    want[(n0, n1)] = (cbind.msm_bytes(pb, a, n0), cbind.msm_bytes(pb, b, n1))
+                assert tuple(got) == want[(n0, n1)], (mode, n0, n1)
+    finally:
+        eng.set_option("pair_phases", 0)
+
+
 @pytest.mark.parametrize("n", [40000, 30000])      # window bits 16, and 13 (the size range 10 240 .. 2^15: a short top window, always heavy)
 @pytest.mark.parametrize("shape", ["all_same", "two_values", "bits01", "bits_and_blinding", "small_range"])
 def test_msm_heavy_partitions(gp, shape, n):

@@ -47,6 +47,7 @@ while time.time() - t0 < budget:
         eng.set_option("small_pair", rnd.choice((1, 1, 0)))
         eng.set_option("ipa_small_step", rnd.choice((0, 0, 1)))
         eng.set_option("fold_wnaf", rnd.choice((2, 2, 1, 0)))
+        eng.set_option("pair_phases", rnd.choice((0, 1)))
         pts = [rnd.choice(pool) for _ in range(2 * n + 1)]
         g, h, u = pts[:n], pts[n:2 * n], pts[2 * n]
         a = [special_scalar() for _ in range(n)]
@@ -73,6 +74,7 @@ while time.time() - t0 < budget:
         eng.set_option("small_pair", 1)
         eng.set_option("ipa_small_step", 0)
         eng.set_option("fold_wnaf", 2)
+        eng.set_option("pair_phases", 0)
         check(ok, "ipa n=%d" % n)
     elif op == 1:    # lincomb2
         n = rnd.randrange(1, 400)

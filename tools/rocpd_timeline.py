@@ -3,7 +3,8 @@
 writes as DIR/NAME_results.db on this image).
   python tools/rocpd_timeline.py DB stats                        per-kernel calls / total / average / min / max (us)
   python tools/rocpd_timeline.py DB timeline [FIRST [COUNT]]     dispatches in start order: start (us, relative), duration, queue, kernel, grid
-  python tools/rocpd_timeline.py DB after KERNEL_SUBSTRING [COUNT]   the timeline starting at the LAST dispatch whose name contains the substring"""
+  python tools/rocpd_timeline.py DB after KERNEL_SUBSTRING [COUNT]   the timeline starting at the LAST dispatch whose name contains the substring
+  python tools/rocpd_timeline.py DB nth KERNEL_SUBSTRING N [COUNT] [BACK]   ... starting BACK rows before the N-th (0-based) such dispatch"""
 import re
 import sqlite3
 import sys
@@ -39,6 +40,12 @@ else:
         idx = [i for i, r in enumerate(rows) if sys.argv[3] in r[0]]
         first = idx[-1] if idx else 0
         count = int(sys.argv[4]) if len(sys.argv) > 4 else 80
+    elif mode == "nth":
+        idx = [i for i, r in enumerate(rows) if sys.argv[3] in r[0]]
+        nth = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+        back = int(sys.argv[6]) if len(sys.argv) > 6 else 0
+        first = max(0, (idx[nth] if len(idx) > nth else 0) - back)
+        count = int(sys.argv[5]) if len(sys.argv) > 5 else 80
     else:
         first = int(sys.argv[3]) if len(sys.argv) > 3 else 0
         count = int(sys.argv[4]) if len(sys.argv) > 4 else 200
