@@ -48,6 +48,7 @@ using namespace bpmi;
 #include "context.hpp"
 #include "device_util.hpp"
 #include "msm_kernels.hpp"
+#include "fold_ops_host.hpp"
 #include "point_kernels.hpp"
 #include "scalar_kernels.hpp"
 #include "host_tail.hpp"
@@ -1013,38 +1014,10 @@ int bpmi_ipa_fold(bpmi_ipa *st, const uint8_t x[32], const uint8_t xinv[32]) {
       u32 *tabx_a = (u32 *)(dw + 2 * wn_bytes), *tabx_b = (u32 *)(dw + 2 * wn_bytes + tabx_bytes);
       if (glv) {
         // the coefficients in two 128-bit halves each (k = k1 + k2 lambda): row 2 t + half, a negative half with its digits negated
+        // the coefficients in two 128-bit halves each, as the ladder's operation list (fold_ops_host.hpp)
         static thread_local WnafG hga, hgb;
-        for (int side = 0; side < 2; side++) {
-          WnafG &hw = side ? hgb : hga;
-          static thread_local signed char dg[2 * MULTIFOLD_MAXK][136];
-          int top = -1;
-          for (u32 t = 0; t < K2; t++) {
-            u32 k1[4], k2[4];
-            bool n1, n2;
-            glv_split(k1, n1, k2, n2, side ? st->hch[t] : st->hcg[t]);
-            for (int hf = 0; hf < 2; hf++) {
-              uint8_t k32[32] = {0};
-              memcpy(k32, hf ? k2 : k1, 16);
-              signed char *row = dg[2 * t + hf];
-              host_wnaf4(k32, row, top, 136);
-              if (hf ? n2 : n1) for (int q = 0; q < 136; q++) row[q] = (signed char)-row[q];
-            }
-          }
-          hw.nops = 0;
-          u32 ndbl = 0;                                        // nothing to double before the first addition
-          for (int pos = top; pos >= 0; pos--) {
-            for (u32 r = 0; r < 2 * K2; r++) {
-              const int d = dg[r][pos];
-              if (!d) continue;
-              if (hw.nops >= WNAFG_MAXOPS) return fail(ctx, BPMI_E_STATE, "fold: operation list overflow");   // (cannot happen: at most one digit in four positions, 32 x 34 < 2048)
-              const u32 mag = (u32)(d < 0 ? -d : d);
-              hw.op[hw.nops++] = ndbl | (r << 8) | ((mag >> 1) << 13) | ((d < 0 ? 1u : 0u) << 16);
-              ndbl = 0;
-            }
-            if (hw.nops) ndbl++;                               // the doubling that moves on to position pos - 1
-          }
-          hw.tail = hw.nops ? ndbl - 1u : 0u;                  // (the last position has no doubling after it)
-        }
+        if (!glv_fold_ops(hga, st->hcg.data(), K2) || !glv_fold_ops(hgb, st->hch.data(), K2))
+          return fail(ctx, BPMI_E_STATE, "fold: operation list overflow");
         HIPCHK(ctx, h2d(ctx, dw, &hga, sizeof(WnafG), ctx->stream));
         HIPCHK(ctx, h2d(ctx, dw + wn_bytes, &hgb, sizeof(WnafG), ctx->stream));
         {

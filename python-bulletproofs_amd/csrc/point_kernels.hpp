@@ -534,25 +534,6 @@ template <int PER> __global__ void __launch_bounds__(256, 3) k_ec_odd_multiples(
 }
 // digits of the K (<= 16) shared scalars, width-4 NAF: dg[t][pos] in {0, +-1, +-3, +-5, +-7}, pos <= top
 struct WnafK { signed char dg[MULTIFOLD_MAXK][264]; int top; };
-static void host_wnaf4(const uint8_t k32[32], signed char *dg, int &top, int len = 264) {
-  u32 w[9];
-  memcpy(w, k32, 32);
-  w[8] = 0;
-  memset(dg, 0, (size_t)len);
-  for (int pos = 0; pos < len - 4; pos++) {
-    if (w[0] & 1u) {
-      int d = (int)(w[0] & 15u);                     // k mod 16
-      if (d > 8) d -= 16;                            // odd digit in [-7, 7]
-      dg[pos] = (signed char)d;
-      // k -= d
-      if (d > 0) { u64 br = (u64)d; for (int i = 0; i < 9 && br; i++) { const u64 t = (u64)w[i] - br; w[i] = (u32)t; br = (t >> 32) & 1u; } }
-      else { u64 c = (u64)(-d); for (int i = 0; i < 9 && c; i++) { const u64 t = (u64)w[i] + c; w[i] = (u32)t; c = t >> 32; } }
-      if (pos > top) top = pos;
-    }
-    for (int i = 0; i < 8; i++) w[i] = (w[i] >> 1) | (w[i + 1] << 31);
-    w[8] >>= 1;
-  }
-}
 __global__ void __launch_bounds__(256, 3) k_ec_multifold_w4(MultifoldJob ja, MultifoldJob jb, const u32 *__restrict__ tab_a, const u32 *__restrict__ tab_b,
                                                             const WnafK *__restrict__ wa, const WnafK *__restrict__ wb, u32 m, u32 K) {
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -602,8 +583,7 @@ __global__ void __launch_bounds__(256, 3) k_ec_multifold_w4(MultifoldJob ja, Mul
 // add (-)(j-th odd multiple) of (lambda?) point row / 2".  The kernel fetches the point of operation q + 1 before it computes
 // operation q: 2^17 outputs are 2 048 waves -- two per SIMD, too few to hide a load behind the other waves' arithmetic.
 //   op = n_dbl | row << 8 | j << 13 | neg << 16          tail = doublings after the last addition
-#define WNAFG_MAXOPS 2048
-struct WnafG { u32 nops, tail; u32 op[WNAFG_MAXOPS]; };
+// (WnafG and its builder: fold_ops_host.hpp)
 __device__ __forceinline__ void multifold_fetch(affine &P, u32 op, u32 i, u32 m, u32 npts, const u32 *base, const u32 *tab, const u32 *tabx) {
   const u32 r = (op >> 8) & 31u, j = (op >> 13) & 7u, k = i + (r >> 1) * m;      // j = 0: P, 1: 3P, 2: 5P, 3: 7P
   const bool lam = (r & 1u) != 0u;                                               // wave-uniform: the half that multiplies lambda (jP)

@@ -6,6 +6,7 @@
 #include "field.hpp"
 #include "curve.hpp"
 #include "scalar.hpp"
+#include "fold_ops_host.hpp"
 using namespace bpmi;
 
 static void load_fe(fe &r, const uint8_t *b) { u32 w[8]; memcpy(w, b, 32); fe_from_words(r, w); }
@@ -61,6 +62,17 @@ void t_glv_split(const uint8_t *k, uint8_t *k1, uint8_t *k2, int *signs) {
   glv_split(a, n1, b, n2, s);
   memcpy(k1, a, 16); memcpy(k2, b, 16);
   signs[0] = n1; signs[1] = n2;
+}
+// the GLV ladder's operation list for K coefficients (32 bytes LE each, < q): ops out (capacity WNAFG_MAXOPS), returns nops or -1; *tail
+int t_glv_fold_ops(const uint8_t *coef, uint32_t K, uint32_t *ops, uint32_t *tail) {
+  sc c[WNAFG_MAXK];
+  if (K > WNAFG_MAXK) return -1;
+  for (uint32_t t = 0; t < K; t++) memcpy(c[t].v, coef + 32 * t, 32);
+  static WnafG hw;
+  if (!glv_fold_ops(hw, c, K)) return -1;
+  memcpy(ops, hw.op, 4 * hw.nops);
+  *tail = hw.tail;
+  return (int)hw.nops;
 }
 void t_fe_mul_beta(const uint8_t *x, uint8_t *out) {
   fe a, r;

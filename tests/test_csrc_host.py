@@ -364,3 +364,44 @@ def test_glv_split_and_beta(shim):
         assert bx == beta * pt.x % p
         img = lam * pt
         assert (img.x, img.y) == (bx, pt.y)
+
+
+def test_glv_fold_operation_list_spells_the_coefficients(shim):
+    """csrc/fold_ops_host.hpp glv_fold_ops -- the host half of the inner-product prover's 16-way generator fold (round 4): the ladder
+    k_ec_multifold_w4g runs "double n times, then add (-)(j-th odd multiple) of (lambda?) point row / 2" from this list, so the list,
+    read as integers, must spell every coefficient: with c_r = sum over the operations of row r of (+-)(2 j + 1) 2^(doublings still to
+    come), c_(2t) + c_(2t+1) lambda == coefficient t (mod q).  Also: every digit odd and <= 7, at most 129 doublings in all, the
+    first operation doubles nothing, rows within one position in ascending order."""
+    q = secp256k1.q
+    lam = 0x5363AD4CC05C30E0A5261C028812645A122E22EA20816678DF02967C1B23BD72
+    shim.t_glv_fold_ops.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]
+    shim.t_glv_fold_ops.restype = ctypes.c_int
+    rnd = random.Random(41)
+    edge = [0, 1, 2, q - 1, q - 2, q // 2, lam, q - lam, (1 << 128) - 1, 1 << 128, (1 << 255) % q, 7, 8, 15, 16]
+    for K in (1, 2, 16, 16, 16):
+        coefs = [rnd.choice(edge) if rnd.random() < 0.3 else rnd.randrange(q) for _ in range(K)]
+        ops = (ctypes.c_uint32 * 2048)()
+        tail = ctypes.c_uint32()
+        nops = shim.t_glv_fold_ops(b"".join(c.to_bytes(32, "little") for c in coefs), K, ops, ctypes.byref(tail))
+        assert nops >= 0
+        ops = list(ops[:nops])
+        assert not ops or ops[0] & 255 == 0
+        total_dbl = sum(o & 255 for o in ops) + tail.value
+        assert total_dbl <= 132
+        rows = [0] * (2 * K)
+        left = total_dbl
+        prev_row = -1
+        for o in ops:
+            n_dbl, r, j, neg = o & 255, (o >> 8) & 31, (o >> 13) & 7, (o >> 16) & 1
+            assert r < 2 * K and j < 4
+            left -= n_dbl
+            if n_dbl == 0 and prev_row >= 0:
+                assert r > prev_row
+            prev_row = r
+            rows[r] += (-1 if neg else 1) * (2 * j + 1) << left
+        assert left == tail.value
+        for t in range(K):
+            assert abs(rows[2 * t]) < 1 << 129 and abs(rows[2 * t + 1]) < 1 << 129
+            assert (rows[2 * t] + rows[2 * t + 1] * lam - coefs[t]) % q == 0, (K, t)
+    assert shim.t_glv_fold_ops(bytes(32 * 17), 17, (ctypes.c_uint32 * 2048)(), ctypes.byref(ctypes.c_uint32())) == -1
+
