@@ -54,6 +54,7 @@ using namespace bpmi;
 #include "host_tail.hpp"
 #include "msm_host.hpp"
 #include "rp_batch_host.hpp"
+#include "host_pool.hpp"
 #include "rp_algebra_host.hpp"
 #include "transcript_host.hpp"
 #include "rp_wire_v2_host.hpp"

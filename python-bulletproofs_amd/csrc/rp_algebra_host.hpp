@@ -51,9 +51,7 @@ template <typename F> static inline void parallel(uint64_t count, int threads, F
   if (threads < 1) threads = 1;
   if ((uint64_t)threads > count / 512 + 1) threads = (int)(count / 512 + 1);
   if (threads == 1) { f(0, (uint64_t)0, count); return; }
-  std::vector<std::thread> th;
-  for (int t = 0; t < threads; t++) th.emplace_back(f, t, count * t / threads, count * (t + 1) / threads);
-  for (auto &x : th) x.join();
+  hostpool::run(threads, [&](int t) { f(t, count * t / threads, count * (t + 1) / threads); });      // (host_pool.hpp: sleeping workers, not new threads)
 }
 
 }  // namespace rpa

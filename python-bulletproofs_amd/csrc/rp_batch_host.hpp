@@ -17,6 +17,10 @@
 #pragma once
 #include <stdint.h>
 #include <string.h>
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+#include <cpuid.h>
+#include <immintrin.h>
+#endif
 
 #include <thread>
 #include <vector>
@@ -120,7 +124,52 @@ static const uint32_t SHA_K[64] = {
     0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f,
     0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
 static inline uint32_t rotr(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
-static inline void sha_block(uint32_t h[8], const uint8_t *p) {
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+#define BPMI_SHA_NI 1
+// The same compression function on the SHA extensions of the host CPU (sha256rnds2 / sha256msg1 / sha256msg2), chosen at run time
+// (CPUID leaf 7, EBX bit 29).  The provers' seeded blinding vectors are 2 n m hashes (16 384 for a 128 x 64-bit proof: 0.68 ms of a
+// 8.6 ms proof on eight threads with the portable code), every challenge of every transcript is two more.
+// tests/test_csrc_host.py::test_sha_block_on_cpu_extensions_equals_the_portable_one pins it to sha_block_portable.
+__attribute__((target("sha,sse4.1,ssse3"))) static inline void sha_block_ni(uint32_t h[8], const uint8_t *p) {
+  const __m128i flip = _mm_set_epi64x(0x0c0d0e0f08090a0bULL, 0x0405060700010203ULL);
+  __m128i t = _mm_loadu_si128((const __m128i *)&h[0]);                // DCBA (a in lane 0)
+  __m128i s1 = _mm_loadu_si128((const __m128i *)&h[4]);               // HGFE
+  t = _mm_shuffle_epi32(t, 0xB1);                                     // CDAB
+  s1 = _mm_shuffle_epi32(s1, 0x1B);                                   // EFGH
+  __m128i s0 = _mm_alignr_epi8(t, s1, 8);                             // ABEF
+  s1 = _mm_blend_epi16(s1, t, 0xF0);                                  // CDGH
+  const __m128i save0 = s0, save1 = s1;
+  __m128i m[4];
+  for (int g = 0; g < 16; g++) {
+    if (g < 4) m[g] = _mm_shuffle_epi8(_mm_loadu_si128((const __m128i *)(p + 16 * g)), flip);
+    else {
+      const __m128i w4 = m[g & 3], w3 = m[(g + 1) & 3], w2 = m[(g + 2) & 3], w1 = m[(g + 3) & 3];      // W[g-4], W[g-3], W[g-2], W[g-1] (4 words each)
+      m[g & 3] = _mm_sha256msg2_epu32(_mm_add_epi32(_mm_sha256msg1_epu32(w4, w3), _mm_alignr_epi8(w1, w2, 4)), w1);
+    }
+    __m128i x = _mm_add_epi32(m[g & 3], _mm_loadu_si128((const __m128i *)&SHA_K[4 * g]));
+    s1 = _mm_sha256rnds2_epu32(s1, s0, x);
+    x = _mm_shuffle_epi32(x, 0x0E);
+    s0 = _mm_sha256rnds2_epu32(s0, s1, x);
+  }
+  s0 = _mm_add_epi32(s0, save0);
+  s1 = _mm_add_epi32(s1, save1);
+  t = _mm_shuffle_epi32(s0, 0x1B);                                    // FEBA
+  s1 = _mm_shuffle_epi32(s1, 0xB1);                                   // DCHG
+  s0 = _mm_blend_epi16(t, s1, 0xF0);                                  // DCBA
+  s1 = _mm_alignr_epi8(s1, t, 8);                                     // HGFE
+  _mm_storeu_si128((__m128i *)&h[0], s0);
+  _mm_storeu_si128((__m128i *)&h[4], s1);
+}
+static inline bool cpu_has_sha_extensions() {
+  unsigned a = 0, b = 0, c = 0, d = 0;
+  if (!__get_cpuid_count(7, 0, &a, &b, &c, &d)) return false;
+  const bool sha = (b >> 29) & 1u;
+  if (!__get_cpuid(1, &a, &b, &c, &d)) return false;
+  return sha && ((c >> 19) & 1u) && ((c >> 9) & 1u);                  // + SSE4.1, SSSE3
+}
+static const bool g_sha_ni = cpu_has_sha_extensions();
+#endif
+static inline void sha_block_portable(uint32_t h[8], const uint8_t *p) {
   uint32_t w[64];
   for (int i = 0; i < 16; i++) w[i] = ((uint32_t)p[4 * i] << 24) | ((uint32_t)p[4 * i + 1] << 16) | ((uint32_t)p[4 * i + 2] << 8) | p[4 * i + 3];
   for (int i = 16; i < 64; i++) {
@@ -139,6 +188,12 @@ static inline void sha_block(uint32_t h[8], const uint8_t *p) {
     hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
   }
   h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+}
+static inline void sha_block(uint32_t h[8], const uint8_t *p) {
+#if defined(BPMI_SHA_NI)
+  if (g_sha_ni) { sha_block_ni(h, p); return; }
+#endif
+  sha_block_portable(h, p);
 }
 static inline void sha_init(Sha &s) {
   static const uint32_t H0[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};

@@ -81,12 +81,7 @@ int bpmi_mod_hash_range(const uint8_t *tail, uint64_t tail_len, uint64_t lo, uin
       rp::q_to_le(out + 32 * (i - lo), v);
     }
   };
-  if (threads == 1) work(0);
-  else {
-    std::vector<std::thread> th;
-    for (int t = 0; t < threads; t++) th.emplace_back(work, t);
-    for (auto &x : th) x.join();
-  }
+  hostpool::run(threads, work);
   return BPMI_OK;
 }
 

@@ -67,7 +67,7 @@ def _mod_hash_ints(lo, hi, digest, q):
         import os
         from .. import _native
         out = ctypes.create_string_buffer(32 * (hi - lo))
-        threads = max(1, min(8, len(os.sched_getaffinity(0)), (hi - lo) // 1024))
+        threads = _threads(hi - lo)
         if _native.load().bpmi_mod_hash_range(digest, len(digest), lo, hi, threads, out) != 0:
             raise RuntimeError("bpmi_mod_hash_range failed")
         return PackedScalars.from_bytes(out.raw)
@@ -85,8 +85,10 @@ _ASCII_BITS = bytes(range(256)).translate(bytes(c & 1 for c in range(256)))     
 
 
 def _threads(count):
+    """Host threads for the native O(n m) loops: one per 1 024 elements, at most BPMI_HOST_THREADS (default 8) and the CPUs of the process."""
     import os
-    return max(1, min(8, len(os.sched_getaffinity(0)), count // 1024))
+    cap = int(os.environ.get("BPMI_HOST_THREADS", "8") or 8)
+    return max(1, min(cap, len(os.sched_getaffinity(0)), count // 1024))
 
 
 def _le32(v, q):
@@ -110,8 +112,8 @@ def _native_prove(vs, n, g, h, gs, hs, gammas, u, group, seed, aggregated):
     aL = PackedScalars.from_bytes(b"".join(map(_BIT_LE.__getitem__, bits)))
     aR = PackedScalars.from_bytes(b"".join(map((_MINUS1_LE, _BIT_LE[0]).__getitem__, bits)))
     alpha = mod_hash(b"alpha" + tr.digest, q).x
-    sL = _mod_hash_ints(0, nm, tr.digest, q)
-    sR = _mod_hash_ints(nm, 2 * nm, tr.digest, q)
+    sLR = _mod_hash_ints(0, 2 * nm, tr.digest, q)        # one native call (one set of threads) for both blinding vectors
+    sL, sR = PackedScalars.from_bytes(sLR.packed[:32 * nm]), PackedScalars.from_bytes(sLR.packed[32 * nm:])
     rho = mod_hash(str(2 * n).encode() + tr.digest, q).x     # sic: 2*n also when aggregated (:61)
     gs, hs = PackedPoints(gs) if not isinstance(gs, PackedPoints) else gs, PackedPoints(hs) if not isinstance(hs, PackedPoints) else hs
     base = PackedPoints.join(gs, hs, [h])

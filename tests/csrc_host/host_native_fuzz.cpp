@@ -15,6 +15,7 @@
 
 #include "../../include/bpmi.h"
 #include "rp_batch_host.hpp"
+#include "host_pool.hpp"
 #include "rp_algebra_host.hpp"
 #include "transcript_host.hpp"
 #include "rp_wire_v2_host.hpp"

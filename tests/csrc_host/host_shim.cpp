@@ -2,11 +2,14 @@
 // for unit tests only: the headers are plain C++, so their limb arithmetic,
 // magnitude discipline and exceptional-case handling can be checked against
 // Python integers here, without a GPU.  Not part of the product library.
+#include <stdio.h>
 #include <string.h>
 #include "field.hpp"
 #include "curve.hpp"
 #include "scalar.hpp"
 #include "fold_ops_host.hpp"
+#include "../../include/bpmi.h"
+#include "rp_batch_host.hpp"
 using namespace bpmi;
 
 static void load_fe(fe &r, const uint8_t *b) { u32 w[8]; memcpy(w, b, 32); fe_from_words(r, w); }
@@ -73,6 +76,18 @@ int t_glv_fold_ops(const uint8_t *coef, uint32_t K, uint32_t *ops, uint32_t *tai
   memcpy(ops, hw.op, 4 * hw.nops);
   *tail = hw.tail;
   return (int)hw.nops;
+}
+// SHA-256 compression of one block from the given state: which = 0 the portable code, 1 the CPU's SHA extensions (returns 0 and
+// leaves the state alone when the CPU has none), 2 whatever the library dispatches to
+int t_sha_block(int which, uint32_t *state, const uint8_t *block) {
+  if (which == 0) { rp::sha_block_portable(state, block); return 1; }
+#if defined(BPMI_SHA_NI)
+  if (which == 1) { if (!rp::g_sha_ni) return 0; rp::sha_block_ni(state, block); return 1; }
+#else
+  if (which == 1) return 0;
+#endif
+  rp::sha_block(state, block);
+  return 1;
 }
 void t_fe_mul_beta(const uint8_t *x, uint8_t *out) {
   fe a, r;

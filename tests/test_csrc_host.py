@@ -405,3 +405,34 @@ def test_glv_fold_operation_list_spells_the_coefficients(shim):
             assert (rows[2 * t] + rows[2 * t + 1] * lam - coefs[t]) % q == 0, (K, t)
     assert shim.t_glv_fold_ops(bytes(32 * 17), 17, (ctypes.c_uint32 * 2048)(), ctypes.byref(ctypes.c_uint32())) == -1
 
+
+
+def test_sha_block_on_cpu_extensions_equals_the_portable_one(shim):
+    """csrc/rp_batch_host.hpp: the SHA-256 compression function on the host CPU's SHA extensions (round 4; chosen at run time) against
+    the portable one, from random states on random and structured blocks; and the dispatched function against hashlib."""
+    import hashlib
+    import struct
+    shim.t_sha_block.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_uint32), ctypes.c_char_p]
+    shim.t_sha_block.restype = ctypes.c_int
+    rnd = random.Random(77)
+    h0 = (0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19)
+    have = None
+    for k in range(3000):
+        block = bytes([0] * 64) if k == 0 else bytes([255] * 64) if k == 1 else bytes(range(64)) if k == 2 else rnd.randbytes(64)
+        start = h0 if k % 2 == 0 else tuple(rnd.getrandbits(32) for _ in range(8))
+        outs = []
+        for which in (0, 1, 2):
+            st = (ctypes.c_uint32 * 8)(*start)
+            ok = shim.t_sha_block(which, st, block)
+            outs.append(tuple(st) if ok else None)
+        have = outs[1] is not None
+        assert outs[0] == outs[2] and (outs[1] is None or outs[1] == outs[0]), k
+    # the dispatched function as a whole hash: one padded block
+    msg = b"bpmi" * 9
+    block = msg + b"\x80" + bytes(64 - len(msg) - 9) + struct.pack(">Q", 8 * len(msg))
+    st = (ctypes.c_uint32 * 8)(*h0)
+    shim.t_sha_block(2, st, block)
+    assert struct.pack(">8I", *st) == hashlib.sha256(msg).digest()
+    if not have:
+        pytest.skip("this CPU has no SHA extensions: only the portable path and the dispatch were checked")
+
