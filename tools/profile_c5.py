@@ -26,7 +26,7 @@ for j in range(distinct):
     v = ModP(int.from_bytes(hashlib.sha256(b"v%d" % j).digest()[:8], "big"), Q)
     gamma = mod_hash(b"gamma%d" % j, Q)
     Vd.append(commitment(g, h, v, gamma))
-    wire.append(proof_to_bytes(NIRangeProver(v, n, g, h, gs, hs, gamma, u, secp256k1, b"seed%d" % j).prove()))
+    wire.append(proof_to_bytes(NIRangeProver(v, n, g, h, gs, hs, gamma, u, secp256k1, b"seed%d" % j).prove(), version=int(os.environ.get("C5_WIRE", "1"))))
 Vs = [Vd[k % distinct] for k in range(total)]
 blobs = [wire[k % distinct] for k in range(total)]
 threads = min(32, len(os.sched_getaffinity(0)))
@@ -49,12 +49,13 @@ if os.environ.get("C5_SERIAL"):                         # point decoding behind 
     eng.set_option("rp_overlap", 0)
 if os.environ.get("C5_ONLY_ROLE"):
     eng.set_option("rp_only_role", int(os.environ["C5_ONLY_ROLE"]))
-if PREPARE != "host":
+if PREPARE != "host" and not os.environ.get("C5_NO_STAGE_TIMERS"):
     eng.profile(1)
 bv = BatchRangeVerifier(g, h, gs, hs, u)
-for rep in range(3):
+REPS = int(os.environ.get("C5_REPS", "3"))
+for rep in range(REPS):
     t0 = time.perf_counter()
-    if rep == 2:
+    if rep == REPS - 1:
         pr = cProfile.Profile()
         pr.enable()
     try:
@@ -69,7 +70,7 @@ for rep in range(3):
         t1 = time.perf_counter()
         ok = repr(exc)
     t2 = time.perf_counter()
-    if rep == 2:
+    if rep == REPS - 1:
         pr.disable()
     bv.reset()
     print("prepare=%s" % PREPARE, end=" ")
