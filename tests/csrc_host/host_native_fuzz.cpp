@@ -5,11 +5,13 @@
 //                         bounded export, bpmi_mod_hash_range (src/utils/utils.py:84-97)
 //   host_tail.hpp         the MSM's window combine on the host
 //   rp_wire_v2_host.hpp   wire format 2 -> format 1 (untrusted bytes in: every malformed shape must be refused, never overrun)
+//   host_pool.hpp         the sleeping worker pool those loops run on: concurrent callers, nested loops, every width
 // Built by tests/test_host_native_sanitizers.py with -fsanitize=address,undefined (every output buffer is a heap block of
 // EXACTLY the documented size, so an overrun of one byte is a report) and again with -fsanitize=thread (the threaded entry
 // points with 1..8 threads).  Besides "no report" it checks what can be checked without an oracle: results do not depend on the
 // thread count, t_hat == <l, r>, the export refuses a buffer one byte short and fills one that fits exactly.
 //   host_native_fuzz <iterations> [seed]        exit 0 = every check held
+#include <atomic>
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -253,6 +255,33 @@ static void test_wire_v2() {
   CHECK(bpmi_rp_wire_v2_to_v1(in.p, total, off.data(), (uint64_t)count, big.p, big.n, out_off.data(), &bad) == BPMI_E_ARG);
 }
 
+// host_pool.hpp: several application threads run data-parallel loops at the same time (one gets the pool, the others fall back
+// to threads of their own), a loop body that starts a loop of its own (nested: the pool is busy, so it must not wait for it),
+// widths from 1 to more than the pool has had so far -- every index exactly once, nothing lost, nothing run twice
+static void test_host_pool() {
+  std::atomic<int> bad{0};
+  auto caller = [&bad](unsigned seed) {
+    for (int rep = 0; rep < 24; rep++) {
+      const int n = 1 + (int)((seed * 2654435761u + (unsigned)rep * 40503u) % 13u);
+      std::vector<std::atomic<int>> hit(n);
+      for (auto &h : hit) h = 0;
+      hostpool::run(n, [&](int t) {
+        hit[t]++;
+        if (rep % 6 == 0 && t == 1) {                             // nested
+          std::atomic<int> inner{0};
+          hostpool::run(3, [&](int) { inner++; });
+          if (inner != 3) bad++;
+        }
+      });
+      for (auto &h : hit) if (h != 1) bad++;
+    }
+  };
+  std::vector<std::thread> callers;
+  for (unsigned c = 0; c < 4; c++) callers.emplace_back(caller, c + 1u);
+  for (auto &x : callers) x.join();
+  CHECK(bad == 0);
+}
+
 int main(int argc, char **argv) {
   const long iters = argc > 1 ? atol(argv[1]) : 200;
   if (argc > 2) rng_state ^= (uint64_t)atoll(argv[2]) * 0x9E3779B97F4A7C15ULL;
@@ -261,6 +290,7 @@ int main(int argc, char **argv) {
     test_transcript();
     test_mod_hash_range();
     test_host_tail();
+    if (it % 8 == 0) test_host_pool();
     for (int r = 0; r < 8; r++) test_wire_v2();
   }
   printf("host_native_fuzz: %ld iterations, %d failed checks\n", iters, fails);
