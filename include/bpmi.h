@@ -49,6 +49,7 @@ extern "C" {
 
 typedef struct bpmi_ctx bpmi_ctx;
 typedef struct bpmi_ipa bpmi_ipa;
+typedef struct bpmi_rp_prover bpmi_rp_prover;
 
 /* ---- library / context ---------------------------------------------------- */
 int bpmi_version(void);
@@ -318,6 +319,32 @@ int bpmi_rp_batch_prepare_dev(bpmi_ctx *ctx, uint32_t n_gens, uint32_t values_pe
 int bpmi_rp_batch_verify_dev(bpmi_ctx *ctx, uint32_t n_gens, uint32_t values_per_proof, uint64_t n_proofs, const uint8_t *blobs, uint64_t blobs_len,
                              const uint64_t *blob_off, const uint8_t *weights, const uint8_t *seed, const uint8_t *v_points, const void *d_gens, void *d_points,
                              void *d_scalars, uint8_t out[64], int64_t *first_bad);
+/* ---- a BATCH of single-value range proofs, proved on the device in one call (csrc/rp_prove_kernels.hpp, rp_prove_host.hpp) -------------
+ * Replaces a LOOP of NIRangeProver(v, n, g, h, gs, hs, gamma, u, group, seed).prove() (/root/reference/src/rangeproofs/
+ * rangeproof_prover.py:35-91) with NIProver.prove / FastNIProver2.prove inside (/root/reference/src/innerproduct/
+ * inner_product_prover.py:27-44, :84-110) over proofs that share their generators: the same transcripts
+ * (/root/reference/src/utils/transcript.py:13-33), the same seeded blinding scalars (/root/reference/src/utils/utils.py:84-97), the
+ * same proofs byte for byte -- but every protocol step is ONE launch over all proofs, every scalar multiplication a lookup in tables
+ * of the fixed generators, and the Fiat-Shamir hashes run on the device.
+ *   bpmi_rp_prover_create   nbits: a power of two in [2, 128]; g, h, u: 64-byte points; gs, hs: nbits points each.  Builds the tables
+ *                           (34 MB of device memory for 64-bit proofs, a few milliseconds) and keeps them for the prover's lifetime.
+ *                           PRECONDITION: the points are on the curve (the Python layer's Point constructor checked them).
+ *   bpmi_rp_prove_batch     values, gammas: n_proofs x 32 B little-endian, in [0, q) (of a value only the low nbits bits enter the
+ *                           proof, as in rangeproof_prover.py:40); seeds: proof i's transcript seed = seeds[seed_off[i] .. seed_off[i+1])
+ *                           (at most 65 535 bytes).  out[out_off[i] .. out_off[i+1]) = proof i in wire format 2
+ *                           (python-bulletproofs_amd/rangeproofs/codec.py; bpmi_rp_wire_v2_to_v1 expands it, bpmi_rp_batch_verify_dev
+ *                           takes it as it is); out_off has n_proofs + 1 entries; cap >= n_proofs x bpmi_rp_prove_batch_proof_bytes
+ *                           (of the longest seed).  At most 2^20 proofs per call; one call at a time per prover and ctx.
+ *   bpmi_rp_prover_last_ms  device milliseconds of the last batch: A and S | y, z, T1, T2 | x, the vectors, P_new | the rounds of the
+ *                           inner-product argument | the wire bytes | their copy to the host | the whole batch */
+int bpmi_rp_prover_create(bpmi_ctx *ctx, uint32_t nbits, const uint8_t g[64], const uint8_t h[64], const uint8_t u[64], const uint8_t *gs, const uint8_t *hs,
+                          bpmi_rp_prover **out);
+void bpmi_rp_prover_destroy(bpmi_rp_prover *pv);
+uint64_t bpmi_rp_prove_batch_proof_bytes(const bpmi_rp_prover *pv, uint64_t seed_len);
+int bpmi_rp_prove_batch(bpmi_rp_prover *pv, uint64_t n_proofs, const uint8_t *values, const uint8_t *gammas, const uint8_t *seeds, const uint64_t *seed_off,
+                        uint8_t *out, uint64_t cap, uint64_t *out_off);
+int bpmi_rp_prover_last_ms(const bpmi_rp_prover *pv, double ms[7]);
+
 /* Page-locked host memory (hipHostMalloc) for buffers handed to the library repeatedly, e.g. the receive buffer of wire proofs. */
 int bpmi_host_alloc(bpmi_ctx *ctx, size_t bytes, void **out);
 int bpmi_host_free(bpmi_ctx *ctx, void *p);

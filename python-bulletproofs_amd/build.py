@@ -9,7 +9,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbpmi.so")
 SOURCES = ["bpmi.hip"]
 HEADERS = ["field.hpp", "field_gen.hpp", "curve.hpp", "scalar.hpp", "context.hpp", "device_util.hpp", "msm_kernels.hpp",
-           "point_kernels.hpp", "fold_ops_host.hpp", "scalar_kernels.hpp", "msm_host.hpp", "host_tail.hpp", "rp_batch_host.hpp", "host_pool.hpp", "rp_algebra_host.hpp", "transcript_host.hpp", "rp_wire_v2_host.hpp", "rp_batch_kernels.hpp", "scalar_gen.hpp", os.path.join("..", "..", "include", "bpmi.h")]
+           "point_kernels.hpp", "fold_ops_host.hpp", "scalar_kernels.hpp", "msm_host.hpp", "host_tail.hpp", "rp_batch_host.hpp", "host_pool.hpp", "rp_algebra_host.hpp", "transcript_host.hpp", "rp_wire_v2_host.hpp", "rp_batch_kernels.hpp", "rp_prove_kernels.hpp", "rp_prove_host.hpp", "scalar_gen.hpp", os.path.join("..", "..", "include", "bpmi.h")]
 
 
 def hipcc():

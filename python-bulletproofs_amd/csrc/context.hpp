@@ -100,6 +100,10 @@ struct bpmi_ctx {
   int opt_direct = 1;                   // the last kernel of an MSM writes its result into the slot's page-locked host buffer (0: workspace + copy)
   int opt_pair_phases = 0;              // 1: a synchronous pair of MSMs queues both sorts before either accumulation (measured neutral: profiles/r04_C3_pair_phases_ab.txt)
   int opt_graph = 0;                    // 1: replay an MSM's launch sequence as a HIP graph when the same call comes again
+  // round 5 (the mid-size floor; every one on by default, 0 = the round-4 path for A/B runs and tests)
+  int opt_top2 = 1;                     // c = 15: 17 windows, the last one unsigned with 2B buckets (0: 18 windows, the last one a carry window)
+  int opt_inblock = 1;                  // n <= 2^17: the sort's level B handles partitions of any size itself, the two heavy-tile launches are skipped
+  int opt_segfuse = 1;                  // the segmented scan's last level runs in the block that finishes the level before it last (one launch instead of two)
   double prof_ms[BPMI_NSTAGES] = {0};
   uint64_t prof_calls[BPMI_NSTAGES] = {0};
 };

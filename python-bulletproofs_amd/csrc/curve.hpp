@@ -281,6 +281,6 @@ BPMI_HD void xyzz_load(xyzz &a, const u32 *src) {
 
 // bit offsets of the (<= 4) partial sums a bucket reduction leaves per MSM window:
 // window value = sum_v 2^(off[v]) E[v], off ascending, off[0] = 0
-struct TailOffs { u32 nv; u32 off[4]; };
+struct TailOffs { u32 nv; u32 off[4]; u32 top; u32 top_off[4]; };      // top = 1: the last window uses top_off (MsmGeom.top2)
 
 }  // namespace bpmi

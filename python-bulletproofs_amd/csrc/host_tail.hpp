@@ -114,9 +114,10 @@ static inline void tail_combine(uint8_t out[64], const bpmi::u32 *E, bpmi::u32 W
   pt_set_inf(acc);
   for (int w = (int)W - 1; w >= 0; w--) {
     int prev = (int)c;
+    const bpmi::u32 *offs = (to.top && w == (int)W - 1) ? to.top_off : to.off;      // (top2: the last window's own split offsets)
     for (int v = (int)to.nv - 1; v >= 0; v--) {
-      for (int k = prev; k > (int)to.off[v]; k--) pt_dbl(acc, acc);
-      prev = (int)to.off[v];
+      for (int k = prev; k > (int)offs[v]; k--) pt_dbl(acc, acc);
+      prev = (int)offs[v];
       pt e;
       pt_load(e, E + ((size_t)w * to.nv + v) * 36);
       pt_add(acc, acc, e);

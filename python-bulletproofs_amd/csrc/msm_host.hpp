@@ -60,7 +60,7 @@ static void msm_layout(const MsmGeom &g, MsmWs &w, char *base, bool glv = false)
   const u32 rec1_max = 2 * ((w.rec0_max + 255) / 256);
   // sort path 2 (LDS partition sort) when the bucket key has more than 8 bits and the
   // packed entry (8-bit lo | sign | 23-bit index) fits; path 1 (global atomics) otherwise
-  w.P = (g.c >= 10 && g.n <= (1u << 23)) ? g.W * (g.B >> 8) : 0;
+  w.P = (g.c >= 10 && g.n <= (1u << 23)) ? (g.G >> 8) : 0;
   w.hist = take(4ull * g.G);                 // path 1 only
   w.off = take(4ull * (g.G + 1));
   w.cursor = take(4ull * g.G);               // path 1 only
@@ -91,7 +91,7 @@ static u32 digit_group_log(u32 elements, u32 epl) {          // lanes per sum: e
   return gl;
 }
 static u32 digit_job_blocks(const DigitJobs &J, u32 k) {
-  const uint64_t lanes = (uint64_t)J.cnt * J.j[k].nsums << J.j[k].gl_log;
+  const uint64_t lanes = (uint64_t)J.j[k].cnt * J.j[k].nsums << J.j[k].gl_log;
   return (u32)((lanes + 255) / 256);
 }
 // the two jobs (by lo, by hi) that split every array [in_off .. in_off + N) of `cnt` arrays at bit s;
@@ -99,9 +99,10 @@ static u32 digit_job_blocks(const DigitJobs &J, u32 k) {
 static DigitJobs digit_jobs2(u32 cnt, u32 in_off, u32 in_stride, u32 N, u32 s, u32 out_off, u32 out_stride, u32 epl) {
   DigitJobs J;
   memset(&J, 0, sizeof(J));
-  J.cnt = cnt; J.njobs = 2;
+  J.njobs = 2;
   for (u32 type = 0; type < 2; type++) {
     DigitJob &j = J.j[type];
+    j.cnt = cnt;
     j.in_off = in_off; j.in_stride = in_stride; j.N = N; j.s = s; j.type = type;
     j.nsums = type ? (N >> s) : ((1u << s) - 1u);
     j.gl_log = digit_group_log(type ? (1u << s) : ((N - 1u) >> s) + 1u, epl);
@@ -169,7 +170,7 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, int slot, const Segs &segs_in, u
   pd.active = false;
   if (n == 0) return BPMI_OK;
   if (n > BPMI_MAX_N) return fail(ctx, BPMI_E_ARG, "n exceeds BPMI_MAX_N");
-  MsmGeom g;
+  MsmGeom g{};
   g.n = (u32)n;
   const uint64_t small_max = ctx->opt_small < 0 ? 0 : (ctx->opt_small ? (uint64_t)ctx->opt_small : SMALL_N_DEFAULT);
   // the one-block-per-window bucket kernel (k_msm_mid) between the small-MSM kernel and the pipeline
@@ -189,10 +190,16 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, int slot, const Segs &segs_in, u
   const bool glv = ctx->opt_glv > 0 && !small && wcount == 0 && n >= 2 && 2 * n <= (1ull << 23);
   if (glv) g.n = (u32)(2 * n);
   g.c = mid ? MID_C : (small ? SMALL_C : pick_window_bits(ctx, n));
-  g.W = wcount ? wcount : (glv ? 128u / g.c + 1u : 255u / g.c + 1u);
+  // c = 15 (255 = 17 c): 17 windows, the last one unsigned with 2B buckets, instead of 18 whose last holds one bucket of n / 2 carries
+  g.top2 = (g.c == 15u && !glv && !wcount && !mid && !small && ctx->opt_top2) ? 1u : 0u;
+  g.W = wcount ? wcount : (glv ? 128u / g.c + 1u : (g.top2 ? 255u / g.c : 255u / g.c + 1u));
   g.w0 = w0;
   g.B = 1u << (g.c - 1);
-  g.G = g.W * g.B;
+  g.G = (g.W + g.top2) * g.B;
+  // up to 2^17 pairs a partition of the sort (<= n entries: one window's) is sorted by ONE block whatever its size (k_fine_sort_part)
+  // (c = 16 only above 2^15: the short top window of c = 12 .. 14 is ONE partition of n entries by construction, and one block's two passes
+  // over 2^17 entries are 0.15 ms -- measured, profiles/r05_mid_size_ab.txt)
+  g.inblock = (ctx->opt_inblock && (n <= (1u << 15) || (g.c == 16u && n <= (1u << 17)))) ? 1u : 0u;
   // tools/tune_msm.py sweeps; on the two-lane pipeline 86 entries per thread fill the 3 waves per SIMD exactly once at n = 2^20
   // (profiles/r02_chunk_sweep_two_lanes.txt).  Round 3, at steady clocks (profiles/r03_chunk_sweep_steady_clocks.txt,
   // r03_chunk_length_vs_kernel_events.txt): L = 128 -- one round of TWO waves per SIMD, room for a 144-VGPR wave of the other lane's
@@ -278,7 +285,8 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, int slot, const Segs &segs_in, u
     segs.glv_sub = w.glv_sub; segs.glv_neg = w.glv_neg; segs.glv_bx = w.glv_bx;
   }
   TailOffs to;
-  to.nv = 1; to.off[0] = to.off[1] = to.off[2] = to.off[3] = 0;
+  memset(&to, 0, sizeof(to));
+  to.nv = 1;
   if (mid) {
     g.nv = 1;
     {
@@ -343,9 +351,9 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, int slot, const Segs &segs_in, u
       // (heavy partitions: counted and scattered by the tile kernels, which return at once when there are none)
       const u32 nft = (u32)(((size_t)g.n * g.W + FINE_TILE - 1) / FINE_TILE);
       const u32 *any_heavy = w.coarse_hist + PART_MAX;
-      hipLaunchKernelGGL(k_fine_hist_heavy, dim3(nft), dim3(256), 0, st, g, w.P, w.coarse_off, w.dig, w.coarse_off + w.P, any_heavy, w.hist);
+      if (!g.inblock) hipLaunchKernelGGL(k_fine_hist_heavy, dim3(nft), dim3(256), 0, st, g, w.P, w.coarse_off, w.dig, w.coarse_off + w.P, any_heavy, w.hist);
       hipLaunchKernelGGL(k_fine_sort_part, dim3(w.P), dim3(FINE_THREADS), 0, st, g, w.coarse_off, w.dig, w.hist, w.off, w.cursor, w.chunk_key, w.sidx, w.buckets);
-      hipLaunchKernelGGL(k_fine_scatter_heavy, dim3(nft), dim3(256), 0, st, g, w.P, w.coarse_off, w.dig, w.coarse_off + w.P, any_heavy, w.cursor, w.sidx);
+      if (!g.inblock) hipLaunchKernelGGL(k_fine_scatter_heavy, dim3(nft), dim3(256), 0, st, g, w.P, w.coarse_off, w.dig, w.coarse_off + w.P, any_heavy, w.cursor, w.sidx);
     }
     debug_sync(ctx, "ST_SCATTER", st);
   } else {
@@ -384,12 +392,15 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, int slot, const Segs &segs_in, u
     StageTimer t(ctx, ST_SEGSCAN, st);
     u32 R = w.rec0_max;
     int level = 1, src = 0;
+    // the ticket word of the last-block-done fusion (zeroed by the memset above; sort path 2 only, first level only)
+    u32 *ticket = (w.P && ctx->opt_segfuse) ? w.coarse_hist + PART_MAX + 1 : nullptr;
     for (;;) {
       const u32 nb = (R + 255) / 256;
+      if (nb > 128u || nb <= 1u) ticket = nullptr;      // (the kernel's own block count is at most this one: fewer entries than the bound)
       hipLaunchKernelGGL(k_segscan, dim3(nb), dim3(256), 0, st, g, w.off, level, w.rec_key[src], w.rec_pt[src],
-                         w.rec_key[src ^ 1], w.rec_pt[src ^ 1], w.buckets);
+                         w.rec_key[src ^ 1], w.rec_pt[src ^ 1], w.buckets, ticket);
       if (g_debug_sync) { fprintf(stderr, "[bpmi] segscan level %d nb %u R %u\n", level, nb, R); debug_sync(ctx, "segscan level", st); }
-      if (nb <= 1) break;
+      if (nb <= 1 || ticket) break;
       R = 2 * nb;
       // ping-pong: level 1 reads buffer 0 (large) and writes buffer 1; later levels are
       // small enough for either buffer (rec1_max >= every later level)
@@ -413,19 +424,35 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, int slot, const Segs &segs_in, u
       // stage 1: as many elements per lane as keep about one wave on every SIMD (16 at c = 16 with all 16 windows: measured
       // best of 4 / 8 / 12 / 16 there; fewer buckets -- smaller c, a window group of a split MSM -- get shorter chains
       // instead of idle SIMDs); stage 2 + the finish are pure latency: one element per lane, 16-lane butterflies, one launch
-      u32 epl = ctx->opt_epl > 0 ? (u32)ctx->opt_epl : (u32)(((uint64_t)g.W * g.B) >> 15);
+      const u32 Wr = g.W - g.top2;                       // windows with B buckets
+      u32 epl = ctx->opt_epl > 0 ? (u32)ctx->opt_epl : (u32)(((uint64_t)g.G) >> 15);
       epl = epl < 2u ? 2u : (epl > 16u ? 16u : epl);
-      DigitJobs j1 = digit_jobs2(g.W, 0, g.B, g.B, s0, 0, stride1, epl);
+      DigitJobs j1 = digit_jobs2(Wr, 0, g.B, g.B, s0, 0, stride1, epl);
+      // stage 2: D0 -> (D00, D01), D1 -> (D10, D11), each <= 16 sums of <= 16 elements, and E[a][r] = sum_d d * D..[d]
+      DigitJobs ja = digit_jobs2(Wr, 0, stride1, N0, t0, 0, 64, 1);
+      DigitJobs jb = digit_jobs2(Wr, N0, stride1, N1, t1, 0, 64, 1);
+      DigitJobs j2 = digit_jobs_concat(ja, jb), j2top;
+      memset(&j2top, 0, sizeof(j2top));
+      to.nv = 4; to.off[0] = 0; to.off[1] = t0; to.off[2] = s0; to.off[3] = s0 + t1;
+      if (g.top2) {
+        // the unsigned last window: ONE array of 2B buckets behind the others, split like a window of c + 1 bits (its D sums fit the
+        // per-window slot of w.D: 2^((c+1)/2) + 2^(c/2) records)
+        const u32 Bt = 2u * g.B, s0t = (g.c + 1u) / 2u, N0t = (1u << s0t) - 1u, N1t = Bt >> s0t;
+        const u32 t0t = (s0t + 1u) / 2u, t1t = (msb_index(N1t) + 1u) / 2u;
+        const u32 d_top = Wr * stride1;                  // first D record of the top window
+        DigitJobs jt = digit_jobs2(1, Wr * g.B, 0, Bt, s0t, d_top, 0, epl);
+        j1 = digit_jobs_concat(j1, jt);
+        DigitJobs jta = digit_jobs2(1, d_top, 0, N0t, t0t, 0, 64, 1);
+        DigitJobs jtb = digit_jobs2(1, d_top + N0t, 0, N1t, t1t, 0, 64, 1);
+        j2top = digit_jobs_concat(jta, jtb);
+        to.top = 1; to.top_off[0] = 0; to.top_off[1] = t0t; to.top_off[2] = s0t; to.top_off[3] = s0t + t1t;
+      }
       j1.prio = g.prio;
       hipLaunchKernelGGL(k_digit_sums, dim3(j1.j[j1.njobs - 1].blk0 + digit_job_blocks(j1, j1.njobs - 1)), dim3(256), 0, st, w.buckets, w.D, j1);
-      // stage 2: D0 -> (D00, D01), D1 -> (D10, D11), each <= 16 sums of <= 16 elements, and E[a][r] = sum_d d * D..[d]
-      DigitJobs ja = digit_jobs2(g.W, 0, stride1, N0, t0, 0, 64, 1);
-      DigitJobs jb = digit_jobs2(g.W, N0, stride1, N1, t1, 0, 64, 1);
-      DigitJobs j2 = digit_jobs_concat(ja, jb);
-      j2.prio = g.prio;
-      if (ctx->opt_quad) hipLaunchKernelGGL(k_digit_final_quad, dim3(g.W * 4u), dim3(1024), 0, st, w.D, E_red, j2);
-      else hipLaunchKernelGGL(k_digit_final, dim3(g.W * 4u), dim3(256), 0, st, w.D, E_red, j2);
-      to.nv = 4; to.off[0] = 0; to.off[1] = t0; to.off[2] = s0; to.off[3] = s0 + t1;
+      j2.prio = j2top.prio = g.prio;
+      const u32 top_w = g.top2 ? Wr : 0xFFFFFFFFu;
+      if (ctx->opt_quad) hipLaunchKernelGGL(k_digit_final_quad, dim3(g.W * 4u), dim3(1024), 0, st, w.D, E_red, j2, j2top, top_w);
+      else hipLaunchKernelGGL(k_digit_final, dim3(g.W * 4u), dim3(256), 0, st, w.D, E_red, j2, j2top, top_w);
     }
   }
   debug_sync(ctx, "ST_BREDUCE", st);
@@ -573,7 +600,8 @@ static int msm_enqueue_small_pair(bpmi_ctx *ctx, const Segs &s0, const Segs &s1,
   }
   debug_sync(ctx, "k_msm_small_pair / k_msm_mid", st);
   TailOffs to;
-  to.nv = 1; to.off[0] = to.off[1] = to.off[2] = to.off[3] = 0;
+  memset(&to, 0, sizeof(to));
+  to.nv = 1;
   // a failure from here on leaves none of THIS call's slots pending (both were free on entry: nobody else's is touched)
   unsigned mine = 0;
   auto queue_results = [&]() -> int {

@@ -16,6 +16,10 @@ struct MsmGeom {
   u32 nv;      // partial sums per window that the bucket reduction hands to the tail (1 or 4)
   u32 prio;    // 1: every kernel but the accumulation raises its waves' issue priority (see raise_priority)
   u32 fuse;    // 1: k_accum_l0 folds the partial records of a wave's 64 chunks itself (two records per WAVE go to k_segscan, not two per thread)
+  u32 top2;    // 1 (c = 15 only: 255 = 17 c): the LAST window is not recoded -- its digit t in [0, 2B] is kept unsigned and owns 2B buckets
+               // (keys [(W-1) B, (W+1) B)), so there is no carry window: W = 255 / c windows, G = (W + 1) B
+  u32 inblock; // 1 (n <= 2^17): k_fine_sort_part sorts a partition of ANY size itself (a heavy one without the LDS staging buffer);
+               // the two tile kernels for heavy partitions are not launched
 };
 // Experiment (option "priority", default off; profiles/r03_wave_priority_ab.txt).  The stages around the accumulation are chains
 // of dependent work with few waves; beside the OTHER lane's accumulation (three busy waves on every SIMD) they stretch three- to
@@ -59,8 +63,8 @@ __device__ __forceinline__ bool for_each_digit_raw(const Segs &segs, const MsmGe
     for (int k = 0; k < 7; k++) s.v[k] = (u32)((((u64)s.v[k + 1] << 32) | s.v[k]) >> g.c);
     s.v[7] >>= g.c;
     u32 b, sign;
-    if (t > g.B) { b = (1u << g.c) - t; sign = 1; carry = 1; }
-    else { b = t; sign = 0; carry = 0; }
+    if (t > g.B && !(g.top2 && w + 1u == wend)) { b = (1u << g.c) - t; sign = 1; carry = 1; }
+    else { b = t; sign = 0; carry = 0; }              // (top2: the last window keeps t in [0, 2B] as it is)
     if (w >= g.w0) f(w - g.w0, b, b ? sign : 0u);
   }
   return neg;
@@ -79,8 +83,8 @@ __device__ __forceinline__ void for_each_digit(const Segs &segs, const MsmGeom &
     for (int k = 0; k < 7; k++) s.v[k] = (u32)((((u64)s.v[k + 1] << 32) | s.v[k]) >> g.c);
     s.v[7] >>= g.c;
     u32 b, sign;
-    if (t > g.B) { b = (1u << g.c) - t; sign = 1; carry = 1; }
-    else { b = t; sign = 0; carry = 0; }
+    if (t > g.B && !(g.top2 && w + 1u == wend)) { b = (1u << g.c) - t; sign = 1; carry = 1; }
+    else { b = t; sign = 0; carry = 0; }              // (top2: the last window keeps t in [0, 2B] as it is)
     if (w >= g.w0) f(w - g.w0, b, b ? (sign ^ (u32)neg) : 0u);      // lower windows only feed the carry
   }
 }
@@ -203,9 +207,10 @@ __global__ void __launch_bounds__(1024) k_partition(MsmGeom g, u32 P, u32 TS, co
   raise_priority(g.prio);
   __shared__ u32 cnt[128], excl[128], delta[128];
   __shared__ u32 s_out[PT_MAX];
-  const u32 Bc = g.B >> 8, w = blockIdx.y, tid = threadIdx.x;
+  const u32 w = blockIdx.y, tid = threadIdx.x;
+  const u32 Bc0 = g.B >> 8, Bc = (g.top2 && w + 1u == g.W) ? 2u * Bc0 : Bc0;       // partitions of this window (top2: the last one owns 2B buckets; <= 128)
   const u32 lin = blockIdx.y * gridDim.x + blockIdx.x, nblk = gridDim.x * gridDim.y;
-  for (u32 p = lin; p < P; p += nblk) {
+  if (!g.inblock) for (u32 p = lin; p < P; p += nblk) {
     if (coarse_off[p + 1] - coarse_off[p] > FINE_CAP) {        // block-uniform
       if (tid < 256u) fine_hist[p * 256u + tid] = 0;
       if (tid == 0) *any_heavy = 1u;
@@ -236,7 +241,7 @@ __global__ void __launch_bounds__(1024) k_partition(MsmGeom g, u32 P, u32 TS, co
     const u32 start = excl[tid] - c;
     excl[tid] = start;
     cnt[tid] = start;                                          // LDS write cursor of the partition
-    if (c) delta[tid] = atomicAdd(&coarse_cursor[w * Bc + tid], c) - start;
+    if (c) delta[tid] = atomicAdd(&coarse_cursor[w * Bc0 + tid], c) - start;
   }
   __syncthreads();
   for (u32 i = i0 + tid; i < i1; i += blockDim.x) {
@@ -281,6 +286,31 @@ __device__ __forceinline__ void fill_chunk_keys(u32 *__restrict__ chunk_key, u32
 // tile-based version: 0.125 ms of its 0.15 ms at n = 2^20).  For a partition larger than the
 // staging buffer the block only turns the counts of k_fine_hist_heavy into offsets.
 #define FINE_THREADS 512
+// bins[bin]++ and the old value.  A partition that outgrew the staging buffer is a few buckets with thousands of entries each (equal
+// scalars, bit vectors): the lanes of a wave that name the same bin share ONE atomic -- up to four such groups per call, whoever is
+// left takes its own (tens of thousands of increments of one LDS word otherwise)
+__device__ __forceinline__ u32 lds_take_slot(u32 *bins, u32 bin) {
+  const u32 lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  u32 pos = 0;
+  bool done = false;
+  for (int it = 0; it < 4; it++) {
+    const unsigned long long rem = __ballot(!done);
+    if (rem == 0ull) break;
+    const u32 first = (u32)__shfl((int)bin, __ffsll((long long)rem) - 1, 64);
+    const bool match = !done && bin == first;
+    const unsigned long long m = __ballot(match);
+    if (match) {
+      const u32 rank = (u32)__popcll(m & ((1ull << lane) - 1ull));
+      u32 basepos = 0;
+      if (rank == 0) basepos = atomicAdd(&bins[first], (u32)__popcll(m));
+      basepos = (u32)__shfl((int)basepos, __ffsll((long long)m) - 1, 64);
+      pos = basepos + rank;
+      done = true;
+    }
+  }
+  if (!done) pos = atomicAdd(&bins[bin], 1u);
+  return pos;
+}
 __global__ void __launch_bounds__(FINE_THREADS) k_fine_sort_part(MsmGeom g, const u32 *__restrict__ coarse_off, const u32 *__restrict__ part,
                                                                   const u32 *__restrict__ fine_hist, u32 *__restrict__ off, u32 *__restrict__ cursor,
                                                                   u32 *__restrict__ chunk_key, u32 *__restrict__ sidx, u32 *__restrict__ buckets) {
@@ -289,11 +319,13 @@ __global__ void __launch_bounds__(FINE_THREADS) k_fine_sort_part(MsmGeom g, cons
   __shared__ u32 s_out[FINE_CAP];
   const u32 p = blockIdx.x, tid = threadIdx.x;
   const u32 base = coarse_off[p], m = coarse_off[p + 1] - base;
-  const bool heavy = m > FINE_CAP;               // counted by k_fine_hist_heavy, scattered by k_fine_scatter_heavy
+  const bool big = m > FINE_CAP;                 // does not fit the staging buffer (skewed digits only)
+  const bool heavy = big && !g.inblock;          // counted by k_fine_hist_heavy, scattered by k_fine_scatter_heavy
   if (tid < 256u) bins[tid] = heavy ? fine_hist[p * 256u + tid] : 0u;
   __syncthreads();
   if (!heavy) {
-    for (u32 i = tid; i < m; i += FINE_THREADS) atomicAdd(&bins[part[base + i] >> 24], 1u);
+    if (big) for (u32 i = tid; i < m; i += FINE_THREADS) (void)lds_take_slot(bins, part[base + i] >> 24);
+    else for (u32 i = tid; i < m; i += FINE_THREADS) atomicAdd(&bins[part[base + i] >> 24], 1u);
     __syncthreads();
   }
   // exclusive prefix over the 256 bins (threads 0..255; Hillis-Steele in place)
@@ -322,6 +354,15 @@ __global__ void __launch_bounds__(FINE_THREADS) k_fine_sort_part(MsmGeom g, cons
   __syncthreads();
   if (tid < 256u) bins[tid] -= cnt;            // bins = tile-local write cursor of every bucket
   __syncthreads();
+  if (big) {
+    // inblock (n <= 2^17: a partition has at most n entries): this block scatters the partition straight to memory -- two passes of
+    // at most 256 entries per thread instead of two more launches on the path of EVERY mid-sized MSM
+    for (u32 i = tid; i < m; i += FINE_THREADS) {
+      const u32 e = part[base + i];
+      sidx[base + lds_take_slot(bins, e >> 24)] = (e & 0x7FFFFFu) | ((e & 0x800000u) << 8);
+    }
+    return;
+  }
   for (u32 i = tid; i < m; i += FINE_THREADS) {
     const u32 e = part[base + i];
     s_out[atomicAdd(&bins[e >> 24], 1u)] = (e & 0x7FFFFFu) | ((e & 0x800000u) << 8);
@@ -687,58 +728,76 @@ __device__ __forceinline__ u32 records_at_level(u32 E, u32 L, u32 fuse, int leve
 }
 
 // ---- levels >= 1: block-wide segmented scan over partial records -------------------------
+// `ticket` (round 5; nullptr = off): when this level leaves at most 256 records (nb <= 128 blocks), the block that finishes LAST
+// runs the final level itself instead of a second launch of one block (8 us on the path of every MSM up to ~2^21 pairs: the fused
+// wave scan of k_accum_l0 leaves two records per wave, so level 1 has <= 128 blocks up to 16 384 waves).  The ticket word is
+// zeroed by the MSM's memset and left at nb.
 __global__ void __launch_bounds__(256) k_segscan(MsmGeom g, const u32 *__restrict__ off, int level,
-                                                 const u32 *__restrict__ in_key, const u32 *__restrict__ in_pt,
-                                                 u32 *__restrict__ out_key, u32 *__restrict__ out_pt, u32 *__restrict__ buckets) {
+                                                 const u32 *in_key, const u32 *in_pt,
+                                                 u32 *out_key, u32 *out_pt, u32 *__restrict__ buckets, u32 *ticket) {
   raise_priority(g.prio);
   __shared__ u32 s_key[256];
   __shared__ u32 s_val[256 * LDS_STRIDE];
+  __shared__ u32 s_last;
   bool is_final;
-  const u32 R = records_at_level(off[g.G], g.L, g.fuse, level, is_final);
-  const u32 nb = (R + 255u) / 256u;
+  u32 R = records_at_level(off[g.G], g.L, g.fuse, level, is_final);
+  u32 nb = (R + 255u) / 256u;
   if (blockIdx.x >= nb) return;
   const u32 tid = threadIdx.x;
-  const u32 j = blockIdx.x * 256u + tid;
-  const bool valid = j < R;
-  const u32 key = valid ? in_key[j] : 0xFFFFFFFFu;
-  xyzz val;
-  if (valid) xyzz_load_g(val, in_pt + (u64)j * XYZZ_WORDS); else xyzz_set_inf(val);
-  s_key[tid] = key;
-  __syncthreads();
-  for (u32 d = 1; d < 256; d <<= 1) {
-    // the records are in bucket order, so equal keys are contiguous: when no thread of the block
-    // finds its key at distance d, none will at 2d, 4d, ... (uniform scalars stop after d = 1 or 2)
-    const bool act = valid && tid >= d && s_key[tid - d] == key;
-    if (!__syncthreads_or(act)) break;
-    xyzz_store(s_val + tid * LDS_STRIDE, val);
+  u32 blk = blockIdx.x;
+  for (;;) {
+    const u32 j = blk * 256u + tid;
+    const bool valid = j < R;
+    const u32 key = valid ? in_key[j] : 0xFFFFFFFFu;
+    xyzz val;
+    if (valid) xyzz_load_g(val, in_pt + (u64)j * XYZZ_WORDS); else xyzz_set_inf(val);
+    s_key[tid] = key;
     __syncthreads();
-    if (act) {
-      xyzz other;
-      xyzz_load(other, s_val + (tid - d) * LDS_STRIDE);
-      xyzz_add(val, other, val);
+    for (u32 d = 1; d < 256; d <<= 1) {
+      // the records are in bucket order, so equal keys are contiguous: when no thread of the block
+      // finds its key at distance d, none will at 2d, 4d, ... (uniform scalars stop after d = 1 or 2)
+      const bool act = valid && tid >= d && s_key[tid - d] == key;
+      if (!__syncthreads_or(act)) break;
+      xyzz_store(s_val + tid * LDS_STRIDE, val);
+      __syncthreads();
+      if (act) {
+        xyzz other;
+        xyzz_load(other, s_val + (tid - d) * LDS_STRIDE);
+        xyzz_add(val, other, val);
+      }
+      __syncthreads();
     }
+    const u32 last_idx = (R - blk * 256u >= 256u) ? 255u : (R - blk * 256u - 1u);
+    const bool run_end = valid && ((tid == last_idx) || (s_key[tid + (tid < 255u ? 1u : 0u)] != key));
+    if (run_end) {
+      const u32 first_key = s_key[0], last_key = s_key[last_idx];
+      // One store site with a per-thread destination.  (A three-way if/else over
+      // buckets / head record / tail record made hipcc 7.2 merge the stores behind
+      // scalar base-pointer selects in divergent flow, and the multi-block case faulted
+      // on gfx950; tests/test_gpu_msm.py::test_msm_multiblock_segscan pins this.)
+      const bool to_bucket = is_final || (key != first_key && key != last_key);
+      const bool is_head = !to_bucket && (key == first_key);
+      const u32 slot = 2u * blk + (is_head ? 0u : 1u);
+      u32 *dst = to_bucket ? buckets + (u64)key * XYZZ_WORDS : out_pt + (u64)slot * XYZZ_WORDS;
+      if (!to_bucket) out_key[slot] = key;
+      xyzz_store_g(dst, val);
+      if (is_head && first_key == last_key) {       // the block is one single run: empty tail record
+        xyzz inf;
+        xyzz_set_inf(inf);
+        out_key[slot + 1u] = key;
+        xyzz_store_g(out_pt + (u64)(slot + 1u) * XYZZ_WORDS, inf);
+      }
+    }
+    if (is_final || !ticket || nb > 128u) return;            // (block-uniform)
+    // the last block to get here owns the final level: its records are this level's output, complete and visible
+    __threadfence();
     __syncthreads();
-  }
-  if (!valid) return;
-  const u32 last_idx = (R - blockIdx.x * 256u >= 256u) ? 255u : (R - blockIdx.x * 256u - 1u);
-  const bool run_end = (tid == last_idx) || (s_key[tid + 1] != key);
-  if (!run_end) return;
-  const u32 first_key = s_key[0], last_key = s_key[last_idx];
-  // One store site with a per-thread destination.  (A three-way if/else over
-  // buckets / head record / tail record made hipcc 7.2 merge the stores behind
-  // scalar base-pointer selects in divergent flow, and the multi-block case faulted
-  // on gfx950; tests/test_gpu_msm.py::test_msm_multiblock_segscan pins this.)
-  const bool to_bucket = is_final || (key != first_key && key != last_key);
-  const bool is_head = !to_bucket && (key == first_key);
-  const u32 slot = 2u * blockIdx.x + (is_head ? 0u : 1u);
-  u32 *dst = to_bucket ? buckets + (u64)key * XYZZ_WORDS : out_pt + (u64)slot * XYZZ_WORDS;
-  if (!to_bucket) out_key[slot] = key;
-  xyzz_store_g(dst, val);
-  if (is_head && first_key == last_key) {       // the block is one single run: empty tail record
-    xyzz inf;
-    xyzz_set_inf(inf);
-    out_key[slot + 1u] = key;
-    xyzz_store_g(out_pt + (u64)(slot + 1u) * XYZZ_WORDS, inf);
+    if (tid == 0) s_last = (atomicAdd(ticket, 1u) == nb - 1u) ? 1u : 0u;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    R = 2u * nb; nb = 1; blk = 0; is_final = true;
+    in_key = out_key; in_pt = out_pt;
   }
 }
 
@@ -772,8 +831,9 @@ struct DigitJob {
   u32 nsums;                 // sums per array: 2^s - 1 (type 0) or N >> s (type 1)
   u32 out_off, out_stride;   // sum idx (1-based) of array a -> record a * out_stride + out_off + idx - 1 of D
   u32 blk0;                  // first block of this job
+  u32 cnt;                   // arrays (windows) of this job
 };
-struct DigitJobs { DigitJob j[4]; u32 njobs, cnt, prio; };
+struct DigitJobs { DigitJob j[4]; u32 njobs, prio; };
 
 __device__ __forceinline__ void xyzz_shfl_xor(xyzz &r, const xyzz &a, int mask) {
 #pragma unroll
@@ -802,12 +862,12 @@ __global__ void __launch_bounds__(256) k_digit_sums(const u32 *__restrict__ X, u
   const u32 t = (blockIdx.x - J.blk0) * blockDim.x + threadIdx.x;
   const u32 GL = 1u << J.gl_log;
   const u32 sum_id = t >> J.gl_log, l = t & (GL - 1u);
-  const bool active = sum_id < jobs.cnt * J.nsums;
+  const bool active = sum_id < J.cnt * J.nsums;
   const u32 a = sum_id / J.nsums, idx = sum_id % J.nsums + 1u;
   xyzz acc;
   xyzz_set_inf(acc);
+  const u32 *base = X + ((u64)a * J.in_stride + J.in_off) * XYZZ_WORDS;
   if (active) {
-    const u32 *base = X + ((u64)a * J.in_stride + J.in_off) * XYZZ_WORDS;
     if (J.type == 0) {
       for (u32 hi = l; ((hi << J.s) | idx) <= J.N; hi += GL) {
         xyzz x;
@@ -833,11 +893,14 @@ __global__ void __launch_bounds__(256) k_digit_sums(const u32 *__restrict__ X, u
 // elements of sum j + 1 of the array's digit job with a butterfly, parks it in LDS, and the first 16 lanes turn the (<= 16)
 // sums into sum_d d * X[d]: inclusive suffix scan (4 steps), then the sum of all suffixes (4 steps).  E[a][r] out.  Saves a launch and the trip of 64 records per window
 // through HBM on a path that is nothing but latency.
-__global__ void __launch_bounds__(256) k_digit_final(const u32 *__restrict__ X, u32 *__restrict__ Eout, DigitJobs jobs) {
+// (top2: window `top_w` has 2B buckets and its own job set `jtop`, its arrays numbered from 0; top_w = ~0: none)
+__global__ void __launch_bounds__(256) k_digit_final(const u32 *__restrict__ X, u32 *__restrict__ Eout, DigitJobs jobs, DigitJobs jtop, u32 top_w) {
   raise_priority(jobs.prio);
   __shared__ u32 s_val[16 * LDS_STRIDE];
-  const u32 a = blockIdx.x >> 2, r = blockIdx.x & 3u, tid = threadIdx.x;
-  const DigitJob J = jobs.j[r];
+  const u32 r = blockIdx.x & 3u, tid = threadIdx.x;
+  const bool is_top = (blockIdx.x >> 2) == top_w;
+  const u32 a = is_top ? 0u : (blockIdx.x >> 2);
+  const DigitJob J = is_top ? jtop.j[r] : jobs.j[r];
   const u32 idx = (tid >> 4) + 1u, l = tid & 15u;
   xyzz acc;
   xyzz_set_inf(acc);
@@ -983,10 +1046,12 @@ __device__ __forceinline__ void quad_add(fe &a, const fe &b, u32 q) {
 // k_digit_final on quads: block (array r of window a) = 16 waves; wave j adds up the (<= 16) elements of sum j + 1, one element
 // per QUAD of lanes, with a butterfly of quad additions, parks it in LDS, and the first wave turns the (<= 16) sums into
 // sum_d d * X[d] (suffix scan over quads, then the sum of all suffixes).  The same 12 dependent additions, each 4 levels deep.
-__global__ void __launch_bounds__(1024) k_digit_final_quad(const u32 *__restrict__ X, u32 *__restrict__ Eout, DigitJobs jobs) {
+__global__ void __launch_bounds__(1024) k_digit_final_quad(const u32 *__restrict__ X, u32 *__restrict__ Eout, DigitJobs jobs, DigitJobs jtop, u32 top_w) {
   __shared__ u32 s_val[16 * XYZZ_WORDS];
-  const u32 a_idx = blockIdx.x >> 2, r = blockIdx.x & 3u, tid = threadIdx.x;
-  const DigitJob J = jobs.j[r];
+  const u32 r = blockIdx.x & 3u, tid = threadIdx.x;
+  const bool is_top = (blockIdx.x >> 2) == top_w;
+  const u32 a_idx = is_top ? 0u : (blockIdx.x >> 2);
+  const DigitJob J = is_top ? jtop.j[r] : jobs.j[r];
   const u32 wave = tid >> 6, lane = tid & 63u, e = lane >> 2, q = lane & 3u;
   const u32 idx = wave + 1u;
   fe a;
@@ -1387,7 +1452,9 @@ BPMI_HD void msm_tail_combine(u32 out_words[16], const u32 *E, u32 W, u32 c, con
     if (r == 0) { w--; r = c; }
     r--;
     xyzz_dbl(acc, acc);
-    const u32 v = r == o0 ? 0u : r == o1 ? 1u : r == o2 ? 2u : r == o3 ? 3u : 4u;
+    const bool tw = to.top && w + 1u == W;            // the unsigned last window (top2) was split at its own bit offsets
+    const u32 v = tw ? (r == to.top_off[0] ? 0u : r == to.top_off[1] ? 1u : r == to.top_off[2] ? 2u : r == to.top_off[3] ? 3u : 4u)
+                     : (r == o0 ? 0u : r == o1 ? 1u : r == o2 ? 2u : r == o3 ? 3u : 4u);
     if (v < 4u) {
       xyzz e;
       xyzz_load(e, E + ((u64)w * to.nv + v) * XYZZ_WORDS);

@@ -1,0 +1,292 @@
+// rp_prove_host.hpp -- part of libbpmi (included by bpmi.hip; one translation unit).  HOST code.
+// The batched range-proof prover's object and launch sequence (kernels: rp_prove_kernels.hpp): bpmi_rp_prover_create builds the
+// fixed-base tables of a generator set once; bpmi_rp_prove_batch proves any number of single-value proofs over them, every protocol
+// step as one launch over the whole batch, and returns the proofs as wire format 2.
+#pragma once
+
+struct bpmi_rp_prover {
+  bpmi_ctx *ctx = nullptr;
+  u32 n = 0, k = 0, nbases = 0;
+  u32 *table = nullptr;                        // [(3 + 2n)][32][128] affine points
+  unsigned short *bases = nullptr;             // device: the base lists of every job kind (offsets below, in entries)
+  u32 off_S = 0, off_T = 0, off_P = 0, off_round = 0;
+  rpp::sc x_ip;                                // mod_hash(b"&", q): the Protocol-1 challenge of an empty seed (the same for every proof)
+  std::string ip_prefix;                       // "&&" str(x_ip) "&"
+  unsigned char *d_ip_prefix = nullptr;
+  u32 u_new[16];                               // x_ip u, affine words
+  void *buf = nullptr; size_t buf_bytes = 0;   // the batch's device arrays (grown on demand)
+  void *pin = nullptr; size_t pin_bytes = 0;   // page-locked staging of the inputs / the proofs
+  double last_ms[8] = {0};                     // device milliseconds of the last batch: blind+A/S | y,z+T | x+final+P_new | rounds | emit+copy | total
+};
+
+namespace rpp_host {
+
+static inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// decimal text of a 256-bit little-endian value
+static std::string decimal_of(const uint8_t le[32]) {
+  rp::Sq v;
+  rp::q_from_le(v, le);
+  std::vector<uint8_t> dg;
+  rpt::append_decimal(dg, v);
+  return std::string((const char *)dg.data(), dg.size() - 1);
+}
+static std::string b64(const uint8_t *p, size_t n) {
+  static const char T[] = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/";
+  std::string o;
+  o.reserve((n + 2) / 3 * 4);
+  for (size_t i = 0; i < n; i += 3) {
+    const uint32_t a = p[i], b = i + 1 < n ? p[i + 1] : 0, c = i + 2 < n ? p[i + 2] : 0;
+    const uint32_t v = (a << 16) | (b << 8) | c;
+    o.push_back(T[v >> 18]); o.push_back(T[(v >> 12) & 63]);
+    o.push_back(i + 1 < n ? T[(v >> 6) & 63] : '='); o.push_back(i + 2 < n ? T[v & 63] : '=');
+  }
+  return o;
+}
+
+}  // namespace rpp_host
+
+extern "C" {
+
+void bpmi_rp_prover_destroy(bpmi_rp_prover *pv) {
+  if (!pv) return;
+  if (pv->ctx) { (void)hipSetDevice(pv->ctx->device); (void)hipStreamSynchronize(pv->ctx->stream); }
+  if (pv->table) (void)hipFree(pv->table);
+  if (pv->bases) (void)hipFree(pv->bases);
+  if (pv->d_ip_prefix) (void)hipFree(pv->d_ip_prefix);
+  if (pv->buf) (void)hipFree(pv->buf);
+  if (pv->pin) (void)hipHostFree(pv->pin);
+  delete pv;
+}
+
+int bpmi_rp_prover_create(bpmi_ctx *ctx, uint32_t nbits, const uint8_t g[64], const uint8_t h[64], const uint8_t u[64], const uint8_t *gs, const uint8_t *hs,
+                          bpmi_rp_prover **out) {
+  if (!ctx || !g || !h || !u || !gs || !hs || !out) return ctx ? fail(ctx, BPMI_E_ARG, "null argument") : BPMI_E_ARG;
+  *out = nullptr;
+  if (nbits < 2 || nbits > 128 || (nbits & (nbits - 1))) return fail(ctx, BPMI_E_ARG, "the bit width must be a power of two in [2, 128]");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  bpmi_rp_prover *pv = new bpmi_rp_prover();
+  pv->ctx = ctx; pv->n = nbits; pv->k = 0;
+  while ((1u << pv->k) < nbits) pv->k++;
+  const u32 n = nbits, nb = 3 + 2 * n;
+  pv->nbases = nb;
+  auto bail = [&](int rc) { bpmi_rp_prover_destroy(pv); return rc; };
+  // the Protocol-1 challenge of the empty seed: transcript b"&" (inner_product_prover.py:33; transcript.py:13-14)
+  {
+    const uint8_t amp = '&';
+    rp::Sha one;
+    rp::sha_init(one);
+    rp::sha_update(one, (const uint8_t *)"1", 1);
+    rp::sha_update(one, &amp, 1);
+    rp::Sq x;
+    rp::mod_hash_q(x, one, &amp, 1);
+    uint8_t le[32];
+    rp::q_to_le(le, x);
+    memcpy(pv->x_ip.v, le, 32);
+    pv->ip_prefix = "&&" + rpp_host::decimal_of(le) + "&";
+  }
+  // points of the bases, the table's inputs and the table: entry (b, k, d) = d 2^(8k) base_b by the engine's batched multiplication
+  const size_t entries = (size_t)nb * PV_WT * PV_BT;
+  std::vector<uint8_t> basepts(64 * (size_t)nb);
+  memcpy(&basepts[0], g, 64); memcpy(&basepts[64], h, 64); memcpy(&basepts[128], u, 64);
+  memcpy(&basepts[192], gs, 64 * (size_t)n); memcpy(&basepts[192 + 64 * (size_t)n], hs, 64 * (size_t)n);
+  u32 *d_base = nullptr, *d_pts = nullptr, *d_sc = nullptr;
+  hipError_t e = hipMalloc(&d_base, 64 * (size_t)nb + 96);
+  if (e == hipSuccess) e = hipMalloc(&d_pts, 64 * entries);
+  if (e == hipSuccess) e = hipMalloc(&d_sc, 32 * entries);
+  if (e == hipSuccess) e = hipMalloc(&pv->table, 64 * entries);
+  auto free_tmp = [&]() { if (d_base) (void)hipFree(d_base); if (d_pts) (void)hipFree(d_pts); if (d_sc) (void)hipFree(d_sc); };
+  if (e != hipSuccess) { free_tmp(); return bail(fail(ctx, BPMI_E_NOMEM, std::string("bpmi_rp_prover_create: ") + hipGetErrorString(e))); }
+  e = hipMemcpyAsync(d_base, basepts.data(), basepts.size(), hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);          // (basepts is pageable and local)
+  if (e != hipSuccess) { free_tmp(); return bail(fail(ctx, BPMI_E_HIP, std::string("bpmi_rp_prover_create: ") + hipGetErrorString(e))); }
+  hipLaunchKernelGGL(rpp::k_pv_table_scalars, dim3((u32)((entries + 255) / 256)), dim3(256), 0, ctx->stream, d_base, nb, d_pts, d_sc);
+  int rc = bpmi_ec_mul_batch_dev(ctx, d_pts, d_sc, entries, pv->table);
+  // u_new = x_ip u
+  if (rc == BPMI_OK) {
+    e = hipMemcpyAsync((char *)d_base + 64 * (size_t)nb, pv->x_ip.v, 32, hipMemcpyHostToDevice, ctx->stream);
+    if (e != hipSuccess) rc = fail(ctx, BPMI_E_HIP, hipGetErrorString(e));
+  }
+  if (rc == BPMI_OK) rc = bpmi_ec_mul_batch_dev(ctx, (char *)d_base + 128, (char *)d_base + 64 * (size_t)nb, 1, (char *)d_base + 64 * (size_t)nb + 32);
+  if (rc == BPMI_OK) {
+    e = hipMemcpyAsync(pv->u_new, (char *)d_base + 64 * (size_t)nb + 32, 64, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) rc = fail(ctx, BPMI_E_HIP, hipGetErrorString(e));
+  }
+  free_tmp();
+  if (rc) return bail(rc);
+  // base lists: S / P_new: gs_0.., hs_0.., then h (S) or u (P_new); T: g, h; round r: L then R (rp_prove_kernels.hpp k_pv_round_scalars)
+  std::vector<unsigned short> bl;
+  pv->off_S = 0;
+  for (u32 i = 0; i < n; i++) bl.push_back((unsigned short)(3 + i));
+  for (u32 i = 0; i < n; i++) bl.push_back((unsigned short)(3 + n + i));
+  bl.push_back(1);
+  pv->off_T = (u32)bl.size();
+  bl.push_back(0); bl.push_back(1);
+  pv->off_P = (u32)bl.size();
+  for (u32 i = 0; i < n; i++) bl.push_back((unsigned short)(3 + i));
+  for (u32 i = 0; i < n; i++) bl.push_back((unsigned short)(3 + n + i));
+  bl.push_back(2);
+  pv->off_round = (u32)bl.size();
+  for (u32 r = 0; r < pv->k; r++) {
+    const u32 len = n >> r, half = len >> 1;
+    for (int side = 0; side < 2; side++) {               // 0: L, 1: R
+      for (u32 j = 0; j < n; j++) if (((j & (len - 1)) >= half) == (side == 0)) bl.push_back((unsigned short)(3 + j));
+      for (u32 j = 0; j < n; j++) if (((j & (len - 1)) < half) == (side == 0)) bl.push_back((unsigned short)(3 + n + j));
+      bl.push_back(2);
+    }
+  }
+  e = hipMalloc(&pv->bases, 2 * bl.size());
+  if (e == hipSuccess) e = hipMemcpy(pv->bases, bl.data(), 2 * bl.size(), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMalloc(&pv->d_ip_prefix, pv->ip_prefix.size() + 16);
+  if (e == hipSuccess) e = hipMemcpy(pv->d_ip_prefix, pv->ip_prefix.data(), pv->ip_prefix.size(), hipMemcpyHostToDevice);
+  if (e != hipSuccess) return bail(fail(ctx, BPMI_E_HIP, std::string("bpmi_rp_prover_create: ") + hipGetErrorString(e)));
+  *out = pv;
+  return BPMI_OK;
+}
+
+uint64_t bpmi_rp_prove_batch_proof_bytes(const bpmi_rp_prover *pv, uint64_t seed_len) {
+  if (!pv) return 0;
+  const uint64_t k = pv->k;
+  return 6 + 32 * (5 + k) + 33 * (6 + 2 * k) + 128 + 2 + seed_len + 2;
+}
+
+int bpmi_rp_prove_batch(bpmi_rp_prover *pv, uint64_t n_proofs, const uint8_t *values, const uint8_t *gammas, const uint8_t *seeds, const uint64_t *seed_off,
+                        uint8_t *out, uint64_t cap, uint64_t *out_off) {
+  if (!pv) return BPMI_E_ARG;
+  bpmi_ctx *ctx = pv->ctx;
+  if (!values || !gammas || !seed_off || !out || !out_off || (!seeds && seed_off[n_proofs] != seed_off[0])) return fail(ctx, BPMI_E_ARG, "null argument");
+  if (n_proofs == 0) { out_off[0] = 0; return BPMI_OK; }
+  if (n_proofs > (1u << 20)) return fail(ctx, BPMI_E_ARG, "at most 2^20 proofs per call");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const u32 P = (u32)n_proofs, n = pv->n, k = pv->k, npt = 6 + 2 * k;
+  // the proofs' seeds: base64(seed) || '&' starts every range-proof transcript (transcript.py:13-14)
+  uint64_t max_seed = 0, total_out = 0;
+  for (u32 p = 0; p < P; p++) {
+    if (seed_off[p + 1] < seed_off[p]) return fail(ctx, BPMI_E_ARG, "seed offsets must not decrease");
+    const uint64_t sl = seed_off[p + 1] - seed_off[p];
+    if (sl > 0xFFFF) return fail(ctx, BPMI_E_ARG, "a seed is longer than 65535 bytes");
+    max_seed = std::max(max_seed, sl);
+    out_off[p] = total_out;
+    total_out += bpmi_rp_prove_batch_proof_bytes(pv, sl);
+  }
+  out_off[P] = total_out;
+  if (total_out > cap) return fail(ctx, BPMI_E_ARG, "the output buffer is too small (bpmi_rp_prove_batch_proof_bytes per proof)");
+  const u32 dig0_stride = (u32)((((max_seed + 2) / 3) * 4 + 1 + 15) & ~15ull);
+  const u32 tr_stride = (u32)((std::max<uint64_t>(dig0_stride + 4 * 45 + 3 * 80, pv->ip_prefix.size() + (uint64_t)k * (90 + 80)) + 64 + 15) & ~15ull);
+  // ---- device layout
+  using rpp_host::up256;
+  size_t o = 0;
+  auto take = [&](size_t bytes) { const size_t at = o; o += up256(bytes); return at; };
+  const size_t o_dig0 = take((size_t)P * dig0_stride), o_dlen = take(4ull * P), o_val = take(32ull * P), o_gam = take(32ull * P);
+  const size_t o_seeds = take(seed_off[P] - seed_off[0] + 16), o_soff = take(8ull * (P + 1)), o_ooff = take(8ull * (P + 1));
+  const size_t in_bytes = o;                                   // everything above is uploaded in one copy
+  const size_t o_tr = take((size_t)P * tr_stride), o_trlen = take(4ull * P);
+  const size_t o_slr = take(32ull * P * (2 * n + 1)), o_alpha = take(32ull * P), o_chal = take(128ull * P), o_tau = take(64ull * P), o_tsc = take(128ull * P);
+  const size_t o_res = take(160ull * P), o_xs = take(32ull * P * k);
+  const size_t o_a = take(32ull * P * n), o_b = take(32ull * P * n), o_cg = take(32ull * P * n), o_hf = take(32ull * P * n);
+  const size_t o_jsc = take(32ull * P * (2 * n + 2)), o_jout = take(144ull * 2 * P), o_pts = take(64ull * P * npt);
+  const size_t o_out = take(total_out + 16);
+  if (o > pv->buf_bytes) {
+    if (pv->buf) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(pv->buf)); pv->buf = nullptr; pv->buf_bytes = 0; }
+    HIPCHK(ctx, hipMalloc(&pv->buf, o + o / 8));
+    pv->buf_bytes = o + o / 8;
+  }
+  const size_t pin_need = std::max(in_bytes, (size_t)total_out);
+  if (pin_need > pv->pin_bytes) {
+    if (pv->pin) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipHostFree(pv->pin)); pv->pin = nullptr; pv->pin_bytes = 0; }
+    HIPCHK(ctx, hipHostMalloc(&pv->pin, pin_need + pin_need / 8, hipHostMallocDefault));
+    pv->pin_bytes = pin_need + pin_need / 8;
+  }
+  char *d = (char *)pv->buf, *hp = (char *)pv->pin;
+  // ---- inputs into the staging buffer
+  memset(hp, 0, in_bytes);
+  for (u32 p = 0; p < P; p++) {
+    const std::string t = rpp_host::b64(seeds + seed_off[p], seed_off[p + 1] - seed_off[p]) + "&";
+    memcpy(hp + o_dig0 + (size_t)p * dig0_stride, t.data(), t.size());
+    ((u32 *)(hp + o_dlen))[p] = (u32)t.size();
+    ((uint64_t *)(hp + o_soff))[p] = seed_off[p] - seed_off[0];
+    ((uint64_t *)(hp + o_ooff))[p] = out_off[p];
+  }
+  ((uint64_t *)(hp + o_soff))[P] = seed_off[P] - seed_off[0];
+  ((uint64_t *)(hp + o_ooff))[P] = out_off[P];
+  memcpy(hp + o_val, values, 32ull * P);
+  memcpy(hp + o_gam, gammas, 32ull * P);
+  if (seed_off[P] > seed_off[0]) memcpy(hp + o_seeds, seeds + seed_off[0], seed_off[P] - seed_off[0]);
+  hipStream_t st = ctx->stream;
+  HIPCHK(ctx, hipMemcpyAsync(d, hp, in_bytes, hipMemcpyHostToDevice, st));
+  rpp::Batch B;
+  memset(&B, 0, sizeof(B));
+  B.P = P; B.n = n; B.k = k; B.table = pv->table;
+  B.dig0 = (const unsigned char *)(d + o_dig0); B.dig0_stride = dig0_stride; B.dig0_len = (const u32 *)(d + o_dlen);
+  B.values = (const u32 *)(d + o_val); B.gammas = (const u32 *)(d + o_gam);
+  B.ip_prefix = pv->d_ip_prefix; B.ip_prefix_len = (u32)pv->ip_prefix.size(); B.x_ip = pv->x_ip;
+  memcpy(B.u_new, pv->u_new, 64);
+  B.tr = (unsigned char *)(d + o_tr); B.tr_stride = tr_stride; B.tr_len = (u32 *)(d + o_trlen);
+  B.slr = (u32 *)(d + o_slr); B.alpha = (u32 *)(d + o_alpha); B.chal = (u32 *)(d + o_chal); B.tau = (u32 *)(d + o_tau); B.tsc = (u32 *)(d + o_tsc);
+  B.res = (u32 *)(d + o_res); B.xs = (u32 *)(d + o_xs);
+  B.a = (u32 *)(d + o_a); B.b = (u32 *)(d + o_b); B.cg = (u32 *)(d + o_cg); B.hf = (u32 *)(d + o_hf);
+  B.jsc = (u32 *)(d + o_jsc); B.jout = (u32 *)(d + o_jout); B.pts = (u32 *)(d + o_pts);
+  hipEvent_t ev[7];
+  for (int i = 0; i < 7; i++) { ev[i] = nullptr; HIPCHK(ctx, hipEventCreate(&ev[i])); }
+  auto drop_events = [&]() { for (int i = 0; i < 7; i++) if (ev[i]) (void)hipEventDestroy(ev[i]); };
+  auto blocks = [](uint64_t threads, u32 per) { return dim3((u32)((threads + per - 1) / per)); };
+  auto msm = [&](u32 njobs, u32 ntypes, u32 T, u32 base_off, const u32 *scalars, u32 stride, int gl) {
+    rpp::MsmJobs J;
+    J.njobs = njobs; J.ntypes = ntypes; J.T = T; J.bases = pv->bases + base_off; J.scalars = scalars; J.stride = stride; J.out = B.jout;
+    const uint64_t threads = (uint64_t)njobs << gl;
+    if (gl == 4) hipLaunchKernelGGL(rpp::k_pv_msm<4>, blocks(threads, 256), dim3(256), 0, st, J, (const u32 *)pv->table);
+    else hipLaunchKernelGGL(rpp::k_pv_msm<1>, blocks(threads, 256), dim3(256), 0, st, J, (const u32 *)pv->table);
+  };
+  auto affine = [&](u32 count, u32 per, u32 slot0, u32 step) {
+    hipLaunchKernelGGL(rpp::k_pv_affine, blocks(count, 256), dim3(256), 0, st, (const u32 *)B.jout, count, per, B.pts, npt, slot0, step);
+  };
+  (void)hipEventRecord(ev[0], st);
+  // A, S (rangeproof_prover.py:40-59)
+  hipLaunchKernelGGL(rpp::k_pv_blind, blocks((uint64_t)P * (2 * n + 2), 256), dim3(256), 0, st, B);
+  hipLaunchKernelGGL(rpp::k_pv_commit_A, blocks((uint64_t)P * 16, 256), dim3(256), 0, st, B, B.jout);
+  affine(P, 1, PV_PT_A, 0);
+  msm(P, 1, 2 * n + 1, pv->off_S, B.slr, 2 * n + 1, 4);
+  affine(P, 1, PV_PT_S, 0);
+  (void)hipEventRecord(ev[1], st);
+  // y, z, tau1, tau2; t1, t2; T1, T2 (:60-67)
+  hipLaunchKernelGGL(rpp::k_pv_chal_yz, blocks(P, 64), dim3(64), 0, st, B);
+  hipLaunchKernelGGL(rpp::k_pv_poly, blocks(P, 64), dim3(64), 0, st, B);
+  msm(2 * P, 1, 2, pv->off_T, B.tsc, 2, 1);
+  affine(2 * P, 2, PV_PT_T1, 1);
+  (void)hipEventRecord(ev[2], st);
+  // x; l, r, t_hat, taux, mu; P_new (:68-90; inner_product_prover.py:33-37)
+  hipLaunchKernelGGL(rpp::k_pv_final, blocks(P, 64), dim3(64), 0, st, B);
+  msm(P, 1, 2 * n + 1, pv->off_P, B.jsc, 2 * n + 1, 4);
+  affine(P, 1, PV_PT_PNEW, 0);
+  (void)hipEventRecord(ev[3], st);
+  // the rounds of Protocol 2 (inner_product_prover.py:94-110)
+  for (u32 r = 0; r < k; r++) {
+    hipLaunchKernelGGL(rpp::k_pv_round_scalars, blocks(P, 64), dim3(64), 0, st, B, r);
+    msm(2 * P, 2, n + 1, pv->off_round + r * 2 * (n + 1), B.jsc, n + 1, 4);
+    affine(2 * P, 2, 6 + r, k);
+    hipLaunchKernelGGL(rpp::k_pv_round_fold, blocks(P, 64), dim3(64), 0, st, B, r);
+  }
+  (void)hipEventRecord(ev[4], st);
+  hipLaunchKernelGGL(rpp::k_pv_emit, blocks(P, 64), dim3(64), 0, st, B, (const unsigned char *)(d + o_seeds), (const uint64_t *)(d + o_soff), (unsigned char *)(d + o_out),
+                     (const uint64_t *)(d + o_ooff));
+  (void)hipEventRecord(ev[5], st);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(hp, d + o_out, total_out, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipEventRecord(ev[6], st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e != hipSuccess) { drop_events(); return fail(ctx, BPMI_E_HIP, std::string("bpmi_rp_prove_batch: ") + hipGetErrorString(e)); }
+  memcpy(out, hp, total_out);
+  for (int i = 0; i < 6; i++) { float ms = 0; (void)hipEventElapsedTime(&ms, ev[i], ev[i + 1]); pv->last_ms[i] = ms; }
+  { float ms = 0; (void)hipEventElapsedTime(&ms, ev[0], ev[6]); pv->last_ms[6] = ms; }
+  drop_events();
+  return BPMI_OK;
+}
+
+int bpmi_rp_prover_last_ms(const bpmi_rp_prover *pv, double ms[7]) {
+  if (!pv || !ms) return BPMI_E_ARG;
+  for (int i = 0; i < 7; i++) ms[i] = pv->last_ms[i];
+  return BPMI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,85 @@
+"""Many single-value range proofs over the same generators, proved in ONE device call (SURVEY.md section 2.1 K11;
+csrc/rp_prove_kernels.hpp).  The reference proves one at a time -- a loop of
+NIRangeProver(v, n, g, h, gs, hs, gamma, u, group, seed).prove() (/root/reference/src/rangeproofs/rangeproof_prover.py:35-91 with
+/root/reference/src/innerproduct/inner_product_prover.py:27-44, :84-110 inside) -- and so did this package (2.1 ms a proof, every
+step a launch).  Here every protocol step is one launch over the whole batch, the generators' multiples come from tables built once
+per prover, and the transcripts are hashed on the device.  Same proofs, byte for byte:
+
+    bp = BatchRangeProver(n, g, h, gs, hs, u)
+    blobs = bp.prove_wire(vs, gammas, seeds)        # wire format 2 (rangeproofs/codec.py), one bytes object per proof
+    proofs = bp.prove(vs, gammas, seeds)            # the same as Proof objects
+    # blobs[i] == proof_to_bytes(NIRangeProver(vs[i], n, g, h, gs, hs, gammas[i], u, group, seeds[i]).prove(), version=2)
+"""
+import ctypes
+
+from .. import engine as _engine
+from ..ec import secp256k1
+from .codec import proofs_from_bytes
+
+Q = secp256k1.q
+
+
+def _le32(v):
+    return (int(v.x if hasattr(v, "x") else v) % Q).to_bytes(32, "little")
+
+
+class BatchRangeProver:
+    def __init__(self, n, g, h, gs, hs, u, engine=None):
+        """n: bits per value (a power of two up to 64); g, h, u: points; gs, hs: n points each.  Builds the fixed-base tables on the
+        engine's device (34 MB for n = 64) and keeps them until close()."""
+        if len(gs) != n or len(hs) != n:
+            raise ValueError("gs and hs must have n points each")
+        self.n = n
+        self._engine = engine or _engine.default_engine()
+        eng = self._engine
+        handle = ctypes.c_void_p()
+        eng._ck(eng.lib.bpmi_rp_prover_create(eng.ctx, n, g.to_le64(), h.to_le64(), u.to_le64(), b"".join(p.to_le64() for p in gs),
+                                              b"".join(p.to_le64() for p in hs), ctypes.byref(handle)))
+        self._handle = handle.value
+
+    def prove_wire_packed(self, vs, gammas, seeds):
+        """(packed bytes, offsets): proof i = packed[offsets[i]: offsets[i + 1]], wire format 2 -- what
+        BatchRangeVerifier.add_wire_native / bpmi_rp_batch_verify_dev take as they are."""
+        m = len(vs)
+        if len(gammas) != m or len(seeds) != m:
+            raise ValueError("values, blinding factors and seeds must have the same length")
+        eng = self._engine
+        off = (ctypes.c_uint64 * (m + 1))()
+        pos = 0
+        for i, s in enumerate(seeds):
+            off[i] = pos
+            pos += len(s)
+        off[m] = pos
+        longest = max((len(s) for s in seeds), default=0)
+        cap = m * eng.lib.bpmi_rp_prove_batch_proof_bytes(self._handle, longest) + 16
+        out = ctypes.create_string_buffer(cap)
+        out_off = (ctypes.c_uint64 * (m + 1))()
+        eng._ck(eng.lib.bpmi_rp_prove_batch(self._handle, m, b"".join(_le32(v) for v in vs), b"".join(_le32(x) for x in gammas), b"".join(seeds),
+                                            off, out, cap, out_off))
+        return out.raw[:out_off[m]], list(out_off)
+
+    def prove_wire(self, vs, gammas, seeds):
+        packed, off = self.prove_wire_packed(vs, gammas, seeds)
+        return [packed[off[i]: off[i + 1]] for i in range(len(vs))]
+
+    def prove(self, vs, gammas, seeds):
+        """The proofs as Proof objects (every point decompressed in one more launch)."""
+        return proofs_from_bytes(self.prove_wire(vs, gammas, seeds), engine=self._engine)
+
+    def last_ms(self):
+        """Device milliseconds of the last batch by phase (bpmi_rp_prover_last_ms)."""
+        ms = (ctypes.c_double * 7)()
+        self._engine._ck(self._engine.lib.bpmi_rp_prover_last_ms(self._handle, ms))
+        names = ("A_S", "yz_T1_T2", "x_vectors_Pnew", "ipa_rounds", "wire_bytes", "copy_out", "total")
+        return dict(zip(names, ms))
+
+    def close(self):
+        if getattr(self, "_handle", None):
+            self._engine.lib.bpmi_rp_prover_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

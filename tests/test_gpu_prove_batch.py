@@ -1,0 +1,141 @@
+"""GPU parity of the batched range-proof prover (bpmi_rp_prove_batch, rangeproofs/batch_prover.py): every proof of a batch is
+byte-identical to the one the single-proof prover (NIRangeProver.prove, the reference's call surface:
+/root/reference/src/rangeproofs/rangeproof_prover.py:35-91) makes for the same inputs, and to the reference's own golden proofs
+(tests/golden/rangeproofs.json); the proofs verify one by one and in the batch verifier."""
+import random
+
+import pytest
+
+from conftest import load_golden
+from helpers import P, Q, gens, hx
+from oracle import bp_ref as R
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gp():
+    import gpu_common
+    return gpu_common
+
+
+def _setup(gp, n, tag=b"bp"):
+    gs, hs = gp.to_gpu_list(gens(n, tag + b"g")), gp.to_gpu_list(gens(n, tag + b"h"))
+    g, h, u = (gp.to_gpu(R.elliptic_hash(tag + s)) for s in (b"G", b"H", b"U"))
+    return g, h, gs, hs, u
+
+
+def _seeds(count, rnd):
+    out = []
+    for i in range(count):
+        kind = i % 5
+        if kind == 0:
+            out.append(b"")
+        elif kind == 1:
+            out.append(bytes([rnd.randrange(256)]))
+        elif kind == 2:
+            out.append(rnd.randbytes(rnd.randrange(2, 40)))
+        elif kind == 3:
+            out.append(b"seed-%d" % i)
+        else:
+            out.append(rnd.randbytes(rnd.randrange(40, 200)))
+    return out
+
+
+@pytest.mark.parametrize("n,count", [(64, 1024), (32, 200), (8, 130), (2, 70), (16, 1), (128, 40)])
+def test_batch_prover_equals_the_single_proof_prover(gp, n, count):
+    from bulletproofs_amd.ec import secp256k1
+    from bulletproofs_amd.rangeproofs import BatchRangeProver, NIRangeProver, proof_to_bytes
+    from bulletproofs_amd.utils import ModP
+    g, h, gs, hs, u = _setup(gp, n)
+    rnd = random.Random(1000 + n)
+    vs = [ModP(rnd.randrange(1 << n), Q) for _ in range(count)]
+    for j, edge in enumerate((0, 1, (1 << n) - 1, 1 << (n - 1))):
+        if j < count:
+            vs[j] = ModP(edge, Q)
+    if count > 8:
+        vs[5] = ModP((1 << n) + 5, Q)                    # out of range: the prover still proves the low n bits (and the proof fails)
+    gammas = [ModP(rnd.randrange(Q), Q) for _ in range(count)]
+    seeds = _seeds(count, rnd)
+    bp = BatchRangeProver(n, g, h, gs, hs, u)
+    try:
+        blobs = bp.prove_wire(vs, gammas, seeds)
+        again = bp.prove_wire(vs[: max(1, count // 3)], gammas[: max(1, count // 3)], seeds[: max(1, count // 3)])     # a second, smaller batch on the same prover
+    finally:
+        bp.close()
+    assert again == blobs[: len(again)]
+    step = 1 if count <= 1024 else 4
+    for i in range(0, count, step):
+        want = proof_to_bytes(NIRangeProver(vs[i], n, g, h, gs, hs, gammas[i], u, secp256k1, seeds[i]).prove(), version=2)
+        assert blobs[i] == want, (n, i)
+
+
+@pytest.mark.parametrize("k", range(7))
+def test_batch_prover_reproduces_the_reference_goldens(gp, k):
+    """The single-value goldens of tests/golden/rangeproofs.json (made by the reference itself): the batch prover, given the same
+    value, blinding factor, seed and generators, writes the proof whose fields are the golden's."""
+    from bulletproofs_amd.rangeproofs import BatchRangeProver, proofs_from_bytes
+    from bulletproofs_amd.utils import ModP, mod_hash
+    from test_gpu_rangeproofs import check_range_proof, inputs
+    c = load_golden("rangeproofs.json")["single"][k]
+    s, n, gs, hs, g, h, u = inputs(gp, c, 1)
+    v = ModP(int(c["v"], 16), Q)
+    gamma = mod_hash(s[5], Q)
+    bp = BatchRangeProver(n, g, h, gs, hs, u)
+    try:
+        pr = bp.prove([v, v], [gamma, gamma], [s[6], s[6]])
+    finally:
+        bp.close()
+    check_range_proof(gp, pr[0], c["proof"])
+    check_range_proof(gp, pr[1], c["proof"])
+
+
+def test_batch_prover_output_verifies(gp):
+    """The wire bytes go straight into the verifiers: one by one (RangeVerifier) and as one batch (BatchRangeVerifier); a wrong
+    commitment is rejected."""
+    from bulletproofs_amd.rangeproofs import BatchRangeProver, BatchRangeVerifier, RangeVerifier, proofs_from_bytes
+    from bulletproofs_amd.utils import ModP, commitment
+    n, count = 64, 96
+    g, h, gs, hs, u = _setup(gp, n, b"vf")
+    rnd = random.Random(5)
+    vs = [ModP(rnd.randrange(1 << n), Q) for _ in range(count)]
+    gammas = [ModP(rnd.randrange(Q), Q) for _ in range(count)]
+    seeds = [b"verify-%d" % i for i in range(count)]
+    bp = BatchRangeProver(n, g, h, gs, hs, u)
+    try:
+        blobs = bp.prove_wire(vs, gammas, seeds)
+        ms = bp.last_ms()
+    finally:
+        bp.close()
+    assert ms["total"] > 0
+    Vs = [commitment(g, h, v, x) for v, x in zip(vs, gammas)]
+    proofs = proofs_from_bytes(blobs)
+    for i in (0, 1, count - 1):
+        assert RangeVerifier(Vs[i], g, h, gs, hs, u, proofs[i]).verify() is True
+    bv = BatchRangeVerifier(g, h, gs, hs, u)
+    for V, pr in zip(Vs, proofs):
+        bv.add(V, pr)
+    assert bv.verify() is True
+    bv = BatchRangeVerifier(g, h, gs, hs, u)
+    for i, (V, pr) in enumerate(zip(Vs, proofs)):
+        bv.add(Vs[0] if i == 7 else V, pr)
+    with pytest.raises(Exception, match="Proof invalid"):
+        bv.verify()
+
+
+def test_batch_prover_argument_errors(gp):
+    from bulletproofs_amd.engine import EngineError
+    from bulletproofs_amd.rangeproofs import BatchRangeProver
+    from bulletproofs_amd.utils import ModP
+    g, h, gs, hs, u = _setup(gp, 8)
+    with pytest.raises(ValueError):
+        BatchRangeProver(8, g, h, gs[:7], hs, u)
+    with pytest.raises(EngineError, match="power of two"):
+        BatchRangeProver(3, g, h, gs[:3], hs[:3], u)
+    bp = BatchRangeProver(8, g, h, gs, hs, u)
+    try:
+        assert bp.prove_wire([], [], []) == []
+        with pytest.raises(ValueError):
+            bp.prove_wire([ModP(1, Q)], [], [b""])
+    finally:
+        bp.close()
