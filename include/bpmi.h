@@ -22,6 +22,12 @@
  *     throws, never aborts; bpmi_last_error(ctx) gives the message
  *     (ctx == NULL: the message of the last failed bpmi_ctx_create);
  *   - a ctx is for use by one thread at a time; distinct ctxs are independent;
+ *   - a ctx, the objects made from it and the library's host worker threads do not survive fork(): a child process creates
+ *     its own ctx (the HIP runtime does not survive a fork either);
+ *   - points handed in through HOST pointers are checked to be the identity or on the curve (option "validate_points", default 1;
+ *     BPMI_E_ARG names the first bad index and no result is written).  Points behind DEVICE pointers are the caller's
+ *     responsibility unless the option is 2: PRECONDITION -- each is 64 zero bytes or (x, y) with x, y < p and y^2 = x^3 + 7;
+ *     anything else gives an unspecified (never out-of-bounds) result;
  *   - `*_dev` variants take DEVICE pointers (hipMalloc'd, or torch tensors'
  *     data_ptr()) on the ctx's device and enqueue on the ctx's stream; results
  *     written to host pointers are complete when the call returns;
@@ -102,6 +108,15 @@ int bpmi_sync(bpmi_ctx *ctx);
  *                  (0 = default 4096, 1 = never, else a power of two; the later rounds then run on the one-launch small-MSM kernel)
  *   "pair_phases"  1: bpmi_msm2 on the bucket pipeline queues both MSMs' sorts before either accumulation.  An experiment that came out
  *                  neutral (profiles/r04_C3_pair_phases_ab.txt); default 0
+ *   "validate_points" on-curve check of input points: 0 never, 1 (default) every entry point that takes HOST pointers to points (bpmi_msm,
+ *                  bpmi_msm2, bpmi_ec_mul_batch, bpmi_ec_lincomb2_batch, bpmi_ec_sum, bpmi_ipa_create[_scaled], the extra points of
+ *                  bpmi_ipa_verify_dev, the commitments of bpmi_rp_batch_verify_dev, bpmi_rp_prover_create), 2 also the synchronous entry
+ *                  points that take DEVICE pointers (bpmi_msm_dev, the generators of bpmi_ipa_verify_dev and bpmi_rp_batch_verify_dev).
+ *                  What fastecdsa's Point constructor does for the reference (reached from /root/reference/src/utils/utils.py:119-131).
+ *                  Cost: one kernel behind the upload, no extra wait (profiles/r05_validate_points_cost.txt)
+ *   "top_window_unsigned" window_bits = 15: 1 (default) 17 windows, the last one unsigned with twice the buckets; 0 the 18-window recoding
+ *   "sort_inblock" 1 (default): up to 2^17 pairs the sort's second level handles partitions of any size in one block (two launches fewer)
+ *   "segscan_fused" 1 (default): the segmented scan's last level runs in the block that finishes the level before it last
  *   "fold_wnaf"    the ladder of that 16-way fold: 2 (default) width-4 non-adjacent forms of the coefficients' GLV halves over affine
  *                  tables of 3P, 5P, 7P and of beta x (k_ec_multifold_w4g; 792 B of workspace per generator, kept by the ctx after the first fold),
  *                  1 of the whole coefficients (k_ec_multifold_w4), 0 the plain NAF ladder without tables (k_ec_multifold) */

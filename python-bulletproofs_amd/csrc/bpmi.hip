@@ -107,6 +107,8 @@ void bpmi_ctx_destroy(bpmi_ctx *ctx) {
   if (ctx->ws) (void)hipFree(ctx->ws);
   if (ctx->stage_in) (void)hipFree(ctx->stage_in);
   if (ctx->rp_buf) (void)hipFree(ctx->rp_buf);
+  if (ctx->vflag) (void)hipHostFree(ctx->vflag);
+  if (ctx->vflag_dev) (void)hipFree(ctx->vflag_dev);
   if (ctx->pin) (void)hipHostFree(ctx->pin);
   if (ctx->up_ring) (void)hipHostFree(ctx->up_ring);
   if (ctx->up_ev) (void)hipEventDestroy(ctx->up_ev);
@@ -142,6 +144,7 @@ int bpmi_set_option(bpmi_ctx *ctx, const char *name, int64_t value) {
   if (!ctx || !name) return BPMI_E_ARG;
   if (!strcmp(name, "window_bits")) { if (value != 0 && (value < 2 || value > 16)) return fail(ctx, BPMI_E_ARG, "window_bits must be 0 or 2..16"); ctx->opt_c = (int)value; return BPMI_OK; }
   if (!strcmp(name, "top_window_unsigned")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "top_window_unsigned must be 0 or 1"); ctx->opt_top2 = (int)value; msm_graphs_clear(ctx); return BPMI_OK; }
+  if (!strcmp(name, "validate_points")) { if (value < 0 || value > 2) return fail(ctx, BPMI_E_ARG, "validate_points must be 0, 1 or 2"); ctx->opt_validate = (int)value; return BPMI_OK; }
   if (!strcmp(name, "sort_inblock")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "sort_inblock must be 0 or 1"); ctx->opt_inblock = (int)value; msm_graphs_clear(ctx); return BPMI_OK; }
   if (!strcmp(name, "segscan_fused")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "segscan_fused must be 0 or 1"); ctx->opt_segfuse = (int)value; msm_graphs_clear(ctx); return BPMI_OK; }
   if (!strcmp(name, "priority")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "priority must be 0 or 1"); ctx->opt_prio = (int)value; return BPMI_OK; }
@@ -210,8 +213,67 @@ int bpmi_download(bpmi_ctx *ctx, void *host, const void *dptr, size_t bytes) {
   return BPMI_OK;
 }
 
+// ---- on-curve check of caller-supplied points (option "validate_points") --------------------------------------------------
+// The reference can never hand an off-curve point to multiexp: fastecdsa's Point constructor rejects it (reached from
+// /root/reference/src/utils/utils.py:119-131), and ec.py keeps that check for Python callers.  A C caller hands in raw bytes, so
+// the entry points that take HOST pointers check them here (level 1, the default; level 2: the synchronous _dev entry points as
+// well; 0: never): the identity (64 zero bytes) or x, y < p with y^2 = x^3 + 7.  Large arrays: k_ec_validate queued behind the
+// upload, its verdict (the smallest bad index) copied to a page-locked word that is read after the call's own synchronisation --
+// no extra wait; the call then fails with BPMI_E_ARG and writes NO result.  A few points: checked on the host.
+#define VALIDATE_HOST_MAX 64u
+static int validate_begin(bpmi_ctx *ctx, hipStream_t st) {
+  if (!ctx->vflag) {
+    HIPCHK(ctx, hipHostMalloc((void **)&ctx->vflag, 64, hipHostMallocDefault));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->vflag_dev, 256));
+  }
+  *ctx->vflag = 0xFFFFFFFFu;
+  HIPCHK(ctx, hipMemsetAsync(ctx->vflag_dev, 0xFF, 4, st));
+  return BPMI_OK;
+}
+// array `which` (0 .. 3) of the call: d_pts[0 .. n) on the device
+static void validate_enqueue(bpmi_ctx *ctx, const void *d_pts, uint64_t n, u32 which, hipStream_t st) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_ec_validate, dim3((u32)((n + 255) / 256)), dim3(256), 0, st, (const u32 *)d_pts, (u32)n, which << 28, ctx->vflag_dev);
+}
+static int validate_fetch(bpmi_ctx *ctx, hipStream_t st) {
+  HIPCHK(ctx, hipMemcpyAsync(ctx->vflag, ctx->vflag_dev, 4, hipMemcpyDeviceToHost, st));
+  return BPMI_OK;
+}
+// after the stream has been synchronised: names[which] = what the bad array is called in the message
+static int validate_end(bpmi_ctx *ctx, const char *fn, const char *const *names) {
+  const u32 v = *ctx->vflag;
+  if (v == 0xFFFFFFFFu) return BPMI_OK;
+  return fail(ctx, BPMI_E_ARG, std::string(fn) + ": " + names[v >> 28] + "[" + std::to_string(v & 0x0FFFFFFFu) + "] is not a point of the curve");
+}
+static int validate_host(bpmi_ctx *ctx, const uint8_t *pts, uint64_t n, const char *fn, const char *name) {
+  for (uint64_t i = 0; i < n; i++) {
+    u32 w[16];
+    memcpy(w, pts + 64 * i, 64);
+    if (!wire_point_valid(w)) return fail(ctx, BPMI_E_ARG, std::string(fn) + ": " + name + "[" + std::to_string(i) + "] is not a point of the curve");
+  }
+  return BPMI_OK;
+}
+
 // ---- MSM ------------------------------------------------------------------------------
+static int msm_dev_impl(bpmi_ctx *ctx, const void *d_pts, const void *d_scalars, uint64_t n, uint8_t out[64]);
 int bpmi_msm_dev(bpmi_ctx *ctx, const void *d_pts, const void *d_scalars, uint64_t n, uint8_t out[64]) {
+  if (!ctx || !out || (n && (!d_pts || !d_scalars))) return ctx ? fail(ctx, BPMI_E_ARG, "null argument") : BPMI_E_ARG;
+  if (n > BPMI_MAX_N) return fail(ctx, BPMI_E_ARG, "n exceeds BPMI_MAX_N");
+  if (ctx->opt_validate < 2 || n == 0) return msm_dev_impl(ctx, d_pts, d_scalars, n, out);
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  int rc = validate_begin(ctx, ctx->stream);
+  if (rc) return rc;
+  validate_enqueue(ctx, d_pts, n, 0, ctx->stream);
+  rc = validate_fetch(ctx, ctx->stream);
+  if (rc) return rc;
+  rc = msm_dev_impl(ctx, d_pts, d_scalars, n, out);
+  if (rc) return rc;
+  static const char *const names[] = {"d_pts"};
+  rc = validate_end(ctx, "bpmi_msm_dev", names);
+  if (rc) memset(out, 0, 64);
+  return rc;
+}
+static int msm_dev_impl(bpmi_ctx *ctx, const void *d_pts, const void *d_scalars, uint64_t n, uint8_t out[64]) {
   if (!ctx || !out || (n && (!d_pts || !d_scalars))) return ctx ? fail(ctx, BPMI_E_ARG, "null argument") : BPMI_E_ARG;
   if (n > BPMI_MAX_N) return fail(ctx, BPMI_E_ARG, "n exceeds BPMI_MAX_N");
   HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -270,22 +332,19 @@ int bpmi_msm_dev_enqueue(bpmi_ctx *ctx, int slot, const void *d_pts, const void 
   int rc;
   if (ctx->opt_async_lanes) {
     rc = ensure_lane(ctx, 1);
-    if (rc == BPMI_OK && slot == 2) rc = ensure_lane(ctx, 2);
+    if (rc == BPMI_OK) rc = ensure_lane(ctx, 2);               // (both extra lanes exist from the first burst on: see below)
     if (rc) return rc;
   }
-  if (lane == 2 && !ctx->async_lane2_ordered) {               // as below for lane 1: once per burst, before this lane's first MSM
-    HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->stream));
-    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_join, 0));
-    ctx->async_lane2_ordered = true;
-  }
   if (ctx->opt_async_lanes && !ctx->async_lane1_ordered) {
-    // order lane 1 after whatever produced the inputs on the ctx stream, once per burst and BEFORE this burst's first MSM is
-    // queued (the option's contract: inputs complete before the first enqueue of a burst).  Recorded at the first use of
-    // slot 1 instead, the event sat behind slot 0's whole MSM and a caller that queues a pair and then waits for both got
-    // them one after the other (profiles/r03_pair_modes.txt).
+    // Order EVERY extra lane after whatever produced the inputs on the ctx stream, once per burst and BEFORE this burst's first MSM
+    // is queued (the option's contract: inputs complete before the first enqueue of a burst).  Recorded at a lane's first use
+    // instead, the event sits behind slot 0's whole MSM: round 3 found that for lane 1 (a caller that queued a pair and waited for
+    // both got them one after the other, profiles/r03_pair_modes.txt), and round 4's lane 2 still did it -- its "three in flight"
+    // measurements ran on a partly serialised pipeline (re-measured: profiles/r05_pipeline_depth_ab.txt).
     HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
     HIPCHK(ctx, hipStreamWaitEvent(ctx->stream1, ctx->ev_fork, 0));
-    ctx->async_lane1_ordered = true;
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+    ctx->async_lane1_ordered = ctx->async_lane2_ordered = true;
   }
   ctx->chain_accum = ctx->opt_async_lanes != 0;
   rc = msm_enqueue(ctx, lane, slot, s);
@@ -316,7 +375,20 @@ int bpmi_msm(bpmi_ctx *ctx, const uint8_t *pts, const uint8_t *scalars, uint64_t
   char *ds = dp + align_up(64 * n, 256);
   HIPCHK(ctx, h2d(ctx, dp, pts, 64 * n, ctx->stream));
   HIPCHK(ctx, h2d(ctx, ds, scalars, 32 * n, ctx->stream));
-  return bpmi_msm_dev(ctx, dp, ds, n, out);
+  const bool check = ctx->opt_validate >= 1;
+  if (check) {
+    rc = validate_begin(ctx, ctx->stream);
+    if (rc) return rc;
+    validate_enqueue(ctx, dp, n, 0, ctx->stream);
+    rc = validate_fetch(ctx, ctx->stream);
+    if (rc) return rc;
+  }
+  rc = msm_dev_impl(ctx, dp, ds, n, out);
+  if (rc || !check) return rc;
+  static const char *const names[] = {"pts"};
+  rc = validate_end(ctx, "bpmi_msm", names);
+  if (rc) memset(out, 0, 64);
+  return rc;
 }
 
 // two independent MSMs from host buffers, overlapped on the ctx's two lanes (one staging upload,
@@ -335,7 +407,21 @@ int bpmi_msm2(bpmi_ctx *ctx, const uint8_t *pts0, const uint8_t *sc0, uint64_t n
   Segs a = segs_init(), b = segs_init();
   a.pts[0] = (const u32 *)d; a.sc[0] = (const u32 *)(d + o_s0); a.n[0] = (u32)n0; a.total = (u32)n0;
   b.pts[0] = (const u32 *)(d + o_p1); b.sc[0] = (const u32 *)(d + o_s1); b.n[0] = (u32)n1; b.total = (u32)n1;
-  return msm_run_pair(ctx, a, out0, b, out1);
+  const bool check = ctx->opt_validate >= 1 && (n0 || n1);
+  if (check) {
+    rc = validate_begin(ctx, ctx->stream);
+    if (rc) return rc;
+    validate_enqueue(ctx, d, n0, 0, ctx->stream);
+    validate_enqueue(ctx, d + o_p1, n1, 1, ctx->stream);
+    rc = validate_fetch(ctx, ctx->stream);
+    if (rc) return rc;
+  }
+  rc = msm_run_pair(ctx, a, out0, b, out1);
+  if (rc || !check) return rc;
+  static const char *const names[] = {"pts0", "pts1"};
+  rc = validate_end(ctx, "bpmi_msm2", names);
+  if (rc) { memset(out0, 0, 64); memset(out1, 0, 64); }
+  return rc;
 }
 
 // ---- batched point ops --------------------------------------------------------------------
@@ -380,8 +466,22 @@ int bpmi_ec_mul_batch(bpmi_ctx *ctx, const uint8_t *pts, const uint8_t *scalars,
   char *dp = (char *)ctx->stage_in, *ds = dp + align_up(64 * n, 256), *dout = ds + align_up(32 * n, 256);
   HIPCHK(ctx, h2d(ctx, dp, pts, 64 * n, ctx->stream));
   HIPCHK(ctx, h2d(ctx, ds, scalars, 32 * n, ctx->stream));
+  const bool check = ctx->opt_validate >= 1;
+  if (check) {
+    rc = validate_begin(ctx, ctx->stream);
+    if (rc) return rc;
+    validate_enqueue(ctx, dp, n, 0, ctx->stream);
+    rc = validate_fetch(ctx, ctx->stream);
+    if (rc) return rc;
+  }
   rc = bpmi_ec_mul_batch_dev(ctx, dp, ds, n, dout);
   if (rc) return rc;
+  if (check) {                                   // the verdict before anything is written to the caller's buffer
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    static const char *const names[] = {"pts"};
+    rc = validate_end(ctx, "bpmi_ec_mul_batch", names);
+    if (rc) return rc;
+  }
   HIPCHK(ctx, hipMemcpyAsync(out, dout, 64 * n, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return BPMI_OK;
@@ -426,8 +526,23 @@ int bpmi_ec_lincomb2_batch(bpmi_ctx *ctx, const uint8_t *p1, const uint8_t *p2, 
   char *d1 = (char *)ctx->stage_in, *d2 = d1 + align_up(64 * n, 256), *dout = d2 + align_up(64 * n, 256);
   HIPCHK(ctx, h2d(ctx, d1, p1, 64 * n, ctx->stream));
   HIPCHK(ctx, h2d(ctx, d2, p2, 64 * n, ctx->stream));
+  const bool check = ctx->opt_validate >= 1;
+  if (check) {
+    rc = validate_begin(ctx, ctx->stream);
+    if (rc) return rc;
+    validate_enqueue(ctx, d1, n, 0, ctx->stream);
+    validate_enqueue(ctx, d2, n, 1, ctx->stream);
+    rc = validate_fetch(ctx, ctx->stream);
+    if (rc) return rc;
+  }
   rc = bpmi_ec_lincomb2_batch_dev(ctx, d1, d2, k1, k2, n, dout);
   if (rc) return rc;
+  if (check) {
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    static const char *const names[] = {"p1", "p2"};
+    rc = validate_end(ctx, "bpmi_ec_lincomb2_batch", names);
+    if (rc) return rc;
+  }
   HIPCHK(ctx, hipMemcpyAsync(out, dout, 64 * n, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return BPMI_OK;
@@ -441,12 +556,29 @@ int bpmi_ec_sum(bpmi_ctx *ctx, const uint8_t *pts, uint64_t n, uint8_t out[64]) 
   if (rc) return rc;
   char *dp = (char *)ctx->stage_in, *dout = dp + align_up(64 * n, 256);
   HIPCHK(ctx, h2d(ctx, dp, pts, 64 * n, ctx->stream));
+  // (the per-GPU partial results a sharded caller folds here are the library's own outputs; a few points: checked on the host)
+  const bool check = ctx->opt_validate >= 1;
+  if (check && n <= VALIDATE_HOST_MAX) { rc = validate_host(ctx, pts, n, "bpmi_ec_sum", "pts"); if (rc) return rc; }
+  else if (check) {
+    rc = validate_begin(ctx, ctx->stream);
+    if (rc) return rc;
+    validate_enqueue(ctx, dp, n, 0, ctx->stream);
+    rc = validate_fetch(ctx, ctx->stream);
+    if (rc) return rc;
+  }
   {
     StageTimer t(ctx, ST_MISC);
     hipLaunchKernelGGL(k_ec_sum, dim3(1), dim3(256), 0, ctx->stream, (const u32 *)dp, (u32)n, (u32 *)dout);
   }
-  HIPCHK(ctx, hipMemcpyAsync(out, dout, 64, hipMemcpyDeviceToHost, ctx->stream));
+  uint8_t tmp[64];
+  HIPCHK(ctx, hipMemcpyAsync(tmp, dout, 64, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (check && n > VALIDATE_HOST_MAX) {
+    static const char *const names[] = {"pts"};
+    rc = validate_end(ctx, "bpmi_ec_sum", names);
+    if (rc) return rc;
+  }
+  memcpy(out, tmp, 64);
   return BPMI_OK;
 }
 
@@ -690,6 +822,10 @@ int bpmi_ipa_verify_dev(bpmi_ctx *ctx, const void *d_g, const void *d_h, const v
   SvecLayout L;
   int rc = svector_layout(ctx, n, k, o_es + 32 * n_extra, L);
   if (rc) return rc;
+  const bool check_host = ctx->opt_validate >= 1 && n_extra && n_extra <= VALIDATE_HOST_MAX;
+  const bool check_dev = ctx->opt_validate >= 2 || (ctx->opt_validate >= 1 && n_extra > VALIDATE_HOST_MAX);
+  if (check_host) { rc = validate_host(ctx, extra_pts, n_extra, "bpmi_ipa_verify_dev", "extra_pts"); if (rc) return rc; }
+  if (check_dev) { rc = validate_begin(ctx, ctx->stream); if (rc) return rc; }
   rc = svector_launch(ctx, L, d_hscale, n, xs, xinvs, a, b);
   if (rc) return rc;
   u32 *d_sa = L.sa, *d_sb = L.sb;
@@ -703,7 +839,18 @@ int bpmi_ipa_verify_dev(bpmi_ctx *ctx, const void *d_g, const void *d_h, const v
   s.pts[1] = (const u32 *)d_h; s.sc[1] = d_sb; s.n[1] = (u32)n;
   s.pts[2] = (const u32 *)d_ex; s.sc[2] = (const u32 *)(d_ex + o_es); s.n[2] = (u32)n_extra;
   s.total = (u32)(2 * n + n_extra);
-  return msm_run(ctx, s, out);
+  if (check_dev) {
+    if (ctx->opt_validate >= 2) { validate_enqueue(ctx, d_g, n, 0, ctx->stream); validate_enqueue(ctx, d_h, n, 1, ctx->stream); }
+    if (n_extra > VALIDATE_HOST_MAX) validate_enqueue(ctx, d_ex, n_extra, 2, ctx->stream);
+    rc = validate_fetch(ctx, ctx->stream);
+    if (rc) return rc;
+  }
+  rc = msm_run(ctx, s, out);
+  if (rc || !check_dev) return rc;
+  static const char *const names[] = {"d_g", "d_h", "extra_pts"};
+  rc = validate_end(ctx, "bpmi_ipa_verify_dev", names);
+  if (rc) memset(out, 0xFF, 64);                // (never the identity, which a verifier reads as "valid")
+  return rc;
 }
 
 // ---- IPA prover state ---------------------------------------------------------------------------
@@ -822,13 +969,29 @@ int bpmi_ipa_create(bpmi_ctx *ctx, const uint8_t *g, const uint8_t *h, const uin
   int rc = ipa_alloc(ctx, n, &st);
   if (rc) return rc;
   hipStream_t s = ctx->stream;
+  const bool check = ctx->opt_validate >= 1;
+  if (check) {
+    rc = validate_host(ctx, u, 1, "bpmi_ipa_create", "u");
+    if (rc == BPMI_OK) rc = validate_begin(ctx, s);
+    if (rc) { (void)hipFree(st->block); delete st; return rc; }
+  }
   hipError_t e = h2d(ctx, st->g, g, 64 * n, s);
   if (e == hipSuccess) e = h2d(ctx, st->h, h, 64 * n, s);
   if (e == hipSuccess) e = h2d(ctx, st->a, a, 32 * n, s);
   if (e == hipSuccess) e = h2d(ctx, st->b, b, 32 * n, s);
   if (e == hipSuccess) e = h2d(ctx, st->u, u, 64, s);
+  if (e == hipSuccess && check) {
+    validate_enqueue(ctx, st->g, n, 0, s);
+    validate_enqueue(ctx, st->h, n, 1, s);
+    e = hipMemcpyAsync(ctx->vflag, ctx->vflag_dev, 4, hipMemcpyDeviceToHost, s);
+  }
   if (e == hipSuccess) e = hipStreamSynchronize(s);
   if (e != hipSuccess) { (void)hipFree(st->block); delete st; return fail(ctx, BPMI_E_HIP, std::string("ipa_create copy: ") + hipGetErrorString(e)); }
+  if (check) {
+    static const char *const names[] = {"g", "h"};
+    rc = validate_end(ctx, "bpmi_ipa_create", names);
+    if (rc) { (void)hipFree(st->block); delete st; return rc; }
+  }
   *out = st;
   return BPMI_OK;
 }
@@ -1267,12 +1430,19 @@ int bpmi_rp_batch_prepare(uint32_t n_gens, uint32_t values_per_proof, uint64_t n
   // wire format 2 (rp_wire_v2_host.hpp): expanded to format 1 here, then everything below runs as before
   std::vector<uint8_t> expanded;
   std::vector<uint64_t> expanded_off;
-  if (n_proofs && blob_off[1] >= blob_off[0] + 5 && blobs[blob_off[0] + 4] == '2') {
+  bool any_v2 = false;
+  for (uint64_t g = 0; g < n_proofs && !any_v2; g++) any_v2 = blob_off[g + 1] >= blob_off[g] + 5 && blobs[blob_off[g] + 4] == '2';
+  if (any_v2) {
     expanded_off.assign(n_proofs + 1, 0);
     std::vector<uint8_t> one;
     for (uint64_t g = 0; g < n_proofs; g++) {
-      if (!rpw::expand_v2(blobs + blob_off[g], (size_t)(blob_off[g + 1] - blob_off[g]), one)) { *first_bad = (int64_t)g; return BPMI_OK; }
-      expanded.insert(expanded.end(), one.begin(), one.end());
+      const uint8_t *b = blobs + blob_off[g];
+      const size_t len = (size_t)(blob_off[g + 1] - blob_off[g]);
+      if (len < 5 || b[4] != '2') expanded.insert(expanded.end(), b, b + len);           // a format-1 proof among format-2 ones: taken as it is
+      else {
+        if (!rpw::expand_v2(b, len, one)) { *first_bad = (int64_t)g; return BPMI_OK; }
+        expanded.insert(expanded.end(), one.begin(), one.end());
+      }
       expanded_off[g + 1] = expanded.size();
     }
     blobs = expanded.data(); blobs_len = expanded.size(); blob_off = expanded_off.data();
@@ -1314,6 +1484,20 @@ int bpmi_rp_batch_prepare(uint32_t n_gens, uint32_t values_per_proof, uint64_t n
 // are decoded where they lie in the blobs into d_points, and only the (5 + 2n) shared coefficients and the verdict come back.
 struct RpQueued { u32 *d_shared; unsigned long long *d_bad; u32 ncols; };
 #define RP_UPLOAD_SLICES 4
+// A batch is read in the wire format of its FIRST proof.  A well-formed proof of the OTHER format inside it is not a forged proof: the
+// device paths report it as an argument error ("mixed wire formats"), not as a verdict -- a verifier must be able to tell a
+// sender's mix-up from an attack (the host path, bpmi_rp_batch_prepare, takes the formats proof by proof).
+static int rp_mixed_formats(bpmi_ctx *ctx, const uint8_t *blobs, uint64_t blobs_len, const uint64_t *blob_off, int64_t first_bad) {
+  if (first_bad < 0) return BPMI_OK;
+  const uint64_t a0 = blob_off[0], a = blob_off[first_bad], e = blob_off[first_bad + 1];
+  if (a0 + 5 > blobs_len || e > blobs_len || e < a + 5) return BPMI_OK;
+  const uint8_t *b = blobs + a;
+  const bool v2 = blobs[a0 + 4] == '2';
+  if (b[0] == 'B' && b[1] == 'P' && b[2] == 'R' && b[3] == 'P' && b[4] == (v2 ? '1' : '2'))
+    return fail(ctx, BPMI_E_ARG, "mixed wire formats: proof " + std::to_string(first_bad) + " is format " + (v2 ? "1" : "2") + " in a format-" + (v2 ? "2" : "1") +
+                                     " batch (one format per call; bpmi_rp_wire_v2_to_v1 converts)");
+  return BPMI_OK;
+}
 // queues everything on the ctx's two lanes and returns without waiting; the results stay on the device (d_shared: 5 + 2n
 // scalars of 8 words, *d_bad behind them).  The caller waits for both lanes whatever this returns.
 static int rp_prepare_enqueue(bpmi_ctx *ctx, uint32_t n_gens, uint32_t m, uint64_t n_proofs, const uint8_t *blobs, uint64_t blobs_len, const uint64_t *blob_off,
@@ -1478,6 +1662,8 @@ int bpmi_rp_batch_prepare_dev(bpmi_ctx *ctx, uint32_t n_gens, uint32_t values_pe
   unsigned long long bad;
   memcpy(&bad, (char *)ctx->pin + out_row, 8);
   *first_bad = bad == ~0ull ? -1 : (int64_t)bad;
+  rc = rp_mixed_formats(ctx, blobs, blobs_len, blob_off, *first_bad);
+  if (rc) return rc;
   if (ctx->opt_rp_only_role >= 0) *first_bad = 0;        // a profiling run checked part of every proof: it must never read as "all valid"
   return BPMI_OK;
 }
@@ -1502,6 +1688,15 @@ int bpmi_rp_batch_verify_dev(bpmi_ctx *ctx, uint32_t n_gens, uint32_t values_per
   HIPCHK(ctx, hipSetDevice(ctx->device));
   // commitments: the first nv points / scalars of the per-proof arrays
   HIPCHK(ctx, h2d(ctx, d_points, v_points, 64 * nv, ctx->stream));
+  const bool check = ctx->opt_validate >= 1;
+  if (check) {
+    int vrc = validate_begin(ctx, ctx->stream);
+    if (vrc) return vrc;
+    validate_enqueue(ctx, d_points, nv, 0, ctx->stream);
+    if (ctx->opt_validate >= 2) validate_enqueue(ctx, d_gens, 3 + 2 * (uint64_t)n_gens, 1, ctx->stream);
+    vrc = validate_fetch(ctx, ctx->stream);
+    if (vrc) return vrc;
+  }
   RpQueued Q;
   int rc = rp_prepare_enqueue(ctx, n_gens, values_per_proof, n_proofs, blobs, blobs_len, blob_off, weights, seed, d_scalars, (char *)d_scalars + 32 * nv,
                               (char *)d_points + 64 * nv, Q);
@@ -1523,9 +1718,16 @@ int bpmi_rp_batch_verify_dev(bpmi_ctx *ctx, uint32_t n_gens, uint32_t values_per
   rc = msm_run(ctx, s, out);                      // waits for the MSM (ctx stream: behind everything queued above)
   rc = rp_wait_lanes(ctx, rc);
   if (rc) return rc;
+  if (check) {
+    static const char *const names[] = {"v_points", "d_gens"};
+    rc = validate_end(ctx, "bpmi_rp_batch_verify_dev", names);
+    if (rc) { memset(out, 0xFF, 64); return rc; }                  // (never the identity)
+  }
   unsigned long long bad;
   memcpy(&bad, ctx->pin, 8);
   *first_bad = bad == ~0ull ? -1 : (int64_t)bad;
+  rc = rp_mixed_formats(ctx, blobs, blobs_len, blob_off, *first_bad);
+  if (rc) { memset(out, 0xFF, 64); return rc; }
   if (ctx->opt_rp_only_role >= 0) *first_bad = 0;
   return BPMI_OK;
 }

@@ -281,6 +281,36 @@ BPMI_HD void xyzz_load(xyzz &a, const u32 *src) {
 
 // bit offsets of the (<= 4) partial sums a bucket reduction leaves per MSM window:
 // window value = sum_v 2^(off[v]) E[v], off ascending, off[0] = 0
+// Is the 64-byte wire point (x, y: 8 little-endian words each) the identity (all zero) or a point of y^2 = x^3 + 7 with x, y < p?
+// What fastecdsa's Point constructor checks for the reference (reached from /root/reference/src/utils/utils.py:119-131); the C-ABI
+// checks it for callers that hand in raw bytes (bpmi.hip validate_*).  Host and device.
+BPMI_HD bool wire_point_valid(const u32 w[16]) {
+  u32 any = 0;
+#pragma unroll
+  for (int k = 0; k < 16; k++) any |= w[k];
+  if (!any) return true;
+  bool ok = true;
+#pragma unroll
+  for (int h = 0; h < 2; h++) {               // coordinate < p:  v + (2^32 + 977) must not carry out of 256 bits
+    const u32 *v = w + 8 * h;
+    u64 c = (u64)v[0] + 977u; c >>= 32;
+    c += (u64)v[1] + 1u; c >>= 32;
+#pragma unroll
+    for (int k = 2; k < 8; k++) { c += v[k]; c >>= 32; }
+    ok = ok && (c == 0);
+  }
+  fe x, y, a, t, seven;
+  fe_from_words(x, w);
+  fe_from_words(y, w + 8);
+  fe_sqr(t, x); fe_mul(a, t, x);
+  fe_set_zero(seven); seven.v[0] = 7;
+  fe_add(a, a, seven); fe_carry(a, a);          // x^3 + 7
+  fe_sqr(t, y);
+  fe ca, ct;
+  fe_canon(ca, a); fe_canon(ct, t);
+  return ok && fe_equal(ca, ct);
+}
+
 struct TailOffs { u32 nv; u32 off[4]; u32 top; u32 top_off[4]; };      // top = 1: the last window uses top_off (MsmGeom.top2)
 
 }  // namespace bpmi

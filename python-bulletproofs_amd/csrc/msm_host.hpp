@@ -143,7 +143,11 @@ struct MsmGraphEntry {
 };
 struct MsmGraphCache { std::vector<MsmGraphEntry> entries; };
 static void msm_graphs_clear(bpmi_ctx *ctx) {
-  if (!ctx->graphs) return;
+  if (!ctx->graphs || ctx->graphs->entries.empty()) return;
+  // a replayed graph may still be running on any lane: nothing is destroyed under it
+  (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->stream1) (void)hipStreamSynchronize(ctx->stream1);
+  if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
   for (auto &e : ctx->graphs->entries) { if (e.exec) (void)hipGraphExecDestroy(e.exec); if (e.graph) (void)hipGraphDestroy(e.graph); }
   ctx->graphs->entries.clear();
 }

@@ -1296,7 +1296,7 @@ __global__ void __launch_bounds__(64) k_small_combine_pair(CombinePair c) {
 #define MID_C 7
 #define MID_B 64                 // 2^(MID_C - 1)
 #define MID_THREADS 512
-#define MID_NMAX 8448            // pairs per MSM: the digit and entry arrays live in LDS
+#define MID_NMAX 8448            // pairs per MSM: the digit and entry arrays live in LDS (139 KB of the 160 KB a gfx950 CU has: this kernel does not build for earlier CDNA parts)
 struct MidPair { Segs segs[2]; MsmGeom g[2]; u32 *E[2]; };
 __global__ void __launch_bounds__(MID_THREADS) k_msm_mid(MidPair p) {
   __shared__ u32 s_cnt[MID_B + 2], s_off[MID_B + 2], s_cur[MID_B + 2], s_lane0[MID_B + 2];
@@ -1403,35 +1403,50 @@ __global__ void __launch_bounds__(MID_THREADS) k_msm_mid(MidPair p) {
   if (key != 0xFFFFFFFFu && (tid + 1 == MID_THREADS || s_key[tid + 1] != key)) xyzz_store(s_bkt + (key - 1u) * XYZZ_WORDS, acc);
   __syncthreads();
   // 5. sum_b b X[b] over the 64 buckets: bucket b = rec + 1 on the quad of lanes 4 rec .. 4 rec + 3 -- the first four waves; the
-  // other four are done (a wave that has ended no longer counts at the block's barriers)
-  if (tid >= 4 * MID_B) return;
+  // other four only keep the block's barriers company (`live` is wave-uniform: a barrier that part of the block never reaches is
+  // undefined behaviour in the programming model, whatever today's hardware makes of ended waves)
+  const bool live = tid < 4 * MID_B;
   const u32 rec = tid >> 2, q4 = tid & 3u;
   fe a;
+  fe_set_zero(a);
+  if (live) {
 #pragma unroll
-  for (int k = 0; k < 9; k++) a.v[k] = s_bkt[rec * XYZZ_WORDS + q4 * 9u + k];
-  u32 *mine = s_val + rec * XYZZ_WORDS + q4 * 9u;                // (s_val is free again)
+    for (int k = 0; k < 9; k++) a.v[k] = s_bkt[rec * XYZZ_WORDS + q4 * 9u + k];
+  }
+  u32 *mine = s_val + (live ? rec : 0u) * XYZZ_WORDS + q4 * 9u;                // (s_val is free again)
 #pragma unroll 1
   for (u32 d = 1; d < MID_B; d <<= 1) {                           // inclusive suffix scan
+    if (live) {
 #pragma unroll
-    for (int k = 0; k < 9; k++) mine[k] = a.v[k];
+      for (int k = 0; k < 9; k++) mine[k] = a.v[k];
+    }
     __syncthreads();
     fe b;
+    fe_set_zero(b);
+    if (live) {
 #pragma unroll
-    for (int k = 0; k < 9; k++) b.v[k] = (rec + d < MID_B) ? mine[d * XYZZ_WORDS + k] : 0u;
+      for (int k = 0; k < 9; k++) b.v[k] = (rec + d < MID_B) ? mine[d * XYZZ_WORDS + k] : 0u;
+    }
     __syncthreads();
-    quad_add(a, b, q4);
+    if (live) quad_add(a, b, q4);
   }
 #pragma unroll 1
   for (u32 d = MID_B >> 1; d > 0; d >>= 1) {                      // sum of all suffixes: records [0, 2d) -> [0, d)
+    if (live) {
 #pragma unroll
-    for (int k = 0; k < 9; k++) mine[k] = a.v[k];
+      for (int k = 0; k < 9; k++) mine[k] = a.v[k];
+    }
     __syncthreads();
     fe b;
+    fe_set_zero(b);
+    if (live) {
 #pragma unroll
-    for (int k = 0; k < 9; k++) b.v[k] = (rec < d) ? mine[d * XYZZ_WORDS + k] : 0u;
+      for (int k = 0; k < 9; k++) b.v[k] = (rec < d) ? mine[d * XYZZ_WORDS + k] : 0u;
+    }
     __syncthreads();
-    quad_add(a, b, q4);
+    if (live) quad_add(a, b, q4);
   }
+  if (!live) return;
   if (rec == 0) {
 #pragma unroll
     for (int k = 0; k < 9; k++) p.E[job][(u64)w * XYZZ_WORDS + q4 * 9u + k] = a.v[k];

@@ -721,6 +721,16 @@ __global__ void __launch_bounds__(256, 3) k_ec_decompress_wire(const uint8_t *__
   store_words16(out + 16ull * i, w16);
 }
 
+// C-ABI input check (bpmi.hip validate_*): *first_bad = min(*first_bad, tag | i) over the points i that are neither the identity nor
+// on the curve (curve.hpp wire_point_valid)
+__global__ void __launch_bounds__(256) k_ec_validate(const u32 *__restrict__ pts, u32 n, u32 tag, u32 *first_bad) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u32 w[16];
+  load_words16(w, pts + 16ull * i);
+  if (!wire_point_valid(w)) atomicMin(first_bad, tag | i);
+}
+
 // out = sum of n affine points (one block)
 __global__ void __launch_bounds__(256) k_ec_sum(const u32 *__restrict__ pts, u32 n, u32 *__restrict__ out) {
   __shared__ u32 s_val[256 * LDS_STRIDE];

@@ -65,6 +65,14 @@ int bpmi_rp_prover_create(bpmi_ctx *ctx, uint32_t nbits, const uint8_t g[64], co
   *out = nullptr;
   if (nbits < 2 || nbits > 128 || (nbits & (nbits - 1))) return fail(ctx, BPMI_E_ARG, "the bit width must be a power of two in [2, 128]");
   HIPCHK(ctx, hipSetDevice(ctx->device));
+  if (ctx->opt_validate >= 1) {
+    int vrc = validate_host(ctx, g, 1, "bpmi_rp_prover_create", "g");
+    if (!vrc) vrc = validate_host(ctx, h, 1, "bpmi_rp_prover_create", "h");
+    if (!vrc) vrc = validate_host(ctx, u, 1, "bpmi_rp_prover_create", "u");
+    if (!vrc) vrc = validate_host(ctx, gs, nbits, "bpmi_rp_prover_create", "gs");
+    if (!vrc) vrc = validate_host(ctx, hs, nbits, "bpmi_rp_prover_create", "hs");
+    if (vrc) return vrc;
+  }
   bpmi_rp_prover *pv = new bpmi_rp_prover();
   pv->ctx = ctx; pv->n = nbits; pv->k = 0;
   while ((1u << pv->k) < nbits) pv->k++;

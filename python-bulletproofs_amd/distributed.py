@@ -82,6 +82,8 @@ class ShardedMSM:
             # RCCL: gather straight into one device buffer and fold it there -- no copy of the partials back to
             # the host and up again; everything on the exchange stream (see the class docstring)
             return self.combine_wait(self.combine_begin(partial))
+        if len(partial) != 64:
+            raise ValueError("ShardedMSM: a partial result is one 64-byte point, got %d bytes" % len(partial))
         parts = all_gather_bytes(partial, self.group)
         return self.fold(b"".join(parts), len(parts))
 
@@ -89,6 +91,8 @@ class ShardedMSM:
         """Start combine() and return a handle for combine_wait(): on RCCL the copy up, the all_gather and the fold kernel
         are only QUEUED on the exchange stream, so a pipelined caller can enqueue its next MSM before it waits -- the fold
         kernel may have to wait for the running accumulate kernel to free a wave slot, and nobody should wait with it."""
+        if len(partial) != 64:
+            raise ValueError("ShardedMSM: a partial result is one 64-byte point, got %d bytes" % len(partial))
         if not dist.is_initialized():
             return ("done", partial)
         if self.device_fold and dist.get_backend(self.group) == "nccl":
@@ -97,6 +101,10 @@ class ShardedMSM:
                                    "its staging buffers are still in use")
             world = dist.get_world_size(self.group)
             stream, eng2, pin, mine, flat, d_out, pin_out = self._comm_setup(world)
+            # the exchange buffers live on the device the fold's ctx drives: a mismatch (a rank that changed its current device between
+            # two exchanges) would hand RCCL and the fold kernel pointers of another GPU
+            if not (mine.device.index == flat.device.index == d_out.device.index == eng2.device) or flat.numel() != 64 * world:
+                raise RuntimeError("ShardedMSM: exchange buffers on device %s / %s, fold ctx on device %s" % (mine.device, flat.device, eng2.device))
             self._inflight = True
             pin.copy_(torch.frombuffer(bytearray(partial), dtype=torch.uint8))
             with torch.cuda.stream(stream):

@@ -87,7 +87,10 @@ _ASCII_BITS = bytes(range(256)).translate(bytes(c & 1 for c in range(256)))     
 def _threads(count):
     """Host threads for the native O(n m) loops: one per 1 024 elements, at most BPMI_HOST_THREADS (default 8) and the CPUs of the process."""
     import os
-    cap = int(os.environ.get("BPMI_HOST_THREADS", "8") or 8)
+    try:
+        cap = int(os.environ.get("BPMI_HOST_THREADS", "8") or 8)
+    except ValueError:                       # a malformed setting must not fail a proof
+        cap = 8
     return max(1, min(cap, len(os.sched_getaffinity(0)), count // 1024))
 
 

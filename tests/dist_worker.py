@@ -34,19 +34,32 @@ def batch_mode():
     rank, world = dist.get_rank(), dist.get_world_size()
     b = make_batch(5)
     sm = ShardedMSM(msm=oracle_msm, fold=oracle_fold)
-    lo, hi = shard_bounds(5, world, rank)
-    for corrupt in (False, True):
-        bv = BatchRangeVerifier(b["g"], b["h"], b["gs"], b["hs"], b["u"], msm=oracle_msm)
-        for k in range(lo, hi):
-            pr = b["proofs"][k]
-            if corrupt and k == 4:
-                pr.mu = pr.mu + ModP(1, secp256k1.q)
-            bv.add(b["Vs"][k], pr)
+    # the two lines bench.py reports for N > 1 (extra_c5): "strong" = ONE batch split over the ranks by proof (5 proofs: ranks
+    # without a proof contribute the identity), "weak" = a batch per rank (3 proofs each, the distinct proofs repeated: total 3 N)
+    for line, total in (("strong", 5), ("weak", 3 * world)):
+        lo, hi = shard_bounds(total, world, rank)
+        for corrupt in (False, True):
+            bad_at = total - 1                        # (one proof of the last rank's shard)
+            bv = BatchRangeVerifier(b["g"], b["h"], b["gs"], b["hs"], b["u"], msm=oracle_msm)
+            for k in range(lo, hi):
+                pr = b["proofs"][k % 5]
+                mu = pr.mu
+                if corrupt and k == bad_at:
+                    pr.mu = pr.mu + ModP(1, secp256k1.q)
+                bv.add(b["Vs"][k % 5], pr)
+                pr.mu = mu
+            try:
+                ok = bv.verify(sharded=sm)
+            except Exception as e:
+                ok = str(e)
+            assert ok == ("Proof invalid" if corrupt else True), (rank, line, corrupt, ok)
+    # a partial result is exactly one 64-byte point: anything else is refused before a collective is entered (on every rank alike)
+    for wrong in (b"", bytes(63), bytes(128)):
         try:
-            ok = bv.verify(sharded=sm)
-        except Exception as e:
-            ok = str(e)
-        assert ok == ("Proof invalid" if corrupt else True), (rank, corrupt, ok)
+            sm.combine(wrong)
+            raise AssertionError("a %d-byte partial was accepted" % len(wrong))
+        except ValueError:
+            pass
     dist.barrier()
     if rank == 0:
         print("DIST_BATCH_OK world=%d" % world)

@@ -63,6 +63,12 @@ def test_eight_rank_gloo_sharded_msm_and_batch_verifier():
     _run_ranks(8, "batch", 29527, "DIST_BATCH_OK")
 
 
+def test_two_rank_gloo_batch_verifier_strong_and_weak_lines():
+    """Both C5 lines of `bench.py --gpus N` (one batch split over the ranks; one batch per rank) at world 2 -- world 8 runs in
+    test_eight_rank_gloo_sharded_msm_and_batch_verifier -- and the 64-byte guard of ShardedMSM.combine."""
+    _run_ranks(2, "batch", 29531, "DIST_BATCH_OK")
+
+
 def test_sharded_prover_rejects_a_non_cyclic_layout():
     """Unequal shard lengths that are not 'shorter than the ranks' must be a clear ValueError on every rank, not a torch
     buffer error from a collective."""

@@ -281,26 +281,40 @@ def test_c4_aggregated_128x64_equals_oracle(gp):
 
 
 def test_c5_batch_verify_2e14_from_wire(gp):
-    from bulletproofs_amd.ec import secp256k1
-    from bulletproofs_amd.rangeproofs import BatchRangeVerifier, NIRangeProver, RangeVerifier
-    from bulletproofs_amd.rangeproofs.codec import proof_to_bytes
-    from bulletproofs_amd.utils import ModP, commitment, mod_hash
+    """BASELINE config C5 on one GPU: 2^14 DISTINCT 64-bit proofs (values, blinding factors, seeds) -- made by the batched prover in
+    one device call (round 5; round 4 repeated 1 024 proofs 16 times), a sample of them byte-identical to the single-proof prover's
+    and accepted by the individual verifier -- verified as ONE batch from wire bytes."""
+    from bulletproofs_amd.ec import Point, secp256k1
+    from bulletproofs_amd.rangeproofs import BatchRangeProver, BatchRangeVerifier, NIRangeProver, RangeVerifier
+    from bulletproofs_amd.rangeproofs.codec import proof_to_bytes, proofs_from_bytes, wire_v2_to_v1
+    from bulletproofs_amd.utils import ModP, commitment
     eng = gp.engine()
-    n, total, distinct = 64, 1 << 14, 1024        # 1024 DISTINCT proofs (values, blindings, seeds), each 16 times, positions interleaved
+    n, total = 64, 1 << 14
+    distinct = total
     gs, hs = gp.to_gpu_list(gens(n, b"c5gs")), gp.to_gpu_list(gens(n, b"c5hs"))
     g, h, u = (gp.to_gpu(R.elliptic_hash(s)) for s in (b"c5g", b"c5h", b"c5u"))
-    Vd, wire = [], []
-    for j in range(distinct):
-        v = ModP(int.from_bytes(hashlib.sha256(b"c5v%d" % j).digest()[:8], "big"), Q)
-        gamma = mod_hash(b"c5gamma%d" % j, Q)
-        V = commitment(g, h, v, gamma)
-        pr = NIRangeProver(v, n, g, h, gs, hs, gamma, u, secp256k1, b"c5seed%d" % j).prove()
-        if j < 3:      # the individual verifier (parity-tested against the reference goldens) accepts what the batch will see
-            assert RangeVerifier(V, g, h, gs, hs, u, pr).verify() is True
-        Vd.append(V)
-        wire.append(proof_to_bytes(pr))
-    Vs = [Vd[k % distinct] for k in range(total)]
-    blobs = [wire[k % distinct] for k in range(total)]
+    vals = [int.from_bytes(hashlib.sha256(b"c5v%d" % j).digest()[:8], "big") for j in range(total)]
+    gams = [int.from_bytes(hashlib.sha256(b"c5gamma%d" % j).digest(), "big") % Q for j in range(total)]
+    seeds = [b"c5seed%d" % j for j in range(total)]
+    bp = BatchRangeProver(n, g, h, gs, hs, u)
+    try:
+        wire2 = bp.prove_wire(vals, gams, seeds)
+    finally:
+        bp.close()
+    assert len(set(wire2)) == total
+    le = lambda xs: b"".join(int(x).to_bytes(32, "little") for x in xs)
+    one = (1).to_bytes(32, "little")
+    vsum = eng.ec_lincomb2_batch_bytes(eng.ec_mul_batch_bytes(g.to_le64() * total, le(vals), total), eng.ec_mul_batch_bytes(h.to_le64() * total, le(gams), total),
+                                       one, one, total)
+    Vd = [Point.from_le64(vsum[64 * j: 64 * j + 64]) for j in range(total)]
+    for j in (0, 1, 4097, total - 1):      # the single-proof prover writes the same bytes; the individual verifier (parity-tested against the reference goldens) accepts them
+        v, gamma = ModP(vals[j], Q), ModP(gams[j], Q)
+        assert Vd[j] == commitment(g, h, v, gamma)
+        pr = NIRangeProver(v, n, g, h, gs, hs, gamma, u, secp256k1, seeds[j]).prove()
+        assert proof_to_bytes(pr, version=2) == wire2[j]
+        assert RangeVerifier(Vd[j], g, h, gs, hs, u, proofs_from_bytes([wire2[j]])[0]).verify() is True
+    wire = [wire_v2_to_v1(b) for b in wire2]
+    Vs, blobs = Vd, wire
     threads = min(32, len(os.sched_getaffinity(0)))
     bv = BatchRangeVerifier(g, h, gs, hs, u)
     bv.add_wire_native(Vs, blobs, threads=threads)
