@@ -108,6 +108,9 @@ int bpmi_sync(bpmi_ctx *ctx);
  *                  (0 = default 4096, 1 = never, else a power of two; the later rounds then run on the one-launch small-MSM kernel)
  *   "pair_phases"  1: bpmi_msm2 on the bucket pipeline queues both MSMs' sorts before either accumulation.  An experiment that came out
  *                  neutral (profiles/r04_C3_pair_phases_ab.txt); default 0
+ *   "ipa_fixed_generators" 1: the generator arrays handed to bpmi_ipa_create_dev are deployment constants.  The tables of odd multiples that
+ *                  the prover's 16-way generator fold builds from them (1.1 ms at n = 2^20) are then kept between proofs for as long as the
+ *                  calls name the same d_g, d_h and n: the caller's promise that the arrays were not modified.  Default 0
  *   "validate_points" on-curve check of input points: 0 never, 1 (default) every entry point that takes HOST pointers to points (bpmi_msm,
  *                  bpmi_msm2, bpmi_ec_mul_batch, bpmi_ec_lincomb2_batch, bpmi_ec_sum, bpmi_ipa_create[_scaled], the extra points of
  *                  bpmi_ipa_verify_dev, the commitments of bpmi_rp_batch_verify_dev, bpmi_rp_prover_create), 2 also the synchronous entry

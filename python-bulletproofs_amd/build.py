@@ -27,18 +27,46 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def build(force=False, verbose=False):
+def hipcc_version():
+    try:
+        out = subprocess.run([hipcc(), "--version"], capture_output=True, text=True, timeout=60).stdout
+        lines = [ln.strip() for ln in out.splitlines() if ln.strip()]
+        return "; ".join(ln for ln in lines if ln.startswith(("HIP version", "AMD clang version")))[:200] or (lines[0] if lines else "unknown")
+    except Exception as e:          # the record must not fail the build
+        return "unknown (%s)" % type(e).__name__
+
+
+def build(force=False, verbose=False, report=None):
+    """Compile libbpmi.so for gfx950 when it is missing or older than a source (force: always).  `report` (a callable taking one
+    line of text) is told what happened -- "compiled" with the compiler's version and the seconds it took, or "reused" with the reason
+    -- so that a build record says whether anything was compiled (the prebuilt .so travels with the snapshot)."""
+    import time
+    report = report or (lambda line: None)
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
     if not force and not needs_build():
+        report("libbpmi.so: reused (up to date: newer than its %d sources and build.py; sha256 %s)" % (len(deps), sha256_of(LIB)[:16]))
         return LIB
+    why = "forced" if force and os.path.exists(LIB) else ("missing" if not os.path.exists(LIB) else "older than a source")
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
            "-Wno-unused-result", "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
         print(" ".join(cmd), file=sys.stderr)
+    t0 = time.time()
     subprocess.check_call(cmd)
+    report("libbpmi.so: compiled for gfx950 in %.1f s (was %s) with %s; sha256 %s" % (time.time() - t0, why, hipcc_version(), sha256_of(LIB)[:16]))
     return LIB
 
 
+def sha256_of(path):
+    import hashlib
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for chunk in iter(lambda: f.read(1 << 20), b""):
+            h.update(chunk)
+    return h.hexdigest()
+
+
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, verbose="-v" in sys.argv)
+    build(force="--force" in sys.argv, verbose="-v" in sys.argv, report=print)
     print(LIB)

@@ -144,6 +144,7 @@ int bpmi_set_option(bpmi_ctx *ctx, const char *name, int64_t value) {
   if (!ctx || !name) return BPMI_E_ARG;
   if (!strcmp(name, "window_bits")) { if (value != 0 && (value < 2 || value > 16)) return fail(ctx, BPMI_E_ARG, "window_bits must be 0 or 2..16"); ctx->opt_c = (int)value; return BPMI_OK; }
   if (!strcmp(name, "top_window_unsigned")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "top_window_unsigned must be 0 or 1"); ctx->opt_top2 = (int)value; msm_graphs_clear(ctx); return BPMI_OK; }
+  if (!strcmp(name, "ipa_fixed_generators")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "ipa_fixed_generators must be 0 or 1"); ctx->opt_ipa_fixed = (int)value; ctx->fold_key_g = ctx->fold_key_h = nullptr; return BPMI_OK; }
   if (!strcmp(name, "validate_points")) { if (value < 0 || value > 2) return fail(ctx, BPMI_E_ARG, "validate_points must be 0, 1 or 2"); ctx->opt_validate = (int)value; return BPMI_OK; }
   if (!strcmp(name, "sort_inblock")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "sort_inblock must be 0 or 1"); ctx->opt_inblock = (int)value; msm_graphs_clear(ctx); return BPMI_OK; }
   if (!strcmp(name, "segscan_fused")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "segscan_fused must be 0 or 1"); ctx->opt_segfuse = (int)value; msm_graphs_clear(ctx); return BPMI_OK; }
@@ -879,6 +880,7 @@ struct bpmi_ipa {
   std::vector<sc> hcg, hch;   // host copies of the coefficient tables while 2^d <= 16
   bool lr_done;
   bool prep_ready;      // the scalars of the next L / R and c_L, c_R are on the device already (k_ipa_small_step did the next round's preparation)
+  const void *src_g = nullptr, *src_h = nullptr;      // bpmi_ipa_create_dev: the caller's generator arrays (the key of the kept fold tables, option ipa_fixed_generators)
 };
 
 // deferral policy: bases of 2^18 points or more are folded 16-way at once (an MSM over the
@@ -957,6 +959,7 @@ int bpmi_ipa_create_dev(bpmi_ctx *ctx, const void *d_g, const void *d_h, const v
   if (e == hipSuccess) e = h2d(ctx, st->u, u, 64, s);
   if (e == hipSuccess) e = hipStreamSynchronize(s);
   if (e != hipSuccess) { (void)hipFree(st->block); delete st; return fail(ctx, BPMI_E_HIP, std::string("ipa_create copy: ") + hipGetErrorString(e)); }
+  st->src_g = d_g; st->src_h = d_h;
   *out = st;
   return BPMI_OK;
 }
@@ -1171,6 +1174,7 @@ int bpmi_ipa_fold(bpmi_ipa *st, const uint8_t x[32], const uint8_t xinv[32]) {
     if (ctx->opt_fold_wnaf && npts >= 256) {
       const size_t need = 2 * tab_bytes + scr_bytes + 2 * wn_bytes + 2 * tabx_bytes;
       if (need > ctx->fold_tab_bytes) {
+        ctx->fold_key_g = ctx->fold_key_h = nullptr;
         if (ctx->fold_tab) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->fold_tab); ctx->fold_tab = nullptr; ctx->fold_tab_bytes = 0; }
         if (hipMalloc(&ctx->fold_tab, need) == hipSuccess) ctx->fold_tab_bytes = need; else { (void)hipGetLastError(); ctx->fold_tab = nullptr; }
       }
@@ -1190,8 +1194,16 @@ int bpmi_ipa_fold(bpmi_ipa *st, const uint8_t x[32], const uint8_t xinv[32]) {
         HIPCHK(ctx, h2d(ctx, dw + wn_bytes, &hgb, sizeof(WnafG), ctx->stream));
         {
           StageTimer t(ctx, ST_LINCOMB2);
-          hipLaunchKernelGGL(k_ec_odd_multiples<ODDMUL_PER_THREAD>, dim3((u32)((2 * nthr + 255) / 256)), dim3(256), 0, ctx->stream, st->g, st->h, (u32)npts, tab_a, tab_b, scr,
-                             tabx_a, tabx_b);
+          // Option ipa_fixed_generators: the generators of a deployment are constants, and so are the tables of their odd multiples
+          // (3P, 5P, 7P and the beta x column: 1.1 ms of k_ec_odd_multiples at 2^20).  They are kept between proofs that name the SAME
+          // caller arrays (bpmi_ipa_create_dev: d_g, d_h, n) -- the caller's promise that the arrays have not changed.
+          const bool kept = ctx->opt_ipa_fixed && st->src_g && ctx->fold_key_g == st->src_g && ctx->fold_key_h == st->src_h && ctx->fold_key_n == npts && !st->hscale;
+          if (!kept) {
+            hipLaunchKernelGGL(k_ec_odd_multiples<ODDMUL_PER_THREAD>, dim3((u32)((2 * nthr + 255) / 256)), dim3(256), 0, ctx->stream, st->g, st->h, (u32)npts, tab_a, tab_b, scr,
+                               tabx_a, tabx_b);
+            if (ctx->opt_ipa_fixed && st->src_g && !st->hscale) { ctx->fold_key_g = st->src_g; ctx->fold_key_h = st->src_h; ctx->fold_key_n = npts; }
+            else ctx->fold_key_g = ctx->fold_key_h = nullptr;
+          }
           hipLaunchKernelGGL(k_ec_multifold_w4g, dim3((u32)((2 * st->n + 255) / 256)), dim3(256), 0, ctx->stream, ja, jb, tab_a, tab_b, tabx_a, tabx_b,
                              (const WnafG *)dw, (const WnafG *)(dw + wn_bytes), (u32)st->n, K2);
         }
@@ -1208,6 +1220,7 @@ int bpmi_ipa_fold(bpmi_ipa *st, const uint8_t x[32], const uint8_t xinv[32]) {
         HIPCHK(ctx, h2d(ctx, dwb, &hwb, sizeof(WnafK), ctx->stream));
         {
           StageTimer t(ctx, ST_LINCOMB2);
+          ctx->fold_key_g = ctx->fold_key_h = nullptr;
           hipLaunchKernelGGL(k_ec_odd_multiples<ODDMUL_PER_THREAD>, dim3((u32)((2 * nthr + 255) / 256)), dim3(256), 0, ctx->stream, st->g, st->h, (u32)npts, tab_a, tab_b, scr,
                              (u32 *)nullptr, (u32 *)nullptr);
           hipLaunchKernelGGL(k_ec_multifold_w4, dim3((u32)((2 * st->n + 255) / 256)), dim3(256), 0, ctx->stream, ja, jb, tab_a, tab_b, dwa, dwb,

@@ -90,6 +90,8 @@ struct bpmi_ctx {
   int opt_fold_shared = 1;   // the product fold of a state without per-generator scales: shared GLV halves, two terms per thread (0: per-lane products)
   int64_t opt_ipa_small = 0; // logical length at which smaller bases are folded through products (0 = default 4096, 1 = never)
   void *fold_tab = nullptr; size_t fold_tab_bytes = 0;     // tables + scratch of the width-4 NAF generator fold, allocated at the first fold, kept
+  int opt_ipa_fixed = 0;     // 1: the generator arrays of bpmi_ipa_create_dev are deployment constants: the fold's tables of their odd multiples are kept between proofs
+  const void *fold_key_g = nullptr, *fold_key_h = nullptr; uint64_t fold_key_n = 0;     // whose tables fold_tab holds (nullptr: nobody's)
   // profiling
   bool prof = false;
   int prof_only = -1;      // >= 0: time only this stage (every event record costs a ~10 us bubble between kernels)

@@ -311,6 +311,8 @@ BPMI_HD bool wire_point_valid(const u32 w[16]) {
   return ok && fe_equal(ca, ct);
 }
 
-struct TailOffs { u32 nv; u32 off[4]; u32 top; u32 top_off[4]; };      // top = 1: the last window uses top_off (MsmGeom.top2)
+// bit offsets of the (<= 4) partial sums the bucket reduction leaves per window; top = 1: the LAST window was split at top_off instead
+// (MsmGeom.top2).  The round-5 fields default to "none", so code that fills nv / off only stays right.
+struct TailOffs { u32 nv; u32 off[4]; u32 top = 0; u32 top_off[4] = {0, 0, 0, 0}; };
 
 }  // namespace bpmi

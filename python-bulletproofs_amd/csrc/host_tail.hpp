@@ -39,14 +39,8 @@ static inline void f_sub(f64 &r, const f64 &a, const f64 &b) {
   for (int i = 0; i < 4; i++) { u128 t = (u128)a.v[i] - b.v[i] - br; r.v[i] = (u64)t; br = (u64)(t >> 64) & 1; }
   if (br) { u64 c = 0; for (int i = 0; i < 4; i++) { u128 t = (u128)r.v[i] + P64[i] + c; r.v[i] = (u64)t; c = (u64)(t >> 64); } }
 }
-static inline void f_mul(f64 &r, const f64 &a, const f64 &b) {
-  u64 t[8] = {0};
-  for (int i = 0; i < 4; i++) {
-    u128 c = 0;
-    for (int j = 0; j < 4; j++) { c += (u128)a.v[i] * b.v[j] + t[i + j]; t[i + j] = (u64)c; c >>= 64; }
-    t[i + 4] = (u64)c;
-  }
-  // lo + hi * PC, twice
+// lo + hi * (2^256 - p), twice, then the conditional subtraction: t[0..8) -> r in [0, p)
+static inline void f_reduce512(f64 &r, const u64 t[8]) {
   u64 m[5];
   u128 c = 0;
   for (int i = 0; i < 4; i++) { c += (u128)t[4 + i] * PC + t[i]; m[i] = (u64)c; c >>= 64; }
@@ -60,15 +54,61 @@ static inline void f_mul(f64 &r, const f64 &a, const f64 &b) {
   if (k) { u128 a0 = (u128)r.v[0] + PC; r.v[0] = (u64)a0; u64 kk = (u64)(a0 >> 64); for (int i = 1; i < 4 && kk; i++) { a0 = (u128)r.v[i] + kk; r.v[i] = (u64)a0; kk = (u64)(a0 >> 64); } }
   if (ge_p(r.v)) sub_p(r.v);
 }
-static inline void f_sqr(f64 &r, const f64 &a) { f_mul(r, a, a); }
-static inline void f_inv(f64 &r, const f64 &a) {          // a^(p-2), plain square-and-multiply
-  static const u64 E[4] = {0xFFFFFFFEFFFFFC2DULL, ~0ULL, ~0ULL, ~0ULL};
-  f64 acc = {{1, 0, 0, 0}};
-  for (int i = 255; i >= 0; i--) {
-    f_sqr(acc, acc);
-    if ((E[i >> 6] >> (i & 63)) & 1) f_mul(acc, acc, a);
+static inline void f_mul(f64 &r, const f64 &a, const f64 &b) {
+  u64 t[8] = {0};
+  for (int i = 0; i < 4; i++) {
+    u128 c = 0;
+    for (int j = 0; j < 4; j++) { c += (u128)a.v[i] * b.v[j] + t[i + j]; t[i + j] = (u64)c; c >>= 64; }
+    t[i + 4] = (u64)c;
   }
-  r = acc;
+  f_reduce512(r, t);
+}
+// Round 5: a squaring of its own (6 cross products doubled + 4 squares instead of 16 products): 1 000 of the tail's 3 300
+// field multiplications are squarings.
+static inline void f_sqr(f64 &r, const f64 &a) {
+  u64 t[8];
+  u128 c;
+  // cross products a_i a_j, i < j, into t[1..6]
+  c = (u128)a.v[0] * a.v[1]; t[1] = (u64)c; c >>= 64;
+  c += (u128)a.v[0] * a.v[2]; t[2] = (u64)c; c >>= 64;
+  c += (u128)a.v[0] * a.v[3]; t[3] = (u64)c; t[4] = (u64)(c >> 64);
+  c = (u128)a.v[1] * a.v[2] + t[3]; t[3] = (u64)c; c >>= 64;
+  c += (u128)a.v[1] * a.v[3] + t[4]; t[4] = (u64)c; t[5] = (u64)(c >> 64);
+  c = (u128)a.v[2] * a.v[3] + t[5]; t[5] = (u64)c; t[6] = (u64)(c >> 64);
+  // double them
+  t[7] = t[6] >> 63;
+  for (int i = 6; i >= 2; i--) t[i] = (t[i] << 1) | (t[i - 1] >> 63);
+  t[1] <<= 1;
+  // add the squares a_i^2 at word 2i
+  c = (u128)a.v[0] * a.v[0]; t[0] = (u64)c; c >>= 64;
+  c += t[1]; t[1] = (u64)c; c >>= 64;
+  for (int i = 1; i < 4; i++) {
+    const u128 sq = (u128)a.v[i] * a.v[i];
+    c += (u128)(u64)sq + t[2 * i]; t[2 * i] = (u64)c; c >>= 64;
+    c += (u128)(u64)(sq >> 64) + t[2 * i + 1]; t[2 * i + 1] = (u64)c; c >>= 64;
+  }
+  f_reduce512(r, t);
+}
+static inline void f_sqr_n(f64 &r, const f64 &a, int n) { r = a; for (int i = 0; i < n; i++) f_sqr(r, r); }
+// a^(p-2) by the addition chain over the runs of ones of p - 2 = 2^256 - 2^32 - 979 (223, 22, 1, 2, 1 ones): 255 squarings and
+// 15 multiplications (round 4: 256 + 249 with plain square-and-multiply)
+static inline void f_inv(f64 &r, const f64 &a) {
+  f64 x2, x3, x6, x9, x11, x22, x44, x88, x176, x220, x223, t;
+  f_sqr(t, a); f_mul(x2, t, a);
+  f_sqr(t, x2); f_mul(x3, t, a);
+  f_sqr_n(t, x3, 3); f_mul(x6, t, x3);
+  f_sqr_n(t, x6, 3); f_mul(x9, t, x3);
+  f_sqr_n(t, x9, 2); f_mul(x11, t, x2);
+  f_sqr_n(t, x11, 11); f_mul(x22, t, x11);
+  f_sqr_n(t, x22, 22); f_mul(x44, t, x22);
+  f_sqr_n(t, x44, 44); f_mul(x88, t, x44);
+  f_sqr_n(t, x88, 88); f_mul(x176, t, x88);
+  f_sqr_n(t, x176, 44); f_mul(x220, t, x44);
+  f_sqr_n(t, x220, 3); f_mul(x223, t, x3);
+  f_sqr_n(t, x223, 23); f_mul(t, t, x22);
+  f_sqr_n(t, t, 5); f_mul(t, t, a);
+  f_sqr_n(t, t, 3); f_mul(t, t, x2);
+  f_sqr_n(t, t, 2); f_mul(r, t, a);
 }
 static inline void f_from_limbs(f64 &r, const bpmi::u32 limbs[9]) {
   bpmi::fe t, c;
@@ -108,6 +148,28 @@ static inline void pt_add(pt &r, const pt &a, const pt &b) {   // add-2008-s, co
   f_mul(t2, a.ZZZ, b.ZZZ); f_mul(r.ZZZ, t2, PPP);
   r.X = X3; r.Y = t;
 }
+// k doublings in a row.  Round 5: from two on they run in Jacobian coordinates (dbl-2009-l, a = 0: 2M + 5S against the 6M + 3S of
+// the XYZZ doubling; in: (X ZZ, Y ZZZ, ZZ), out: ZZ = Z^2, ZZZ = Z ZZ -- 3M + 1S for the round trip, and the identity Z = 0 stays
+// the identity).  The chain is 256 doublings and ~64 additions: the doublings are what the tail costs.
+static inline void pt_dbl_run(pt &a, int k) {
+  if (k <= 0) return;
+  if (k == 1 || f_is_zero(a.ZZ)) { for (int i = 0; i < k; i++) pt_dbl(a, a); return; }
+  f64 X, Y, Z, A, B, C, D, E, F, t;
+  f_mul(X, a.X, a.ZZ); f_mul(Y, a.Y, a.ZZZ); Z = a.ZZ;
+  for (int i = 0; i < k; i++) {
+    f_sqr(A, X); f_sqr(B, Y); f_sqr(C, B);
+    f_add(t, X, B); f_sqr(t, t); f_sub(t, t, A); f_sub(t, t, C); f_add(D, t, t);
+    f_add(E, A, A); f_add(E, E, A);
+    f_sqr(F, E);
+    f_mul(t, Y, Z); f_add(Z, t, t);
+    f_sub(t, F, D); f_sub(X, t, D);
+    f_sub(t, D, X); f_mul(t, E, t);
+    f_add(C, C, C); f_add(C, C, C); f_add(C, C, C);
+    f_sub(Y, t, C);
+  }
+  a.X = X; a.Y = Y;
+  f_sqr(a.ZZ, Z); f_mul(a.ZZZ, a.ZZ, Z);
+}
 // result = sum_w 2^(c w) sum_v 32^v E[w][v] as ONE Horner chain over bit positions
 static inline void tail_combine(uint8_t out[64], const bpmi::u32 *E, bpmi::u32 W, bpmi::u32 c, const bpmi::TailOffs &to) {
   pt acc;
@@ -116,7 +178,7 @@ static inline void tail_combine(uint8_t out[64], const bpmi::u32 *E, bpmi::u32 W
     int prev = (int)c;
     const bpmi::u32 *offs = (to.top && w == (int)W - 1) ? to.top_off : to.off;      // (top2: the last window's own split offsets)
     for (int v = (int)to.nv - 1; v >= 0; v--) {
-      for (int k = prev; k > (int)offs[v]; k--) pt_dbl(acc, acc);
+      pt_dbl_run(acc, prev - (int)offs[v]);
       prev = (int)offs[v];
       pt e;
       pt_load(e, E + ((size_t)w * to.nv + v) * 36);

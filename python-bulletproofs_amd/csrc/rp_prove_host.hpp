@@ -191,7 +191,7 @@ int bpmi_rp_prove_batch(bpmi_rp_prover *pv, uint64_t n_proofs, const uint8_t *va
   const size_t in_bytes = o;                                   // everything above is uploaded in one copy
   const size_t o_tr = take((size_t)P * tr_stride), o_trlen = take(4ull * P);
   const size_t o_slr = take(32ull * P * (2 * n + 1)), o_alpha = take(32ull * P), o_chal = take(128ull * P), o_tau = take(64ull * P), o_tsc = take(128ull * P);
-  const size_t o_res = take(160ull * P), o_xs = take(32ull * P * k);
+  const size_t o_res = take(160ull * P), o_xs = take(32ull * P * k), o_xr = take(64ull * P);
   const size_t o_a = take(32ull * P * n), o_b = take(32ull * P * n), o_cg = take(32ull * P * n), o_hf = take(32ull * P * n);
   const size_t o_jsc = take(32ull * P * (2 * n + 2)), o_jout = take(144ull * 2 * P), o_pts = take(64ull * P * npt);
   const size_t o_out = take(total_out + 16);
@@ -232,7 +232,7 @@ int bpmi_rp_prove_batch(bpmi_rp_prover *pv, uint64_t n_proofs, const uint8_t *va
   memcpy(B.u_new, pv->u_new, 64);
   B.tr = (unsigned char *)(d + o_tr); B.tr_stride = tr_stride; B.tr_len = (u32 *)(d + o_trlen);
   B.slr = (u32 *)(d + o_slr); B.alpha = (u32 *)(d + o_alpha); B.chal = (u32 *)(d + o_chal); B.tau = (u32 *)(d + o_tau); B.tsc = (u32 *)(d + o_tsc);
-  B.res = (u32 *)(d + o_res); B.xs = (u32 *)(d + o_xs);
+  B.res = (u32 *)(d + o_res); B.xs = (u32 *)(d + o_xs); B.xr = (u32 *)(d + o_xr);
   B.a = (u32 *)(d + o_a); B.b = (u32 *)(d + o_b); B.cg = (u32 *)(d + o_cg); B.hf = (u32 *)(d + o_hf);
   B.jsc = (u32 *)(d + o_jsc); B.jout = (u32 *)(d + o_jout); B.pts = (u32 *)(d + o_pts);
   hipEvent_t ev[7];
@@ -269,11 +269,13 @@ int bpmi_rp_prove_batch(bpmi_rp_prover *pv, uint64_t n_proofs, const uint8_t *va
   affine(P, 1, PV_PT_PNEW, 0);
   (void)hipEventRecord(ev[3], st);
   // the rounds of Protocol 2 (inner_product_prover.py:94-110)
+  const u32 per_block = 256u / n;                      // proofs per block of k_pv_round_wide (n lanes each)
+  hipLaunchKernelGGL(rpp::k_pv_round_wide, dim3((P + per_block - 1) / per_block), dim3(256), 0, st, B, 0u, 1u);
   for (u32 r = 0; r < k; r++) {
-    hipLaunchKernelGGL(rpp::k_pv_round_scalars, blocks(P, 64), dim3(64), 0, st, B, r);
     msm(2 * P, 2, n + 1, pv->off_round + r * 2 * (n + 1), B.jsc, n + 1, 4);
     affine(2 * P, 2, 6 + r, k);
-    hipLaunchKernelGGL(rpp::k_pv_round_fold, blocks(P, 64), dim3(64), 0, st, B, r);
+    hipLaunchKernelGGL(rpp::k_pv_round_chal, blocks(P, 64), dim3(64), 0, st, B, r);
+    hipLaunchKernelGGL(rpp::k_pv_round_wide, dim3((P + per_block - 1) / per_block), dim3(256), 0, st, B, r, 0u);
   }
   (void)hipEventRecord(ev[4], st);
   hipLaunchKernelGGL(rpp::k_pv_emit, blocks(P, 64), dim3(64), 0, st, B, (const unsigned char *)(d + o_seeds), (const uint64_t *)(d + o_soff), (unsigned char *)(d + o_out),

@@ -178,6 +178,7 @@ struct Batch {
   u32 *tsc;                  // P x 4: t1, tau1, t2, tau2   (the scalars of T1 and T2 over g, h)
   u32 *res;                  // P x 5: taux, mu, t_hat, a, b
   u32 *xs;                   // P x k
+  u32 *xr;                   // P x 2: the current round's challenge and its inverse
   u32 *a, *b, *cg, *hf;      // P x n each: the inner-product state (cg / hf: coefficient of gs_j / hs_j in the folded generators, y^-j included)
   u32 *jsc;                  // job scalars: P x (2n + 1) (P_new), or 2P x (n + 1) (the L / R of a round)
   u32 *jout;                 // job results, XYZZ: up to 2P x 36 words
@@ -432,38 +433,15 @@ __global__ void __launch_bounds__(64) k_pv_final(Batch B) {
 // cg_j (gs side) / hf_j (hs side, y^-j included).  Job 2p is L, job 2p + 1 is R, n + 1 terms each in the base order of `bases`
 // (host: the gs_j with (j mod len) >= half, then the hs_j with (j mod len) < half, then u, for L; the complements for R):
 //   L = sum a_(i-half) cg_j gs_j + sum b_(i+half) hf_j hs_j + (x_ip cl) u,   i = j mod len
-__global__ void __launch_bounds__(64) k_pv_round_scalars(Batch B, u32 round) {
+// Two kernels per round: k_pv_round_chal, ONE lane per proof (the transcript, its hash, the inversion: serial work, dense waves),
+// and k_pv_round_wide, n lanes per proof (the folds and the next round's scalars: 2-6 multiplications per lane).  With one lane per
+// proof for everything a round cost 1.4 ms beside its 3.1 ms of additions (profiles/r05_batch_prover_first_run.txt).
+
+// L, R -> transcript -> x, 1 / x (inner_product_prover.py:100-106)
+__global__ void __launch_bounds__(64) k_pv_round_chal(Batch B, u32 round) {
   const u32 p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= B.P) return;
-  const u32 n = B.n, len = n >> round, half = len >> 1;
-  const u32 *a = B.a + 8ull * (size_t)p * n, *b = B.b + 8ull * (size_t)p * n, *cg = B.cg + 8ull * (size_t)p * n, *hf = B.hf + 8ull * (size_t)p * n;
-  u32 *jl = B.jsc + 8ull * (size_t)(2u * p) * (n + 1u), *jr = jl + 8ull * (n + 1u);
-  sc cl = sc_u32(0), cr = sc_u32(0);
-  for (u32 i = 0; i < half; i++) {
-    cl = addq(cl, mulq(ld_sc(a + 8ull * i), ld_sc(b + 8ull * (half + i))));
-    cr = addq(cr, mulq(ld_sc(a + 8ull * (half + i)), ld_sc(b + 8ull * i)));
-  }
-  u32 ng_l = 0, ng_r = 0;                        // terms written so far on the gs side
-  for (u32 j = 0; j < n; j++) {
-    const u32 i = j & (len - 1u);
-    const sc c = ld_sc(cg + 8ull * j);
-    if (i >= half) st_sc(jl + 8ull * ng_l++, mulq(ld_sc(a + 8ull * (i - half)), c));
-    else st_sc(jr + 8ull * ng_r++, mulq(ld_sc(a + 8ull * (i + half)), c));
-  }
-  for (u32 j = 0; j < n; j++) {
-    const u32 i = j & (len - 1u);
-    const sc c = ld_sc(hf + 8ull * j);
-    if (i < half) st_sc(jl + 8ull * ng_l++, mulq(ld_sc(b + 8ull * (i + half)), c));
-    else st_sc(jr + 8ull * ng_r++, mulq(ld_sc(b + 8ull * (i - half)), c));
-  }
-  st_sc(jl + 8ull * n, mulq(B.x_ip, cl));
-  st_sc(jr + 8ull * n, mulq(B.x_ip, cr));
-}
-// L, R -> transcript -> x -> the folds (inner_product_prover.py:100-110); after the last round a[0], b[0] are the proof's scalars
-__global__ void __launch_bounds__(64) k_pv_round_fold(Batch B, u32 round) {
-  const u32 p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= B.P) return;
-  const u32 n = B.n, len = n >> round, half = len >> 1, npt = 6u + 2u * B.k;
+  const u32 npt = 6u + 2u * B.k;
   u8 *tr = B.tr + (size_t)p * B.tr_stride;
   u32 tl = B.tr_len[p];
   const u32 *pt = B.pts + 16ull * (size_t)p * npt;
@@ -473,19 +451,73 @@ __global__ void __launch_bounds__(64) k_pv_round_fold(Batch B, u32 round) {
   tl += put_number(tr + tl, x);
   B.tr_len[p] = tl;
   st_sc(B.xs + 8ull * ((size_t)p * B.k + round), x);
-  const sc xi = invq(x);
-  u32 *a = B.a + 8ull * (size_t)p * n, *b = B.b + 8ull * (size_t)p * n, *cg = B.cg + 8ull * (size_t)p * n, *hf = B.hf + 8ull * (size_t)p * n;
-  for (u32 i = 0; i < half; i++) {
-    const sc a0 = ld_sc(a + 8ull * i), a1 = ld_sc(a + 8ull * (half + i)), b0 = ld_sc(b + 8ull * i), b1 = ld_sc(b + 8ull * (half + i));
-    st_sc(a + 8ull * i, addq(mulq(x, a0), mulq(xi, a1)));
-    st_sc(b + 8ull * i, addq(mulq(xi, b0), mulq(x, b1)));
+  st_sc(B.xr + 16ull * p, x);
+  st_sc(B.xr + 16ull * p + 8, invq(x));
+}
+// n lanes per proof (block = 256 threads = 256 / n proofs; n <= 128).  round = the round whose challenge was just drawn: the state is
+// folded with it (:107-110), then the scalars of the NEXT round's L and R are written; first = 1: no fold, the state is the one
+// k_pv_final left (the scalars of round 0).  After the last fold a[0], b[0] are the proof's scalars.
+__global__ void __launch_bounds__(256) k_pv_round_wide(Batch B, u32 round, u32 first) {
+  __shared__ u32 s_a[256 * 8], s_b[256 * 8], s_l[256 * 8], s_r[256 * 8];
+  const u32 n = B.n, tid = threadIdx.x;
+  const u32 p = blockIdx.x * (256u / n) + tid / n, j = tid & (n - 1u);
+  const bool live = p < B.P;
+  const u32 base = tid - j;                                  // first thread of this proof in the block
+  u32 len = first ? n : (n >> round);                        // length BEFORE this call's fold
+  sc cgj = sc_u32(0), hfj = sc_u32(0);
+  if (live) {
+    u32 *a = B.a + 8ull * (size_t)p * n, *b = B.b + 8ull * (size_t)p * n;
+    cgj = ld_sc(B.cg + 8ull * ((size_t)p * n + j)); hfj = ld_sc(B.hf + 8ull * ((size_t)p * n + j));
+    if (!first) {
+      const u32 half = len >> 1;
+      const sc x = ld_sc(B.xr + 16ull * p), xi = ld_sc(B.xr + 16ull * p + 8);
+      if (j < half) {
+        const sc a0 = ld_sc(a + 8ull * j), a1 = ld_sc(a + 8ull * (half + j)), b0 = ld_sc(b + 8ull * j), b1 = ld_sc(b + 8ull * (half + j));
+        const sc an = addq(mulq(x, a0), mulq(xi, a1)), bn = addq(mulq(xi, b0), mulq(x, b1));
+        st_sc(s_a + 8u * tid, an); st_sc(s_b + 8u * tid, bn);
+      }
+      const bool low = (j & (len - 1u)) < half;
+      cgj = mulq(cgj, low ? xi : x); hfj = mulq(hfj, low ? x : xi);
+      st_sc(B.cg + 8ull * ((size_t)p * n + j), cgj); st_sc(B.hf + 8ull * ((size_t)p * n + j), hfj);
+      len = half;
+    } else {
+      st_sc(s_a + 8u * tid, ld_sc(a + 8ull * j)); st_sc(s_b + 8u * tid, ld_sc(b + 8ull * j));
+    }
   }
-  for (u32 j = 0; j < n; j++) {
-    const bool low = (j & (len - 1u)) < half;
-    st_sc(cg + 8ull * j, mulq(ld_sc(cg + 8ull * j), low ? xi : x));
-    st_sc(hf + 8ull * j, mulq(ld_sc(hf + 8ull * j), low ? x : xi));
+  __syncthreads();                                           // s_a / s_b [base + i], i < len: the folded state
+  if (live && !first && j < len) {                           // (the folded halves go back in place: nobody reads the old ones any more)
+    st_sc(B.a + 8ull * ((size_t)p * n + j), ld_sc(s_a + 8u * tid));
+    st_sc(B.b + 8ull * ((size_t)p * n + j), ld_sc(s_b + 8u * tid));
   }
-  if (half == 1u) { u32 *res = B.res + 40ull * p; st_sc(res + 24, ld_sc(a)); st_sc(res + 32, ld_sc(b)); }
+  if (len == 1u) {
+    if (live && j == 0u) { u32 *res = B.res + 40ull * p; st_sc(res + 24, ld_sc(s_a + 8u * tid)); st_sc(res + 32, ld_sc(s_b + 8u * tid)); }
+    return;                                                  // (block-uniform: len depends on the arguments only)
+  }
+  const u32 half = len >> 1, i = j & (len - 1u);
+  // the products of c_L = <a_lo, b_hi>, c_R = <a_hi, b_lo>, summed over the proof's lanes in LDS
+  sc pl = sc_u32(0), pr = sc_u32(0);
+  if (live && j < half) {
+    pl = mulq(ld_sc(s_a + 8u * (base + j)), ld_sc(s_b + 8u * (base + half + j)));
+    pr = mulq(ld_sc(s_a + 8u * (base + half + j)), ld_sc(s_b + 8u * (base + j)));
+  }
+  st_sc(s_l + 8u * tid, pl); st_sc(s_r + 8u * tid, pr);
+  __syncthreads();
+  for (u32 d = n >> 1; d > 0u; d >>= 1) {
+    if (j < d) {
+      st_sc(s_l + 8u * tid, addq(ld_sc(s_l + 8u * tid), ld_sc(s_l + 8u * (tid + d))));
+      st_sc(s_r + 8u * tid, addq(ld_sc(s_r + 8u * tid), ld_sc(s_r + 8u * (tid + d))));
+    }
+    __syncthreads();
+  }
+  if (!live) return;
+  u32 *jl = B.jsc + 8ull * (size_t)(2u * p) * (n + 1u), *jr = jl + 8ull * (n + 1u);
+  if (j == 0u) { st_sc(jl + 8ull * n, mulq(B.x_ip, ld_sc(s_l + 8u * tid))); st_sc(jr + 8ull * n, mulq(B.x_ip, ld_sc(s_r + 8u * tid))); }
+  // generator j: rank among the generators of its side of the split = (j / len) half + (i mod half)
+  const bool up = i >= half;
+  const u32 rank = (j / len) * half + (up ? i - half : i);
+  const sc ga = ld_sc(s_a + 8u * (base + (up ? i - half : i + half))), hb = ld_sc(s_b + 8u * (base + (up ? i - half : i + half)));
+  st_sc((up ? jl : jr) + 8ull * rank, mulq(ga, cgj));                       // L: a_(i-half) cg_j for i >= half; R: a_(i+half) cg_j for i < half
+  st_sc((up ? jr : jl) + 8ull * ((n >> 1) + rank), mulq(hb, hfj));          // L: b_(i+half) hf_j for i < half; R: b_(i-half) hf_j for i >= half
 }
 
 // ---- the proofs as wire format 2 (rangeproofs/codec.py): "BPRP2" k | taux mu t_hat a b | xs | 6 + 2k compressed points | y z x x_ip |

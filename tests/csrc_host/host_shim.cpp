@@ -10,6 +10,7 @@
 #include "fold_ops_host.hpp"
 #include "../../include/bpmi.h"
 #include "rp_batch_host.hpp"
+#include "host_tail.hpp"
 using namespace bpmi;
 
 static void load_fe(fe &r, const uint8_t *b) { u32 w[8]; memcpy(w, b, 32); fe_from_words(r, w); }
@@ -181,5 +182,42 @@ void t_xyzz_dbl_n(const uint8_t *pt, int n, uint8_t *out) {
   xyzz q; xyzz_from_affine(q, p);
   for (int k = 0; k < n; k++) xyzz_dbl(q, q);
   affine r; xyzz_to_affine(r, q); store_aff(out, r);
+}
+// the host tail's own field arithmetic (host_tail.hpp, 4 x 64-bit limbs): op 0 a*b, 1 a^2, 2 a^-1, 3 a+b, 4 a-b; fully reduced in and out
+void t_host_f_op(int op, const uint8_t *a, const uint8_t *b, uint8_t *out) {
+  bpmi_host::f64 x, y, r;
+  memcpy(x.v, a, 32); memcpy(y.v, b, 32);
+  switch (op) {
+    case 0: bpmi_host::f_mul(r, x, y); break;
+    case 1: bpmi_host::f_sqr(r, x); break;
+    case 2: bpmi_host::f_inv(r, x); break;
+    case 3: bpmi_host::f_add(r, x, y); break;
+    default: bpmi_host::f_sub(r, x, y); break;
+  }
+  memcpy(out, r.v, 32);
+}
+// The MSM's host tail on window sums given as AFFINE points scaled by z (pts: W * nv points of 64 bytes; zs: as many 32-byte
+// field elements, 0 = the identity record): X = x z^2, Y = y z^3, ZZ = z^2, ZZZ = z^3 in the device's 9 x 29-bit limb records.
+void t_host_tail(const uint8_t *pts, const uint8_t *zs, u32 W, u32 c, u32 nv, const u32 *off, u32 top, const u32 *top_off, uint8_t *out) {
+  std::vector<u32> E(36 * (size_t)W * nv);
+  for (size_t i = 0; i < (size_t)W * nv; i++) {
+    fe z, zz, zzz, t;
+    load_fe(z, zs + 32 * i);
+    affine p; load_aff(p, pts + 64 * i);
+    xyzz r;
+    if (fe_is_zero(z) || affine_is_inf(p)) xyzz_set_inf(r);
+    else {
+      fe_sqr(zz, z); fe_mul(zzz, zz, z);
+      fe_mul(t, p.x, zz); fe_carry(r.X, t);
+      fe_mul(t, p.y, zzz); fe_carry(r.Y, t);
+      fe_carry(r.ZZ, zz); fe_carry(r.ZZZ, zzz);
+    }
+    xyzz_store(E.data() + 36 * i, r);
+  }
+  TailOffs to;
+  memset(&to, 0, sizeof(to));
+  to.nv = nv; to.top = top;
+  for (int k = 0; k < 4; k++) { to.off[k] = off[k]; to.top_off[k] = top_off[k]; }
+  bpmi_host::tail_combine(out, E.data(), W, c, to);
 }
 }

@@ -34,6 +34,9 @@ def shim():
     L.t_sc_op.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p]
     L.t_sq_raw.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_char_p]
     L.t_sq_from_sc.argtypes = [ctypes.c_char_p, ctypes.c_void_p]
+    L.t_host_f_op.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p]
+    L.t_host_tail.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p,
+                              ctypes.c_char_p]
     return L
 
 
@@ -436,3 +439,52 @@ def test_sha_block_on_cpu_extensions_equals_the_portable_one(shim):
     if not have:
         pytest.skip("this CPU has no SHA extensions: only the portable path and the dispatch were checked")
 
+
+
+def test_host_tail_field_arithmetic(shim):
+    """host_tail.hpp's 4 x 64-bit field routines (round 5: a squaring of its own, the inversion by an addition chain) against Python
+    integers: random values and the carry edges of the 2^256 - p folding."""
+    rnd = random.Random(99)
+    edge = [0, 1, 2, P - 1, P - 2, (1 << 255), (1 << 256) - (1 << 32) - 978, (1 << 128) - 1, (1 << 192) + 5, 0x1000003D1, P - 0x1000003D1, (P + 1) // 2]
+    vals = edge + [rnd.randrange(P) for _ in range(300)]
+
+    def op(code, a, b=0):
+        out = ctypes.create_string_buffer(32)
+        shim.t_host_f_op(code, a.to_bytes(32, "little"), b.to_bytes(32, "little"), out)
+        return int.from_bytes(out.raw, "little")
+
+    for i, a in enumerate(vals):
+        b = vals[(i * 7 + 3) % len(vals)]
+        assert op(0, a, b) == a * b % P
+        assert op(1, a) == a * a % P
+        assert op(3, a, b) == (a + b) % P and op(4, a, b) == (a - b) % P
+        if a and i < 80:
+            assert op(2, a) == pow(a, -1, P)
+    assert op(2, 0) == 0
+
+
+@pytest.mark.parametrize("c,nv,off,top,top_off", [(16, 4, (0, 4, 8, 12), 0, (0, 0, 0, 0)), (15, 4, (0, 4, 7, 11), 1, (0, 4, 8, 12)), (13, 4, (0, 3, 6, 9), 0, (0, 0, 0, 0)),
+                                                  (8, 1, (0, 0, 0, 0), 0, (0, 0, 0, 0)), (7, 1, (0, 0, 0, 0), 0, (0, 0, 0, 0))])
+def test_host_tail_combines_the_window_sums(shim, c, nv, off, top, top_off):
+    """tail_combine (the MSM's Horner chain over bit positions, on the host): sum_w 2^(c w) sum_v 2^(off_v) E[w][v] for window sums in
+    projective form with random scalings, identities among them, the unsigned last window's own offsets (c = 15), against the
+    oracle's affine arithmetic."""
+    W = (255 // c) if top else 255 // c + 1
+    rnd = random.Random(c * 100 + nv)
+    base = gens(7, seed(3))
+    pts, zs, want = [], [], INF
+    for w in range(W):
+        for v in range(nv):
+            k = rnd.randrange(1, 1 << 40)
+            kind = rnd.randrange(10)
+            pt = INF if kind == 0 else base[rnd.randrange(7)] * k
+            z = 0 if kind == 1 else rnd.randrange(1, P)
+            pts.append(pt)
+            zs.append(z)
+            if kind > 1:
+                o = (top_off if (top and w == W - 1) else off)[v]
+                want = want + pt * (1 << (c * w + o))
+    out = ctypes.create_string_buffer(64)
+    o4, t4 = (ctypes.c_uint32 * 4)(*off), (ctypes.c_uint32 * 4)(*top_off)
+    shim.t_host_tail(b"".join(point_to_le64(p) for p in pts), b"".join(z.to_bytes(32, "little") for z in zs), W, c, nv, o4, top, t4, out)
+    assert out.raw == point_to_le64(want)

@@ -651,3 +651,35 @@ def test_format_2_corrupted_proofs_same_verdict_as_their_expansion(eng):
     assert rejected >= 90           # (flips in taux, mu, t_hat, a, b pass the byte-level checks: those proofs fail in the MSM)
     assert dev_prepare(eng, 8, 1, [blobs[0], v1s[1], blobs[2]], w, None)[1] == 1
     assert dev_prepare(eng, 8, 1, [v1s[0], blobs[1], v1s[2]], w, None)[1] == 1
+
+
+def test_mixed_wire_formats_are_an_argument_error_not_a_verdict(eng):
+    """A batch is read in the format of its first proof: a well-formed proof of the OTHER format inside it is reported by
+    the device paths as an argument error that names it -- not as "Proof invalid", which is what a forged proof gets; the host
+    preparation takes the formats proof by proof and accepts the mix."""
+    from bulletproofs_amd.engine import EngineError
+    b = make_batch(6, n=8)
+    v1 = [proof_to_bytes(pr) for pr in b["proofs"]]
+    v2 = _v2(b["proofs"])
+    bv = BatchRangeVerifier(b["g"], b["h"], b["gs"], b["hs"], b["u"])
+    assert bv.partial_wire(b["Vs"], v1) == bytes(64) and bv.partial_wire(b["Vs"], v2) == bytes(64)
+    with pytest.raises(EngineError, match="mixed wire formats: proof 3 is format 1 in a format-2 batch"):
+        bv.partial_wire(b["Vs"], v2[:3] + [v1[3]] + v2[4:])
+    with pytest.raises(EngineError, match="mixed wire formats: proof 2 is format 2 in a format-1 batch"):
+        bv.partial_wire(b["Vs"], v1[:2] + [v2[2]] + v1[3:])
+    # a CORRUPTED proof of the batch's own format is still a verdict: a flipped scalar bit fails the MSM, a broken header the parser
+    bad = bytearray(v2[4])
+    bad[40] ^= 1
+    with pytest.raises(Exception, match="^Proof invalid$"):
+        bv.verify_wire(b["Vs"], v2[:4] + [bytes(bad)] + v2[5:])
+    bad = bytearray(v2[4])
+    bad[2] = ord("X")
+    with pytest.raises(Exception, match="^Proof invalid$"):
+        bv.partial_wire(b["Vs"], v2[:4] + [bytes(bad)] + v2[5:])
+    seed = bytes(range(32))
+    for mixed in (v2[:3] + [v1[3]] + v2[4:], v1[:2] + [v2[2]] + v1[3:]):
+        h = host_prepare(8, 1, mixed, None, seed)
+        want = host_prepare(8, 1, v1, None, seed)
+        assert h[0] == 0 and h[1] == -1 and h[2:5] == want[2:5]
+        d = dev_prepare(eng, 8, 1, mixed, None, seed)
+        assert d[0] == -3

@@ -181,6 +181,60 @@ def test_sixteen_way_generator_fold_three_ladders_one_result(gp, n, big_m):
     assert seen[0] == seen[1] == seen[2]
 
 
+@pytest.mark.parametrize("n,big_m", [(4096, 256), (1 << 13, 1 << 13)])
+def test_fixed_generators_keep_the_fold_tables_between_proofs(gp, n, big_m):
+    """Option ipa_fixed_generators (round 5): the tables of odd multiples the 16-way fold builds from the generators are kept between
+    proofs that name the SAME device arrays.  Three proofs over the same generators (different a, b, challenges) give what they give
+    with the option off; other arrays, another length, a host-pointer state or switching the option off rebuild the tables."""
+    eng = gp.engine()
+    pts, _ = gp.rand_points(2 * n + 1, 91 + n)
+    g, h, u = cbind.pack_points(pts[:n]), cbind.pack_points(pts[n:2 * n]), cbind.pack_points([pts[2 * n]])
+    d_g, d_h, d_h2 = eng.upload(g), eng.upload(h), eng.upload(g)
+    rnd = random.Random(n)
+
+    def run(dg, dh, nn, seed, host=False):
+        r = random.Random(seed)
+        a = cbind.pack_scalars([r.randrange(Q) for _ in range(nn)])
+        b = cbind.pack_scalars([r.randrange(Q) for _ in range(nn)])
+        if host:
+            st = eng.ipa_create(g[: 64 * nn], h[: 64 * nn], a, b, nn, u)
+        else:
+            d_a, d_b = eng.upload(a), eng.upload(b)
+            st = eng.ipa_create_dev(dg, dh, d_a, d_b, nn, u)
+        trace = []
+        for _ in range(nn.bit_length() - 1):
+            trace.append(st.round_LR())
+            x = r.randrange(1, Q)
+            st.fold(x, pow(x, -1, Q))
+        trace.append(st.finish())
+        st.close()
+        if not host:
+            d_a.free(); d_b.free()
+        return trace
+
+    try:
+        eng.set_option("ipa_big_m", big_m)
+        eng.set_option("ipa_small_m", 1)
+        want = [run(d_g, d_h, n, s) for s in (1, 2, 3)]
+        want_swapped = run(d_g, d_h2, n, 4)
+        want_half = run(d_g, d_h, n // 2, 5)
+        eng.set_option("ipa_fixed_generators", 1)
+        assert [run(d_g, d_h, n, s) for s in (1, 2, 3)] == want               # built once, used three times
+        assert run(d_g, d_h2, n, 4) == want_swapped                           # another array: rebuilt
+        assert run(d_g, d_h, n, 1) == want[0]                                 # ... and back
+        assert run(d_g, d_h, n // 2, 5) == want_half                          # another length
+        assert run(None, None, n, 2, host=True) == want[1]                    # host pointers: never kept
+        assert run(d_g, d_h, n, 3) == want[2]
+        eng.set_option("ipa_fixed_generators", 0)
+        assert run(d_g, d_h, n, 2) == want[1]
+    finally:
+        eng.set_option("ipa_fixed_generators", 0)
+        eng.set_option("ipa_big_m", 0)
+        eng.set_option("ipa_small_m", 0)
+        for d in (d_g, d_h, d_h2):
+            d.free()
+
+
 @pytest.mark.parametrize("n,small_m", [(1024, 64), (1 << 14, 1024), (1 << 16, 0)])
 def test_product_fold_shared_scalars_equals_per_lane_products(gp, n, small_m):
     """The two forms of the product fold -- shared GLV halves in non-adjacent form with two terms per thread (k_ec_fold_glv, the
