@@ -105,6 +105,7 @@ struct bpmi_ctx {
   // round 5 (the mid-size floor; every one on by default, 0 = the round-4 path for A/B runs and tests)
   int opt_top2 = 1;                     // c = 15: 17 windows, the last one unsigned with 2B buckets (0: 18 windows, the last one a carry window)
   int opt_inblock = 1;                  // n <= 2^17: the sort's level B handles partitions of any size itself, the two heavy-tile launches are skipped
+  int opt_prover_tw = 0;                // bpmi_rp_prover_create: window bits of the fixed-base tables (0 = default 12; 4 .. 13)
   int opt_validate = 1;                 // on-curve check of the points a caller hands in: 0 never, 1 the host-pointer entry points (default), 2 the synchronous _dev ones too
   u32 *vflag = nullptr, *vflag_dev = nullptr;      // the check's verdict (smallest bad index, ~0 = none): device word, and the page-locked word it is copied to
   int opt_segfuse = 1;                  // the segmented scan's last level runs in the block that finishes the level before it last (one launch instead of two)

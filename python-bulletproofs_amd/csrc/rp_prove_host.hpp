@@ -7,7 +7,8 @@
 struct bpmi_rp_prover {
   bpmi_ctx *ctx = nullptr;
   u32 n = 0, k = 0, nbases = 0;
-  u32 *table = nullptr;                        // [(3 + 2n)][32][128] affine points
+  u32 *table = nullptr;                        // [(3 + 2n)][wt][bt] affine points
+  u32 tw = 12, wt = 22, bt = 2048;             // table windows: tw bits, wt = ceil(256 / tw) per scalar, bt = 2^(tw-1) entries each
   unsigned short *bases = nullptr;             // device: the base lists of every job kind (offsets below, in entries)
   u32 off_S = 0, off_T = 0, off_P = 0, off_round = 0;
   rpp::sc x_ip;                                // mod_hash(b"&", q): the Protocol-1 challenge of an empty seed (the same for every proof)
@@ -94,7 +95,12 @@ int bpmi_rp_prover_create(bpmi_ctx *ctx, uint32_t nbits, const uint8_t g[64], co
     pv->ip_prefix = "&&" + rpp_host::decimal_of(le) + "&";
   }
   // points of the bases, the table's inputs and the table: entry (b, k, d) = d 2^(8k) base_b by the engine's batched multiplication
-  const size_t entries = (size_t)nb * PV_WT * PV_BT;
+  // table windows (ctx option "prover_table_bits", read HERE): wider windows are fewer additions per term and a larger table
+  // (measured at 2^14 64-bit proofs, profiles/r05_batch_prover_table_bits.txt: 8 bits 36.0 ms / 34 MB / 16 ms to build, 10: 31.0 / 112 / 29,
+  // 11: 29.3 / 206 / 44, 12: 28.1 / 378 / 72, 13: 26.6 / 687 / 126 -- 12 is the default: a prover lives for many batches)
+  pv->tw = ctx->opt_prover_tw ? (u32)ctx->opt_prover_tw : 12u;
+  pv->wt = (256u + pv->tw - 1u) / pv->tw; pv->bt = 1u << (pv->tw - 1u);
+  const size_t entries = (size_t)nb * pv->wt * pv->bt;
   std::vector<uint8_t> basepts(64 * (size_t)nb);
   memcpy(&basepts[0], g, 64); memcpy(&basepts[64], h, 64); memcpy(&basepts[128], u, 64);
   memcpy(&basepts[192], gs, 64 * (size_t)n); memcpy(&basepts[192 + 64 * (size_t)n], hs, 64 * (size_t)n);
@@ -108,7 +114,8 @@ int bpmi_rp_prover_create(bpmi_ctx *ctx, uint32_t nbits, const uint8_t g[64], co
   e = hipMemcpyAsync(d_base, basepts.data(), basepts.size(), hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);          // (basepts is pageable and local)
   if (e != hipSuccess) { free_tmp(); return bail(fail(ctx, BPMI_E_HIP, std::string("bpmi_rp_prover_create: ") + hipGetErrorString(e))); }
-  hipLaunchKernelGGL(rpp::k_pv_table_scalars, dim3((u32)((entries + 255) / 256)), dim3(256), 0, ctx->stream, d_base, nb, d_pts, d_sc);
+  rpp::Tab T0 = {nullptr, pv->tw, pv->wt, pv->bt};
+  hipLaunchKernelGGL(rpp::k_pv_table_scalars, dim3((u32)((entries + 255) / 256)), dim3(256), 0, ctx->stream, d_base, nb, T0, d_pts, d_sc);
   int rc = bpmi_ec_mul_batch_dev(ctx, d_pts, d_sc, entries, pv->table);
   // u_new = x_ip u
   if (rc == BPMI_OK) {
@@ -225,7 +232,7 @@ int bpmi_rp_prove_batch(bpmi_rp_prover *pv, uint64_t n_proofs, const uint8_t *va
   HIPCHK(ctx, hipMemcpyAsync(d, hp, in_bytes, hipMemcpyHostToDevice, st));
   rpp::Batch B;
   memset(&B, 0, sizeof(B));
-  B.P = P; B.n = n; B.k = k; B.table = pv->table;
+  B.P = P; B.n = n; B.k = k; B.table = rpp::Tab{pv->table, pv->tw, pv->wt, pv->bt};
   B.dig0 = (const unsigned char *)(d + o_dig0); B.dig0_stride = dig0_stride; B.dig0_len = (const u32 *)(d + o_dlen);
   B.values = (const u32 *)(d + o_val); B.gammas = (const u32 *)(d + o_gam);
   B.ip_prefix = pv->d_ip_prefix; B.ip_prefix_len = (u32)pv->ip_prefix.size(); B.x_ip = pv->x_ip;
@@ -243,8 +250,8 @@ int bpmi_rp_prove_batch(bpmi_rp_prover *pv, uint64_t n_proofs, const uint8_t *va
     rpp::MsmJobs J;
     J.njobs = njobs; J.ntypes = ntypes; J.T = T; J.bases = pv->bases + base_off; J.scalars = scalars; J.stride = stride; J.out = B.jout;
     const uint64_t threads = (uint64_t)njobs << gl;
-    if (gl == 4) hipLaunchKernelGGL(rpp::k_pv_msm<4>, blocks(threads, 256), dim3(256), 0, st, J, (const u32 *)pv->table);
-    else hipLaunchKernelGGL(rpp::k_pv_msm<1>, blocks(threads, 256), dim3(256), 0, st, J, (const u32 *)pv->table);
+    if (gl == 4) hipLaunchKernelGGL(rpp::k_pv_msm<4>, blocks(threads, 256), dim3(256), 0, st, J, B.table);
+    else hipLaunchKernelGGL(rpp::k_pv_msm<1>, blocks(threads, 256), dim3(256), 0, st, J, B.table);
   };
   auto affine = [&](u32 count, u32 per, u32 slot0, u32 step) {
     hipLaunchKernelGGL(rpp::k_pv_affine, blocks(count, 256), dim3(256), 0, st, (const u32 *)B.jout, count, per, B.pts, npt, slot0, step);

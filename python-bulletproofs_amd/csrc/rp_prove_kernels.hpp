@@ -9,8 +9,8 @@
 // per-proof launches made it 2.1 ms a proof (474 proofs/s, profiles/r04_rocprofv3_kernel_stats_C5_batch_verify_2e14.csv).  Here
 // every step is ONE launch over all proofs of the batch:
 //   * the generators are fixed for a prover, so every scalar multiplication is a FIXED-BASE one: table[b][k][d - 1] = d 2^(8k) base_b
-//     for the 3 + 2n generators, 32 windows of signed 8-bit digits (k_pv_table_scalars + the engine's batched multiplication; 34 MB
-//     for 64-bit proofs, built once per prover), and a term costs 32 mixed additions with no doubling.  The inner-product rounds never
+//     for the 3 + 2n generators, windows of signed tw-bit digits (k_pv_table_scalars + the engine's batched multiplication; tw = 8: 32
+//     windows, 34 MB for 64-bit proofs, built once per prover), and a term costs one mixed addition per window with no doubling.  The inner-product rounds never
 //     fold a generator: L and R are sums over the ORIGINAL generators with the fold coefficients in the scalars (cg, hf below) -- 65
 //     terms per side and round, whatever the round;
 //   * a multi-scalar multiplication is a JOB of k_pv_msm: 2^G lanes take its terms round-robin, each walks the 32 windows of its
@@ -33,10 +33,18 @@ using bpmi::affine;
 using bpmi::xyzz;
 typedef unsigned char u8;
 
-#define PV_TW 8u                       // table window bits
-#define PV_WT 32u                      // windows per scalar
-#define PV_BT 128u                     // table entries per (base, window): d = 1 .. 128
-#define PV_MAXK 6u                     // log2 of the largest bit width (64)
+// geometry of the fixed-base tables: windows of tw bits (signed digits), wt = ceil(256 / tw) windows per scalar, bt = 2^(tw-1) entries
+// per (base, window): entry (b, k, d) = d 2^(tw k) base_b at table + 64 ((b wt + k) bt + d - 1) bytes
+struct Tab { const u32 *p; u32 tw, wt, bt; };
+// the next tw-bit window of a magnitude that is shifted down as it is consumed (static register indexing), recoded to a signed digit:
+// d in [0, bt], sg = 1 for a negative digit, the carry goes into the next window (the top one cannot carry out: |s| < 2^255)
+__device__ __forceinline__ void next_digit(sc &s, const Tab &T, u32 &carry, u32 &d, u32 &sg) {
+  const u32 tt = (s.v[0] & ((1u << T.tw) - 1u)) + carry;
+#pragma unroll
+  for (int i = 0; i < 7; i++) s.v[i] = (u32)((((u64)s.v[i + 1] << 32) | s.v[i]) >> T.tw);
+  s.v[7] >>= T.tw;
+  if (tt > T.bt) { d = (1u << T.tw) - tt; sg = 1; carry = 1; } else { d = tt; sg = 0; carry = 0; }
+}
 
 // ---- mod q helpers (out of line: dozens of call sites) --------------------------------------------------------------------------
 __device__ __noinline__ sc mulq(const sc a, const sc b) { sc r; bpmi::sc_mul(r, a, b); return r; }
@@ -163,7 +171,7 @@ __device__ __noinline__ u32 put_number(u8 *dst, const sc v) {
 // Device arrays of one batch (P proofs of n bits, k = log2 n).  Scalars: 8 words little-endian.  Points: 16 words (x, y) little-endian.
 struct Batch {
   u32 P, n, k;
-  const u32 *table;          // [(3 + 2n) bases][32 windows][128] affine points: base 0 g, 1 h, 2 u, 3 + i gs_i, 3 + n + i hs_i
+  Tab table;                 // [(3 + 2n) bases][wt windows][bt] affine points: base 0 g, 1 h, 2 u, 3 + i gs_i, 3 + n + i hs_i
   const u8 *dig0;  u32 dig0_stride; const u32 *dig0_len;       // base64(seed) || '&' of every proof
   const u32 *values;         // P scalars: v (only its low n bits are used, as in rangeproof_prover.py:40)
   const u32 *gammas;         // P scalars
@@ -191,17 +199,19 @@ struct Batch {
 #define PV_PT_UNEW 4u
 #define PV_PT_PNEW 5u
 
-// ---- the table's scalars: entry (b, k, d) = d 2^(8k) ----------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_pv_table_scalars(const u32 *__restrict__ bases, u32 nbases, u32 *__restrict__ pts, u32 *__restrict__ scal) {
+// ---- the table's scalars: entry (b, k, d) = d 2^(tw k) ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_pv_table_scalars(const u32 *__restrict__ bases, u32 nbases, Tab T, u32 *__restrict__ pts, u32 *__restrict__ scal) {
   const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= nbases * PV_WT * PV_BT) return;
-  const u32 d = (t % PV_BT) + 1u, k = (t / PV_BT) % PV_WT, b = t / (PV_BT * PV_WT);
+  if (t >= nbases * T.wt * T.bt) return;
+  const u32 d = (t % T.bt) + 1u, k = (t / T.bt) % T.wt, b = t / (T.bt * T.wt);
   u32 w[16];
   ::load_words16(w, bases + 16ull * b);
   ::store_words16(pts + 16ull * t, w);
   u32 s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  const u32 bit = 8u * k;                       // d < 2^8 at bit 8k: inside word bit / 32 (8k is a multiple of 8, d <= 128 fits the byte; 128 << 24 stays in the word)
-  s[bit >> 5] = d << (bit & 31u);
+  const u32 bit = T.tw * k;                     // d <= 2^(tw-1) at bit tw k: at most two words (the top window's entries stay below 2^256: tw k + tw - 1 <= 255 + tw - 1, d's
+  const u64 v = (u64)d << (bit & 31u);          // top bit only set for d = bt, whose position tw k + tw - 1 <= 255 for every window a magnitude < 2^255 can reach)
+  s[bit >> 5] = (u32)v;
+  if ((bit >> 5) + 1u < 8u) s[(bit >> 5) + 1u] = (u32)(v >> 32);
   ::store_words8(scal + 8ull * t, s);
 }
 
@@ -234,8 +244,8 @@ struct MsmJobs {
   u32 stride;
   u32 *out;                // XYZZ of job j at out + 36 j
 };
-// signed 8-bit digits of |s| (s folded to s or q - s: the top digit cannot carry out): digit k in [-128, 128]
-template <int GL> __global__ void __launch_bounds__(256) k_pv_msm(MsmJobs J, const u32 *__restrict__ table) {
+// signed tw-bit digits of |s| (s folded to s or q - s: the top digit cannot carry out)
+template <int GL> __global__ void __launch_bounds__(256) k_pv_msm(MsmJobs J, Tab T) {
   const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
   const u32 job = t >> GL, l = t & ((1u << GL) - 1u);
   const bool live = job < J.njobs;
@@ -248,25 +258,20 @@ template <int GL> __global__ void __launch_bounds__(256) k_pv_msm(MsmJobs J, con
       if (bpmi::sc_is_zero(s)) continue;
       const bool neg = bpmi::sc_is_high(s);
       if (neg) bpmi::sc_neg(s, s);
-      const u32 *tb = table + 16ull * ((size_t)bl[term] * PV_WT * PV_BT);
+      const u32 *tb = T.p + 16ull * ((size_t)bl[term] * T.wt * T.bt);
       // window k + 1's entry is requested before window k's addition
       u32 carry = 0;
       u32 wv[16];
       u32 d_cur, sg_cur;
-      {
-        const u32 tt = (s.v[0] & 0xFFu) + carry;
-        if (tt > 128u) { d_cur = 256u - tt; sg_cur = 1; carry = 1; } else { d_cur = tt; sg_cur = 0; carry = 0; }
-        ::load_words16(wv, tb + 16ull * (d_cur ? d_cur - 1u : 0u));
-      }
-      for (u32 k = 0; k < PV_WT; k++) {
+      next_digit(s, T, carry, d_cur, sg_cur);
+      ::load_words16(wv, tb + 16ull * (d_cur ? d_cur - 1u : 0u));
+      for (u32 k = 0; k < T.wt; k++) {
         affine Pt;
         bpmi::affine_from_words(Pt, wv);
         const u32 d = d_cur, sg = sg_cur;
-        if (k + 1u < PV_WT) {
-          const u32 bit = 8u * (k + 1u);
-          const u32 tt = ((s.v[bit >> 5] >> (bit & 31u)) & 0xFFu) + carry;
-          if (tt > 128u) { d_cur = 256u - tt; sg_cur = 1; carry = 1; } else { d_cur = tt; sg_cur = 0; carry = 0; }
-          ::load_words16(wv, tb + 16ull * ((size_t)(k + 1u) * PV_BT + (d_cur ? d_cur - 1u : 0u)));
+        if (k + 1u < T.wt) {
+          next_digit(s, T, carry, d_cur, sg_cur);
+          ::load_words16(wv, tb + 16ull * ((size_t)(k + 1u) * T.bt + (d_cur ? d_cur - 1u : 0u)));
         }
         if (d) bpmi::xyzz_madd_signed(acc, Pt, (sg != 0u) != neg);
       }
@@ -281,8 +286,8 @@ template <int GL> __global__ void __launch_bounds__(256) k_pv_msm(MsmJobs J, con
   if (live && l == 0) ::xyzz_store_g(J.out + 36ull * job, acc);
 }
 
-// A = sum_i (bit_i ? gs_i : -hs_i) + alpha h (rangeproof_prover.py:40-49: aL the bits, aR = aL - 1): 16 lanes per proof, four bit
-// positions and two windows of alpha h each
+// A = sum_i (bit_i ? gs_i : -hs_i) + alpha h (rangeproof_prover.py:40-49: aL the bits, aR = aL - 1): 16 lanes per proof, n / 16 bit
+// positions and every sixteenth window of alpha h each
 __global__ void __launch_bounds__(256) k_pv_commit_A(Batch B, u32 *__restrict__ out) {
   const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
   const u32 p = t >> 4, l = t & 15u;
@@ -295,21 +300,19 @@ __global__ void __launch_bounds__(256) k_pv_commit_A(Batch B, u32 *__restrict__ 
       const u32 bit = (v.v[i >> 5] >> (i & 31u)) & 1u;
       const u32 base = bit ? 3u + i : 3u + B.n + i;
       affine Pt;
-      ::load_affine(Pt, B.table + 16ull * ((size_t)base * PV_WT * PV_BT));          // window 0, d = 1: the generator itself
+      ::load_affine(Pt, B.table.p + 16ull * ((size_t)base * B.table.wt * B.table.bt));          // window 0, d = 1: the generator itself
       bpmi::xyzz_madd_signed(acc, Pt, bit == 0u);
     }
     sc s = ld_sc(B.alpha + 8ull * p);
     const bool neg = bpmi::sc_is_high(s);
     if (neg) bpmi::sc_neg(s, s);
     u32 carry = 0;
-    for (u32 k = 0; k < PV_WT; k++) {
-      const u32 bit = 8u * k;
-      const u32 tt = ((s.v[bit >> 5] >> (bit & 31u)) & 0xFFu) + carry;
+    for (u32 k = 0; k < B.table.wt; k++) {
       u32 d, sg;
-      if (tt > 128u) { d = 256u - tt; sg = 1; carry = 1; } else { d = tt; sg = 0; carry = 0; }
+      next_digit(s, B.table, carry, d, sg);
       if ((k & 15u) == l && d) {
         affine Pt;
-        ::load_affine(Pt, B.table + 16ull * ((size_t)(1u * PV_WT + k) * PV_BT + d - 1u));
+        ::load_affine(Pt, B.table.p + 16ull * ((size_t)(1u * B.table.wt + k) * B.table.bt + d - 1u));
         bpmi::xyzz_madd_signed(acc, Pt, (sg != 0u) != neg);
       }
     }

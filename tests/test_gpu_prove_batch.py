@@ -90,6 +90,34 @@ def test_batch_prover_reproduces_the_reference_goldens(gp, k):
     check_range_proof(gp, pr[1], c["proof"])
 
 
+@pytest.mark.parametrize("bits", [4, 5, 7, 9, 10, 11, 12, 13])
+def test_batch_prover_table_windows(gp, bits):
+    """The fixed-base tables with windows of 4 .. 13 bits (ctx option prover_table_bits, read when the prover is created; 8 is the
+    default): windows that straddle words, a top window of 1 .. 8 bits, digits of magnitude 2^(bits-1) -- the same proofs."""
+    from bulletproofs_amd.ec import secp256k1
+    from bulletproofs_amd.rangeproofs import BatchRangeProver, NIRangeProver, proof_to_bytes
+    from bulletproofs_amd.utils import ModP
+    n, count = 16, 40
+    g, h, gs, hs, u = _setup(gp, n, b"tw")
+    rnd = random.Random(bits)
+    vs = [ModP(rnd.randrange(1 << n), Q) for _ in range(count)]
+    gammas = [ModP(rnd.randrange(Q), Q) for _ in range(count)]
+    gammas[0], gammas[1], gammas[2] = ModP(0, Q), ModP(Q - 1, Q), ModP((Q - 1) // 2, Q)
+    seeds = [b"tw%d" % i for i in range(count)]
+    eng = gp.engine()
+    try:
+        eng.set_option("prover_table_bits", bits)
+        bp = BatchRangeProver(n, g, h, gs, hs, u)
+    finally:
+        eng.set_option("prover_table_bits", 0)
+    try:
+        blobs = bp.prove_wire(vs, gammas, seeds)
+    finally:
+        bp.close()
+    for i in range(0, count, 3):
+        assert blobs[i] == proof_to_bytes(NIRangeProver(vs[i], n, g, h, gs, hs, gammas[i], u, secp256k1, seeds[i]).prove(), version=2), (bits, i)
+
+
 def test_batch_prover_output_verifies(gp):
     """The wire bytes go straight into the verifiers: one by one (RangeVerifier) and as one batch (BatchRangeVerifier); a wrong
     commitment is rejected."""
@@ -139,3 +167,20 @@ def test_batch_prover_argument_errors(gp):
             bp.prove_wire([ModP(1, Q)], [], [b""])
     finally:
         bp.close()
+
+
+def test_c_program_proves_and_verifies_a_batch_through_the_abi_only(gp, tmp_path):
+    """examples/prove_batch_c_abi.c: a C99 program over include/bpmi.h and libbpmi.so alone builds a prover, proves a batch in one
+    call and verifies the wire bytes as one batch (bpmi_rp_batch_verify_dev); with one commitment changed the batch is rejected."""
+    import os
+    import subprocess
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(repo, "python-bulletproofs_amd")
+    exe = str(tmp_path / "prove_batch_c_abi")
+    subprocess.check_call(["gcc", "-O2", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(repo, "include"),
+                           os.path.join(repo, "examples", "prove_batch_c_abi.c"), "-o", exe, os.path.join(libdir, "libbpmi.so"),
+                           "-Wl,-rpath," + libdir, "-Wl,--allow-shlib-undefined"])
+    for args, code, word in ((["300", "64"], 0, "batch verification: VALID"), (["70", "8"], 0, "batch verification: VALID"),
+                             (["300", "64", "1"], 1, "batch verification: INVALID")):
+        r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=300)
+        assert r.returncode == code and word in r.stdout, r.stdout + r.stderr

@@ -2,7 +2,7 @@
 """Randomised differential test of the HIP MSM against the C oracle: random sizes, scalar
 shapes (uniform, tiny, near q/2 and q, repeated, zero), point shapes (duplicates, negated
 pairs, identities) and engine options (window bits, chunk length, tail placement, window-group
-split, small-MSM threshold, GLV split on / off, fused / unfused wave scan); a few percent of the cases are large enough for the LDS sort path.
+split, small-MSM threshold, GLV split on / off, fused / unfused wave scan, the round-5 options); a few percent of the cases are large enough for the LDS sort path.
   python tools/fuzz_msm.py [seconds]"""
 import os
 import random
@@ -48,6 +48,8 @@ while time.time() - t0 < budget:
         n = rnd.randrange(30000, 90000)            # default options: c = 16, LDS sort, 4096-scalar level-A tiles
     elif r < 0.05:
         n = rnd.randrange(1 << 19, (1 << 19) + 70000)   # 16384-scalar level-A tiles, L = 64
+    elif r < 0.06:
+        n = rnd.randrange((1 << 17) - 3000, (1 << 17) + 3000)      # either side of the in-block sort's bound
     pts = [rnd.choice(pool) for _ in range(n)]
     shape = rnd.randrange(6)
     if shape == 1:
@@ -60,15 +62,17 @@ while time.time() - t0 < budget:
     es = [scalar(kind if kind < 6 else rnd.randrange(6)) for _ in range(n)]
     if rnd.random() < 0.2:
         es = [es[0]] * n
-    opts = {"window_bits": rnd.choice((0, 0, 0, 2, 4, 5, 7, 8, 9, 10, 11, 13, 16)),
+    opts = {"window_bits": rnd.choice((0, 0, 0, 2, 4, 5, 7, 8, 9, 10, 11, 12, 13, 14, 15, 15, 16)),
             "chunk": rnd.choice((0, 0, 1, 2, 5, 16, 33, 64, 200)), "tail": rnd.choice((0, 1, 2)),
             "split": rnd.choice((0, 0, 0, 1)), "small_n": rnd.choice((0, 0, -1, 100, 65536)),
             "glv": rnd.choice((0, 0, 1, 1, -1)),          # 1: the GLV split at every size the bucket pipeline takes, -1: never
             "fused_scan": rnd.choice((1, 1, 1, 0)),       # 0: two partial records per thread and k_segscan's first level (round 3)
             "direct_result": rnd.choice((1, 1, 0)), "graphs": rnd.choice((0, 0, 1)),
-            "mid_single_min": rnd.choice((0, 0, 1, 300, -1))}   # k_msm_mid for single MSMs from that many pairs (0: default 2560, -1: never)
+            "mid_single_min": rnd.choice((0, 0, 1, 300, -1)),   # k_msm_mid for single MSMs from that many pairs (0: default 2560, -1: never)
+            # round 5: the unsigned last window of c = 15, level B of the sort on partitions of any size, the segmented scan's fused last level
+            "top_window_unsigned": rnd.choice((1, 1, 0)), "sort_inblock": rnd.choice((1, 1, 0)), "segscan_fused": rnd.choice((1, 1, 0))}
     if n > 20000:
-        opts["window_bits"] = rnd.choice((0, 0, 13, 16))
+        opts["window_bits"] = rnd.choice((0, 0, 13, 15, 15, 16))
         opts["chunk"] = rnd.choice((0, 0, 16, 64))
     for k, v in opts.items():
         eng.set_option(k, v)
@@ -81,6 +85,8 @@ while time.time() - t0 < budget:
         print("MISMATCH n=%d shape=%d kind=%d opts=%s seed=%d case=%d" % (n, shape, kind, opts, seed, cases), flush=True)
 for k in ("window_bits", "chunk", "tail", "split", "small_n", "glv", "mid_single_min"):
     eng.set_option(k, 0)
+for k in ("top_window_unsigned", "sort_inblock", "segscan_fused"):
+    eng.set_option(k, 1)
 eng.set_option("fused_scan", 1)
 eng.set_option("direct_result", 1)
 eng.set_option("graphs", 0)
