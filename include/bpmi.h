@@ -121,7 +121,9 @@ int bpmi_sync(bpmi_ctx *ctx);
  *                  Cost: one kernel behind the upload, no extra wait (profiles/r05_validate_points_cost.txt)
  *   "top_window_unsigned" window_bits = 15: 1 (default) 17 windows, the last one unsigned with twice the buckets; 0 the 18-window recoding
  *   "sort_inblock" 1 (default): up to 2^17 pairs the sort's second level handles partitions of any size in one block (two launches fewer)
- *   "segscan_fused" 1 (default): the segmented scan's last level runs in the block that finishes the level before it last
+ *   "segscan_fused" / "hist_scan_fused" 1: the segmented scan's last level / the scan of the sort's partition counts run in the block that
+ *                  finishes the level / the histogram kernel last (one launch fewer each).  Experiments that lost to the cost of the
+ *                  device-scope fence every block needs (profiles/r05_last_block_fusions_ab.txt); default 0
  *   "fold_wnaf"    the ladder of that 16-way fold: 2 (default) width-4 non-adjacent forms of the coefficients' GLV halves over affine
  *                  tables of 3P, 5P, 7P and of beta x (k_ec_multifold_w4g; 792 B of workspace per generator, kept by the ctx after the first fold),
  *                  1 of the whole coefficients (k_ec_multifold_w4), 0 the plain NAF ladder without tables (k_ec_multifold) */

@@ -147,6 +147,7 @@ int bpmi_set_option(bpmi_ctx *ctx, const char *name, int64_t value) {
   if (!strcmp(name, "prover_table_bits")) { if (value != 0 && (value < 4 || value > 13)) return fail(ctx, BPMI_E_ARG, "prover_table_bits must be 0 or 4..13"); ctx->opt_prover_tw = (int)value; return BPMI_OK; }
   if (!strcmp(name, "ipa_fixed_generators")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "ipa_fixed_generators must be 0 or 1"); ctx->opt_ipa_fixed = (int)value; ctx->fold_key_g = ctx->fold_key_h = nullptr; return BPMI_OK; }
   if (!strcmp(name, "validate_points")) { if (value < 0 || value > 2) return fail(ctx, BPMI_E_ARG, "validate_points must be 0, 1 or 2"); ctx->opt_validate = (int)value; return BPMI_OK; }
+  if (!strcmp(name, "hist_scan_fused")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "hist_scan_fused must be 0 or 1"); ctx->opt_histscan = (int)value; msm_graphs_clear(ctx); return BPMI_OK; }
   if (!strcmp(name, "sort_inblock")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "sort_inblock must be 0 or 1"); ctx->opt_inblock = (int)value; msm_graphs_clear(ctx); return BPMI_OK; }
   if (!strcmp(name, "segscan_fused")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "segscan_fused must be 0 or 1"); ctx->opt_segfuse = (int)value; msm_graphs_clear(ctx); return BPMI_OK; }
   if (!strcmp(name, "priority")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "priority must be 0 or 1"); ctx->opt_prio = (int)value; return BPMI_OK; }
@@ -1452,11 +1453,11 @@ int bpmi_rp_batch_prepare(uint32_t n_gens, uint32_t values_per_proof, uint64_t n
     for (uint64_t g = 0; g < n_proofs; g++) {
       const uint8_t *b = blobs + blob_off[g];
       const size_t len = (size_t)(blob_off[g + 1] - blob_off[g]);
-      if (len < 5 || b[4] != '2') expanded.insert(expanded.end(), b, b + len);           // a format-1 proof among format-2 ones: taken as it is
-      else {
-        if (!rpw::expand_v2(b, len, one)) { *first_bad = (int64_t)g; return BPMI_OK; }
-        expanded.insert(expanded.end(), one.begin(), one.end());
-      }
+      // a format-1 proof among format-2 ones is taken as it is; so is a blob that claims format 2 and does not expand -- it is not a
+      // format-1 proof either, so the checks below reject it AT ITS INDEX, behind any earlier bad proof (returning here at once made
+      // the host name a later proof than the device: tools/fuzz_batch_prepare.py, round 5)
+      if (len >= 5 && b[4] == '2' && rpw::expand_v2(b, len, one)) expanded.insert(expanded.end(), one.begin(), one.end());
+      else expanded.insert(expanded.end(), b, b + len);
       expanded_off[g + 1] = expanded.size();
     }
     blobs = expanded.data(); blobs_len = expanded.size(); blob_off = expanded_off.data();

@@ -108,7 +108,10 @@ struct bpmi_ctx {
   int opt_prover_tw = 0;                // bpmi_rp_prover_create: window bits of the fixed-base tables (0 = default 12; 4 .. 13)
   int opt_validate = 1;                 // on-curve check of the points a caller hands in: 0 never, 1 the host-pointer entry points (default), 2 the synchronous _dev ones too
   u32 *vflag = nullptr, *vflag_dev = nullptr;      // the check's verdict (smallest bad index, ~0 = none): device word, and the page-locked word it is copied to
-  int opt_segfuse = 1;                  // the segmented scan's last level runs in the block that finishes the level before it last (one launch instead of two)
+  int opt_histscan = 0;                 // 1: the scan of the sort's partition counts runs in the block of k_coarse_hist that flushes last.  LOST (profiles/r05_last_block_fusions_ab.txt):
+                                        // the device-scope fence every block needs writes its XCD's L2 back behind 33 MB of digit codes -- +60 us at 2^20, +16 us at 2^16.  Off; kept with its tests
+  int opt_segfuse = 0;                  // 1: the segmented scan's last level runs in the block that finishes the level before it last.  No gain one MSM at a time, and the fence costs
+                                        // two MSMs in flight 3 % (the other lane's dirty bucket lines are written back with it).  Off; kept with its tests
   double prof_ms[BPMI_NSTAGES] = {0};
   uint64_t prof_calls[BPMI_NSTAGES] = {0};
 };

@@ -337,10 +337,14 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, int slot, const Segs &segs_in, u
       // n = 2^20, 256 blocks of 1024: 28.5; options "hist_threads" / "hist_blocks", tools/hist_sweep.py)
       const u32 ht = ctx->opt_hist_threads > 0 ? (u32)ctx->opt_hist_threads : 1024u;
       const u32 hb = (u32)std::min<uint64_t>(((uint64_t)g.n + ht - 1) / ht, ctx->opt_hist_blocks > 0 ? (u32)ctx->opt_hist_blocks : 256u);
-      hipLaunchKernelGGL(k_coarse_hist, dim3(hb), dim3(ht), 0, st, segs, g, w.P, w.coarse_hist, w.dig16, w.negs);
+      // (round 5: the last block to flush runs the scan of the partition counts itself; ticket word behind the any_heavy flag and the
+      // segmented scan's ticket, zeroed by the memset above)
+      CoarseScanOut so = {nullptr, nullptr, nullptr, nullptr};
+      if (ctx->opt_histscan) { so.coarse_off = w.coarse_off; so.coarse_cursor = w.coarse_cursor; so.offG = w.off + g.G; so.ticket = w.coarse_hist + PART_MAX + 2; }
+      hipLaunchKernelGGL(k_coarse_hist, dim3(hb), dim3(ht), 0, st, segs, g, w.P, w.coarse_hist, w.dig16, w.negs, so);
     }
     debug_sync(ctx, "ST_DIGITS", st);
-    {
+    if (!ctx->opt_histscan) {
       StageTimer t(ctx, ST_SCAN, st);
       // exclusive scan of <= 2048 partition counts; total -> coarse_off[P] and off[G]
       hipLaunchKernelGGL(k_coarse_scan, dim3(1), dim3(1024), 0, st, w.coarse_hist, w.P, w.coarse_off, w.coarse_cursor, w.off + g.G);

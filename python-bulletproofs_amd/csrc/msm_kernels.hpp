@@ -152,10 +152,15 @@ __global__ void __launch_bounds__(256) k_digits_hist(Segs segs, MsmGeom g, u32 *
 // per scalar says whether it was negated.  Level A then reads one window of one tile as a
 // contiguous 2-byte stream instead of recoding the scalars.
 #define DIG_NONE 0xFFFFu
-__global__ void __launch_bounds__(1024) k_coarse_hist(Segs segs, MsmGeom g, u32 P, u32 *__restrict__ coarse_hist, unsigned short *__restrict__ dig16,
-                                                     unsigned char *__restrict__ negs) {
+// Round 5 (`scan` != nullptr): the block that flushes its histogram LAST also runs the exclusive scan of the <= 2048 partition counts
+// (k_coarse_scan's work: coarse_off[0..P], coarse_cursor = copy, *offG = total) -- one launch fewer on the path of every MSM of the
+// bucket pipeline.  The ticket word is zeroed with the histogram by the MSM's memset.
+struct CoarseScanOut { u32 *coarse_off, *coarse_cursor, *offG, *ticket; };
+__global__ void __launch_bounds__(1024) k_coarse_hist(Segs segs, MsmGeom g, u32 P, u32 *coarse_hist, unsigned short *__restrict__ dig16,
+                                                     unsigned char *__restrict__ negs, CoarseScanOut scan) {
   raise_priority(g.prio);
   __shared__ u32 lh[PART_MAX];
+  __shared__ u32 s_last;
   for (u32 p = threadIdx.x; p < P; p += blockDim.x) lh[p] = 0;
   __syncthreads();
   const u32 Bc = g.B >> 8;
@@ -169,6 +174,37 @@ __global__ void __launch_bounds__(1024) k_coarse_hist(Segs segs, MsmGeom g, u32 
   }
   __syncthreads();
   for (u32 p = threadIdx.x; p < P; p += blockDim.x) { const u32 v = lh[p]; if (v) atomicAdd(&coarse_hist[p], v); }
+  if (!scan.ticket) return;
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = (atomicAdd(scan.ticket, 1u) == gridDim.x - 1u) ? 1u : 0u;
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  // every block's counts are in: exclusive scan, `per` consecutive partitions per thread (8 at 256 threads), the threads' sums in lh
+  const u32 tid = threadIdx.x, nt = blockDim.x, per = (P + nt - 1u) / nt;
+  u32 loc[8], sum = 0;
+#pragma unroll
+  for (u32 k = 0; k < 8u; k++) {
+    const u32 idx = tid * per + k;
+    loc[k] = (k < per && idx < P) ? __atomic_load_n(&coarse_hist[idx], __ATOMIC_RELAXED) : 0u;
+    sum += loc[k];
+  }
+  lh[tid] = sum;
+  __syncthreads();
+  for (u32 d = 1; d < nt; d <<= 1) {
+    const u32 v = tid >= d ? lh[tid - d] : 0u;
+    __syncthreads();
+    lh[tid] += v;
+    __syncthreads();
+  }
+  u32 excl = lh[tid] - sum;
+#pragma unroll
+  for (u32 k = 0; k < 8u; k++) {
+    const u32 idx = tid * per + k;
+    if (k < per && idx < P) { scan.coarse_off[idx] = excl; scan.coarse_cursor[idx] = excl; excl += loc[k]; }
+  }
+  if (tid == nt - 1u) { scan.coarse_off[P] = lh[tid]; *scan.offG = lh[tid]; }
 }
 // exclusive scan of the <= PART_MAX partition counts in one block:
 // coarse_off[0..P] (coarse_off[P] = total), coarse_cursor = copy, off[G] = total

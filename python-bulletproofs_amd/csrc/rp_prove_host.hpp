@@ -130,7 +130,7 @@ int bpmi_rp_prover_create(bpmi_ctx *ctx, uint32_t nbits, const uint8_t g[64], co
   }
   free_tmp();
   if (rc) return bail(rc);
-  // base lists: S / P_new: gs_0.., hs_0.., then h (S) or u (P_new); T: g, h; round r: L then R (rp_prove_kernels.hpp k_pv_round_scalars)
+  // base lists: S / P_new: gs_0.., hs_0.., then h (S) or u (P_new); T: g, h; round r: L then R (rp_prove_kernels.hpp k_pv_round_wide)
   std::vector<unsigned short> bl;
   pv->off_S = 0;
   for (u32 i = 0; i < n; i++) bl.push_back((unsigned short)(3 + i));

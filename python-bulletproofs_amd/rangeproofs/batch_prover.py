@@ -40,23 +40,37 @@ class BatchRangeProver:
 
     def prove_wire_packed(self, vs, gammas, seeds):
         """(packed bytes, offsets): proof i = packed[offsets[i]: offsets[i + 1]], wire format 2 -- what
-        BatchRangeVerifier.add_wire_native / bpmi_rp_batch_verify_dev take as they are."""
-        m = len(vs)
-        if len(gammas) != m or len(seeds) != m:
+        BatchRangeVerifier.add_wire_native / bpmi_rp_batch_verify_dev take as they are.
+        vs, gammas: lists of ModP / int, or ALREADY PACKED bytes (32 bytes little-endian per value, reduced mod q): a service that
+        receives its inputs as bytes skips 2 x len Python conversions.  seeds: a list of bytes, or (joined bytes, offsets)."""
+        if isinstance(vs, (bytes, bytearray, memoryview)):
+            vb, m = bytes(vs), len(vs) // 32
+        else:
+            m = len(vs)
+            vb = b"".join([_le32(v) for v in vs])
+        gb = bytes(gammas) if isinstance(gammas, (bytes, bytearray, memoryview)) else b"".join([_le32(x) for x in gammas])
+        if isinstance(seeds, tuple):
+            sb, offs = seeds
+            if len(offs) != m + 1:
+                raise ValueError("values, blinding factors and seeds must have the same length")
+            off = offs if isinstance(offs, ctypes.Array) else (ctypes.c_uint64 * (m + 1))(*offs)
+        else:
+            if len(seeds) != m:
+                raise ValueError("values, blinding factors and seeds must have the same length")
+            off = (ctypes.c_uint64 * (m + 1))()
+            pos = 0
+            for i, sd in enumerate(seeds):
+                off[i] = pos
+                pos += len(sd)
+            off[m] = pos
+            sb = b"".join(seeds)
+        if len(vb) != 32 * m or len(gb) != 32 * m:
             raise ValueError("values, blinding factors and seeds must have the same length")
         eng = self._engine
-        off = (ctypes.c_uint64 * (m + 1))()
-        pos = 0
-        for i, s in enumerate(seeds):
-            off[i] = pos
-            pos += len(s)
-        off[m] = pos
-        longest = max((len(s) for s in seeds), default=0)
-        cap = m * eng.lib.bpmi_rp_prove_batch_proof_bytes(self._handle, longest) + 16
+        cap = m * eng.lib.bpmi_rp_prove_batch_proof_bytes(self._handle, 0) + (off[m] - off[0]) + 16      # a proof is a fixed part + its seed
         out = ctypes.create_string_buffer(cap)
         out_off = (ctypes.c_uint64 * (m + 1))()
-        eng._ck(eng.lib.bpmi_rp_prove_batch(self._handle, m, b"".join(_le32(v) for v in vs), b"".join(_le32(x) for x in gammas), b"".join(seeds),
-                                            off, out, cap, out_off))
+        eng._ck(eng.lib.bpmi_rp_prove_batch(self._handle, m, vb, gb, sb, off, out, cap, out_off))
         return out.raw[:out_off[m]], list(out_off)
 
     def prove_wire(self, vs, gammas, seeds):

@@ -1,7 +1,8 @@
 """GPU parity for the round-5 changes to the bucket pipeline at mid sizes (Pippenger.multiexp,
 /root/reference/src/pippenger/pippenger.py:22-61): the unsigned last window of c = 15 (17 windows, no carry window), level B of
-the sort handling partitions of any size itself up to 2^17 pairs, and the segmented scan's last level fused into the level
-before it.  Every case is compared with the C oracle, and with the round-4 path of the same option switched off."""
+the sort handling partitions of any size itself up to 2^17 pairs, and the two "last block done" fusions (the segmented scan's last
+level, the scan of the sort's partition counts: measured, lost to the cost of their device-scope fences, off by default).  Every
+case is compared with the C oracle, and with the other setting of the same option."""
 import random
 
 import pytest
@@ -11,7 +12,7 @@ from oracle import cbind
 
 pytestmark = pytest.mark.gpu
 
-R5_OPTIONS = ("top_window_unsigned", "sort_inblock", "segscan_fused")
+R5_DEFAULTS = {"top_window_unsigned": 1, "sort_inblock": 1, "segscan_fused": 0, "hist_scan_fused": 0}
 
 
 @pytest.fixture(scope="module")
@@ -51,13 +52,37 @@ def _scalars(shape, n, rnd):
 
 
 def _reset(eng):
-    for o in R5_OPTIONS:
-        eng.set_option(o, 1)
+    for o, v in R5_DEFAULTS.items():
+        eng.set_option(o, v)
     eng.set_option("window_bits", 0)
     eng.set_option("chunk", 0)
     eng.set_option("tail", 0)
     eng.set_option("fused_scan", 1)
     eng.set_option("reduce_epl", 0)
+    eng.set_option("hist_threads", 0)
+    eng.set_option("hist_blocks", 0)
+
+
+@pytest.mark.parametrize("n,c", [(10240, 0), (11000, 12), (40000, 16), (40000, 15), (70001, 13), (300000, 16), (1 << 20, 0)])
+def test_msm_partition_count_scan_in_the_histogram_kernels_last_block(gp, n, c):
+    """k_coarse_hist's last block scans the partition counts itself (hist_scan_fused; 1 .. 256 blocks of 256 / 512 / 1024 threads: 8, 4 or 2
+    partitions per thread in the scan) against the separate k_coarse_scan launch and the oracle."""
+    eng = gp.engine()
+    pts, _ = gp.rand_points(1000, 43)
+    pts = (pts * (n // 1000 + 1))[:n]
+    es = _scalars("uniform" if n % 2 else "bits_and_blinding", n, random.Random(n + c))
+    pb, sb = cbind.pack_points(pts), cbind.pack_scalars(es)
+    want = cbind.msm_bytes(pb, sb, n)
+    try:
+        eng.set_option("window_bits", c)
+        for threads, blocks in ((0, 0), (256, 0), (512, 7), (1024, 1)):
+            eng.set_option("hist_threads", threads)
+            eng.set_option("hist_blocks", blocks)
+            for fused in (1, 0, 1):
+                eng.set_option("hist_scan_fused", fused)
+                assert eng.msm_bytes(pb, sb, n) == want, (threads, blocks, fused)
+    finally:
+        _reset(eng)
 
 
 @pytest.mark.parametrize("c", [10, 12, 13, 14, 15, 16])

@@ -64,6 +64,16 @@ def test_batch_prover_equals_the_single_proof_prover(gp, n, count):
     finally:
         bp.close()
     assert again == blobs[: len(again)]
+    # the same inputs as packed bytes (what a service receives) give the same proofs
+    if n == 32:
+        from itertools import accumulate
+        bp2 = BatchRangeProver(n, g, h, gs, hs, u)
+        try:
+            packed, off = bp2.prove_wire_packed(b"".join(v.x.to_bytes(32, "little") for v in vs), b"".join(x.x.to_bytes(32, "little") for x in gammas),
+                                                (b"".join(seeds), [0, *accumulate(map(len, seeds))]))
+        finally:
+            bp2.close()
+        assert [packed[off[i]: off[i + 1]] for i in range(count)] == blobs
     step = 1 if count <= 1024 else 4
     for i in range(0, count, step):
         want = proof_to_bytes(NIRangeProver(vs[i], n, g, h, gs, hs, gammas[i], u, secp256k1, seeds[i]).prove(), version=2)

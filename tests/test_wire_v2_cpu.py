@@ -83,3 +83,43 @@ def test_a_proof_with_foreign_transcripts_has_no_format_2_form():
     pr.transcript = pr.transcript + b"extra&"
     with pytest.raises(ValueError, match="not canonical"):
         proof_to_bytes(pr, version=2)
+
+
+def _host_prepare(n, blobs, seed=bytes(range(32))):
+    lib = _native.load()
+    count = len(blobs)
+    k = n.bit_length() - 1
+    npts = count * (6 + 2 * k)
+    joined = b"".join(blobs) + b"\x00"
+    offs = [0]
+    for x in blobs:
+        offs.append(offs[-1] + len(x))
+    o = (ctypes.c_uint64 * (count + 1))(*offs)
+    v_sc, p_sc = ctypes.create_string_buffer(32 * count), ctypes.create_string_buffer(32 * npts)
+    shared, comp = ctypes.create_string_buffer(32 * (5 + 2 * n)), ctypes.create_string_buffer(33 * npts)
+    bad = ctypes.c_int64(-1)
+    rc = lib.bpmi_rp_batch_prepare(n, 1, count, joined, len(joined), ctypes.cast(o, ctypes.c_void_p), None, seed, 2, v_sc, p_sc, shared, comp,
+                                   ctypes.cast(ctypes.pointer(bad), ctypes.c_void_p))
+    return rc, bad.value, v_sc.raw, p_sc.raw, shared.raw
+
+
+def test_host_preparation_takes_the_formats_proof_by_proof_and_names_the_first_bad_proof():
+    """bpmi_rp_batch_prepare (round 5): a batch may mix the two wire formats; a blob that CLAIMS format 2 and does not expand is
+    rejected at its own index, behind any earlier bad proof (returning at once from the expansion made the host name a later proof
+    than the device: tools/fuzz_batch_prepare.py); an empty blob is a bad proof, not a crash (the sanitizer harness's find)."""
+    b = make_batch(6, n=8)
+    v1 = [proof_to_bytes(pr) for pr in b["proofs"]]
+    v2 = [proof_to_bytes(pr, version=2) for pr in b["proofs"]]
+    want = _host_prepare(8, v1)
+    assert want[:2] == (0, -1)
+    for mixed in (v2, v2[:3] + [v1[3]] + v2[4:], v1[:2] + [v2[2]] + v1[3:], [v1[0]] + v2[1:]):
+        assert _host_prepare(8, mixed) == want
+    garbage2 = b"BPRP2" + bytes(200)                       # claims format 2, is nothing
+    broken1 = bytearray(v1[1])
+    broken1[len(broken1) - 9] ^= 4                          # a flipped transcript bit
+    assert _host_prepare(8, v1[:1] + [bytes(broken1)] + v1[2:4] + [garbage2] + v1[5:])[:2] == (0, 1)
+    assert _host_prepare(8, v1[:4] + [garbage2] + v1[5:])[:2] == (0, 4)
+    assert _host_prepare(8, v2[:2] + [b""] + v2[3:])[:2] == (0, 2)
+    assert _host_prepare(8, [b""] + v1[1:])[:2] == (0, 0)
+    rc, first, _ = native_expand([v2[0], b"", v2[1]])
+    assert (rc, first) == (0, 1)
