@@ -121,6 +121,14 @@ int bpmi_sync(bpmi_ctx *ctx);
  *                  Cost: one kernel behind the upload, no extra wait (profiles/r05_validate_points_cost.txt)
  *   "top_window_unsigned" window_bits = 15: 1 (default) 17 windows, the last one unsigned with twice the buckets; 0 the 18-window recoding
  *   "sort_inblock" 1 (default): up to 2^17 pairs the sort's second level handles partitions of any size in one block (two launches fewer)
+ *   "reduce_fit"   1 (default): stage 1 of the bucket reduction gives every sum as many lanes (any number up to 64, not only powers of two)
+ *                  as keep its waves within the chip's 1 024 SIMDs at one wave each; 0: round 4's rule (total buckets / 2^15 elements
+ *                  per lane, power-of-two groups).  "reduce_epl" > 0 forces the elements per lane
+ *   "final_spread" the finish of the bucket reduction (12 dependent point additions on quads of lanes): 0 one 16-wave block per (window,
+ *                  array) (k_digit_final_quad: the 16 waves share one CU, 49 us); 3 (default) the 16 second-level sums of every array as
+ *                  waves of their own, in blocks of four, and a second launch of one wave per array for the last 8 additions (18 + 21 us);
+ *                  2 the same with one-wave blocks; 1 one launch, the wave that draws an array's last ticket runs the finish (60 us: the
+ *                  tickets' device-scope fences cost more than the launch they save; profiles/r05_bucket_reduction_finish_ab.txt)
  *   "segscan_fused" / "hist_scan_fused" 1: the segmented scan's last level / the scan of the sort's partition counts run in the block that
  *                  finishes the level / the histogram kernel last (one launch fewer each).  Experiments that lost to the cost of the
  *                  device-scope fence every block needs (profiles/r05_last_block_fusions_ab.txt); default 0

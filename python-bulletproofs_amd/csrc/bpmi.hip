@@ -148,6 +148,8 @@ int bpmi_set_option(bpmi_ctx *ctx, const char *name, int64_t value) {
   if (!strcmp(name, "ipa_fixed_generators")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "ipa_fixed_generators must be 0 or 1"); ctx->opt_ipa_fixed = (int)value; ctx->fold_key_g = ctx->fold_key_h = nullptr; return BPMI_OK; }
   if (!strcmp(name, "validate_points")) { if (value < 0 || value > 2) return fail(ctx, BPMI_E_ARG, "validate_points must be 0, 1 or 2"); ctx->opt_validate = (int)value; return BPMI_OK; }
   if (!strcmp(name, "hist_scan_fused")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "hist_scan_fused must be 0 or 1"); ctx->opt_histscan = (int)value; msm_graphs_clear(ctx); return BPMI_OK; }
+  if (!strcmp(name, "reduce_fit")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "reduce_fit must be 0 or 1"); ctx->opt_reduce_fit = (int)value; msm_graphs_clear(ctx); return BPMI_OK; }
+  if (!strcmp(name, "final_spread")) { if (value < 0 || value > 3) return fail(ctx, BPMI_E_ARG, "final_spread must be 0 .. 3"); ctx->opt_final_spread = (int)value; msm_graphs_clear(ctx); return BPMI_OK; }
   if (!strcmp(name, "sort_inblock")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "sort_inblock must be 0 or 1"); ctx->opt_inblock = (int)value; msm_graphs_clear(ctx); return BPMI_OK; }
   if (!strcmp(name, "segscan_fused")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "segscan_fused must be 0 or 1"); ctx->opt_segfuse = (int)value; msm_graphs_clear(ctx); return BPMI_OK; }
   if (!strcmp(name, "priority")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "priority must be 0 or 1"); ctx->opt_prio = (int)value; return BPMI_OK; }

@@ -104,6 +104,8 @@ struct bpmi_ctx {
   int opt_graph = 0;                    // 1: replay an MSM's launch sequence as a HIP graph when the same call comes again
   // round 5 (the mid-size floor; every one on by default, 0 = the round-4 path for A/B runs and tests)
   int opt_top2 = 1;                     // c = 15: 17 windows, the last one unsigned with 2B buckets (0: 18 windows, the last one a carry window)
+  int opt_reduce_fit = 1;               // stage 1 of the bucket reduction: elements per lane chosen so that its waves fit the SIMDs at one each
+  int opt_final_spread = 3;             // the bucket reduction's finish: 0 one 16-wave block per array, 1 one-wave blocks + tickets, 2 / 3 two launches (include/bpmi.h)
   int opt_inblock = 1;                  // n <= 2^17: the sort's level B handles partitions of any size itself, the two heavy-tile launches are skipped
   int opt_prover_tw = 0;                // bpmi_rp_prover_create: window bits of the fixed-base tables (0 = default 12; 4 .. 13)
   int opt_validate = 1;                 // on-curve check of the points a caller hands in: 0 never, 1 the host-pointer entry points (default), 2 the synchronous _dev ones too

@@ -13,12 +13,13 @@ static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; 
 // handful of buckets, so c in {8, 16} (top window 7, 15 bits) are preferred.
 static u32 pick_window_bits(const bpmi_ctx *ctx, uint64_t n) {
   if (ctx->opt_c >= 2 && ctx->opt_c <= 16) return (u32)ctx->opt_c;
-  // tools/tune_msm_mid.py (profiles/r03_tune_msm_mid_sizes.txt, ..._small_window_table.txt): c = 16 from 2^15 (the LDS sort and
-  // the two-digit bucket reduction made 2^15 buckets per window cheap; c = 12 .. 15 lose at every size above), c = 13 between
-  // 10 240 and 2^15 (0.30-0.33 ms against 0.33-0.46 with c = 8), c = 8 below
-  if (n >= (1u << 15)) return 16;
-  if (n >= 20480u) return 13;
-  if (n >= 10240u) return 12;          // round 4, with the wave-level scan in the accumulation: 0.303 ms against 0.312 at 2^14 (profiles/r04_tune_msm_mid_sizes_fused_scan.txt)
+  // Round 5 (tools/r05_ab_mid.py, profiles/r05_window_table_sweep.txt): c = 15 with the unsigned last window from 15 360 to 2^17 pairs --
+  // half the buckets of c = 16, and with 12-lane sums the reduction's first stage fits the SIMDs at one wave each (0.279-0.330 ms
+  // against 0.303-0.338 for the round-4 table of c = 12 / 13 / 16 there); c = 16 from 2^17 (a tie up to ~3 x 10^5, ahead beyond);
+  // c = 12 between 10 240 and 15 360 (0.263 against 0.296 at 12 288); c = 8 below (round 3: profiles/r03_tune_msm_small_window_table.txt)
+  if (n >= (1u << 17)) return 16;
+  if (n >= 15360u) return ctx->opt_top2 ? 15 : 16;
+  if (n >= 10240u) return 12;
   if (n >= (1u << 10)) return 8;
   u32 lg = 0;
   while ((1ull << (lg + 1)) <= n) lg++;
@@ -43,7 +44,7 @@ struct MsmWs {
   unsigned char *negs;        // path 2: 1 = the scalar was replaced by q - s
   u32 P;          // partitions of sort path 2 (0 = path 1)
   u32 *rec_key[2], *rec_pt[2];
-  u32 *D, *E, *out;
+  u32 *D, *E, *F, *out;
   size_t total;
   u32 nscan_blocks, rec0_max, nchunks;
 };
@@ -80,20 +81,27 @@ static void msm_layout(const MsmGeom &g, MsmWs &w, char *base, bool glv = false)
   w.rec_pt[1] = take(4ull * XYZZ_WORDS * rec1_max);
   w.D = take(4ull * XYZZ_WORDS * g.W * (g.B > 256u ? (1u << ((g.c + 1u) / 2u)) + (1u << (g.c / 2u)) : 1u));   // stage-1 digit sums
   w.E = take(4ull * XYZZ_WORDS * g.W * 4);
+  w.F = take(4ull * XYZZ_WORDS * g.W * 64);       // k_digit_final_spread: 16 sums per (window, array)
   w.out = take(64);
   w.total = o;
 }
 
 static u32 msb_index(u32 v) { u32 k = 0; while ((2u << k) <= v) k++; return k; }     // floor(log2 v), v >= 1
-static u32 digit_group_log(u32 elements, u32 epl) {          // lanes per sum: epl elements per lane, at most one wave
-  u32 gl = 0;
-  while (gl < 6 && (epl << gl) < elements) gl++;
-  return gl;
+// lanes per sum for `epl` elements per lane: a sum lives in ONE wave, so the group is widened to the largest size that keeps the same
+// number of sums per wave (12 lanes -> 5 sums per wave; 13 .. 16 lanes -> 4)
+static void digit_group(DigitJob &j, u32 elements, u32 epl) {
+  u32 lanes = (elements + epl - 1u) / epl;
+  if (lanes > 64u) lanes = 64u;
+  if (lanes < 1u) lanes = 1u;
+  j.gpw = 64u / lanes;
+  j.glanes = 64u / j.gpw;
+  if (j.glanes > elements) j.glanes = elements ? elements : 1u;
 }
-static u32 digit_job_blocks(const DigitJobs &J, u32 k) {
-  const uint64_t lanes = (uint64_t)J.j[k].cnt * J.j[k].nsums << J.j[k].gl_log;
-  return (u32)((lanes + 255) / 256);
+static u32 digit_job_waves(const DigitJobs &J, u32 k) {
+  const uint64_t sums = (uint64_t)J.j[k].cnt * J.j[k].nsums;
+  return (u32)((sums + J.j[k].gpw - 1u) / J.j[k].gpw);
 }
+static u32 digit_job_blocks(const DigitJobs &J, u32 k) { return (digit_job_waves(J, k) + 3u) / 4u; }
 // the two jobs (by lo, by hi) that split every array [in_off .. in_off + N) of `cnt` arrays at bit s;
 // results at out_off (2^s - 1 sums) and behind them (N >> s sums)
 static DigitJobs digit_jobs2(u32 cnt, u32 in_off, u32 in_stride, u32 N, u32 s, u32 out_off, u32 out_stride, u32 epl) {
@@ -105,7 +113,7 @@ static DigitJobs digit_jobs2(u32 cnt, u32 in_off, u32 in_stride, u32 N, u32 s, u
     j.cnt = cnt;
     j.in_off = in_off; j.in_stride = in_stride; j.N = N; j.s = s; j.type = type;
     j.nsums = type ? (N >> s) : ((1u << s) - 1u);
-    j.gl_log = digit_group_log(type ? (1u << s) : ((N - 1u) >> s) + 1u, epl);
+    digit_group(j, type ? (1u << s) : ((N - 1u) >> s) + 1u, epl);
     j.out_off = out_off + (type ? (1u << s) - 1u : 0u); j.out_stride = out_stride;
   }
   J.j[0].blk0 = 0;
@@ -203,7 +211,7 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, int slot, const Segs &segs_in, u
   // up to 2^17 pairs a partition of the sort (<= n entries: one window's) is sorted by ONE block whatever its size (k_fine_sort_part)
   // (c = 16 only above 2^15: the short top window of c = 12 .. 14 is ONE partition of n entries by construction, and one block's two passes
   // over 2^17 entries are 0.15 ms -- measured, profiles/r05_mid_size_ab.txt)
-  g.inblock = (ctx->opt_inblock && (n <= (1u << 15) || (g.c == 16u && n <= (1u << 17)))) ? 1u : 0u;
+  g.inblock = (ctx->opt_inblock && (n <= (1u << 15) || ((g.c == 16u || g.top2) && n <= (1u << 17)))) ? 1u : 0u;
   // tools/tune_msm.py sweeps; on the two-lane pipeline 86 entries per thread fill the 3 waves per SIMD exactly once at n = 2^20
   // (profiles/r02_chunk_sweep_two_lanes.txt).  Round 3, at steady clocks (profiles/r03_chunk_sweep_steady_clocks.txt,
   // r03_chunk_length_vs_kernel_events.txt): L = 128 -- one round of TWO waves per SIMD, room for a 144-VGPR wave of the other lane's
@@ -433,9 +441,33 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, int slot, const Segs &segs_in, u
       // best of 4 / 8 / 12 / 16 there; fewer buckets -- smaller c, a window group of a split MSM -- get shorter chains
       // instead of idle SIMDs); stage 2 + the finish are pure latency: one element per lane, 16-lane butterflies, one launch
       const u32 Wr = g.W - g.top2;                       // windows with B buckets
-      u32 epl = ctx->opt_epl > 0 ? (u32)ctx->opt_epl : (u32)(((uint64_t)g.G) >> 15);
-      epl = epl < 2u ? 2u : (epl > 16u ? 16u : epl);
-      DigitJobs j1 = digit_jobs2(Wr, 0, g.B, g.B, s0, 0, stride1, epl);
+      // the unsigned last window (top2): ONE array of 2B buckets behind the others, split like a window of c + 1 bits (its D sums fit the
+      // per-window slot of w.D: 2^((c+1)/2) + 2^(c/2) records)
+      const u32 Bt = 2u * g.B, s0t = (g.c + 1u) / 2u, N0t = (1u << s0t) - 1u, N1t = Bt >> s0t;
+      const u32 t0t = (s0t + 1u) / 2u, t1t = (msb_index(N1t) + 1u) / 2u;
+      const u32 d_top = Wr * stride1;                    // first D record of the top window
+      auto stage1 = [&](u32 epl, DigitJobs &j) -> u32 {  // the jobs for `epl` elements per lane; returns their waves
+        j = digit_jobs2(Wr, 0, g.B, g.B, s0, 0, stride1, epl);
+        u32 waves = digit_job_waves(j, 0) + digit_job_waves(j, 1);
+        if (g.top2) {
+          DigitJobs jt = digit_jobs2(1, Wr * g.B, 0, Bt, s0t, d_top, 0, epl);
+          waves += digit_job_waves(jt, 0) + digit_job_waves(jt, 1);
+          j = digit_jobs_concat(j, jt);
+        }
+        return waves;
+      };
+      DigitJobs j1;
+      if (ctx->opt_epl > 0) stage1((u32)ctx->opt_epl, j1);
+      else if (ctx->opt_reduce_fit) {
+        // the fewest elements per lane whose waves fit the chip's 1 024 SIMDs at one each: a wave alone on its SIMD already runs at
+        // 86 % of the multiply-add pipe, so a SIMD with two takes twice as long (c = 15 with 16-lane sums: 1 148 waves, 124 SIMDs doubled,
+        // no faster than c = 16; with 12-lane sums, five to a wave: 931)
+        u32 epl = 2;
+        while (epl < 64u && stage1(epl, j1) > 1024u) epl++;
+      } else {
+        u32 epl = (u32)(((uint64_t)g.G) >> 15);
+        stage1(epl < 2u ? 2u : (epl > 16u ? 16u : epl), j1);
+      }
       // stage 2: D0 -> (D00, D01), D1 -> (D10, D11), each <= 16 sums of <= 16 elements, and E[a][r] = sum_d d * D..[d]
       DigitJobs ja = digit_jobs2(Wr, 0, stride1, N0, t0, 0, 64, 1);
       DigitJobs jb = digit_jobs2(Wr, N0, stride1, N1, t1, 0, 64, 1);
@@ -443,13 +475,6 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, int slot, const Segs &segs_in, u
       memset(&j2top, 0, sizeof(j2top));
       to.nv = 4; to.off[0] = 0; to.off[1] = t0; to.off[2] = s0; to.off[3] = s0 + t1;
       if (g.top2) {
-        // the unsigned last window: ONE array of 2B buckets behind the others, split like a window of c + 1 bits (its D sums fit the
-        // per-window slot of w.D: 2^((c+1)/2) + 2^(c/2) records)
-        const u32 Bt = 2u * g.B, s0t = (g.c + 1u) / 2u, N0t = (1u << s0t) - 1u, N1t = Bt >> s0t;
-        const u32 t0t = (s0t + 1u) / 2u, t1t = (msb_index(N1t) + 1u) / 2u;
-        const u32 d_top = Wr * stride1;                  // first D record of the top window
-        DigitJobs jt = digit_jobs2(1, Wr * g.B, 0, Bt, s0t, d_top, 0, epl);
-        j1 = digit_jobs_concat(j1, jt);
         DigitJobs jta = digit_jobs2(1, d_top, 0, N0t, t0t, 0, 64, 1);
         DigitJobs jtb = digit_jobs2(1, d_top + N0t, 0, N1t, t1t, 0, 64, 1);
         j2top = digit_jobs_concat(jta, jtb);
@@ -459,7 +484,15 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, int slot, const Segs &segs_in, u
       hipLaunchKernelGGL(k_digit_sums, dim3(j1.j[j1.njobs - 1].blk0 + digit_job_blocks(j1, j1.njobs - 1)), dim3(256), 0, st, w.buckets, w.D, j1);
       j2.prio = j2top.prio = g.prio;
       const u32 top_w = g.top2 ? Wr : 0xFFFFFFFFu;
-      if (ctx->opt_quad) hipLaunchKernelGGL(k_digit_final_quad, dim3(g.W * 4u), dim3(1024), 0, st, w.D, E_red, j2, j2top, top_w);
+      // (the tickets of the spread finish live behind the sort's partition counts: zeroed by this MSM's memset when the LDS sort runs)
+      if (ctx->opt_quad && ctx->opt_final_spread == 1 && w.P)
+        hipLaunchKernelGGL(k_digit_final_spread<0>, dim3(g.W * 64u), dim3(64), 0, st, w.D, w.F, w.coarse_hist + PART_MAX + 8, E_red, j2, j2top, top_w);
+      else if (ctx->opt_quad && ctx->opt_final_spread >= 2) {
+        if (ctx->opt_final_spread == 2) hipLaunchKernelGGL(k_digit_final_spread<1>, dim3(g.W * 64u), dim3(64), 0, st, w.D, w.F, nullptr, E_red, j2, j2top, top_w);
+        else hipLaunchKernelGGL(k_digit_final_spread<1>, dim3(g.W * 16u), dim3(256), 0, st, w.D, w.F, nullptr, E_red, j2, j2top, top_w);
+        hipLaunchKernelGGL(k_digit_final_spread<2>, dim3(g.W * 4u), dim3(64), 0, st, w.D, w.F, nullptr, E_red, j2, j2top, top_w);
+      }
+      else if (ctx->opt_quad) hipLaunchKernelGGL(k_digit_final_quad, dim3(g.W * 4u), dim3(1024), 0, st, w.D, E_red, j2, j2top, top_w);
       else hipLaunchKernelGGL(k_digit_final, dim3(g.W * 4u), dim3(256), 0, st, w.D, E_red, j2, j2top, top_w);
     }
   }

@@ -145,7 +145,8 @@ __global__ void __launch_bounds__(256) k_digits_hist(Segs segs, MsmGeom g, u32 *
 // (tile, partition); level B gives every partition to one block, which counting-sorts it
 // by lo entirely in LDS.  No per-element global atomic anywhere.
 #define PART_MAX 2048          // W * (B / 256) <= 2048 for every c in [10, 16]
-#define COARSE_HIST_WORDS (PART_MAX + 64)      // the partition counts + the any_heavy flag, padded to whole 256-byte lines
+#define COARSE_HIST_WORDS (PART_MAX + 192)     // the partition counts, the any_heavy flag (+0), the tickets of the last-block fusions (+1, +2) and of
+                                               // k_digit_final_spread (+8 .. +8 + 4 W), padded to whole 256-byte lines
 #define FINE_CAP 12288          // entries of a partition that level B sorts in one block's LDS
 // The recoded digits are kept, 16 bits each, window-major: dig16[w * n + i] = (b - 1) | digit sign << 15,
 // DIG_NONE for b = 0 (a negative digit has b <= 2^(c-1) - 1, so that code is free), and one byte
@@ -863,7 +864,7 @@ __device__ __forceinline__ void block_tree_sum(xyzz &val, u32 *s_val) {
 struct DigitJob {
   u32 in_off, in_stride;     // array a starts at record a * in_stride + in_off of X
   u32 N, s, type;            // entries, split bits, 0 = D0 (by lo) / 1 = D1 (by hi)
-  u32 gl_log;                // lanes per sum = 2^gl_log (<= 64)
+  u32 glanes, gpw;           // lanes per sum (1 .. 64, any value) and sums per wave = 64 / glanes: a sum never straddles two waves
   u32 nsums;                 // sums per array: 2^s - 1 (type 0) or N >> s (type 1)
   u32 out_off, out_stride;   // sum idx (1-based) of array a -> record a * out_stride + out_off + idx - 1 of D
   u32 blk0;                  // first block of this job
@@ -878,6 +879,15 @@ __device__ __forceinline__ void xyzz_shfl_xor(xyzz &r, const xyzz &a, int mask) 
     r.Y.v[i] = (u32)__shfl_xor((int)a.Y.v[i], mask, 64);
     r.ZZ.v[i] = (u32)__shfl_xor((int)a.ZZ.v[i], mask, 64);
     r.ZZZ.v[i] = (u32)__shfl_xor((int)a.ZZZ.v[i], mask, 64);
+  }
+}
+__device__ __forceinline__ void xyzz_shfl_down(xyzz &r, const xyzz &a, int d) {        // across the wave (lanes past the end read their own)
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    r.X.v[i] = (u32)__shfl_down((int)a.X.v[i], d, 64);
+    r.Y.v[i] = (u32)__shfl_down((int)a.Y.v[i], d, 64);
+    r.ZZ.v[i] = (u32)__shfl_down((int)a.ZZ.v[i], d, 64);
+    r.ZZZ.v[i] = (u32)__shfl_down((int)a.ZZZ.v[i], d, 64);
   }
 }
 __device__ __forceinline__ void xyzz_shfl_down16(xyzz &r, const xyzz &a, int d) {      // within groups of 16 lanes
@@ -896,9 +906,10 @@ __global__ void __launch_bounds__(256) k_digit_sums(const u32 *__restrict__ X, u
   for (u32 k = 1; k < jobs.njobs; k++) if (blockIdx.x >= jobs.j[k].blk0) ji = k;
   const DigitJob J = jobs.j[ji];
   const u32 t = (blockIdx.x - J.blk0) * blockDim.x + threadIdx.x;
-  const u32 GL = 1u << J.gl_log;
-  const u32 sum_id = t >> J.gl_log, l = t & (GL - 1u);
-  const bool active = sum_id < J.cnt * J.nsums;
+  const u32 GL = J.glanes, lane = t & 63u;
+  const u32 grp = lane / GL, l = lane - grp * GL;
+  const u32 sum_id = (t >> 6) * J.gpw + grp;
+  const bool active = grp < J.gpw && sum_id < J.cnt * J.nsums;
   const u32 a = sum_id / J.nsums, idx = sum_id % J.nsums + 1u;
   xyzz acc;
   xyzz_set_inf(acc);
@@ -918,10 +929,26 @@ __global__ void __launch_bounds__(256) k_digit_sums(const u32 *__restrict__ X, u
       }
     }
   }
-  for (u32 m = 1; m < GL; m <<= 1) {
-    xyzz other;
-    xyzz_shfl_xor(other, acc, (int)m);
-    xyzz_add(acc, acc, other);
+  // tree over the group's lanes: the first step folds the lanes above the largest power of two below GL, the rest halve
+  // the group's tree.  Powers of two: a butterfly of __shfl_xor (DPP for the short distances), every lane adding.  Other sizes: lanes l < d
+  // take lane l + d, first the ones above the largest power of two below GL -- every lane still runs the addition (against the identity
+  // where it has no partner): the addition under a partial EXEC mask measured 11 us slower per launch at c = 16 than the butterfly, this
+  // form 4 (gpurun_out/r05_exp_tree.txt -> profiles/r05_reduction_tree_forms.txt)
+  if ((GL & (GL - 1u)) == 0u) {
+    for (u32 m = 1; m < GL; m <<= 1) {
+      xyzz other;
+      xyzz_shfl_xor(other, acc, (int)m);
+      xyzz_add(acc, acc, other);
+    }
+  } else {
+    u32 d = 1;
+    while ((d << 1) < GL) d <<= 1;
+    for (u32 width = GL; d > 0 && width > 1; width = d, d >>= 1) {
+      xyzz other;
+      xyzz_shfl_down(other, acc, (int)d);
+      if (!(l < d && l + d < width)) xyzz_set_inf(other);
+      xyzz_add(acc, acc, other);
+    }
   }
   if (active && l == 0) xyzz_store_g(D + ((u64)a * J.out_stride + J.out_off + idx - 1u) * XYZZ_WORDS, acc);
 }
@@ -1139,6 +1166,82 @@ __global__ void __launch_bounds__(1024) k_digit_final_quad(const u32 *__restrict
 #pragma unroll
     for (int k = 0; k < 9; k++) Eout[(u64)blockIdx.x * XYZZ_WORDS + q * 9u + k] = a.v[k];
   }
+}
+
+// k_digit_final_quad with its first phase spread over the chip (round 5).  In the kernel above the 16 waves of a block share ONE CU -- four
+// per SIMD, each running the same 4 dependent quad additions -- while 68 blocks leave three quarters of the CUs idle: the phase
+// costs 4 waves x 4 additions of issue time (~30 of the kernel's 49 us) on a path that is nothing but latency.  Here every sum is a
+// wave of its own (<= 1 088 waves: about one per SIMD) that parks its result in `F` (16 records per array), and the last 8 additions
+// over an array's <= 16 sums run in a wave per array.  MODE 1 + MODE 2: two launches (18 + 21 us, the default); MODE 0: one launch,
+// the wave that draws the array's last ticket runs the finish -- measured 60 us: the device-scope fences around the ticket cost more
+// than a launch (as in k_coarse_hist's last-block scan).  `ticket` (MODE 0): one word per array, zero on entry, left zero.
+template <int MODE> __global__ void __launch_bounds__(256) k_digit_final_spread(const u32 *__restrict__ X, u32 *F, u32 *ticket, u32 *__restrict__ Eout, DigitJobs jobs,
+                                                                               DigitJobs jtop, u32 top_w) {
+  raise_priority(jobs.prio);
+  const u32 gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);            // blocks of one wave or of four
+  const u32 arr = MODE == 2 ? gw : gw >> 4, wave = MODE == 2 ? 0u : gw & 15u, r = arr & 3u;
+  const bool is_top = (arr >> 2) == top_w;
+  const u32 a_idx = is_top ? 0u : (arr >> 2);
+  const DigitJob J = is_top ? jtop.j[r] : jobs.j[r];
+  const u32 lane = threadIdx.x & 63u, e = lane >> 2, q = lane & 3u;
+  const u32 idx = wave + 1u;
+  fe a;
+  if (MODE != 2 && idx <= J.nsums) {                        // (wave-uniform)
+    fe_set_zero(a);
+    const u32 *base = X + ((u64)a_idx * J.in_stride + J.in_off) * XYZZ_WORDS;
+    u32 rec = 0;                                            // 1-based record of this quad's element, 0 = none
+    if (J.type == 0) { const u32 b = (e << J.s) | idx; if (b <= J.N) rec = b; }
+    else { const u32 b = (idx << J.s) | e; if (e < (1u << J.s) && b <= J.N) rec = b; }
+    if (rec) {
+      const u32 *p = base + (u64)(rec - 1u) * XYZZ_WORDS + q * 9u;
+#pragma unroll
+      for (int k = 0; k < 9; k++) a.v[k] = p[k];
+    }
+#pragma unroll 1
+    for (u32 m = 4; m < 64u; m <<= 1) {
+      fe b;
+#pragma unroll
+      for (int k = 0; k < 9; k++) b.v[k] = (u32)__shfl_xor((int)a.v[k], (int)m, 64);
+      quad_add(a, b, q);
+    }
+    if (e == 0) {
+#pragma unroll
+      for (int k = 0; k < 9; k++) F[((u64)arr * 16u + wave) * XYZZ_WORDS + q * 9u + k] = a.v[k];
+    }
+  }
+  if (MODE == 1) return;
+  if (MODE == 0) {
+    __threadfence();
+    u32 t = 0;
+    if (lane == 0) t = atomicAdd(ticket + arr, 1u);
+    t = (u32)__shfl((int)t, 0, 64);
+    if (t != 15u) return;
+    __threadfence();                                        // the other 15 waves' sums are complete and visible
+  }
+  fe_set_zero(a);
+  if (e < J.nsums) {                                        // quad d holds X[d + 1]
+#pragma unroll
+    for (int k = 0; k < 9; k++) a.v[k] = F[((u64)arr * 16u + e) * XYZZ_WORDS + q * 9u + k];
+  }
+#pragma unroll 1
+  for (u32 d = 1; d < 16u; d <<= 1) {                       // inclusive suffix scan over the 16 quads
+    fe b;
+#pragma unroll
+    for (int k = 0; k < 9; k++) { const u32 v = (u32)__shfl_down((int)a.v[k], (int)(4u * d), 64); b.v[k] = (e + d < 16u) ? v : 0u; }
+    quad_add(a, b, q);
+  }
+#pragma unroll 1
+  for (u32 m = 4; m < 64u; m <<= 1) {                       // the sum of all suffixes
+    fe b;
+#pragma unroll
+    for (int k = 0; k < 9; k++) b.v[k] = (u32)__shfl_xor((int)a.v[k], (int)m, 64);
+    quad_add(a, b, q);
+  }
+  if (e == 0) {
+#pragma unroll
+    for (int k = 0; k < 9; k++) Eout[(u64)arr * XYZZ_WORDS + q * 9u + k] = a.v[k];
+  }
+  if (MODE == 0 && lane == 0) ticket[arr] = 0u;
 }
 
 // self-test hook (bpmi_debug_quad_add): out[i] = a[i] + b[i] for XYZZ records, one quad per pair

@@ -60,13 +60,16 @@ def test_msm_vs_oracle_random(gp, n):
     assert gp.engine().msm_bytes(pb, sb, n) == cbind.msm_bytes(pb, sb, n)
 
 
-@pytest.mark.parametrize("n", [4096, 4097, 10239, 10240, 32767, 32768])
+@pytest.mark.parametrize("n", [4096, 4097, 10239, 10240, 15359, 15360, 32767, 32768])
 def test_msm_at_the_window_table_boundaries(gp, n):
-    """Either side of every switch of the geometry: one-launch kernel / bucket pipeline (4096), window bits 8 / 13 (10 240) and
-    13 / 16 (2^15); scalars with the edge values mixed in (0, 1, q - 1, >= q, 2^255 and the half-order boundary)."""
+    """Either side of every switch of the geometry: one-launch kernel / bucket pipeline (4096), window bits 8 / 12 (10 240),
+    12 / 15 with the unsigned last window (15 360; round 5) and round 4's 13 / 16 (2^15); 15 / 16 at 2^17 is in
+    test_gpu_msm_midsize.py.  Scalars with the edge values mixed in (0, 1, q - 1, >= q, 2^255, the half-order boundary, and the
+    largest digits of a 15-bit window)."""
     pts, _ = gp.rand_points(n, 900 + n)
     rnd = random.Random(n)
-    edge = [0, 1, Q - 1, Q, Q + 1, (1 << 256) - 1, 1 << 255, (Q - 1) // 2, (Q + 1) // 2, (1 << 13) - 1, 1 << 12, (1 << 16) - 1, 1 << 15]
+    edge = [0, 1, Q - 1, Q, Q + 1, (1 << 256) - 1, 1 << 255, (Q - 1) // 2, (Q + 1) // 2, (1 << 13) - 1, 1 << 12, (1 << 16) - 1, 1 << 15,
+            (1 << 15) - 1, 1 << 14, (0x7FFF << 240) % Q, ((1 << 255) - 1) % Q]
     es = [edge[rnd.randrange(len(edge))] if i % 5 == 0 else rnd.randrange(Q) for i in range(n)]
     pb, sb = cbind.pack_points(pts), b"".join(e.to_bytes(32, "little") for e in es)       # unreduced: both sides reduce mod q
     assert gp.engine().msm_bytes(pb, sb, n) == cbind.msm_bytes(pb, sb, n)
@@ -272,7 +275,7 @@ def test_msm_sliced_above_2e23(gp):
         d_e.free()
 
 
-@pytest.mark.parametrize("c", [10, 13, 16])
+@pytest.mark.parametrize("c", [10, 12, 13, 15, 16])            # (15: the last window is unsigned, 2B buckets -- digits B and 2B - 1 land there too)
 def test_msm_digit_of_magnitude_B_both_signs(gp, c):
     """Signed recoding edge: a digit of magnitude exactly B = 2^(c-1) is always a positive digit,
     but the scalar may have been replaced by q - s, so the ENTRY's sign can be either; the sort's
@@ -287,6 +290,8 @@ def test_msm_digit_of_magnitude_B_both_signs(gp, c):
         r = 0
         for w in range(rnd.randrange(1, 6)):
             r |= (B if rnd.random() < 0.7 else rnd.randrange(1 << c)) << (c * rnd.randrange(0, 200 // c))
+        if i % 3 == 0:
+            r |= rnd.choice((B, 2 * B - 1, B - 1, B + 1)) << (c * (254 // c))          # the last window's own edge digits
         r %= Q // 2
         es.append(r if i % 2 else Q - r)              # odd i: digits of r; even i: negated scalar, same digits
     pb, sb = cbind.pack_points(pts), cbind.pack_scalars(es)
@@ -343,9 +348,10 @@ def test_msm2_both_sorts_before_either_accumulation(gp):
         eng.set_option("pair_phases", 0)
 
 
-@pytest.mark.parametrize("n", [40000, 30000])      # window bits 16, and 13 (the size range 10 240 .. 2^15: a short top window, always heavy)
+# (40 000, 0): the default table's c = 15 with the unsigned last window; window bits 16, and 13 / 12 with their short top window, always heavy
+@pytest.mark.parametrize("n,c", [(40000, 0), (40000, 16), (30000, 13), (14000, 0), (140000, 0)])
 @pytest.mark.parametrize("shape", ["all_same", "two_values", "bits01", "bits_and_blinding", "small_range"])
-def test_msm_heavy_partitions(gp, shape, n):
+def test_msm_heavy_partitions(gp, shape, n, c):
     """Skewed digit distributions on the LDS-sort path: partitions with more than 12 288 entries
     are counted and scattered by the tile kernels (k_fine_hist_heavy / k_fine_scatter_heavy) instead of
     one block's LDS; mixed with light partitions in the same MSM.  Buckets with thousands of entries also take the
@@ -367,7 +373,11 @@ def test_msm_heavy_partitions(gp, shape, n):
     else:
         es = [rnd.randrange(1 << 20) if i % 3 else rnd.randrange(Q) for i in range(n)]
     pb, sb = cbind.pack_points(pts), cbind.pack_scalars(es)
-    assert eng.msm_bytes(pb, sb, n) == cbind.msm_bytes(pb, sb, n)
+    try:
+        eng.set_option("window_bits", c)
+        assert eng.msm_bytes(pb, sb, n) == cbind.msm_bytes(pb, sb, n)
+    finally:
+        eng.set_option("window_bits", 0)
 
 
 @pytest.mark.parametrize("n", [300, 5000, 40000])

@@ -12,7 +12,7 @@ from oracle import cbind
 
 pytestmark = pytest.mark.gpu
 
-R5_DEFAULTS = {"top_window_unsigned": 1, "sort_inblock": 1, "segscan_fused": 0, "hist_scan_fused": 0}
+R5_DEFAULTS = {"top_window_unsigned": 1, "sort_inblock": 1, "segscan_fused": 0, "hist_scan_fused": 0, "final_spread": 3, "reduce_fit": 1}
 
 
 @pytest.fixture(scope="module")
@@ -88,8 +88,8 @@ def test_msm_partition_count_scan_in_the_histogram_kernels_last_block(gp, n, c):
 @pytest.mark.parametrize("c", [10, 12, 13, 14, 15, 16])
 @pytest.mark.parametrize("n", [11000, 40000, 70001])
 def test_msm_bucket_reduction_group_sizes(gp, n, c):
-    """Stage 1 of the bucket reduction with 1 .. 64 lanes per sum (reduce_epl), the unsigned last window's own job set included
-    (c = 15), against the oracle."""
+    """Stage 1 of the bucket reduction with 1 .. 64 lanes per sum (reduce_epl) -- any number, not only powers of two: a wave holds
+    64 / lanes sums and the rest of its lanes idle -- the unsigned last window's own job set included (c = 15), against the oracle."""
     eng = gp.engine()
     pts, _ = gp.rand_points(1000, 41)
     pts = (pts * (n // 1000 + 1))[:n]
@@ -98,9 +98,12 @@ def test_msm_bucket_reduction_group_sizes(gp, n, c):
     want = cbind.msm_bytes(pb, sb, n)
     try:
         eng.set_option("window_bits", c)
-        for epl in (0, 1, 3, 5, 16, 33, 64):
+        for epl in (0, 1, 3, 5, 7, 11, 13, 16, 20, 33, 64):     # 64, 64, 32, 21, 12, 10, 8, 7, 4, 2 lanes per sum of 128 elements
             eng.set_option("reduce_epl", epl)
             assert eng.msm_bytes(pb, sb, n) == want, epl
+        eng.set_option("reduce_epl", 0)
+        eng.set_option("reduce_fit", 0)                         # round 4's rule for the lanes per sum
+        assert eng.msm_bytes(pb, sb, n) == want
     finally:
         _reset(eng)
 
@@ -177,12 +180,43 @@ def test_msm_segscan_last_level_in_the_last_block(gp, shape, n, chunk, c):
         _reset(eng)
 
 
+@pytest.mark.parametrize("c", [10, 11, 12, 13, 14, 15, 16])
+@pytest.mark.parametrize("n,shape", [(11000, "uniform"), (40000, "top_window_edges"), (70001, "bits_and_blinding"), (300000, "uniform")])
+def test_msm_bucket_reduction_finish_spread_over_waves(gp, n, shape, c):
+    """The finish of the bucket reduction with its 16 second-level sums per (window, array) as waves of their own
+    (k_digit_final_spread: two launches with blocks of four waves -- the default -- or of one, or one launch with a ticket per array)
+    against the 16-wave block per array (k_digit_final_quad), the one-lane k_digit_final and the oracle; called again and again on
+    one workspace (the tickets go back to zero), both tails, the unsigned last window of c = 15 included."""
+    eng = gp.engine()
+    pts, _ = gp.rand_points(1000, 47)
+    pts = (pts * (n // 1000 + 1))[:n]
+    es = _scalars(shape, n, random.Random(n * 3 + c))
+    pb, sb = cbind.pack_points(pts), cbind.pack_scalars(es)
+    want = cbind.msm_bytes(pb, sb, n)
+    try:
+        eng.set_option("window_bits", c)
+        for spread in (3, 1, 1, 0, 2, 3, 2, 1):               # 1: tickets; 2, 3 (default): two launches, sums in blocks of one wave / of four
+            eng.set_option("final_spread", spread)
+            for tail in (2, 1):
+                eng.set_option("tail", tail)
+                assert eng.msm_bytes(pb, sb, n) == want, (spread, tail)
+        eng.set_option("tail", 0)
+        eng.set_option("quad_final", 0)
+        assert eng.msm_bytes(pb, sb, n) == want
+        eng.set_option("quad_final", 1)
+        handles = [eng.msm_bytes(pb, sb, n) for _ in range(5)]
+        assert handles == [want] * 5
+    finally:
+        eng.set_option("quad_final", 1)
+        _reset(eng)
+
+
 def test_msm_default_geometry_sizes_around_the_switches(gp):
     """Either side of every size at which the default geometry changes (window bits, the in-block sort bound), edge scalars mixed in."""
     eng = gp.engine()
     pts, _ = gp.rand_points(2048, 9)
     edge = [0, 1, Q - 1, (Q - 1) // 2, (Q + 1) // 2, 1 << 254, (1 << 255) % Q, (1 << 15) - 1, 1 << 14, (0x7FFF << 240) % Q]
-    for n in (32767, 32768, 65535, 65536, 65537, 131071, 131072, 131073, 200000, 262144, 262145):
+    for n in (15359, 15360, 20479, 20480, 32767, 32768, 65535, 65536, 65537, 131071, 131072, 131073, 200000, 262144, 262145):
         rnd = random.Random(n)
         es = [edge[rnd.randrange(len(edge))] if i % 7 == 0 else rnd.randrange(Q) for i in range(n)]
         p = (pts * (n // 2048 + 1))[:n]
