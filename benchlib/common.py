@@ -44,7 +44,7 @@ def synth_scalars(n, seed):
 
 def isa_counts():
     try:
-        for name in ("r04_isa_counts.json", "r03_isa_counts.json", "r02_isa_counts.json"):
+        for name in ("r05_isa_counts.json", "r04_isa_counts.json", "r03_isa_counts.json", "r02_isa_counts.json"):
             path = os.path.join(REPO, "profiles", name)
             if os.path.exists(path):
                 with open(path) as f:
@@ -56,7 +56,7 @@ def isa_counts():
 
 def committed_traffic(logn):
     """Per-launch HBM bytes of the dominant kernel from the committed rocprofv3 --pmc passes (NOT measured in this run)."""
-    for name in ("r04_pmc_traffic_msm_n2e20.json", "r03_pmc_traffic_msm_n2e20.json", "r02_pmc_traffic_msm_n2e20.json", "r01_pmc_traffic_msm_n2e20.json"):
+    for name in ("r05_pmc_traffic_msm_n2e20.json", "r04_pmc_traffic_msm_n2e20.json", "r03_pmc_traffic_msm_n2e20.json", "r02_pmc_traffic_msm_n2e20.json", "r01_pmc_traffic_msm_n2e20.json"):
         try:
             with open(os.path.join(REPO, "profiles", name)) as f:
                 for row in json.load(f)["kernels"]:

@@ -298,11 +298,16 @@ def extra_c2(eng, world, rank, dev, d_pts, d_sc, n, dlog, G64):
     eng.profile(False)
     stage_ms = {k: round(v[0] / max(v[1], 1), 4) for k, v in prof.items() if v[1]}
     acc_s = stage_ms.get("msm_accumulate", 0.0) / 1e3
-    # the integer-issue figures, as for the headline: multiply-adds of the bucket additions (16 windows x n mixed additions; the bucket
-    # reduction's 2^20 general additions counted too, at 14/10.5 of a mixed one) against the chip's raw v_mad_u64_u32 rate
+    # the integer-issue figures, as for the headline: multiply-adds of the bucket additions (W windows x n mixed additions; the bucket
+    # reduction's two GENERAL additions per bucket counted too, at 14/10.5 of a mixed one) against the chip's raw v_mad_u64_u32 rate.
+    # Geometry as csrc/msm_host.hpp pick_window_bits: from 15 360 to 2^17 pairs c = 15 as 17 windows, the last one unsigned with twice
+    # the buckets; c = 16, 16 windows, from 2^17
     isa = isa_counts() or {}
     mads = isa.get("v_mad_u64_u32_per_madd") or 1055
-    W, buckets = 16, 16 << 15
+    if 15360 <= n < (1 << 17):
+        c_bits, W, buckets = 15, 17, 16 * (1 << 14) + (1 << 15)
+    else:
+        c_bits, W, buckets = 16, 16, 16 << 15
     mad_accum = W * n * mads
     mad_reduce = 2 * buckets * mads * 14.0 / MULS_PER_MADD
     red_s = stage_ms.get("msm_bucket_reduce", 0.0) / 1e3
@@ -310,12 +315,14 @@ def extra_c2(eng, world, rank, dev, d_pts, d_sc, n, dlog, G64):
     def frac(work, secs):
         return (work / secs / 1e12 / RAW_MAD_TOPS) if secs > 0 else None
     alu = {"unit": "T lane multiply-adds/s (v_mad_u64_u32)", "peak": RAW_MAD_TOPS, "mads_per_madd": mads,
-           "work": "16 windows x n mixed additions (accumulation) + 2 x 2^19 general additions (bucket reduction, 14 / 10.5 of a mixed one)",
+           "window_bits": c_bits, "windows": W, "buckets": buckets,
+           "work": "%d windows x n mixed additions (accumulation) + 2 x %d general additions (bucket reduction, 14 / 10.5 of a mixed one)" % (W, buckets),
            "frac_vs_raw_mad_accumulate_kernel": frac(mad_accum, acc_s), "frac_vs_raw_mad_reduction_stage": frac(mad_reduce, red_s),
            "frac_vs_raw_mad_one_at_a_time": frac(mad_accum + mad_reduce, sync_s), "frac_vs_raw_mad_two_in_flight": frac(mad_accum + mad_reduce, pipe_s),
            "frac_vs_raw_mad_accumulation_only_one_at_a_time": frac(mad_accum, sync_s),
-           "note": "at this size the bucket reduction (2^19 buckets whatever n is) is as much arithmetic as the accumulation; the two stages run at "
-                   "their issue bound, the rest of a call is latency-bound chains (sort, segmented scan, the finish on quads, the host tail): DESIGN.md section 5"}
+           "note": "at this size the bucket reduction (its bucket count does not depend on n) is about half as much arithmetic as the accumulation; "
+                   "stage 1 of it runs one wave per SIMD, the rest of a call is latency-bound chains (sort, segmented scan, the finish on quads, the "
+                   "host tail): DESIGN.md section 5"}
     return {"metric": "Pippenger MSM scalar-point pairs/sec at n=2^16 (config C2)", "alu_roofline": alu, "value": n / pipe_s, "unit": "pairs/s", "n": n,
             "ms_per_msm_two_in_flight": pipe_s * 1e3, "ms_per_msm_one_at_a_time": sync_s * 1e3, "pairs_per_s_one_at_a_time": n / sync_s,
             "result_ok": bool(got == expect), "stage_ms_per_msm": stage_ms,

@@ -32,17 +32,17 @@ static std::string decimal_of(const uint8_t le[32]) {
   rpt::append_decimal(dg, v);
   return std::string((const char *)dg.data(), dg.size() - 1);
 }
-static std::string b64(const uint8_t *p, size_t n) {
+// base64 of a seed, written where it is needed (a batch encodes one seed per proof: no string per proof); returns the length
+static size_t b64_into(char *o, const uint8_t *p, size_t n) {
   static const char T[] = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/";
-  std::string o;
-  o.reserve((n + 2) / 3 * 4);
+  char *q = o;
   for (size_t i = 0; i < n; i += 3) {
     const uint32_t a = p[i], b = i + 1 < n ? p[i + 1] : 0, c = i + 2 < n ? p[i + 2] : 0;
     const uint32_t v = (a << 16) | (b << 8) | c;
-    o.push_back(T[v >> 18]); o.push_back(T[(v >> 12) & 63]);
-    o.push_back(i + 1 < n ? T[(v >> 6) & 63] : '='); o.push_back(i + 2 < n ? T[v & 63] : '=');
+    *q++ = T[v >> 18]; *q++ = T[(v >> 12) & 63];
+    *q++ = i + 1 < n ? T[(v >> 6) & 63] : '='; *q++ = i + 2 < n ? T[v & 63] : '=';
   }
-  return o;
+  return (size_t)(q - o);
 }
 
 }  // namespace rpp_host
@@ -217,9 +217,10 @@ int bpmi_rp_prove_batch(bpmi_rp_prover *pv, uint64_t n_proofs, const uint8_t *va
   // ---- inputs into the staging buffer
   memset(hp, 0, in_bytes);
   for (u32 p = 0; p < P; p++) {
-    const std::string t = rpp_host::b64(seeds + seed_off[p], seed_off[p + 1] - seed_off[p]) + "&";
-    memcpy(hp + o_dig0 + (size_t)p * dig0_stride, t.data(), t.size());
-    ((u32 *)(hp + o_dlen))[p] = (u32)t.size();
+    char *dg = hp + o_dig0 + (size_t)p * dig0_stride;                 // (dig0_stride >= 4 ceil(len / 3) + 1)
+    size_t tl = rpp_host::b64_into(dg, seeds + seed_off[p], seed_off[p + 1] - seed_off[p]);
+    dg[tl++] = '&';
+    ((u32 *)(hp + o_dlen))[p] = (u32)tl;
     ((uint64_t *)(hp + o_soff))[p] = seed_off[p] - seed_off[0];
     ((uint64_t *)(hp + o_ooff))[p] = out_off[p];
   }

@@ -71,7 +71,7 @@ class BatchRangeProver:
         out = ctypes.create_string_buffer(cap)
         out_off = (ctypes.c_uint64 * (m + 1))()
         eng._ck(eng.lib.bpmi_rp_prove_batch(self._handle, m, vb, gb, sb, off, out, cap, out_off))
-        return out.raw[:out_off[m]], list(out_off)
+        return ctypes.string_at(out, out_off[m]), list(out_off)          # (one copy of the proofs, not .raw's two)
 
     def prove_wire(self, vs, gammas, seeds):
         packed, off = self.prove_wire_packed(vs, gammas, seeds)
