@@ -221,15 +221,18 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, int slot, const Segs &segs_in, u
   const u32 L_lanes = 86u;
   // One MSM at a time (and the pairs of the IPA): the accumulation as ONE round of three waves per SIMD (3072 waves) from the size
   // where that leaves chunks of 20 entries, one round of two below (a chunk is a chain of dependent additions and every chunk
-  // costs a pair of partial records), never fewer than 8 entries, at most 64.  Powers of two missed the quantisation points:
+  // costs a pair of partial records), at most 64.  Powers of two missed the quantisation points:
   // 311 427 pairs at L = 32 are 2 433 waves -- a third round for a fifth of the chip, 0.635 ms against 0.590 at L = 26
   // (profiles/r03_chunk_sweep_wave_quantisation.txt).
   u32 L_one = 64u;
   {
     const uint64_t e_max = (uint64_t)g.W * n;
     auto chunks_for = [&](uint64_t waves) { return (u32)((e_max * 1000 + 64 * waves * 1005 - 1) / (64 * waves * 1005)); };   // 0.5 % over is no extra round
-    const u32 l3 = chunks_for(3072), l2 = chunks_for(2048);
-    L_one = l3 >= 20u ? l3 : (l2 < 8u ? 8u : l2);
+    const u32 l3 = chunks_for(3072), l2 = chunks_for(2048), l1 = chunks_for(1024);
+    // Round 5 (profiles/r05_chunk_length_mid_sizes.txt): below ~50 000 pairs the old floor of 8 entries per chunk left 500 .. 1 600 waves
+    // -- whatever the count, a SIMD with two waves sets the time -- and the wave counts just under 2 048 win at every size measured
+    // (32 768 pairs: L = 5, 1 741 waves, 0.275 ms against 0.293 at L = 8 with 1 088); under three entries per chunk one wave per SIMD
+    L_one = l3 >= 20u ? l3 : (l2 >= 3u ? l2 : (l1 < 2u ? 2u : l1));
     if (L_one > 64u) L_one = 64u;
   }
   g.L = ctx->opt_chunk > 0 ? (u32)ctx->opt_chunk : ((n >= (1u << 19) && ctx->chain_accum) ? L_lanes : L_one);
