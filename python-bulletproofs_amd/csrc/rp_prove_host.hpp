@@ -267,12 +267,13 @@ int bpmi_rp_prove_batch(bpmi_rp_prover *pv, uint64_t n_proofs, const uint8_t *va
   (void)hipEventRecord(ev[1], st);
   // y, z, tau1, tau2; t1, t2; T1, T2 (:60-67)
   hipLaunchKernelGGL(rpp::k_pv_chal_yz, blocks(P, 64), dim3(64), 0, st, B);
-  hipLaunchKernelGGL(rpp::k_pv_poly, blocks(P, 64), dim3(64), 0, st, B);
+  hipLaunchKernelGGL(rpp::k_pv_poly, dim3((P + 256u / n - 1) / (256u / n)), dim3(256), 0, st, B);
   msm(2 * P, 1, 2, pv->off_T, B.tsc, 2, 1);
   affine(2 * P, 2, PV_PT_T1, 1);
   (void)hipEventRecord(ev[2], st);
   // x; l, r, t_hat, taux, mu; P_new (:68-90; inner_product_prover.py:33-37)
-  hipLaunchKernelGGL(rpp::k_pv_final, blocks(P, 64), dim3(64), 0, st, B);
+  hipLaunchKernelGGL(rpp::k_pv_final_chal, blocks(P, 64), dim3(64), 0, st, B);
+  hipLaunchKernelGGL(rpp::k_pv_final_wide, dim3((P + 256u / n - 1) / (256u / n)), dim3(256), 0, st, B);
   msm(P, 1, 2 * n + 1, pv->off_P, B.jsc, 2 * n + 1, 4);
   affine(P, 1, PV_PT_PNEW, 0);
   (void)hipEventRecord(ev[3], st);

@@ -181,7 +181,7 @@ struct Batch {
   u8 *tr;  u32 tr_stride;  u32 *tr_len;                        // the range-proof transcript, then (from k_pv_final on) the Protocol-2 transcript
   u32 *slr;                  // P x (2n + 1): sL, sR, rho     (the scalars of S in base order gs, hs, h)
   u32 *alpha;                // P
-  u32 *chal;                 // P x 4: y, z, x, (unused)
+  u32 *chal;                 // P x 4: y, z, x, 1 / y
   u32 *tau;                  // P x 2
   u32 *tsc;                  // P x 4: t1, tau1, t2, tau2   (the scalars of T1 and T2 over g, h)
   u32 *res;                  // P x 5: taux, mu, t_hat, a, b
@@ -362,35 +362,68 @@ __global__ void __launch_bounds__(64) k_pv_chal_yz(Batch B) {
   st_sc(B.tau + 16ull * p + 8, mod_hash_q(t2, 4, tr, len));
 }
 
-// ---- t1, t2 (rangeproof_prover.py:93-101): one lane per proof -------------------------------------------------------------------------------
-//   t1 = sum sL_i (y^i (aR_i + z) + z^2 2^i) + sum (aL_i - z) y^i sR_i,   t2 = sum sL_i y^i sR_i
-__global__ void __launch_bounds__(64) k_pv_poly(Batch B) {
-  const u32 p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= B.P) return;
-  const sc y = ld_sc(B.chal + 32ull * p), z = ld_sc(B.chal + 32ull * p + 8);
-  const sc v = ld_sc(B.values + 8ull * p);
-  const sc one = sc_u32(1), zz = mulq(z, z), zm1 = subq(z, one), mz = negq(z), omz = subq(one, z);
-  const u32 *slr = B.slr + 8ull * (size_t)p * (2u * B.n + 1u);
-  sc t1 = sc_u32(0), t2 = sc_u32(0), yp = one, tw = zz;            // y^i, z^2 2^i
-  for (u32 i = 0; i < B.n; i++) {
-    const u32 bit = (v.v[i >> 5] >> (i & 31u)) & 1u;
-    const sc sL = ld_sc(slr + 8ull * i), sR = ld_sc(slr + 8ull * (B.n + i));
-    const sc ysr = mulq(yp, sR);
-    // aR + z = z - 1 + bit;  aL - z = bit - z
-    t1 = addq(t1, mulq(sL, addq(mulq(yp, bit ? z : zm1), tw)));
-    t1 = addq(t1, mulq(bit ? omz : mz, ysr));
-    t2 = addq(t2, mulq(sL, ysr));
-    yp = mulq(yp, y);
-    tw = addq(tw, tw);
+// ---- the vector steps with n lanes per proof (block = 256 threads = 256 / n proofs, n <= 128 a power of two) -------------------------------
+// With ONE lane per proof these two steps ran 2^14 lanes of 64 serial iterations on a quarter of the SIMDs (0.65 + 0.88 ms of a 28 ms
+// batch); here lane j owns element j: the powers y^j / y^-j are an inclusive PRODUCT scan over the proof's lanes in LDS (log2 n
+// multiplications per lane), the sums over j an LDS tree.  The hashes and the inversion of y stay one lane per proof (k_pv_final_chal).
+// v[tid] <- product of v[base .. tid] over the proof's n lanes (every thread of the block calls it)
+__device__ __forceinline__ sc lane_product_scan(u32 *s_v, u32 tid, u32 j, u32 n, sc v) {
+  for (u32 d = 1; d < n; d <<= 1) {
+    st_sc(s_v + 8u * tid, v);
+    __syncthreads();
+    if (j >= d) v = mulq(v, ld_sc(s_v + 8u * (tid - d)));
+    __syncthreads();
   }
-  u32 *o = B.tsc + 32ull * p;
-  st_sc(o, t1); st_sc(o + 8, ld_sc(B.tau + 16ull * p)); st_sc(o + 16, t2); st_sc(o + 24, ld_sc(B.tau + 16ull * p + 8));
+  return v;
+}
+// v summed over the proof's n lanes; valid in lane j == 0 (every thread of the block calls it)
+__device__ __forceinline__ sc lane_tree_sum(u32 *s_v, u32 tid, u32 j, u32 n, sc v) {
+  st_sc(s_v + 8u * tid, v);
+  __syncthreads();
+  for (u32 d = n >> 1; d > 0u; d >>= 1) {
+    if (j < d) st_sc(s_v + 8u * tid, addq(ld_sc(s_v + 8u * tid), ld_sc(s_v + 8u * (tid + d))));
+    __syncthreads();
+  }
+  return ld_sc(s_v + 8u * tid);
+}
+__device__ __forceinline__ sc sc_pow2(u32 e) {                // 2^e, e < 128
+  sc r = sc_u32(0);
+  r.v[e >> 5] = 1u << (e & 31u);
+  return r;
+}
+// ---- t1, t2 (rangeproof_prover.py:93-101) -------------------------------------------------------------------------------------------------
+//   t1 = sum sL_i (y^i (aR_i + z) + z^2 2^i) + sum (aL_i - z) y^i sR_i,   t2 = sum sL_i y^i sR_i;   y^j is left in cg_j for k_pv_final_wide
+__global__ void __launch_bounds__(256) k_pv_poly(Batch B) {
+  __shared__ u32 s_v[256 * 8], s_w[256 * 8];
+  const u32 n = B.n, tid = threadIdx.x;
+  const u32 p = blockIdx.x * (256u / n) + tid / n, j = tid & (n - 1u);
+  const bool live = p < B.P;
+  const size_t pc = live ? p : 0;                             // (lanes past the batch compute on proof 0 and store nothing)
+  const sc y = ld_sc(B.chal + 32ull * pc), z = ld_sc(B.chal + 32ull * pc + 8);
+  const sc v = ld_sc(B.values + 8ull * pc);
+  const sc one = sc_u32(1), zz = mulq(z, z);
+  const sc yp = lane_product_scan(s_v, tid, j, n, j ? y : one);                  // y^j
+  const u32 *slr = B.slr + 8ull * pc * (2u * n + 1u);
+  const u32 bit = (v.v[j >> 5] >> (j & 31u)) & 1u;
+  const sc sL = ld_sc(slr + 8ull * j), sR = ld_sc(slr + 8ull * (n + j));
+  const sc ysr = mulq(yp, sR);
+  // aR + z = z - 1 + bit;  aL - z = bit - z
+  sc c1 = mulq(sL, addq(mulq(yp, bit ? z : subq(z, one)), mulq(zz, sc_pow2(j))));
+  c1 = addq(c1, mulq(bit ? subq(one, z) : negq(z), ysr));
+  const sc t1 = lane_tree_sum(s_v, tid, j, n, c1);
+  const sc t2 = lane_tree_sum(s_w, tid, j, n, mulq(sL, ysr));
+  if (!live) return;
+  st_sc(B.cg + 8ull * ((size_t)p * n + j), yp);
+  if (j == 0u) {
+    u32 *o = B.tsc + 32ull * p;
+    st_sc(o, t1); st_sc(o + 8, ld_sc(B.tau + 16ull * p)); st_sc(o + 16, t2); st_sc(o + 24, ld_sc(B.tau + 16ull * p + 8));
+  }
 }
 
-// ---- challenge x; l, r, t_hat, taux, mu; the inner-product state and the scalars of P_new (rangeproof_prover.py:68-90, :103-112;
-// inner_product_prover.py:33-37): P + (-mu) h = <l, gs> + <r, hsp> with hsp_i = y^-i hs_i (the h terms cancel: mu = alpha + rho x), so
-// P_new = sum l_i gs_i + sum (r_i y^-i) hs_i + (x_ip t_hat) u -- one fixed-base job, A and S never touched again
-__global__ void __launch_bounds__(64) k_pv_final(Batch B) {
+// ---- x; l, r, t_hat, taux, mu; the scalars of P_new and the state of Protocol 2 (rangeproof_prover.py:68-90, inner_product_prover.py:33-37)
+//   P + (-mu) h = <l, gs> + <r, hsp>,  hsp_i = y^-i hs_i   ->   P_new = sum l_i gs_i + sum (r_i y^-i) hs_i + (x_ip t_hat) u
+// k_pv_final_chal, one lane per proof: the hash, 1 / y, taux, mu, the Protocol-2 transcript's start; k_pv_final_wide: the vectors
+__global__ void __launch_bounds__(64) k_pv_final_chal(Batch B) {
   const u32 p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= B.P) return;
   u8 *tr = B.tr + (size_t)p * B.tr_stride;
@@ -402,33 +435,45 @@ __global__ void __launch_bounds__(64) k_pv_final(Batch B) {
   const sc x = mod_hash_q(0, 0, tr, len);
   st_sc(B.chal + 32ull * p + 16, x);
   const sc y = ld_sc(B.chal + 32ull * p), z = ld_sc(B.chal + 32ull * p + 8);
-  const sc v = ld_sc(B.values + 8ull * p);
-  const sc one = sc_u32(1), zz = mulq(z, z), zm1 = subq(z, one), mz = negq(z), omz = subq(one, z), yinv = invq(y);
+  st_sc(B.chal + 32ull * p + 24, invq(y));
   const u32 n = B.n;
   const u32 *slr = B.slr + 8ull * (size_t)p * (2u * n + 1u);
-  u32 *a = B.a + 8ull * (size_t)p * n, *b = B.b + 8ull * (size_t)p * n, *cg = B.cg + 8ull * (size_t)p * n, *hf = B.hf + 8ull * (size_t)p * n;
-  u32 *js = B.jsc + 8ull * (size_t)p * (2u * n + 1u);
-  sc t_hat = sc_u32(0), yp = one, yip = one, tw = zz;
-  for (u32 i = 0; i < n; i++) {
-    const u32 bit = (v.v[i >> 5] >> (i & 31u)) & 1u;
-    const sc sL = ld_sc(slr + 8ull * i), sR = ld_sc(slr + 8ull * (n + i));
-    const sc l = addq(bit ? omz : mz, mulq(sL, x));                                   // aL - z + sL x
-    const sc r = addq(mulq(yp, addq(bit ? z : zm1, mulq(sR, x))), tw);                // y^i (aR + z + sR x) + z^2 2^i
-    t_hat = addq(t_hat, mulq(l, r));
-    st_sc(a + 8ull * i, l); st_sc(b + 8ull * i, r);
-    st_sc(cg + 8ull * i, one); st_sc(hf + 8ull * i, yip);
-    st_sc(js + 8ull * i, l); st_sc(js + 8ull * (n + i), mulq(r, yip));
-    yp = mulq(yp, y); yip = mulq(yip, yinv); tw = addq(tw, tw);
-  }
-  st_sc(js + 8ull * (2u * n), mulq(B.x_ip, t_hat));
   const sc tau1 = ld_sc(B.tau + 16ull * p), tau2 = ld_sc(B.tau + 16ull * p + 8), alpha = ld_sc(B.alpha + 8ull * p), rho = ld_sc(slr + 8ull * (2u * n));
-  const sc taux = addq(addq(mulq(tau2, mulq(x, x)), mulq(tau1, x)), mulq(zz, ld_sc(B.gammas + 8ull * p)));
+  const sc taux = addq(addq(mulq(tau2, mulq(x, x)), mulq(tau1, x)), mulq(mulq(z, z), ld_sc(B.gammas + 8ull * p)));
   const sc mu = addq(alpha, mulq(rho, x));
   u32 *res = B.res + 40ull * p;
-  st_sc(res, taux); st_sc(res + 8, mu); st_sc(res + 16, t_hat);
+  st_sc(res, taux); st_sc(res + 8, mu);
   // the Protocol-2 transcript starts here: "&" (its own empty seed) || "&" || str(x_ip) || "&" (inner_product_prover.py:60-63)
   for (u32 i = 0; i < B.ip_prefix_len; i++) tr[i] = B.ip_prefix[i];
   B.tr_len[p] = B.ip_prefix_len;
+}
+__global__ void __launch_bounds__(256) k_pv_final_wide(Batch B) {
+  __shared__ u32 s_v[256 * 8];
+  const u32 n = B.n, tid = threadIdx.x;
+  const u32 p = blockIdx.x * (256u / n) + tid / n, j = tid & (n - 1u);
+  const bool live = p < B.P;
+  const size_t pc = live ? p : 0;
+  const sc y_inv = ld_sc(B.chal + 32ull * pc + 24), z = ld_sc(B.chal + 32ull * pc + 8), x = ld_sc(B.chal + 32ull * pc + 16);
+  const sc v = ld_sc(B.values + 8ull * pc);
+  const sc one = sc_u32(1);
+  const sc yip = lane_product_scan(s_v, tid, j, n, j ? y_inv : one);             // y^-j
+  const sc yp = ld_sc(B.cg + 8ull * (pc * n + j));                               // y^j (k_pv_poly)
+  const u32 *slr = B.slr + 8ull * pc * (2u * n + 1u);
+  const u32 bit = (v.v[j >> 5] >> (j & 31u)) & 1u;
+  const sc sL = ld_sc(slr + 8ull * j), sR = ld_sc(slr + 8ull * (n + j));
+  const sc l = addq(bit ? subq(one, z) : negq(z), mulq(sL, x));                                          // aL - z + sL x
+  const sc r = addq(mulq(yp, addq(bit ? z : subq(z, one), mulq(sR, x))), mulq(mulq(z, z), sc_pow2(j)));   // y^j (aR + z + sR x) + z^2 2^j
+  const sc t_hat = lane_tree_sum(s_v, tid, j, n, mulq(l, r));
+  if (!live) return;
+  const size_t e = (size_t)p * n + j;
+  st_sc(B.a + 8ull * e, l); st_sc(B.b + 8ull * e, r);
+  st_sc(B.cg + 8ull * e, one); st_sc(B.hf + 8ull * e, yip);
+  u32 *js = B.jsc + 8ull * (size_t)p * (2u * n + 1u);
+  st_sc(js + 8ull * j, l); st_sc(js + 8ull * (n + j), mulq(r, yip));
+  if (j == 0u) {
+    st_sc(js + 8ull * (2u * n), mulq(B.x_ip, t_hat));
+    st_sc(B.res + 40ull * p + 16, t_hat);
+  }
 }
 
 // ---- one round of Protocol 2 (inner_product_prover.py:94-110) over the UNFOLDED generators ----------------------------------------------------
