@@ -287,9 +287,20 @@ def extra_c2(eng, world, rank, dev, d_pts, d_sc, n, dlog, G64):
             if j + 1 < reps:
                 eng.msm_dev_enqueue((j + 1) & 1, d_pts, d_sc, n)
             eng.msm_finish(j & 1)
-        return sync, (time.perf_counter() - t0) / reps
+        pipe2 = (time.perf_counter() - t0) / reps
+        # ... and with three (the engine's three asynchronous slots): at this size an MSM is a chain of a dozen short kernels, two chains do
+        # not fill the chip (the arithmetic of one MSM is ~75 us of the whole chip's issue slots)
+        eng.msm_dev_enqueue(0, d_pts, d_sc, n)
+        eng.msm_dev_enqueue(1, d_pts, d_sc, n)
+        t0 = time.perf_counter()
+        r3 = None
+        for j in range(reps):
+            if j + 2 < reps:
+                eng.msm_dev_enqueue((j + 2) % 3, d_pts, d_sc, n)
+            r3 = eng.msm_finish(j % 3)
+        return sync, pipe2, (time.perf_counter() - t0) / reps, r3
 
-    sync_s, pipe_s = measure()
+    sync_s, pipe_s, pipe3_s, got3 = measure()
     eng.profile(1)
     eng.profile_reset()
     for _ in range(10):
@@ -300,14 +311,13 @@ def extra_c2(eng, world, rank, dev, d_pts, d_sc, n, dlog, G64):
     acc_s = stage_ms.get("msm_accumulate", 0.0) / 1e3
     # the integer-issue figures, as for the headline: multiply-adds of the bucket additions (W windows x n mixed additions; the bucket
     # reduction's two GENERAL additions per bucket counted too, at 14/10.5 of a mixed one) against the chip's raw v_mad_u64_u32 rate.
-    # Geometry as csrc/msm_host.hpp pick_window_bits: from 15 360 to 2^17 pairs c = 15 as 17 windows, the last one unsigned with twice
-    # the buckets; c = 16, 16 windows, from 2^17
+    # Geometry as csrc/msm_host.hpp pick_window_bits: mixed window widths -- 256 // c windows of which the last 256 - (256 // c) c are
+    # c + 1 bits wide with twice the buckets -- with c = 12 up to 19 000 pairs, 13 up to 185 000; 16 windows of 16 bits beyond
     isa = isa_counts() or {}
     mads = isa.get("v_mad_u64_u32_per_madd") or 1055
-    if 15360 <= n < (1 << 17):
-        c_bits, W, buckets = 15, 17, 16 * (1 << 14) + (1 << 15)
-    else:
-        c_bits, W, buckets = 16, 16, 16 << 15
+    c_bits = 12 if n < 19000 else (13 if n < 185000 else 16)
+    W = 256 // c_bits
+    buckets = (W + (256 - W * c_bits)) << (c_bits - 1)
     mad_accum = W * n * mads
     mad_reduce = 2 * buckets * mads * 14.0 / MULS_PER_MADD
     red_s = stage_ms.get("msm_bucket_reduce", 0.0) / 1e3
@@ -319,13 +329,15 @@ def extra_c2(eng, world, rank, dev, d_pts, d_sc, n, dlog, G64):
            "work": "%d windows x n mixed additions (accumulation) + 2 x %d general additions (bucket reduction, 14 / 10.5 of a mixed one)" % (W, buckets),
            "frac_vs_raw_mad_accumulate_kernel": frac(mad_accum, acc_s), "frac_vs_raw_mad_reduction_stage": frac(mad_reduce, red_s),
            "frac_vs_raw_mad_one_at_a_time": frac(mad_accum + mad_reduce, sync_s), "frac_vs_raw_mad_two_in_flight": frac(mad_accum + mad_reduce, pipe_s),
+           "frac_vs_raw_mad_three_in_flight": frac(mad_accum + mad_reduce, pipe3_s),
            "frac_vs_raw_mad_accumulation_only_one_at_a_time": frac(mad_accum, sync_s),
-           "note": "at this size the bucket reduction (its bucket count does not depend on n) is about half as much arithmetic as the accumulation; "
-                   "stage 1 of it runs one wave per SIMD, the rest of a call is latency-bound chains (sort, segmented scan, the finish on quads, the "
-                   "host tail): DESIGN.md section 5"}
+           "note": "at this size one MSM's arithmetic is ~75 us of the whole chip's issue slots and its dozen kernels are a 0.22 ms chain of mostly "
+                   "latency-bound stages (sort, segmented scan, the reduction's finish on quads) plus the host tail: the more calls in flight, the "
+                   "closer to the arithmetic (DESIGN.md section 5)"}
     return {"metric": "Pippenger MSM scalar-point pairs/sec at n=2^16 (config C2)", "alu_roofline": alu, "value": n / pipe_s, "unit": "pairs/s", "n": n,
-            "ms_per_msm_two_in_flight": pipe_s * 1e3, "ms_per_msm_one_at_a_time": sync_s * 1e3, "pairs_per_s_one_at_a_time": n / sync_s,
-            "result_ok": bool(got == expect), "stage_ms_per_msm": stage_ms,
+            "ms_per_msm_two_in_flight": pipe_s * 1e3, "ms_per_msm_three_in_flight": pipe3_s * 1e3, "ms_per_msm_one_at_a_time": sync_s * 1e3,
+            "pairs_per_s_one_at_a_time": n / sync_s, "pairs_per_s_three_in_flight": n / pipe3_s,
+            "result_ok": bool(got == expect and got3 == expect), "stage_ms_per_msm": stage_ms,
             "roofline": {"bound": "hbm", "kernel": "k_accum_l0 (msm_accumulate)", "kernel_ms": acc_s * 1e3,
                          "achieved": ALGO_BYTES_PER_PAIR * n / acc_s / 1e9 if acc_s > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ALGO_BYTES_PER_PAIR * n / acc_s / 1e9 / HBM_PEAK_GBS if acc_s > 0 else None, "traffic": None,

@@ -119,7 +119,11 @@ int bpmi_sync(bpmi_ctx *ctx);
  *                  points that take DEVICE pointers (bpmi_msm_dev, the generators of bpmi_ipa_verify_dev and bpmi_rp_batch_verify_dev).
  *                  What fastecdsa's Point constructor does for the reference (reached from /root/reference/src/utils/utils.py:119-131).
  *                  Cost: one kernel behind the upload, no extra wait (profiles/r05_validate_points_cost.txt)
- *   "top_window_unsigned" window_bits = 15: 1 (default) 17 windows, the last one unsigned with twice the buckets; 0 the 18-window recoding
+ *   "mixed_windows" 1 (default): window bits c = 10 .. 14 as 256 / c windows of which the last 256 - (256 / c) c are c + 1 bits wide with twice
+ *                  the buckets -- the windows cover the 256 bit positions exactly: no carry window, no short top window (13 bits: 10 + 9
+ *                  windows) --, and the window table that goes with it (12 bits from 5 632 pairs, 13 from 19 000, 16 from 185 000);
+ *                  0: uniform windows and the earlier table
+ *   "top_window_unsigned" 1 (default): the same for window_bits = 15 (16 + 1 windows); 0: every width uniform, with its carry window
  *   "sort_inblock" 1 (default): up to 2^17 pairs the sort's second level handles partitions of any size in one block (two launches fewer)
  *   "reduce_fit"   1 (default): stage 1 of the bucket reduction gives every sum as many lanes (any number up to 64, not only powers of two)
  *                  as keep its waves within the chip's 1 024 SIMDs at one wave each; 0: round 4's rule (total buckets / 2^15 elements

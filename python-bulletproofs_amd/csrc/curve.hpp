@@ -313,6 +313,6 @@ BPMI_HD bool wire_point_valid(const u32 w[16]) {
 
 // bit offsets of the (<= 4) partial sums the bucket reduction leaves per window; top = 1: the LAST window was split at top_off instead
 // (MsmGeom.top2).  The round-5 fields default to "none", so code that fills nv / off only stays right.
-struct TailOffs { u32 nv; u32 off[4]; u32 top = 0; u32 top_off[4] = {0, 0, 0, 0}; };
+struct TailOffs { u32 nv; u32 off[4]; u32 top = 0; u32 top_off[4] = {0, 0, 0, 0}; };      // top: number of WIDE (c + 1 bit) windows at the top, split at top_off
 
 }  // namespace bpmi

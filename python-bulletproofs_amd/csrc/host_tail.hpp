@@ -175,8 +175,9 @@ static inline void tail_combine(uint8_t out[64], const bpmi::u32 *E, bpmi::u32 W
   pt acc;
   pt_set_inf(acc);
   for (int w = (int)W - 1; w >= 0; w--) {
-    int prev = (int)c;
-    const bpmi::u32 *offs = (to.top && w == (int)W - 1) ? to.top_off : to.off;      // (top2: the last window's own split offsets)
+    const bool wide = to.top && (bpmi::u32)w + to.top >= W;                          // (to.top = Wb: the last Wb windows are c + 1 bits wide)
+    int prev = (int)c + (wide ? 1 : 0);
+    const bpmi::u32 *offs = wide ? to.top_off : to.off;                              // ... and were split at their own bit offsets
     for (int v = (int)to.nv - 1; v >= 0; v--) {
       pt_dbl_run(acc, prev - (int)offs[v]);
       prev = (int)offs[v];

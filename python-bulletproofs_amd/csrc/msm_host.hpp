@@ -11,15 +11,25 @@ static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; 
 // Besides the usual bucket-count trade-off, windows whose TOP window holds only a few
 // bits (255 mod c small: c = 15, 14, 12, 11) concentrate a whole window's digits in a
 // handful of buckets, so c in {8, 16} (top window 7, 15 bits) are preferred.
+// one MSM at a time: the one-block-per-window kernel up to here when the pipeline has mixed window widths (5 120 pairs: 0.202 ms against
+// 0.208; 6 144: 0.214 against 0.207; 8 192: 0.245 against 0.208), up to MID_NMAX otherwise
+#define MID_SINGLE_MAX_MIXED 5632u
 static u32 pick_window_bits(const bpmi_ctx *ctx, uint64_t n) {
   if (ctx->opt_c >= 2 && ctx->opt_c <= 16) return (u32)ctx->opt_c;
-  // Round 5 (tools/r05_ab_mid.py, profiles/r05_window_table_sweep.txt): c = 15 with the unsigned last window from 15 360 to 2^17 pairs --
-  // half the buckets of c = 16, and with 12-lane sums the reduction's first stage fits the SIMDs at one wave each (0.279-0.330 ms
-  // against 0.303-0.338 for the round-4 table of c = 12 / 13 / 16 there); c = 16 from 2^17 (a tie up to ~3 x 10^5, ahead beyond);
-  // c = 12 between 10 240 and 15 360 (0.263 against 0.296 at 12 288); c = 8 below (round 3: profiles/r03_tune_msm_small_window_table.txt)
-  if (n >= (1u << 17)) return 16;
-  if (n >= 15360u) return ctx->opt_top2 ? 15 : 16;
-  if (n >= 10240u) return 12;
+  // Round 5, with mixed window widths (MsmGeom.top2: no carry window and no short top window at ANY width; tools/r05_exp_mixed.sh,
+  // profiles/r05_mixed_window_widths_sweep.txt): 12 bits (17 + 4 windows, 51 k buckets) from the end of the one-block kernel's range
+  // to 19 000 pairs, 13 bits (10 + 9 windows, 115 k buckets) to 185 000 -- 2^16: 0.272 ms against 0.299 for c = 15 and 0.311 for c = 16 --,
+  // 16 bits beyond (14 / 15 tie with it around 2 x 10^5 and lose above).  Without them: the table of the first half of the round
+  // (c = 15 with its one wide window from 15 360 to 2^17, 12 from 10 240, 8 below; profiles/r05_window_table_sweep.txt)
+  if (ctx->opt_mixed && ctx->opt_top2) {
+    if (n >= 185000u) return 16;
+    if (n >= 19000u) return 13;
+    if (n >= MID_SINGLE_MAX_MIXED) return 12;
+  } else {
+    if (n >= (1u << 17)) return 16;
+    if (n >= 15360u) return ctx->opt_top2 ? 15 : 16;
+    if (n >= 10240u) return 12;
+  }
   if (n >= (1u << 10)) return 8;
   u32 lg = 0;
   while ((1ull << (lg + 1)) <= n) lg++;
@@ -189,7 +199,8 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, int slot, const Segs &segs_in, u
   // (measured, profiles/r04_mid_kernel_latency.txt: one MSM at a time it wins from ~2 500 pairs -- 0.18 ms against 0.21 at 3 000, 0.25
   // against 0.29 at 8 193 --, a PAIR in one launch from ~1 500 pairs each: 0.29 ms against 0.44 for two lanes of the pipeline at 4 097)
   const uint64_t mid_single = ctx->opt_mid_single > 0 ? (uint64_t)ctx->opt_mid_single : MID_SINGLE_MIN_DEFAULT;
-  const bool mid = ctx->opt_mid_single >= 0 && n >= mid_single && n <= MID_NMAX && ctx->opt_c == 0 && wcount == 0 && ctx->opt_glv <= 0;
+  const uint64_t mid_single_max = (ctx->opt_mixed && ctx->opt_top2 && ctx->opt_mid_single == 0) ? MID_SINGLE_MAX_MIXED - 1u : MID_NMAX;
+  const bool mid = ctx->opt_mid_single >= 0 && n >= mid_single && n <= mid_single_max && ctx->opt_c == 0 && wcount == 0 && ctx->opt_glv <= 0;
   const bool small = !mid && n <= small_max && ctx->opt_c == 0 && wcount == 0;
   // GLV (option "glv" = 1; OFF by default): 2n virtual pairs with 128-bit scalars (+ 1 bit of signed-digit carry) instead of n
   // with 255-bit ones: as many bucket additions, half the windows.  Measured (profiles/r03_glv_msm_on_off.txt) it LOSES at every
@@ -202,9 +213,13 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, int slot, const Segs &segs_in, u
   const bool glv = ctx->opt_glv > 0 && !small && wcount == 0 && n >= 2 && 2 * n <= (1ull << 23);
   if (glv) g.n = (u32)(2 * n);
   g.c = mid ? MID_C : (small ? SMALL_C : pick_window_bits(ctx, n));
-  // c = 15 (255 = 17 c): 17 windows, the last one unsigned with 2B buckets, instead of 18 whose last holds one bucket of n / 2 carries
-  g.top2 = (g.c == 15u && !glv && !wcount && !mid && !small && ctx->opt_top2) ? 1u : 0u;
-  g.W = wcount ? wcount : (glv ? 128u / g.c + 1u : (g.top2 ? 255u / g.c : 255u / g.c + 1u));
+  // Mixed window widths (round 5; MsmGeom.top2 = Wb): W = 256 / c windows of which the last Wb = 256 - W c are c + 1 bits wide with 2B
+  // buckets, so the windows cover the 256 bit positions exactly -- no carry window, no short top window.  c = 15: 16 + 1 (the
+  // "unsigned last window" of the first half of the round is this case), c = 14: 14 + 4, c = 13: 10 + 9, c = 12: 17 + 4, c = 11: 20 + 3,
+  // c = 10: 19 + 6; c = 16 is uniform by itself (16 windows of 16 bits).  LDS-sort path only (c >= 10), never for window groups / GLV.
+  g.top2 = 0;
+  if (g.c >= 10u && g.c <= 15u && !glv && !wcount && !mid && !small && ctx->opt_top2 && (g.c == 15u || ctx->opt_mixed)) g.top2 = 256u - (256u / g.c) * g.c;
+  g.W = wcount ? wcount : (glv ? 128u / g.c + 1u : (g.top2 ? 256u / g.c : 255u / g.c + 1u));
   g.w0 = w0;
   g.B = 1u << (g.c - 1);
   g.G = (g.W + g.top2) * g.B;
@@ -444,16 +459,16 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, int slot, const Segs &segs_in, u
       // best of 4 / 8 / 12 / 16 there; fewer buckets -- smaller c, a window group of a split MSM -- get shorter chains
       // instead of idle SIMDs); stage 2 + the finish are pure latency: one element per lane, 16-lane butterflies, one launch
       const u32 Wr = g.W - g.top2;                       // windows with B buckets
-      // the unsigned last window (top2): ONE array of 2B buckets behind the others, split like a window of c + 1 bits (its D sums fit the
-      // per-window slot of w.D: 2^((c+1)/2) + 2^(c/2) records)
+      // the wide windows (mixed widths, g.top2 of them): arrays of 2B buckets behind the others, split like windows of c + 1 bits (their D sums
+      // fit the per-window slot of w.D: 2^((c+1)/2) + 2^(c/2) records)
       const u32 Bt = 2u * g.B, s0t = (g.c + 1u) / 2u, N0t = (1u << s0t) - 1u, N1t = Bt >> s0t;
       const u32 t0t = (s0t + 1u) / 2u, t1t = (msb_index(N1t) + 1u) / 2u;
-      const u32 d_top = Wr * stride1;                    // first D record of the top window
+      const u32 d_top = Wr * stride1, stride1t = N0t + N1t;      // first D record of the wide windows, and their records per window
       auto stage1 = [&](u32 epl, DigitJobs &j) -> u32 {  // the jobs for `epl` elements per lane; returns their waves
         j = digit_jobs2(Wr, 0, g.B, g.B, s0, 0, stride1, epl);
         u32 waves = digit_job_waves(j, 0) + digit_job_waves(j, 1);
         if (g.top2) {
-          DigitJobs jt = digit_jobs2(1, Wr * g.B, 0, Bt, s0t, d_top, 0, epl);
+          DigitJobs jt = digit_jobs2(g.top2, Wr * g.B, Bt, Bt, s0t, d_top, stride1t, epl);
           waves += digit_job_waves(jt, 0) + digit_job_waves(jt, 1);
           j = digit_jobs_concat(j, jt);
         }
@@ -478,10 +493,10 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, int slot, const Segs &segs_in, u
       memset(&j2top, 0, sizeof(j2top));
       to.nv = 4; to.off[0] = 0; to.off[1] = t0; to.off[2] = s0; to.off[3] = s0 + t1;
       if (g.top2) {
-        DigitJobs jta = digit_jobs2(1, d_top, 0, N0t, t0t, 0, 64, 1);
-        DigitJobs jtb = digit_jobs2(1, d_top + N0t, 0, N1t, t1t, 0, 64, 1);
+        DigitJobs jta = digit_jobs2(g.top2, d_top, stride1t, N0t, t0t, 0, 64, 1);
+        DigitJobs jtb = digit_jobs2(g.top2, d_top + N0t, stride1t, N1t, t1t, 0, 64, 1);
         j2top = digit_jobs_concat(jta, jtb);
-        to.top = 1; to.top_off[0] = 0; to.top_off[1] = t0t; to.top_off[2] = s0t; to.top_off[3] = s0t + t1t;
+        to.top = g.top2; to.top_off[0] = 0; to.top_off[1] = t0t; to.top_off[2] = s0t; to.top_off[3] = s0t + t1t;
       }
       j1.prio = g.prio;
       hipLaunchKernelGGL(k_digit_sums, dim3(j1.j[j1.njobs - 1].blk0 + digit_job_blocks(j1, j1.njobs - 1)), dim3(256), 0, st, w.buckets, w.D, j1);

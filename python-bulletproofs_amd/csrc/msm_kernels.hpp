@@ -16,8 +16,11 @@ struct MsmGeom {
   u32 nv;      // partial sums per window that the bucket reduction hands to the tail (1 or 4)
   u32 prio;    // 1: every kernel but the accumulation raises its waves' issue priority (see raise_priority)
   u32 fuse;    // 1: k_accum_l0 folds the partial records of a wave's 64 chunks itself (two records per WAVE go to k_segscan, not two per thread)
-  u32 top2;    // 1 (c = 15 only: 255 = 17 c): the LAST window is not recoded -- its digit t in [0, 2B] is kept unsigned and owns 2B buckets
-               // (keys [(W-1) B, (W+1) B)), so there is no carry window: W = 255 / c windows, G = (W + 1) B
+  u32 top2;    // Wb, the number of WIDE windows (round 5): the last Wb of the W windows have c + 1 bits and 2B buckets each, chosen so that
+               // (W - Wb) c + Wb (c + 1) = 256 -- the windows cover exactly the 256 bit positions, the top bit of a folded scalar (< 2^255)
+               // is 0, so the last window's digit never exceeds its 2^c and there is NO carry window and no short one (a window of a few
+               // bits is one partition of n entries for the sort and a handful of giant buckets for the accumulation).  c = 15: 16 + 1
+               // windows; c = 13: 10 + 9; c = 12: 17 + 4.  Keys of window w start at (w + max(0, w - (W - Wb))) B;  G = (W + Wb) B.  0: uniform
   u32 inblock; // 1 (n <= 2^17): k_fine_sort_part sorts a partition of ANY size itself (a heavy one without the LDS staging buffer);
                // the two tile kernels for heavy partitions are not launched
 };
@@ -27,6 +30,9 @@ struct MsmGeom {
 // expected to bring the lane behind them to its own accumulation sooner; measured, two MSMs in flight get 2.6 % (2^20) to
 // 6 % (2^16) SLOWER -- the accumulation's waves lose more than the chains gain.
 __device__ __forceinline__ void raise_priority(u32 on) { if (on) __builtin_amdgcn_s_setprio(3); }
+// mixed window widths (MsmGeom.top2 = Wb): is window w one of the wide ones, and the first key / partition of window w in units of B / (B >> 8)
+__device__ __forceinline__ u32 geom_wide(const MsmGeom &g, u32 w) { return (g.top2 && w + g.top2 >= g.W) ? 1u : 0u; }
+__device__ __forceinline__ u32 geom_slot(const MsmGeom &g, u32 w) { return (g.top2 && w + g.top2 > g.W) ? 2u * w + g.top2 - g.W : w; }   // w + max(0, w - (W - Wb))
 
 // Signed-digit recoding of scalar i: calls f(w, b, sign) for every window, b = |digit|
 // in [0, B] (0 = nothing to add), sign = 1 when the NEGATED point is added.
@@ -55,16 +61,16 @@ __device__ __forceinline__ bool for_each_digit_raw(const Segs &segs, const MsmGe
   sc s;
   const bool neg = load_digit_source(s, segs, i);
   u32 carry = 0;
-  const u32 mask = (1u << g.c) - 1u;
   const u32 wend = g.w0 + g.W;
   for (u32 w = 0; w < wend; w++) {
-    const u32 t = (s.v[0] & mask) + carry;
+    const u32 wd = g.c + geom_wide(g, w);               // (mixed widths only with w0 = 0)
+    const u32 t = (s.v[0] & ((1u << wd) - 1u)) + carry;
 #pragma unroll
-    for (int k = 0; k < 7; k++) s.v[k] = (u32)((((u64)s.v[k + 1] << 32) | s.v[k]) >> g.c);
-    s.v[7] >>= g.c;
+    for (int k = 0; k < 7; k++) s.v[k] = (u32)((((u64)s.v[k + 1] << 32) | s.v[k]) >> wd);
+    s.v[7] >>= wd;
     u32 b, sign;
-    if (t > g.B && !(g.top2 && w + 1u == wend)) { b = (1u << g.c) - t; sign = 1; carry = 1; }
-    else { b = t; sign = 0; carry = 0; }              // (top2: the last window keeps t in [0, 2B] as it is)
+    if (t > (1u << (wd - 1u))) { b = (1u << wd) - t; sign = 1; carry = 1; }
+    else { b = t; sign = 0; carry = 0; }              // (mixed widths: the last window's t is at most its 2^(wd - 1): never a carry out)
     if (w >= g.w0) f(w - g.w0, b, b ? sign : 0u);
   }
   return neg;
@@ -74,17 +80,17 @@ __device__ __forceinline__ void for_each_digit(const Segs &segs, const MsmGeom &
   sc s;
   const bool neg = load_digit_source(s, segs, i);
   u32 carry = 0;
-  const u32 mask = (1u << g.c) - 1u;
   const u32 wend = g.w0 + g.W;
   for (u32 w = 0; w < wend; w++) {
-    const u32 t = (s.v[0] & mask) + carry;
-    // shift the 256-bit register right by c (static register indexing)
+    const u32 wd = g.c + geom_wide(g, w);
+    const u32 t = (s.v[0] & ((1u << wd) - 1u)) + carry;
+    // shift the 256-bit register right by the window's width (static register indexing)
 #pragma unroll
-    for (int k = 0; k < 7; k++) s.v[k] = (u32)((((u64)s.v[k + 1] << 32) | s.v[k]) >> g.c);
-    s.v[7] >>= g.c;
+    for (int k = 0; k < 7; k++) s.v[k] = (u32)((((u64)s.v[k + 1] << 32) | s.v[k]) >> wd);
+    s.v[7] >>= wd;
     u32 b, sign;
-    if (t > g.B && !(g.top2 && w + 1u == wend)) { b = (1u << g.c) - t; sign = 1; carry = 1; }
-    else { b = t; sign = 0; carry = 0; }              // (top2: the last window keeps t in [0, 2B] as it is)
+    if (t > (1u << (wd - 1u))) { b = (1u << wd) - t; sign = 1; carry = 1; }
+    else { b = t; sign = 0; carry = 0; }
     if (w >= g.w0) f(w - g.w0, b, b ? (sign ^ (u32)neg) : 0u);      // lower windows only feed the carry
   }
 }
@@ -169,7 +175,7 @@ __global__ void __launch_bounds__(1024) k_coarse_hist(Segs segs, MsmGeom g, u32 
   for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < g.n; i += stride) {
     const bool neg = for_each_digit_raw(segs, g, i, [&](u32 w, u32 b, u32 dsign) {
       dig16[(u64)w * g.n + i] = (unsigned short)(b ? ((b - 1u) | (dsign << 15)) : DIG_NONE);
-      if (b) atomicAdd(&lh[w * Bc + ((b - 1u) >> 8)], 1u);
+      if (b) atomicAdd(&lh[geom_slot(g, w) * Bc + ((b - 1u) >> 8)], 1u);
     });
     negs[i] = neg ? 1 : 0;
   }
@@ -245,7 +251,7 @@ __global__ void __launch_bounds__(1024) k_partition(MsmGeom g, u32 P, u32 TS, co
   __shared__ u32 cnt[128], excl[128], delta[128];
   __shared__ u32 s_out[PT_MAX];
   const u32 w = blockIdx.y, tid = threadIdx.x;
-  const u32 Bc0 = g.B >> 8, Bc = (g.top2 && w + 1u == g.W) ? 2u * Bc0 : Bc0;       // partitions of this window (top2: the last one owns 2B buckets; <= 128)
+  const u32 Bc0 = g.B >> 8, Bc = Bc0 << geom_wide(g, w), pbase = geom_slot(g, w) * Bc0;       // partitions of this window (a wide one owns 2B buckets; <= 128) and the first of them
   const u32 lin = blockIdx.y * gridDim.x + blockIdx.x, nblk = gridDim.x * gridDim.y;
   if (!g.inblock) for (u32 p = lin; p < P; p += nblk) {
     if (coarse_off[p + 1] - coarse_off[p] > FINE_CAP) {        // block-uniform
@@ -278,7 +284,7 @@ __global__ void __launch_bounds__(1024) k_partition(MsmGeom g, u32 P, u32 TS, co
     const u32 start = excl[tid] - c;
     excl[tid] = start;
     cnt[tid] = start;                                          // LDS write cursor of the partition
-    if (c) delta[tid] = atomicAdd(&coarse_cursor[w * Bc0 + tid], c) - start;
+    if (c) delta[tid] = atomicAdd(&coarse_cursor[pbase + tid], c) - start;
   }
   __syncthreads();
   for (u32 i = i0 + tid; i < i1; i += blockDim.x) {
@@ -956,13 +962,13 @@ __global__ void __launch_bounds__(256) k_digit_sums(const u32 *__restrict__ X, u
 // elements of sum j + 1 of the array's digit job with a butterfly, parks it in LDS, and the first 16 lanes turn the (<= 16)
 // sums into sum_d d * X[d]: inclusive suffix scan (4 steps), then the sum of all suffixes (4 steps).  E[a][r] out.  Saves a launch and the trip of 64 records per window
 // through HBM on a path that is nothing but latency.
-// (top2: window `top_w` has 2B buckets and its own job set `jtop`, its arrays numbered from 0; top_w = ~0: none)
+// (mixed widths: the windows from `top_w` on have 2B buckets and their own job set `jtop`, their arrays numbered from 0; top_w = ~0: none)
 __global__ void __launch_bounds__(256) k_digit_final(const u32 *__restrict__ X, u32 *__restrict__ Eout, DigitJobs jobs, DigitJobs jtop, u32 top_w) {
   raise_priority(jobs.prio);
   __shared__ u32 s_val[16 * LDS_STRIDE];
   const u32 r = blockIdx.x & 3u, tid = threadIdx.x;
-  const bool is_top = (blockIdx.x >> 2) == top_w;
-  const u32 a = is_top ? 0u : (blockIdx.x >> 2);
+  const bool is_top = (blockIdx.x >> 2) >= top_w;
+  const u32 a = is_top ? (blockIdx.x >> 2) - top_w : (blockIdx.x >> 2);
   const DigitJob J = is_top ? jtop.j[r] : jobs.j[r];
   const u32 idx = (tid >> 4) + 1u, l = tid & 15u;
   xyzz acc;
@@ -1112,8 +1118,8 @@ __device__ __forceinline__ void quad_add(fe &a, const fe &b, u32 q) {
 __global__ void __launch_bounds__(1024) k_digit_final_quad(const u32 *__restrict__ X, u32 *__restrict__ Eout, DigitJobs jobs, DigitJobs jtop, u32 top_w) {
   __shared__ u32 s_val[16 * XYZZ_WORDS];
   const u32 r = blockIdx.x & 3u, tid = threadIdx.x;
-  const bool is_top = (blockIdx.x >> 2) == top_w;
-  const u32 a_idx = is_top ? 0u : (blockIdx.x >> 2);
+  const bool is_top = (blockIdx.x >> 2) >= top_w;
+  const u32 a_idx = is_top ? (blockIdx.x >> 2) - top_w : (blockIdx.x >> 2);
   const DigitJob J = is_top ? jtop.j[r] : jobs.j[r];
   const u32 wave = tid >> 6, lane = tid & 63u, e = lane >> 2, q = lane & 3u;
   const u32 idx = wave + 1u;
@@ -1180,8 +1186,8 @@ template <int MODE> __global__ void __launch_bounds__(256) k_digit_final_spread(
   raise_priority(jobs.prio);
   const u32 gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);            // blocks of one wave or of four
   const u32 arr = MODE == 2 ? gw : gw >> 4, wave = MODE == 2 ? 0u : gw & 15u, r = arr & 3u;
-  const bool is_top = (arr >> 2) == top_w;
-  const u32 a_idx = is_top ? 0u : (arr >> 2);
+  const bool is_top = (arr >> 2) >= top_w;
+  const u32 a_idx = is_top ? (arr >> 2) - top_w : (arr >> 2);
   const DigitJob J = is_top ? jtop.j[r] : jobs.j[r];
   const u32 lane = threadIdx.x & 63u, e = lane >> 2, q = lane & 3u;
   const u32 idx = wave + 1u;
@@ -1594,19 +1600,20 @@ __global__ void __launch_bounds__(MID_THREADS) k_msm_mid(MidPair p) {
 
 // ---- tail: result = sum_w 2^(c w) sum_v 2^(off[v]) E[w][v], to canonical affine -------------
 BPMI_HD void msm_tail_combine(u32 out_words[16], const u32 *E, u32 W, u32 c, const TailOffs &to) {
-  // ONE Horner chain over bit positions: E[w][v] carries weight 2^(c*w + off[v]), so walking from the top bit down costs
-  // c*W doublings in total.  A flat loop over positions with the (<= 4) offsets in scalars: no indexed private array, the
-  // accumulator stays in registers.
+  // ONE Horner chain over bit positions: E[w][v] carries weight 2^(start of window w + off[v]), so walking from the top bit down
+  // costs one doubling per bit position in total.  A flat loop over positions with the (<= 4) offsets in scalars: no indexed
+  // private array, the accumulator stays in registers.  (to.top = Wb: the last Wb windows are c + 1 bits wide and were split at
+  // their own bit offsets top_off.)
   const u32 o0 = to.off[0], o1 = to.nv > 1 ? to.off[1] : 0xFFFFFFFFu, o2 = to.nv > 2 ? to.off[2] : 0xFFFFFFFFu,
             o3 = to.nv > 3 ? to.off[3] : 0xFFFFFFFFu;
   xyzz acc;
   xyzz_set_inf(acc);
-  u32 w = W, r = 0;                                   // position = w * c + r
-  for (u32 pos = W * c; pos-- > 0;) {
-    if (r == 0) { w--; r = c; }
+  u32 w = W, r = 0;                                   // position = start of window w + r
+  for (u32 pos = W * c + to.top; pos-- > 0;) {
+    if (r == 0) { w--; r = c + ((to.top && w + to.top >= W) ? 1u : 0u); }
     r--;
     xyzz_dbl(acc, acc);
-    const bool tw = to.top && w + 1u == W;            // the unsigned last window (top2) was split at its own bit offsets
+    const bool tw = to.top && w + to.top >= W;        // a wide window
     const u32 v = tw ? (r == to.top_off[0] ? 0u : r == to.top_off[1] ? 1u : r == to.top_off[2] ? 2u : r == to.top_off[3] ? 3u : 4u)
                      : (r == o0 ? 0u : r == o1 ? 1u : r == o2 ? 2u : r == o3 ? 3u : 4u);
     if (v < 4u) {

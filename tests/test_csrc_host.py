@@ -464,12 +464,15 @@ def test_host_tail_field_arithmetic(shim):
 
 
 @pytest.mark.parametrize("c,nv,off,top,top_off", [(16, 4, (0, 4, 8, 12), 0, (0, 0, 0, 0)), (15, 4, (0, 4, 7, 11), 1, (0, 4, 8, 12)), (13, 4, (0, 3, 6, 9), 0, (0, 0, 0, 0)),
+                                                  (13, 4, (0, 3, 6, 9), 9, (0, 4, 7, 10)), (12, 4, (0, 3, 6, 9), 4, (0, 3, 6, 9)), (10, 4, (0, 3, 5, 7), 6, (0, 3, 5, 8)),
                                                   (8, 1, (0, 0, 0, 0), 0, (0, 0, 0, 0)), (7, 1, (0, 0, 0, 0), 0, (0, 0, 0, 0))])
 def test_host_tail_combines_the_window_sums(shim, c, nv, off, top, top_off):
-    """tail_combine (the MSM's Horner chain over bit positions, on the host): sum_w 2^(c w) sum_v 2^(off_v) E[w][v] for window sums in
-    projective form with random scalings, identities among them, the unsigned last window's own offsets (c = 15), against the
-    oracle's affine arithmetic."""
-    W = (255 // c) if top else 255 // c + 1
+    """tail_combine (the MSM's Horner chain over bit positions, on the host): sum_w 2^(start of window w) sum_v 2^(off_v) E[w][v] for
+    window sums in projective form with random scalings, identities among them, against the oracle's affine arithmetic.  top = the
+    number of WIDE windows at the top (mixed widths: 256 // c windows, the last `top` of them c + 1 bits wide and split at their
+    own offsets; 1 at c = 15 is the round's first form of it)."""
+    W = (256 // c) if top else 255 // c + 1
+    assert not top or (W - top) * c + top * (c + 1) == 256
     rnd = random.Random(c * 100 + nv)
     base = gens(7, seed(3))
     pts, zs, want = [], [], INF
@@ -482,8 +485,9 @@ def test_host_tail_combines_the_window_sums(shim, c, nv, off, top, top_off):
             pts.append(pt)
             zs.append(z)
             if kind > 1:
-                o = (top_off if (top and w == W - 1) else off)[v]
-                want = want + pt * (1 << (c * w + o))
+                wide = top and w >= W - top
+                o = (top_off if wide else off)[v]
+                want = want + pt * (1 << (c * w + max(0, w - (W - top)) * (1 if top else 0) + o))
     out = ctypes.create_string_buffer(64)
     o4, t4 = (ctypes.c_uint32 * 4)(*off), (ctypes.c_uint32 * 4)(*top_off)
     shim.t_host_tail(b"".join(point_to_le64(p) for p in pts), b"".join(z.to_bytes(32, "little") for z in zs), W, c, nv, o4, top, t4, out)

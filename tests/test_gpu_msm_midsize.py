@@ -12,7 +12,7 @@ from oracle import cbind
 
 pytestmark = pytest.mark.gpu
 
-R5_DEFAULTS = {"top_window_unsigned": 1, "sort_inblock": 1, "segscan_fused": 0, "hist_scan_fused": 0, "final_spread": 3, "reduce_fit": 1}
+R5_DEFAULTS = {"top_window_unsigned": 1, "sort_inblock": 1, "segscan_fused": 0, "hist_scan_fused": 0, "final_spread": 3, "reduce_fit": 1, "mixed_windows": 1}
 
 
 @pytest.fixture(scope="module")
@@ -136,6 +136,66 @@ def test_msm_c15_unsigned_last_window(gp, shape, n):
         _reset(eng)
 
 
+def _digit_edge_scalars(c, n, rnd):
+    """Scalars assembled window by window (the mixed layout of c) from the digits at the edges of the signed recoding: 0, 1, B - 1, B,
+    B + 1, all ones -- for the narrow and for the wide windows -- and random ones; every second one negated."""
+    W = 256 // c
+    Wb = 256 - W * c
+    widths = [c] * (W - Wb) + [c + 1] * Wb
+    out = []
+    for i in range(n):
+        s, pos = 0, 0
+        for wd in widths:
+            B = 1 << (wd - 1)
+            s |= rnd.choice((0, 1, B - 1, B, B + 1, (1 << wd) - 1, rnd.randrange(1 << wd), rnd.randrange(1 << wd))) << pos
+            pos += wd
+        s %= Q
+        out.append(s if i % 2 else (Q - s) % Q)
+    return out
+
+
+@pytest.mark.parametrize("c", [10, 11, 12, 13, 14, 15])
+@pytest.mark.parametrize("shape", ["uniform", "digit_edges", "top_window_edges", "all_same", "bits_and_blinding", "top_heavy"])
+@pytest.mark.parametrize("n", [12000, 40000, 140000])
+def test_msm_mixed_window_widths(gp, shape, n, c):
+    """Window bits c as 256 // c windows of which the last 256 - (256 // c) c are c + 1 bits wide with twice the buckets (no carry
+    window, no short top window): against the oracle and against the uniform recoding with its carry window, under both tails,
+    with the unfused scan and with short chunks; every stage-1 group size of the wide windows' own job set."""
+    eng = gp.engine()
+    pts, _ = gp.rand_points(1000, 53 + c)
+    pts = (pts * (n // 1000 + 1))[:n]
+    es = _digit_edge_scalars(c, n, random.Random(n * 5 + c)) if shape == "digit_edges" else _scalars(shape, n, random.Random(n * 5 + c))
+    pb, sb = cbind.pack_points(pts), cbind.pack_scalars(es)
+    want = cbind.msm_bytes(pb, sb, n)
+    try:
+        eng.set_option("window_bits", c)
+        for mixed in (1, 0):
+            eng.set_option("mixed_windows", mixed)
+            for tail in (2, 1):
+                eng.set_option("tail", tail)
+                assert eng.msm_bytes(pb, sb, n) == want, (mixed, tail)
+        eng.set_option("mixed_windows", 1)
+        eng.set_option("tail", 0)
+        eng.set_option("fused_scan", 0)
+        assert eng.msm_bytes(pb, sb, n) == want
+        eng.set_option("fused_scan", 1)
+        eng.set_option("chunk", 3)
+        assert eng.msm_bytes(pb, sb, n) == want
+        eng.set_option("chunk", 0)
+        for epl in (1, 5, 11, 33):
+            eng.set_option("reduce_epl", epl)
+            assert eng.msm_bytes(pb, sb, n) == want, epl
+        eng.set_option("reduce_epl", 0)
+        for fs in (0, 1, 2):
+            eng.set_option("final_spread", fs)
+            assert eng.msm_bytes(pb, sb, n) == want, fs
+        eng.set_option("quad_final", 0)
+        assert eng.msm_bytes(pb, sb, n) == want
+    finally:
+        eng.set_option("quad_final", 1)
+        _reset(eng)
+
+
 @pytest.mark.parametrize("c", [12, 13, 15, 16])
 @pytest.mark.parametrize("shape", ["all_same", "two_values", "bits01", "bits_and_blinding", "small_range", "top_heavy"])
 @pytest.mark.parametrize("n", [30000, 131072, 131073])
@@ -216,7 +276,7 @@ def test_msm_default_geometry_sizes_around_the_switches(gp):
     eng = gp.engine()
     pts, _ = gp.rand_points(2048, 9)
     edge = [0, 1, Q - 1, (Q - 1) // 2, (Q + 1) // 2, 1 << 254, (1 << 255) % Q, (1 << 15) - 1, 1 << 14, (0x7FFF << 240) % Q]
-    for n in (15359, 15360, 20479, 20480, 32767, 32768, 65535, 65536, 65537, 131071, 131072, 131073, 200000, 262144, 262145):
+    for n in (5631, 5632, 8448, 8449, 15359, 15360, 18999, 19000, 32767, 32768, 65535, 65536, 65537, 131071, 131072, 131073, 184999, 185000, 200000, 262144, 262145):
         rnd = random.Random(n)
         es = [edge[rnd.randrange(len(edge))] if i % 7 == 0 else rnd.randrange(Q) for i in range(n)]
         p = (pts * (n // 2048 + 1))[:n]

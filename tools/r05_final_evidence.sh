@@ -16,8 +16,8 @@ for k in (1, 2, 3):
         rows.append("run %d: unreadable (%s)" % (k, e)); continue
     ex = d["extra"]
     c5, c3, c2 = ex["C5_batch_verify"], ex["C3_ipa_prover"], ex["C2_msm_2e16"]
-    rows.append("run %d (--steps 20 --warmup 5): %.4f ms/step  %.4g pairs/s  ok %s | C2 %.4f one at a time %.4f two in flight | C3 %.4f s (fixed generators %s) | C4 prove %.5f s | C5 %.4g verifies/s (v2 %.4g; one at a time %.3f / %.3f ms) | batch prover %.4g proofs/s (device %.4g)" % (
-        k, d["ms_per_step"], d["value"], d["result_ok"], c2.get("ms_per_msm_one_at_a_time", -1), c2.get("ms_per_msm_two_in_flight", -1), c3["value"],
+    rows.append("run %d (--steps 20 --warmup 5): %.4f ms/step  %.4g pairs/s  ok %s | C2 %.4f one at a time %.4f two in flight %.4f three | C3 %.4f s (fixed generators %s) | C4 prove %.5f s | C5 %.4g verifies/s (v2 %.4g; one at a time %.3f / %.3f ms) | batch prover %.4g proofs/s (device %.4g)" % (
+        k, d["ms_per_step"], d["value"], d["result_ok"], c2.get("ms_per_msm_one_at_a_time", -1), c2.get("ms_per_msm_two_in_flight", -1), c2.get("ms_per_msm_three_in_flight", -1), c3["value"],
         (c3.get("with_fixed_generators") or {}).get("seconds"), ex["C4_aggregated_range_proof"]["value"], c5["value"], c5["wire_format_2"]["value"],
         c5.get("batch_latency_s", -1) * 1e3, c5["wire_format_2"].get("batch_latency_s", -1) * 1e3, c5["batch_prover"]["proves_per_s"], c5["batch_prover"]["proves_per_s_device_time"]))
 try:
