@@ -50,6 +50,10 @@ while time.time() - t0 < budget:
         n = rnd.randrange(1 << 19, (1 << 19) + 70000)   # 16384-scalar level-A tiles, L = 64
     elif r < 0.06:
         n = rnd.randrange((1 << 17) - 3000, (1 << 17) + 3000)      # either side of the in-block sort's bound
+    elif r < 0.12:
+        n = rnd.randrange(5000, 30000)             # the one-block kernel's end, 12-bit and 13-bit mixed-width windows (round 5)
+    elif r < 0.13:
+        n = rnd.randrange(180000, 190000)          # 13 / 16 bits
     pts = [rnd.choice(pool) for _ in range(n)]
     shape = rnd.randrange(6)
     if shape == 1:
@@ -74,7 +78,7 @@ while time.time() - t0 < budget:
             "hist_scan_fused": rnd.choice((0, 0, 1)), "final_spread": rnd.choice((3, 3, 2, 1, 0)), "reduce_fit": rnd.choice((1, 1, 0)), "mixed_windows": rnd.choice((1, 1, 0)),
             "reduce_epl": rnd.choice((0, 0, 0, 1, 3, 7, 11, 13, 20))}
     if n > 20000:
-        opts["window_bits"] = rnd.choice((0, 0, 13, 15, 15, 16))
+        opts["window_bits"] = rnd.choice((0, 0, 0, 10, 11, 12, 13, 13, 14, 15, 16))       # (10 .. 15: mixed window widths unless mixed_windows drew 0)
         opts["chunk"] = rnd.choice((0, 0, 16, 64))
     for k, v in opts.items():
         eng.set_option(k, v)
