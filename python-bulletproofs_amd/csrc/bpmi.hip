@@ -143,6 +143,7 @@ int bpmi_sync(bpmi_ctx *ctx) {
 int bpmi_set_option(bpmi_ctx *ctx, const char *name, int64_t value) {
   if (!ctx || !name) return BPMI_E_ARG;
   if (!strcmp(name, "window_bits")) { if (value != 0 && (value < 2 || value > 16)) return fail(ctx, BPMI_E_ARG, "window_bits must be 0 or 2..16"); ctx->opt_c = (int)value; return BPMI_OK; }
+  if (!strcmp(name, "mid_parts")) { if (value < 0 || value > 4) return fail(ctx, BPMI_E_ARG, "mid_parts must be 0 .. 4"); ctx->opt_mid_parts = (int)value; msm_graphs_clear(ctx); return BPMI_OK; }
   if (!strcmp(name, "mixed_windows")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "mixed_windows must be 0 or 1"); ctx->opt_mixed = (int)value; msm_graphs_clear(ctx); return BPMI_OK; }
   if (!strcmp(name, "top_window_unsigned")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "top_window_unsigned must be 0 or 1"); ctx->opt_top2 = (int)value; msm_graphs_clear(ctx); return BPMI_OK; }
   if (!strcmp(name, "prover_table_bits")) { if (value != 0 && (value < 4 || value > 13)) return fail(ctx, BPMI_E_ARG, "prover_table_bits must be 0 or 4..13"); ctx->opt_prover_tw = (int)value; return BPMI_OK; }

@@ -103,6 +103,7 @@ struct bpmi_ctx {
   int opt_pair_phases = 0;              // 1: a synchronous pair of MSMs queues both sorts before either accumulation (measured neutral: profiles/r04_C3_pair_phases_ab.txt)
   int opt_graph = 0;                    // 1: replay an MSM's launch sequence as a HIP graph when the same call comes again
   // round 5 (the mid-size floor; every one on by default, 0 = the round-4 path for A/B runs and tests)
+  int opt_mid_parts = 0;                // k_msm_mid: blocks per window (0: three from 3 000 pairs, else one; 1 .. 4 forced)
   int opt_mixed = 1;                    // window bits 10 .. 14 as mixed widths c / c + 1 covering 256 bits exactly (15 always does, under opt_top2)
   int opt_top2 = 1;                     // c = 15: 17 windows, the last one unsigned with 2B buckets (0: 18 windows, the last one a carry window)
   int opt_reduce_fit = 1;               // stage 1 of the bucket reduction: elements per lane chosen so that its waves fit the SIMDs at one each

@@ -46,6 +46,12 @@ static u32 pick_window_bits(const bpmi_ctx *ctx, uint64_t n) {
 #define MID_MIN_DEFAULT 1536
 #define MID_SINGLE_MIN_DEFAULT 2560      // one MSM at a time (option "mid_single_min": 0 default, -1 never)
 
+// blocks per window of k_msm_mid (option "mid_parts": 0 = this rule, 1 .. 4 forced): from 3 000 pairs three -- a part more costs every window
+// one more addition in the host tail (~13 us per result), a third of the pairs less per block saves 18 us at 2 049 pairs, 37 at 4 097, 70 at 8 193
+static u32 mid_parts(const bpmi_ctx *ctx, uint64_t n) {
+  if (ctx->opt_mid_parts >= 1 && ctx->opt_mid_parts <= 4) return (u32)ctx->opt_mid_parts;
+  return n >= 3000u ? 3u : 1u;
+}
 struct MsmWs {
   u32 *glv_sub, *glv_bx;      // GLV: 2n x 16 B magnitudes, n x 32 B beta x
   unsigned char *glv_neg;     // GLV: 2n sign bytes
@@ -318,17 +324,19 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, int slot, const Segs &segs_in, u
   memset(&to, 0, sizeof(to));
   to.nv = 1;
   if (mid) {
-    g.nv = 1;
+    const u32 parts = mid_parts(ctx, n);
+    g.nv = parts;
+    to.nv = parts;                                   // (every part of a window at bit offset 0: the host tail adds them)
     {
       StageTimer t(ctx, ST_ACCUM, st);
       MidPair mp;
       memset(&mp, 0, sizeof(mp));
       mp.segs[0] = segs; mp.g[0] = g; mp.E[0] = E_dst;
-      hipLaunchKernelGGL(k_msm_mid, dim3(g.W, 1), dim3(MID_THREADS), 0, st, mp);
+      hipLaunchKernelGGL(k_msm_mid, dim3(g.W, 1, parts), dim3(MID_THREADS), 0, st, mp);
     }
     debug_sync(ctx, "k_msm_mid", st);
-    if (!ctx->opt_direct) HIPCHK(ctx, hipMemcpyAsync(pd.pin, w.E, 4ull * XYZZ_WORDS * g.W, hipMemcpyDeviceToHost, st));
-    return commit(g.W, 1, g.c, 2, to);
+    if (!ctx->opt_direct) HIPCHK(ctx, hipMemcpyAsync(pd.pin, w.E, 4ull * XYZZ_WORDS * g.W * parts, hipMemcpyDeviceToHost, st));
+    return commit(g.W, parts, g.c, 2, to);
   }
   if (small) {
     g.nv = 1;
@@ -634,7 +642,8 @@ static int msm_enqueue_small_pair(bpmi_ctx *ctx, const Segs &s0, const Segs &s1,
   }
   int rc = ensure_ws(ctx, total);
   if (rc) return rc;
-  const size_t eb = 4ull * XYZZ_WORDS * gg[0].W;
+  const u32 parts = mid ? mid_parts(ctx, std::max(s0.total, s1.total)) : 1u;
+  const size_t eb = 4ull * XYZZ_WORDS * gg[0].W * parts;
   for (int j = 0; j < 2; j++) { rc = ensure_pin_slot(ctx, j, eb); if (rc) return rc; }
   u32 Smax = 1, threads = 64;
   for (int j = 0; j < 2; j++) {
@@ -651,7 +660,7 @@ static int msm_enqueue_small_pair(bpmi_ctx *ctx, const Segs &s0, const Segs &s1,
   hipStream_t st = ctx->stream;
   {
     StageTimer t(ctx, ST_ACCUM, st);
-    if (mid) hipLaunchKernelGGL(k_msm_mid, dim3(gg[0].W, 2), dim3(MID_THREADS), 0, st, mp);
+    if (mid) hipLaunchKernelGGL(k_msm_mid, dim3(gg[0].W, 2, parts), dim3(MID_THREADS), 0, st, mp);
     else {
       hipLaunchKernelGGL(k_msm_small_pair, dim3(gg[0].W, Smax, 2), dim3(threads), 0, st, sp);
       if (Smax > 1) hipLaunchKernelGGL(k_small_combine_pair, dim3(gg[0].W, 2), dim3(64), 0, st, cp);
@@ -660,7 +669,7 @@ static int msm_enqueue_small_pair(bpmi_ctx *ctx, const Segs &s0, const Segs &s1,
   debug_sync(ctx, "k_msm_small_pair / k_msm_mid", st);
   TailOffs to;
   memset(&to, 0, sizeof(to));
-  to.nv = 1;
+  to.nv = parts;
   // a failure from here on leaves none of THIS call's slots pending (both were free on entry: nobody else's is touched)
   unsigned mine = 0;
   auto queue_results = [&]() -> int {
@@ -668,7 +677,7 @@ static int msm_enqueue_small_pair(bpmi_ctx *ctx, const Segs &s0, const Segs &s1,
       bpmi_ctx::PendingMsm &pd = ctx->pend[j];
       if (!ctx->opt_direct) HIPCHK(ctx, hipMemcpyAsync(pd.pin, w[j].E, eb, hipMemcpyDeviceToHost, st));
       HIPCHK(ctx, hipEventRecord(pd.done, st));
-      pd.active = true; pd.W = gg[j].W; pd.nv = 1; pd.c = c; pd.tail = 2; pd.to = to;
+      pd.active = true; pd.W = gg[j].W; pd.nv = parts; pd.c = c; pd.tail = 2; pd.to = to;
       mine |= 1u << j;
     }
     HIPCHK(ctx, hipGetLastError());

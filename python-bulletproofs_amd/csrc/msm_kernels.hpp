@@ -1453,6 +1453,11 @@ __global__ void __launch_bounds__(MID_THREADS) k_msm_mid(MidPair p) {
   const u32 job = blockIdx.y, w = blockIdx.x, tid = threadIdx.x;
   const MsmGeom g = p.g[job];
   const u32 n = g.n;
+  // round 5: a window's pairs may be split over gridDim.z blocks (`parts`): block z runs the whole method on pairs [i0, i1) and leaves its
+  // own window sum -- sum_b b X[b] is linear in the buckets -- in E[w][z]; the host tail adds the parts of a window at the same bit offset.
+  // 74 blocks of a pair of 8 193-pair MSMs used 74 of 256 CUs with 19 additions per lane; three parts: 222 blocks, 7 per lane
+  const u32 parts = gridDim.z, part = blockIdx.z;
+  const u32 i0 = (u32)((u64)n * part / parts), i1 = (u32)((u64)n * (part + 1u) / parts);
   if (tid < MID_B + 2) s_cnt[tid] = 0;
   for (u32 i = tid; i < MID_B * XYZZ_WORDS; i += MID_THREADS) s_bkt[i] = 0;          // empty buckets are the identity
   __syncthreads();
@@ -1460,7 +1465,7 @@ __global__ void __launch_bounds__(MID_THREADS) k_msm_mid(MidPair p) {
   // of the 37 blocks of an MSM would walk it for every scalar) is replaced by its closed form: with K = 64 sum_{j < 36} 2^(7 j),
   // the 7-bit field j of s + K is d_j + 64 for digits d_j in [-64, 63] that represent the same s (the top field, bits 252 .. 255,
   // stays as it is: s < 2^255 and K < 2^252, so it is at most 9) -- one 256-bit addition and a bit-field extraction per scalar.
-  for (u32 i = tid; i < n; i += MID_THREADS) {
+  for (u32 i = i0 + tid; i < i1; i += MID_THREADS) {
     sc v;
     const bool neg = load_digit_source(v, p.segs[job], i);       // s or q - s (< 2^255), and whether the point is negated
     {
@@ -1484,7 +1489,7 @@ __global__ void __launch_bounds__(MID_THREADS) k_msm_mid(MidPair p) {
     int d = (int)field - (w + 1u < g.W ? (int)MID_B : 0);
     const u32 b = (u32)(d < 0 ? -d : d);
     const u32 sign = (d < 0 ? 1u : 0u) ^ (neg ? 1u : 0u);
-    s_dig[i] = (unsigned short)(b | ((b ? sign : 0u) << 15));
+    s_dig[i - i0] = (unsigned short)(b | ((b ? sign : 0u) << 15));
     if (b) atomicAdd(&s_cnt[b], 1u);
   }
   __syncthreads();
@@ -1500,8 +1505,8 @@ __global__ void __launch_bounds__(MID_THREADS) k_msm_mid(MidPair p) {
   }
   __syncthreads();
   // 3. counting sort, then every lane adds its share of its bucket
-  for (u32 i = tid; i < n; i += MID_THREADS) {
-    const u32 d = s_dig[i], b = d & 0x7FFFu;
+  for (u32 i = i0 + tid; i < i1; i += MID_THREADS) {
+    const u32 d = s_dig[i - i0], b = d & 0x7FFFu;
     if (b) s_ent[atomicAdd(&s_cur[b], 1u)] = i | ((d >> 15) << 31);
   }
   __syncthreads();
@@ -1594,7 +1599,7 @@ __global__ void __launch_bounds__(MID_THREADS) k_msm_mid(MidPair p) {
   if (!live) return;
   if (rec == 0) {
 #pragma unroll
-    for (int k = 0; k < 9; k++) p.E[job][(u64)w * XYZZ_WORDS + q4 * 9u + k] = a.v[k];
+    for (int k = 0; k < 9; k++) p.E[job][((u64)w * parts + part) * XYZZ_WORDS + q4 * 9u + k] = a.v[k];
   }
 }
 

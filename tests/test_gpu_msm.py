@@ -456,13 +456,20 @@ def test_msm_mid_kernel_one_block_per_window(gp, shape, n):
         eng.set_option("mid_min", 1)
         eng.set_option("mid_single_min", 1)
         assert eng.msm_bytes(pb, sb, n) == want
+        want1 = cbind.msm_bytes(pb[:64 * (n - 7)], sb[:32 * (n - 7)], n - 7, 4)
         o0, o1 = eng.msm2_bytes(pb, sb, n, pb[:64 * (n - 7)], sb[:32 * (n - 7)], n - 7)      # the pair in ONE launch, unequal sizes
-        assert o0 == want and o1 == cbind.msm_bytes(pb[:64 * (n - 7)], sb[:32 * (n - 7)], n - 7, 4)
+        assert o0 == want and o1 == want1
+        for parts in (1, 2, 3, 4):                           # round 5: a window's pairs over 1 .. 4 blocks, their sums added by the host tail
+            eng.set_option("mid_parts", parts)
+            assert eng.msm_bytes(pb, sb, n) == want, parts
+            assert tuple(eng.msm2_bytes(pb, sb, n, pb[:64 * (n - 7)], sb[:32 * (n - 7)], n - 7)) == (want, want1), parts
+        eng.set_option("mid_parts", 0)
         eng.set_option("mid_min", -1)
         eng.set_option("mid_single_min", -1)
         assert eng.msm_bytes(pb, sb, n) == want
         o0, o1 = eng.msm2_bytes(pb, sb, n, pb[:64 * (n - 7)], sb[:32 * (n - 7)], n - 7)
         assert o0 == want
     finally:
+        eng.set_option("mid_parts", 0)
         eng.set_option("mid_min", 0)
         eng.set_option("mid_single_min", 0)

@@ -75,7 +75,7 @@ while time.time() - t0 < budget:
             "mid_single_min": rnd.choice((0, 0, 1, 300, -1)),   # k_msm_mid for single MSMs from that many pairs (0: default 2560, -1: never)
             # round 5: the unsigned last window of c = 15, level B of the sort on partitions of any size, the segmented scan's fused last level
             "top_window_unsigned": rnd.choice((1, 1, 0)), "sort_inblock": rnd.choice((1, 1, 0)), "segscan_fused": rnd.choice((0, 0, 1)),
-            "hist_scan_fused": rnd.choice((0, 0, 1)), "final_spread": rnd.choice((3, 3, 2, 1, 0)), "reduce_fit": rnd.choice((1, 1, 0)), "mixed_windows": rnd.choice((1, 1, 0)),
+            "hist_scan_fused": rnd.choice((0, 0, 1)), "final_spread": rnd.choice((3, 3, 2, 1, 0)), "reduce_fit": rnd.choice((1, 1, 0)), "mixed_windows": rnd.choice((1, 1, 0)), "mid_parts": rnd.choice((0, 0, 1, 2, 3, 4)),
             "reduce_epl": rnd.choice((0, 0, 0, 1, 3, 7, 11, 13, 20))}
     if n > 20000:
         opts["window_bits"] = rnd.choice((0, 0, 0, 10, 11, 12, 13, 13, 14, 15, 16))       # (10 .. 15: mixed window widths unless mixed_windows drew 0)
@@ -91,7 +91,7 @@ while time.time() - t0 < budget:
         print("MISMATCH n=%d shape=%d kind=%d opts=%s seed=%d case=%d" % (n, shape, kind, opts, seed, cases), flush=True)
 for k in ("window_bits", "chunk", "tail", "split", "small_n", "glv", "mid_single_min"):
     eng.set_option(k, 0)
-for k, v in (("top_window_unsigned", 1), ("sort_inblock", 1), ("segscan_fused", 0), ("hist_scan_fused", 0), ("final_spread", 3), ("reduce_fit", 1), ("mixed_windows", 1), ("reduce_epl", 0)):
+for k, v in (("top_window_unsigned", 1), ("sort_inblock", 1), ("segscan_fused", 0), ("hist_scan_fused", 0), ("final_spread", 3), ("reduce_fit", 1), ("mixed_windows", 1), ("mid_parts", 0), ("reduce_epl", 0)):
     eng.set_option(k, v)
 eng.set_option("fused_scan", 1)
 eng.set_option("direct_result", 1)
