@@ -177,6 +177,7 @@ static void test_host_tail() {
   to.off[0] = 0;
   for (uint32_t v = 1; v < 4; v++) to.off[v] = to.nv == 4 ? to.off[v - 1] + 1 + (uint32_t)(rnd() % 3) : 0;
   if (to.nv == 4 && to.off[3] >= c) { to.nv = 1; to.off[1] = to.off[2] = to.off[3] = 0; }
+  if (to.nv == 1 && (rnd() & 1)) to.nv = 2 + (uint32_t)(rnd() % 3);      // several sums per window at offset 0 (the parts of k_msm_mid)
   if (to.nv == 4 && (rnd() & 1)) {                                // wide windows at the top with their own offsets (round 5): any count, any increasing offsets below c
     to.top = 1 + (uint32_t)(rnd() % W);
     to.top_off[0] = 0;

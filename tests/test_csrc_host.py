@@ -465,7 +465,8 @@ def test_host_tail_field_arithmetic(shim):
 
 @pytest.mark.parametrize("c,nv,off,top,top_off", [(16, 4, (0, 4, 8, 12), 0, (0, 0, 0, 0)), (15, 4, (0, 4, 7, 11), 1, (0, 4, 8, 12)), (13, 4, (0, 3, 6, 9), 0, (0, 0, 0, 0)),
                                                   (13, 4, (0, 3, 6, 9), 9, (0, 4, 7, 10)), (12, 4, (0, 3, 6, 9), 4, (0, 3, 6, 9)), (10, 4, (0, 3, 5, 7), 6, (0, 3, 5, 8)),
-                                                  (8, 1, (0, 0, 0, 0), 0, (0, 0, 0, 0)), (7, 1, (0, 0, 0, 0), 0, (0, 0, 0, 0))])
+                                                  (8, 1, (0, 0, 0, 0), 0, (0, 0, 0, 0)), (7, 1, (0, 0, 0, 0), 0, (0, 0, 0, 0)),
+                                                  (7, 3, (0, 0, 0, 0), 0, (0, 0, 0, 0)), (7, 4, (0, 0, 0, 0), 0, (0, 0, 0, 0))])      # k_msm_mid's parts: several sums per window at offset 0
 def test_host_tail_combines_the_window_sums(shim, c, nv, off, top, top_off):
     """tail_combine (the MSM's Horner chain over bit positions, on the host): sum_w 2^(start of window w) sum_v 2^(off_v) E[w][v] for
     window sums in projective form with random scalings, identities among them, against the oracle's affine arithmetic.  top = the
