@@ -1,5 +1,7 @@
 #!/bin/bash
-# which reduction tree of k_digit_sums: four builds, the same loop of synchronous 2^16-pair MSMs under the kernel trace
+# which reduction tree of k_digit_sums: four builds, the same loop of synchronous 2^16-pair MSMs under the kernel trace.
+# (Record of an experiment: the builds libbpmi_exp_{XOR,NOPRED}.so came from -DBPMI_EXP_TREE_XOR / _NOPRED switches in k_digit_sums that were
+# removed once the winner -- butterfly for power-of-two groups, every lane adding otherwise -- was in; profiles/r05_reduction_tree_forms.txt)
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/r05_exp_tree
 mkdir -p $OUT
