@@ -96,6 +96,8 @@ def extra_c5(eng, world, rank, dev, ready, log_batch=14, distinct=None, per_gpu=
         wire_buf = eng.host_alloc(len(wire_joined))       # page-locked, as a receive buffer registered with the GPU would be
         wire_buf.view[:] = wire_joined
         v_packed = b"".join(V.to_le64() for V in Vs_in)   # commitments in the library's 64-byte point format
+        v_pinned = eng.host_alloc(len(v_packed))          # ... page-locked like the receive buffer: no staging copy on the way up
+        v_pinned.view[:] = v_packed
         import ctypes
         wire_off_c = (ctypes.c_uint64 * len(wire_off))(*wire_off)
         usable = usable_cpus()
@@ -121,7 +123,7 @@ def extra_c5(eng, world, rank, dev, ready, log_batch=14, distinct=None, per_gpu=
                 bad[(wire_off[len(blobs_in) // 2] + wire_off[len(blobs_in) // 2 + 1]) // 2] ^= 1
                 buf = bytes(bad)
             try:
-                part = bv.partial_wire(v_packed, buf, offsets=wire_off_c)      # ONE native call: upload, preparation, decoding, MSM
+                part = bv.partial_wire(v_pinned, buf, offsets=wire_off_c)      # ONE native call: upload, preparation, decoding, MSM
             except Exception as e:
                 # "Proof invalid" is a verdict (the batch holds a bad proof); anything else is a defect and is reported as such
                 if str(e) != "Proof invalid":
@@ -177,7 +179,7 @@ def extra_c5(eng, world, rank, dev, ready, log_batch=14, distinct=None, per_gpu=
         def local_partial(slot):
             bv, buf = slots[slot]
             try:
-                return bv.partial_wire(v_packed, buf, offsets=wire_off_c)
+                return bv.partial_wire(v_pinned, buf, offsets=wire_off_c)
             except Exception as e:
                 if str(e) != "Proof invalid":
                     errors.append("%s: %s" % (type(e).__name__, e))

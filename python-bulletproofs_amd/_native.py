@@ -58,7 +58,7 @@ SIGNATURES = {
     "bpmi_rp_verifier_vectors": (_i, [ctypes.c_uint32, ctypes.c_uint32, _i, _cp, _cp, _i, _cp, _cp, _cp]),
     "bpmi_rp_wire_v2_to_v1": (_i, [_vp, _u64, _vp, _u64, _vp, _u64, _vp, _vp]),
     "bpmi_rp_batch_prepare_dev": (_i, [_vp, ctypes.c_uint32, ctypes.c_uint32, _u64, _vp, _u64, _vp, _cp, _cp, _vp, _vp, _vp, _cp, _vp]),
-    "bpmi_rp_batch_verify_dev": (_i, [_vp, ctypes.c_uint32, ctypes.c_uint32, _u64, _vp, _u64, _vp, _cp, _cp, _cp, _vp, _vp, _vp, _cp, _vp]),
+    "bpmi_rp_batch_verify_dev": (_i, [_vp, ctypes.c_uint32, ctypes.c_uint32, _u64, _vp, _u64, _vp, _cp, _cp, _vp, _vp, _vp, _vp, _cp, _vp]),      # (v_points: bytes or a page-locked address)
     "bpmi_rp_prover_create": (_i, [_vp, ctypes.c_uint32, _cp, _cp, _cp, _cp, _cp, ctypes.POINTER(_vp)]),
     "bpmi_rp_prover_destroy": (None, [_vp]),
     "bpmi_rp_prove_batch_proof_bytes": (_u64, [_vp, _u64]),

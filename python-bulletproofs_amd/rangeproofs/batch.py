@@ -434,7 +434,8 @@ class BatchRangeVerifier:
         slices with the point decoding beside it, GPU preparation, the shared coefficients folded on the device, one MSM -- no
         host round trip between the preparation and the MSM and no Python loop over anything.  Stand-alone: nothing is added to
         this verifier's accumulators (a verifier that also holds proofs added otherwise folds the two values with ec_sum).
-        Vs / blobs / offsets as for add_wire_native (commitments packed, or Points / lists of Points).  Raises
+        Vs / blobs / offsets as for add_wire_native (commitments packed -- bytes or a page-locked HostBuffer --, or Points / lists of
+        Points).  Raises
         Exception("Proof invalid") when a proof fails its byte-level checks or has an invalid point; the MSM's verdict is the
         returned value (64 zero bytes = valid)."""
         import ctypes
@@ -455,7 +456,12 @@ class BatchRangeVerifier:
         if not count:
             return _ZERO64
         k = self.n.bit_length() - 1
-        if isinstance(Vs, (bytes, bytearray, memoryview)):
+        if hasattr(Vs, "ptr") and hasattr(Vs, "nbytes"):           # a page-locked HostBuffer (engine.host_alloc): uploaded without a staging copy
+            vbytes, vlen = Vs.ptr, Vs.nbytes
+            m = vlen // (64 * count)
+            if m < 1 or vlen != 64 * count * m or self.n % m:
+                raise Exception("Proof invalid")
+        elif isinstance(Vs, (bytes, bytearray, memoryview)):
             vbytes = bytes(Vs)
             m = len(vbytes) // (64 * count)
             if m < 1 or len(vbytes) != 64 * count * m or self.n % m:

@@ -505,6 +505,16 @@ def test_one_call_batch_verification_equals_the_two_step_path(eng):
     many = [blobs[i % 6] for i in range(5000)]                      # above the slicing threshold (4096 proofs)
     manyV = [b["Vs"][i % 6] for i in range(5000)]
     assert bv.partial_wire(manyV, many) == bytes(64)
+    # the commitments packed: as bytes, and as a page-locked buffer (uploaded without a staging copy)
+    packed = b"".join(V.to_le64() for V in manyV)
+    assert bv.partial_wire(packed, many) == bytes(64)
+    pinned = eng.host_alloc(len(packed))
+    pinned.view[:] = packed
+    assert bv.partial_wire(pinned, many) == bytes(64)
+    pinned.view[64 * 4321: 64 * 4322] = packed[64 * 4322: 64 * 4323]
+    assert bv.partial_wire(pinned, many) != bytes(64)
+    with pytest.raises(Exception, match="Proof invalid"):
+        bv.partial_wire(eng.host_alloc(64 * 4999), many)              # a buffer of the wrong size
     wrong = list(manyV)
     wrong[4321] = manyV[4322]
     assert bv.partial_wire(wrong, many) != bytes(64)
