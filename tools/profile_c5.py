@@ -40,7 +40,10 @@ if os.environ.get("C5_PINNED"):                         # page-locked receive bu
     hb = eng.host_alloc(len(wire_buf))
     hb.view[:] = wire_buf
     wire_buf = hb
-    Vs = b"".join(V.to_le64() for V in Vs)
+    vb = b"".join(V.to_le64() for V in Vs)
+    Vs = eng.host_alloc(len(vb)) if os.environ.get("C5_ONECALL") else vb      # (the one-call path takes the commitments page-locked too)
+    if os.environ.get("C5_ONECALL"):
+        Vs.view[:] = vb
     import ctypes
     wire_off = (ctypes.c_uint64 * len(wire_off))(*wire_off)
 if os.environ.get("C5_LANES"):
