@@ -120,11 +120,11 @@ int bpmi_sync(bpmi_ctx *ctx);
  *                  What fastecdsa's Point constructor does for the reference (reached from /root/reference/src/utils/utils.py:119-131).
  *                  Cost: one kernel behind the upload, no extra wait (profiles/r05_validate_points_cost.txt)
  *   "mid_parts"    blocks per window of the one-block-per-window kernel (k_msm_mid: MSMs of 1 536 .. 8 448 pairs in the inner-product rounds,
- *                  2 560 .. 5 631 one at a time): 0 (default) three from 3 000 pairs, else one; 1 .. 4 forced.  Every part leaves its own window
+ *                  2 560 .. 8 448 one at a time): 0 (default) three from 3 000 pairs, else one; 1 .. 4 forced.  Every part leaves its own window
  *                  sum, the host tail adds them (profiles/r05_mid_kernel_parts_ab.txt: C4's argument 4.05 -> 3.2 ms)
  *   "mixed_windows" 1 (default): window bits c = 10 .. 14 as 256 / c windows of which the last 256 - (256 / c) c are c + 1 bits wide with twice
  *                  the buckets -- the windows cover the 256 bit positions exactly: no carry window, no short top window (13 bits: 10 + 9
- *                  windows) --, and the window table that goes with it (12 bits from 5 632 pairs, 13 from 19 000, 16 from 185 000);
+ *                  windows) --, and the window table that goes with it (12 bits above the one-block kernel's 8 448 pairs, 13 from 19 000, 16 from 185 000);
  *                  0: uniform windows and the earlier table
  *   "top_window_unsigned" 1 (default): the same for window_bits = 15 (16 + 1 windows); 0: every width uniform, with its carry window
  *   "sort_inblock" 1 (default): up to 2^17 pairs the sort's second level handles partitions of any size in one block (two launches fewer)

@@ -11,13 +11,13 @@ static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; 
 // Besides the usual bucket-count trade-off, windows whose TOP window holds only a few
 // bits (255 mod c small: c = 15, 14, 12, 11) concentrate a whole window's digits in a
 // handful of buckets, so c in {8, 16} (top window 7, 15 bits) are preferred.
-// one MSM at a time: the one-block-per-window kernel up to here when the pipeline has mixed window widths (5 120 pairs: 0.202 ms against
-// 0.208; 6 144: 0.214 against 0.207; 8 192: 0.245 against 0.208), up to MID_NMAX otherwise
+// the 12-bit mixed-width pipeline's lower end (when the one-block-per-window kernel is switched off; with it -- three blocks per window --
+// that kernel keeps its whole range for single MSMs too: 8 192 pairs 0.184 ms against 0.207, profiles/r05_mid_kernel_parts_ab.txt)
 #define MID_SINGLE_MAX_MIXED 5632u
 static u32 pick_window_bits(const bpmi_ctx *ctx, uint64_t n) {
   if (ctx->opt_c >= 2 && ctx->opt_c <= 16) return (u32)ctx->opt_c;
   // Round 5, with mixed window widths (MsmGeom.top2: no carry window and no short top window at ANY width; tools/r05_exp_mixed.sh,
-  // profiles/r05_mixed_window_widths_sweep.txt): 12 bits (17 + 4 windows, 51 k buckets) from the end of the one-block kernel's range
+  // profiles/r05_mixed_window_widths_sweep.txt): 12 bits (17 + 4 windows, 51 k buckets) from the end of the one-block kernel's range (8 448)
   // to 19 000 pairs, 13 bits (10 + 9 windows, 115 k buckets) to 185 000 -- 2^16: 0.272 ms against 0.299 for c = 15 and 0.311 for c = 16 --,
   // 16 bits beyond (14 / 15 tie with it around 2 x 10^5 and lose above).  Without them: the table of the first half of the round
   // (c = 15 with its one wide window from 15 360 to 2^17, 12 from 10 240, 8 below; profiles/r05_window_table_sweep.txt)
@@ -205,7 +205,8 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, int slot, const Segs &segs_in, u
   // (measured, profiles/r04_mid_kernel_latency.txt: one MSM at a time it wins from ~2 500 pairs -- 0.18 ms against 0.21 at 3 000, 0.25
   // against 0.29 at 8 193 --, a PAIR in one launch from ~1 500 pairs each: 0.29 ms against 0.44 for two lanes of the pipeline at 4 097)
   const uint64_t mid_single = ctx->opt_mid_single > 0 ? (uint64_t)ctx->opt_mid_single : MID_SINGLE_MIN_DEFAULT;
-  const uint64_t mid_single_max = (ctx->opt_mixed && ctx->opt_top2 && ctx->opt_mid_single == 0) ? MID_SINGLE_MAX_MIXED - 1u : MID_NMAX;
+  // (with one block per window the 12-bit mixed-width pipeline passes it at ~5 600 pairs: mid_parts = 1 keeps that bound)
+  const uint64_t mid_single_max = (ctx->opt_mixed && ctx->opt_top2 && ctx->opt_mid_single == 0 && ctx->opt_mid_parts == 1) ? MID_SINGLE_MAX_MIXED - 1u : MID_NMAX;
   const bool mid = ctx->opt_mid_single >= 0 && n >= mid_single && n <= mid_single_max && ctx->opt_c == 0 && wcount == 0 && ctx->opt_glv <= 0;
   const bool small = !mid && n <= small_max && ctx->opt_c == 0 && wcount == 0;
   // GLV (option "glv" = 1; OFF by default): 2n virtual pairs with 128-bit scalars (+ 1 bit of signed-digit carry) instead of n

@@ -60,10 +60,11 @@ def test_msm_vs_oracle_random(gp, n):
     assert gp.engine().msm_bytes(pb, sb, n) == cbind.msm_bytes(pb, sb, n)
 
 
-@pytest.mark.parametrize("n", [4096, 4097, 4608, 4609, 5631, 5632, 10239, 10240, 15359, 15360, 18999, 19000, 32767, 32768])
+@pytest.mark.parametrize("n", [4096, 4097, 4608, 4609, 5631, 5632, 8448, 8449, 10239, 10240, 15359, 15360, 18999, 19000, 32767, 32768])
 def test_msm_at_the_window_table_boundaries(gp, n):
     """Either side of every switch of the geometry, this round's and the earlier ones': one-launch kernel / one-block-per-window kernel
-    (4 608), that kernel / the bucket pipeline with 12-bit mixed-width windows (5 632), 12 / 13 bits (19 000); 13 / 16 at 185 000 is
+    (4 608), that kernel / the bucket pipeline with 12-bit mixed-width windows (8 448; 5 632 with one block per window), 12 / 13 bits
+    (19 000); 13 / 16 at 185 000 is
     in test_gpu_msm_midsize.py.  Scalars with the edge values mixed in (0, 1, q - 1, >= q, 2^255, the half-order boundary, and the
     largest digits of a 15-bit window)."""
     pts, _ = gp.rand_points(n, 900 + n)

@@ -10,7 +10,8 @@ from bulletproofs_amd.engine import default_engine
 from bulletproofs_amd.ec import secp256k1
 Q = secp256k1.q
 eng = default_engine()
-DEFAULTS = {"top_window_unsigned": 1, "sort_inblock": 1, "segscan_fused": 0, "hist_scan_fused": 0, "final_spread": 3, "reduce_fit": 1, "mixed_windows": 1, "graphs": 0, "window_bits": 0, "chunk": 0, "reduce_epl": 0}
+# (an option a configuration names must be listed here with its default: the list is what is set before every measurement)
+DEFAULTS = {"mid_single_min": 0, "mid_min": 0, "mid_parts": 0, "top_window_unsigned": 1, "sort_inblock": 1, "segscan_fused": 0, "hist_scan_fused": 0, "final_spread": 3, "reduce_fit": 1, "mixed_windows": 1, "graphs": 0, "window_bits": 0, "chunk": 0, "reduce_epl": 0}
 CONFIGS = [("r4", {"top_window_unsigned": 0, "sort_inblock": 0, "segscan_fused": 0, "hist_scan_fused": 0}),
            ("inblock", {"top_window_unsigned": 0, "sort_inblock": 1, "segscan_fused": 0}),
            ("inblock+segfuse", {"top_window_unsigned": 0, "segscan_fused": 1}),
