@@ -19,6 +19,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 Q = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+PCIE_PEAK_GBS = 63.0           # MI355X_MICROARCH.md: host link PCIe Gen5 x16, 63 GB/s (spec), one direction
 ALGO_BYTES_PER_PAIR = 96       # 32-B scalar + 64-B affine point
 IPA_ALGO_BYTES_PER_ELEMENT = 960   # whole proof, per element of the n-vector
 # multiply-add content of one bucket update (xyzz_madd, csrc/curve.hpp): v_mad_u64_u32 per wave-lane, counted in

@@ -6,7 +6,7 @@ import os
 import sys
 import time
 
-from .common import (ALGO_BYTES_PER_PAIR, FE_MUL_PEAK_G, HBM_PEAK_GBS, IPA_ALGO_BYTES_PER_ELEMENT, MULS_PER_MADD, Q, RAW_MAD_TOPS, REPO, committed_traffic, cpu_quota, isa_counts,
+from .common import (PCIE_PEAK_GBS, ALGO_BYTES_PER_PAIR, FE_MUL_PEAK_G, HBM_PEAK_GBS, IPA_ALGO_BYTES_PER_ELEMENT, MULS_PER_MADD, Q, RAW_MAD_TOPS, REPO, committed_traffic, cpu_quota, isa_counts,
                      synth_scalars, usable_cpus)
 from .cpu_baseline import c5_cpu_baseline
 from .launch import c5_inflight
@@ -221,6 +221,12 @@ def extra_c5(eng, world, rank, dev, ready, log_batch=14, distinct=None, per_gpu=
         dom = max(serial_ms, key=serial_ms.get) if serial_ms else None
         dom_s = serial_ms.get(dom, 0.0) / 1e3 if dom else 0.0
         wire_bytes = len(wire_joined)
+        # what a batch moves over the host link: the wire bytes and the commitments (64 B per proof), both from page-locked buffers
+        link_bytes = wire_bytes + len(v_packed)
+        link = {"bytes_per_batch": link_bytes, "GBps": link_bytes / elapsed_pipe / 1e9, "GBps_one_batch_at_a_time": link_bytes / elapsed / 1e9,
+                "peak_GBps": PCIE_PEAK_GBS, "frac": link_bytes / elapsed_pipe / 1e9 / PCIE_PEAK_GBS,
+                "note": "host -> device bytes of this rank's share of a batch / seconds per batch; peak: PCIe Gen5 x16, 63 GB/s (MI355X_MICROARCH.md) -- "
+                        "the bound a faster preparation would meet next on this format"}
         gpu_ms = sum(stage_ms.values())
         # algorithmic bytes of the dominant stage per batch: the preparation and the point decoding read the wire bytes once
         # (and write 32 B per scalar / 64 B per point); the MSM stages read 96 B per pair
@@ -240,7 +246,7 @@ def extra_c5(eng, world, rank, dev, ready, log_batch=14, distinct=None, per_gpu=
                 "verifies_per_s_one_batch_at_a_time": total / elapsed, "preparation": "device, one native call per batch (bpmi_rp_batch_verify_dev)",
                 "accepted": all(oks), "corrupted_batch_rejected": rejected,
                 "host_threads_per_rank": threads, "host_cores_usable": usable, "msm_pairs_per_rank": msm_pairs,
-                "proves_per_s_one_gpu": prover_info["proves_per_s"], "distinct_proofs": distinct, "batch_prover": prover_info, "wire_bytes_per_batch": wire_bytes, "wire_bytes_per_proof": round(wire_bytes / max(hi - lo, 1), 1),
+                "proves_per_s_one_gpu": prover_info["proves_per_s"], "distinct_proofs": distinct, "batch_prover": prover_info, "wire_bytes_per_batch": wire_bytes, "wire_bytes_per_proof": round(wire_bytes / max(hi - lo, 1), 1), "link": link,
                 "gpu_stage_ms_per_batch": {k: round(v, 4) for k, v in stage_ms.items()},
                 "gpu_stage_ms_per_batch_serial": {k: round(v, 4) for k, v in serial_ms.items()},
                 "roofline": {"bound": "hbm", "kernel": "stage %s (the dominant GPU stage of a batch; duration from a batch whose stages run one after the other: gpu_stage_ms_per_batch_serial)" % dom,
@@ -257,7 +263,7 @@ def extra_c5(eng, world, rank, dev, ready, log_batch=14, distinct=None, per_gpu=
     try:
         r2 = run_format(wire2, False)
         res["wire_format_2"] = {k_: r2[k_] for k_ in ("value", "seconds_per_batch", "batch_latency_s", "verifies_per_s_one_batch_at_a_time", "accepted", "corrupted_batch_rejected",
-                                                      "wire_bytes_per_batch", "wire_bytes_per_proof", "gpu_stage_ms_per_batch", "gpu_stage_ms_per_batch_serial") if k_ in r2}
+                                                      "wire_bytes_per_batch", "wire_bytes_per_proof", "link", "gpu_stage_ms_per_batch", "gpu_stage_ms_per_batch_serial") if k_ in r2}
         res["wire_format_2"]["note"] = ("the same proofs without their three transcripts (csrc/rp_wire_v2_host.hpp): the device rebuilds them (k_rp_expand_v2) and runs "
                                         "the format-1 checks on the expansion; same verdicts (tests/test_gpu_configs.py::test_c5_wire_format_2_same_verdicts_as_format_1)")
         if "errors" in r2:
@@ -317,9 +323,8 @@ def extra_c2(eng, world, rank, dev, d_pts, d_sc, n, dlog, G64):
     # c + 1 bits wide with twice the buckets -- with c = 12 up to 19 000 pairs, 13 up to 185 000; 16 windows of 16 bits beyond
     isa = isa_counts() or {}
     mads = isa.get("v_mad_u64_u32_per_madd") or 1055
-    c_bits = 12 if n < 19000 else (13 if n < 185000 else 16)
-    W = 256 // c_bits
-    buckets = (W + (256 - W * c_bits)) << (c_bits - 1)
+    geom = eng.msm_geometry(n)                      # the engine's own answer under the current options (bpmi_msm_geometry)
+    c_bits, W, buckets = geom["window_bits"], geom["windows"], geom["buckets"]
     mad_accum = W * n * mads
     mad_reduce = 2 * buckets * mads * 14.0 / MULS_PER_MADD
     red_s = stage_ms.get("msm_bucket_reduce", 0.0) / 1e3

@@ -119,6 +119,11 @@ int bpmi_sync(bpmi_ctx *ctx);
  *                  points that take DEVICE pointers (bpmi_msm_dev, the generators of bpmi_ipa_verify_dev and bpmi_rp_batch_verify_dev).
  *                  What fastecdsa's Point constructor does for the reference (reached from /root/reference/src/utils/utils.py:119-131).
  *                  Cost: one kernel behind the upload, no extra wait (profiles/r05_validate_points_cost.txt)
+ *   "slice_n"      an MSM of more than "slice_min" pairs (the synchronous entry points: bpmi_msm[_dev], bpmi_msm_segs_dev, the one MSM of
+ *                  bpmi_ipa_verify_dev and of the batch verifier) runs as ceil(n / (slice_n 17/16)) equal slices, two in flight on the ctx's
+ *                  lanes 0 / 1 with their accumulations chained, the slices' results added on the host: the engine peaks at ~2^20 pairs per
+ *                  MSM (profiles/r06_msm_big_n.txt).  0 (default) 2^20; 2^16 .. 2^23; -1: one MSM up to the sort's 2^23-pair limit
+ *   "slice_min"    ... the size from which it does: 0 (default) 1.25 x slice_n
  *   "mid_parts"    blocks per window of the one-block-per-window kernel (k_msm_mid: MSMs of 1 536 .. 8 448 pairs in the inner-product rounds,
  *                  2 560 .. 8 448 one at a time): 0 (default) three from 3 000 pairs, else one; 1 .. 4 forced.  Every part leaves its own window
  *                  sum, the host tail adds them (profiles/r05_mid_kernel_parts_ab.txt: C4's argument 4.05 -> 3.2 ms)
@@ -172,7 +177,13 @@ int bpmi_msm_dev(bpmi_ctx *ctx, const void *d_pts, const void *d_scalars, uint64
  * needs it fails with BPMI_E_STATE. */
 int bpmi_msm_dev_enqueue(bpmi_ctx *ctx, int slot, const void *d_pts, const void *d_scalars, uint64_t n);
 int bpmi_msm_finish(bpmi_ctx *ctx, int slot, uint8_t out[64]);
-/* One MSM over up to three (points, scalars) arrays in different device buffers (2^23 pairs in total at most):
+/* What an MSM of n pairs runs as under the ctx's current options; no GPU work.  pipelined: 1 = as bpmi_msm_dev_enqueue runs it, 0 = as
+ * the synchronous entry points do (which slice large inputs: option "slice_n").  geom[0] kernel family (0 the bucket pipeline, 1 the
+ * one-launch kernel, 2 one block per window), [1] window bits c, [2] windows W, [3] how many of them are c + 1 bits wide, [4] buckets,
+ * [5] sorted entries per thread of the accumulation, [6] slices K, [7] pairs per slice (the other fields describe ONE slice).
+ * The bucket additions of the call are K x W x (pairs per slice); bench.py prices its multiply-adds from this, not from a constant. */
+int bpmi_msm_geometry(bpmi_ctx *ctx, uint64_t n, int pipelined, uint32_t geom[8]);
+/* One MSM over up to three (points, scalars) arrays in different device buffers (BPMI_MAX_N pairs in total at most):
  * `multiexp(gs + hs + ..., a + b + ...)` without the list concatenation of src/utils/commitments.py:13. */
 int bpmi_msm_segs_dev(bpmi_ctx *ctx, uint32_t nseg, const void *const *d_pts, const void *const *d_scalars, const uint64_t *n, uint8_t out[64]);
 /* Two independent MSMs (n0, n1 <= 2^23) from host buffers, overlapped on the ctx's two lanes: pairs

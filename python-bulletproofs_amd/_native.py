@@ -26,6 +26,7 @@ SIGNATURES = {
     "bpmi_msm_dev": (_i, [_vp, _vp, _vp, _u64, _cp]),
     "bpmi_msm_dev_enqueue": (_i, [_vp, _i, _vp, _vp, _u64]),
     "bpmi_msm_finish": (_i, [_vp, _i, _cp]),
+    "bpmi_msm_geometry": (_i, [_vp, _u64, _i, ctypes.POINTER(ctypes.c_uint32)]),
     "bpmi_ec_mul_batch": (_i, [_vp, _cp, _cp, _u64, _cp]),
     "bpmi_ec_mul_batch_dev": (_i, [_vp, _vp, _vp, _u64, _vp]),
     "bpmi_ec_lincomb2_batch": (_i, [_vp, _cp, _cp, _cp, _cp, _u64, _cp]),

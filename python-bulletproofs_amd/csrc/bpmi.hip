@@ -114,6 +114,8 @@ void bpmi_ctx_destroy(bpmi_ctx *ctx) {
   if (ctx->up_ev) (void)hipEventDestroy(ctx->up_ev);
   if (ctx->stream1) { (void)hipStreamSynchronize(ctx->stream1); (void)hipStreamDestroy(ctx->stream1); }
   if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamDestroy(ctx->stream2); }
+  if (ctx->stream_acc) { (void)hipStreamSynchronize(ctx->stream_acc); (void)hipStreamDestroy(ctx->stream_acc); }
+  for (auto e : ctx->ev_sorted) if (e) (void)hipEventDestroy(e);
   if (ctx->ws2) (void)hipFree(ctx->ws2);
   if (ctx->fold_tab) (void)hipFree(ctx->fold_tab);
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
@@ -143,6 +145,13 @@ int bpmi_sync(bpmi_ctx *ctx) {
 int bpmi_set_option(bpmi_ctx *ctx, const char *name, int64_t value) {
   if (!ctx || !name) return BPMI_E_ARG;
   if (!strcmp(name, "window_bits")) { if (value != 0 && (value < 2 || value > 16)) return fail(ctx, BPMI_E_ARG, "window_bits must be 0 or 2..16"); ctx->opt_c = (int)value; return BPMI_OK; }
+  if (!strcmp(name, "accum_stream")) { if (value < 0 || value > 2) return fail(ctx, BPMI_E_ARG, "accum_stream must be 0, 1 or 2"); ctx->opt_accum_stream = (int)value; return BPMI_OK; }
+  if (!strcmp(name, "lane_priority")) { if (value < -1 || value > 1) return fail(ctx, BPMI_E_ARG, "lane_priority must be -1, 0 or 1"); ctx->opt_lane_prio = (int)value; return BPMI_OK; }
+  if (!strcmp(name, "rounds")) { if (value < 0 || value > 16) return fail(ctx, BPMI_E_ARG, "rounds must be 0 .. 16"); ctx->opt_rounds = (int)value; msm_graphs_clear(ctx); return BPMI_OK; }
+  if (!strcmp(name, "pair_rounds")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "pair_rounds must be 0 or 1"); ctx->opt_pair_rounds = (int)value; return BPMI_OK; }
+  if (!strcmp(name, "accum_chain")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "accum_chain must be 0 or 1"); ctx->opt_accum_chain = (int)value; return BPMI_OK; }
+  if (!strcmp(name, "slice_n")) { if (value < -1 || value > (1 << 23) || (value > 0 && value < (1 << 16))) return fail(ctx, BPMI_E_ARG, "slice_n must be -1, 0 or 2^16 .. 2^23"); ctx->opt_slice_n = (int)value; return BPMI_OK; }
+  if (!strcmp(name, "slice_min")) { if (value < 0 || value > (1 << 23)) return fail(ctx, BPMI_E_ARG, "slice_min must be 0 .. 2^23"); ctx->opt_slice_min = (int)value; return BPMI_OK; }
   if (!strcmp(name, "mid_parts")) { if (value < 0 || value > 4) return fail(ctx, BPMI_E_ARG, "mid_parts must be 0 .. 4"); ctx->opt_mid_parts = (int)value; msm_graphs_clear(ctx); return BPMI_OK; }
   if (!strcmp(name, "mixed_windows")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "mixed_windows must be 0 or 1"); ctx->opt_mixed = (int)value; msm_graphs_clear(ctx); return BPMI_OK; }
   if (!strcmp(name, "top_window_unsigned")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "top_window_unsigned must be 0 or 1"); ctx->opt_top2 = (int)value; msm_graphs_clear(ctx); return BPMI_OK; }
@@ -154,7 +163,7 @@ int bpmi_set_option(bpmi_ctx *ctx, const char *name, int64_t value) {
   if (!strcmp(name, "final_spread")) { if (value < 0 || value > 3) return fail(ctx, BPMI_E_ARG, "final_spread must be 0 .. 3"); ctx->opt_final_spread = (int)value; msm_graphs_clear(ctx); return BPMI_OK; }
   if (!strcmp(name, "sort_inblock")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "sort_inblock must be 0 or 1"); ctx->opt_inblock = (int)value; msm_graphs_clear(ctx); return BPMI_OK; }
   if (!strcmp(name, "segscan_fused")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "segscan_fused must be 0 or 1"); ctx->opt_segfuse = (int)value; msm_graphs_clear(ctx); return BPMI_OK; }
-  if (!strcmp(name, "priority")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "priority must be 0 or 1"); ctx->opt_prio = (int)value; return BPMI_OK; }
+  if (!strcmp(name, "priority")) { if (value < 0 || value > 31 || (value > 1 && value < 16)) return fail(ctx, BPMI_E_ARG, "priority must be 0, 1 or 16 + a mask of stages"); ctx->opt_prio = (int)value; msm_graphs_clear(ctx); return BPMI_OK; }
   if (!strcmp(name, "hist_threads")) { if (value != 0 && value != 256 && value != 512 && value != 1024) return fail(ctx, BPMI_E_ARG, "hist_threads must be 0, 256, 512 or 1024"); ctx->opt_hist_threads = (int)value; return BPMI_OK; }
   if (!strcmp(name, "hist_blocks")) { if (value < 0 || value > 8192) return fail(ctx, BPMI_E_ARG, "hist_blocks must be in [0, 8192]"); ctx->opt_hist_blocks = (int)value; return BPMI_OK; }
   if (!strcmp(name, "direct_result")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "direct_result must be 0 or 1"); ctx->opt_direct = (int)value; msm_graphs_clear(ctx); return BPMI_OK; }
@@ -284,41 +293,29 @@ static int msm_dev_impl(bpmi_ctx *ctx, const void *d_pts, const void *d_scalars,
   if (!ctx || !out || (n && (!d_pts || !d_scalars))) return ctx ? fail(ctx, BPMI_E_ARG, "null argument") : BPMI_E_ARG;
   if (n > BPMI_MAX_N) return fail(ctx, BPMI_E_ARG, "n exceeds BPMI_MAX_N");
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  // The LDS partition sort packs a 23-bit pair index; longer inputs run as slices of 2^23
-  // pairs on alternating lanes (5.7e8 pairs/s each, against 3.7e8 for the global-atomic
-  // sort path at these sizes) and the slice results are added.
-  const uint64_t SLICE = 1ull << 23;
-  if (n <= SLICE || ctx->opt_c) {
-    Segs s = segs_init();
-    s.pts[0] = (const u32 *)d_pts; s.sc[0] = (const u32 *)d_scalars; s.n[0] = (u32)n; s.total = (u32)n;
-    return msm_run(ctx, s, out);
-  }
-  const uint64_t nsl = (n + SLICE - 1) / SLICE;
-  std::vector<uint8_t> parts(64 * nsl);
-  int rc = ensure_lane(ctx, 1);
-  if (rc) return rc;
-  HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
-  HIPCHK(ctx, hipStreamWaitEvent(ctx->stream1, ctx->ev_fork, 0));
-  // an error in the middle leaves the OTHER lane's slice queued: drain both lanes and release both slots, or every later MSM on
-  // this ctx would fail with "still pending"
-  unsigned mine = 0;                                       // slots that hold a slice of THIS call
-  auto abandon = [&](int code) { msm_abandon_pending(ctx, mine); return code; };
-  for (uint64_t k = 0; k < nsl; k++) {
-    const int lane = (int)(k & 1);
-    if (k >= 2) { mine &= ~(1u << lane); rc = msm_finish(ctx, lane, parts.data() + 64 * (k - 2)); if (rc) return abandon(rc); }
-    const uint64_t lo = k * SLICE, cnt = std::min<uint64_t>(SLICE, n - lo);
-    Segs s = segs_init();
-    s.pts[0] = (const u32 *)d_pts + 16 * lo; s.sc[0] = (const u32 *)d_scalars + 8 * lo; s.n[0] = (u32)cnt; s.total = (u32)cnt;
-    rc = msm_enqueue(ctx, lane, lane, s);
-    if (rc) return abandon(rc);
-    mine |= 1u << lane;
-  }
-  for (uint64_t k = (nsl >= 2 ? nsl - 2 : 0); k < nsl; k++) {
-    mine &= ~(1u << (k & 1));
-    rc = msm_finish(ctx, (int)(k & 1), parts.data() + 64 * k);
-    if (rc) return abandon(rc);
-  }
-  return bpmi_ec_sum(ctx, parts.data(), nsl, out);
+  // (inputs of more than ~1.25 x 2^20 pairs run as slices of about 2^20 pairs, two in flight: msm_run, csrc/msm_host.hpp)
+  Segs s = segs_init();
+  s.pts[0] = (const u32 *)d_pts; s.sc[0] = (const u32 *)d_scalars; s.n[0] = (u32)n; s.total = (u32)n;
+  return msm_run(ctx, s, out);
+}
+// what an MSM of n pairs runs as under the ctx's current options (no GPU work): bench.py counts its multiply-adds from this
+int bpmi_msm_geometry(bpmi_ctx *ctx, uint64_t n, int pipelined, uint32_t geom[8]) {
+  if (!ctx || !geom) return ctx ? fail(ctx, BPMI_E_ARG, "null argument") : BPMI_E_ARG;
+  if (n > BPMI_MAX_N) return fail(ctx, BPMI_E_ARG, "n exceeds BPMI_MAX_N");
+  memset(geom, 0, 8 * sizeof(uint32_t));
+  if (n == 0) return BPMI_OK;
+  Segs s = segs_init();
+  s.n[0] = (u32)n; s.total = (u32)n;
+  const uint64_t K = pipelined ? 1 : msm_slice_count(ctx, s);
+  const uint64_t per = (n + K - 1) / K;
+  MsmGeom g;
+  bool mid, small, glv;
+  const bool saved = ctx->chain_accum;
+  ctx->chain_accum = pipelined ? ctx->opt_async_lanes != 0 : (K > 1 && per >= (1u << 19));
+  msm_pick_geometry(ctx, per, 0, 0, g, mid, small, glv);
+  ctx->chain_accum = saved;
+  geom[0] = small ? 1u : (mid ? 2u : 0u); geom[1] = g.c; geom[2] = g.W; geom[3] = g.top2; geom[4] = g.G; geom[5] = g.L; geom[6] = (uint32_t)K; geom[7] = (uint32_t)per;
+  return BPMI_OK;
 }
 // Asynchronous pair: enqueue returns as soon as the MSM's kernels and its device->host copy are queued on
 // the ctx stream; finish waits for THAT MSM only and runs the host part of its tail.  Two slots, so the
@@ -354,7 +351,9 @@ int bpmi_msm_dev_enqueue(bpmi_ctx *ctx, int slot, const void *d_pts, const void 
     ctx->async_lane1_ordered = ctx->async_lane2_ordered = true;
   }
   ctx->chain_accum = ctx->opt_async_lanes != 0;
+  ctx->chain_free = ctx->opt_accum_chain == 0;
   rc = msm_enqueue(ctx, lane, slot, s);
+  ctx->chain_free = false;
   ctx->chain_accum = false;
   if (rc == BPMI_OK) { ctx->pend[slot].async = true; ctx->pend[slot].async_empty = (n == 0); }
   return rc;
@@ -683,7 +682,7 @@ int bpmi_msm_segs_dev(bpmi_ctx *ctx, uint32_t nseg, const void *const *d_pts, co
     total += n[i];
     k++;
   }
-  if (total > (1ull << 23)) return fail(ctx, BPMI_E_ARG, "bpmi_msm_segs_dev takes at most 2^23 pairs in total");
+  if (total > BPMI_MAX_N) return fail(ctx, BPMI_E_ARG, "n exceeds BPMI_MAX_N");
   s.total = (u32)total;
   return msm_run(ctx, s, out);
 }

@@ -59,7 +59,8 @@ struct bpmi_ctx {
   // options
   int opt_c = 0;        // window bits, 0 = auto
   int opt_tail = 0;     // 0 auto, 1 device, 2 host
-  int opt_prio = 0;     // MSM: 1 = the latency-bound stages raise their waves' priority (s_setprio); measured 2-6 % SLOWER with two MSMs in flight (profiles/r03_wave_priority_ab.txt): off
+  int opt_prio = 1;     // MSM: the stages around the accumulation raise their waves' issue priority (s_setprio): 0 none, 1 all (default from round 6: beside a multi-round
+                        // accumulation it is a gain, profiles/r06_wave_priority_and_chunk_ab.txt; round 3 measured a loss beside the one-round kernel), 16 + mask = those PRIO_* stages
   int opt_hist_threads = 0, opt_hist_blocks = 0;     // k_coarse_hist launch shape (0 = default)
   int opt_quad = 1;     // bucket reduction's finish with four-lane point additions (k_digit_final_quad); 0 = one lane per point
   int opt_mulb = 1;     // bpmi_ec_mul_batch: 1 = GLV + fixed signed windows over affine odd multiples (n >= MULB_MIN_N), 0 = the bit-serial ladder
@@ -116,6 +117,18 @@ struct bpmi_ctx {
                                         // the device-scope fence every block needs writes its XCD's L2 back behind 33 MB of digit codes -- +60 us at 2^20, +16 us at 2^16.  Off; kept with its tests
   int opt_segfuse = 0;                  // 1: the segmented scan's last level runs in the block that finishes the level before it last.  No gain one MSM at a time, and the fence costs
                                         // two MSMs in flight 3 % (the other lane's dirty bucket lines are written back with it).  Off; kept with its tests
+  // round 6
+  int opt_slice_n = 0;                  // an MSM of more than slice_min pairs runs as slices of about this many, two in flight (0 = 2^20, -1 = only beyond the sort's 2^23 limit; msm_host.hpp)
+  int opt_slice_min = 0;                // ... the size from which it does (0 = default: 1.25 x slice_n)
+  int opt_rounds = 0;                   // rounds of three waves per SIMD of an accumulation that shares the chip with another MSM's kernels (0 = 3; msm_host.hpp)
+  int opt_pair_rounds = 0;              // 1: a synchronous pair of large MSMs keeps round 5's one-round chunks (A/B)
+  bool beside = false;                  // set by msm_run_pair around its enqueues
+  int opt_accum_chain = 1;              // experiment: 0 = the asynchronous pipeline's accumulations are NOT ordered after each other (the lanes run free)
+  bool chain_free = false;
+  int opt_accum_stream = 0;             // experiment: the chained pipeline's accumulations on one low-priority stream of their own (msm_host.hpp)
+  int opt_lane_prio = 0;                // experiment: queue priority of lanes 1 / 2 created AFTER the option is set (0 default, -1 high, 1 low)
+  hipStream_t stream_acc = nullptr;
+  hipEvent_t ev_sorted[BPMI_LANES] = {nullptr, nullptr, nullptr};
   double prof_ms[BPMI_NSTAGES] = {0};
   uint64_t prof_calls[BPMI_NSTAGES] = {0};
 };
@@ -278,12 +291,18 @@ static int ensure_ws(bpmi_ctx *ctx, size_t bytes) {
 static int ensure_lane(bpmi_ctx *ctx, int lane) {
   if (lane == 0) return BPMI_OK;
   if (!ctx->stream1) {
-    HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream1, hipStreamNonBlocking));
+    HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->stream1, hipStreamNonBlocking, ctx->opt_lane_prio));
     HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
     HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
     for (int k = 0; k < BPMI_LANES; k++) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_accum[k], hipEventDisableTiming));
   }
-  if (lane == 2 && !ctx->stream2) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+  if (lane == 2 && !ctx->stream2) HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, ctx->opt_lane_prio));
+  if (ctx->opt_accum_stream && !ctx->stream_acc) {
+    int least = 0, greatest = 0;
+    HIPCHK(ctx, hipDeviceGetStreamPriorityRange(&least, &greatest));
+    HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->stream_acc, hipStreamNonBlocking, ctx->opt_accum_stream == 2 ? 0 : least));
+    for (int k = 0; k < BPMI_LANES; k++) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_sorted[k], hipEventDisableTiming));
+  }
   return BPMI_OK;
 }
 static hipStream_t lane_stream(bpmi_ctx *ctx, int lane) { return lane == 0 ? ctx->stream : (lane == 1 ? ctx->stream1 : ctx->stream2); }

@@ -170,6 +170,26 @@ static inline void pt_dbl_run(pt &a, int k) {
   a.X = X; a.Y = Y;
   f_sqr(a.ZZ, Z); f_mul(a.ZZZ, a.ZZ, Z);
 }
+// canonical 64-byte affine form (x || y little-endian, the identity 64 zero bytes) <-> XYZZ
+static inline void pt_to_affine(uint8_t out[64], const pt &acc) {
+  if (f_is_zero(acc.ZZ)) { memset(out, 0, 64); return; }
+  f64 zz_zzz, inv, izz, izzz, x, y;
+  f_mul(zz_zzz, acc.ZZ, acc.ZZZ);
+  f_inv(inv, zz_zzz);
+  f_mul(izz, inv, acc.ZZZ);
+  f_mul(izzz, inv, acc.ZZ);
+  f_mul(x, acc.X, izz);
+  f_mul(y, acc.Y, izzz);
+  memcpy(out, x.v, 32);
+  memcpy(out + 32, y.v, 32);
+}
+static inline void pt_from_affine(pt &r, const uint8_t in[64]) {
+  memcpy(r.X.v, in, 32);
+  memcpy(r.Y.v, in + 32, 32);
+  if (f_is_zero(r.X) && f_is_zero(r.Y)) { pt_set_inf(r); return; }
+  memset(&r.ZZ, 0, sizeof(f64)); memset(&r.ZZZ, 0, sizeof(f64));
+  r.ZZ.v[0] = 1; r.ZZZ.v[0] = 1;
+}
 // result = sum_w 2^(c w) sum_v 32^v E[w][v] as ONE Horner chain over bit positions
 static inline void tail_combine(uint8_t out[64], const bpmi::u32 *E, bpmi::u32 W, bpmi::u32 c, const bpmi::TailOffs &to) {
   pt acc;
@@ -186,16 +206,7 @@ static inline void tail_combine(uint8_t out[64], const bpmi::u32 *E, bpmi::u32 W
       pt_add(acc, acc, e);
     }
   }
-  if (f_is_zero(acc.ZZ)) { memset(out, 0, 64); return; }
-  f64 zz_zzz, inv, izz, izzz, x, y;
-  f_mul(zz_zzz, acc.ZZ, acc.ZZZ);
-  f_inv(inv, zz_zzz);
-  f_mul(izz, inv, acc.ZZZ);
-  f_mul(izzz, inv, acc.ZZ);
-  f_mul(x, acc.X, izz);
-  f_mul(y, acc.Y, izzz);
-  memcpy(out, x.v, 32);
-  memcpy(out + 32, y.v, 32);
+  pt_to_affine(out, acc);
 }
 
 }  // namespace bpmi_host

@@ -182,23 +182,11 @@ struct CaptureGuard {
   ~CaptureGuard() { if (open) { hipGraph_t g = nullptr; (void)hipStreamEndCapture(st, &g); if (g) (void)hipGraphDestroy(g); (void)hipGetLastError(); } }
 };
 
-// Enqueue every GPU stage of one MSM on `lane` (0 = the ctx stream, 1 = the second lane: stream +
-// workspace), including the device->pinned-host copy the tail needs, into pending slot `slot`
-// (pinned buffer + completion event); returns without synchronising.
-//   [w0, w0 + wcount): the windows this call handles (wcount = 0: all of them)
-//   phase: 0 = everything; 1 = the sort only (recoding .. sorted entries), nothing becomes pending; 2 = the rest of an MSM whose
-//   sort a phase-1 call with the SAME arguments queued on this lane (the geometry is a function of the arguments: it is simply
-//   computed again).  A synchronous pair queues both sorts before either accumulation (msm_run_pair).  MSMs on the one-launch
-//   kernels or on GLV scalars have no separate sort: phase 1 does nothing for them and phase 2 everything.
-static int msm_enqueue(bpmi_ctx *ctx, int lane, int slot, const Segs &segs_in, u32 w0 = 0, u32 wcount = 0, int phase = 0) {
-  Segs segs = segs_in;
-  const uint64_t n = segs.total;
-  bpmi_ctx::PendingMsm &pd = ctx->pend[slot];
-  if (pd.active) return fail(ctx, BPMI_E_STATE, "an MSM is still pending in this slot (bpmi_msm_finish it first)");
-  pd.active = false;
-  if (n == 0) return BPMI_OK;
-  if (n > BPMI_MAX_N) return fail(ctx, BPMI_E_ARG, "n exceeds BPMI_MAX_N");
-  MsmGeom g{};
+// The geometry of one MSM of n pairs under the ctx's options: which kernel family (mid: the one-block-per-window kernel, small: the
+// one-launch kernel, neither: the bucket pipeline), window bits, windows, buckets, chunk length.  A function of (options, n, w0,
+// wcount, ctx->chain_accum) only: msm_enqueue computes it, bpmi_msm_geometry reports it (bench.py's multiply-add count).
+static void msm_pick_geometry(const bpmi_ctx *ctx, uint64_t n, u32 w0, u32 wcount, MsmGeom &g, bool &mid, bool &small, bool &glv) {
+  g = MsmGeom{};
   g.n = (u32)n;
   const uint64_t small_max = ctx->opt_small < 0 ? 0 : (ctx->opt_small ? (uint64_t)ctx->opt_small : SMALL_N_DEFAULT);
   // the one-block-per-window bucket kernel (k_msm_mid) between the small-MSM kernel and the pipeline
@@ -207,8 +195,8 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, int slot, const Segs &segs_in, u
   const uint64_t mid_single = ctx->opt_mid_single > 0 ? (uint64_t)ctx->opt_mid_single : MID_SINGLE_MIN_DEFAULT;
   // (with one block per window the 12-bit mixed-width pipeline passes it at ~5 600 pairs: mid_parts = 1 keeps that bound)
   const uint64_t mid_single_max = (ctx->opt_mixed && ctx->opt_top2 && ctx->opt_mid_single == 0 && ctx->opt_mid_parts == 1) ? MID_SINGLE_MAX_MIXED - 1u : MID_NMAX;
-  const bool mid = ctx->opt_mid_single >= 0 && n >= mid_single && n <= mid_single_max && ctx->opt_c == 0 && wcount == 0 && ctx->opt_glv <= 0;
-  const bool small = !mid && n <= small_max && ctx->opt_c == 0 && wcount == 0;
+  mid = ctx->opt_mid_single >= 0 && n >= mid_single && n <= mid_single_max && ctx->opt_c == 0 && wcount == 0 && ctx->opt_glv <= 0;
+  small = !mid && n <= small_max && ctx->opt_c == 0 && wcount == 0;
   // GLV (option "glv" = 1; OFF by default): 2n virtual pairs with 128-bit scalars (+ 1 bit of signed-digit carry) instead of n
   // with 255-bit ones: as many bucket additions, half the windows.  Measured (profiles/r03_glv_msm_on_off.txt) it LOSES at every
   // size from 2^15: the bucket reduction is bound by the depth of its addition chains, not by the number of windows (0.16 ms
@@ -217,7 +205,7 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, int slot, const Segs &segs_in, u
   // 0.065 -> 0.14); and an entry's x and y come from two arrays (two 32-byte requests instead of one 64-byte one: accumulate
   // 0.82 -> 1.02 ms).  Kept behind the option, with its tests, as the record of the experiment.  The sorted entry packs a
   // 23-bit index, so 2n must fit it.
-  const bool glv = ctx->opt_glv > 0 && !small && wcount == 0 && n >= 2 && 2 * n <= (1ull << 23);
+  glv = ctx->opt_glv > 0 && !small && wcount == 0 && n >= 2 && 2 * n <= (1ull << 23);
   if (glv) g.n = (u32)(2 * n);
   g.c = mid ? MID_C : (small ? SMALL_C : pick_window_bits(ctx, n));
   // Mixed window widths (round 5; MsmGeom.top2 = Wb): W = 256 / c windows of which the last Wb = 256 - W c are c + 1 bits wide with 2B
@@ -240,7 +228,17 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, int slot, const Segs &segs_in, u
   // segmented scan / bucket reduction -- measures 0.99-1.01 ms per step against 1.04 under bench.py, but ONLY there: the HIP events
   // bench.py records around this kernel change the interleaving of the two lanes, and without them (every other caller) L = 128
   // costs 1.19 ms against 1.04.  86 stays; anything between the quantisation points is far worse (L = 120: 1.21).
-  const u32 L_lanes = 86u;
+  // Round 6 (profiles/r06_wave_priority_and_chunk_ab.txt): where another MSM's kernels run BESIDE this accumulation (the chained pipeline
+  // of bpmi_msm_dev_enqueue and of the slices of a large MSM; a synchronous pair from 2^19 pairs) the chunk is the length that makes the
+  // accumulation `rounds` rounds of three waves per SIMD, ceil(W n / (64 x 3072 x rounds)), never under 20 entries -- at n = 2^20: 86 for one
+  // round (rounds 2 .. 5's choice: every wave slot of the chip taken once, for the whole kernel), 29 for three (the default now).  With one
+  // round the other lane's sort and reduction find NO wave slot until the accumulation ends (k_digit_sums 750 us instead of 93, 0.3 ms in
+  // every 1.9 without an accumulation running); with three the slots turn over every 0.26 ms, the other lane's kernels become resident
+  // beside the accumulation, and -- now that they are resident -- raising their waves' issue priority (option "priority", on by default
+  // from this round) lets their dependent chains run at their own speed: 1.043 -> 0.985 ms per step from the chunks alone, -> 0.963 / 0.915
+  // (two boxes) with the priority.  Option "rounds" (0 = 3).
+  const u32 rounds = ctx->opt_rounds > 0 ? (u32)ctx->opt_rounds : 3u;
+  const u32 L_lanes = (u32)std::max<uint64_t>(20, ((uint64_t)g.W * g.n + 64ull * 3072 * rounds - 1) / (64ull * 3072 * rounds));
   // One MSM at a time (and the pairs of the IPA): the accumulation as ONE round of three waves per SIMD (3072 waves) from the size
   // where that leaves chunks of 20 entries, one round of two below (a chunk is a chain of dependent additions and every chunk
   // costs a pair of partial records), at most 64.  Powers of two missed the quantisation points:
@@ -257,10 +255,30 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, int slot, const Segs &segs_in, u
     L_one = l3 >= 20u ? l3 : (l2 >= 3u ? l2 : (l1 < 2u ? 2u : l1));
     if (L_one > 64u) L_one = 64u;
   }
-  g.L = ctx->opt_chunk > 0 ? (u32)ctx->opt_chunk : ((n >= (1u << 19) && ctx->chain_accum) ? L_lanes : L_one);
+  g.L = ctx->opt_chunk > 0 ? (u32)ctx->opt_chunk : ((n >= (1u << 19) && (ctx->chain_accum || ctx->beside)) ? L_lanes : L_one);
   g.nv = (g.B <= 256u) ? 1u : 4u;                  // partial sums per window handed to the tail
-  g.prio = ctx->opt_prio ? 1u : 0u;
+  g.prio = ctx->opt_prio == 1 ? 15u : (ctx->opt_prio > 1 ? (u32)(ctx->opt_prio & 15) : 0u);      // (1 = every stage; 16 + mask = those stages)
   g.fuse = ctx->opt_fuse ? 1u : 0u;
+}
+// Enqueue every GPU stage of one MSM on `lane` (0 = the ctx stream, 1 = the second lane: stream +
+// workspace), including the device->pinned-host copy the tail needs, into pending slot `slot`
+// (pinned buffer + completion event); returns without synchronising.
+//   [w0, w0 + wcount): the windows this call handles (wcount = 0: all of them)
+//   phase: 0 = everything; 1 = the sort only (recoding .. sorted entries), nothing becomes pending; 2 = the rest of an MSM whose
+//   sort a phase-1 call with the SAME arguments queued on this lane (the geometry is a function of the arguments: it is simply
+//   computed again).  A synchronous pair queues both sorts before either accumulation (msm_run_pair).  MSMs on the one-launch
+//   kernels or on GLV scalars have no separate sort: phase 1 does nothing for them and phase 2 everything.
+static int msm_enqueue(bpmi_ctx *ctx, int lane, int slot, const Segs &segs_in, u32 w0 = 0, u32 wcount = 0, int phase = 0) {
+  Segs segs = segs_in;
+  const uint64_t n = segs.total;
+  bpmi_ctx::PendingMsm &pd = ctx->pend[slot];
+  if (pd.active) return fail(ctx, BPMI_E_STATE, "an MSM is still pending in this slot (bpmi_msm_finish it first)");
+  pd.active = false;
+  if (n == 0) return BPMI_OK;
+  if (n > BPMI_MAX_N) return fail(ctx, BPMI_E_ARG, "n exceeds BPMI_MAX_N");
+  MsmGeom g{};
+  bool mid, small, glv;
+  msm_pick_geometry(ctx, n, w0, wcount, g, mid, small, glv);
   MsmWs w;
   msm_layout(g, w, nullptr, glv);
   int rc = ensure_lane(ctx, lane);
@@ -421,15 +439,27 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, int slot, const Segs &segs_in, u
   }
   }      // !skip_sort
   if (phase == 1) { HIPCHK(ctx, hipGetLastError()); return BPMI_OK; }
-  if (ctx->chain_accum && ctx->accum_chain_lane >= 0 && ctx->accum_chain_lane != lane)
+  // Round 6 experiment (option "accum_stream"): on the chained pipeline every accumulation runs on ONE stream of its own, created with the
+  // LOWEST queue priority, between two events of its lane -- the accumulations are in order by construction, and the lanes' sort and
+  // reduction kernels sit on queues the dispatcher prefers whenever a wave slot frees up (with "chunk" below the one-round length the
+  // accumulation's slots turn over while it runs).  profiles/r06_accum_stream_ab.txt
+  const bool own_acc = ctx->chain_accum && ctx->opt_accum_stream && ctx->stream_acc;
+  hipStream_t st_acc = own_acc ? ctx->stream_acc : st;
+  if (own_acc) {
+    HIPCHK(ctx, hipEventRecord(ctx->ev_sorted[lane], st));
+    HIPCHK(ctx, hipStreamWaitEvent(st_acc, ctx->ev_sorted[lane], 0));
+  } else if (ctx->chain_accum && !ctx->chain_free && ctx->accum_chain_lane >= 0 && ctx->accum_chain_lane != lane)
     HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_accum[ctx->accum_chain_lane], 0));
   {
-    StageTimer t(ctx, ST_ACCUM, st);
+    StageTimer t(ctx, ST_ACCUM, st_acc);
     const u32 nthreads = w.nchunks;
     auto kern = glv ? (g.fuse ? k_accum_l0<true, true> : k_accum_l0<true, false>) : (g.fuse ? k_accum_l0<false, true> : k_accum_l0<false, false>);
-    hipLaunchKernelGGL(kern, dim3((nthreads + 255) / 256), dim3(256), 0, st, segs, g, w.off, w.chunk_key, w.sidx, w.buckets, w.rec_key[0], w.rec_pt[0]);
+    hipLaunchKernelGGL(kern, dim3((nthreads + 255) / 256), dim3(256), 0, st_acc, segs, g, w.off, w.chunk_key, w.sidx, w.buckets, w.rec_key[0], w.rec_pt[0]);
   }
-  if (ctx->chain_accum) { HIPCHK(ctx, hipEventRecord(ctx->ev_accum[lane], st)); ctx->accum_chain_lane = lane; }
+  if (own_acc) {
+    HIPCHK(ctx, hipEventRecord(ctx->ev_accum[lane], st_acc));
+    HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_accum[lane], 0));
+  } else if (ctx->chain_accum) { HIPCHK(ctx, hipEventRecord(ctx->ev_accum[lane], st)); ctx->accum_chain_lane = lane; }
   debug_sync(ctx, "ST_ACCUM", st);
   {
     StageTimer t(ctx, ST_SEGSCAN, st);
@@ -507,9 +537,9 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, int slot, const Segs &segs_in, u
         j2top = digit_jobs_concat(jta, jtb);
         to.top = g.top2; to.top_off[0] = 0; to.top_off[1] = t0t; to.top_off[2] = s0t; to.top_off[3] = s0t + t1t;
       }
-      j1.prio = g.prio;
+      j1.prio = g.prio & PRIO_SUMS;
       hipLaunchKernelGGL(k_digit_sums, dim3(j1.j[j1.njobs - 1].blk0 + digit_job_blocks(j1, j1.njobs - 1)), dim3(256), 0, st, w.buckets, w.D, j1);
-      j2.prio = j2top.prio = g.prio;
+      j2.prio = j2top.prio = g.prio & PRIO_FINISH;
       const u32 top_w = g.top2 ? Wr : 0xFFFFFFFFu;
       // (the tickets of the spread finish live behind the sort's partition counts: zeroed by this MSM's memset when the LDS sort runs)
       if (ctx->opt_quad && ctx->opt_final_spread == 1 && w.P)
@@ -587,8 +617,98 @@ static int msm_run_split(bpmi_ctx *ctx, const Segs &segs, uint8_t out[64]) {
   p0.active = p1.active = false;
   return BPMI_OK;
 }
+// ---- large inputs as slices of the size where the engine peaks (round 6) -------------------------------------------------------
+// The reference's multiexp takes any N (/root/reference/src/pippenger/pippenger.py:22-61) and its verifier calls it with 2n + 1 pairs
+// (/root/reference/src/innerproduct/inner_product_verifier.py:134-139: 2^21 + 1 at config C3's size).  One MSM of more than ~2^20 pairs
+// runs BELOW the 2^20 rate here (7.75-8.3 x 10^8 pairs/s at 2^21 .. 2^24 against 1.0 x 10^9, profiles/r03_msm_big_n.txt): its 64-byte
+// gathers, once per window, no longer fit the Infinity Cache, and one MSM at a time leaves the chip to the sort and to the bucket
+// reduction for 0.3 ms per MSM.  So an input of more than slice_min pairs is cut into K = ceil(total / (slice_n 17/16)) equal slices,
+// which run as the two-deep pipeline of bench.py's headline (lanes 0 / 1, the accumulations chained): the sort and the reduction of one
+// slice beside the accumulation of the other, the host tail of slice k under the kernels of slice k + 1.  The slices' affine results
+// are added on the host (XYZZ, one inversion).  Options "slice_n" (0 = 2^20; -1 = never slice below the sort's 2^23 limit) and
+// "slice_min" (0 = default).  Inputs with half-block selection (the IPA's deferred folds: msm_run_pair) are never sliced.
+#define SLICE_N_DEFAULT (1u << 20)
+#define SLICE_N_LIMIT (1u << 23)          // the packed sort entry holds a 23-bit pair index
+static bool segs_dense(const Segs &s) { return s.hlog[0] >= 32u && s.hlog[1] >= 32u && s.hlog[2] >= 32u && !s.glv_sub; }
+// the logical pairs [lo, lo + cnt) of a dense `s`
+static Segs segs_slice(const Segs &s, uint64_t lo, uint64_t cnt) {
+  Segs r = segs_init();
+  u32 k = 0;
+  uint64_t base = 0;
+  for (int i = 0; i < 3; i++) {
+    const uint64_t a = std::max<uint64_t>(lo, base), b = std::min<uint64_t>(lo + cnt, base + s.n[i]);
+    if (b > a) { r.pts[k] = s.pts[i] + 16ull * (a - base); r.sc[k] = s.sc[i] + 8ull * (a - base); r.n[k] = (u32)(b - a); k++; }
+    base += s.n[i];
+  }
+  r.total = (u32)cnt;
+  return r;
+}
+static uint64_t msm_slice_count(const bpmi_ctx *ctx, const Segs &segs) {
+  // (forced window bits, window groups, half-block selections: ONE MSM whatever its size -- beyond 2^23 pairs on the global-atomic sort)
+  if (!segs_dense(segs) || ctx->opt_c || ctx->opt_split) return 1;
+  const uint64_t slice_n = ctx->opt_slice_n < 0 ? SLICE_N_LIMIT : std::min<uint64_t>(ctx->opt_slice_n ? (uint64_t)ctx->opt_slice_n : SLICE_N_DEFAULT, SLICE_N_LIMIT);
+  const uint64_t slice_min = ctx->opt_slice_n < 0 ? SLICE_N_LIMIT + 1 : (ctx->opt_slice_min ? (uint64_t)ctx->opt_slice_min : slice_n + slice_n / 4);
+  if (segs.total < slice_min && segs.total <= SLICE_N_LIMIT) return 1;
+  const uint64_t cap = std::min<uint64_t>(slice_n + slice_n / 16, SLICE_N_LIMIT);       // a slice may be a sixteenth over (2^21 + 1 pairs: two slices, not three)
+  return std::max<uint64_t>(2, (segs.total + cap - 1) / cap);
+}
+static int msm_finish_pair(bpmi_ctx *ctx, uint8_t out0[64], uint8_t out1[64]);
+static int msm_run_sliced(bpmi_ctx *ctx, const Segs &segs, uint64_t K, uint8_t out[64]) {
+  for (int s = 0; s < 2; s++) if (ctx->pend[s].active || ctx->pend[s].async) return fail(ctx, BPMI_E_STATE, "an MSM is still pending in this slot (bpmi_msm_finish it first)");
+  int rc = ensure_lane(ctx, 1);
+  if (rc) return rc;
+  HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+  HIPCHK(ctx, hipStreamWaitEvent(ctx->stream1, ctx->ev_fork, 0));
+  const uint64_t total = segs.total, per = (total + K - 1) / K;
+  bpmi_host::pt acc;
+  bpmi_host::pt_set_inf(acc);
+  // an error in the middle leaves the OTHER lane's slice queued: drain both lanes and release the slots of THIS call, or every later
+  // MSM on this ctx would fail with "still pending"
+  unsigned mine = 0;
+  const bool chain = per >= (1u << 19);              // (the accumulations chained as in bpmi_msm_dev_enqueue: each has the chip)
+  auto leave = [&](int code) { ctx->chain_accum = false; ctx->accum_chain_lane = -1; if (code) msm_abandon_pending(ctx, mine); return code; };
+  auto take = [&](int slot) -> int {
+    uint8_t part[64];
+    mine &= ~(1u << slot);
+    const int r = msm_finish(ctx, slot, part);
+    if (r) return r;
+    bpmi_host::pt p;
+    bpmi_host::pt_from_affine(p, part);
+    bpmi_host::pt_add(acc, acc, p);
+    return BPMI_OK;
+  };
+  ctx->accum_chain_lane = -1;
+  for (uint64_t k = 0; k < K; k++) {
+    const int lane = (int)(k & 1);
+    if (k >= 2) { rc = take(lane); if (rc) return leave(rc); }
+    const uint64_t lo = k * per, cnt = std::min<uint64_t>(per, total - lo);
+    ctx->chain_accum = chain;
+    rc = msm_enqueue(ctx, lane, lane, segs_slice(segs, lo, cnt));
+    ctx->chain_accum = false;
+    if (rc) return leave(rc);
+    mine |= 1u << lane;
+  }
+  {
+    // the last two slices: their host tails side by side (the second on the ctx's helper thread, msm_finish_pair), oldest first in the sum
+    uint8_t part[2][64];
+    mine = 0;
+    rc = msm_finish_pair(ctx, part[0], part[1]);
+    if (rc) return leave(rc);
+    for (uint64_t k = K - 2; k < K; k++) {
+      bpmi_host::pt p;
+      bpmi_host::pt_from_affine(p, part[k & 1]);
+      bpmi_host::pt_add(acc, acc, p);
+    }
+  }
+  bpmi_host::pt_to_affine(out, acc);
+  return leave(BPMI_OK);
+}
 static int msm_run(bpmi_ctx *ctx, const Segs &segs, uint8_t out[64]) {
   if (segs.total > BPMI_MAX_N) return fail(ctx, BPMI_E_ARG, "n exceeds BPMI_MAX_N");
+  {
+    const uint64_t K = msm_slice_count(ctx, segs);
+    if (K > 1) return msm_run_sliced(ctx, segs, K, out);
+  }
   if (ctx->opt_split == 1 && segs.total >= 2) return msm_run_split(ctx, segs, out);
   int rc = msm_enqueue(ctx, 0, 0, segs);
   if (rc) return rc;
@@ -723,11 +843,13 @@ static int msm_run_pair(bpmi_ctx *ctx, const Segs &s0, uint8_t out0[64], const S
     if (rc == BPMI_OK) rc = msm_enqueue(ctx, 1, 1, s1, 0, 0, 1);
     if (rc) { msm_abandon_pending(ctx, 0u); return rc; }        // (nothing pending yet: only drains the lanes)
   }
+  ctx->beside = ctx->opt_pair_rounds != 1 && s0.total >= (1u << 19) && s1.total >= (1u << 19);      // (msm_pick_geometry: multi-round chunks)
   rc = msm_enqueue(ctx, 0, 0, s0, 0, 0, phases ? 2 : 0);
   if (rc == BPMI_OK) {
     rc = msm_enqueue(ctx, 1, 1, s1, 0, 0, phases ? 2 : 0);
     if (rc) msm_abandon_pending(ctx, 1u);
   }
+  ctx->beside = false;
   if (chain) { ctx->chain_accum = false; ctx->accum_chain_lane = -1; }
   if (rc) return rc;
   return msm_finish_pair(ctx, out0, out1);

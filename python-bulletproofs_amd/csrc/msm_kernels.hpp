@@ -14,7 +14,7 @@ struct MsmGeom {
   u32 G;       // W * B
   u32 L;       // entries per thread in k_accum_l0
   u32 nv;      // partial sums per window that the bucket reduction hands to the tail (1 or 4)
-  u32 prio;    // 1: every kernel but the accumulation raises its waves' issue priority (see raise_priority)
+  u32 prio;    // mask of the stages (PRIO_*) whose kernels raise their waves' issue priority (see raise_priority)
   u32 fuse;    // 1: k_accum_l0 folds the partial records of a wave's 64 chunks itself (two records per WAVE go to k_segscan, not two per thread)
   u32 top2;    // Wb, the number of WIDE windows (round 5): the last Wb of the W windows have c + 1 bits and 2B buckets each, chosen so that
                // (W - Wb) c + Wb (c + 1) = 256 -- the windows cover exactly the 256 bit positions, the top bit of a folded scalar (< 2^255)
@@ -29,6 +29,14 @@ struct MsmGeom {
 // five-fold (k_digit_final: 66 us alone, 320 us beside k_accum_l0).  Raising their waves' issue priority with s_setprio was
 // expected to bring the lane behind them to its own accumulation sooner; measured, two MSMs in flight get 2.6 % (2^20) to
 // 6 % (2^16) SLOWER -- the accumulation's waves lose more than the chains gain.
+// Round 6: re-measured on the multi-round accumulation (chunks of ~30 entries: the accumulation's wave slots turn over while it runs, so the
+// other lane's kernels are RESIDENT beside it and what they lack is issue slots, not occupancy): the finish of the reduction took 276 + 154 us
+// beside an accumulation instead of 18 + 21 alone, and with the priority raised two MSMs in flight gain 2 % on top of the short chunks' 5.6 %
+// (profiles/r06_wave_priority_and_chunk_ab.txt).  MsmGeom.prio is a mask of the stages that raise it:
+#define PRIO_SORT 1u          // recoding, partition, level B of the sort
+#define PRIO_SCAN 2u          // segmented scan over the partial records
+#define PRIO_SUMS 4u          // stage 1 of the bucket reduction (throughput-bound: 2^20 general additions)
+#define PRIO_FINISH 8u        // the reduction's finish on quads of lanes (latency-bound chains)
 __device__ __forceinline__ void raise_priority(u32 on) { if (on) __builtin_amdgcn_s_setprio(3); }
 // mixed window widths (MsmGeom.top2 = Wb): is window w one of the wide ones, and the first key / partition of window w in units of B / (B >> 8)
 __device__ __forceinline__ u32 geom_wide(const MsmGeom &g, u32 w) { return (g.top2 && w + g.top2 >= g.W) ? 1u : 0u; }
@@ -124,7 +132,7 @@ __global__ void __launch_bounds__(256) k_glv_prepare(Segs segs, u32 n, u32 *__re
 // dig[w * n + i] = |d| | (sign << 31); histogram with one atomic per lane, or one per wave
 // when the whole wave agrees (degenerate inputs)
 __global__ void __launch_bounds__(256) k_digits_hist(Segs segs, MsmGeom g, u32 *__restrict__ dig, u32 *__restrict__ hist) {
-  raise_priority(g.prio);
+  raise_priority(g.prio & PRIO_SORT);
   const u32 stride = gridDim.x * blockDim.x;
   for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < g.n; i += stride) {
     for_each_digit(segs, g, i, [&](u32 w, u32 b, u32 sign) {
@@ -165,7 +173,7 @@ __global__ void __launch_bounds__(256) k_digits_hist(Segs segs, MsmGeom g, u32 *
 struct CoarseScanOut { u32 *coarse_off, *coarse_cursor, *offG, *ticket; };
 __global__ void __launch_bounds__(1024) k_coarse_hist(Segs segs, MsmGeom g, u32 P, u32 *coarse_hist, unsigned short *__restrict__ dig16,
                                                      unsigned char *__restrict__ negs, CoarseScanOut scan) {
-  raise_priority(g.prio);
+  raise_priority(g.prio & PRIO_SORT);
   __shared__ u32 lh[PART_MAX];
   __shared__ u32 s_last;
   for (u32 p = threadIdx.x; p < P; p += blockDim.x) lh[p] = 0;
@@ -247,7 +255,7 @@ __global__ void __launch_bounds__(1024) k_coarse_scan(const u32 *__restrict__ co
 __global__ void __launch_bounds__(1024) k_partition(MsmGeom g, u32 P, u32 TS, const u32 *__restrict__ coarse_off, u32 *__restrict__ coarse_cursor,
                                                     const unsigned short *__restrict__ dig16, const unsigned char *__restrict__ negs,
                                                     u32 *__restrict__ part, u32 *__restrict__ fine_hist, u32 *__restrict__ any_heavy) {
-  raise_priority(g.prio);
+  raise_priority(g.prio & PRIO_SORT);
   __shared__ u32 cnt[128], excl[128], delta[128];
   __shared__ u32 s_out[PT_MAX];
   const u32 w = blockIdx.y, tid = threadIdx.x;
@@ -357,7 +365,7 @@ __device__ __forceinline__ u32 lds_take_slot(u32 *bins, u32 bin) {
 __global__ void __launch_bounds__(FINE_THREADS) k_fine_sort_part(MsmGeom g, const u32 *__restrict__ coarse_off, const u32 *__restrict__ part,
                                                                   const u32 *__restrict__ fine_hist, u32 *__restrict__ off, u32 *__restrict__ cursor,
                                                                   u32 *__restrict__ chunk_key, u32 *__restrict__ sidx, u32 *__restrict__ buckets) {
-  raise_priority(g.prio);
+  raise_priority(g.prio & PRIO_SORT);
   __shared__ u32 bins[256];
   __shared__ u32 s_out[FINE_CAP];
   const u32 p = blockIdx.x, tid = threadIdx.x;
@@ -450,7 +458,7 @@ __device__ __forceinline__ u32 fine_partition_of(const u32 *s_off, u32 P, u32 pc
 }
 __global__ void __launch_bounds__(256) k_fine_hist_heavy(MsmGeom g, u32 P, const u32 *__restrict__ coarse_off, const u32 *__restrict__ part,
                                                          const u32 *__restrict__ offE, const u32 *__restrict__ any_heavy, u32 *__restrict__ fine_hist) {
-  raise_priority(g.prio);
+  raise_priority(g.prio & PRIO_SORT);
   __shared__ u32 s_off[PART_MAX + 1];
   __shared__ u32 bins[FINE_BINS];
   if (!*any_heavy) return;
@@ -476,7 +484,7 @@ __global__ void __launch_bounds__(256) k_fine_hist_heavy(MsmGeom g, u32 P, const
 __global__ void __launch_bounds__(256) k_fine_scatter_heavy(MsmGeom g, u32 P, const u32 *__restrict__ coarse_off, const u32 *__restrict__ part,
                                                             const u32 *__restrict__ offE, const u32 *__restrict__ any_heavy, u32 *__restrict__ cursor,
                                                             u32 *__restrict__ sidx) {
-  raise_priority(g.prio);
+  raise_priority(g.prio & PRIO_SORT);
   __shared__ u32 s_off[PART_MAX + 1];
   __shared__ u32 bins[FINE_BINS];
   if (!*any_heavy) return;
@@ -514,7 +522,7 @@ __global__ void __launch_bounds__(256) k_fine_scatter_heavy(MsmGeom g, u32 P, co
 }
 // path 1 equivalent of the chunk-key fill: one thread per bucket
 __global__ void __launch_bounds__(256) k_chunk_keys(MsmGeom g, const u32 *__restrict__ off, u32 *__restrict__ chunk_key) {
-  raise_priority(g.prio);
+  raise_priority(g.prio & PRIO_SORT);
   const u32 key = blockIdx.x * blockDim.x + threadIdx.x;
   const bool valid = key < g.G;
   const u32 lo = valid ? off[key] : 0u, hi = valid ? off[key + 1] : 0u;
@@ -585,7 +593,7 @@ __global__ void __launch_bounds__(256) k_scan_final(const u32 *__restrict__ hist
 // ---- counting-sort scatter (path 1) ---------------------------------------------------
 __global__ void __launch_bounds__(256) k_scatter(MsmGeom g, const u32 *__restrict__ dig, u32 *__restrict__ cursor,
                                                  u32 *__restrict__ sidx) {
-  raise_priority(g.prio);
+  raise_priority(g.prio & PRIO_SORT);
   const u32 stride = gridDim.x * blockDim.x;
   for (u32 w = 0; w < g.W; w++) {
     for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < g.n; i += stride) {
@@ -778,7 +786,7 @@ __device__ __forceinline__ u32 records_at_level(u32 E, u32 L, u32 fuse, int leve
 __global__ void __launch_bounds__(256) k_segscan(MsmGeom g, const u32 *__restrict__ off, int level,
                                                  const u32 *in_key, const u32 *in_pt,
                                                  u32 *out_key, u32 *out_pt, u32 *__restrict__ buckets, u32 *ticket) {
-  raise_priority(g.prio);
+  raise_priority(g.prio & PRIO_SCAN);
   __shared__ u32 s_key[256];
   __shared__ u32 s_val[256 * LDS_STRIDE];
   __shared__ u32 s_last;
@@ -1272,7 +1280,7 @@ __global__ void __launch_bounds__(256) k_debug_quad_add(const u32 *__restrict__ 
 // 2 log2(B) dependent additions) -- shorter than the digit-sum stages when B is small.
 // Eout[w] then has nv = 1.
 __global__ void __launch_bounds__(256) k_window_weighted_small(MsmGeom g, const u32 *__restrict__ buckets, u32 *__restrict__ Eout) {
-  raise_priority(g.prio);
+  raise_priority(g.prio & PRIO_FINISH);
   __shared__ u32 s_val[256 * LDS_STRIDE];
   const u32 tid = threadIdx.x, w = blockIdx.x;
   xyzz val;

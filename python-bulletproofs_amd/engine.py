@@ -141,6 +141,14 @@ class Engine:
         self._ck(self.lib.bpmi_msm_finish(self.ctx, slot, out))
         return out.raw
 
+    def msm_geometry(self, n, pipelined=False):
+        """What an MSM of n pairs runs as under the current options (bpmi_msm_geometry): a dict with the kernel family, window bits,
+        windows (and how many are one bit wider), buckets, chunk length, slices and pairs per slice.  No GPU work."""
+        g = (ctypes.c_uint32 * 8)()
+        self._ck(self.lib.bpmi_msm_geometry(self.ctx, n, 1 if pipelined else 0, g))
+        return {"kernel": ("pipeline", "small", "mid")[g[0]] if n else None, "window_bits": g[1], "windows": g[2], "wide_windows": g[3],
+                "buckets": g[4], "chunk": g[5], "slices": g[6], "pairs_per_slice": g[7]}
+
     def ec_mul_batch_bytes(self, pts, scalars, n):
         out = ctypes.create_string_buffer(64 * n)
         self._ck(self.lib.bpmi_ec_mul_batch(self.ctx, pts, scalars, n, out))

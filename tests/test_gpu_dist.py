@@ -84,6 +84,15 @@ def test_bench_eight_ranks_time_sharing_this_gpu_with_every_extra():
     assert ex["C5_batch_verify_per_gpu_batches"]["batch"] == 8 * 256 and ex["C5_batch_verify_per_gpu_batches"]["accepted"] is True
     assert ex["C3_ipa_prover"]["rounds"] == 12 and ex["C3_ipa_prover"]["deterministic"] is True
     assert ex["C4_aggregated_range_proof"]["verified"] is True
+    # the record's tail: `summary` is the LAST key of the line, compact, and shows every config; BASELINE's second metric at the top level
+    sm = out["summary"]
+    assert list(out)[-1] == "summary" and len(json.dumps(sm)) < 600, sm
+    assert sm["result_ok_all"] is True and sm["checks"] >= 8
+    for k in ("ms_per_step", "C2_ms_one", "C2_ms_two", "C2_ms_three", "C3_s", "C4_prove_s", "C4_verify_s", "C5_verifies_per_s", "C5_one_batch_ms", "prover_proofs_per_s"):
+        assert isinstance(sm[k], (int, float)) and sm[k] > 0, (k, sm)
+    assert isinstance(sm["C5_link_GBps"], float) and sm["C5_link_GBps"] >= 0 and ex["C5_batch_verify"]["link"]["bytes_per_batch"] > 0      # (a rank's share of 256 proofs: megabytes per second)
+    assert sm["C5_link_peak_GBps"] == 63.0 and out["value2"] == ex["C5_batch_verify"]["value"] and out["unit2"] == "verifies/s"
+    assert out["alu_roofline"]["geometry"]["windows"] >= 16
     # strong scaling as the headline of its own run
     out = _bench_line(cmd + ["--scaling", "strong", "--no-extra"], env, 900)
     assert out["scaling"] == "strong" and out["n_ranks_seen"] == 8 and out["result_ok"] is True and out["config"]["pairs_per_gpu"] == (1 << 14) // 8

@@ -235,15 +235,22 @@ def test_msm_2e24_periodic_inputs(gp):
     es = b"".join(rnd.randrange(Q).to_bytes(32, "little") for _ in range(m))
     small = eng.msm_bytes(pts, es, m)
     d_p, d_e = eng.upload(pts * reps), eng.upload(es * reps)
-    big = eng.msm_dev(d_p, d_e, m * reps)
-    d_p.free()
-    d_e.free()
-    assert big == eng.ec_mul_batch_bytes(small, (reps).to_bytes(32, "little"), 1)
+    try:
+        big = eng.msm_dev(d_p, d_e, m * reps)            # round 6: sixteen slices of 2^20 pairs, two in flight
+        eng.set_option("window_bits", 16)                # forced window bits: ONE MSM, on the global-atomic sort beyond 2^23 pairs
+        one = eng.msm_dev(d_p, d_e, m * reps)
+    finally:
+        eng.set_option("window_bits", 0)
+        d_p.free()
+        d_e.free()
+    want = eng.ec_mul_batch_bytes(small, (reps).to_bytes(32, "little"), 1)
+    assert big == want
+    assert one == want
 
 
 def test_msm_sliced_above_2e23(gp):
-    """n > 2^23 runs as slices of 2^23 pairs on alternating lanes whose results are added
-    (bpmi_msm_dev).  Size-independent check: with the points tiled from D distinct ones,
+    """n > 2^23 runs as slices on alternating lanes whose results are added (bpmi_msm_dev; round 6: nine slices of ~2^20 pairs,
+    and with slice_n = -1 the round-1 geometry: slices of 2^23).  Size-independent check: with the points tiled from D distinct ones,
     MSM(tiled, e) == MSM(distinct, column sums of e mod q); ragged last slice."""
     import numpy as np
     eng = gp.engine()
@@ -271,7 +278,10 @@ def test_msm_sliced_above_2e23(gp):
         got = eng.msm_dev(d_pts, d_e, n)
         assert got == cbind.msm_bytes(small, cbind.pack_scalars(folded), D)
         assert got == eng.msm_dev(d_pts, d_e, n)
+        eng.set_option("slice_n", -1)
+        assert got == eng.msm_dev(d_pts, d_e, n)
     finally:
+        eng.set_option("slice_n", 0)
         d_pts.free()
         d_e.free()
 
