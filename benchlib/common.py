@@ -56,16 +56,22 @@ def isa_counts():
 
 
 def committed_traffic(logn):
-    """Per-launch HBM bytes of the dominant kernel from the committed rocprofv3 --pmc passes (NOT measured in this run)."""
-    for name in ("r05_pmc_traffic_msm_n2e20.json", "r04_pmc_traffic_msm_n2e20.json", "r03_pmc_traffic_msm_n2e20.json", "r02_pmc_traffic_msm_n2e20.json", "r01_pmc_traffic_msm_n2e20.json"):
+    """Per-launch HBM bytes of the dominant kernel from the committed rocprofv3 --pmc passes (NOT measured in this run):
+    (raw bytes, guide-corrected bytes, source).  The RAW figure (FETCH_SIZE + WRITE_SIZE as counted) is the one reported as
+    `roofline.traffic`: the guide's x2 correction of FETCH_SIZE is calibrated on wide coalesced streaming reads (128-B requests tallied
+    at 64 B), and this kernel's reads are 64-B gathers -- the bytes it REQUESTS are 1.14 GB per launch, below the corrected 3.25 GB and
+    consistent with the raw 1.67 GB (VERDICT r05 weak #3).  The corrected figure is reported beside it."""
+    for name in ("r06_pmc_traffic_msm_n2e20.json", "r05_pmc_traffic_msm_n2e20.json", "r04_pmc_traffic_msm_n2e20.json", "r03_pmc_traffic_msm_n2e20.json",
+                 "r02_pmc_traffic_msm_n2e20.json", "r01_pmc_traffic_msm_n2e20.json"):
         try:
             with open(os.path.join(REPO, "profiles", name)) as f:
                 for row in json.load(f)["kernels"]:
                     if row["kernel"] == "k_accum_l0" and logn == 20:
-                        return row["hbm_bytes_per_launch_guide_corrected"], "profiles/%s (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes; committed file, not this run)" % name
+                        return (row.get("hbm_bytes_per_launch_raw"), row["hbm_bytes_per_launch_guide_corrected"],
+                                "profiles/%s (FETCH_SIZE + WRITE_SIZE, separate --pmc passes; committed file, not this run)" % name)
         except (OSError, KeyError, ValueError):
             pass
-    return None, None
+    return None, None, None
 
 
 # ---- extra: config C5, batch verification of 2^14 64-bit range proofs -----------------------------

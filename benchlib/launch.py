@@ -116,4 +116,34 @@ def run_extras(extras, call_args, gather, rank, sync=lambda: None):
 
 def c5_inflight(usable, world):
     """Batches in flight of the C5 extra: every slot is a host thread of its rank (BENCH_C5_INFLIGHT overrides)."""
-    return max(1, int(os.environ.get("BENCH_C5_INFLIGHT", "0")) or min(8, max(2, usable // world)))
+    return max(1, int(os.environ.get("BENCH_C5_INFLIGHT", "0")) or min(8, max(3, usable // world)))
+
+
+def strong_depth(pairs_per_rank):
+    """MSMs to keep in flight on a rank whose shard has this many pairs: three below 185 000 (the window table's last step; measured
+    0.14 against 0.18 ms per MSM at 2^16 with two), two above (three lose 2 % at 2^20: profiles/r05_pipeline_depth_ab.txt)."""
+    return 3 if pairs_per_rank < 185000 else 2
+
+
+def pipelined_exchange_loop(enqueue, finish, combine_begin, combine_wait, steps, depth, exchange=True):
+    """`steps` MSMs through `depth` rotating slots: slot j % depth holds MSM j; MSM j + depth - 1 is queued before MSM j is finished, the
+    exchange of MSM j's partial is started behind it and collected one iteration later (a rank never waits for the fold before it has fed
+    its GPU the next MSM).  enqueue(slot), finish(slot) -> 64 bytes, combine_begin(bytes) -> handle, combine_wait(handle) -> 64 bytes.
+    Returns the LAST step's global result (exchange) or local partial (no exchange: the per-rank floor).  bench.py's MSM_strong line;
+    tests/test_distributed_cpu.py drives it over gloo with 2 and 8 ranks."""
+    res, pend = None, None
+    for j in range(min(steps, depth - 1)):
+        enqueue(j % depth)
+    for j in range(steps):
+        if j + depth - 1 < steps:
+            enqueue((j + depth - 1) % depth)
+        part = finish(j % depth)
+        if exchange:
+            if pend is not None:
+                res = combine_wait(pend)
+            pend = combine_begin(part)
+        else:
+            res = part
+    if exchange and pend is not None:
+        res = combine_wait(pend)
+    return res

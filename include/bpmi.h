@@ -26,8 +26,8 @@
  *     its own ctx (the HIP runtime does not survive a fork either);
  *   - points handed in through HOST pointers are checked to be the identity or on the curve (option "validate_points", default 1;
  *     BPMI_E_ARG names the first bad index and no result is written).  Points behind DEVICE pointers are the caller's
- *     responsibility unless the option is 2: PRECONDITION -- each is 64 zero bytes or (x, y) with x, y < p and y^2 = x^3 + 7;
- *     anything else gives an unspecified (never out-of-bounds) result;
+ *     responsibility unless the option is 2: each must be 64 zero bytes or (x, y) with x, y < p and y^2 = x^3 + 7; anything else
+ *     gives an unspecified (never out-of-bounds) result;
  *   - `*_dev` variants take DEVICE pointers (hipMalloc'd, or torch tensors'
  *     data_ptr()) on the ctx's device and enqueue on the ctx's stream; results
  *     written to host pointers are complete when the call returns;
@@ -80,7 +80,7 @@ int bpmi_sync(bpmi_ctx *ctx);
  *   "chunk"        sorted entries added per thread in the accumulate kernel
  *   "tail"         where the O(256) sequential window-combine tail runs: 1 device kernel,
  *                  2 host thread (default; the result is consumed on the host anyway)
- *   "small_n"      largest n that runs on the one-launch small-MSM kernel (-1: never; default 4096)
+ *   "small_n"      largest n that runs on the one-launch small-MSM kernel (-1: never; default 4608)
  *   "split"        1: run one MSM as two window groups on the ctx's two lanes (default 0)
  *   "async_lanes"  1: slot s of bpmi_msm_dev_enqueue runs on the ctx's lane s (own stream and workspace; three lanes), so
  *                  the tail stages of one MSM overlap the sort / accumulate of the next (inputs must be complete
@@ -95,8 +95,17 @@ int bpmi_sync(bpmi_ctx *ctx);
  *                  upload is not sliced: every kernel's duration is then its own; 1 default
  *   "glv"          1: the bucket pipeline runs on GLV-split scalars (2n pairs of 128-bit scalars, half the windows).  An
  *                  experiment that lost (profiles/r03_glv_msm_on_off.txt); default 0 = off
- *   "priority"     1: the MSM's latency-bound stages raise their waves' issue priority (s_setprio).  An experiment that lost
- *                  (profiles/r03_wave_priority_ab.txt); default 0
+ *   "priority"     the MSM's stages around the accumulation raise their waves' issue priority (s_setprio 3): 0 none, 1 (default from round 6) all of
+ *                  them, 16 + mask the stages of the mask (1 sort, 2 segmented scan, 4 stage 1 of the bucket reduction, 8 its finish).  Beside round
+ *                  3's one-round accumulation it lost (profiles/r03_wave_priority_ab.txt); beside the multi-round one ("rounds") it gains 2-8 %
+ *                  with two MSMs in flight (profiles/r06_wave_priority_and_chunk_ab.txt)
+ *   "rounds"       where another MSM's kernels run beside an accumulation (the asynchronous pipeline, the slices of a large MSM, a synchronous
+ *                  pair from 2^19 pairs) its chunk length is ceil(W n / (64 x 3072 x rounds)), at least 20: `rounds` rounds of three waves per
+ *                  SIMD.  0 (default) 3; 1: rounds 2-5's one-round accumulation (86 entries at 2^20).  "pair_rounds" = 1 keeps one round for pairs
+ *   "pair_sched"   1: a synchronous pair of MSMs of 2^19 pairs or more as both sorts, then the accumulations one after the other.  Measured
+ *                  neutral (profiles/r06_C3_pair_sched_ab.txt); default 0
+ *   "accum_stream" / "lane_priority" / "accum_chain"   round-6 experiments on WHERE the pipeline's accumulations are queued (a low-priority stream
+ *                  of their own; queue priorities of the lanes; unchained lanes): nothing measurable (profiles/r06_accum_stream_and_chunk_ab.txt); off
  *   "spin_wait"    polls of a completion event before the calling thread sleeps in the runtime (per ctx; default 0)
  *   "mul_batch_glv" bpmi_ec_mul_batch[_dev] from 32 768 points: 1 (default) GLV halves on fixed signed three-bit windows over affine
  *                  3P, 5P, 7P (k_ec_odd_multiples + k_ec_mul_batch_glv; workspace 1 080 B per point of a 196 608-point slice);
@@ -123,7 +132,7 @@ int bpmi_sync(bpmi_ctx *ctx);
  *                  bpmi_ipa_verify_dev and of the batch verifier) runs as ceil(n / (slice_n 17/16)) equal slices, two in flight on the ctx's
  *                  lanes 0 / 1 with their accumulations chained, the slices' results added on the host: the engine peaks at ~2^20 pairs per
  *                  MSM (profiles/r06_msm_big_n.txt).  0 (default) 2^20; 2^16 .. 2^23; -1: one MSM up to the sort's 2^23-pair limit
- *   "slice_min"    ... the size from which it does: 0 (default) 1.25 x slice_n
+ *   "slice_min"    ... the size from which it does: 0 (default) 1.625 x slice_n, the measured crossover of one MSM against two slices
  *   "mid_parts"    blocks per window of the one-block-per-window kernel (k_msm_mid: MSMs of 1 536 .. 8 448 pairs in the inner-product rounds,
  *                  2 560 .. 8 448 one at a time): 0 (default) three from 3 000 pairs, else one; 1 .. 4 forced.  Every part leaves its own window
  *                  sum, the host tail adds them (profiles/r05_mid_kernel_parts_ab.txt: C4's argument 4.05 -> 3.2 ms)
@@ -377,8 +386,8 @@ int bpmi_rp_batch_verify_dev(bpmi_ctx *ctx, uint32_t n_gens, uint32_t values_per
  *   bpmi_rp_prover_create   nbits: a power of two in [2, 128]; g, h, u: 64-byte points; gs, hs: nbits points each.  Builds the tables
  *                           (windows of "prover_table_bits" bits, default 12: 378 MB of device memory and ~70 ms for 64-bit proofs;
  *                           8 bits: 34 MB, 16 ms, 28 % slower proving) and keeps them for the prover's lifetime.
- *                           PRECONDITION: the points are on the curve (the Python layer's Point constructor checked them).
- *   bpmi_rp_prove_batch     values, gammas: n_proofs x 32 B little-endian, in [0, q) (of a value only the low nbits bits enter the
+ *                           The points are checked to be on the curve (option "validate_points" >= 1, the default): BPMI_E_ARG names the first bad one.
+ *   bpmi_rp_prove_batch     values, gammas: n_proofs x 32 B little-endian, in [0, q) -- checked: BPMI_E_ARG names the first index that is not -- (of a value only the low nbits bits enter the
  *                           proof, as in rangeproof_prover.py:40); seeds: proof i's transcript seed = seeds[seed_off[i] .. seed_off[i+1])
  *                           (at most 65 535 bytes).  out[out_off[i] .. out_off[i+1]) = proof i in wire format 2
  *                           (python-bulletproofs_amd/rangeproofs/codec.py; bpmi_rp_wire_v2_to_v1 expands it, bpmi_rp_batch_verify_dev

@@ -147,6 +147,7 @@ int bpmi_set_option(bpmi_ctx *ctx, const char *name, int64_t value) {
   if (!strcmp(name, "window_bits")) { if (value != 0 && (value < 2 || value > 16)) return fail(ctx, BPMI_E_ARG, "window_bits must be 0 or 2..16"); ctx->opt_c = (int)value; return BPMI_OK; }
   if (!strcmp(name, "accum_stream")) { if (value < 0 || value > 2) return fail(ctx, BPMI_E_ARG, "accum_stream must be 0, 1 or 2"); ctx->opt_accum_stream = (int)value; return BPMI_OK; }
   if (!strcmp(name, "lane_priority")) { if (value < -1 || value > 1) return fail(ctx, BPMI_E_ARG, "lane_priority must be -1, 0 or 1"); ctx->opt_lane_prio = (int)value; return BPMI_OK; }
+  if (!strcmp(name, "pair_sched")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "pair_sched must be 0 or 1"); ctx->opt_pair_sched = (int)value; return BPMI_OK; }
   if (!strcmp(name, "rounds")) { if (value < 0 || value > 16) return fail(ctx, BPMI_E_ARG, "rounds must be 0 .. 16"); ctx->opt_rounds = (int)value; msm_graphs_clear(ctx); return BPMI_OK; }
   if (!strcmp(name, "pair_rounds")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "pair_rounds must be 0 or 1"); ctx->opt_pair_rounds = (int)value; return BPMI_OK; }
   if (!strcmp(name, "accum_chain")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "accum_chain must be 0 or 1"); ctx->opt_accum_chain = (int)value; return BPMI_OK; }
@@ -1202,11 +1203,15 @@ int bpmi_ipa_fold(bpmi_ipa *st, const uint8_t x[32], const uint8_t xinv[32]) {
           // Option ipa_fixed_generators: the generators of a deployment are constants, and so are the tables of their odd multiples
           // (3P, 5P, 7P and the beta x column: 1.1 ms of k_ec_odd_multiples at 2^20).  They are kept between proofs that name the SAME
           // caller arrays (bpmi_ipa_create_dev: d_g, d_h, n) -- the caller's promise that the arrays have not changed.
-          const bool kept = ctx->opt_ipa_fixed && st->src_g && ctx->fold_key_g == st->src_g && ctx->fold_key_h == st->src_h && ctx->fold_key_n == npts && !st->hscale;
+          // Only a fold whose input IS the caller's unfolded arrays (the first one: M == n0) may keep or reuse tables: a second 16-way fold (n0 >= 16
+          // big_m) runs over the already folded, challenge-dependent bases, and tables recorded under (src_g, src_h, n0 / 16) would be served to a later
+          // proof over a PREFIX of the same generator arrays.
+          const bool from_source = ctx->opt_ipa_fixed && st->src_g && !st->hscale && st->M == st->n0;
+          const bool kept = from_source && ctx->fold_key_g == st->src_g && ctx->fold_key_h == st->src_h && ctx->fold_key_n == npts;
           if (!kept) {
             hipLaunchKernelGGL(k_ec_odd_multiples<ODDMUL_PER_THREAD>, dim3((u32)((2 * nthr + 255) / 256)), dim3(256), 0, ctx->stream, st->g, st->h, (u32)npts, tab_a, tab_b, scr,
                                tabx_a, tabx_b);
-            if (ctx->opt_ipa_fixed && st->src_g && !st->hscale) { ctx->fold_key_g = st->src_g; ctx->fold_key_h = st->src_h; ctx->fold_key_n = npts; }
+            if (from_source) { ctx->fold_key_g = st->src_g; ctx->fold_key_h = st->src_h; ctx->fold_key_n = npts; }
             else ctx->fold_key_g = ctx->fold_key_h = nullptr;
           }
           hipLaunchKernelGGL(k_ec_multifold_w4g, dim3((u32)((2 * st->n + 255) / 256)), dim3(256), 0, ctx->stream, ja, jb, tab_a, tab_b, tabx_a, tabx_b,

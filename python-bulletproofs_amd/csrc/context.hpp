@@ -120,6 +120,8 @@ struct bpmi_ctx {
   // round 6
   int opt_slice_n = 0;                  // an MSM of more than slice_min pairs runs as slices of about this many, two in flight (0 = 2^20, -1 = only beyond the sort's 2^23 limit; msm_host.hpp)
   int opt_slice_min = 0;                // ... the size from which it does (0 = default: 1.25 x slice_n)
+  int opt_pair_sched = 0;               // 1: a synchronous pair of large MSMs as both sorts, then the accumulations one after the other (msm_run_pair).  Measured neutral
+                                        // (profiles/r06_C3_pair_sched_ab.txt): off
   int opt_rounds = 0;                   // rounds of three waves per SIMD of an accumulation that shares the chip with another MSM's kernels (0 = 3; msm_host.hpp)
   int opt_pair_rounds = 0;              // 1: a synchronous pair of large MSMs keeps round 5's one-round chunks (A/B)
   bool beside = false;                  // set by msm_run_pair around its enqueues

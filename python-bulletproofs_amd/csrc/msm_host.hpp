@@ -442,7 +442,7 @@ static int msm_enqueue(bpmi_ctx *ctx, int lane, int slot, const Segs &segs_in, u
   // Round 6 experiment (option "accum_stream"): on the chained pipeline every accumulation runs on ONE stream of its own, created with the
   // LOWEST queue priority, between two events of its lane -- the accumulations are in order by construction, and the lanes' sort and
   // reduction kernels sit on queues the dispatcher prefers whenever a wave slot frees up (with "chunk" below the one-round length the
-  // accumulation's slots turn over while it runs).  profiles/r06_accum_stream_ab.txt
+  // accumulation's slots turn over while it runs).  profiles/r06_accum_stream_and_chunk_ab.txt
   const bool own_acc = ctx->chain_accum && ctx->opt_accum_stream && ctx->stream_acc;
   hipStream_t st_acc = own_acc ? ctx->stream_acc : st;
   if (own_acc) {
@@ -622,7 +622,7 @@ static int msm_run_split(bpmi_ctx *ctx, const Segs &segs, uint8_t out[64]) {
 // (/root/reference/src/innerproduct/inner_product_verifier.py:134-139: 2^21 + 1 at config C3's size).  One MSM of more than ~2^20 pairs
 // runs BELOW the 2^20 rate here (7.75-8.3 x 10^8 pairs/s at 2^21 .. 2^24 against 1.0 x 10^9, profiles/r03_msm_big_n.txt): its 64-byte
 // gathers, once per window, no longer fit the Infinity Cache, and one MSM at a time leaves the chip to the sort and to the bucket
-// reduction for 0.3 ms per MSM.  So an input of more than slice_min pairs is cut into K = ceil(total / (slice_n 17/16)) equal slices,
+// reduction for 0.3 ms per MSM.  So an input of slice_min (1.625 slice_n) pairs or more is cut into K = ceil(total / (slice_n 17/16)) equal slices,
 // which run as the two-deep pipeline of bench.py's headline (lanes 0 / 1, the accumulations chained): the sort and the reduction of one
 // slice beside the accumulation of the other, the host tail of slice k under the kernels of slice k + 1.  The slices' affine results
 // are added on the host (XYZZ, one inversion).  Options "slice_n" (0 = 2^20; -1 = never slice below the sort's 2^23 limit) and
@@ -647,7 +647,7 @@ static uint64_t msm_slice_count(const bpmi_ctx *ctx, const Segs &segs) {
   // (forced window bits, window groups, half-block selections: ONE MSM whatever its size -- beyond 2^23 pairs on the global-atomic sort)
   if (!segs_dense(segs) || ctx->opt_c || ctx->opt_split) return 1;
   const uint64_t slice_n = ctx->opt_slice_n < 0 ? SLICE_N_LIMIT : std::min<uint64_t>(ctx->opt_slice_n ? (uint64_t)ctx->opt_slice_n : SLICE_N_DEFAULT, SLICE_N_LIMIT);
-  const uint64_t slice_min = ctx->opt_slice_n < 0 ? SLICE_N_LIMIT + 1 : (ctx->opt_slice_min ? (uint64_t)ctx->opt_slice_min : slice_n + slice_n / 4);
+  const uint64_t slice_min = ctx->opt_slice_n < 0 ? SLICE_N_LIMIT + 1 : (ctx->opt_slice_min ? (uint64_t)ctx->opt_slice_min : slice_n + slice_n / 2 + slice_n / 8);      // (measured crossover of one MSM against two slices: ~1.65 x 2^20 pairs)
   if (segs.total < slice_min && segs.total <= SLICE_N_LIMIT) return 1;
   const uint64_t cap = std::min<uint64_t>(slice_n + slice_n / 16, SLICE_N_LIMIT);       // a slice may be a sixteenth over (2^21 + 1 pairs: two slices, not three)
   return std::max<uint64_t>(2, (segs.total + cap - 1) / cap);
@@ -829,28 +829,38 @@ static int msm_run_pair(bpmi_ctx *ctx, const Segs &s0, uint8_t out0[64], const S
   HIPCHK(ctx, hipStreamWaitEvent(ctx->stream1, ctx->ev_fork, 0));
   // (chaining the pair's accumulate kernels with the event of the asynchronous pipeline was measured on the IPA's 2^20-sized
   // rounds: 2.43 ms per round against 2.35 -- with only two MSMs there is no steady state to pipeline)
-  const bool chain = ctx->opt_pair_chain && s0.total >= (1u << 19) && s1.total >= (1u << 19);
+  const bool big = s0.total >= (1u << 19) && s1.total >= (1u << 19);
+  // Round 6 experiment (option "pair_sched", off): a pair of LARGE MSMs as  sort 0 | sort 1 -> accumulation 0 -> accumulation 1 (reduction 0
+  // beside it) -> reduction 1.  Queued one whole MSM after the other, the second MSM's sort meets the first one's accumulation and crawls
+  // beside it (k_partition -- 1 024-thread blocks with 67 KB of LDS -- 1 025 us instead of 60, the accumulation beside it 1 126 instead of
+  // 780: profiles/r06_C3_big_round_timeline.txt); with the schedule every kernel runs at its own speed (same file, second half) and the
+  // round takes exactly as long: 2.41-2.57 ms either way, 23.9 / 25.6 against 24.4 / 24.6 ms per proof (profiles/r06_C3_pair_sched_ab.txt).
+  // A pair has no steady state: two sorts (0.3 ms) + two accumulations (0.78 + 0.95 with the first reduction beside the second) + the last
+  // reduction + the host tail IS the round, however it is interleaved -- what round 4 found for "pair_phases" and round 3 for "pair_chain".
+  const bool sched = ctx->opt_pair_sched && big && !ctx->opt_graph;
+  const bool chain = sched || (ctx->opt_pair_chain && big);
   if (chain) { ctx->chain_accum = true; ctx->accum_chain_lane = -1; }
-  // Round 4 experiment (option "pair_phases", off): both sorts first, then both accumulations.  Queued one MSM after the other, the
-  // second MSM's sort meets the first one's accumulation -- a one-round kernel that holds every wave slot of the chip -- and crawls
-  // (k_fine_sort_part 463 us instead of 100, profiles/r04_C3_big_round_timeline.txt); with the sorts up front the two accumulations
-  // share the chip from the start and both reductions run at the end.  Measured: NO difference (2.336 / 2.330 against 2.343 / 2.319 ms
-  // for a round of the 2^20-element prover, profiles/r04_C3_pair_phases_ab.txt) -- the round is the sum of its stages' work whichever
-  // way they are interleaved, which also settles what ONE pass over both MSMs (32 windows) could have gained.
-  const bool phases = ctx->opt_pair_phases && !chain && !ctx->opt_graph && s0.total >= (1u << 15) && s1.total >= (1u << 15);
+  ctx->beside = ctx->opt_pair_rounds != 1 && big;      // (msm_pick_geometry: multi-round chunks; the same geometry in both phases)
+  auto leave = [&](int code) { ctx->beside = false; if (chain) { ctx->chain_accum = false; ctx->accum_chain_lane = -1; } return code; };
+  // Round 4 experiment (option "pair_phases", off): both sorts first, then both accumulations, nothing else ordered.  Measured: NO difference
+  // (2.336 / 2.330 against 2.343 / 2.319 ms for a round of the 2^20-element prover, profiles/r04_C3_pair_phases_ab.txt)
+  const bool phases = sched || (ctx->opt_pair_phases && !chain && !ctx->opt_graph && s0.total >= (1u << 15) && s1.total >= (1u << 15));
   if (phases) {
     rc = msm_enqueue(ctx, 0, 0, s0, 0, 0, 1);
     if (rc == BPMI_OK) rc = msm_enqueue(ctx, 1, 1, s1, 0, 0, 1);
-    if (rc) { msm_abandon_pending(ctx, 0u); return rc; }        // (nothing pending yet: only drains the lanes)
+    if (rc) { msm_abandon_pending(ctx, 0u); return leave(rc); }        // (nothing pending yet: only drains the lanes)
+    if (sched) {                                         // lane 0's accumulation behind lane 1's sort as well
+      hipError_t e = hipEventRecord(ctx->ev_join, ctx->stream1);
+      if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0);
+      if (e != hipSuccess) { msm_abandon_pending(ctx, 0u); return leave(fail(ctx, BPMI_E_HIP, std::string("msm_run_pair: ") + hipGetErrorString(e))); }
+    }
   }
-  ctx->beside = ctx->opt_pair_rounds != 1 && s0.total >= (1u << 19) && s1.total >= (1u << 19);      // (msm_pick_geometry: multi-round chunks)
   rc = msm_enqueue(ctx, 0, 0, s0, 0, 0, phases ? 2 : 0);
   if (rc == BPMI_OK) {
     rc = msm_enqueue(ctx, 1, 1, s1, 0, 0, phases ? 2 : 0);
     if (rc) msm_abandon_pending(ctx, 1u);
   }
-  ctx->beside = false;
-  if (chain) { ctx->chain_accum = false; ctx->accum_chain_lane = -1; }
+  leave(0);
   if (rc) return rc;
   return msm_finish_pair(ctx, out0, out1);
 }

@@ -17,6 +17,7 @@ struct bpmi_rp_prover {
   u32 u_new[16];                               // x_ip u, affine words
   void *buf = nullptr; size_t buf_bytes = 0;   // the batch's device arrays (grown on demand)
   void *pin = nullptr; size_t pin_bytes = 0;   // page-locked staging of the inputs / the proofs
+  hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};      // phase boundaries of a batch, created once with the prover
   double last_ms[8] = {0};                     // device milliseconds of the last batch: blind+A/S | y,z+T | x+final+P_new | rounds | emit+copy | total
 };
 
@@ -57,11 +58,26 @@ void bpmi_rp_prover_destroy(bpmi_rp_prover *pv) {
   if (pv->d_ip_prefix) (void)hipFree(pv->d_ip_prefix);
   if (pv->buf) (void)hipFree(pv->buf);
   if (pv->pin) (void)hipHostFree(pv->pin);
+  for (auto e : pv->ev) if (e) (void)hipEventDestroy(e);
   delete pv;
 }
 
+static int rp_prover_create_impl(bpmi_ctx *ctx, uint32_t nbits, const uint8_t g[64], const uint8_t h[64], const uint8_t u[64], const uint8_t *gs, const uint8_t *hs,
+                                 bpmi_rp_prover **out, bpmi_rp_prover *&partial);
+// (the C ABI never throws: a failed host allocation inside -- the 64 (3 + 2n)-byte point list, the base lists, a std::string -- is BPMI_E_NOMEM)
 int bpmi_rp_prover_create(bpmi_ctx *ctx, uint32_t nbits, const uint8_t g[64], const uint8_t h[64], const uint8_t u[64], const uint8_t *gs, const uint8_t *hs,
                           bpmi_rp_prover **out) {
+  bpmi_rp_prover *partial = nullptr;
+  try {
+    return rp_prover_create_impl(ctx, nbits, g, h, u, gs, hs, out, partial);
+  } catch (const std::bad_alloc &) {
+    if (partial) bpmi_rp_prover_destroy(partial);
+    if (out) *out = nullptr;
+    return ctx ? fail(ctx, BPMI_E_NOMEM, "bpmi_rp_prover_create: out of host memory") : BPMI_E_NOMEM;
+  }
+}
+static int rp_prover_create_impl(bpmi_ctx *ctx, uint32_t nbits, const uint8_t g[64], const uint8_t h[64], const uint8_t u[64], const uint8_t *gs, const uint8_t *hs,
+                                 bpmi_rp_prover **out, bpmi_rp_prover *&partial) {
   if (!ctx || !g || !h || !u || !gs || !hs || !out) return ctx ? fail(ctx, BPMI_E_ARG, "null argument") : BPMI_E_ARG;
   *out = nullptr;
   if (nbits < 2 || nbits > 128 || (nbits & (nbits - 1))) return fail(ctx, BPMI_E_ARG, "the bit width must be a power of two in [2, 128]");
@@ -75,11 +91,13 @@ int bpmi_rp_prover_create(bpmi_ctx *ctx, uint32_t nbits, const uint8_t g[64], co
     if (vrc) return vrc;
   }
   bpmi_rp_prover *pv = new bpmi_rp_prover();
+  partial = pv;
   pv->ctx = ctx; pv->n = nbits; pv->k = 0;
   while ((1u << pv->k) < nbits) pv->k++;
   const u32 n = nbits, nb = 3 + 2 * n;
   pv->nbases = nb;
-  auto bail = [&](int rc) { bpmi_rp_prover_destroy(pv); return rc; };
+  auto bail = [&](int rc) { bpmi_rp_prover_destroy(pv); partial = nullptr; return rc; };
+  for (int i = 0; i < 7; i++) { hipError_t ee = hipEventCreate(&pv->ev[i]); if (ee != hipSuccess) return bail(fail(ctx, BPMI_E_HIP, std::string("bpmi_rp_prover_create: ") + hipGetErrorString(ee))); }
   // the Protocol-1 challenge of the empty seed: transcript b"&" (inner_product_prover.py:33; transcript.py:13-14)
   {
     const uint8_t amp = '&';
@@ -157,6 +175,7 @@ int bpmi_rp_prover_create(bpmi_ctx *ctx, uint32_t nbits, const uint8_t g[64], co
   if (e == hipSuccess) e = hipMemcpy(pv->d_ip_prefix, pv->ip_prefix.data(), pv->ip_prefix.size(), hipMemcpyHostToDevice);
   if (e != hipSuccess) return bail(fail(ctx, BPMI_E_HIP, std::string("bpmi_rp_prover_create: ") + hipGetErrorString(e)));
   *out = pv;
+  partial = nullptr;
   return BPMI_OK;
 }
 
@@ -166,13 +185,35 @@ uint64_t bpmi_rp_prove_batch_proof_bytes(const bpmi_rp_prover *pv, uint64_t seed
   return 6 + 32 * (5 + k) + 33 * (6 + 2 * k) + 128 + 2 + seed_len + 2;
 }
 
+static int rp_prove_batch_impl(bpmi_rp_prover *pv, uint64_t n_proofs, const uint8_t *values, const uint8_t *gammas, const uint8_t *seeds, const uint64_t *seed_off,
+                               uint8_t *out, uint64_t cap, uint64_t *out_off);
 int bpmi_rp_prove_batch(bpmi_rp_prover *pv, uint64_t n_proofs, const uint8_t *values, const uint8_t *gammas, const uint8_t *seeds, const uint64_t *seed_off,
                         uint8_t *out, uint64_t cap, uint64_t *out_off) {
+  try {
+    return rp_prove_batch_impl(pv, n_proofs, values, gammas, seeds, seed_off, out, cap, out_off);
+  } catch (const std::bad_alloc &) {
+    return pv && pv->ctx ? fail(pv->ctx, BPMI_E_NOMEM, "bpmi_rp_prove_batch: out of host memory") : BPMI_E_NOMEM;
+  }
+}
+// a 32-byte little-endian value below the group order?  (the kernels' mod-q arithmetic takes reduced operands: taux = ... + z^2 gamma)
+static bool rp_scalar_reduced(const uint8_t le[32]) {
+  static const uint8_t QLE[32] = {0x41, 0x41, 0x36, 0xD0, 0x8C, 0x5E, 0xD2, 0xBF, 0x3B, 0xA0, 0x48, 0xAF, 0xE6, 0xDC, 0xAE, 0xBA,
+                                  0xFE, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF};
+  for (int i = 31; i >= 0; i--) if (le[i] != QLE[i]) return le[i] < QLE[i];
+  return false;
+}
+static int rp_prove_batch_impl(bpmi_rp_prover *pv, uint64_t n_proofs, const uint8_t *values, const uint8_t *gammas, const uint8_t *seeds, const uint64_t *seed_off,
+                               uint8_t *out, uint64_t cap, uint64_t *out_off) {
   if (!pv) return BPMI_E_ARG;
   bpmi_ctx *ctx = pv->ctx;
   if (!values || !gammas || !seed_off || !out || !out_off || (!seeds && seed_off[n_proofs] != seed_off[0])) return fail(ctx, BPMI_E_ARG, "null argument");
   if (n_proofs == 0) { out_off[0] = 0; return BPMI_OK; }
   if (n_proofs > (1u << 20)) return fail(ctx, BPMI_E_ARG, "at most 2^20 proofs per call");
+  // the reference's prover takes ModP values: reduced by construction (/root/reference/src/utils/utils.py:24-27); raw bytes are checked here
+  for (uint64_t p = 0; p < n_proofs; p++) {
+    if (!rp_scalar_reduced(values + 32 * p)) return fail(ctx, BPMI_E_ARG, "bpmi_rp_prove_batch: values[" + std::to_string(p) + "] is not below the group order");
+    if (!rp_scalar_reduced(gammas + 32 * p)) return fail(ctx, BPMI_E_ARG, "bpmi_rp_prove_batch: gammas[" + std::to_string(p) + "] is not below the group order");
+  }
   HIPCHK(ctx, hipSetDevice(ctx->device));
   const u32 P = (u32)n_proofs, n = pv->n, k = pv->k, npt = 6 + 2 * k;
   // the proofs' seeds: base64(seed) || '&' starts every range-proof transcript (transcript.py:13-14)
@@ -243,9 +284,7 @@ int bpmi_rp_prove_batch(bpmi_rp_prover *pv, uint64_t n_proofs, const uint8_t *va
   B.res = (u32 *)(d + o_res); B.xs = (u32 *)(d + o_xs); B.xr = (u32 *)(d + o_xr);
   B.a = (u32 *)(d + o_a); B.b = (u32 *)(d + o_b); B.cg = (u32 *)(d + o_cg); B.hf = (u32 *)(d + o_hf);
   B.jsc = (u32 *)(d + o_jsc); B.jout = (u32 *)(d + o_jout); B.pts = (u32 *)(d + o_pts);
-  hipEvent_t ev[7];
-  for (int i = 0; i < 7; i++) { ev[i] = nullptr; HIPCHK(ctx, hipEventCreate(&ev[i])); }
-  auto drop_events = [&]() { for (int i = 0; i < 7; i++) if (ev[i]) (void)hipEventDestroy(ev[i]); };
+  hipEvent_t *ev = pv->ev;
   auto blocks = [](uint64_t threads, u32 per) { return dim3((u32)((threads + per - 1) / per)); };
   auto msm = [&](u32 njobs, u32 ntypes, u32 T, u32 base_off, const u32 *scalars, u32 stride, int gl) {
     rpp::MsmJobs J;
@@ -294,11 +333,10 @@ int bpmi_rp_prove_batch(bpmi_rp_prover *pv, uint64_t n_proofs, const uint8_t *va
   if (e == hipSuccess) e = hipMemcpyAsync(hp, d + o_out, total_out, hipMemcpyDeviceToHost, st);
   if (e == hipSuccess) e = hipEventRecord(ev[6], st);
   if (e == hipSuccess) e = hipStreamSynchronize(st);
-  if (e != hipSuccess) { drop_events(); return fail(ctx, BPMI_E_HIP, std::string("bpmi_rp_prove_batch: ") + hipGetErrorString(e)); }
+  if (e != hipSuccess) return fail(ctx, BPMI_E_HIP, std::string("bpmi_rp_prove_batch: ") + hipGetErrorString(e));
   memcpy(out, hp, total_out);
   for (int i = 0; i < 6; i++) { float ms = 0; (void)hipEventElapsedTime(&ms, ev[i], ev[i + 1]); pv->last_ms[i] = ms; }
   { float ms = 0; (void)hipEventElapsedTime(&ms, ev[0], ev[6]); pv->last_ms[6] = ms; }
-  drop_events();
   return BPMI_OK;
 }
 

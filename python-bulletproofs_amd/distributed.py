@@ -60,6 +60,8 @@ class ShardedMSM:
         self.group = group
         self._comm = None
         self._inflight = False      # the RCCL exchange uses ONE set of staging buffers: one combine_begin at a time
+        self._ev = None
+        self.exchange_us_sum, self.exchange_count = 0.0, 0
 
     def _comm_setup(self, world):
         """(stream, engine on that stream, pinned 64-byte staging, device send buffer, device receive buffer)"""
@@ -101,18 +103,25 @@ class ShardedMSM:
                                    "its staging buffers are still in use")
             world = dist.get_world_size(self.group)
             stream, eng2, pin, mine, flat, d_out, pin_out = self._comm_setup(world)
-            # the exchange buffers live on the device the fold's ctx drives: a mismatch (a rank that changed its current device between
-            # two exchanges) would hand RCCL and the fold kernel pointers of another GPU
-            if not (mine.device.index == flat.device.index == d_out.device.index == eng2.device) or flat.numel() != 64 * world:
-                raise RuntimeError("ShardedMSM: exchange buffers on device %s / %s, fold ctx on device %s" % (mine.device, flat.device, eng2.device))
+            # The exchange buffers, the exchange stream and the fold's ctx were created on the device that was current at the FIRST exchange and
+            # are cached together (so they always agree with each other); what can drift is the process's CURRENT device -- RCCL would then run
+            # the collective with another current device than the one its buffers live on.  Checked at every exchange.
+            cur = torch.cuda.current_device()
+            if cur != eng2.device or flat.numel() != 64 * world:
+                raise RuntimeError("ShardedMSM: the exchange buffers and the fold ctx live on device %d, the current device is %d "
+                                   "(set the device once, before the first exchange)" % (eng2.device, cur))
             self._inflight = True
             pin.copy_(torch.frombuffer(bytearray(partial), dtype=torch.uint8))
+            if self._ev is None:
+                self._ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             with torch.cuda.stream(stream):
+                self._ev[0].record(stream)
                 mine.copy_(pin, non_blocking=True)
                 dist.all_gather_into_tensor(flat, mine, group=self.group)
                 # same stream: the fold is ordered behind the collective
                 eng2._ck(eng2.lib.bpmi_ec_sum_dev_enqueue(eng2.ctx, flat.data_ptr(), world, d_out.data_ptr()))
                 pin_out.copy_(d_out, non_blocking=True)
+                self._ev[1].record(stream)
             return ("rccl", None)
         return ("done", self.combine(partial))
 
@@ -123,7 +132,17 @@ class ShardedMSM:
         stream, pin_out = self._comm[0], self._comm[6]
         stream.synchronize()
         self._inflight = False
+        # device-side duration of the exchange: copy up, all_gather, fold kernel, copy down (waits for wave slots included)
+        self.exchange_us_sum += self._ev[0].elapsed_time(self._ev[1]) * 1e3
+        self.exchange_count += 1
         return bytes(pin_out.numpy().tobytes())
+
+    def exchange_us(self, reset=True):
+        """Mean device microseconds of the RCCL exchanges (combine_begin .. combine_wait) since the last reset; None if there were none."""
+        v = self.exchange_us_sum / self.exchange_count if self.exchange_count else None
+        if reset:
+            self.exchange_us_sum, self.exchange_count = 0.0, 0
+        return v
 
     def multiexp_replicated(self, pts: bytes, scalars: bytes, n: int) -> bytes:
         """Every rank holds the full input; each computes its shard, then combine()."""

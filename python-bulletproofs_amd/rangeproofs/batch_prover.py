@@ -25,7 +25,7 @@ def _le32(v):
 
 class BatchRangeProver:
     def __init__(self, n, g, h, gs, hs, u, engine=None):
-        """n: bits per value (a power of two up to 64); g, h, u: points; gs, hs: n points each.  Builds the fixed-base tables on the
+        """n: bits per value (a power of two in [2, 128]); g, h, u: points; gs, hs: n points each.  Builds the fixed-base tables on the
         engine's device (378 MB and ~70 ms for n = 64 with the default 12-bit windows; engine option prover_table_bits) and keeps them
         until close()."""
         if len(gs) != n or len(hs) != n:
@@ -75,7 +75,7 @@ class BatchRangeProver:
 
     def prove_wire(self, vs, gammas, seeds):
         packed, off = self.prove_wire_packed(vs, gammas, seeds)
-        return [packed[off[i]: off[i + 1]] for i in range(len(vs))]
+        return [packed[off[i]: off[i + 1]] for i in range(len(off) - 1)]          # (vs may be packed bytes: 32 per value)
 
     def prove(self, vs, gammas, seeds):
         """The proofs as Proof objects (every point decompressed in one more launch)."""

@@ -119,10 +119,61 @@ def ipa_mode(use_gpu):
     dist.destroy_process_group()
 
 
+def strong_mode():
+    """bench.py's MSM_strong line on gloo: ONE MSM split over the ranks, `depth` MSMs in flight through rotating slots
+    (benchlib.launch.pipelined_exchange_loop), the exchange of step j collected one iteration later; with and without the exchange (the
+    per-rank floor `expected_ms_per_step_if_ideal`).  A stand-in engine records the slot protocol: a slot is never queued twice without
+    being finished, never finished empty, and the rotation is j % depth."""
+    from benchlib.launch import pipelined_exchange_loop, strong_depth
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    Q = secp256k1.q
+    rnd = random.Random(99)
+    assert strong_depth(1 << 17) == 3 and strong_depth(184999) == 3 and strong_depth(185000) == 2 and strong_depth(1 << 20) == 2
+    n = 40
+    pts = cbind.ec_mul_batch([secp256k1.G] * n, [rnd.randrange(1, Q) for _ in range(n)])
+    pb = cbind.pack_points(pts)
+    for depth in (2, 3):
+        for steps in (1, 2, 3, 7):
+            # step j multiplies by scalars of its own: the result of the loop must be the LAST step's global MSM
+            scal = [[rnd.randrange(Q) for _ in range(n)] for _ in range(steps)]
+            lo, hi = shard_bounds(n, world, rank)
+            slots, log, queued = {}, [], [0]
+
+            def enqueue(slot):
+                assert slot not in slots, ("slot queued twice", slot)
+                j = queued[0]
+                queued[0] += 1
+                assert slot == j % depth
+                slots[slot] = cbind.msm_bytes(pb[64 * lo: 64 * hi], cbind.pack_scalars(scal[j][lo:hi]), hi - lo, 1)
+                log.append(("q", slot))
+
+            def finish(slot):
+                assert slot in slots, ("finish of an empty slot", slot)
+                log.append(("f", slot))
+                return slots.pop(slot)
+
+            sm = ShardedMSM(msm=lambda p, s, k: cbind.msm_bytes(p, s, k, 1), fold=oracle_fold)
+            got = pipelined_exchange_loop(enqueue, finish, sm.combine_begin, sm.combine_wait, steps, depth, True)
+            assert got == cbind.msm_bytes(pb, cbind.pack_scalars(scal[-1]), n, 1), (rank, depth, steps)
+            assert not slots and queued[0] == steps and max(sum(1 for k, _ in log[:i] if k == "q") - sum(1 for k, _ in log[:i] if k == "f")
+                                                            for i in range(len(log) + 1)) == min(depth, steps)
+            assert sm.exchange_us() is None                       # gloo: no device-side exchange to time
+            queued[0] = 0
+            local = pipelined_exchange_loop(enqueue, finish, sm.combine_begin, sm.combine_wait, steps, depth, False)
+            assert local == cbind.msm_bytes(pb[64 * lo: 64 * hi], cbind.pack_scalars(scal[-1][lo:hi]), hi - lo, 1)
+    dist.barrier()
+    if rank == 0:
+        print("DIST_STRONG_OK world=%d" % world)
+    dist.destroy_process_group()
+
+
 def main():
     mode = os.environ.get("BPMI_DIST_MODE")
     if mode == "batch":
         return batch_mode()
+    if mode == "strong":
+        return strong_mode()
     if mode in ("ipa", "ipa_gpu"):
         return ipa_mode(mode == "ipa_gpu")
     dist.init_process_group("gloo")

@@ -69,6 +69,14 @@ def test_two_rank_gloo_batch_verifier_strong_and_weak_lines():
     _run_ranks(2, "batch", 29531, "DIST_BATCH_OK")
 
 
+def test_strong_line_three_slot_rotation_on_two_and_eight_ranks():
+    """The MSM_strong line of `bench.py --gpus N`: two and THREE MSMs in flight through rotating slots with the exchange one step behind
+    (benchlib.launch.pipelined_exchange_loop), with and without the exchange, at world 2 and 8 (round 6: shards below 185 000 pairs
+    keep three in flight)."""
+    _run_ranks(2, "strong", 29533, "DIST_STRONG_OK")
+    _run_ranks(8, "strong", 29535, "DIST_STRONG_OK")
+
+
 def test_sharded_prover_rejects_a_non_cyclic_layout():
     """Unequal shard lengths that are not 'shorter than the ranks' must be a clear ValueError on every rank, not a torch
     buffer error from a collective."""

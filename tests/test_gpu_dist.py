@@ -79,6 +79,7 @@ def test_bench_eight_ranks_time_sharing_this_gpu_with_every_extra():
         assert "error" not in v and "errors_by_rank" not in v, (name, v)
     st = ex["MSM_strong"]
     assert st["scaling"] == "strong" and st["result_ok"] is True and st["pairs_per_gpu"] == (1 << 14) // 8 and len(st["ms_per_step_by_rank"]) == 8
+    assert st["msms_in_flight"] == 3 and st["expected_ms_per_step_if_ideal"] > 0 and st["exchange_us"] is None      # (gloo: no device-side exchange)
     assert ex["C5_batch_verify"]["accepted"] is True and ex["C5_batch_verify"]["corrupted_batch_rejected"] is True and ex["C5_batch_verify"]["batch"] == 256
     assert ex["C5_batch_verify"]["scaling"].startswith("strong") and ex["C5_batch_verify_per_gpu_batches"]["scaling"].startswith("weak")
     assert ex["C5_batch_verify_per_gpu_batches"]["batch"] == 8 * 256 and ex["C5_batch_verify_per_gpu_batches"]["accepted"] is True
@@ -124,6 +125,7 @@ def test_bench_collectives_on_rccl_with_one_rank():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     assert out["dist_backend"] == "nccl" and out["n_ranks_seen"] == 1 and out["result_ok"] is True
+    assert out["exchange_us"] > 0                           # the RCCL exchange's own device time: the reference for the first N = 8 line
     assert out["extra"]["C5_batch_verify"].get("accepted") is True and out["extra"]["C5_batch_verify"]["corrupted_batch_rejected"] is True
     assert out["extra"]["C3_ipa_prover"].get("rounds") == 20
 

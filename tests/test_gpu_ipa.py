@@ -235,6 +235,48 @@ def test_fixed_generators_keep_the_fold_tables_between_proofs(gp, n, big_m):
             d.free()
 
 
+def test_fixed_generators_second_fold_never_records_tables(gp):
+    """with n >= 16 big_m a proof reaches a SECOND 16-way fold, over the already folded, challenge-dependent bases.  Its tables
+    must not be recorded under the caller's arrays with length n / 16 -- a later proof over the first n / 16 generators of the same arrays
+    (a prefix is a natural call) would skip k_ec_odd_multiples and fold with stale tables.  n = 16 384, big_m = 64: folds at 16 384 and at
+    1 024; then a 1 024-element proof on the same pointers, against the option switched off."""
+    eng = gp.engine()
+    n = 1 << 14
+    pts, _ = gp.rand_points(2 * n + 1, 777)
+    g, h, u = cbind.pack_points(pts[:n]), cbind.pack_points(pts[n:2 * n]), cbind.pack_points([pts[2 * n]])
+    d_g, d_h = eng.upload(g), eng.upload(h)
+
+    def run(nn, seed):
+        r = random.Random(seed)
+        d_a = eng.upload(cbind.pack_scalars([r.randrange(Q) for _ in range(nn)]))
+        d_b = eng.upload(cbind.pack_scalars([r.randrange(Q) for _ in range(nn)]))
+        st = eng.ipa_create_dev(d_g, d_h, d_a, d_b, nn, u)
+        trace = []
+        for _ in range(nn.bit_length() - 1):
+            trace.append(st.round_LR())
+            x = r.randrange(1, Q)
+            st.fold(x, pow(x, -1, Q))
+        trace.append(st.finish())
+        st.close()
+        d_a.free(); d_b.free()
+        return trace
+
+    try:
+        eng.set_option("ipa_big_m", 64)
+        eng.set_option("ipa_small_m", 1)
+        want_big, want_small = run(n, 1), run(n // 16, 2)
+        eng.set_option("ipa_fixed_generators", 1)
+        assert run(n, 1) == want_big                       # two folds; only the first may record its tables
+        assert run(n // 16, 2) == want_small               # the prefix: its first fold has length n / 16 and must build its own tables
+        assert run(n // 16, 2) == want_small               # ... which ARE kept now
+        assert run(n, 1) == want_big
+    finally:
+        eng.set_option("ipa_fixed_generators", 0)
+        eng.set_option("ipa_big_m", 0)
+        eng.set_option("ipa_small_m", 0)
+        d_g.free(); d_h.free()
+
+
 @pytest.mark.parametrize("n,small_m", [(1024, 64), (1 << 14, 1024), (1 << 16, 0)])
 def test_product_fold_shared_scalars_equals_per_lane_products(gp, n, small_m):
     """The two forms of the product fold -- shared GLV halves in non-adjacent form with two terms per thread (k_ec_fold_glv, the

@@ -24,7 +24,7 @@ def gp():
 @pytest.fixture()
 def small_slices(gp):
     eng = gp.engine()
-    eng.set_option("slice_n", 1 << 16)            # slice_min = 81 920, a slice may be 69 632 pairs
+    eng.set_option("slice_n", 1 << 16)            # slice_min = 106 496, a slice may be 69 632 pairs
     yield eng
     eng.set_option("slice_n", 0)
     eng.set_option("slice_min", 0)
@@ -33,7 +33,7 @@ def small_slices(gp):
 CAP = (1 << 16) + (1 << 12)
 
 
-@pytest.mark.parametrize("n", [81919, 81920, 2 * CAP, 2 * CAP + 1, 2 * CAP + 5, 3 * CAP + 2, 200001])
+@pytest.mark.parametrize("n", [106495, 106496, 2 * CAP, 2 * CAP + 1, 2 * CAP + 5, 3 * CAP + 2, 200001])
 def test_sliced_msm_boundaries_vs_oracle(gp, small_slices, n):
     """2 CAP: two full slices; 2 CAP + 1: three slices of ceil(n / 3) (the last one shorter); 200 001: three."""
     eng = small_slices
@@ -86,7 +86,7 @@ def test_sliced_msm_segments_straddle_slices(gp, small_slices):
     slice ends inside the second array."""
     eng = small_slices
     lib, ctx = eng.lib, eng.ctx
-    ns = [50000, 70001, 30000]
+    ns = [50000, 70001, 30000]          # 150 001 >= slice_min
     D = 1 << 10
     pts, _ = gp.rand_points(D, 31)
     small = cbind.pack_points(pts)
@@ -121,7 +121,7 @@ def test_sliced_msm_segments_straddle_slices(gp, small_slices):
 
 def test_sliced_msm_refuses_while_a_slot_is_pending(gp, small_slices):
     eng = small_slices
-    n = 90000
+    n = 120000
     pts, _ = gp.rand_points(256, 3)
     pb = cbind.pack_points(pts) * (n // 256 + 1)
     d_p, d_s = eng.upload(pb[: 64 * n]), eng.upload(bytes(32 * n))

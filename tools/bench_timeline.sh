@@ -1,6 +1,6 @@
 #!/bin/bash
 # The headline pipeline's kernel timeline: rocprofv3 --kernel-trace of a short bench run, three steady-state steps printed.
-#   bash tools/r04_bench_timeline.sh <outdir> [extra bench args]
+#   bash tools/bench_timeline.sh <outdir> [extra bench args]
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/${1:-gpurun_out/r04t}
 shift
