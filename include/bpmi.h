@@ -395,6 +395,12 @@ int bpmi_rp_batch_verify_dev(bpmi_ctx *ctx, uint32_t n_gens, uint32_t values_per
  *                           (of the longest seed).  At most 2^20 proofs per call; one call at a time per prover and ctx.
  *   bpmi_rp_prover_last_ms  device milliseconds of the last batch: A and S | y, z, T1, T2 | x, the vectors, P_new | the rounds of the
  *                           inner-product argument | the wire bytes | their copy to the host | the whole batch */
+/* The same for AGGREGATED proofs (round 6): a proof covers m values of nbits bits each (AggregNIRangeProver,
+ * /root/reference/src/rangeproofs/rangeproof_aggreg_prover.py:36-146); nbits and m powers of two with 2 <= nbits x m <= 128, gs and hs nbits x m
+ * points each; bpmi_rp_prove_batch then takes n_proofs x m values and blinding factors (proof p: entries p m .. p m + m - 1).  m = 1 is
+ * bpmi_rp_prover_create.  Longer vectors (the 128 x 64-bit proof of config C4) are the single-proof prover's: one proof fills the chip there. */
+int bpmi_rp_prover_create_aggregated(bpmi_ctx *ctx, uint32_t nbits, uint32_t m, const uint8_t g[64], const uint8_t h[64], const uint8_t u[64], const uint8_t *gs,
+                                     const uint8_t *hs, bpmi_rp_prover **out);
 int bpmi_rp_prover_create(bpmi_ctx *ctx, uint32_t nbits, const uint8_t g[64], const uint8_t h[64], const uint8_t u[64], const uint8_t *gs, const uint8_t *hs,
                           bpmi_rp_prover **out);
 void bpmi_rp_prover_destroy(bpmi_rp_prover *pv);

@@ -61,6 +61,7 @@ SIGNATURES = {
     "bpmi_rp_batch_prepare_dev": (_i, [_vp, ctypes.c_uint32, ctypes.c_uint32, _u64, _vp, _u64, _vp, _cp, _cp, _vp, _vp, _vp, _cp, _vp]),
     "bpmi_rp_batch_verify_dev": (_i, [_vp, ctypes.c_uint32, ctypes.c_uint32, _u64, _vp, _u64, _vp, _cp, _cp, _vp, _vp, _vp, _vp, _cp, _vp]),      # (v_points: bytes or a page-locked address)
     "bpmi_rp_prover_create": (_i, [_vp, ctypes.c_uint32, _cp, _cp, _cp, _cp, _cp, ctypes.POINTER(_vp)]),
+    "bpmi_rp_prover_create_aggregated": (_i, [_vp, ctypes.c_uint32, ctypes.c_uint32, _cp, _cp, _cp, _cp, _cp, ctypes.POINTER(_vp)]),
     "bpmi_rp_prover_destroy": (None, [_vp]),
     "bpmi_rp_prove_batch_proof_bytes": (_u64, [_vp, _u64]),
     "bpmi_rp_prove_batch": (_i, [_vp, _u64, _cp, _cp, _cp, _vp, _vp, _u64, _vp]),

@@ -6,7 +6,8 @@
 
 struct bpmi_rp_prover {
   bpmi_ctx *ctx = nullptr;
-  u32 n = 0, k = 0, nbases = 0;
+  u32 n = 0, k = 0, nbases = 0;                // n: elements of a proof's vectors = nb m
+  u32 nb = 0, m = 1;                           // bits per value, values per proof (m > 1: aggregated proofs)
   u32 *table = nullptr;                        // [(3 + 2n)][wt][bt] affine points
   u32 tw = 12, wt = 22, bt = 2048;             // table windows: tw bits, wt = ceil(256 / tw) per scalar, bt = 2^(tw-1) entries each
   unsigned short *bases = nullptr;             // device: the base lists of every job kind (offsets below, in entries)
@@ -62,25 +63,31 @@ void bpmi_rp_prover_destroy(bpmi_rp_prover *pv) {
   delete pv;
 }
 
-static int rp_prover_create_impl(bpmi_ctx *ctx, uint32_t nbits, const uint8_t g[64], const uint8_t h[64], const uint8_t u[64], const uint8_t *gs, const uint8_t *hs,
+static int rp_prover_create_impl(bpmi_ctx *ctx, uint32_t vbits, uint32_t m, const uint8_t g[64], const uint8_t h[64], const uint8_t u[64], const uint8_t *gs, const uint8_t *hs,
                                  bpmi_rp_prover **out, bpmi_rp_prover *&partial);
 // (the C ABI never throws: a failed host allocation inside -- the 64 (3 + 2n)-byte point list, the base lists, a std::string -- is BPMI_E_NOMEM)
-int bpmi_rp_prover_create(bpmi_ctx *ctx, uint32_t nbits, const uint8_t g[64], const uint8_t h[64], const uint8_t u[64], const uint8_t *gs, const uint8_t *hs,
-                          bpmi_rp_prover **out) {
+int bpmi_rp_prover_create_aggregated(bpmi_ctx *ctx, uint32_t nbits, uint32_t m, const uint8_t g[64], const uint8_t h[64], const uint8_t u[64], const uint8_t *gs,
+                                     const uint8_t *hs, bpmi_rp_prover **out) {
   bpmi_rp_prover *partial = nullptr;
   try {
-    return rp_prover_create_impl(ctx, nbits, g, h, u, gs, hs, out, partial);
+    return rp_prover_create_impl(ctx, nbits, m, g, h, u, gs, hs, out, partial);
   } catch (const std::bad_alloc &) {
     if (partial) bpmi_rp_prover_destroy(partial);
     if (out) *out = nullptr;
     return ctx ? fail(ctx, BPMI_E_NOMEM, "bpmi_rp_prover_create: out of host memory") : BPMI_E_NOMEM;
   }
 }
-static int rp_prover_create_impl(bpmi_ctx *ctx, uint32_t nbits, const uint8_t g[64], const uint8_t h[64], const uint8_t u[64], const uint8_t *gs, const uint8_t *hs,
+int bpmi_rp_prover_create(bpmi_ctx *ctx, uint32_t nbits, const uint8_t g[64], const uint8_t h[64], const uint8_t u[64], const uint8_t *gs, const uint8_t *hs,
+                          bpmi_rp_prover **out) {
+  return bpmi_rp_prover_create_aggregated(ctx, nbits, 1, g, h, u, gs, hs, out);
+}
+static int rp_prover_create_impl(bpmi_ctx *ctx, uint32_t vbits, uint32_t m, const uint8_t g[64], const uint8_t h[64], const uint8_t u[64], const uint8_t *gs, const uint8_t *hs,
                                  bpmi_rp_prover **out, bpmi_rp_prover *&partial) {
   if (!ctx || !g || !h || !u || !gs || !hs || !out) return ctx ? fail(ctx, BPMI_E_ARG, "null argument") : BPMI_E_ARG;
   *out = nullptr;
-  if (nbits < 2 || nbits > 128 || (nbits & (nbits - 1))) return fail(ctx, BPMI_E_ARG, "the bit width must be a power of two in [2, 128]");
+  if (vbits < 1 || vbits > 128 || (vbits & (vbits - 1)) || m < 1 || (m & (m - 1)) || (uint64_t)vbits * m < 2 || (uint64_t)vbits * m > 128)
+    return fail(ctx, BPMI_E_ARG, "the bit width and the number of values must be powers of two with 2 <= bits x values <= 128");
+  const uint32_t nbits = vbits * m;                      // elements of a proof's vectors
   HIPCHK(ctx, hipSetDevice(ctx->device));
   if (ctx->opt_validate >= 1) {
     int vrc = validate_host(ctx, g, 1, "bpmi_rp_prover_create", "g");
@@ -92,7 +99,7 @@ static int rp_prover_create_impl(bpmi_ctx *ctx, uint32_t nbits, const uint8_t g[
   }
   bpmi_rp_prover *pv = new bpmi_rp_prover();
   partial = pv;
-  pv->ctx = ctx; pv->n = nbits; pv->k = 0;
+  pv->ctx = ctx; pv->n = nbits; pv->nb = vbits; pv->m = m; pv->k = 0;
   while ((1u << pv->k) < nbits) pv->k++;
   const u32 n = nbits, nb = 3 + 2 * n;
   pv->nbases = nb;
@@ -210,7 +217,7 @@ static int rp_prove_batch_impl(bpmi_rp_prover *pv, uint64_t n_proofs, const uint
   if (n_proofs == 0) { out_off[0] = 0; return BPMI_OK; }
   if (n_proofs > (1u << 20)) return fail(ctx, BPMI_E_ARG, "at most 2^20 proofs per call");
   // the reference's prover takes ModP values: reduced by construction (/root/reference/src/utils/utils.py:24-27); raw bytes are checked here
-  for (uint64_t p = 0; p < n_proofs; p++) {
+  for (uint64_t p = 0; p < n_proofs * pv->m; p++) {
     if (!rp_scalar_reduced(values + 32 * p)) return fail(ctx, BPMI_E_ARG, "bpmi_rp_prove_batch: values[" + std::to_string(p) + "] is not below the group order");
     if (!rp_scalar_reduced(gammas + 32 * p)) return fail(ctx, BPMI_E_ARG, "bpmi_rp_prove_batch: gammas[" + std::to_string(p) + "] is not below the group order");
   }
@@ -234,7 +241,7 @@ static int rp_prove_batch_impl(bpmi_rp_prover *pv, uint64_t n_proofs, const uint
   using rpp_host::up256;
   size_t o = 0;
   auto take = [&](size_t bytes) { const size_t at = o; o += up256(bytes); return at; };
-  const size_t o_dig0 = take((size_t)P * dig0_stride), o_dlen = take(4ull * P), o_val = take(32ull * P), o_gam = take(32ull * P);
+  const size_t o_dig0 = take((size_t)P * dig0_stride), o_dlen = take(4ull * P), o_val = take(32ull * P * pv->m), o_gam = take(32ull * P * pv->m);
   const size_t o_seeds = take(seed_off[P] - seed_off[0] + 16), o_soff = take(8ull * (P + 1)), o_ooff = take(8ull * (P + 1));
   const size_t in_bytes = o;                                   // everything above is uploaded in one copy
   const size_t o_tr = take((size_t)P * tr_stride), o_trlen = take(4ull * P);
@@ -267,14 +274,14 @@ static int rp_prove_batch_impl(bpmi_rp_prover *pv, uint64_t n_proofs, const uint
   }
   ((uint64_t *)(hp + o_soff))[P] = seed_off[P] - seed_off[0];
   ((uint64_t *)(hp + o_ooff))[P] = out_off[P];
-  memcpy(hp + o_val, values, 32ull * P);
-  memcpy(hp + o_gam, gammas, 32ull * P);
+  memcpy(hp + o_val, values, 32ull * P * pv->m);
+  memcpy(hp + o_gam, gammas, 32ull * P * pv->m);
   if (seed_off[P] > seed_off[0]) memcpy(hp + o_seeds, seeds + seed_off[0], seed_off[P] - seed_off[0]);
   hipStream_t st = ctx->stream;
   HIPCHK(ctx, hipMemcpyAsync(d, hp, in_bytes, hipMemcpyHostToDevice, st));
   rpp::Batch B;
   memset(&B, 0, sizeof(B));
-  B.P = P; B.n = n; B.k = k; B.table = rpp::Tab{pv->table, pv->tw, pv->wt, pv->bt};
+  B.P = P; B.n = n; B.k = k; B.nb = pv->nb; B.m = pv->m; B.table = rpp::Tab{pv->table, pv->tw, pv->wt, pv->bt};
   B.dig0 = (const unsigned char *)(d + o_dig0); B.dig0_stride = dig0_stride; B.dig0_len = (const u32 *)(d + o_dlen);
   B.values = (const u32 *)(d + o_val); B.gammas = (const u32 *)(d + o_gam);
   B.ip_prefix = pv->d_ip_prefix; B.ip_prefix_len = (u32)pv->ip_prefix.size(); B.x_ip = pv->x_ip;

@@ -169,12 +169,16 @@ __device__ __noinline__ u32 put_number(u8 *dst, const sc v) {
 
 // ---- parameters of a batch ----------------------------------------------------------------------------------------------------------------
 // Device arrays of one batch (P proofs of n bits, k = log2 n).  Scalars: 8 words little-endian.  Points: 16 words (x, y) little-endian.
+// Round 6: AGGREGATED proofs (AggregNIRangeProver, /root/reference/src/rangeproofs/rangeproof_aggreg_prover.py:36-146): a proof covers m values of
+// nb bits, its vectors have n = nb m elements (element i = bit i % nb of value i / nb), z^2 2^i becomes z^(2 + i / nb) 2^(i % nb) (:85, :120-131)
+// and the blinding of taux is sum_j z^(2 + j) gamma_j (:138-142).  m = 1 is the single-value prover (rangeproof_prover.py:35-91).
 struct Batch {
   u32 P, n, k;
+  u32 nb, m;                 // bits per value, values per proof: n = nb m
   Tab table;                 // [(3 + 2n) bases][wt windows][bt] affine points: base 0 g, 1 h, 2 u, 3 + i gs_i, 3 + n + i hs_i
   const u8 *dig0;  u32 dig0_stride; const u32 *dig0_len;       // base64(seed) || '&' of every proof
-  const u32 *values;         // P scalars: v (only its low n bits are used, as in rangeproof_prover.py:40)
-  const u32 *gammas;         // P scalars
+  const u32 *values;         // P x m scalars: v (only its low nb bits are used, as in rangeproof_prover.py:40)
+  const u32 *gammas;         // P x m scalars
   const u8 *ip_prefix; u32 ip_prefix_len;                      // "&&" || str(x_ip) || "&": the Protocol-2 transcript before the first round
   sc x_ip;
   u32 u_new[16];             // x_ip u (inner_product_prover.py:37), the same for every proof
@@ -215,8 +219,21 @@ __global__ void __launch_bounds__(256) k_pv_table_scalars(const u32 *__restrict_
   ::store_words8(scal + 8ull * t, s);
 }
 
+// element i of a proof's bit vector aL: bit i % nb of value i / nb
+__device__ __forceinline__ u32 bit_of(const Batch &B, size_t p, u32 i) {
+  const u32 jv = i / B.nb, jb = i % B.nb;
+  return (B.values[8ull * (p * B.m + jv) + (jb >> 5)] >> (jb & 31u)) & 1u;
+}
+// z^(2 + e), e < m (a short loop: m is 1 for single-value proofs and a handful for aggregated ones)
+__device__ __forceinline__ sc z_pow2p(const sc &z, const sc &zz, u32 e) {
+  sc r = zz;
+  for (u32 t = 0; t < e; t++) r = mulq(r, z);
+  return r;
+}
+
 // ---- blinding scalars: one hash per lane ----------------------------------------------------------------------------------------------------
-// lane (p, i): i < 2n: s_i = mod_hash(str(i) || digest) (rangeproof_prover.py:50-57); i = 2n: rho = mod_hash(str(2n) || digest) (:58);
+// lane (p, i): i < 2n: s_i = mod_hash(str(i) || digest) (rangeproof_prover.py:50-57); i = 2n: rho = mod_hash(str(2 nb) || digest) (:58 -- the
+// aggregated prover hashes str(2 * n) with n the bits PER VALUE, rangeproof_aggreg_prover.py:62: rho then equals one of the s_i; kept as it is);
 // i = 2n + 1: alpha = mod_hash(b"alpha" || digest) (:48)
 __global__ void __launch_bounds__(256) k_pv_blind(Batch B) {
   const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -231,7 +248,7 @@ __global__ void __launch_bounds__(256) k_pv_blind(Batch B) {
     return;
   }
   u32 tl;
-  const u64 tag = tag_of_index(i, tl);
+  const u64 tag = tag_of_index(i == 2u * B.n ? 2u * B.nb : i, tl);
   st_sc(B.slr + 8ull * ((size_t)p * (2u * B.n + 1u) + i), mod_hash_q(tag, tl, dg, dl));
 }
 
@@ -295,9 +312,8 @@ __global__ void __launch_bounds__(256) k_pv_commit_A(Batch B, u32 *__restrict__ 
   xyzz acc;
   bpmi::xyzz_set_inf(acc);
   if (live) {
-    const sc v = ld_sc(B.values + 8ull * p);
     for (u32 i = l; i < B.n; i += 16u) {
-      const u32 bit = (v.v[i >> 5] >> (i & 31u)) & 1u;
+      const u32 bit = bit_of(B, p, i);
       const u32 base = bit ? 3u + i : 3u + B.n + i;
       affine Pt;
       ::load_affine(Pt, B.table.p + 16ull * ((size_t)base * B.table.wt * B.table.bt));          // window 0, d = 1: the generator itself
@@ -392,7 +408,7 @@ __device__ __forceinline__ sc sc_pow2(u32 e) {                // 2^e, e < 128
   return r;
 }
 // ---- t1, t2 (rangeproof_prover.py:93-101) -------------------------------------------------------------------------------------------------
-//   t1 = sum sL_i (y^i (aR_i + z) + z^2 2^i) + sum (aL_i - z) y^i sR_i,   t2 = sum sL_i y^i sR_i;   y^j is left in cg_j for k_pv_final_wide
+//   t1 = sum sL_i (y^i (aR_i + z) + z^(2 + i / nb) 2^(i % nb)) + sum (aL_i - z) y^i sR_i,   t2 = sum sL_i y^i sR_i;   y^j is left in cg_j for k_pv_final_wide
 __global__ void __launch_bounds__(256) k_pv_poly(Batch B) {
   __shared__ u32 s_v[256 * 8], s_w[256 * 8];
   const u32 n = B.n, tid = threadIdx.x;
@@ -400,15 +416,14 @@ __global__ void __launch_bounds__(256) k_pv_poly(Batch B) {
   const bool live = p < B.P;
   const size_t pc = live ? p : 0;                             // (lanes past the batch compute on proof 0 and store nothing)
   const sc y = ld_sc(B.chal + 32ull * pc), z = ld_sc(B.chal + 32ull * pc + 8);
-  const sc v = ld_sc(B.values + 8ull * pc);
   const sc one = sc_u32(1), zz = mulq(z, z);
   const sc yp = lane_product_scan(s_v, tid, j, n, j ? y : one);                  // y^j
   const u32 *slr = B.slr + 8ull * pc * (2u * n + 1u);
-  const u32 bit = (v.v[j >> 5] >> (j & 31u)) & 1u;
+  const u32 bit = bit_of(B, pc, j);
   const sc sL = ld_sc(slr + 8ull * j), sR = ld_sc(slr + 8ull * (n + j));
   const sc ysr = mulq(yp, sR);
-  // aR + z = z - 1 + bit;  aL - z = bit - z
-  sc c1 = mulq(sL, addq(mulq(yp, bit ? z : subq(z, one)), mulq(zz, sc_pow2(j))));
+  // aR + z = z - 1 + bit;  aL - z = bit - z;  the power of two: z^(2 + j / nb) 2^(j % nb)
+  sc c1 = mulq(sL, addq(mulq(yp, bit ? z : subq(z, one)), mulq(z_pow2p(z, zz, j / B.nb), sc_pow2(j % B.nb))));
   c1 = addq(c1, mulq(bit ? subq(one, z) : negq(z), ysr));
   const sc t1 = lane_tree_sum(s_v, tid, j, n, c1);
   const sc t2 = lane_tree_sum(s_w, tid, j, n, mulq(sL, ysr));
@@ -439,7 +454,11 @@ __global__ void __launch_bounds__(64) k_pv_final_chal(Batch B) {
   const u32 n = B.n;
   const u32 *slr = B.slr + 8ull * (size_t)p * (2u * n + 1u);
   const sc tau1 = ld_sc(B.tau + 16ull * p), tau2 = ld_sc(B.tau + 16ull * p + 8), alpha = ld_sc(B.alpha + 8ull * p), rho = ld_sc(slr + 8ull * (2u * n));
-  const sc taux = addq(addq(mulq(tau2, mulq(x, x)), mulq(tau1, x)), mulq(mulq(z, z), ld_sc(B.gammas + 8ull * p)));
+  sc taux = addq(mulq(tau2, mulq(x, x)), mulq(tau1, x));
+  {
+    sc zp = mulq(z, z);                                           // sum_j z^(2 + j) gamma_j (rangeproof_aggreg_prover.py:138-142; m = 1: z^2 gamma)
+    for (u32 jv = 0; jv < B.m; jv++) { taux = addq(taux, mulq(zp, ld_sc(B.gammas + 8ull * ((size_t)p * B.m + jv)))); zp = mulq(zp, z); }
+  }
   const sc mu = addq(alpha, mulq(rho, x));
   u32 *res = B.res + 40ull * p;
   st_sc(res, taux); st_sc(res + 8, mu);
@@ -454,15 +473,14 @@ __global__ void __launch_bounds__(256) k_pv_final_wide(Batch B) {
   const bool live = p < B.P;
   const size_t pc = live ? p : 0;
   const sc y_inv = ld_sc(B.chal + 32ull * pc + 24), z = ld_sc(B.chal + 32ull * pc + 8), x = ld_sc(B.chal + 32ull * pc + 16);
-  const sc v = ld_sc(B.values + 8ull * pc);
   const sc one = sc_u32(1);
   const sc yip = lane_product_scan(s_v, tid, j, n, j ? y_inv : one);             // y^-j
   const sc yp = ld_sc(B.cg + 8ull * (pc * n + j));                               // y^j (k_pv_poly)
   const u32 *slr = B.slr + 8ull * pc * (2u * n + 1u);
-  const u32 bit = (v.v[j >> 5] >> (j & 31u)) & 1u;
+  const u32 bit = bit_of(B, pc, j);
   const sc sL = ld_sc(slr + 8ull * j), sR = ld_sc(slr + 8ull * (n + j));
   const sc l = addq(bit ? subq(one, z) : negq(z), mulq(sL, x));                                          // aL - z + sL x
-  const sc r = addq(mulq(yp, addq(bit ? z : subq(z, one), mulq(sR, x))), mulq(mulq(z, z), sc_pow2(j)));   // y^j (aR + z + sR x) + z^2 2^j
+  const sc r = addq(mulq(yp, addq(bit ? z : subq(z, one), mulq(sR, x))), mulq(z_pow2p(z, mulq(z, z), j / B.nb), sc_pow2(j % B.nb)));   // y^j (aR + z + sR x) + z^(2 + j / nb) 2^(j % nb)
   const sc t_hat = lane_tree_sum(s_v, tid, j, n, mulq(l, r));
   if (!live) return;
   const size_t e = (size_t)p * n + j;

@@ -9,6 +9,12 @@ per prover, and the transcripts are hashed on the device.  Same proofs, byte for
     blobs = bp.prove_wire(vs, gammas, seeds)        # wire format 2 (rangeproofs/codec.py), one bytes object per proof
     proofs = bp.prove(vs, gammas, seeds)            # the same as Proof objects
     # blobs[i] == proof_to_bytes(NIRangeProver(vs[i], n, g, h, gs, hs, gammas[i], u, group, seeds[i]).prove(), version=2)
+
+Round 6: AGGREGATED proofs too -- a loop of AggregNIRangeProver(vs_i, n, g, h, gs, hs, gammas_i, u, group, seed_i).prove()
+(/root/reference/src/rangeproofs/rangeproof_aggreg_prover.py:36-146) over proofs of m values each, n m <= 128:
+
+    bp = BatchRangeProver(n, g, h, gs, hs, u, m=4)        # gs, hs: n m points
+    blobs = bp.prove_wire(vss, gammass, seeds)            # vss[i], gammass[i]: the m values / blinding factors of proof i
 """
 import ctypes
 
@@ -24,31 +30,41 @@ def _le32(v):
 
 
 class BatchRangeProver:
-    def __init__(self, n, g, h, gs, hs, u, engine=None):
-        """n: bits per value (a power of two in [2, 128]); g, h, u: points; gs, hs: n points each.  Builds the fixed-base tables on the
-        engine's device (378 MB and ~70 ms for n = 64 with the default 12-bit windows; engine option prover_table_bits) and keeps them
-        until close()."""
-        if len(gs) != n or len(hs) != n:
-            raise ValueError("gs and hs must have n points each")
-        self.n = n
+    def __init__(self, n, g, h, gs, hs, u, engine=None, m=1):
+        """n: bits per value, m: values per proof (powers of two, 2 <= n m <= 128; m = 1: single-value proofs); g, h, u: points; gs, hs:
+        n m points each.  Builds the fixed-base tables on the engine's device (378 MB and ~70 ms for n m = 64 with the default 12-bit
+        windows; engine option prover_table_bits) and keeps them until close()."""
+        if len(gs) != n * m or len(hs) != n * m:
+            raise ValueError("gs and hs must have n m points each")
+        self.n, self.m = n, m
         self._engine = engine or _engine.default_engine()
         eng = self._engine
         handle = ctypes.c_void_p()
-        eng._ck(eng.lib.bpmi_rp_prover_create(eng.ctx, n, g.to_le64(), h.to_le64(), u.to_le64(), b"".join(p.to_le64() for p in gs),
-                                              b"".join(p.to_le64() for p in hs), ctypes.byref(handle)))
+        eng._ck(eng.lib.bpmi_rp_prover_create_aggregated(eng.ctx, n, m, g.to_le64(), h.to_le64(), u.to_le64(), b"".join(p.to_le64() for p in gs),
+                                                         b"".join(p.to_le64() for p in hs), ctypes.byref(handle)))
         self._handle = handle.value
 
     def prove_wire_packed(self, vs, gammas, seeds):
         """(packed bytes, offsets): proof i = packed[offsets[i]: offsets[i + 1]], wire format 2 -- what
         BatchRangeVerifier.add_wire_native / bpmi_rp_batch_verify_dev take as they are.
-        vs, gammas: lists of ModP / int, or ALREADY PACKED bytes (32 bytes little-endian per value, reduced mod q): a service that
-        receives its inputs as bytes skips 2 x len Python conversions.  seeds: a list of bytes, or (joined bytes, offsets)."""
+        vs, gammas: lists of ModP / int (aggregated provers: a list of m values per proof), or ALREADY PACKED bytes (32 bytes
+        little-endian per value, reduced mod q, proof after proof): a service that receives its inputs as bytes skips 2 x len Python
+        conversions.  seeds: a list of bytes, or (joined bytes, offsets)."""
+        vm = self.m
+
+        def flat(xs):
+            if vm == 1 and not (len(xs) and isinstance(xs[0], (list, tuple))):
+                return xs
+            for row in xs:
+                if len(row) != vm:
+                    raise ValueError("every proof of this prover takes %d values" % vm)
+            return [x for row in xs for x in row]
         if isinstance(vs, (bytes, bytearray, memoryview)):
-            vb, m = bytes(vs), len(vs) // 32
+            vb, m = bytes(vs), len(vs) // (32 * vm)
         else:
             m = len(vs)
-            vb = b"".join([_le32(v) for v in vs])
-        gb = bytes(gammas) if isinstance(gammas, (bytes, bytearray, memoryview)) else b"".join([_le32(x) for x in gammas])
+            vb = b"".join([_le32(v) for v in flat(vs)])
+        gb = bytes(gammas) if isinstance(gammas, (bytes, bytearray, memoryview)) else b"".join([_le32(x) for x in flat(gammas)])
         if isinstance(seeds, tuple):
             sb, offs = seeds
             if len(offs) != m + 1:
@@ -64,7 +80,7 @@ class BatchRangeProver:
                 pos += len(sd)
             off[m] = pos
             sb = b"".join(seeds)
-        if len(vb) != 32 * m or len(gb) != 32 * m:
+        if len(vb) != 32 * m * vm or len(gb) != 32 * m * vm:
             raise ValueError("values, blinding factors and seeds must have the same length")
         eng = self._engine
         cap = m * eng.lib.bpmi_rp_prove_batch_proof_bytes(self._handle, 0) + (off[m] - off[0]) + 16      # a proof is a fixed part + its seed

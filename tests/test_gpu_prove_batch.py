@@ -100,6 +100,76 @@ def test_batch_prover_reproduces_the_reference_goldens(gp, k):
     check_range_proof(gp, pr[1], c["proof"])
 
 
+@pytest.mark.parametrize("n,m,count", [(16, 4, 150), (64, 2, 60), (8, 8, 70), (2, 2, 33), (32, 4, 25), (1, 2, 9), (4, 1, 17)])
+def test_batch_prover_aggregated_equals_single(gp, n, m, count):
+    """Round 6: batches of AGGREGATED proofs (m values of n bits per proof, n m <= 128): every proof byte-identical to the one
+    AggregNIRangeProver.prove (/root/reference/src/rangeproofs/rangeproof_aggreg_prover.py:36-146 behind the product's call surface) makes
+    for the same values, blinding factors, seed and generators -- including the reference's rho = mod_hash(str(2 n) ...) with n the bits
+    PER VALUE, values out of range, and edge values per slot -- and accepted by AggregRangeVerifier."""
+    from bulletproofs_amd.ec import secp256k1
+    from bulletproofs_amd.rangeproofs import AggregNIRangeProver, AggregRangeVerifier, BatchRangeProver, proof_to_bytes, proofs_from_bytes
+    from bulletproofs_amd.utils import ModP, commitment
+    g, h, gs, hs, u = _setup(gp, n * m, b"ag")
+    rnd = random.Random(7000 + 16 * n + m)
+    vss = [[ModP(rnd.randrange(1 << n), Q) for _ in range(m)] for _ in range(count)]
+    vss[0] = [ModP(0, Q)] * m
+    vss[1] = [ModP((1 << n) - 1, Q)] * m
+    vss[2] = [ModP((1 << n) - 1 if j % 2 else 0, Q) for j in range(m)]
+    if count > 8:
+        vss[5][m - 1] = ModP((1 << n) + 1, Q)                # out of range in the last slot: proved on its low n bits, must fail to verify
+    gss = [[ModP(rnd.randrange(Q), Q) for _ in range(m)] for _ in range(count)]
+    gss[3] = [ModP(0, Q)] * m
+    seeds = _seeds(count, rnd)
+    bp = BatchRangeProver(n, g, h, gs, hs, u, m=m)
+    try:
+        blobs = bp.prove_wire(vss, gss, seeds)
+        packed, off = bp.prove_wire_packed(b"".join(v.x.to_bytes(32, "little") for row in vss for v in row),
+                                           b"".join(x.x.to_bytes(32, "little") for row in gss for x in row), seeds)
+    finally:
+        bp.close()
+    assert [packed[off[i]: off[i + 1]] for i in range(count)] == blobs
+    step = 1 if count <= 40 else 3
+    for i in list(range(0, 6)) + list(range(6, count, step)):
+        if i >= count:
+            continue
+        if m == 1:
+            from bulletproofs_amd.rangeproofs import NIRangeProver
+            want = NIRangeProver(vss[i][0], n, g, h, gs, hs, gss[i][0], u, secp256k1, seeds[i]).prove()
+        else:
+            want = AggregNIRangeProver(vss[i], n, g, h, gs, hs, gss[i], u, secp256k1, seeds[i]).prove()
+        assert blobs[i] == proof_to_bytes(want, version=2), (n, m, i)
+    if m > 1:
+        proofs = proofs_from_bytes(blobs[:8])
+        for i in (0, 1, 2, 3, 4, 6):
+            Vs = [commitment(g, h, v, x) for v, x in zip(vss[i], gss[i])]
+            assert AggregRangeVerifier(Vs, g, h, gs, hs, u, proofs[i]).verify() is True
+        if count > 8:
+            Vs = [commitment(g, h, v, x) for v, x in zip(vss[5], gss[5])]
+            with pytest.raises(Exception, match="Proof invalid"):
+                AggregRangeVerifier(Vs, g, h, gs, hs, u, proofs[5]).verify()
+
+
+@pytest.mark.parametrize("k", [0, 1])
+def test_batch_prover_reproduces_the_reference_aggregated_goldens(gp, k):
+    """The aggregated goldens of tests/golden/rangeproofs.json that fit the batched prover (16 bits x 4 values, 64 x 2; the third, 16 x 32,
+    is 512 elements: the single-proof prover's): same values, blinding factors, seed and generators -> the golden's fields, twice in one batch."""
+    from bulletproofs_amd.rangeproofs import BatchRangeProver
+    from bulletproofs_amd.utils import ModP, mod_hash
+    from test_gpu_rangeproofs import check_range_proof, inputs
+    c = load_golden("rangeproofs.json")["aggregated"][k]
+    m = c["m"]
+    s, n, gs, hs, g, h, u = inputs(gp, c, m)
+    vs = [ModP(int(v, 16), Q) for v in c["vs"]]
+    gammas = [mod_hash(str(j).encode() + s[5], Q) for j in range(m)]
+    bp = BatchRangeProver(n, g, h, gs, hs, u, m=m)
+    try:
+        pr = bp.prove([vs, vs], [gammas, gammas], [s[6], s[6]])
+    finally:
+        bp.close()
+    check_range_proof(gp, pr[0], c["proof"])
+    check_range_proof(gp, pr[1], c["proof"])
+
+
 @pytest.mark.parametrize("bits", [4, 5, 7, 9, 10, 11, 12, 13])
 def test_batch_prover_table_windows(gp, bits):
     """The fixed-base tables with windows of 4 .. 13 bits (ctx option prover_table_bits, read when the prover is created; 8 is the
@@ -168,8 +238,16 @@ def test_batch_prover_argument_errors(gp):
     g, h, gs, hs, u = _setup(gp, 8)
     with pytest.raises(ValueError):
         BatchRangeProver(8, g, h, gs[:7], hs, u)
-    with pytest.raises(EngineError, match="power of two"):
+    with pytest.raises(EngineError, match="powers of two"):
         BatchRangeProver(3, g, h, gs[:3], hs[:3], u)
+    with pytest.raises(EngineError, match="powers of two"):
+        BatchRangeProver(2, g, h, gs[:6], hs[:6], u, m=3)
+    bp = BatchRangeProver(4, g, h, gs, hs, u, m=2)
+    try:
+        with pytest.raises(ValueError, match="takes 2 values"):
+            bp.prove_wire([[ModP(1, Q)]], [[ModP(1, Q)]], [b""])
+    finally:
+        bp.close()
     bp = BatchRangeProver(8, g, h, gs, hs, u)
     try:
         assert bp.prove_wire([], [], []) == []
