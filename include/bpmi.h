@@ -117,8 +117,9 @@ int bpmi_sync(bpmi_ctx *ctx);
  *                  (0 = default 4096, 1 = never, else a power of two; the later rounds then run on the one-launch small-MSM kernel)
  *   "pair_phases"  1: bpmi_msm2 on the bucket pipeline queues both MSMs' sorts before either accumulation.  An experiment that came out
  *                  neutral (profiles/r04_C3_pair_phases_ab.txt); default 0
- *   "prover_table_bits" window bits of the fixed-base tables a bpmi_rp_prover builds, read by bpmi_rp_prover_create: 0 = default 12, else 4 .. 13
- *                  (wider: fewer additions per scalar multiplication, a larger table; profiles/r05_batch_prover_table_bits.txt)
+ *   "prover_table_bits" window bits of the fixed-base tables a bpmi_rp_prover builds, read by bpmi_rp_prover_create: 0 = default 16, else 4 .. 16
+ *                  (wider: fewer additions per scalar multiplication, a larger table -- 16 bits: 64 KB x 32 768 entries per (generator, window),
+ *                  4.4 GB and 72 ms to build for 64-bit proofs; 12 bits: 378 MB, 17 ms, 22 % slower proving; profiles/r06_batch_prover_table_bits.txt)
  *   "ipa_fixed_generators" 1: the generator arrays handed to bpmi_ipa_create_dev are deployment constants.  The tables of odd multiples that
  *                  the prover's 16-way generator fold builds from them (1.1 ms at n = 2^20) are then kept between proofs for as long as the
  *                  calls name the same d_g, d_h and n: the caller's promise that the arrays were not modified.  Default 0
@@ -384,8 +385,8 @@ int bpmi_rp_batch_verify_dev(bpmi_ctx *ctx, uint32_t n_gens, uint32_t values_per
  * same proofs byte for byte -- but every protocol step is ONE launch over all proofs, every scalar multiplication a lookup in tables
  * of the fixed generators, and the Fiat-Shamir hashes run on the device.
  *   bpmi_rp_prover_create   nbits: a power of two in [2, 128]; g, h, u: 64-byte points; gs, hs: nbits points each.  Builds the tables
- *                           (windows of "prover_table_bits" bits, default 12: 378 MB of device memory and ~70 ms for 64-bit proofs;
- *                           8 bits: 34 MB, 16 ms, 28 % slower proving) and keeps them for the prover's lifetime.
+ *                           (windows of "prover_table_bits" bits, default 16: 4.4 GB of device memory and ~72 ms for 64-bit proofs;
+ *                           12 bits: 378 MB, 17 ms, 22 % slower proving) and keeps them for the prover's lifetime.
  *                           The points are checked to be on the curve (option "validate_points" >= 1, the default): BPMI_E_ARG names the first bad one.
  *   bpmi_rp_prove_batch     values, gammas: n_proofs x 32 B little-endian, in [0, q) -- checked: BPMI_E_ARG names the first index that is not -- (of a value only the low nbits bits enter the
  *                           proof, as in rangeproof_prover.py:40); seeds: proof i's transcript seed = seeds[seed_off[i] .. seed_off[i+1])

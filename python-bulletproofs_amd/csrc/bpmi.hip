@@ -148,6 +148,7 @@ int bpmi_set_option(bpmi_ctx *ctx, const char *name, int64_t value) {
   if (!strcmp(name, "accum_stream")) { if (value < 0 || value > 2) return fail(ctx, BPMI_E_ARG, "accum_stream must be 0, 1 or 2"); ctx->opt_accum_stream = (int)value; return BPMI_OK; }
   if (!strcmp(name, "lane_priority")) { if (value < -1 || value > 1) return fail(ctx, BPMI_E_ARG, "lane_priority must be -1, 0 or 1"); ctx->opt_lane_prio = (int)value; return BPMI_OK; }
   if (!strcmp(name, "pair_sched")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "pair_sched must be 0 or 1"); ctx->opt_pair_sched = (int)value; return BPMI_OK; }
+  if (!strcmp(name, "prover_split")) { if (value < 0 || value > (1 << 20)) return fail(ctx, BPMI_E_ARG, "prover_split must be 0, 1 or the smallest half"); ctx->opt_prover_split = (int)value; return BPMI_OK; }
   if (!strcmp(name, "rounds")) { if (value < 0 || value > 16) return fail(ctx, BPMI_E_ARG, "rounds must be 0 .. 16"); ctx->opt_rounds = (int)value; msm_graphs_clear(ctx); return BPMI_OK; }
   if (!strcmp(name, "pair_rounds")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "pair_rounds must be 0 or 1"); ctx->opt_pair_rounds = (int)value; return BPMI_OK; }
   if (!strcmp(name, "accum_chain")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "accum_chain must be 0 or 1"); ctx->opt_accum_chain = (int)value; return BPMI_OK; }
@@ -156,7 +157,7 @@ int bpmi_set_option(bpmi_ctx *ctx, const char *name, int64_t value) {
   if (!strcmp(name, "mid_parts")) { if (value < 0 || value > 4) return fail(ctx, BPMI_E_ARG, "mid_parts must be 0 .. 4"); ctx->opt_mid_parts = (int)value; msm_graphs_clear(ctx); return BPMI_OK; }
   if (!strcmp(name, "mixed_windows")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "mixed_windows must be 0 or 1"); ctx->opt_mixed = (int)value; msm_graphs_clear(ctx); return BPMI_OK; }
   if (!strcmp(name, "top_window_unsigned")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "top_window_unsigned must be 0 or 1"); ctx->opt_top2 = (int)value; msm_graphs_clear(ctx); return BPMI_OK; }
-  if (!strcmp(name, "prover_table_bits")) { if (value != 0 && (value < 4 || value > 13)) return fail(ctx, BPMI_E_ARG, "prover_table_bits must be 0 or 4..13"); ctx->opt_prover_tw = (int)value; return BPMI_OK; }
+  if (!strcmp(name, "prover_table_bits")) { if (value != 0 && (value < 4 || value > 16)) return fail(ctx, BPMI_E_ARG, "prover_table_bits must be 0 or 4..16"); ctx->opt_prover_tw = (int)value; return BPMI_OK; }
   if (!strcmp(name, "ipa_fixed_generators")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "ipa_fixed_generators must be 0 or 1"); ctx->opt_ipa_fixed = (int)value; ctx->fold_key_g = ctx->fold_key_h = nullptr; return BPMI_OK; }
   if (!strcmp(name, "validate_points")) { if (value < 0 || value > 2) return fail(ctx, BPMI_E_ARG, "validate_points must be 0, 1 or 2"); ctx->opt_validate = (int)value; return BPMI_OK; }
   if (!strcmp(name, "hist_scan_fused")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "hist_scan_fused must be 0 or 1"); ctx->opt_histscan = (int)value; msm_graphs_clear(ctx); return BPMI_OK; }

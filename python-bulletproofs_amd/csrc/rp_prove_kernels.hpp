@@ -203,20 +203,52 @@ struct Batch {
 #define PV_PT_UNEW 4u
 #define PV_PT_PNEW 5u
 
-// ---- the table's scalars: entry (b, k, d) = d 2^(tw k) ---------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_pv_table_scalars(const u32 *__restrict__ bases, u32 nbases, Tab T, u32 *__restrict__ pts, u32 *__restrict__ scal) {
+// ---- building the table (round 6) ---------------------------------------------------------------------------------------------------------
+// Round 5 built every entry (b, k, d) = d 2^(tw k) base_b as a scalar multiplication of its own (k_pv_table_scalars + bpmi_ec_mul_batch:
+// 72 ms for the 5.6 M entries of 12-bit windows; 16-bit windows -- 69 M entries -- would have taken 0.9 s).  Now only the nb x wt WINDOW
+// BASES 2^(tw k) base_b are scalar multiplications (k_pv_window_scalars), and the multiples of a window base W come level by level:
+//   d in (2^j, 2^(j+1)]:   d W = 2^j W + (d - 2^j) W        one complete mixed addition + one inversion per entry,
+// every (base, window) pair in the same launch (k_pv_table_level, tw - 1 launches).  ~285 field multiplications per entry: 7 ms for 12-bit
+// windows, ~90 ms for 16-bit ones (4.4 GB for 64-bit proofs: a sixtieth of the HBM).
+__global__ void __launch_bounds__(256) k_pv_window_scalars(const u32 *__restrict__ bases, u32 nbases, Tab T, u32 *__restrict__ pts, u32 *__restrict__ scal) {
   const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= nbases * T.wt * T.bt) return;
-  const u32 d = (t % T.bt) + 1u, k = (t / T.bt) % T.wt, b = t / (T.bt * T.wt);
+  if (t >= nbases * T.wt) return;
+  const u32 k = t % T.wt, b = t / T.wt;
   u32 w[16];
   ::load_words16(w, bases + 16ull * b);
   ::store_words16(pts + 16ull * t, w);
   u32 s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  const u32 bit = T.tw * k;                     // d <= 2^(tw-1) at bit tw k: at most two words (the top window's entries stay below 2^256: tw k + tw - 1 <= 255 + tw - 1, d's
-  const u64 v = (u64)d << (bit & 31u);          // top bit only set for d = bt, whose position tw k + tw - 1 <= 255 for every window a magnitude < 2^255 can reach)
-  s[bit >> 5] = (u32)v;
-  if ((bit >> 5) + 1u < 8u) s[(bit >> 5) + 1u] = (u32)(v >> 32);
+  const u32 bit = T.tw * k;                     // 2^(tw k), tw k <= 255
+  s[bit >> 5] = 1u << (bit & 31u);
   ::store_words8(scal + 8ull * t, s);
+}
+// entry d = 1 of every (base, window): the window bases themselves
+__global__ void __launch_bounds__(256) k_pv_table_seed(const u32 *__restrict__ wbase, u32 nbk, Tab T, u32 *__restrict__ table) {
+  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nbk) return;
+  u32 w[16];
+  ::load_words16(w, wbase + 16ull * t);
+  ::store_words16(table + 16ull * ((size_t)t * T.bt), w);
+}
+// level j: entries d = 2^j + i, i = 1 .. 2^j, of every (base, window) pair bk: slot(d) = d - 1
+__global__ void __launch_bounds__(256) k_pv_table_level(u32 nbk, Tab T, u32 j, u32 *__restrict__ table) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t per = (size_t)1 << j;
+  if (t >= (size_t)nbk * per) return;
+  const size_t bk = t >> j, i = (t & (per - 1)) + 1;
+  u32 *row = table + 16ull * (bk * T.bt);
+  affine Q, Pi;
+  ::load_affine(Q, row + 16ull * (per - 1));
+  ::load_affine(Pi, row + 16ull * (i - 1));
+  xyzz acc;
+  bpmi::xyzz_set_inf(acc);
+  bpmi::xyzz_madd_signed(acc, Q, false);
+  bpmi::xyzz_madd_signed(acc, Pi, false);          // complete: i = 2^j is the doubling 2 (2^j W)
+  affine r;
+  bpmi::xyzz_to_affine(r, acc);
+  u32 w[16];
+  bpmi::affine_to_words(w, r);
+  ::store_words16(row + 16ull * (per + i - 1), w);
 }
 
 // element i of a proof's bit vector aL: bit i % nb of value i / nb
@@ -262,6 +294,9 @@ struct MsmJobs {
   u32 *out;                // XYZZ of job j at out + 36 j
 };
 // signed tw-bit digits of |s| (s folded to s or q - s: the top digit cannot carry out)
+// Round 6: the terms that do not fill a last round of the job's lanes (T mod 2^GL of them: ONE for every job of the prover -- the u term of
+// 2^k + 1 terms) are shared out by WINDOWS, lane l taking the windows l, l + 2^GL, ... of each: with whole terms round-robin lane 0 of a
+// round's 16 lanes walked 5 terms and the other 15 lanes 4 -- the job took 5 x wt additions for 4.06 x wt of work per lane (81 %).
 template <int GL> __global__ void __launch_bounds__(256) k_pv_msm(MsmJobs J, Tab T) {
   const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
   const u32 job = t >> GL, l = t & ((1u << GL) - 1u);
@@ -270,7 +305,8 @@ template <int GL> __global__ void __launch_bounds__(256) k_pv_msm(MsmJobs J, Tab
   bpmi::xyzz_set_inf(acc);
   if (live) {
     const unsigned short *bl = J.bases + (size_t)(job % J.ntypes) * J.T;
-    for (u32 term = l; term < J.T; term += (1u << GL)) {
+    const u32 Tfull = J.T & ~((1u << GL) - 1u);
+    for (u32 term = l; term < Tfull; term += (1u << GL)) {
       sc s = ld_sc(J.scalars + 8ull * ((size_t)job * J.stride + term));
       if (bpmi::sc_is_zero(s)) continue;
       const bool neg = bpmi::sc_is_high(s);
@@ -290,6 +326,24 @@ template <int GL> __global__ void __launch_bounds__(256) k_pv_msm(MsmJobs J, Tab
           next_digit(s, T, carry, d_cur, sg_cur);
           ::load_words16(wv, tb + 16ull * ((size_t)(k + 1u) * T.bt + (d_cur ? d_cur - 1u : 0u)));
         }
+        if (d) bpmi::xyzz_madd_signed(acc, Pt, (sg != 0u) != neg);
+      }
+    }
+    for (u32 term = Tfull; term < J.T; term++) {            // the remainder terms: every lane recodes the scalar, and adds its own windows
+      sc s = ld_sc(J.scalars + 8ull * ((size_t)job * J.stride + term));
+      if (bpmi::sc_is_zero(s)) continue;
+      const bool neg = bpmi::sc_is_high(s);
+      if (neg) bpmi::sc_neg(s, s);
+      const u32 *tb = T.p + 16ull * ((size_t)bl[term] * T.wt * T.bt);
+      // lane l: windows l, l + 2^GL, ...  -- every lane reaches ITS window by a walk of digits (a few instructions each) and all lanes add
+      // in the same iteration: an `if (window is mine)` inside ONE loop over the windows made the wave run wt additions with a lane in
+      // sixteen active, i.e. exactly the time the fifth term had cost
+      u32 carry = 0, walked = 0;
+      for (u32 k = l; k < T.wt; k += (1u << GL)) {
+        u32 d = 0, sg = 0;
+        do { next_digit(s, T, carry, d, sg); walked++; } while (walked <= k);
+        affine Pt;
+        ::load_affine(Pt, tb + 16ull * ((size_t)k * T.bt + (d ? d - 1u : 0u)));
         if (d) bpmi::xyzz_madd_signed(acc, Pt, (sg != 0u) != neg);
       }
     }
@@ -322,15 +376,13 @@ __global__ void __launch_bounds__(256) k_pv_commit_A(Batch B, u32 *__restrict__ 
     sc s = ld_sc(B.alpha + 8ull * p);
     const bool neg = bpmi::sc_is_high(s);
     if (neg) bpmi::sc_neg(s, s);
-    u32 carry = 0;
-    for (u32 k = 0; k < B.table.wt; k++) {
-      u32 d, sg;
-      next_digit(s, B.table, carry, d, sg);
-      if ((k & 15u) == l && d) {
-        affine Pt;
-        ::load_affine(Pt, B.table.p + 16ull * ((size_t)(1u * B.table.wt + k) * B.table.bt + d - 1u));
-        bpmi::xyzz_madd_signed(acc, Pt, (sg != 0u) != neg);
-      }
+    u32 carry = 0, walked = 0;                       // (windows l, l + 16, ...: see k_pv_msm's remainder terms)
+    for (u32 k = l; k < B.table.wt; k += 16u) {
+      u32 d = 0, sg = 0;
+      do { next_digit(s, B.table, carry, d, sg); walked++; } while (walked <= k);
+      affine Pt;
+      ::load_affine(Pt, B.table.p + 16ull * ((size_t)(1u * B.table.wt + k) * B.table.bt + (d ? d - 1u : 0u)));
+      if (d) bpmi::xyzz_madd_signed(acc, Pt, (sg != 0u) != neg);
     }
   }
 #pragma unroll 1

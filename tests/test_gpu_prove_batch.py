@@ -80,6 +80,32 @@ def test_batch_prover_equals_the_single_proof_prover(gp, n, count):
         assert blobs[i] == want, (n, i)
 
 
+@pytest.mark.parametrize("count", [4, 5, 333])
+def test_batch_prover_two_halves_on_two_lanes(gp, count):
+    """Round 6 experiment (option prover_split, off by default: measured neutral): a batch as two halves on the ctx's two lanes -- here
+    forced from 4 proofs, with an odd count: the same bytes as one launch sequence."""
+    from bulletproofs_amd.rangeproofs import BatchRangeProver
+    from bulletproofs_amd.utils import ModP
+    n = 32
+    g, h, gs, hs, u = _setup(gp, n, b"sp")
+    rnd = random.Random(count)
+    vs = [ModP(rnd.randrange(1 << n), Q) for _ in range(count)]
+    gammas = [ModP(rnd.randrange(Q), Q) for _ in range(count)]
+    seeds = _seeds(count, rnd)
+    eng = gp.engine()
+    bp = BatchRangeProver(n, g, h, gs, hs, u)
+    try:
+        eng.set_option("prover_split", 0)
+        one = bp.prove_wire(vs, gammas, seeds)
+        eng.set_option("prover_split", 2)
+        two = bp.prove_wire(vs, gammas, seeds)
+        again = bp.prove_wire(vs, gammas, seeds)
+    finally:
+        eng.set_option("prover_split", 0)
+        bp.close()
+    assert two == one and again == one
+
+
 @pytest.mark.parametrize("k", range(7))
 def test_batch_prover_reproduces_the_reference_goldens(gp, k):
     """The single-value goldens of tests/golden/rangeproofs.json (made by the reference itself): the batch prover, given the same
@@ -170,10 +196,11 @@ def test_batch_prover_reproduces_the_reference_aggregated_goldens(gp, k):
     check_range_proof(gp, pr[1], c["proof"])
 
 
-@pytest.mark.parametrize("bits", [4, 5, 7, 9, 10, 11, 12, 13])
+@pytest.mark.parametrize("bits", [4, 5, 7, 9, 10, 11, 12, 13, 14, 15, 16])
 def test_batch_prover_table_windows(gp, bits):
-    """The fixed-base tables with windows of 4 .. 13 bits (ctx option prover_table_bits, read when the prover is created; 8 is the
-    default): windows that straddle words, a top window of 1 .. 8 bits, digits of magnitude 2^(bits-1) -- the same proofs."""
+    """The fixed-base tables with windows of 4 .. 16 bits (ctx option prover_table_bits, read when the prover is created), built level by
+    level from the window bases (round 6: k_pv_table_level): windows that straddle words, a top window of 1 .. 16 bits, digits of
+    magnitude 2^(bits-1) -- the same proofs."""
     from bulletproofs_amd.ec import secp256k1
     from bulletproofs_amd.rangeproofs import BatchRangeProver, NIRangeProver, proof_to_bytes
     from bulletproofs_amd.utils import ModP

@@ -24,11 +24,13 @@ pts = points(2 * n + 3, 1)
 g, h, u, gs, hs = pts[0], pts[1], pts[2], pts[3:3 + n], pts[3 + n:]
 tw = int(os.environ.get("PB_TW", "0"))
 eng.set_option("prover_table_bits", tw)
+for kv in os.environ.get("PB_OPTS", "").split():          # engine options, e.g. PB_OPTS="prover_split=0"
+    eng.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 t = time.perf_counter()
 bp = BatchRangeProver(n, g, h, gs, hs, u)
 eng.sync()
-print(json.dumps({"prover_create_ms": round((time.perf_counter() - t) * 1e3, 2), "bits": n, "table_window_bits": tw or 12,
-                  "table_MB": round((3 + 2 * n) * ((256 + (tw or 12) - 1) // (tw or 12)) * (1 << ((tw or 12) - 1)) * 64 / 1e6, 1)}), flush=True)
+print(json.dumps({"prover_create_ms": round((time.perf_counter() - t) * 1e3, 2), "bits": n, "table_window_bits": tw or 16,
+                  "table_MB": round((3 + 2 * n) * ((256 + (tw or 16) - 1) // (tw or 16)) * (1 << ((tw or 16) - 1)) * 64 / 1e6, 1)}), flush=True)
 for lg in [int(a) for a in sys.argv[1:]] or [8, 10, 12, 14, 16]:
     m = 1 << lg
     vs = [int.from_bytes(hashlib.sha256(b"v%d" % i).digest()[:8], "big") % (1 << n) for i in range(m)]
