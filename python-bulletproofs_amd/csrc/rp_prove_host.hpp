@@ -21,6 +21,7 @@ struct bpmi_rp_prover {
   void *buf = nullptr; size_t buf_bytes = 0;   // the batch's device arrays (grown on demand)
   void *pin = nullptr; size_t pin_bytes = 0;   // page-locked staging of the inputs / the proofs
   hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};      // phase boundaries of a batch, created once with the prover
+  hipEvent_t ev_chain[2] = {nullptr, nullptr};                                            // two halves of a batch: the last multi-scalar multiplication of each
   double last_ms[8] = {0};                     // device milliseconds of the last batch: blind+A/S | y,z+T | x+final+P_new | rounds | emit+copy | total
 };
 
@@ -62,6 +63,7 @@ void bpmi_rp_prover_destroy(bpmi_rp_prover *pv) {
   if (pv->buf) (void)hipFree(pv->buf);
   if (pv->pin) (void)hipHostFree(pv->pin);
   for (auto e : pv->ev) if (e) (void)hipEventDestroy(e);
+  for (auto e : pv->ev_chain) if (e) (void)hipEventDestroy(e);
   delete pv;
 }
 
@@ -107,6 +109,7 @@ static int rp_prover_create_impl(bpmi_ctx *ctx, uint32_t vbits, uint32_t m, cons
   pv->nbases = nb;
   auto bail = [&](int rc) { bpmi_rp_prover_destroy(pv); partial = nullptr; return rc; };
   for (int i = 0; i < 7; i++) { hipError_t ee = hipEventCreate(&pv->ev[i]); if (ee != hipSuccess) return bail(fail(ctx, BPMI_E_HIP, std::string("bpmi_rp_prover_create: ") + hipGetErrorString(ee))); }
+  for (int i = 0; i < 2; i++) { hipError_t ee = hipEventCreateWithFlags(&pv->ev_chain[i], hipEventDisableTiming); if (ee != hipSuccess) return bail(fail(ctx, BPMI_E_HIP, std::string("bpmi_rp_prover_create: ") + hipGetErrorString(ee))); }
   // the Protocol-1 challenge of the empty seed: transcript b"&" (inner_product_prover.py:33; transcript.py:13-14)
   {
     const uint8_t amp = '&';
@@ -308,13 +311,16 @@ static int rp_prove_batch_impl(bpmi_rp_prover *pv, uint64_t n_proofs, const uint
   B.jsc = (u32 *)(d + o_jsc); B.jout = (u32 *)(d + o_jout); B.pts = (u32 *)(d + o_pts);
   hipEvent_t *ev = pv->ev;
   auto blocks = [](uint64_t threads, u32 per) { return dim3((u32)((threads + per - 1) / per)); };
-  // The launch sequence over the proofs [p0, p0 + cnt) on stream `st` (events only for the part that records them).  Round 6 experiment
-  // (option "prover_split", off): a large batch as TWO halves on the ctx's two lanes -- between two multi-scalar multiplications a half is
-  // a chain of one-lane-per-proof kernels (transcript hash, inversion: a quarter of the SIMDs busy) and short vector kernels, 0.45 ms of a
-  // 2.3 ms round, which the other half's additions could hide.  Measured: they do not -- 19.7-19.9 ms against 19.4-19.6 for 2^14 proofs; the
-  // chains' instructions are issue slots the additions lose (the same conservation as everywhere on this chip).
-  auto run = [&](u32 p0, u32 cnt, hipStream_t st, bool rec) {
-    rpp::Batch H = B;
+  // Round 6 experiment (option "prover_split", off): a large batch as TWO halves on the ctx's two lanes.  Between two multi-scalar
+  // multiplications a half is a chain of one-lane-per-proof kernels (transcript hash, inversion: a quarter of the SIMDs busy) and short vector
+  // kernels, 0.45 ms of a 2.3 ms round, which the other half's additions could hide.  Measured twice -- the halves free-running, and their
+  // multiplications alternating through events (the form below) -- 19.2-19.4 ms per 2^14 proofs either way against 19.1-19.2 unsplit
+  // (profiles/r06_batch_prover_table_bits.txt): the chains' instructions are issue slots the additions lose.
+  struct Half { rpp::Batch H; hipStream_t st; u32 p0; bool rec; };
+  auto make_half = [&](u32 p0, u32 cnt, hipStream_t hs, bool rec) {
+    Half h;
+    h.H = B; h.st = hs; h.p0 = p0; h.rec = rec;
+    rpp::Batch &H = h.H;
     H.P = cnt;
     H.dig0 += (size_t)p0 * dig0_stride; H.dig0_len += p0;
     H.values += 8ull * p0 * pv->m; H.gammas += 8ull * p0 * pv->m;
@@ -323,49 +329,62 @@ static int rp_prove_batch_impl(bpmi_rp_prover *pv, uint64_t n_proofs, const uint
     H.res += 40ull * p0; H.xs += 8ull * p0 * k; H.xr += 16ull * p0;
     H.a += 8ull * p0 * n; H.b += 8ull * p0 * n; H.cg += 8ull * p0 * n; H.hf += 8ull * p0 * n;
     H.jsc += 8ull * p0 * (2 * n + 2); H.jout += 36ull * 2 * p0; H.pts += 16ull * p0 * npt;
+    return h;
+  };
+  // step s of a half: 0 A and S; 1 y, z, T1, T2; 2 x, the vectors, P_new; 3 .. 2 + k the rounds; 3 + k the wire bytes.  Every step is
+  // [kernels before] [ONE multi-scalar multiplication] [kernels behind]; with two halves (`other` set) the multiplication waits for the other
+  // half's previous one and is followed by an event of its own: the additions of the two halves alternate on the chip, and a half's
+  // one-lane-per-proof chains (hash, inversion) run beside the OTHER half's additions instead of beside their own twin's.
+  const u32 per_block = 256u / n;                        // proofs per block of the n-lanes-per-proof kernels
+  const u32 nsteps = 4 + k;
+  auto step = [&](Half &h, u32 sidx, hipEvent_t mine, hipEvent_t other) {
+    rpp::Batch &H = h.H;
+    hipStream_t hs = h.st;
+    const u32 Pc = H.P;
     auto msm = [&](u32 njobs, u32 ntypes, u32 T, u32 base_off, const u32 *scalars, u32 stride, int gl) {
       rpp::MsmJobs J;
       J.njobs = njobs; J.ntypes = ntypes; J.T = T; J.bases = pv->bases + base_off; J.scalars = scalars; J.stride = stride; J.out = H.jout;
       const uint64_t threads = (uint64_t)njobs << gl;
-      if (gl == 4) hipLaunchKernelGGL(rpp::k_pv_msm<4>, blocks(threads, 256), dim3(256), 0, st, J, H.table);
-      else hipLaunchKernelGGL(rpp::k_pv_msm<1>, blocks(threads, 256), dim3(256), 0, st, J, H.table);
+      if (other) (void)hipStreamWaitEvent(hs, other, 0);
+      if (gl == 4) hipLaunchKernelGGL(rpp::k_pv_msm<4>, blocks(threads, 256), dim3(256), 0, hs, J, H.table);
+      else hipLaunchKernelGGL(rpp::k_pv_msm<1>, blocks(threads, 256), dim3(256), 0, hs, J, H.table);
+      if (mine) (void)hipEventRecord(mine, hs);
     };
-    auto affine = [&](u32 count, u32 per, u32 slot0, u32 step) {
-      hipLaunchKernelGGL(rpp::k_pv_affine, blocks(count, 256), dim3(256), 0, st, (const u32 *)H.jout, count, per, H.pts, npt, slot0, step);
+    auto affine = [&](u32 count, u32 per, u32 slot0, u32 stp) {
+      hipLaunchKernelGGL(rpp::k_pv_affine, blocks(count, 256), dim3(256), 0, hs, (const u32 *)H.jout, count, per, H.pts, npt, slot0, stp);
     };
-    const u32 Pc = cnt;
-    if (rec) (void)hipEventRecord(ev[0], st);
-    // A, S (rangeproof_prover.py:40-59)
-    hipLaunchKernelGGL(rpp::k_pv_blind, blocks((uint64_t)Pc * (2 * n + 2), 256), dim3(256), 0, st, H);
-    hipLaunchKernelGGL(rpp::k_pv_commit_A, blocks((uint64_t)Pc * 16, 256), dim3(256), 0, st, H, H.jout);
-    affine(Pc, 1, PV_PT_A, 0);
-    msm(Pc, 1, 2 * n + 1, pv->off_S, H.slr, 2 * n + 1, 4);
-    affine(Pc, 1, PV_PT_S, 0);
-    if (rec) (void)hipEventRecord(ev[1], st);
-    // y, z, tau1, tau2; t1, t2; T1, T2 (:60-67)
-    hipLaunchKernelGGL(rpp::k_pv_chal_yz, blocks(Pc, 64), dim3(64), 0, st, H);
-    hipLaunchKernelGGL(rpp::k_pv_poly, dim3((Pc + 256u / n - 1) / (256u / n)), dim3(256), 0, st, H);
-    msm(2 * Pc, 1, 2, pv->off_T, H.tsc, 2, 1);
-    affine(2 * Pc, 2, PV_PT_T1, 1);
-    if (rec) (void)hipEventRecord(ev[2], st);
-    // x; l, r, t_hat, taux, mu; P_new (:68-90; inner_product_prover.py:33-37)
-    hipLaunchKernelGGL(rpp::k_pv_final_chal, blocks(Pc, 64), dim3(64), 0, st, H);
-    hipLaunchKernelGGL(rpp::k_pv_final_wide, dim3((Pc + 256u / n - 1) / (256u / n)), dim3(256), 0, st, H);
-    msm(Pc, 1, 2 * n + 1, pv->off_P, H.jsc, 2 * n + 1, 4);
-    affine(Pc, 1, PV_PT_PNEW, 0);
-    if (rec) (void)hipEventRecord(ev[3], st);
-    // the rounds of Protocol 2 (inner_product_prover.py:94-110)
-    const u32 per_block = 256u / n;                      // proofs per block of k_pv_round_wide (n lanes each)
-    hipLaunchKernelGGL(rpp::k_pv_round_wide, dim3((Pc + per_block - 1) / per_block), dim3(256), 0, st, H, 0u, 1u);
-    for (u32 r = 0; r < k; r++) {
+    if (sidx == 0) {                                     // A, S (rangeproof_prover.py:40-59)
+      if (h.rec) (void)hipEventRecord(ev[0], hs);
+      hipLaunchKernelGGL(rpp::k_pv_blind, blocks((uint64_t)Pc * (2 * n + 2), 256), dim3(256), 0, hs, H);
+      hipLaunchKernelGGL(rpp::k_pv_commit_A, blocks((uint64_t)Pc * 16, 256), dim3(256), 0, hs, H, H.jout);
+      affine(Pc, 1, PV_PT_A, 0);
+      msm(Pc, 1, 2 * n + 1, pv->off_S, H.slr, 2 * n + 1, 4);
+      affine(Pc, 1, PV_PT_S, 0);
+      if (h.rec) (void)hipEventRecord(ev[1], hs);
+    } else if (sidx == 1) {                              // y, z, tau1, tau2; t1, t2; T1, T2 (:60-67)
+      hipLaunchKernelGGL(rpp::k_pv_chal_yz, blocks(Pc, 64), dim3(64), 0, hs, H);
+      hipLaunchKernelGGL(rpp::k_pv_poly, dim3((Pc + per_block - 1) / per_block), dim3(256), 0, hs, H);
+      msm(2 * Pc, 1, 2, pv->off_T, H.tsc, 2, 1);
+      affine(2 * Pc, 2, PV_PT_T1, 1);
+      if (h.rec) (void)hipEventRecord(ev[2], hs);
+    } else if (sidx == 2) {                              // x; l, r, t_hat, taux, mu; P_new (:68-90; inner_product_prover.py:33-37)
+      hipLaunchKernelGGL(rpp::k_pv_final_chal, blocks(Pc, 64), dim3(64), 0, hs, H);
+      hipLaunchKernelGGL(rpp::k_pv_final_wide, dim3((Pc + per_block - 1) / per_block), dim3(256), 0, hs, H);
+      msm(Pc, 1, 2 * n + 1, pv->off_P, H.jsc, 2 * n + 1, 4);
+      affine(Pc, 1, PV_PT_PNEW, 0);
+      if (h.rec) (void)hipEventRecord(ev[3], hs);
+      hipLaunchKernelGGL(rpp::k_pv_round_wide, dim3((Pc + per_block - 1) / per_block), dim3(256), 0, hs, H, 0u, 1u);
+    } else if (sidx < 3 + k) {                           // a round of Protocol 2 (inner_product_prover.py:94-110)
+      const u32 r = sidx - 3;
       msm(2 * Pc, 2, n + 1, pv->off_round + r * 2 * (n + 1), H.jsc, n + 1, 4);
       affine(2 * Pc, 2, 6 + r, k);
-      hipLaunchKernelGGL(rpp::k_pv_round_chal, blocks(Pc, 64), dim3(64), 0, st, H, r);
-      hipLaunchKernelGGL(rpp::k_pv_round_wide, dim3((Pc + per_block - 1) / per_block), dim3(256), 0, st, H, r, 0u);
+      hipLaunchKernelGGL(rpp::k_pv_round_chal, blocks(Pc, 64), dim3(64), 0, hs, H, r);
+      hipLaunchKernelGGL(rpp::k_pv_round_wide, dim3((Pc + per_block - 1) / per_block), dim3(256), 0, hs, H, r, 0u);
+    } else {
+      if (h.rec) (void)hipEventRecord(ev[4], hs);
+      hipLaunchKernelGGL(rpp::k_pv_emit, blocks(Pc, 64), dim3(64), 0, hs, H, (const unsigned char *)(d + o_seeds), (const uint64_t *)(d + o_soff) + h.p0,
+                         (unsigned char *)(d + o_out), (const uint64_t *)(d + o_ooff) + h.p0);
     }
-    if (rec) (void)hipEventRecord(ev[4], st);
-    hipLaunchKernelGGL(rpp::k_pv_emit, blocks(Pc, 64), dim3(64), 0, st, H, (const unsigned char *)(d + o_seeds), (const uint64_t *)(d + o_soff) + p0,
-                       (unsigned char *)(d + o_out), (const uint64_t *)(d + o_ooff) + p0);
   };
   const bool split = ctx->opt_prover_split && P >= 2u * (ctx->opt_prover_split > 1 ? (u32)ctx->opt_prover_split : PV_SPLIT_MIN);
   if (split) {
@@ -374,11 +393,17 @@ static int rp_prove_batch_impl(bpmi_rp_prover *pv, uint64_t n_proofs, const uint
     const u32 P0 = (P + 1) / 2;
     HIPCHK(ctx, hipEventRecord(ctx->ev_fork, st));                  // (the inputs are up)
     HIPCHK(ctx, hipStreamWaitEvent(ctx->stream1, ctx->ev_fork, 0));
-    run(0, P0, st, true);
-    run(P0, P - P0, ctx->stream1, false);
+    Half ha = make_half(0, P0, st, true), hb = make_half(P0, P - P0, ctx->stream1, false);
+    for (u32 sidx = 0; sidx < nsteps; sidx++) {
+      step(ha, sidx, pv->ev_chain[0], sidx ? pv->ev_chain[1] : nullptr);          // (queued alternately: an event is recorded before it is waited for)
+      step(hb, sidx, pv->ev_chain[1], pv->ev_chain[0]);
+    }
     HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->stream1));
     HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
-  } else run(0, P, st, true);
+  } else {
+    Half ha = make_half(0, P, st, true);
+    for (u32 sidx = 0; sidx < nsteps; sidx++) step(ha, sidx, nullptr, nullptr);
+  }
   (void)hipEventRecord(ev[5], st);
   hipError_t e = hipGetLastError();
   // the proofs go straight into the caller's buffer when it is page-locked (bpmi_host_alloc: what BatchRangeProver hands in), else

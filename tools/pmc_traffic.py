@@ -50,11 +50,12 @@ def main():
     print(json.dumps({
         "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python3 bench.py --steps 3 --warmup 1 "
                    "--no-cpu-baseline (two separate passes; tools/pmc_traffic.py)",
-        "workload": "MSM n=2^20, c=16, L=86 (two-lane pipeline)",
+        "workload": "MSM n=2^20, c=16, two MSMs in flight (round 6: chunks of 29 entries = three rounds of wave slots, wave priority for the stages beside the accumulation)",
         "correction": "MI355X_MICROARCH.md section HBM: FETCH_SIZE counts 128-B requests as 64 B for wide coalesced reads -> x2; "
                       "WRITE_SIZE exact; unit KB",
         "note": "k_accum_l0 gathers 64-B points (4 x dwordx4 per lane from one random 64-B-aligned address): for that width the "
-                "counter's x2 correction is uncalibrated (requested bytes = 16.8M x 64 B + 67 MB indices = 1.14e9 B). The 64 MB point "
+                "counter's x2 correction is uncalibrated (requested bytes = 16.8M x 64 B + 67 MB indices = 1.14e9 B), so bench.py reports the RAW "
+                "figure (hbm_bytes_per_launch_raw) as roofline.traffic and the corrected one beside it. The 64 MB point "
                 "array is re-read once per window (16x) and is served by L2 / Infinity Cache, not HBM.",
         "kernels": rows}, indent=1))
 
