@@ -40,7 +40,8 @@ def summary_of(out):
     ex = out.get("extra") or {}
     c2, c3, c4, c5 = ex.get("C2_msm_2e16") or {}, ex.get("C3_ipa_prover") or {}, ex.get("C4_aggregated_range_proof") or {}, ex.get("C5_batch_verify") or {}
     oks = [out.get("result_ok"), c2.get("result_ok"), c3.get("deterministic"), c4.get("verified"), c4.get("wrong_commitment_rejected"), c5.get("accepted"),
-           c5.get("corrupted_batch_rejected"), _get(c5, "batch_prover", "byte_identical_to_single_proof_prover_on_sample"), _get(ex, "MSM_strong", "result_ok")]
+           c5.get("corrupted_batch_rejected"), _get(c5, "batch_prover", "byte_identical_to_single_proof_prover_on_sample"),
+           _get(c5, "batch_prover", "aggregated", "byte_identical_to_AggregNIRangeProver_on_sample"), _get(ex, "MSM_strong", "result_ok")]
     ran = [v for v in oks if v is not None]
     return {"ms_per_step": _r(out.get("ms_per_step"), 4), "mad_frac_step": _r(_get(out, "alu_roofline", "frac_vs_raw_mad_step"), 3),
             "C2_ms_one": _r(c2.get("ms_per_msm_one_at_a_time"), 4), "C2_ms_two": _r(c2.get("ms_per_msm_two_in_flight"), 4), "C2_ms_three": _r(c2.get("ms_per_msm_three_in_flight"), 4),

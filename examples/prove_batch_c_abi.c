@@ -2,7 +2,7 @@
  *
  *   gcc -O2 -std=c99 -Iinclude examples/prove_batch_c_abi.c -o prove_batch_c_abi \
  *       python-bulletproofs_amd/libbpmi.so -Wl,-rpath,$PWD/python-bulletproofs_amd
- *   ./prove_batch_c_abi [n_proofs [bits [spoil]]]
+ *   ./prove_batch_c_abi [n_proofs [bits [spoil [values_per_proof]]]]
  *
  * What a prover service does, and what it replaces: a loop of NIRangeProver(v, bits, g, h, gs, hs, gamma, u, group, seed).prove()
  * (/root/reference/src/rangeproofs/rangeproof_prover.py:35-91).
@@ -10,7 +10,9 @@
  *   2. bpmi_rp_prove_batch: values, blinding factors and transcript seeds in, wire-format-2 proofs out -- one device call;
  *   3. (the other side) the commitments V_i = v_i g + gamma_i h and bpmi_rp_batch_verify_dev over the same bytes.
  * The generators here are multiples of the curve's base point (a demonstration, not a setup ceremony).  spoil = 1 changes one
- * commitment after proving: the batch must be rejected.  Exit code 0: proved and verified; 1: the batch did not verify; 2: error. */
+ * commitment after proving: the batch must be rejected.  values_per_proof > 1 (round 6): AGGREGATED proofs -- a loop of
+ * AggregNIRangeProver (/root/reference/src/rangeproofs/rangeproof_aggreg_prover.py:36-146) over proofs of that many values of `bits`
+ * bits each (bits x values <= 128), bpmi_rp_prover_create_aggregated.  Exit code 0: proved and verified; 1: the batch did not verify; 2: error. */
 #define _POSIX_C_SOURCE 200809L
 #include <stdio.h>
 #include <stdlib.h>
@@ -36,29 +38,34 @@ int main(int argc, char **argv) {
   const uint64_t P = argc > 1 ? strtoull(argv[1], NULL, 10) : 1024;
   const uint32_t bits = argc > 2 ? (uint32_t)atoi(argv[2]) : 64;
   const int spoil = argc > 3 ? atoi(argv[3]) : 0;
+  const uint32_t m = argc > 4 ? (uint32_t)atoi(argv[4]) : 1;
+  const uint32_t nel = bits * m;                       /* elements of a proof's vectors */
   uint32_t k = 0;
   uint64_t i;
-  while ((1u << k) < bits) k++;
+  while ((1u << k) < nel) k++;
   bpmi_ctx *ctx = bpmi_ctx_create(0, NULL);
   if (!ctx) { fprintf(stderr, "bpmi_ctx_create: %s\n", bpmi_last_error(NULL)); return 2; }
-  /* generators: 3 + 2 bits multiples of G */
-  const uint64_t ng = 3 + 2ull * bits;
+  /* generators: 3 + 2 bits m multiples of G */
+  const uint64_t ng = 3 + 2ull * nel;
   uint8_t *gpts = malloc(64 * ng), *gin = malloc(64 * ng), *gsc = malloc(32 * ng);
   for (i = 0; i < ng; i++) { memcpy(gin + 64 * i, G_LE, 64); small_scalar(gsc + 32 * i, 31); }
   CK(bpmi_ec_mul_batch(ctx, gin, gsc, ng, gpts));
-  const uint8_t *g = gpts, *h = gpts + 64, *u = gpts + 128, *gs = gpts + 192, *hs = gpts + 192 + 64 * (uint64_t)bits;
+  const uint8_t *g = gpts, *h = gpts + 64, *u = gpts + 128, *gs = gpts + 192, *hs = gpts + 192 + 64 * (uint64_t)nel;
   double t0 = now();
   bpmi_rp_prover *pv = NULL;
-  CK(bpmi_rp_prover_create(ctx, bits, g, h, u, gs, hs, &pv));
-  printf("prover for %u-bit proofs: tables built in %.1f ms\n", bits, (now() - t0) * 1e3);
+  CK(bpmi_rp_prover_create_aggregated(ctx, bits, m, g, h, u, gs, hs, &pv));
+  printf("prover for proofs of %u x %u bits: tables built in %.1f ms\n", m, bits, (now() - t0) * 1e3);
   /* inputs: values below 2^bits, blinding factors, seeds "proof-<i>" */
-  uint8_t *vals = calloc(P, 32), *gams = malloc(32 * P), *seeds = malloc(24 * P);
+  const uint64_t NV = P * m;                           /* values: proof i owns entries i m .. i m + m - 1 */
+  uint8_t *vals = calloc(NV, 32), *gams = malloc(32 * NV), *seeds = malloc(24 * P);
   uint64_t *soff = malloc(8 * (P + 1)), *ooff = malloc(8 * (P + 1));
   uint64_t spos = 0;
-  for (i = 0; i < P; i++) {
+  for (i = 0; i < NV; i++) {
     const uint64_t v = bits >= 64 ? rnd() : (rnd() & ((1ull << bits) - 1));
     memcpy(vals + 32 * i, &v, 8);                      /* (little-endian host) */
     small_scalar(gams + 32 * i, 31);
+  }
+  for (i = 0; i < P; i++) {
     soff[i] = spos;
     spos += (uint64_t)sprintf((char *)seeds + spos, "proof-%llu", (unsigned long long)i);
   }
@@ -75,15 +82,15 @@ int main(int argc, char **argv) {
   printf("%llu proofs in %.2f ms (%.0f proofs/s; device %.2f ms), %llu wire bytes\n", (unsigned long long)P, dt * 1e3, P / dt, ms[6],
          (unsigned long long)ooff[P]);
   /* the verifier's side: V_i = v_i g + gamma_i h, then one batch verification over the same bytes */
-  uint8_t *rep = malloc(64 * P), *vg = malloc(64 * P), *rh = malloc(64 * P), *V = malloc(64 * P), one[32] = {1};
-  for (i = 0; i < P; i++) memcpy(rep + 64 * i, g, 64);
-  CK(bpmi_ec_mul_batch(ctx, rep, vals, P, vg));
-  for (i = 0; i < P; i++) memcpy(rep + 64 * i, h, 64);
-  CK(bpmi_ec_mul_batch(ctx, rep, gams, P, rh));
-  CK(bpmi_ec_lincomb2_batch(ctx, vg, rh, one, one, P, V));
-  if (spoil && P > 1) memcpy(V + 64 * (P / 2), V, 64);
+  uint8_t *rep = malloc(64 * NV), *vg = malloc(64 * NV), *rh = malloc(64 * NV), *V = malloc(64 * NV), one[32] = {1};
+  for (i = 0; i < NV; i++) memcpy(rep + 64 * i, g, 64);
+  CK(bpmi_ec_mul_batch(ctx, rep, vals, NV, vg));
+  for (i = 0; i < NV; i++) memcpy(rep + 64 * i, h, 64);
+  CK(bpmi_ec_mul_batch(ctx, rep, gams, NV, rh));
+  CK(bpmi_ec_lincomb2_batch(ctx, vg, rh, one, one, NV, V));
+  if (spoil && NV > 1) memcpy(V + 64 * (NV / 2), V, 64);
   void *d_gens = NULL, *d_pts = NULL, *d_sc = NULL;
-  const uint64_t pairs = P * (1 + 6 + 2ull * k);
+  const uint64_t pairs = P * (m + 6 + 2ull * k);
   CK(bpmi_malloc(ctx, 64 * ng, &d_gens));
   CK(bpmi_malloc(ctx, 64 * pairs, &d_pts));
   CK(bpmi_malloc(ctx, 32 * pairs, &d_sc));
@@ -92,7 +99,7 @@ int main(int argc, char **argv) {
   for (i = 0; i < 32; i++) seed[i] = (uint8_t)rnd();   /* (a real verifier draws this from the system's CSPRNG) */
   int64_t bad = -1;
   t0 = now();
-  CK(bpmi_rp_batch_verify_dev(ctx, bits, 1, P, wire, ooff[P], ooff, NULL, seed, V, d_gens, d_pts, d_sc, out, &bad));
+  CK(bpmi_rp_batch_verify_dev(ctx, nel, m, P, wire, ooff[P], ooff, NULL, seed, V, d_gens, d_pts, d_sc, out, &bad));
   const int valid = bad < 0 && !memcmp(out, zero, 64);
   printf("batch verification: %s in %.2f ms\n", valid ? "VALID" : "INVALID", (now() - t0) * 1e3);
   bpmi_rp_prover_destroy(pv);

@@ -296,6 +296,8 @@ def test_c_program_proves_and_verifies_a_batch_through_the_abi_only(gp, tmp_path
                            os.path.join(repo, "examples", "prove_batch_c_abi.c"), "-o", exe, os.path.join(libdir, "libbpmi.so"),
                            "-Wl,-rpath," + libdir, "-Wl,--allow-shlib-undefined"])
     for args, code, word in ((["300", "64"], 0, "batch verification: VALID"), (["70", "8"], 0, "batch verification: VALID"),
-                             (["300", "64", "1"], 1, "batch verification: INVALID")):
+                             (["300", "64", "1"], 1, "batch verification: INVALID"),
+                             (["200", "16", "0", "4"], 0, "batch verification: VALID"),           # aggregated: 4 values of 16 bits per proof
+                             (["90", "32", "1", "2"], 1, "batch verification: INVALID")):
         r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=300)
         assert r.returncode == code and word in r.stdout, r.stdout + r.stderr
