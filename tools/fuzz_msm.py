@@ -2,7 +2,7 @@
 """Randomised differential test of the HIP MSM against the C oracle: random sizes, scalar
 shapes (uniform, tiny, near q/2 and q, repeated, zero), point shapes (duplicates, negated
 pairs, identities) and engine options (window bits, chunk length, tail placement, window-group
-split, small-MSM threshold, GLV split on / off, fused / unfused wave scan, the round-5 options); a few percent of the cases are large enough for the LDS sort path.
+split, small-MSM threshold, GLV split on / off, fused / unfused wave scan, the round-5 and round-6 options); a few percent of the cases are large enough for the LDS sort path.
   python tools/fuzz_msm.py [seconds]"""
 import os
 import random
@@ -76,7 +76,9 @@ while time.time() - t0 < budget:
             # round 5: the unsigned last window of c = 15, level B of the sort on partitions of any size, the segmented scan's fused last level
             "top_window_unsigned": rnd.choice((1, 1, 0)), "sort_inblock": rnd.choice((1, 1, 0)), "segscan_fused": rnd.choice((0, 0, 1)),
             "hist_scan_fused": rnd.choice((0, 0, 1)), "final_spread": rnd.choice((3, 3, 2, 1, 0)), "reduce_fit": rnd.choice((1, 1, 0)), "mixed_windows": rnd.choice((1, 1, 0)), "mid_parts": rnd.choice((0, 0, 1, 2, 3, 4)),
-            "reduce_epl": rnd.choice((0, 0, 0, 1, 3, 7, 11, 13, 20))}
+            "reduce_epl": rnd.choice((0, 0, 0, 1, 3, 7, 11, 13, 20)),
+            # round 6: the stages' wave priority (mask), slices of a large input (65 536: inputs from 106 496 pairs run as slices), rounds of the accumulation
+            "priority": rnd.choice((1, 1, 0, 17, 26, 28, 31)), "slice_n": rnd.choice((0, 0, 0, 65536, -1)), "rounds": rnd.choice((0, 0, 1, 2, 5))}
     if n > 20000:
         opts["window_bits"] = rnd.choice((0, 0, 0, 10, 11, 12, 13, 13, 14, 15, 16))       # (10 .. 15: mixed window widths unless mixed_windows drew 0)
         opts["chunk"] = rnd.choice((0, 0, 16, 64))
@@ -89,8 +91,9 @@ while time.time() - t0 < budget:
     if got != want:
         fails += 1
         print("MISMATCH n=%d shape=%d kind=%d opts=%s seed=%d case=%d" % (n, shape, kind, opts, seed, cases), flush=True)
-for k in ("window_bits", "chunk", "tail", "split", "small_n", "glv", "mid_single_min"):
+for k in ("window_bits", "chunk", "tail", "split", "small_n", "glv", "mid_single_min", "slice_n", "rounds"):
     eng.set_option(k, 0)
+eng.set_option("priority", 1)
 for k, v in (("top_window_unsigned", 1), ("sort_inblock", 1), ("segscan_fused", 0), ("hist_scan_fused", 0), ("final_spread", 3), ("reduce_fit", 1), ("mixed_windows", 1), ("mid_parts", 0), ("reduce_epl", 0)):
     eng.set_option(k, v)
 eng.set_option("fused_scan", 1)
