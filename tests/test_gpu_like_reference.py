@@ -53,6 +53,28 @@ def test_inner_product_argument_sizes(log_n):
     assert Verifier1(g, h, u, P1, c, NIProver(g, h, u, P1, c, a, b, CURVE, s[5]).prove()).verify()
 
 
+def test_verifier_prints_ok_like_the_reference_when_asked(capsys):
+    """/root/reference/src/innerproduct/inner_product_verifier.py:146 prints "OK" from a successful Verifier2.verify(); here that is
+    opt-in (Verifier2.PRINT_OK), silent by default, and never printed for a proof that fails."""
+    N = 8
+    s = [os.urandom(10) for _ in range(5)]
+    g, h, u = generators(N, s[0]), generators(N, s[1]), elliptic_hash(s[2], CURVE)
+    a, b = scalars(N, s[3]), scalars(N, s[4])
+    P2 = vector_commitment(g, h, a, b) + inner_product(a, b) * u
+    proof = FastNIProver2(g, h, u, P2, a, b, CURVE).prove()
+    assert Verifier2(g, h, u, P2, proof).verify()
+    assert capsys.readouterr().out == ""
+    try:
+        Verifier2.PRINT_OK = True
+        assert Verifier2(g, h, u, P2, proof).verify()
+        assert capsys.readouterr().out == "OK\n"
+        with pytest.raises(Exception, match="Proof invalid"):
+            Verifier2(g, h, u, 2 * P2, proof).verify()
+        assert capsys.readouterr().out == ""
+    finally:
+        Verifier2.PRINT_OK = False
+
+
 def test_inner_product_cheating():
     N = 16
     s = [os.urandom(10) for _ in range(6)]
