@@ -62,6 +62,16 @@ def extra_c5(eng, world, rank, dev, ready, log_batch=14, distinct=None, per_gpu=
     t_batch, batch_ms = best
     wire2 = [packed2[off2[j]: off2[j + 1]] for j in range(distinct)]    # format 2: no transcripts, the device rebuilds them (1.09 KB instead of 2.56 KB per proof)
     assert bp.prove_wire(vals[:16], gams[:16], seeds[:16]) == wire2[:16]
+    # round 6, wire format 3: the same proofs followed by their points' y coordinates (the prover holds them anyway); the verifier
+    # checks each y instead of taking a square root per point (rangeproofs/codec.py, csrc/rp_wire_v2_host.hpp)
+    from bulletproofs_amd.rangeproofs.codec import wire_v2_to_v3
+    bp.wire_format = 3
+    t0 = time.perf_counter()
+    packed3, off3 = bp.prove_wire_packed(vals_b, gams_b, (seeds_b, seeds_off))
+    t_batch3 = time.perf_counter() - t0
+    bp.wire_format = 2
+    wire3 = [packed3[off3[j]: off3[j + 1]] for j in range(distinct)]
+    wire3_ok = wire3[:64] == wire_v2_to_v3(wire2[:64], eng) and all(w3[5:len(w2)] == w2[5:] for w2, w3 in zip(wire2, wire3))
     bp.close()
     sample = min(distinct, 48)
     t0 = time.perf_counter()
@@ -295,6 +305,20 @@ def extra_c5(eng, world, rank, dev, ready, log_batch=14, distinct=None, per_gpu=
             res["wire_format_2"]["errors"] = r2["errors"]
     except Exception as e:
         res["wire_format_2"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    try:
+        r3 = run_format(wire3, False)
+        res["wire_format_3"] = {k_: r3[k_] for k_ in ("value", "seconds_per_batch", "batch_latency_s", "verifies_per_s_one_batch_at_a_time", "accepted", "corrupted_batch_rejected",
+                                                      "wire_bytes_per_batch", "wire_bytes_per_proof", "link", "gpu_stage_ms_per_batch", "gpu_stage_ms_per_batch_serial") if k_ in r3}
+        res["wire_format_3"]["same_proofs_as_format_2_plus_y"] = wire3_ok
+        res["wire_format_3"]["prover_seconds_per_batch"] = t_batch3
+        res["wire_format_3"]["note"] = ("format 2 followed by the y coordinate of each of the proof's 18 points (32 B each): the verifier checks y^2 = x^3 + 7 and the "
+                                        "parity of the encoding's tag instead of taking a square root per point (k_ec_decompress_wire; 253 squarings + 13 multiplications "
+                                        "each, a quarter of a batch's device time on formats 1 and 2); a wrong y is an invalid proof; same verdicts "
+                                        "(tests/test_gpu_batch_dev.py, tests/test_wire_v3_cpu.py)")
+        if "errors" in r3:
+            res["wire_format_3"]["errors"] = r3["errors"]
+    except Exception as e:
+        res["wire_format_3"] = {"error": "%s: %s" % (type(e).__name__, e)}
     return res
 
 

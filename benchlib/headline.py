@@ -40,7 +40,8 @@ def summary_of(out):
     ex = out.get("extra") or {}
     c2, c3, c4, c5 = ex.get("C2_msm_2e16") or {}, ex.get("C3_ipa_prover") or {}, ex.get("C4_aggregated_range_proof") or {}, ex.get("C5_batch_verify") or {}
     oks = [out.get("result_ok"), c2.get("result_ok"), c3.get("deterministic"), c4.get("verified"), c4.get("wrong_commitment_rejected"), c5.get("accepted"),
-           c5.get("corrupted_batch_rejected"), _get(c5, "batch_prover", "byte_identical_to_single_proof_prover_on_sample"),
+           c5.get("corrupted_batch_rejected"), _get(c5, "wire_format_3", "accepted"), _get(c5, "wire_format_3", "corrupted_batch_rejected"),
+           _get(c5, "batch_prover", "byte_identical_to_single_proof_prover_on_sample"),
            _get(c5, "batch_prover", "aggregated", "byte_identical_to_AggregNIRangeProver_on_sample"), _get(ex, "MSM_strong", "result_ok")]
     ran = [v for v in oks if v is not None]
     return {"ms_per_step": _r(out.get("ms_per_step"), 4), "mad_frac_step": _r(_get(out, "alu_roofline", "frac_vs_raw_mad_step"), 3),
@@ -49,7 +50,7 @@ def summary_of(out):
             "C4_prove_s": _r(c4.get("prove_s"), 5), "C4_verify_s": _r(c4.get("verify_s"), 5),
             "C5_verifies_per_s": _r(c5.get("value"), 0), "C5_one_batch_ms": _r((c5.get("batch_latency_s") or 0) * 1e3, 3) if c5 else None,
             "C5_link_GBps": _r(_get(c5, "link", "GBps"), 2), "C5_link_peak_GBps": _get(c5, "link", "peak_GBps"),
-            "C5_v2_verifies_per_s": _r(_get(c5, "wire_format_2", "value"), 0),
+            "C5_v2_verifies_per_s": _r(_get(c5, "wire_format_2", "value"), 0), "C5_v3_verifies_per_s": _r(_get(c5, "wire_format_3", "value"), 0),
             "prover_proofs_per_s": _r(_get(c5, "batch_prover", "proves_per_s"), 0),
             "result_ok_all": bool(ran) and all(ran), "checks": len(ran)}
 

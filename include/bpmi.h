@@ -120,6 +120,8 @@ int bpmi_sync(bpmi_ctx *ctx);
  *   "prover_table_bits" window bits of the fixed-base tables a bpmi_rp_prover builds, read by bpmi_rp_prover_create: 0 = default 16, else 4 .. 16
  *                  (wider: fewer additions per scalar multiplication, a larger table -- 16 bits: 64 KB x 32 768 entries per (generator, window),
  *                  4.4 GB and 72 ms to build for 64-bit proofs; 12 bits: 378 MB, 17 ms, 22 % slower proving; profiles/r06_batch_prover_table_bits.txt)
+ *   "prover_wire_format" 2 (default) or 3: the wire format bpmi_rp_prove_batch writes (3: with the points' y coordinates, see
+ *                  bpmi_rp_wire_v2_to_v1; 32 (6 + 2k) bytes more per proof -- bpmi_rp_prove_batch_proof_bytes counts them)
  *   "ipa_fixed_generators" 1: the generator arrays handed to bpmi_ipa_create_dev are deployment constants.  The tables of odd multiples that
  *                  the prover's 16-way generator fold builds from them (1.1 ms at n = 2^20) are then kept between proofs for as long as the
  *                  calls name the same d_g, d_h and n: the caller's promise that the arrays were not modified.  Default 0
@@ -347,7 +349,14 @@ int bpmi_rp_verifier_vectors(uint32_t n, uint32_t m, int aggregated, const uint8
  * expands n_proofs format-2 proofs (proof g = blobs[off[g], off[g + 1])) into format-1 proofs packed in out[0, cap), out_off[0 ..
  * n_proofs]; HOST code.  *first_bad = first proof that is not a well-formed format-2 proof, or -1.  bpmi_rp_batch_prepare_dev and
  * bpmi_rp_batch_verify_dev take EITHER format (all proofs of a call in the same one, told by the magic of the first): format 2 is
- * uploaded as it is and expanded on the device.  A format-2 proof is valid exactly when its expansion is. */
+ * uploaded as it is and expanded on the device.  A format-2 proof is valid exactly when its expansion is.
+ * Wire format 3 (round 6) is a format-2 proof with the magic "BPRP3", followed by the y coordinate of each of its 6 + 2k points (32 B
+ * big-endian, 0 for the identity; 1.67 KB for a 64-bit proof).  The verifiers CHECK each y -- below p, the parity of the encoding's
+ * tag, on the curve with x: then it is the y a decompression would compute -- instead of taking 6 + 2k square roots per proof, which
+ * were a quarter of a batch verification's device time.  A format-3 proof is valid exactly when its format-2 part is and every y is
+ * right; a wrong y is an invalid proof (*first_bad names it).  This entry point and the three batch entry points take format 3
+ * wherever they take format 2; bpmi_rp_prove_batch writes it under option "prover_wire_format" = 3 (the prover holds the points in
+ * affine form anyway). */
 int bpmi_rp_wire_v2_to_v1(const uint8_t *blobs, uint64_t blobs_len, const uint64_t *off, uint64_t n_proofs, uint8_t *out, uint64_t cap,
                           uint64_t *out_off, int64_t *first_bad);
 
@@ -390,7 +399,7 @@ int bpmi_rp_batch_verify_dev(bpmi_ctx *ctx, uint32_t n_gens, uint32_t values_per
  *                           The points are checked to be on the curve (option "validate_points" >= 1, the default): BPMI_E_ARG names the first bad one.
  *   bpmi_rp_prove_batch     values, gammas: n_proofs x 32 B little-endian, in [0, q) -- checked: BPMI_E_ARG names the first index that is not -- (of a value only the low nbits bits enter the
  *                           proof, as in rangeproof_prover.py:40); seeds: proof i's transcript seed = seeds[seed_off[i] .. seed_off[i+1])
- *                           (at most 65 535 bytes).  out[out_off[i] .. out_off[i+1]) = proof i in wire format 2
+ *                           (at most 65 535 bytes).  out[out_off[i] .. out_off[i+1]) = proof i in wire format 2 (3 under option "prover_wire_format")
  *                           (python-bulletproofs_amd/rangeproofs/codec.py; bpmi_rp_wire_v2_to_v1 expands it, bpmi_rp_batch_verify_dev
  *                           takes it as it is); out_off has n_proofs + 1 entries; cap >= n_proofs x bpmi_rp_prove_batch_proof_bytes
  *                           (of the longest seed).  At most 2^20 proofs per call; one call at a time per prover and ctx.

@@ -148,6 +148,7 @@ int bpmi_set_option(bpmi_ctx *ctx, const char *name, int64_t value) {
   if (!strcmp(name, "accum_stream")) { if (value < 0 || value > 2) return fail(ctx, BPMI_E_ARG, "accum_stream must be 0, 1 or 2"); ctx->opt_accum_stream = (int)value; return BPMI_OK; }
   if (!strcmp(name, "lane_priority")) { if (value < -1 || value > 1) return fail(ctx, BPMI_E_ARG, "lane_priority must be -1, 0 or 1"); ctx->opt_lane_prio = (int)value; return BPMI_OK; }
   if (!strcmp(name, "pair_sched")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "pair_sched must be 0 or 1"); ctx->opt_pair_sched = (int)value; return BPMI_OK; }
+  if (!strcmp(name, "prover_wire_format")) { if (value != 2 && value != 3) return fail(ctx, BPMI_E_ARG, "prover_wire_format must be 2 or 3"); ctx->opt_prover_wire = (int)value; return BPMI_OK; }
   if (!strcmp(name, "prover_split")) { if (value < 0 || value > (1 << 20)) return fail(ctx, BPMI_E_ARG, "prover_split must be 0, 1 or the smallest half"); ctx->opt_prover_split = (int)value; return BPMI_OK; }
   if (!strcmp(name, "rounds")) { if (value < 0 || value > 16) return fail(ctx, BPMI_E_ARG, "rounds must be 0 .. 16"); ctx->opt_rounds = (int)value; msm_graphs_clear(ctx); return BPMI_OK; }
   if (!strcmp(name, "pair_rounds")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "pair_rounds must be 0 or 1"); ctx->opt_pair_rounds = (int)value; return BPMI_OK; }
@@ -1451,11 +1452,13 @@ int bpmi_rp_batch_prepare(uint32_t n_gens, uint32_t values_per_proof, uint64_t n
   // the offset table comes from the caller, the proofs from the network: never read outside blobs[0, blobs_len)
   if (blob_off[0] > blobs_len) return BPMI_E_ARG;
   for (uint64_t g = 0; g < n_proofs; g++) if (blob_off[g] > blob_off[g + 1] || blob_off[g + 1] > blobs_len) return BPMI_E_ARG;
-  // wire format 2 (rp_wire_v2_host.hpp): expanded to format 1 here, then everything below runs as before
+  // wire formats 2 and 3 (rp_wire_v2_host.hpp): expanded to format 1 here (format 3's y coordinates checked), then everything below
+  // runs as before
   std::vector<uint8_t> expanded;
   std::vector<uint64_t> expanded_off;
   bool any_v2 = false;
-  for (uint64_t g = 0; g < n_proofs && !any_v2; g++) any_v2 = blob_off[g + 1] >= blob_off[g] + 5 && blobs[blob_off[g] + 4] == '2';
+  for (uint64_t g = 0; g < n_proofs && !any_v2; g++)
+    any_v2 = blob_off[g + 1] >= blob_off[g] + 5 && (blobs[blob_off[g] + 4] == '2' || blobs[blob_off[g] + 4] == '3');
   if (any_v2) {
     expanded_off.assign(n_proofs + 1, 0);
     std::vector<uint8_t> one;
@@ -1465,7 +1468,7 @@ int bpmi_rp_batch_prepare(uint32_t n_gens, uint32_t values_per_proof, uint64_t n
       // a format-1 proof among format-2 ones is taken as it is; so is a blob that claims format 2 and does not expand -- it is not a
       // format-1 proof either, so the checks below reject it AT ITS INDEX, behind any earlier bad proof (returning here at once made
       // the host name a later proof than the device: tools/fuzz_batch_prepare.py, round 5)
-      if (len >= 5 && b[4] == '2' && rpw::expand_v2(b, len, one)) expanded.insert(expanded.end(), one.begin(), one.end());
+      if (len >= 5 && (b[4] == '2' || b[4] == '3') && rpw::expand_v2(b, len, one)) expanded.insert(expanded.end(), one.begin(), one.end());
       else expanded.insert(expanded.end(), b, b + len);
       expanded_off[g + 1] = expanded.size();
     }
@@ -1516,10 +1519,10 @@ static int rp_mixed_formats(bpmi_ctx *ctx, const uint8_t *blobs, uint64_t blobs_
   const uint64_t a0 = blob_off[0], a = blob_off[first_bad], e = blob_off[first_bad + 1];
   if (a0 + 5 > blobs_len || e > blobs_len || e < a + 5) return BPMI_OK;
   const uint8_t *b = blobs + a;
-  const bool v2 = blobs[a0 + 4] == '2';
-  if (b[0] == 'B' && b[1] == 'P' && b[2] == 'R' && b[3] == 'P' && b[4] == (v2 ? '1' : '2'))
-    return fail(ctx, BPMI_E_ARG, "mixed wire formats: proof " + std::to_string(first_bad) + " is format " + (v2 ? "1" : "2") + " in a format-" + (v2 ? "2" : "1") +
-                                     " batch (one format per call; bpmi_rp_wire_v2_to_v1 converts)");
+  const uint8_t call = (blobs[a0 + 4] == '2' || blobs[a0 + 4] == '3') ? blobs[a0 + 4] : (uint8_t)'1';
+  if (b[0] == 'B' && b[1] == 'P' && b[2] == 'R' && b[3] == 'P' && b[4] >= '1' && b[4] <= '3' && b[4] != call)
+    return fail(ctx, BPMI_E_ARG, "mixed wire formats: proof " + std::to_string(first_bad) + " is format " + std::string(1, (char)b[4]) + " in a format-" +
+                                     std::string(1, (char)call) + " batch (one format per call; bpmi_rp_wire_v2_to_v1 converts)");
   return BPMI_OK;
 }
 // queues everything on the ctx's two lanes and returns without waiting; the results stay on the device (d_shared: 5 + 2n
@@ -1535,7 +1538,9 @@ static int rp_prepare_enqueue(bpmi_ctx *ctx, uint32_t n_gens, uint32_t m, uint64
   if (blob_off[0] > blobs_len) return fail(ctx, BPMI_E_ARG, "offset table leaves the buffer");
   // wire format 2 (rp_wire_v2_host.hpp): told by the first proof's magic; every proof of the call must then be format 2 (the device
   // expander refuses the others).  The array the roles read holds the EXPANDED proofs: its rows are sized by the longest expansion
-  const bool v2 = blob_off[1] >= blob_off[0] + 5 && blob_off[0] + 5 <= blobs_len && blobs[blob_off[0] + 4] == '2';
+  const uint8_t fmt0 = (blob_off[1] >= blob_off[0] + 5 && blob_off[0] + 5 <= blobs_len) ? blobs[blob_off[0] + 4] : (uint8_t)'1';
+  const bool v2 = fmt0 == '2' || fmt0 == '3';
+  const uint64_t hint_bytes = fmt0 == '3' ? 32ull * (6 + 2 * k) : 0;             // format 3: the points' y coordinates behind the format-2 proof
   uint64_t maxlen = 0;
   for (uint64_t g = 0; g < n_proofs; g++) {
     if (blob_off[g] > blob_off[g + 1] || blob_off[g + 1] > blobs_len) return fail(ctx, BPMI_E_ARG, "offset table leaves the buffer");
@@ -1545,7 +1550,7 @@ static int rp_prepare_enqueue(bpmi_ctx *ctx, uint32_t n_gens, uint32_t m, uint64
       // the receive buffer cost more than the upload saves): S seed bytes in all, base64 of them at most three times (the
       // Protocol-1 seed appears in two transcripts), every point item 45 bytes, every decimal item 79
       const uint64_t body = 6 + 32ull * (5 + k) + 33ull * (6 + 2 * k);
-      const uint64_t S = len > body + 132 ? len - body - 132 : 0;
+      const uint64_t S = len > body + 132 + hint_bytes ? len - body - 132 - hint_bytes : 0;
       len = body + 2 + 12 + 3 * (4 * ((S + 2) / 3) + 1) + 4 * 45 + 3 * 79 + 2 * 79 + 1 + (uint64_t)k * (45 + 45 + 79);
     }
     maxlen = std::max(maxlen, len);
@@ -1616,7 +1621,8 @@ static int rp_prepare_enqueue(bpmi_ctx *ctx, uint32_t n_gens, uint32_t m, uint64
     // the expander writes the format-1 proofs word-major itself; what it does not write must read as zero
     HIPCHK(ctx, hipMemsetAsync(d_T, 0, T_bytes, ctx->stream));
     StageTimer t(ctx, ST_RPPREP);
-    hipLaunchKernelGGL(rpd::k_rp_expand_v2, dim3((P + 3) / 4), dim3(64), 0, ctx->stream, (const uint8_t *)din, (const u64 *)(din + o_off), P, k, W, d_T, d_lens);
+    hipLaunchKernelGGL(rpd::k_rp_expand_v2, dim3((P + 3) / 4), dim3(64), 0, ctx->stream, (const uint8_t *)din, (const u64 *)(din + o_off), P, k, W, d_T, d_lens,
+                       (u32)fmt0);
   } else {
     StageTimer t(ctx, ST_RPPREP);
     hipLaunchKernelGGL(rpd::k_rp_transpose, dim3((P + 63) / 64, (W + 63) / 64), dim3(256), 0, ctx->stream, (const uint8_t *)din, (const u64 *)(din + o_off), P, W, d_T);

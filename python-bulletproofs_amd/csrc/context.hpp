@@ -122,6 +122,7 @@ struct bpmi_ctx {
   int opt_slice_min = 0;                // ... the size from which it does (0 = default: 1.25 x slice_n)
   int opt_pair_sched = 0;               // 1: a synchronous pair of large MSMs as both sorts, then the accumulations one after the other (msm_run_pair).  Measured neutral
                                         // (profiles/r06_C3_pair_sched_ab.txt): off
+  int opt_prover_wire = 2;              // bpmi_rp_prove_batch: the wire format of the proofs it returns, 2 or 3 (3: with the points' y coordinates, rp_wire_v2_host.hpp)
   int opt_prover_split = 0;             // bpmi_rp_prove_batch: 1 = a batch of 4 096 proofs or more as two halves on two lanes, N > 1 = from 2 N proofs (rp_prove_host.hpp).
                                         // Measured: 19.7-19.9 ms against 19.4-19.6 for 2^14 proofs (profiles/r06_batch_prover_table_bits.txt): off
   int opt_rounds = 0;                   // rounds of three waves per SIMD of an accumulation that shares the chip with another MSM's kernels (0 = 3; msm_host.hpp)

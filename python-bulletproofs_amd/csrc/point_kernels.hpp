@@ -686,6 +686,47 @@ __device__ __forceinline__ bool ec_decompress_one(const uint8_t *src, u32 w16[16
   }
   return valid;
 }
+// The same point from its encoding AND its y coordinate (wire format 3, rangeproofs/codec.py: 32 bytes big-endian per point behind
+// the proof): no square root -- y is taken when it is below p, has the parity the encoding's tag asks for and lies on the curve
+// with x, which makes it the ONE y ec_decompress_one would have computed; anything else is an invalid proof.  (The root is 253
+// squarings + 13 multiplications per point; at 2^14 64-bit proofs it was a quarter of a batch verification's device time.)
+__device__ __forceinline__ bool ec_hinted_one(const uint8_t *src, const uint8_t *hint, u32 w16[16]) {
+  const u32 tag = src[0];
+  u32 wx[8], wy[8];
+  u32 any = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const uint8_t *q = src + 1 + 28 - 4 * k, *h = hint + 28 - 4 * k;
+    wx[k] = ((u32)q[0] << 24) | ((u32)q[1] << 16) | ((u32)q[2] << 8) | (u32)q[3];
+    wy[k] = ((u32)h[0] << 24) | ((u32)h[1] << 16) | ((u32)h[2] << 8) | (u32)h[3];
+    any |= wx[k] | wy[k];
+  }
+#pragma unroll
+  for (int k = 0; k < 16; k++) w16[k] = 0;
+  if (tag == 0u) return any == 0;             // identity: 33 zero bytes and a zero hint
+  if (tag != 2u && tag != 3u) return false;
+  // x, y < p:  v + (2^32 + 977) must not carry out of 256 bits
+  u64 cx = (u64)wx[0] + 977u, cy = (u64)wy[0] + 977u;
+  cx >>= 32; cy >>= 32;
+  cx += (u64)wx[1] + 1u; cy += (u64)wy[1] + 1u;
+  cx >>= 32; cy >>= 32;
+#pragma unroll
+  for (int k = 2; k < 8; k++) { cx += wx[k]; cx >>= 32; cy += wy[k]; cy >>= 32; }
+  bool valid = (cx | cy) == 0 && (wy[0] & 1u) == (tag & 1u);
+  fe x, y, a, t;
+  fe_from_words(x, wx);
+  fe_from_words(y, wy);
+  fe_sqr(t, x); fe_mul(a, t, x);
+  fe seven; fe_set_zero(seven); seven.v[0] = 7;
+  fe_add(a, a, seven); fe_carry(a, a);        // a = x^3 + 7
+  fe_sqr(t, y);
+  valid = valid && fe_equal(t, a);
+  if (valid) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) { w16[k] = wx[k]; w16[8 + k] = wy[k]; }
+  }
+  return valid;
+}
 __global__ void __launch_bounds__(256, 3) k_ec_decompress(const uint8_t *__restrict__ in, u32 n, u32 *__restrict__ out, uint8_t *__restrict__ ok) {
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -711,12 +752,16 @@ __global__ void __launch_bounds__(256, 3) k_ec_decompress_wire(const uint8_t *__
   const uint8_t *blob = blobs + off[g];
   const u64 len = off[g + 1] - off[g];
   const u32 pts_at = 6 + 32 * (5 + k);
-  // (both wire formats hold the encodings at the same offset; which one a batch is in, and that every proof is in it, is the
-  // preparation's business)
-  if (len >= pts_at + 33ull * per + 2 && len <= max_len && blob[0] == 'B' && blob[1] == 'P' && blob[2] == 'R' && blob[3] == 'P' &&
-      (blob[4] == '1' || blob[4] == '2') && blob[5] == k) {
-    const bool valid = ec_decompress_one(blob + pts_at + 33 * t, w16);
-    if (!valid) atomicMin(bad, (unsigned long long)(first + g));
+  // (all wire formats hold the encodings at the same offset; which one a batch is in, and that every proof is in it, is the
+  // preparation's business.  Format 3 ends with the points' y coordinates: checked, not computed)
+  if (len >= pts_at + 33ull * per + 2 && len <= max_len && blob[0] == 'B' && blob[1] == 'P' && blob[2] == 'R' && blob[3] == 'P' && blob[5] == k) {
+    if (blob[4] == '1' || blob[4] == '2') {
+      const bool valid = ec_decompress_one(blob + pts_at + 33 * t, w16);
+      if (!valid) atomicMin(bad, (unsigned long long)(first + g));
+    } else if (blob[4] == '3' && len >= pts_at + 33ull * per + 132 + 32ull * per) {
+      const bool valid = ec_hinted_one(blob + pts_at + 33 * t, blob + (len - 32ull * per) + 32 * t, w16);
+      if (!valid) atomicMin(bad, (unsigned long long)(first + g));
+    }
   }
   store_words16(out + 16ull * i, w16);
 }

@@ -983,8 +983,10 @@ __device__ __forceinline__ void tw_decimal(TWriter &t, const uint8_t *p) {
 }
 #define V2_LPP 16u                 // lanes per proof
 #define V2_MAXLEN 64u              // measured items per proof: 4 + k challenges, 4 + 2 k points  (k <= 16)
+// fmt = '2' or '3': the format of the call.  A format-3 proof is a format-2 proof followed by the y coordinates of its 6 + 2k points
+// (32 bytes each; k_ec_decompress_wire checks them instead of taking square roots): only its length differs here.
 __global__ void __launch_bounds__(64) k_rp_expand_v2(const uint8_t *__restrict__ blobs, const u64 *__restrict__ off, u32 P, u32 k, u32 W, u64 *__restrict__ T,
-                                                     u32 *__restrict__ lens) {
+                                                     u32 *__restrict__ lens, u32 fmt) {
   // Lanes of a wave only run side by side when they run the SAME code: the items are therefore written kind by kind -- all decimal
   // items of a proof at once (one per lane), then all point items, then the pieces of the unchanged head -- each at the byte
   // offset the group's first lane has worked out from the measured lengths.  (A first parallel version gave every lane "its"
@@ -998,9 +1000,10 @@ __global__ void __launch_bounds__(64) k_rp_expand_v2(const uint8_t *__restrict__
   const u32 g = blockIdx.x * 4u + pw;
   const bool live = g < P;
   const uint8_t *b = blobs + (live ? off[g] : 0ull);
-  const u64 n = live ? off[g + 1] - off[g] : 0ull;
-  const u32 body = 6 + 32 * (5 + k) + 33 * (6 + 2 * k);
-  bool ok = live && n >= body + 132ull && n <= RP_MAX_PROOF_BYTES && b[0] == 'B' && b[1] == 'P' && b[2] == 'R' && b[3] == 'P' && b[4] == '2' && b[5] == k;
+  const u64 n_wire = live ? off[g + 1] - off[g] : 0ull;
+  const u32 body = 6 + 32 * (5 + k) + 33 * (6 + 2 * k), hints = fmt == (u32)'3' ? 32u * (6 + 2 * k) : 0u;
+  const u64 n = n_wire >= hints ? n_wire - hints : 0ull;          // the format-2 part
+  bool ok = live && n >= body + 132ull && n_wire <= RP_MAX_PROOF_BYTES && b[0] == 'B' && b[1] == 'P' && b[2] == 'R' && b[3] == 'P' && b[4] == fmt && b[5] == k;
   u32 sl = 0, sl1 = 0;
   if (ok) {
     sl = ((u32)b[body + 128] << 8) | b[body + 129];

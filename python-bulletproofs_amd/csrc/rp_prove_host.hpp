@@ -207,7 +207,7 @@ static int rp_prover_create_impl(bpmi_ctx *ctx, uint32_t vbits, uint32_t m, cons
 uint64_t bpmi_rp_prove_batch_proof_bytes(const bpmi_rp_prover *pv, uint64_t seed_len) {
   if (!pv) return 0;
   const uint64_t k = pv->k;
-  return 6 + 32 * (5 + k) + 33 * (6 + 2 * k) + 128 + 2 + seed_len + 2;
+  return 6 + 32 * (5 + k) + 33 * (6 + 2 * k) + 128 + 2 + seed_len + 2 + (pv->ctx->opt_prover_wire == 3 ? 32 * (6 + 2 * k) : 0);
 }
 
 static int rp_prove_batch_impl(bpmi_rp_prover *pv, uint64_t n_proofs, const uint8_t *values, const uint8_t *gammas, const uint8_t *seeds, const uint64_t *seed_off,
@@ -241,6 +241,7 @@ static int rp_prove_batch_impl(bpmi_rp_prover *pv, uint64_t n_proofs, const uint
   }
   HIPCHK(ctx, hipSetDevice(ctx->device));
   const u32 P = (u32)n_proofs, n = pv->n, k = pv->k, npt = 6 + 2 * k;
+  const int wire_fmt = ctx->opt_prover_wire;                  // 2, or 3: with the points' y coordinates (bpmi_rp_prove_batch_proof_bytes counts them)
   // the proofs' seeds: base64(seed) || '&' starts every range-proof transcript (transcript.py:13-14)
   uint64_t max_seed = 0, total_out = 0;
   for (u32 p = 0; p < P; p++) {
@@ -383,7 +384,7 @@ static int rp_prove_batch_impl(bpmi_rp_prover *pv, uint64_t n_proofs, const uint
     } else {
       if (h.rec) (void)hipEventRecord(ev[4], hs);
       hipLaunchKernelGGL(rpp::k_pv_emit, blocks(Pc, 64), dim3(64), 0, hs, H, (const unsigned char *)(d + o_seeds), (const uint64_t *)(d + o_soff) + h.p0,
-                         (unsigned char *)(d + o_out), (const uint64_t *)(d + o_ooff) + h.p0);
+                         (unsigned char *)(d + o_out), (const uint64_t *)(d + o_ooff) + h.p0, (u32)wire_fmt);
     }
   };
   const bool split = ctx->opt_prover_split && P >= 2u * (ctx->opt_prover_split > 1 ? (u32)ctx->opt_prover_split : PV_SPLIT_MIN);

@@ -638,17 +638,19 @@ __global__ void __launch_bounds__(256) k_pv_round_wide(Batch B, u32 round, u32 f
   st_sc((up ? jr : jl) + 8ull * ((n >> 1) + rank), mulq(hb, hfj));          // L: b_(i+half) hf_j for i < half; R: b_(i-half) hf_j for i >= half
 }
 
-// ---- the proofs as wire format 2 (rangeproofs/codec.py): "BPRP2" k | taux mu t_hat a b | xs | 6 + 2k compressed points | y z x x_ip |
+// ---- the proofs as wire format 2 or 3 (rangeproofs/codec.py; option "prover_wire_format"): "BPRP2" k | taux mu t_hat a b | xs | 6 + 2k compressed points | y z x x_ip |
 // len seed | len Protocol-1 seed (empty) ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void put_be32(u8 *dst, const sc &v) {
   for (int i = 0; i < 32; i++) dst[i] = (u8)(v.v[7 - (i >> 2)] >> (8 * (3 - (i & 3))));
 }
-__global__ void __launch_bounds__(64) k_pv_emit(Batch B, const u8 *__restrict__ seeds, const u64 *__restrict__ seed_off, u8 *__restrict__ out, const u64 *__restrict__ out_off) {
+__global__ void __launch_bounds__(64) k_pv_emit(Batch B, const u8 *__restrict__ seeds, const u64 *__restrict__ seed_off, u8 *__restrict__ out, const u64 *__restrict__ out_off,
+                                                u32 fmt) {
   const u32 p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= B.P) return;
   u8 *o = out + out_off[p];
   const u32 k = B.k, npt = 6u + 2u * k;
-  o[0] = 'B'; o[1] = 'P'; o[2] = 'R'; o[3] = 'P'; o[4] = '2'; o[5] = (u8)k;
+  u8 *ys = fmt == 3u ? out + out_off[p + 1] - 32u * npt : nullptr;              // format 3: the points' y coordinates end the proof
+  o[0] = 'B'; o[1] = 'P'; o[2] = 'R'; o[3] = 'P'; o[4] = (u8)('0' + fmt); o[5] = (u8)k;
   u32 pos = 6;
   for (u32 j = 0; j < 5u; j++) { put_be32(o + pos, ld_sc(B.res + 40ull * p + 8u * j)); pos += 32; }
   for (u32 j = 0; j < k; j++) { put_be32(o + pos, ld_sc(B.xs + 8ull * ((size_t)p * k + j))); pos += 32; }
@@ -664,6 +666,7 @@ __global__ void __launch_bounds__(64) k_pv_emit(Batch B, const u8 *__restrict__ 
       o[pos] = (u8)(2u + (w[8] & 1u));
       for (int i = 0; i < 32; i++) o[pos + 1 + i] = (u8)(w[7 - (i >> 2)] >> (8 * (3 - (i & 3))));
     }
+    if (ys) for (int i = 0; i < 32; i++) ys[32u * j + i] = (u8)(w[15 - (i >> 2)] >> (8 * (3 - (i & 3))));      // (zeros for the identity)
     pos += 33;
   }
   for (u32 j = 0; j < 3u; j++) { put_be32(o + pos, ld_sc(B.chal + 32ull * p + 8u * j)); pos += 32; }

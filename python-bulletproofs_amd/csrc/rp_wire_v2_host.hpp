@@ -7,11 +7,16 @@
 //   y | z | x | x_ip                     4 x 32 B big-endian: the challenges the transcripts would spell out in decimal
 //   seed_len (2 B) | seed                item 0 of the range-proof transcript (raw; the transcript holds its base64)
 //   seed1_len (2 B) | seed1              item 0 of the Protocol-1 transcript (empty for the reference's provers)
-// 1.09 KB for a 64-bit proof.  expand_v2() writes the format-1 proof those fields stand for -- the transcripts are the canonical
+// 1.09 KB for a 64-bit proof.  Format 3 (round 6) is a format-2 proof with "BPRP3" for its magic, followed by
+//   ys[0 .. 6 + 2k)                      32 B big-endian each: the y coordinate of the proof's points, in their order (0 for the identity)
+// 1.67 KB: a verifier CHECKS each y (on the curve with x, the parity of the encoding's tag) instead of computing it -- the square
+// roots were a quarter of a batch verification's device time.  A format-3 proof is valid exactly when its format-2 part is AND
+// every y is the one the encoding stands for; a wrong y is an invalid proof.  expand_v2() writes the format-1 proof those fields stand for -- the transcripts are the canonical
 // ones: rangeproof_prover.py:62-92, inner_product_prover.py:25-47, :94-110 -- and every verifier then runs on format 1 as before:
 // a format-2 proof is valid exactly when its expansion is (tests: same verdicts on valid, corrupted and mutated proofs).  The
 // device twin is rpd::k_rp_expand_v2 (rp_batch_kernels.hpp), compared with this byte for byte.
 #pragma once
+#include "host_tail.hpp"
 
 namespace rpw {
 
@@ -28,9 +33,9 @@ static inline void put_point(std::vector<uint8_t> &o, const uint8_t comp[33]) {
   o.insert(o.end(), item, item + l);
   o.push_back('&');
 }
-// length of the format-2 proof that starts at b (0: not a well-formed one within n bytes)
+// length of the format-2 or format-3 proof that starts at b (0: not a well-formed one within n bytes)
 static inline size_t v2_length(const uint8_t *b, size_t n) {
-  if (n < 6 || memcmp(b, "BPRP2", 5) != 0) return 0;
+  if (n < 6 || (memcmp(b, "BPRP2", 5) != 0 && memcmp(b, "BPRP3", 5) != 0)) return 0;
   const uint32_t k = b[5];
   if (k > 16) return 0;
   size_t o = 6 + 32 * (size_t)(5 + k) + 33 * (size_t)(6 + 2 * k) + 128;
@@ -38,7 +43,25 @@ static inline size_t v2_length(const uint8_t *b, size_t n) {
     if (n < o + 2) return 0;
     o += 2 + (((size_t)b[o] << 8) | b[o + 1]);
   }
+  if (b[4] == '3') o += 32 * (size_t)(6 + 2 * k);
   return o <= n ? o : 0;
+}
+// Format 3: y (32 B big-endian) is THE y coordinate of the encoding comp (SEC1 compressed; 33 zero bytes = identity, y = 0)?
+// The device twin is ec_hinted_one (point_kernels.hpp).
+static inline bool hint_ok(const uint8_t comp[33], const uint8_t y[32]) {
+  using namespace bpmi_host;
+  u64 wx[4], wy[4];
+  for (int i = 0; i < 4; i++) {
+    wx[i] = wy[i] = 0;
+    for (int j = 0; j < 8; j++) { wx[i] = (wx[i] << 8) | comp[1 + 8 * (3 - i) + j]; wy[i] = (wy[i] << 8) | y[8 * (3 - i) + j]; }
+  }
+  if (comp[0] == 0) return (wx[0] | wx[1] | wx[2] | wx[3] | wy[0] | wy[1] | wy[2] | wy[3]) == 0;
+  if ((comp[0] != 2 && comp[0] != 3) || ge_p(wx) || ge_p(wy) || (wy[0] & 1u) != (comp[0] & 1u)) return false;
+  f64 fx, fy, a, t, seven = {{7, 0, 0, 0}};
+  memcpy(fx.v, wx, 32); memcpy(fy.v, wy, 32);
+  f_sqr(t, fx); f_mul(a, t, fx); f_add(a, a, seven);
+  f_sqr(t, fy);
+  return memcmp(t.v, a.v, 32) == 0;
 }
 // format 2 -> format 1; false: not a format-2 proof (bad magic / lengths, a challenge >= q)
 static inline bool expand_v2(const uint8_t *b, size_t n, std::vector<uint8_t> &out) {
@@ -48,6 +71,11 @@ static inline bool expand_v2(const uint8_t *b, size_t n, std::vector<uint8_t> &o
   if (n == 0 || v2_length(b, n) != n) return false;
   const uint32_t k = b[5];
   const size_t body = 6 + 32 * (size_t)(5 + k) + 33 * (size_t)(6 + 2 * k);
+  if (b[4] == '3') {                               // the hints must be the points' y coordinates; the rest is a format-2 proof
+    n -= 32 * (size_t)(6 + 2 * k);
+    for (uint32_t j = 0; j < 6 + 2 * k; j++)
+      if (!hint_ok(b + 6 + 32 * (size_t)(5 + k) + 33 * (size_t)j, b + n + 32 * (size_t)j)) return false;
+  }
   const uint8_t *sc = b + 6, *pts = sc + 32 * (size_t)(5 + k), *ch = b + body;
   const uint8_t *T1 = pts, *T2 = pts + 33, *A = pts + 66, *S = pts + 99, *Ls = pts + 33 * 6, *Rs = Ls + 33 * (size_t)k;
   rp::Sq y, z, x, xip, xi[16];

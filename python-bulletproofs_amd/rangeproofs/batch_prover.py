@@ -30,13 +30,17 @@ def _le32(v):
 
 
 class BatchRangeProver:
-    def __init__(self, n, g, h, gs, hs, u, engine=None, m=1):
+    def __init__(self, n, g, h, gs, hs, u, engine=None, m=1, wire_format=2):
         """n: bits per value, m: values per proof (powers of two, 2 <= n m <= 128; m = 1: single-value proofs); g, h, u: points; gs, hs:
         n m points each.  Builds the fixed-base tables on the engine's device (4.4 GB and ~72 ms for n m = 64 with the default 16-bit
-        windows; engine option prover_table_bits: 12 bits are 378 MB, 17 ms and 22 % slower proving) and keeps them until close()."""
+        windows; engine option prover_table_bits: 12 bits are 378 MB, 17 ms and 22 % slower proving) and keeps them until close().
+        wire_format: 2, or 3 -- the proofs then end with their points' y coordinates (rangeproofs/codec.py), which the batch verifier
+        checks instead of taking square roots; the prover has them anyway."""
         if len(gs) != n * m or len(hs) != n * m:
             raise ValueError("gs and hs must have n m points each")
-        self.n, self.m = n, m
+        if wire_format not in (2, 3):
+            raise ValueError("wire_format must be 2 or 3")
+        self.n, self.m, self.wire_format = n, m, wire_format
         self._engine = engine or _engine.default_engine()
         eng = self._engine
         handle = ctypes.c_void_p()
@@ -46,7 +50,7 @@ class BatchRangeProver:
         self._out = None
 
     def prove_wire_packed(self, vs, gammas, seeds):
-        """(packed bytes, offsets): proof i = packed[offsets[i]: offsets[i + 1]], wire format 2 -- what
+        """(packed bytes, offsets): proof i = packed[offsets[i]: offsets[i + 1]], wire format 2 (or 3) -- what
         BatchRangeVerifier.add_wire_native / bpmi_rp_batch_verify_dev take as they are.
         vs, gammas: lists of ModP / int (aggregated provers: a list of m values per proof), or ALREADY PACKED bytes (32 bytes
         little-endian per value, reduced mod q, proof after proof): a service that receives its inputs as bytes skips 2 x len Python
@@ -84,6 +88,7 @@ class BatchRangeProver:
         if len(vb) != 32 * m * vm or len(gb) != 32 * m * vm:
             raise ValueError("values, blinding factors and seeds must have the same length")
         eng = self._engine
+        eng.set_option("prover_wire_format", self.wire_format)           # (an engine option: set per call, provers may share the engine)
         cap = m * eng.lib.bpmi_rp_prove_batch_proof_bytes(self._handle, 0) + (off[m] - off[0]) + 16      # a proof is a fixed part + its seed
         # the proofs land in a page-locked buffer of the prover (kept between batches): the library copies them there straight from the
         # device, and ONE host copy makes the bytes object (a fresh 18 MB ctypes buffer per batch cost three: zero-fill, staging copy, string_at)

@@ -4,7 +4,8 @@
 //   transcript_host.hpp   the transcript builder of bpmi_ipa_prove_rounds (/root/reference/src/utils/transcript.py:13-33) with its
 //                         bounded export, bpmi_mod_hash_range (src/utils/utils.py:84-97)
 //   host_tail.hpp         the MSM's window combine on the host
-//   rp_wire_v2_host.hpp   wire format 2 -> format 1 (untrusted bytes in: every malformed shape must be refused, never overrun)
+//   rp_wire_v2_host.hpp   wire formats 2 and 3 -> format 1 (untrusted bytes in: every malformed shape must be refused, never overrun;
+//                         format 3's y coordinates checked with host_tail.hpp's field arithmetic)
 //   host_pool.hpp         the sleeping worker pool those loops run on: concurrent callers, nested loops, every width
 // Built by tests/test_host_native_sanitizers.py with -fsanitize=address,undefined (every output buffer is a heap block of
 // EXACTLY the documented size, so an overrun of one byte is a report) and again with -fsanitize=thread (the threaded entry
@@ -202,27 +203,45 @@ static void test_host_tail() {
   if (kind == 0) { uint8_t z[64] = {0}; CHECK(!memcmp(out.p, z, 64)); }
 }
 
-// a structurally valid format-2 proof with random content (the expander never decodes a point: any 33 bytes will do)
-static std::vector<uint8_t> random_v2(uint32_t k) {
-  std::vector<uint8_t> b = {'B', 'P', 'R', 'P', '2', (uint8_t)k};
+// a structurally valid format-2 proof with random content (the expander never decodes a point: any 33 bytes will do), or a
+// format-3 one: its points are then the identity, G or -G, followed by their y coordinates
+static const uint8_t GX[32] = {0x79, 0xBE, 0x66, 0x7E, 0xF9, 0xDC, 0xBB, 0xAC, 0x55, 0xA0, 0x62, 0x95, 0xCE, 0x87, 0x0B, 0x07,
+                               0x02, 0x9B, 0xFC, 0xDB, 0x2D, 0xCE, 0x28, 0xD9, 0x59, 0xF2, 0x81, 0x5B, 0x16, 0xF8, 0x17, 0x98};
+static const uint8_t GY[32] = {0x48, 0x3A, 0xDA, 0x77, 0x26, 0xA3, 0xC4, 0x65, 0x5D, 0xA4, 0xFB, 0xFC, 0x0E, 0x11, 0x08, 0xA8,
+                               0xFD, 0x17, 0xB4, 0x48, 0xA6, 0x85, 0x54, 0x19, 0x9C, 0x47, 0xD0, 0x8F, 0xFB, 0x10, 0xD4, 0xB8};
+static std::vector<uint8_t> random_v2(uint32_t k, bool v3 = false) {
+  std::vector<uint8_t> b = {'B', 'P', 'R', 'P', (uint8_t)(v3 ? '3' : '2'), (uint8_t)k};
+  std::vector<uint8_t> ys;
   uint8_t sc32[32];
   auto put_scalar = [&] { rand_scalar(sc32, (int)(rnd() % 3)); for (int i = 31; i >= 0; i--) b.push_back(sc32[i]); };      // big-endian, < q
   for (uint32_t j = 0; j < 5 + k; j++) put_scalar();
-  for (uint32_t j = 0; j < 6 + 2 * k; j++) { const bool inf = rnd() % 9 == 0; for (int i = 0; i < 33; i++) b.push_back(inf ? 0 : (uint8_t)rnd()); }
+  for (uint32_t j = 0; j < 6 + 2 * k; j++) {
+    const bool inf = rnd() % 9 == 0;
+    if (!v3) { for (int i = 0; i < 33; i++) b.push_back(inf ? 0 : (uint8_t)rnd()); continue; }
+    if (inf) { for (int i = 0; i < 33; i++) b.push_back(0); for (int i = 0; i < 32; i++) ys.push_back(0); continue; }
+    const bool neg = rnd() & 1;                      // -G: y = p - Gy (odd)
+    b.push_back(neg ? 3 : 2);
+    for (int i = 0; i < 32; i++) b.push_back(GX[i]);
+    bpmi_host::f64 y, z = {{0, 0, 0, 0}};
+    for (int w = 0; w < 4; w++) { y.v[w] = 0; for (int i = 0; i < 8; i++) y.v[w] = (y.v[w] << 8) | GY[8 * (3 - w) + i]; }
+    if (neg) bpmi_host::f_sub(y, z, y);
+    for (int w = 3; w >= 0; w--) for (int i = 7; i >= 0; i--) ys.push_back((uint8_t)(y.v[w] >> (8 * i)));
+  }
   for (int j = 0; j < 4; j++) put_scalar();
   for (int s = 0; s < 2; s++) {
     const size_t sl = rnd() % 3 == 0 ? 0 : rnd() % 40;
     b.push_back((uint8_t)(sl >> 8)); b.push_back((uint8_t)sl);
     for (size_t i = 0; i < sl; i++) b.push_back((uint8_t)rnd());
   }
+  b.insert(b.end(), ys.begin(), ys.end());
   return b;
 }
 static void test_wire_v2() {
   const uint32_t k = (uint32_t)(rnd() % 17);
   std::vector<std::vector<uint8_t>> proofs;
   const int count = 1 + (int)(rnd() % 4);
-  for (int i = 0; i < count; i++) proofs.push_back(random_v2(k));
-  const int victim = (int)(rnd() % count), kind = (int)(rnd() % 7);
+  for (int i = 0; i < count; i++) proofs.push_back(random_v2(k, rnd() % 2 == 0));
+  const int victim = (int)(rnd() % count), kind = (int)(rnd() % 8);
   std::vector<uint8_t> &v = proofs[victim];
   const size_t body = 6 + 32 * (size_t)(5 + k) + 33 * (size_t)(6 + 2 * k);
   if (kind == 1) v[rnd() % v.size()] ^= (uint8_t)(1u << (rnd() % 8));
@@ -231,6 +250,15 @@ static void test_wire_v2() {
   else if (kind == 4) { v[body + 128] = (uint8_t)rnd(); v[body + 129] = (uint8_t)rnd(); }                       // a seed length that lies
   else if (kind == 5) { for (int i = 0; i < 32; i++) v[body + 32 * (rnd() % 4) + i] = 0xFF; }                    // a challenge >= q
   else if (kind == 6) v[5] = (uint8_t)rnd();
+  else if (kind == 7 && v[4] == '3') {                                                                           // a y that is not its point's
+    const size_t npt = 6 + 2 * (size_t)k, at = v.size() - 32 * npt, t = rnd() % npt;
+    const int how = (int)(rnd() % 3);
+    if (how == 0) v[at + 32 * t + rnd() % 32] ^= (uint8_t)(1u << (rnd() % 8));
+    else if (how == 1) for (int i = 0; i < 32; i++) v[at + 32 * t + i] = 0xFF;
+    else v[6 + 32 * (5 + (size_t)k) + 33 * t] ^= 1;                                                              // the tag: the other root (or 0 <-> 1: no encoding)
+    std::vector<uint8_t> dummy;
+    CHECK(!rpw::expand_v2(v.data(), v.size(), dummy));
+  }
   // one exact-size heap block for the batch, offsets
   size_t total = 0;
   std::vector<uint64_t> off = {0};

@@ -18,6 +18,7 @@ def full_line():
                       "C4_aggregated_range_proof": {"prove_s": 0.00687, "verify_s": 0.00512, "verified": True, "wrong_commitment_rejected": True},
                       "C5_batch_verify": {"value": 13912345.678, "batch_latency_s": 0.0021234, "accepted": True, "corrupted_batch_rejected": True, "batches_in_flight": 8,
                                           "link": {"GBps": 35.512345, "peak_GBps": 63.0}, "wire_format_2": {"value": 16912345.6},
+                                          "wire_format_3": {"value": 19912345.6, "accepted": True, "corrupted_batch_rejected": True},
                                           "batch_prover": {"proves_per_s": 508123.4, "byte_identical_to_single_proof_prover_on_sample": True,
                                                            "aggregated": {"byte_identical_to_AggregNIRangeProver_on_sample": True}}}}}
 
@@ -26,7 +27,7 @@ def test_summary_is_compact_and_complete():
     out = full_line()
     sm = summary_of(out)
     assert len(json.dumps(sm)) < 600
-    assert sm["result_ok_all"] is True and sm["checks"] == 9
+    assert sm["result_ok_all"] is True and sm["checks"] == 11
     assert sm["C2_ms_two"] == 0.1781 and sm["C3_s"] == 0.02312 and sm["C5_one_batch_ms"] == 2.123 and sm["C5_link_GBps"] == 35.51
     assert all(v is not None for v in sm.values())
     m2 = second_metric(out)
@@ -43,4 +44,4 @@ def test_summary_without_extras_and_with_a_failed_check():
     out = full_line()
     out["extra"]["C3_ipa_prover"] = {"error": "RuntimeError: x"}
     sm = summary_of(out)
-    assert sm["C3_s"] is None and sm["result_ok_all"] is True and sm["checks"] == 8
+    assert sm["C3_s"] is None and sm["result_ok_all"] is True and sm["checks"] == 10

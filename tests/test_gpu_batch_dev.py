@@ -693,3 +693,139 @@ def test_mixed_wire_formats_are_an_argument_error_not_a_verdict(eng):
         assert h[0] == 0 and h[1] == -1 and h[2:5] == want[2:5]
         d = dev_prepare(eng, 8, 1, mixed, None, seed)
         assert d[0] == -3
+
+
+# ---- wire format 3 (round 6): format 2 + the points' y coordinates; the device CHECKS each y instead of taking a square root -------
+def _v3(proofs):
+    return [proof_to_bytes(pr, version=3) for pr in proofs]
+
+
+@pytest.mark.parametrize("n", [2, 8, 64])
+def test_format_3_gives_the_same_scalars_points_and_coefficients_as_format_1(eng, n):
+    """The same proofs in formats 1, 2 and 3 through the device preparation: identical V scalars, per-proof point scalars, shared
+    coefficients and DECODED POINTS byte for byte (format 3's come from the hinted branch of k_ec_decompress_wire: no square root),
+    identical to the host twin; and codec.wire_v2_to_v3 (one batched decompression) writes the very bytes the codec writes from Proof objects."""
+    from bulletproofs_amd.rangeproofs.codec import wire_v2_to_v3
+    b = make_batch(7, n=n)
+    v1, v2, v3 = [proof_to_bytes(pr) for pr in b["proofs"]], _v2(b["proofs"]), _v3(b["proofs"])
+    assert wire_v2_to_v3(v2, eng) == v3
+    rnd = random.Random(n + 6)
+    weights = b"".join(rnd.randrange(1, Q).to_bytes(32, "little") for _ in range(4 * 7))
+    for w, seed in ((weights, None), (None, bytes(range(32)))):
+        d1 = dev_prepare(eng, n, 1, v1, w, seed)
+        d3 = dev_prepare(eng, n, 1, v3, w, seed)
+        assert d1[0] == 0 and d1[1] == -1 and d3 == d1
+        assert_same(eng, n, 1, v3, w, seed)
+    # many proofs, several launch shapes, and the sliced upload (>= 4096 proofs: the decoding of a slice runs beside the next upload)
+    want = dev_prepare(eng, n, 1, [v1[i % 7] for i in range(300)], None, b"\x21" * 32)
+    try:
+        for lanes, rows in ((0, 0), (16, 37)):
+            eng.set_option("rp_lanes", lanes)
+            eng.set_option("rp_rows", rows)
+            assert dev_prepare(eng, n, 1, [v3[i % 7] for i in range(300)], None, b"\x21" * 32) == want
+    finally:
+        eng.set_option("rp_lanes", 0)
+        eng.set_option("rp_rows", 0)
+    if n == 8:
+        assert dev_prepare(eng, n, 1, [v3[i % 7] for i in range(4100)], None, b"\x22" * 32) == dev_prepare(eng, n, 1, [v1[i % 7] for i in range(4100)], None, b"\x22" * 32)
+
+
+def test_format_3_a_wrong_y_is_an_invalid_proof_on_the_device_as_on_the_host(eng):
+    """200 corruptions of format-3 proofs -- every section of format 2, and the y coordinates: flipped bits, the other root, another
+    point's y, values not below p, a zero, a flipped tag: the device names the same first failing proof as the host twin (which checks
+    the ys with its own field arithmetic, rp_wire_v2_host.hpp hint_ok).  No corruption of a y passes."""
+    from bulletproofs_amd.ec import secp256k1
+    P = secp256k1.p
+    b = make_batch(4, n=8)
+    blobs = _v3(b["proofs"])
+    v1s, v2s = [proof_to_bytes(pr) for pr in b["proofs"]], _v2(b["proofs"])
+    k, npts = 3, 12
+    body = 6 + 32 * (5 + k) + 33 * npts
+    rnd = random.Random(13)
+    w = b"".join(rnd.randrange(1, Q).to_bytes(32, "little") for _ in range(16))
+    rejected = y_trials = 0
+    for trial in range(200):
+        j = rnd.randrange(4)
+        bad = bytearray(blobs[j])
+        at = len(bad) - 32 * npts
+        kind = rnd.choice(("scalar", "point", "challenge", "seed", "header", "truncate", "extend", "seedlen", "ybit", "ybit", "yneg", "yswap", "ybig", "yzero", "tag"))
+        t = rnd.randrange(npts)
+        y = int.from_bytes(bad[at + 32 * t: at + 32 * t + 32], "big")
+        if kind == "scalar":
+            bad[rnd.randrange(6, 6 + 32 * (5 + k))] ^= 1 << rnd.randrange(8)
+        elif kind == "point":
+            bad[rnd.randrange(6 + 32 * (5 + k), body)] ^= 1 << rnd.randrange(8)
+        elif kind == "challenge":
+            bad[rnd.randrange(body, body + 128)] ^= 1 << rnd.randrange(8)
+        elif kind == "seed":
+            bad[rnd.randrange(body + 130, at)] ^= 1 << rnd.randrange(8)
+        elif kind == "header":
+            bad[rnd.randrange(0, 6)] ^= 1 << rnd.randrange(8)
+        elif kind == "truncate":
+            del bad[rnd.randrange(0, len(bad)):]
+        elif kind == "extend":
+            bad += bytes(rnd.randrange(256) for _ in range(rnd.randrange(1, 40)))
+        elif kind == "seedlen":
+            bad[body + 128 + rnd.randrange(2)] ^= 1 << rnd.randrange(8)
+        elif kind == "ybit":
+            bad[rnd.randrange(at, len(bad))] ^= 1 << rnd.randrange(8)
+        elif kind == "yneg":
+            bad[at + 32 * t: at + 32 * t + 32] = (P - y).to_bytes(32, "big")
+        elif kind == "yswap":
+            t2 = (t + 1 + rnd.randrange(npts - 1)) % npts
+            bad[at + 32 * t: at + 32 * t + 32] = blobs[j][at + 32 * t2: at + 32 * t2 + 32]
+        elif kind == "ybig":
+            bad[at + 32 * t: at + 32 * t + 32] = rnd.choice((P, P + 1, (1 << 256) - 1, y + P if y + P < (1 << 256) else P)).to_bytes(32, "big")
+        elif kind == "yzero":
+            bad[at + 32 * t: at + 32 * t + 32] = bytes(32)
+        elif kind == "tag":
+            bad[6 + 32 * (5 + k) + 33 * t] ^= 1
+        mutated = blobs[:j] + [bytes(bad)] + blobs[j + 1:]
+        if mutated[0][:5] != b"BPRP3":           # the first proof tells the format of the call
+            continue
+        h = host_prepare(8, 1, mutated, w, None)
+        d = dev_prepare(eng, 8, 1, mutated, w, None)
+        assert h[0] == 0 and d[0] == 0
+        host_bad = h[1]
+        upto = 4 if host_bad < 0 else host_bad
+        if upto:
+            _, ok = eng.ec_decompress_batch_bytes(h[5][:33 * upto * npts], upto * npts)
+            if 0 in ok:
+                host_bad = ok.index(0) // npts
+        assert d[1] == host_bad, (trial, kind, d[1], host_bad)
+        rejected += d[1] >= 0
+        if kind[0] == "y" or kind == "tag":
+            y_trials += 1
+            assert d[1] == j, (trial, kind)
+    assert rejected >= 130 and y_trials >= 60
+    for other in (v1s, v2s):
+        assert dev_prepare(eng, 8, 1, [blobs[0], other[1], blobs[2]], w, None)[1] == 1
+        assert dev_prepare(eng, 8, 1, [other[0], blobs[1], other[2]], w, None)[1] == 1
+
+
+def test_format_3_verdicts_and_mixed_formats(eng):
+    from bulletproofs_amd.engine import EngineError
+    b = make_batch(6, n=8)
+    v1, v2, v3 = [proof_to_bytes(pr) for pr in b["proofs"]], _v2(b["proofs"]), _v3(b["proofs"])
+    bv = BatchRangeVerifier(b["g"], b["h"], b["gs"], b["hs"], b["u"])
+    assert bv.partial_wire(b["Vs"], v3) == bytes(64) and bv.verify_wire(b["Vs"], v3) is True
+    with pytest.raises(EngineError, match="mixed wire formats: proof 3 is format 2 in a format-3 batch"):
+        bv.partial_wire(b["Vs"], v3[:3] + [v2[3]] + v3[4:])
+    with pytest.raises(EngineError, match="mixed wire formats: proof 2 is format 3 in a format-1 batch"):
+        bv.partial_wire(b["Vs"], v1[:2] + [v3[2]] + v1[3:])
+    with pytest.raises(EngineError, match="mixed wire formats: proof 5 is format 3 in a format-2 batch"):
+        bv.partial_wire(b["Vs"], v2[:5] + [v3[5]])
+    # the other root of ONE point of ONE proof: a verdict, not an error
+    from bulletproofs_amd.ec import secp256k1
+    bad = bytearray(v3[4])
+    y = int.from_bytes(bad[-32:], "big")
+    bad[-32:] = (secp256k1.p - y).to_bytes(32, "big")
+    with pytest.raises(Exception, match="^Proof invalid$"):
+        bv.verify_wire(b["Vs"], v3[:4] + [bytes(bad)] + v3[5:])
+    # a valid proof with the commitments of another: rejected by the MSM, as in the other formats
+    with pytest.raises(Exception, match="^Proof invalid$"):
+        bv.verify_wire(b["Vs"][1:] + b["Vs"][:1], v3)
+    # the Python path (add_wire: points decoded from the encodings) takes format 3 as well
+    bv2 = BatchRangeVerifier(b["g"], b["h"], b["gs"], b["hs"], b["u"])
+    bv2.add_wire(b["Vs"], v3)
+    assert bv2.verify() is True

@@ -301,3 +301,45 @@ def test_c_program_proves_and_verifies_a_batch_through_the_abi_only(gp, tmp_path
                              (["90", "32", "1", "2"], 1, "batch verification: INVALID")):
         r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=300)
         assert r.returncode == code and word in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("n,m,count", [(32, 1, 40), (64, 1, 9), (8, 4, 7), (2, 1, 3)])
+def test_batch_prover_writes_wire_format_3(gp, n, m, count):
+    """wire_format=3 (round 6): the same proofs followed by the y coordinates of their points -- byte for byte what the codec writes from
+    the single-proof prover's Proof object (src/rangeproofs/rangeproof_prover.py:35-91 / rangeproof_aggreg_prover.py:36-146 behind it), the
+    format-2 part unchanged; the batch verifier accepts them (ys checked, no square roots), and the next batch of the same prover can
+    be format 2 again."""
+    from bulletproofs_amd.rangeproofs import AggregNIRangeProver, BatchRangeProver, BatchRangeVerifier, NIRangeProver
+    from bulletproofs_amd.rangeproofs.codec import proof_to_bytes, wire_v3_to_v2
+    from bulletproofs_amd.ec import secp256k1
+    from bulletproofs_amd.utils import ModP, commitment
+    g, h, gs, hs, u = _setup(gp, n * m, b"w3")
+    rnd = random.Random(31 * n + m)
+    vs = [[ModP(rnd.randrange(1 << n), Q) for _ in range(m)] for _ in range(count)]
+    gammas = [[ModP(rnd.randrange(Q), Q) for _ in range(m)] for _ in range(count)]
+    seeds = _seeds(count, rnd)
+    if m == 1:
+        vs, gammas = [r[0] for r in vs], [r[0] for r in gammas]
+    bp = BatchRangeProver(n, g, h, gs, hs, u, m=m, wire_format=3)
+    try:
+        v3 = bp.prove_wire(vs, gammas, seeds)
+        bp.wire_format = 2
+        v2 = bp.prove_wire(vs, gammas, seeds)
+    finally:
+        bp.close()
+    k = (n * m).bit_length() - 1
+    for i in range(count):
+        assert v3[i][:5] == b"BPRP3" and len(v3[i]) == len(v2[i]) + 32 * (6 + 2 * k) and wire_v3_to_v2(v3[i]) == v2[i]
+        if i % 3 == 0:
+            if m == 1:
+                pr = NIRangeProver(vs[i], n, g, h, gs, hs, gammas[i], u, secp256k1, seeds[i]).prove()
+            else:
+                pr = AggregNIRangeProver(vs[i], n, g, h, gs, hs, gammas[i], u, secp256k1, seeds[i]).prove()
+            assert v3[i] == proof_to_bytes(pr, version=3), (n, m, i)
+    Vs = [[commitment(g, h, v, ga) for v, ga in zip(vr, gr)] if m > 1 else commitment(g, h, vr, gr) for vr, gr in zip(vs, gammas)]
+    bv = BatchRangeVerifier(g, h, gs, hs, u)
+    assert bv.verify_wire(Vs, v3) is True
+    bad = bytearray(v3[count // 2])
+    bad[-5] ^= 0x20                                   # a bit of the last point's y
+    with pytest.raises(Exception, match="^Proof invalid$"):
+        bv.verify_wire(Vs, v3[:count // 2] + [bytes(bad)] + v3[count // 2 + 1:])

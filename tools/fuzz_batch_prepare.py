@@ -4,7 +4,9 @@ host twin (bpmi_rp_batch_prepare): batches of 1..48 proofs drawn from a pool of 
 64 bits; m = 1, 2, 4 values), a random subset mutated (bit flips, byte overwrites, truncation, extension, length fields,
 transcript splices, text edits), explicit or seed-derived weights, random proofs-per-wave and launch sizes.  Every batch must
 give the same first failing proof on both sides (point encodings judged by the decompression), and a valid batch the same
-scalars, shared coefficients and decoded points, byte for byte.    python tools/fuzz_batch_prepare.py [seconds]"""
+scalars, shared coefficients and decoded points, byte for byte.  Round 6: every batch is drawn in wire format 1, 2 or 3 (format 3's y
+coordinates get mutations of their own: bit flips, the other root, another point's y, values not below p).
+    python tools/fuzz_batch_prepare.py [seconds]"""
 import ctypes
 import os
 import random
@@ -42,15 +44,30 @@ for n, m in ((2, 1), (8, 1), (16, 1), (64, 1), (8, 2), (16, 4)):
             pr = R.range_prove(vs[0], n, g, h, gs, hs, gammas[0], u, seed=b"fs%d-%d" % (n, t), multiexp=cbind.msm)
         else:
             pr = R.aggreg_range_prove(vs, bits, g, h, gs, hs, gammas, u, seed=b"fs%d-%d" % (n, t), multiexp=cbind.msm)
-        blobs.append(proof_to_bytes(convert_proof(pr)))
+        blobs.append(tuple(proof_to_bytes(convert_proof(pr), version=f) for f in (1, 2, 3)))
     pool[(n, m)] = blobs
 
+P_FIELD = 2 ** 256 - 2 ** 32 - 977
 
-def mutate(src, k):
+
+def mutate(src, k, fmt):
     ints_end = 6 + 32 * (5 + k)
     pts_end = ints_end + 33 * (6 + 2 * k)
     bad = bytearray(src)
     kind = rnd.randrange(9)
+    if fmt != 1 and kind in (4, 5):                 # (the transcripts' length fields and text: format 1 only)
+        kind = rnd.choice((0, 6, 7, 9 if fmt == 3 else 1))
+    if fmt == 3 and rnd.random() < 0.3:
+        kind = 9
+    if kind == 9:                                   # a y coordinate of format 3
+        npts = 6 + 2 * k
+        at, t = len(bad) - 32 * npts, rnd.randrange(npts)
+        y = int.from_bytes(bad[at + 32 * t: at + 32 * t + 32], "big")
+        how = rnd.randrange(5)
+        new = (P_FIELD - y) % P_FIELD if how == 0 else (0 if how == 1 else (rnd.choice((P_FIELD, 2 ** 256 - 1, min(y + P_FIELD, 2 ** 256 - 1))) if how == 2 else
+               (int.from_bytes(bad[at + 32 * ((t + 1) % npts): at + 32 * ((t + 1) % npts) + 32], "big") if how == 3 else y ^ (1 << rnd.randrange(256)))))
+        bad[at + 32 * t: at + 32 * t + 32] = new.to_bytes(32, "big")
+        return bytes(bad)
     if kind == 0:
         for _ in range(rnd.randrange(1, 4)):
             bad[rnd.randrange(len(bad))] ^= 1 << rnd.randrange(8)
@@ -110,13 +127,19 @@ def dev(n, m, joined, offs, weights, sd):
 
 
 batches = proofs = valid_batches = fails = 0
+by_format = {1: 0, 2: 0, 3: 0}
 t0 = time.time()
 while time.time() - t0 < budget:
     (n, m), blobs0 = rnd.choice(list(pool.items()))
     k = n.bit_length() - 1
     count = rnd.randrange(1, 49)
     p_bad = rnd.choice((0.0, 0.0, 0.02, 0.2, 1.0))
-    blobs = [mutate(b, k) if rnd.random() < p_bad else b for b in (rnd.choice(blobs0) for _ in range(count))]
+    fmt = rnd.choice((1, 1, 2, 3, 3))
+    blobs = [mutate(b, k, fmt) if rnd.random() < p_bad else b for b in (rnd.choice(blobs0)[fmt - 1] for _ in range(count))]
+    # a mutation that turns a proof's magic into ANOTHER format's: the device reads a call in the format of its first proof and reports
+    # the mix as an argument error, the host takes the formats proof by proof (tests/test_gpu_batch_dev.py) -- not a case for this comparison
+    if len({b[4:5] for b in blobs if b[:4] == b"BPRP" and b[4:5] in (b"1", b"2", b"3")} | {b"%d" % fmt}) > 1:
+        continue
     offs = [0]
     for b in blobs:
         offs.append(offs[-1] + len(b))
@@ -143,12 +166,13 @@ while time.time() - t0 < budget:
         good = d[2] == h[2] and d[3] == h[3] and d[4] == h[4] and d[5] == pts
         valid_batches += 1
     batches += 1
+    by_format[fmt] += 1
     proofs += count
     if not good:
         fails += 1
-        print("MISMATCH seed", seed, "batch", batches, "n", n, "m", m, "count", count, "host", h[:2], host_bad, "dev", d[:2], flush=True)
+        print("MISMATCH seed", seed, "batch", batches, "format", fmt, "n", n, "m", m, "count", count, "host", h[:2], host_bad, "dev", d[:2], flush=True)
 eng.set_option("rp_lanes", 0)
 eng.set_option("rp_rows", 0)
-print("fuzz_batch_prepare: %d batches (%d proofs, %d fully valid batches compared byte for byte) in %.0f s, %d mismatches, seed %d"
-      % (batches, proofs, valid_batches, time.time() - t0, fails, seed))
+print("fuzz_batch_prepare: %d batches (formats 1/2/3: %d/%d/%d; %d proofs, %d fully valid batches compared byte for byte) in %.0f s, %d mismatches, seed %d"
+      % (batches, by_format[1], by_format[2], by_format[3], proofs, valid_batches, time.time() - t0, fails, seed))
 sys.exit(1 if fails else 0)
