@@ -1520,7 +1520,12 @@ static int rp_mixed_formats(bpmi_ctx *ctx, const uint8_t *blobs, uint64_t blobs_
   if (a0 + 5 > blobs_len || e > blobs_len || e < a + 5) return BPMI_OK;
   const uint8_t *b = blobs + a;
   const uint8_t call = (blobs[a0 + 4] == '2' || blobs[a0 + 4] == '3') ? blobs[a0 + 4] : (uint8_t)'1';
-  if (b[0] == 'B' && b[1] == 'P' && b[2] == 'R' && b[3] == 'P' && b[4] >= '1' && b[4] <= '3' && b[4] != call)
+  if (!(b[0] == 'B' && b[1] == 'P' && b[2] == 'R' && b[3] == 'P' && b[4] >= '1' && b[4] <= '3' && b[4] != call)) return BPMI_OK;
+  // WELL-FORMED in the format it claims?  (a format-1 proof whose magic a flipped bit turned into "BPRP3" is a bad proof, not a mix-up)
+  const size_t len = (size_t)(e - a);
+  rp::Parsed parsed;
+  const bool well_formed = b[4] == '1' ? rp::parse_blob(parsed, b, len) : (len > 0 && rpw::v2_length(b, len) == len);
+  if (well_formed)
     return fail(ctx, BPMI_E_ARG, "mixed wire formats: proof " + std::to_string(first_bad) + " is format " + std::string(1, (char)b[4]) + " in a format-" +
                                      std::string(1, (char)call) + " batch (one format per call; bpmi_rp_wire_v2_to_v1 converts)");
   return BPMI_OK;
