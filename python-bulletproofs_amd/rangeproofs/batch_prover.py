@@ -49,12 +49,15 @@ class BatchRangeProver:
         self._handle = handle.value
         self._out = None
 
-    def prove_wire_packed(self, vs, gammas, seeds):
+    def prove_wire_packed(self, vs, gammas, seeds, copy=True):
         """(packed bytes, offsets): proof i = packed[offsets[i]: offsets[i + 1]], wire format 2 (or 3) -- what
         BatchRangeVerifier.add_wire_native / bpmi_rp_batch_verify_dev take as they are.
         vs, gammas: lists of ModP / int (aggregated provers: a list of m values per proof), or ALREADY PACKED bytes (32 bytes
         little-endian per value, reduced mod q, proof after proof): a service that receives its inputs as bytes skips 2 x len Python
-        conversions.  seeds: a list of bytes, or (joined bytes, offsets)."""
+        conversions.  seeds: a list of bytes, or (joined bytes, offsets) -- offsets a list or a ctypes c_uint64 array (taken as it is).
+        copy=False: `packed` is a memoryview of the prover's page-locked output buffer and `offsets` the ctypes array the library
+        filled -- valid until the next call on this prover or its close(); a service that forwards the bytes (a socket, the batch verifier's
+        receive buffer) saves the one host copy of the batch (18 MB at 2^14 proofs) and the list of 2^14 Python integers."""
         vm = self.m
 
         def flat(xs):
@@ -98,6 +101,8 @@ class BatchRangeProver:
             self._out = eng.host_alloc(cap + cap // 8)
         out_off = (ctypes.c_uint64 * (m + 1))()
         eng._ck(eng.lib.bpmi_rp_prove_batch(self._handle, m, vb, gb, sb, off, ctypes.c_void_p(self._out.ptr), cap, out_off))
+        if not copy:
+            return self._out.view[: out_off[m]], out_off
         return bytes(self._out.view[: out_off[m]]), list(out_off)
 
     def prove_wire(self, vs, gammas, seeds):

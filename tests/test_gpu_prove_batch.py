@@ -74,6 +74,17 @@ def test_batch_prover_equals_the_single_proof_prover(gp, n, count):
         finally:
             bp2.close()
         assert [packed[off[i]: off[i + 1]] for i in range(count)] == blobs
+        # copy=False: a view of the prover's page-locked buffer and the ctypes offsets (valid until the prover's next call)
+        import ctypes
+        bp3 = BatchRangeProver(n, g, h, gs, hs, u)
+        try:
+            offs_c = (ctypes.c_uint64 * (count + 1))(*[0, *accumulate(map(len, seeds))])
+            view, voff = bp3.prove_wire_packed(b"".join(v.x.to_bytes(32, "little") for v in vs), b"".join(x.x.to_bytes(32, "little") for x in gammas),
+                                               (b"".join(seeds), offs_c), copy=False)
+            assert isinstance(view, memoryview) and [bytes(view[voff[i]: voff[i + 1]]) for i in range(count)] == blobs
+            del view
+        finally:
+            bp3.close()
     step = 1 if count <= 1024 else 4
     for i in range(0, count, step):
         want = proof_to_bytes(NIRangeProver(vs[i], n, g, h, gs, hs, gammas[i], u, secp256k1, seeds[i]).prove(), version=2)
