@@ -83,6 +83,10 @@ class Engine:
         self.ctx = self.lib.bpmi_ctx_create(device, stream)
         if not self.ctx:
             raise EngineError("bpmi_ctx_create failed: %s" % self.lib.bpmi_last_error(None).decode())
+        # A/B experiments on code that creates its own engines (the bench's batches in flight): BPMI_OPTIONS="name=value,name=value"
+        for kv in filter(None, os.environ.get("BPMI_OPTIONS", "").split(",")):
+            name, _, value = kv.partition("=")
+            self.set_option(name.strip(), int(value))
 
     def close(self):
         if getattr(self, "ctx", None):
