@@ -144,7 +144,7 @@ def proof_to_bytes(proof, version=1) -> bytes:
         ip, p2 = proof.innerProof, proof.innerProof.proof2
         v2 = _proof_to_bytes_v2(proof)
         pts = [proof.T1, proof.T2, proof.A, proof.S, ip.u_new, ip.P_new] + list(p2.Ls) + list(p2.Rs)
-        return MAGIC3 + v2[5:] + b"".join(P.to_le64()[32:][::-1] for P in pts)
+        return MAGIC3 + v2[5:] + b"".join(bytes(32) if _pt33(P) == bytes(33) else int(P.y).to_bytes(32, "big") for P in pts)
     ip, p2 = proof.innerProof, proof.innerProof.proof2
     k = len(p2.xs)
     assert len(p2.Ls) == k and len(p2.Rs) == k and k < 256

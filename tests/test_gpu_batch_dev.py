@@ -25,6 +25,12 @@ def eng():
     return default_engine()
 
 
+@pytest.fixture(scope="module")
+def gp():
+    import gpu_common
+    return gpu_common
+
+
 def offsets_of(blobs):
     offs = [0]
     for x in blobs:
@@ -829,3 +835,37 @@ def test_format_3_verdicts_and_mixed_formats(eng):
     bv2 = BatchRangeVerifier(b["g"], b["h"], b["gs"], b["hs"], b["u"])
     bv2.add_wire(b["Vs"], v3)
     assert bv2.verify() is True
+
+
+@pytest.mark.parametrize("family,k", [("single", i) for i in range(7)] + [("aggregated", i) for i in range(3)])
+def test_golden_proofs_in_the_three_formats(eng, gp, family, k):
+    """The REFERENCE-MADE proofs of tests/golden/rangeproofs.json in the three wire formats (bytes pinned by tests/golden/wire_formats.json):
+    the device preparation gives identical scalars, coefficients and points for each, the batch verifier accepts each with the golden's
+    commitments and generators, and rejects each with a commitment exchanged for another point."""
+    import hashlib
+    import os
+    import sys
+    from conftest import load_golden
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_wire_golden
+    from helpers import P
+    from test_gpu_rangeproofs import inputs
+    c = load_golden("rangeproofs.json")[family][k]
+    want = [e for e in load_golden("wire_formats.json")["proofs"] if e["family"] == family and e["index"] == k][0]
+    m = c.get("m", 1)
+    s, n, gs, hs, g, h, u = inputs(gp, c, m)
+    pr = make_wire_golden.proof_of(c["proof"])
+    blobs = [proof_to_bytes(pr, version=v) for v in (1, 2, 3)]
+    for v, b in zip((1, 2, 3), blobs):
+        assert hashlib.sha256(b).hexdigest() == want["format_%d" % v]["sha256"]
+    seed = bytes(range(32))
+    d = [dev_prepare(eng, n * m, m, [b], None, seed) for b in blobs]
+    assert d[0][0] == 0 and d[0][1] == -1 and d[1] == d[0] and d[2] == d[0]
+    Vs = [gp.to_gpu(P(x)) for x in c["Vs"]] if m > 1 else gp.to_gpu(P(c["V"]))
+    bv = BatchRangeVerifier(g, h, gs, hs, u)
+    for b in blobs:
+        assert bv.verify_wire([Vs], [b]) is True
+        wrong = [[Vs[1], Vs[0]] + list(Vs[2:])] if m > 1 else [g]
+        if m == 1 or Vs[0] != Vs[1]:
+            with pytest.raises(Exception, match="^Proof invalid$"):
+                bv.verify_wire(wrong, [b])
