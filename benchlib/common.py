@@ -15,7 +15,10 @@ if REPO not in sys.path:
 # queues round-robin in creation order; once RCCL and the framework have created theirs, both lanes can land on one queue and
 # the pipeline degrades to the one-lane rate (measured: 1.27 ms per step against 1.13 with 8 queues, profiles/r02_hw_queues.txt).
 # Must be set before the HIP runtime initialises, i.e. before torch is imported.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# Round 6: 16.  The batch verifier keeps eight batches in flight, each on an engine with two or three streams of its own; on eight queues
+# those streams share queues and a kernel waits behind another batch's kernel on its queue: C5 +10-30 % (wire format 1), +5-16 % (format 3)
+# with sixteen, the MSM pipeline, C2, C3 and the prover unchanged (profiles/r06_hw_queues_ab.txt).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 Q = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
