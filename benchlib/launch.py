@@ -115,8 +115,10 @@ def run_extras(extras, call_args, gather, rank, sync=lambda: None):
 
 
 def c5_inflight(usable, world):
-    """Batches in flight of the C5 extra: every slot is a host thread of its rank (BENCH_C5_INFLIGHT overrides)."""
-    return max(1, int(os.environ.get("BENCH_C5_INFLIGHT", "0")) or min(8, max(3, usable // world)))
+    """Batches in flight of the C5 extra: every slot is a host thread of its rank (BENCH_C5_INFLIGHT overrides).  Round 6: at most ten
+    (eight until then) -- on sixteen hardware queues wire format 3 gains 8 % from the two more, formats 1 and 2 nothing
+    (profiles/r06_C5_in_flight_at_16_queues.txt)."""
+    return max(1, int(os.environ.get("BENCH_C5_INFLIGHT", "0")) or min(10, max(3, usable // world)))
 
 
 def strong_depth(pairs_per_rank):
