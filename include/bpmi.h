@@ -120,6 +120,9 @@ int bpmi_sync(bpmi_ctx *ctx);
  *   "prover_table_bits" window bits of the fixed-base tables a bpmi_rp_prover builds, read by bpmi_rp_prover_create: 0 = default 16, else 4 .. 16
  *                  (wider: fewer additions per scalar multiplication, a larger table -- 16 bits: 64 KB x 32 768 entries per (generator, window),
  *                  4.4 GB and 72 ms to build for 64-bit proofs; 12 bits: 378 MB, 17 ms, 22 % slower proving; profiles/r06_batch_prover_table_bits.txt)
+ *   "rp_priority"  the batch preparation's chain kernels (expander, roles, elements) raise their waves' issue priority: 0 never, 1 (default) on wire
+ *                  formats 1 and 2, where the point decoding's square roots run beside them (format 2: a batch alone 1.72 -> 1.66 ms, ten in
+ *                  flight +2.4-2.8 %), 2 always (format 3: nothing; profiles/r06_C5_preparation_priority_ab.txt)
  *   "rp_slices"    uploads of a batch of >= 4 096 proofs in bpmi_rp_batch_prepare_dev / bpmi_rp_batch_verify_dev: 1 .. 4, 0 (default) = 4 for wire
  *                  formats 1 and 2 (the points of a slice are decoded on the second lane while the next slice is on the link), 1 for format 3
  *                  (its points are checked, not computed; profiles/r06_C5_upload_slices_ab.txt)

@@ -186,6 +186,7 @@ int bpmi_set_option(bpmi_ctx *ctx, const char *name, int64_t value) {
   if (!strcmp(name, "async_lanes")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "async_lanes must be 0 or 1"); ctx->opt_async_lanes = (int)value; return BPMI_OK; }
   if (!strcmp(name, "rp_only_role")) { if (value < -1 || value > 3) return fail(ctx, BPMI_E_ARG, "rp_only_role must be in [-1, 3]"); ctx->opt_rp_only_role = (int)value; return BPMI_OK; }
   if (!strcmp(name, "glv")) { if (value < -1 || value > 1) return fail(ctx, BPMI_E_ARG, "glv must be -1, 0 or 1"); ctx->opt_glv = (int)value; return BPMI_OK; }
+  if (!strcmp(name, "rp_priority")) { if (value < 0 || value > 2) return fail(ctx, BPMI_E_ARG, "rp_priority must be 0, 1 or 2"); ctx->opt_rp_prio = (int)value; return BPMI_OK; }
   if (!strcmp(name, "rp_slices")) { if (value < 0 || value > 4) return fail(ctx, BPMI_E_ARG, "rp_slices must be 0 .. 4"); ctx->opt_rp_slices = (int)value; return BPMI_OK; }
   if (!strcmp(name, "rp_overlap")) { if (value < 0 || value > 1) return fail(ctx, BPMI_E_ARG, "rp_overlap must be 0 or 1"); ctx->opt_rp_overlap = (int)value; return BPMI_OK; }
   if (!strcmp(name, "rp_rows")) { if (value < 0) return fail(ctx, BPMI_E_ARG, "rp_rows must be >= 0"); ctx->opt_rp_rows = (int)value; return BPMI_OK; }
@@ -1547,6 +1548,11 @@ static int rp_prepare_enqueue(bpmi_ctx *ctx, uint32_t n_gens, uint32_t m, uint64
   const uint8_t fmt0 = (blob_off[1] >= blob_off[0] + 5 && blob_off[0] + 5 <= blobs_len) ? blobs[blob_off[0] + 4] : (uint8_t)'1';
   const bool v2 = fmt0 == '2' || fmt0 == '3';
   const uint64_t hint_bytes = fmt0 == '3' ? 32ull * (6 + 2 * k) : 0;             // format 3: the points' y coordinates behind the format-2 proof
+  // The expander, the roles and the element kernel are chains of dependent instructions, one wave per SIMD; on formats 1 and 2 they run beside
+  // the second lane's square roots (k_ec_decompress_wire: every issue slot it can get).  Raised issue priority lets the chains run at their
+  // own speed: format 2 alone 1.71-1.73 -> 1.64-1.68 ms, ten in flight +2.4-2.8 % (two boxes, profiles/r06_C5_preparation_priority_ab.txt);
+  // format 3 has no square roots beside it and gains nothing (option "rp_priority": 0 off, 1 = formats 1 and 2 (default), 2 = always)
+  const u32 rp_prio = (ctx->opt_rp_prio == 2 || (ctx->opt_rp_prio == 1 && fmt0 != '3')) ? 1u : 0u;
   uint64_t maxlen = 0;
   for (uint64_t g = 0; g < n_proofs; g++) {
     if (blob_off[g] > blob_off[g + 1] || blob_off[g + 1] > blobs_len) return fail(ctx, BPMI_E_ARG, "offset table leaves the buffer");
@@ -1630,7 +1636,7 @@ static int rp_prepare_enqueue(bpmi_ctx *ctx, uint32_t n_gens, uint32_t m, uint64
     HIPCHK(ctx, hipMemsetAsync(d_T, 0, T_bytes, ctx->stream));
     StageTimer t(ctx, ST_RPPREP);
     hipLaunchKernelGGL(rpd::k_rp_expand_v2, dim3((P + 3) / 4), dim3(64), 0, ctx->stream, (const uint8_t *)din, (const u64 *)(din + o_off), P, k, W, d_T, d_lens,
-                       (u32)fmt0);
+                       (u32)fmt0, rp_prio);
   } else {
     StageTimer t(ctx, ST_RPPREP);
     hipLaunchKernelGGL(rpd::k_rp_transpose, dim3((P + 63) / 64, (W + 63) / 64), dim3(256), 0, ctx->stream, (const uint8_t *)din, (const u64 *)(din + o_off), P, W, d_T);
@@ -1641,6 +1647,7 @@ static int rp_prepare_enqueue(bpmi_ctx *ctx, uint32_t n_gens, uint32_t m, uint64
   for (int i = 0; i < 8; i++) q.seed[i] = seed ? ((u32)seed[4 * i] << 24) | ((u32)seed[4 * i + 1] << 16) | ((u32)seed[4 * i + 2] << 8) | seed[4 * i + 3] : 0;
   q.n = n_gens; q.k = k; q.m = m; q.Pall = P; q.only_role = ctx->opt_rp_only_role;
   q.contrib = d_contrib;
+  q.prio = rp_prio;
   q.ctx = d_ctx;
   q.bad = d_bad;
   const size_t lds_bytes = ((size_t)k + 1) * 9 * 64 * sizeof(u32);            // role 2: k + 1 prefix products of 9 limbs per lane

@@ -69,6 +69,7 @@ struct bpmi_ctx {
   int opt_fold_wnaf = 2;     // the IPA's 16-way generator fold: 2 = width-4 NAF of the coefficients' GLV halves over affine tables of odd multiples, 1 = of the whole coefficients, 0 = plain NAF ladder
   int opt_rp_only_role = -1; // profiling only: run one role of the batch preparation kernel (the call then reports proof 0 as bad)
   int opt_glv = 0;           // MSM on GLV-split scalars (an experiment that lost, profiles/r03_glv_msm_on_off.txt): 0 / -1 = never (default), 1 = whenever the bucket pipeline runs
+  int opt_rp_prio = 1;       // batch preparation: its kernels (expander, roles, elements) raise their waves' issue priority: 0 never, 1 on wire formats 1 and 2 (square roots run beside them), 2 always
   int opt_rp_slices = 0;     // batch preparation: uploads of a batch of >= 4096 proofs (1 .. 4); 0 = 4 for formats 1 and 2 (a slice's points are decoded beside the next upload), 1 for format 3
   int opt_rp_overlap = 1;    // batch preparation: point decoding on the second lane beside the preparation kernels (0: behind them; measurements)
   int opt_rp_rows = 0;       // batch preparation: proofs per launch (0 = as many as fit ~256 MB of contribution cells)

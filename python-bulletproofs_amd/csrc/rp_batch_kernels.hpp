@@ -358,6 +358,7 @@ struct Params {
   u32 *v_scalars, *pt_scalars;
   uint8_t *status;           // [role * Pall + g] = verdict of a role (1 = passed); points at this launch's proof 0
   unsigned long long *bad;   // atomicMin of the failing proof indices (whole-batch numbering)
+  u32 prio;                  // the preparation's kernels raise their waves' issue priority (option "rp_priority"; raise_priority, msm_kernels.hpp)
 };
 // context slots of one proof (9 loose limbs each)
 #define CTX_BASE_G 0u                          // w4 a prod x_d^-1
@@ -730,6 +731,7 @@ __device__ __forceinline__ bool role_scalars(const Params &q, u32 g, const Layou
 // is 2.6 KB, the largest shape the format allows (k = 16) under 8 KB.
 #define RP_MAX_PROOF_BYTES 32768u
 __global__ void __launch_bounds__(64) k_rp_roles(Params q) {
+  ::raise_priority(q.prio);
   if (threadIdx.x >= q.lanes) return;
   const u32 role = blockIdx.x & (RP_ROLES - 1);
   const u32 g = (blockIdx.x / RP_ROLES) * q.lanes + threadIdx.x;
@@ -780,6 +782,7 @@ template __global__ void k_rp_role_probe<3>(Params);
 // progressions walk the same tree.  A proof whose role 2 failed gets zeros (its context is not valid).
 struct ElemGeom { u32 el_log, ranges; };       // elements per lane = 2^el_log; ranges per side = n >> el_log
 __global__ void __launch_bounds__(64) k_rp_elements(Params q, ElemGeom eg) {
+  ::raise_priority(q.prio);
   const u32 n = q.n, k = q.k;
   const u32 groups = (q.P + 63u) / 64u;
   const u32 grp = blockIdx.x % groups, rs = blockIdx.x / groups;          // rs = side * ranges + range
@@ -986,7 +989,8 @@ __device__ __forceinline__ void tw_decimal(TWriter &t, const uint8_t *p) {
 // fmt = '2' or '3': the format of the call.  A format-3 proof is a format-2 proof followed by the y coordinates of its 6 + 2k points
 // (32 bytes each; k_ec_decompress_wire checks them instead of taking square roots): only its length differs here.
 __global__ void __launch_bounds__(64) k_rp_expand_v2(const uint8_t *__restrict__ blobs, const u64 *__restrict__ off, u32 P, u32 k, u32 W, u64 *__restrict__ T,
-                                                     u32 *__restrict__ lens, u32 fmt) {
+                                                     u32 *__restrict__ lens, u32 fmt, u32 prio) {
+  ::raise_priority(prio);
   // Lanes of a wave only run side by side when they run the SAME code: the items are therefore written kind by kind -- all decimal
   // items of a proof at once (one per lane), then all point items, then the pieces of the unchanged head -- each at the byte
   // offset the group's first lane has worked out from the measured lengths.  (A first parallel version gave every lane "its"

@@ -869,3 +869,28 @@ def test_golden_proofs_in_the_three_formats(eng, gp, family, k):
         if m == 1 or Vs[0] != Vs[1]:
             with pytest.raises(Exception, match="^Proof invalid$"):
                 bv.verify_wire(wrong, [b])
+
+
+def test_preparation_options_never_change_a_result(eng):
+    """Round 6's scheduling options of the batch preparation -- rp_priority (issue priority of the chain kernels: 0 / 1 / 2) and rp_slices
+    (uploads per batch: 1 .. 4, from 4 096 proofs) -- are about WHEN things run: the scalars, coefficients, points and verdicts of a batch
+    of 4 100 proofs are the same bytes under every setting, in every wire format."""
+    b = make_batch(7, n=8)
+    v1, v2, v3 = [proof_to_bytes(pr) for pr in b["proofs"]], _v2(b["proofs"]), _v3(b["proofs"])
+    seed = b"\x31" * 32
+    want = dev_prepare(eng, 8, 1, [v1[i % 7] for i in range(4100)], None, seed)
+    assert want[0] == 0 and want[1] == -1
+    bad = bytearray(v3[5])
+    bad[-3] ^= 4                                                       # a y of proof 3 001
+    try:
+        for prio, slices in ((0, 0), (1, 1), (2, 2), (2, 3), (1, 4)):
+            eng.set_option("rp_priority", prio)
+            eng.set_option("rp_slices", slices)
+            for blobs in (v1, v2, v3):
+                assert dev_prepare(eng, 8, 1, [blobs[i % 7] for i in range(4100)], None, seed) == want, (prio, slices, blobs[0][:5])
+            mutated = [v3[i % 7] for i in range(4100)]
+            mutated[3001] = bytes(bad)
+            assert dev_prepare(eng, 8, 1, mutated, None, seed)[1] == 3001
+    finally:
+        eng.set_option("rp_priority", 1)
+        eng.set_option("rp_slices", 0)
