@@ -197,23 +197,30 @@ def main():
         # (N > 1: ONE all_gather of the 64-byte partials + bpmi_ec_sum fold on every rank)
         # the exchange of step j is started (queued on its own stream) and collected one iteration later, so the host
         # never waits for the fold kernel before it has fed the GPU its next MSM
+        # (round 6: the slot msm_finish has just freed is refilled AT ONCE, before the exchange's ~0.08 ms of host work -- behind it the next
+        # MSM started that much later and every step with a process group was that much longer; without one the order is the same as before)
         D = args.depth
-        for j in range(min(k, D - 1)):
+        no_exchange = os.environ.get("BENCH_EXCHANGE") == "0"
+        for j in range(min(k, D)):
             eng.msm_dev_enqueue(j % D, d_pts, d_sc, n)
         pending = None
         for j in range(k):
-            ta = time.perf_counter()
-            if j + D - 1 < k:
-                eng.msm_dev_enqueue((j + D - 1) % D, d_pts, d_sc, n)
-            tb = time.perf_counter()
+            t1 = time.perf_counter()
             part = eng.msm_finish(j % D)
-            tc = time.perf_counter()
+            t2 = time.perf_counter()
+            if j + D < k:
+                eng.msm_dev_enqueue(j % D, d_pts, d_sc, n)
+            t3 = time.perf_counter()
+            if no_exchange:                                  # (BENCH_EXCHANGE=0, experiments: a process group without the per-step exchange)
+                res, t4, t5 = part, t3, t3
+                host_t[0] += t3 - t2; host_t[1] += t2 - t1; host_t[4] += 1
+                continue
             if pending is not None:
                 res = sharded.combine_wait(pending)
-            td = time.perf_counter()
+            t4 = time.perf_counter()
             pending = sharded.combine_begin(part)
-            te = time.perf_counter()
-            host_t[0] += tb - ta; host_t[1] += tc - tb; host_t[2] += td - tc; host_t[3] += te - td; host_t[4] += 1
+            t5 = time.perf_counter()
+            host_t[0] += t3 - t2; host_t[1] += t2 - t1; host_t[2] += t4 - t3; host_t[3] += t5 - t4; host_t[4] += 1
         if pending is not None:
             res = sharded.combine_wait(pending)
         return res
@@ -224,10 +231,18 @@ def main():
             return
         t_h = time.perf_counter()
         while (time.perf_counter() - t_h) * 1e3 < args.preheat_ms:
+            if use_dist:                     # with a process group: the very loop that is timed, exchange included (the first dozens of
+                run_steps(8)                 # collectives of a group are slower -- work objects, events, staging -- and belong here, not into 20 timed steps)
+                continue
             for sl in range(args.depth):
                 eng.msm_dev_enqueue(sl, d_pts, d_sc, n)
             for sl in range(args.depth):
                 eng.msm_finish(sl)
+    # Round 6: the FIRST collective of an RCCL group costs tens of milliseconds (lazy set-up inside the first barrier); as the barrier that
+    # opens the timed region it left the GPU idle that long right after the warm-up, the clocks dropped, and a 20-step region ran on the
+    # ramp: 1.01-1.02 ms per step against 0.95 without a group -- nothing to do with the exchange (a 4 000-step run reads 0.943 either way;
+    # profiles/r06_process_group_cost.txt).  One barrier BEFORE the untimed steps takes the set-up; the contract's barrier is then quick.
+    barrier()
     preheat()
     result = run_steps(args.warmup)
     sharded.exchange_us()

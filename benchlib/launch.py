@@ -128,18 +128,21 @@ def strong_depth(pairs_per_rank):
 
 
 def pipelined_exchange_loop(enqueue, finish, combine_begin, combine_wait, steps, depth, exchange=True):
-    """`steps` MSMs through `depth` rotating slots: slot j % depth holds MSM j; MSM j + depth - 1 is queued before MSM j is finished, the
+    """`steps` MSMs through `depth` rotating slots: slot j % depth holds MSM j; `depth` MSMs are in flight whenever the host waits, the
     exchange of MSM j's partial is started behind it and collected one iteration later (a rank never waits for the fold before it has fed
     its GPU the next MSM).  enqueue(slot), finish(slot) -> 64 bytes, combine_begin(bytes) -> handle, combine_wait(handle) -> 64 bytes.
+    Round 6: the slot that finish() has just freed is refilled AT ONCE, before the exchange's host work (combine_wait + combine_begin are
+    ~0.08 ms of Python and RCCL launches per step: queued behind them, the next MSM started that much later and every step was that much
+    longer -- 1.02 against 0.95 ms per step with a process group of one rank, profiles/r06_exchange_host_order.txt).
     Returns the LAST step's global result (exchange) or local partial (no exchange: the per-rank floor).  bench.py's MSM_strong line;
     tests/test_distributed_cpu.py drives it over gloo with 2 and 8 ranks."""
     res, pend = None, None
-    for j in range(min(steps, depth - 1)):
+    for j in range(min(steps, depth)):
         enqueue(j % depth)
     for j in range(steps):
-        if j + depth - 1 < steps:
-            enqueue((j + depth - 1) % depth)
         part = finish(j % depth)
+        if j + depth < steps:
+            enqueue(j % depth)
         if exchange:
             if pend is not None:
                 res = combine_wait(pend)
