@@ -166,6 +166,22 @@ def extra_c5(eng, world, rank, dev, ready, log_batch=14, distinct=None, per_gpu=
                 part = sharded.combine(secp256k1.G.to_le64() if failed else part)
             return (not failed) and part == bytes(64)
 
+        def finish_pipelined(parts):
+            """finish() over a sequence of partials with ONE exchange in flight: the exchange of batch i (copy up, all_gather, fold, copy down
+            on the exchange stream) is collected while batch i + 1's partial is awaited -- every rank still issues its collectives in batch order."""
+            verdicts, pend = [], None
+            for part in parts:
+                failed = part is None
+                if not dist.is_initialized():
+                    verdicts.append((not failed) and part == bytes(64))
+                    continue
+                if pend is not None:
+                    verdicts.append((not pend[0]) and sharded.combine_wait(pend[1]) == bytes(64))
+                pend = (failed, sharded.combine_begin(secp256k1.G.to_le64() if failed else part))
+            if pend is not None:
+                verdicts.append((not pend[0]) and sharded.combine_wait(pend[1]) == bytes(64))
+            return verdicts
+
         def one_batch(corrupt=False):
             buf = wire_buf
             if corrupt:           # flip one bit inside one proof of this rank's shard: the batch must reject
@@ -246,7 +262,7 @@ def extra_c5(eng, world, rank, dev, ready, log_batch=14, distinct=None, per_gpu=
             torch.cuda.synchronize(dev)
             t0 = time.perf_counter()
             futs = [lanes[i % inflight].submit(local_partial, i % inflight) for i in range(pipe_batches)]
-            oks += [finish(f.result()) for f in futs]
+            oks += finish_pipelined(f.result() for f in futs)
             if dist.is_initialized():
                 dist.barrier()
             torch.cuda.synchronize(dev)
